@@ -1,0 +1,40 @@
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+REF_ROOT = Path(os.environ.get("CIRCOM_REF", "/root/reference"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with gpurun)")
+    config.addinivalue_line("markers", "slow: takes more than ~20 s on CPU")
+
+
+def ensure_ref(prime: str) -> Path:
+    """Make sure oracle/_ref/<prime>/ holds the compiled reference runtime; build it if the
+    reference tree is present, otherwise skip (the GPU box only has the prebuilt files)."""
+    out = ROOT / "oracle" / "_ref" / prime
+    need = [out / n for n in ("libfr_shim.so", "main.o", "calcwit.o", "fr.o")]
+    if not all(p.exists() for p in need):
+        if not REF_ROOT.exists():
+            pytest.skip("oracle/_ref not built and reference tree absent")
+        subprocess.run(["make", "-C", str(ROOT / "oracle"), "ref", f"PRIME={prime}", f"REF={REF_ROOT}"],
+                       check=True, capture_output=True)
+    return out
+
+
+@pytest.fixture(scope="session")
+def ref_dir_bn128():
+    return ensure_ref("bn128")
+
+
+@pytest.fixture(scope="session")
+def ref_dir_bls12381():
+    return ensure_ref("bls12381")
