@@ -1,0 +1,36 @@
+"""`circom <file> --r1cs --sym --hip` stand-in: trace a Program and emit every artefact the new back-end
+produces (role of circom/src/compilation_user.rs:31-139 + execution_user.rs:47-55 for the --hip target)."""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+
+from .frontend.dsl import Program
+from .frontend.flatten import flatten, FlatCircuit
+from .hip_elements.lower import lower, Tape
+from .hip_elements import writers
+
+
+@dataclass
+class Compiled:
+    name: str
+    dir: str
+    tape_path: str
+    dat_path: str
+    r1cs_path: str
+    sym_path: str
+    flat: FlatCircuit
+    tape: Tape
+
+
+def compile_program(prog: Program, outdir: str, name: str, sym: bool = True) -> Compiled:
+    os.makedirs(outdir, exist_ok=True)
+    fc = flatten(prog)
+    tape = lower(fc)
+    p = lambda ext: os.path.join(outdir, name + ext)
+    writers.write_tape(p(".cwt"), tape)
+    writers.write_dat(p(".dat"), fc)
+    writers.write_r1cs(p(".r1cs"), fc)
+    if sym:
+        writers.write_sym(p(".sym"), fc)
+    return Compiled(name, outdir, p(".cwt"), p(".dat"), p(".r1cs"), p(".sym"), fc, tape)

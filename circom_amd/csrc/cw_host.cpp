@@ -1,0 +1,997 @@
+// cw_host.cpp — host side of the C ABI (include/circom_amd.h): circuit loading, input ingest with the
+// reference's semantics, kernel sequencing, result egress.  Mirrors the reference's C++ runtime
+// (code_producers/src/c_elements/common/{main.cpp,calcwit.cpp}); each function cites what it replaces.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/circom_amd.h"
+#include "cw_kernels.h"
+
+typedef unsigned __int128 u128;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t e_ = (x);                                                                        \
+        if (e_ != hipSuccess) return fail(CW_EDEVICE, std::string(#x ": ") + hipGetErrorString(e_)); \
+    } while (0)
+
+#define NEED_DEVICE(b) \
+    if ((b)->device < 0) return fail(CW_EDEVICE, "host-only batch: no GPU attached (the hot path has no CPU fallback)")
+
+extern "C" const char *cw_last_error(void) { return g_err.c_str(); }
+extern "C" const char *cw_version(void) { return "circom_amd 0.1 (gfx950)"; }
+
+// ---------------------------------------------------------------------------------------------------------
+// 256-bit host integers (4 x u64, little endian).  Only what ingest/loader need: compare, add, sub,
+// doubling mod q, small-multiplier accumulate.  (The reference uses GMP here: generic/fr.cpp:2766-2811.)
+// ---------------------------------------------------------------------------------------------------------
+struct U256 {
+    uint64_t w[4];
+};
+static U256 u256_zero() { return U256{{0, 0, 0, 0}}; }
+static int u256_cmp(const U256 &a, const U256 &b) {
+    for (int i = 3; i >= 0; i--)
+        if (a.w[i] != b.w[i]) return a.w[i] < b.w[i] ? -1 : 1;
+    return 0;
+}
+static bool u256_is_zero(const U256 &a) { return (a.w[0] | a.w[1] | a.w[2] | a.w[3]) == 0; }
+static uint64_t u256_add(U256 &r, const U256 &a, const U256 &b) {
+    u128 c = 0;
+    for (int i = 0; i < 4; i++) {
+        c += (u128)a.w[i] + b.w[i];
+        r.w[i] = (uint64_t)c;
+        c >>= 64;
+    }
+    return (uint64_t)c;
+}
+static uint64_t u256_sub(U256 &r, const U256 &a, const U256 &b) {
+    uint64_t br = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 t = (u128)a.w[i] - b.w[i] - br;
+        r.w[i] = (uint64_t)t;
+        br = (uint64_t)(t >> 64) & 1;
+    }
+    return br;
+}
+static U256 addmod(const U256 &a, const U256 &b, const U256 &q) {
+    U256 r;
+    uint64_t c = u256_add(r, a, b);
+    if (c || u256_cmp(r, q) >= 0) u256_sub(r, r, q);
+    return r;
+}
+static U256 submod(const U256 &a, const U256 &b, const U256 &q) {
+    U256 r;
+    if (u256_sub(r, a, b)) u256_add(r, r, q);
+    return r;
+}
+// (a * m + d) mod q for small m (<= 16) and d < m, a < q
+static U256 mulsmall_add_mod(const U256 &a, uint32_t m, uint32_t d, const U256 &q) {
+    uint64_t t[5];
+    u128 c = d;
+    for (int i = 0; i < 4; i++) {
+        c += (u128)a.w[i] * m;
+        t[i] = (uint64_t)c;
+        c >>= 64;
+    }
+    t[4] = (uint64_t)c;
+    // reduce: subtract q while t >= q (at most m+1 times)
+    for (;;) {
+        bool ge = t[4] != 0;
+        if (!ge) {
+            U256 x{{t[0], t[1], t[2], t[3]}};
+            ge = u256_cmp(x, q) >= 0;
+        }
+        if (!ge) break;
+        uint64_t br = 0;
+        for (int i = 0; i < 4; i++) {
+            u128 s = (u128)t[i] - q.w[i] - br;
+            t[i] = (uint64_t)s;
+            br = (uint64_t)(s >> 64) & 1;
+        }
+        t[4] -= br;
+    }
+    return U256{{t[0], t[1], t[2], t[3]}};
+}
+// a * 2^k mod q by repeated doubling
+static U256 shlmod(U256 a, unsigned k, const U256 &q) {
+    for (unsigned i = 0; i < k; i++) a = addmod(a, a, q);
+    return a;
+}
+static unsigned u256_bits(const U256 &a) {
+    for (int i = 3; i >= 0; i--)
+        if (a.w[i]) return 64 * i + 64 - __builtin_clzll(a.w[i]);
+    return 0;
+}
+
+// Fr_str2element (generic/fr.cpp:2805-2811): int(s, base) floor-mod q; leading '-' allowed.
+static bool str_to_fe(const char *s, size_t n, unsigned base, const U256 &q, U256 *out) {
+    bool neg = false;
+    size_t i = 0;
+    if (n > 0 && (s[0] == '-' || s[0] == '+')) {
+        neg = s[0] == '-';
+        i = 1;
+    }
+    if (i >= n) return false;
+    U256 v = u256_zero();
+    for (; i < n; i++) {
+        char c = s[i];
+        unsigned d;
+        if (c >= '0' && c <= '9') d = c - '0';
+        else if (c >= 'a' && c <= 'f') d = c - 'a' + 10;
+        else if (c >= 'A' && c <= 'F') d = c - 'A' + 10;
+        else return false;
+        if (d >= base) return false;
+        v = mulsmall_add_mod(v, base, d, q);
+    }
+    if (neg && !u256_is_zero(v)) u256_sub(v, q, v);
+    *out = v;
+    return true;
+}
+
+static FpParams make_params(const U256 &q) {
+    FpParams P;
+    memset(&P, 0, sizeof(P));
+    memcpy(P.q, q.w, 32);
+    U256 half = q;   // (q-1)/2 == q>>1 for odd q
+    for (int i = 0; i < 4; i++) half.w[i] = (q.w[i] >> 1) | (i < 3 ? (q.w[i + 1] << 63) : 0);
+    memcpy(P.half, half.w, 32);
+    U256 one{{1, 0, 0, 0}};
+    U256 r1 = shlmod(one, 256, q);      // R mod q
+    U256 r2 = shlmod(r1, 256, q);       // R^2 mod q
+    memcpy(P.one_m, r1.w, 32);
+    memcpy(P.r2, r2.w, 32);
+    U256 two{{2, 0, 0, 0}}, qm2;
+    u256_sub(qm2, q, two);
+    memcpy(P.qm2, qm2.w, 32);
+    // np = -q^-1 mod 2^32 by Newton iteration
+    uint32_t q0 = (uint32_t)q.w[0], inv = 1;
+    for (int i = 0; i < 5; i++) inv *= 2 - q0 * inv;
+    P.np = (uint32_t)(0u - inv);
+    P.qbits = u256_bits(q);
+    unsigned topbits = P.qbits - 224;             // bits used in the top 32-bit limb
+    P.topmask = topbits >= 32 ? 0xFFFFFFFFu : ((1u << topbits) - 1);
+    return P;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// circuit
+// ---------------------------------------------------------------------------------------------------------
+struct HashEntry {
+    uint64_t hash, signalid, signalsize;   // HashSignalInfo, circom.hpp:17-21
+};
+
+struct cw_circuit {
+    U256 q;
+    FpParams P;
+    uint32_t n_signals = 0, n_tslots = 0, n_witness = 0, n_consts = 0, input_start = 0, n_inputs = 0;
+    uint64_t n_rows = 0, n_mmul = 0;
+    bool need_full = false;
+    std::vector<CwRow> rows;
+    std::vector<uint32_t> consts;          // n_consts * 8
+    std::vector<uint32_t> w2s;
+    std::vector<HashEntry> hashmap;
+    std::map<std::string, std::pair<uint32_t, uint32_t>> input_names;   // name -> (start, size)
+    // r1cs (CSR)
+    uint32_t n_constraints = 0;
+    std::vector<uint32_t> r_ptr, r_slot, r_coef, r_ctab;
+};
+
+static uint64_t fnv1a(const char *s, size_t n) {   // calcwit.cpp:17-24
+    uint64_t h = 0xCBF29CE484222325ULL;
+    for (size_t i = 0; i < n; i++) {
+        h ^= (uint64_t)(unsigned char)s[i];
+        h *= 0x100000001B3ULL;
+    }
+    return h;
+}
+
+static bool read_file(const char *path, std::vector<uint8_t> &buf) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    buf.resize((size_t)n);
+    size_t got = n ? fread(buf.data(), 1, (size_t)n, f) : 0;
+    fclose(f);
+    return got == (size_t)n;
+}
+
+static int load_tape(cw_circuit *c, const char *path) {
+    std::vector<uint8_t> b;
+    if (!read_file(path, b)) return fail(CW_EIO, std::string("tape file not found: ") + path);
+    if (b.size() < 16 + 32 + 48 || memcmp(b.data(), "CWTP", 4)) return fail(CW_EIO, "bad tape magic");
+    const uint32_t *h = (const uint32_t *)(b.data() + 4);
+    if (h[0] != 1) return fail(CW_EIO, "unsupported tape version");
+    if (h[1] != 4) return fail(CW_EIO, "only 4x64-bit primes are supported (bn128, bls12381, ...)");
+    size_t off = 16;
+    memcpy(c->q.w, b.data() + off, 32);
+    off += 32;
+    const uint32_t *m = (const uint32_t *)(b.data() + off);
+    off += 48;
+    c->n_signals = m[0];
+    c->n_tslots = m[1];
+    c->n_witness = m[2];
+    c->n_consts = m[3];
+    c->n_rows = (uint64_t)m[4] | ((uint64_t)m[5] << 32);
+    c->input_start = m[6];
+    c->n_inputs = m[7];
+    uint32_t n_names = m[8], hsize = m[9];
+    size_t need = off + c->n_rows * 16 + (size_t)c->n_consts * 32 + (size_t)c->n_witness * 4;
+    if (b.size() < need) return fail(CW_EIO, "tape file truncated");
+    c->rows.resize(c->n_rows);
+    memcpy(c->rows.data(), b.data() + off, c->n_rows * 16);
+    off += c->n_rows * 16;
+    c->consts.resize((size_t)c->n_consts * 8);
+    memcpy(c->consts.data(), b.data() + off, (size_t)c->n_consts * 32);
+    off += (size_t)c->n_consts * 32;
+    c->w2s.resize(c->n_witness);
+    memcpy(c->w2s.data(), b.data() + off, (size_t)c->n_witness * 4);
+    off += (size_t)c->n_witness * 4;
+    for (uint32_t i = 0; i < n_names; i++) {
+        if (off + 4 > b.size()) return fail(CW_EIO, "tape names truncated");
+        uint32_t len;
+        memcpy(&len, b.data() + off, 4);
+        off += 4;
+        if (off + len + 8 > b.size()) return fail(CW_EIO, "tape names truncated");
+        std::string name((const char *)b.data() + off, len);
+        off += len;
+        uint32_t ss[2];
+        memcpy(ss, b.data() + off, 8);
+        off += 8;
+        c->input_names[name] = {ss[0], ss[1]};
+    }
+    // hash map as generate_hash_map builds it (c_code_generator.rs:575-587); replaced by the .dat's if given
+    c->hashmap.assign(hsize, HashEntry{0, 0, 0});
+    // insertion order must be the reference's (main input list order = slot order)
+    std::vector<std::pair<uint32_t, std::string>> order;
+    for (auto &kv : c->input_names) order.push_back({kv.second.first, kv.first});
+    std::sort(order.begin(), order.end());
+    for (auto &o : order) {
+        uint64_t hsh = fnv1a(o.second.data(), o.second.size());
+        size_t p = hsh % hsize;
+        while (c->hashmap[p].signalid != 0) p = (p + 1) % hsize;
+        c->hashmap[p] = HashEntry{hsh, o.first, c->input_names[o.second].second};
+    }
+    for (auto &r : c->rows) {
+        uint32_t op = r.w0 & 0xFF;
+        if (op >= D_NOPS) return fail(CW_EIO, "tape contains an unknown opcode");
+        if (op == D_MMUL) c->n_mmul++;
+        if (op == D_INV || op == D_IDIV || op == D_MOD || op == D_POW) c->need_full = true;
+    }
+    c->P = make_params(c->q);
+    return CW_OK;
+}
+
+// <name>.dat, reference layout (reader main.cpp:22-124): hash map | witness2signal u64[] | constants ...
+static int load_dat(cw_circuit *c, const char *path) {
+    std::vector<uint8_t> b;
+    if (!read_file(path, b)) return fail(CW_EIO, std::string(".dat file not found: ") + path);
+    size_t hs = c->hashmap.size();
+    size_t need = hs * 24 + (size_t)c->n_witness * 8;
+    if (b.size() < need) return fail(CW_EIO, ".dat file too small for this tape");
+    for (size_t i = 0; i < hs; i++) memcpy(&c->hashmap[i], b.data() + i * 24, 24);
+    const uint8_t *w = b.data() + hs * 24;
+    for (uint32_t i = 0; i < c->n_witness; i++) {
+        uint64_t s;
+        memcpy(&s, w + (size_t)i * 8, 8);
+        if (s >= c->n_signals) return fail(CW_EIO, ".dat witness list refers to a signal out of range");
+        c->w2s[i] = (uint32_t)s;
+    }
+    return CW_OK;
+}
+
+// <name>.r1cs (constraint_writers/src/r1cs_writer.rs; sections may come in any order — the writer emits 2,1,3)
+static int load_r1cs(cw_circuit *c, const char *path) {
+    std::vector<uint8_t> b;
+    if (!read_file(path, b)) return fail(CW_EIO, std::string(".r1cs file not found: ") + path);
+    if (b.size() < 12 || memcmp(b.data(), "r1cs", 4)) return fail(CW_EIO, "bad r1cs magic");
+    uint32_t nsec;
+    memcpy(&nsec, b.data() + 8, 4);
+    size_t off = 12;
+    const uint8_t *sec[6] = {0};
+    uint64_t seclen[6] = {0};
+    for (uint32_t s = 0; s < nsec; s++) {
+        if (off + 12 > b.size()) return fail(CW_EIO, "r1cs truncated");
+        uint32_t typ;
+        uint64_t len;
+        memcpy(&typ, b.data() + off, 4);
+        memcpy(&len, b.data() + off + 4, 8);
+        off += 12;
+        if (off + len > b.size()) return fail(CW_EIO, "r1cs section truncated");
+        if (typ < 6) {
+            sec[typ] = b.data() + off;
+            seclen[typ] = len;
+        }
+        off += len;
+    }
+    if (!sec[1] || !sec[2]) return fail(CW_EIO, "r1cs misses header or constraints section");
+    uint32_t fs;
+    memcpy(&fs, sec[1], 4);
+    if (fs != 32) return fail(CW_EIO, "r1cs field size must be 32 bytes");
+    if (memcmp(sec[1] + 4, c->q.w, 32)) return fail(CW_EIO, "r1cs prime differs from the tape's");
+    uint32_t hdr[4];
+    memcpy(hdr, sec[1] + 36, 16);   // nWires, nPubOut, nPubIn, nPrvIn
+    uint32_t n_wires = hdr[0], n_cons;
+    memcpy(&n_cons, sec[1] + 36 + 16 + 8, 4);
+    if (n_wires != c->n_witness) return fail(CW_EIO, "r1cs wire count differs from the witness size");
+    c->n_constraints = n_cons;
+    c->r_ptr.assign(1, 0);
+    c->r_ptr.reserve((size_t)n_cons * 3 + 1);
+    // coefficient table: id 0 = +1, id 1 = -1, others = c*R mod q
+    c->r_ctab.assign(16, 0);
+    U256 one{{1, 0, 0, 0}}, minus1;
+    u256_sub(minus1, c->q, one);
+    std::map<std::array<uint64_t, 4>, uint32_t> cid;
+    const uint8_t *p = sec[2], *end = sec[2] + seclen[2];
+    for (uint32_t k = 0; k < n_cons; k++) {
+        for (int part = 0; part < 3; part++) {
+            if (p + 4 > end) return fail(CW_EIO, "r1cs constraints truncated");
+            uint32_t nnz;
+            memcpy(&nnz, p, 4);
+            p += 4;
+            if (p + (size_t)nnz * 36 > end) return fail(CW_EIO, "r1cs constraints truncated");
+            for (uint32_t t = 0; t < nnz; t++) {
+                uint32_t wire;
+                U256 co;
+                memcpy(&wire, p, 4);
+                memcpy(co.w, p + 4, 32);
+                p += 36;
+                if (wire >= n_wires) return fail(CW_EIO, "r1cs wire id out of range");
+                uint32_t id;
+                if (u256_cmp(co, one) == 0) id = 0;
+                else if (u256_cmp(co, minus1) == 0) id = 1;
+                else {
+                    std::array<uint64_t, 4> key{co.w[0], co.w[1], co.w[2], co.w[3]};
+                    auto it = cid.find(key);
+                    if (it == cid.end()) {
+                        id = (uint32_t)(c->r_ctab.size() / 8);
+                        U256 cm = shlmod(co, 256, c->q);
+                        uint32_t limbs[8];
+                        memcpy(limbs, cm.w, 32);
+                        c->r_ctab.insert(c->r_ctab.end(), limbs, limbs + 8);
+                        cid[key] = id;
+                    } else id = it->second;
+                }
+                c->r_slot.push_back(c->w2s[wire]);     // wire id = witness position -> value slot
+                c->r_coef.push_back(id);
+            }
+            c->r_ptr.push_back((uint32_t)c->r_slot.size());
+        }
+    }
+    return CW_OK;
+}
+
+extern "C" int cw_load(const char *tape_path, const char *dat_path, const char *r1cs_path, cw_circuit **out) {
+    if (!tape_path || !out) return fail(CW_EINVAL, "cw_load: null argument");
+    cw_circuit *c = new cw_circuit();
+    int rc = load_tape(c, tape_path);
+    if (rc == CW_OK && dat_path) rc = load_dat(c, dat_path);
+    if (rc == CW_OK && r1cs_path) rc = load_r1cs(c, r1cs_path);
+    if (rc != CW_OK) {
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return CW_OK;
+}
+extern "C" void cw_free(cw_circuit *c) { delete c; }
+extern "C" uint32_t cw_n_signals(const cw_circuit *c) { return c->n_signals; }
+extern "C" uint32_t cw_n_witness(const cw_circuit *c) { return c->n_witness; }
+extern "C" uint32_t cw_n_inputs(const cw_circuit *c) { return c->n_inputs; }
+extern "C" uint32_t cw_input_start(const cw_circuit *c) { return c->input_start; }
+extern "C" uint32_t cw_n_constraints(const cw_circuit *c) { return c->n_constraints; }
+extern "C" uint64_t cw_n_rows(const cw_circuit *c) { return c->n_rows; }
+extern "C" uint64_t cw_n_mmul(const cw_circuit *c) { return c->n_mmul; }
+extern "C" void cw_prime(const cw_circuit *c, uint8_t le32[32]) { memcpy(le32, c->q.w, 32); }
+
+// getInputSignalHashPosition (calcwit.cpp:51-69): open addressing, empty slot = signalid 0
+static int64_t hash_pos(const cw_circuit *c, uint64_t h) {
+    size_t n = c->hashmap.size();
+    size_t pos = h % n;
+    if (c->hashmap[pos].hash != h) {
+        size_t ini = pos;
+        pos = (pos + 1) % n;
+        while (pos != ini) {
+            if (c->hashmap[pos].hash == h) return (int64_t)pos;
+            if (c->hashmap[pos].signalid == 0) return -1;
+            pos = (pos + 1) % n;
+        }
+        return -1;
+    }
+    return (int64_t)pos;
+}
+
+extern "C" int64_t cw_input_size(const cw_circuit *c, const char *name, uint32_t *start_slot) {
+    int64_t p = hash_pos(c, fnv1a(name, strlen(name)));
+    if (p < 0 || c->hashmap[p].signalid == 0) return -1;
+    if (start_slot) *start_slot = (uint32_t)c->hashmap[p].signalid;
+    return (int64_t)c->hashmap[p].signalsize;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// batch
+// ---------------------------------------------------------------------------------------------------------
+struct cw_batch {
+    cw_circuit *c = nullptr;
+    int device = 0;
+    uint32_t batch = 0, Bp = 0;
+    hipStream_t stream = nullptr;
+    void *d_V = nullptr;
+    size_t v_bytes = 0;
+    CwRow *d_rows = nullptr;
+    uint32_t *d_consts = nullptr, *d_w2s = nullptr, *d_status = nullptr, *d_first_bad = nullptr;
+    uint32_t *d_rptr = nullptr, *d_rslot = nullptr, *d_rcoef = nullptr, *d_rctab = nullptr;
+    void *d_in = nullptr;          // AoS staging [batch][n_in][32]
+    void *d_gather = nullptr;      // [n_witness][32]
+    const void *ext_in = nullptr;  // caller-owned device inputs (cw_set_inputs_device)
+    std::vector<uint8_t> h_in;     // host staging for per-signal assignment
+    std::vector<uint8_t> assigned; // [batch][n_in] flags (inputSignalAssigned, calcwit.cpp:28-32)
+    std::vector<uint32_t> remaining;
+    bool all_set = false, host_dirty = false, ran = false;
+};
+
+template <typename T>
+static hipError_t upload(T **dst, const std::vector<T> &src, hipStream_t s) {
+    size_t n = std::max<size_t>(src.size(), 1) * sizeof(T);
+    hipError_t e = hipMalloc((void **)dst, n);
+    if (e != hipSuccess) return e;
+    if (!src.empty()) e = hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, s);
+    return e;
+}
+
+extern "C" void cw_batch_free(cw_batch *b) {
+    if (!b) return;
+    if (b->device < 0) {
+        delete b;
+        return;
+    }
+    hipSetDevice(b->device);
+    hipStreamSynchronize(b->stream);
+    void *ptrs[] = {b->d_V, b->d_rows, b->d_consts, b->d_w2s, b->d_status, b->d_first_bad,
+                    b->d_rptr, b->d_rslot, b->d_rcoef, b->d_rctab, b->d_in, b->d_gather};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    delete b;
+}
+
+extern "C" int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *stream, cw_batch **out) {
+    if (!c || !out || batch == 0) return fail(CW_EINVAL, "cw_batch_create: bad argument");
+    if (device < 0) {
+        // host-only batch: input staging and its error semantics can be exercised without a GPU;
+        // anything that computes fails loudly.
+        cw_batch *hb = new cw_batch();
+        hb->c = c;
+        hb->device = -1;
+        hb->batch = batch;
+        hb->Bp = (batch + 255) / 256 * 256;
+        hb->remaining.assign(batch, c->n_inputs);
+        *out = hb;
+        return CW_OK;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(CW_EDEVICE, "no HIP device available: the witness calculator requires a gfx950 GPU (no CPU fallback)");
+    HIPCHK(hipSetDevice(device));
+    cw_batch *b = new cw_batch();
+    b->c = c;
+    b->device = device;
+    b->batch = batch;
+    b->Bp = (batch + 255) / 256 * 256;
+    b->stream = (hipStream_t)stream;
+    size_t slots = (size_t)c->n_signals + c->n_tslots;
+    b->v_bytes = slots * 2 * b->Bp * 16;
+    hipError_t e = hipMalloc(&b->d_V, b->v_bytes);
+    if (e != hipSuccess) {
+        delete b;
+        return fail(CW_EDEVICE, "hipMalloc of the value table failed (" + std::to_string(slots) + " slots): " +
+                                    hipGetErrorString(e));
+    }
+#define TRY(x)                                                              \
+    do {                                                                    \
+        hipError_t e2 = (x);                                                \
+        if (e2 != hipSuccess) {                                             \
+            cw_batch_free(b);                                               \
+            return fail(CW_EDEVICE, std::string(#x ": ") + hipGetErrorString(e2)); \
+        }                                                                   \
+    } while (0)
+    TRY(upload(&b->d_rows, c->rows, b->stream));
+    TRY(upload(&b->d_consts, c->consts, b->stream));
+    TRY(upload(&b->d_w2s, c->w2s, b->stream));
+    TRY(hipMalloc((void **)&b->d_status, (size_t)b->Bp * 4));
+    TRY(hipMalloc((void **)&b->d_first_bad, (size_t)b->Bp * 4));
+    if (c->n_constraints) {
+        TRY(upload(&b->d_rptr, c->r_ptr, b->stream));
+        TRY(upload(&b->d_rslot, c->r_slot, b->stream));
+        TRY(upload(&b->d_rcoef, c->r_coef, b->stream));
+        TRY(upload(&b->d_rctab, c->r_ctab, b->stream));
+    }
+    TRY(hipMalloc(&b->d_in, std::max<size_t>((size_t)batch * c->n_inputs * 32, 32)));
+    TRY(hipMalloc(&b->d_gather, std::max<size_t>((size_t)c->n_witness * 32, 32)));
+    TRY(cwk_init(b->stream, b->d_V, b->Bp, b->d_status, b->d_first_bad));
+#undef TRY
+    b->remaining.assign(batch, c->n_inputs);
+    *out = b;
+    return CW_OK;
+}
+extern "C" uint32_t cw_batch_size(const cw_batch *b) { return b->batch; }
+
+static int ensure_host_staging(cw_batch *b) {
+    size_t n = (size_t)b->batch * b->c->n_inputs;
+    if (b->h_in.size() != n * 32) b->h_in.assign(n * 32, 0);
+    if (b->assigned.size() != n) b->assigned.assign(n, 0);
+    return CW_OK;
+}
+
+// setInputSignal (calcwit.cpp:77-97) with the same four error conditions
+static int set_input_hashed(cw_batch *b, uint32_t inst, uint64_t h, uint32_t idx, const uint8_t val[32],
+                            const char *name_for_msg) {
+    cw_circuit *c = b->c;
+    if (inst >= b->batch) return fail(CW_EINVAL, "instance out of range");
+    ensure_host_staging(b);
+    if (b->remaining[inst] == 0) return fail(CW_EINPUT, "No more signals to be assigned");
+    int64_t pos = hash_pos(c, h);
+    if (pos < 0 || c->hashmap[pos].signalid == 0)
+        return fail(CW_EINPUT, std::string("Signal not found: ") + name_for_msg);
+    if (idx >= c->hashmap[pos].signalsize) return fail(CW_EINPUT, "Input signal array access exceeds the size");
+    uint32_t si = (uint32_t)c->hashmap[pos].signalid + idx;
+    uint32_t k = si - c->input_start;
+    size_t cell = (size_t)inst * c->n_inputs + k;
+    if (b->assigned[cell]) return fail(CW_EINPUT, "Signal assigned twice: " + std::to_string(si));
+    memcpy(&b->h_in[cell * 32], val, 32);
+    b->assigned[cell] = 1;
+    b->remaining[inst]--;
+    b->host_dirty = true;
+    b->ext_in = nullptr;
+    return CW_OK;
+}
+
+extern "C" int cw_set_input_signal(cw_batch *b, uint32_t instance, const char *name, uint32_t idx,
+                                   const uint8_t val[32]) {
+    if (!b || !name || !val) return fail(CW_EINVAL, "null argument");
+    U256 v;
+    memcpy(v.w, val, 32);
+    if (u256_cmp(v, b->c->q) >= 0) return fail(CW_EINVAL, "input value is not reduced modulo the prime");
+    return set_input_hashed(b, instance, fnv1a(name, strlen(name)), idx, val, name);
+}
+
+extern "C" int cw_get_staged_input(cw_batch *b, uint32_t instance, uint32_t k, uint8_t out[32]) {
+    if (!b || !out || instance >= b->batch || k >= b->c->n_inputs) return fail(CW_EINVAL, "bad argument");
+    size_t cell = (size_t)instance * b->c->n_inputs + k;
+    if (b->assigned.size() <= cell || !b->assigned[cell]) return fail(CW_ESTATE, "input not assigned");
+    memcpy(out, &b->h_in[cell * 32], 32);
+    return CW_OK;
+}
+
+extern "C" int64_t cw_remaining_inputs(const cw_batch *b, uint32_t instance) {
+    if (!b || instance >= b->batch) return -1;
+    if (b->all_set) return 0;
+    return b->remaining[instance];
+}
+
+extern "C" int cw_set_inputs(cw_batch *b, const uint8_t *le32) {
+    if (!b || !le32) return fail(CW_EINVAL, "null argument");
+    NEED_DEVICE(b);
+    size_t n = (size_t)b->batch * b->c->n_inputs * 32;
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipMemcpyAsync(b->d_in, le32, n, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));   // caller may free le32 on return
+    b->ext_in = nullptr;
+    b->host_dirty = false;
+    b->all_set = true;
+    std::fill(b->remaining.begin(), b->remaining.end(), 0);
+    return CW_OK;
+}
+
+extern "C" int cw_set_inputs_device(cw_batch *b, const void *d_le32) {
+    if (!b || !d_le32) return fail(CW_EINVAL, "null argument");
+    b->ext_in = d_le32;
+    b->host_dirty = false;
+    b->all_set = true;
+    std::fill(b->remaining.begin(), b->remaining.end(), 0);
+    return CW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// JSON ingest — loadJson / qualify_input / json2FrElements (main.cpp:144-286)
+// ---------------------------------------------------------------------------------------------------------
+struct JVal {
+    enum T { NUL, BOOL, NUM, STR, ARR, OBJ } t = NUL;
+    std::string s;          // STR: text, NUM: source token
+    bool integral = false;  // NUM: token has no fraction/exponent
+    std::vector<JVal> a;
+    std::vector<std::pair<std::string, JVal>> o;
+};
+struct JParser {
+    const char *p, *e;
+    std::string err;
+    void ws() { while (p < e && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++; }
+    bool parse(JVal &v) {
+        ws();
+        if (p >= e) return bad("unexpected end");
+        char c = *p;
+        if (c == '{') {
+            v.t = JVal::OBJ;
+            p++;
+            ws();
+            if (p < e && *p == '}') { p++; return true; }
+            for (;;) {
+                ws();
+                JVal k;
+                if (p >= e || *p != '"' || !str(k.s)) return bad("expected key");
+                ws();
+                if (p >= e || *p != ':') return bad("expected ':'");
+                p++;
+                JVal x;
+                if (!parse(x)) return false;
+                v.o.push_back({k.s, std::move(x)});
+                ws();
+                if (p < e && *p == ',') { p++; continue; }
+                if (p < e && *p == '}') { p++; return true; }
+                return bad("expected ',' or '}'");
+            }
+        }
+        if (c == '[') {
+            v.t = JVal::ARR;
+            p++;
+            ws();
+            if (p < e && *p == ']') { p++; return true; }
+            for (;;) {
+                JVal x;
+                if (!parse(x)) return false;
+                v.a.push_back(std::move(x));
+                ws();
+                if (p < e && *p == ',') { p++; continue; }
+                if (p < e && *p == ']') { p++; return true; }
+                return bad("expected ',' or ']'");
+            }
+        }
+        if (c == '"') { v.t = JVal::STR; return str(v.s); }
+        if (c == 't' && e - p >= 4 && !memcmp(p, "true", 4)) { v.t = JVal::BOOL; p += 4; return true; }
+        if (c == 'f' && e - p >= 5 && !memcmp(p, "false", 5)) { v.t = JVal::BOOL; p += 5; return true; }
+        if (c == 'n' && e - p >= 4 && !memcmp(p, "null", 4)) { v.t = JVal::NUL; p += 4; return true; }
+        if (c == '-' || (c >= '0' && c <= '9')) {
+            const char *s0 = p;
+            v.integral = true;
+            if (*p == '-') p++;
+            while (p < e && ((*p >= '0' && *p <= '9') || *p == '.' || *p == 'e' || *p == 'E' || *p == '+' || *p == '-')) {
+                if (*p == '.' || *p == 'e' || *p == 'E') v.integral = false;
+                p++;
+            }
+            v.t = JVal::NUM;
+            v.s.assign(s0, p - s0);
+            return true;
+        }
+        return bad("unexpected character");
+    }
+    bool str(std::string &out) {
+        p++;   // opening quote
+        while (p < e && *p != '"') {
+            if (*p == '\\' && p + 1 < e) {
+                p++;
+                switch (*p) {
+                case 'n': out += '\n'; break;
+                case 't': out += '\t'; break;
+                case 'r': out += '\r'; break;
+                case 'b': out += '\b'; break;
+                case 'f': out += '\f'; break;
+                case 'u': {
+                    if (e - p < 5) return bad("bad \\u escape");
+                    unsigned cp = (unsigned)strtoul(std::string(p + 1, 4).c_str(), nullptr, 16);
+                    if (cp < 0x80) out += (char)cp;
+                    else if (cp < 0x800) { out += (char)(0xC0 | (cp >> 6)); out += (char)(0x80 | (cp & 0x3F)); }
+                    else { out += (char)(0xE0 | (cp >> 12)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }
+                    p += 4;
+                    break;
+                }
+                default: out += *p;
+                }
+                p++;
+            } else out += *p++;
+        }
+        if (p >= e) return bad("unterminated string");
+        p++;
+        return true;
+    }
+    bool bad(const char *m) { err = m; return false; }
+};
+
+// check_type (main.cpp:190-208): leaf kind of an array (numbers and strings count as the same kind)
+static int leaf_kind(const JVal &v) {
+    if (v.t != JVal::ARR) return (v.t == JVal::NUM || v.t == JVal::STR) ? 100 : (int)v.t;
+    if (v.a.empty()) return (int)JVal::NUL;
+    return leaf_kind(v.a[0]);
+}
+static void qualify(const std::string &prefix, const JVal &in, std::vector<std::pair<std::string, const JVal *>> &out);
+static void qualify_list(const std::string &prefix, const JVal &in, std::vector<std::pair<std::string, const JVal *>> &out) {
+    if (in.t == JVal::ARR) {
+        for (size_t i = 0; i < in.a.size(); i++) qualify_list(prefix + "[" + std::to_string(i) + "]", in.a[i], out);
+    } else qualify(prefix, in, out);
+}
+// qualify_input (main.cpp:221-241): nested objects / arrays of objects -> dotted, indexed keys
+static void qualify(const std::string &prefix, const JVal &in, std::vector<std::pair<std::string, const JVal *>> &out) {
+    if (in.t == JVal::ARR) {
+        if (!in.a.empty() && leaf_kind(in) == (int)JVal::OBJ) qualify_list(prefix, in, out);
+        else out.push_back({prefix, &in});
+    } else if (in.t == JVal::OBJ) {
+        for (auto &kv : in.o) qualify(prefix.empty() ? kv.first : prefix + "." + kv.first, kv.second, out);
+    } else out.push_back({prefix, &in});
+}
+// json2FrElements (main.cpp:144-188)
+static int json_to_fes(const JVal &v, const U256 &q, std::vector<U256> &out) {
+    if (v.t == JVal::ARR) {
+        for (auto &x : v.a) {
+            int rc = json_to_fes(x, q, out);
+            if (rc) return rc;
+        }
+        return CW_OK;
+    }
+    std::string s;
+    unsigned base = 10;
+    if (v.t == JVal::STR) {
+        const std::string &sa = v.s;
+        std::string pre = sa.substr(0, 2);
+        if (pre == "0b" || pre == "0B") { s = sa.substr(2); base = 2; }
+        else if (pre == "0o" || pre == "0O") { s = sa.substr(2); base = 8; }
+        else if (pre == "0x" || pre == "0X") { s = sa.substr(2); base = 16; }
+        else s = sa;
+        // check_valid_number (main.cpp:126-142): digits only, no sign
+        bool ok = true;
+        for (char ch : s) {
+            if (base == 16) ok &= (ch >= '0' && ch <= '9') || (ch >= 'a' && ch <= 'f') || (ch >= 'A' && ch <= 'F');
+            else ok &= (ch >= '0' && ch < (char)('0' + base));
+        }
+        if (!ok) return fail(CW_EINPUT, "Invalid number in JSON input: " + sa);
+        if (s.empty()) { out.push_back(u256_zero()); return CW_OK; }   // mpz_init_set_str("") leaves 0
+    } else if (v.t == JVal::NUM) {
+        // the reference goes through double and prints it with fixed precision 0 (main.cpp:170-175)
+        double vd = strtod(v.s.c_str(), nullptr);
+        char buf[400];
+        snprintf(buf, sizeof buf, "%.0f", vd);
+        s = buf;
+    } else return fail(CW_EINPUT, "Invalid JSON type");
+    U256 x;
+    if (!str_to_fe(s.data(), s.size(), base, q, &x)) return fail(CW_EINPUT, "Invalid number in JSON input: " + s);
+    out.push_back(x);
+    return CW_OK;
+}
+
+extern "C" int cw_set_inputs_json(cw_batch *b, uint32_t instance, const char *json_text) {
+    if (!b || !json_text) return fail(CW_EINVAL, "null argument");
+    JParser jp{json_text, json_text + strlen(json_text), ""};
+    JVal root;
+    if (!jp.parse(root)) return fail(CW_EINPUT, "JSON parse error: " + jp.err);
+    std::vector<std::pair<std::string, const JVal *>> items;
+    qualify("", root, items);
+    // nlohmann's object is an ordered map: keys are visited in sorted order (main.cpp:261)
+    std::stable_sort(items.begin(), items.end(), [](auto &x, auto &y) { return x.first < y.first; });
+    cw_circuit *c = b->c;
+    for (auto &it : items) {
+        std::vector<U256> vals;
+        int rc = json_to_fes(*it.second, c->q, vals);
+        if (rc) return rc;
+        uint64_t h = fnv1a(it.first.data(), it.first.size());
+        int64_t pos = hash_pos(c, h);
+        if (pos < 0 || c->hashmap[pos].signalid == 0) return fail(CW_EINPUT, "Signal not found: " + it.first);
+        uint64_t sz = c->hashmap[pos].signalsize;
+        if (vals.size() < sz) return fail(CW_EINPUT, "Error loading signal " + it.first + ": Not enough values");
+        if (vals.size() > sz) return fail(CW_EINPUT, "Error loading signal " + it.first + ": Too many values");
+        for (size_t i = 0; i < vals.size(); i++) {
+            rc = set_input_hashed(b, instance, h, (uint32_t)i, (const uint8_t *)vals[i].w, it.first.c_str());
+            if (rc) return fail(rc, "Error setting signal: " + it.first + "\n" + g_err);
+        }
+    }
+    return CW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// run / check / egress
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int cw_run(cw_batch *b) {
+    if (!b) return fail(CW_EINVAL, "null batch");
+    NEED_DEVICE(b);
+    cw_circuit *c = b->c;
+    if (!b->all_set) {
+        uint64_t missing = 0;
+        for (uint32_t r : b->remaining) missing += r;
+        if (missing) {
+            // main.cpp:352-355
+            return fail(CW_ESTATE, "Not all inputs have been set. " + std::to_string(missing) + " values missing over the batch");
+        }
+    }
+    HIPCHK(hipSetDevice(b->device));
+    if (b->host_dirty) {
+        HIPCHK(hipMemcpyAsync(b->d_in, b->h_in.data(), b->h_in.size(), hipMemcpyHostToDevice, b->stream));
+        b->host_dirty = false;
+    }
+    const void *in = b->ext_in ? b->ext_in : b->d_in;
+    HIPCHK(cwk_init(b->stream, b->d_V, b->Bp, b->d_status, b->d_first_bad));
+    HIPCHK(cwk_ingest(b->stream, in, b->d_V, c->input_start, c->n_inputs, b->batch, b->Bp));
+    HIPCHK(cwk_eval(b->stream, c->need_full, b->d_rows, c->n_rows, b->d_V, b->d_consts, c->n_signals, b->Bp, b->batch,
+                    b->d_status, c->P));
+    b->ran = true;
+    return CW_OK;
+}
+
+extern "C" int cw_check_r1cs(cw_batch *b) {
+    if (!b) return fail(CW_EINVAL, "null batch");
+    cw_circuit *c = b->c;
+    NEED_DEVICE(b);
+    if (!b->ran) return fail(CW_ESTATE, "cw_check_r1cs before cw_run");
+    if (c->n_constraints == 0) return fail(CW_ESTATE, "no .r1cs was loaded for this circuit");
+    HIPCHK(hipSetDevice(b->device));
+    uint32_t rows_per_block = 64;
+    HIPCHK(cwk_r1cs(b->stream, b->d_rptr, b->d_rslot, b->d_rcoef, b->d_rctab, c->n_constraints, rows_per_block, b->d_V,
+                    b->Bp, b->batch, b->d_status, b->d_first_bad, c->P));
+    return CW_OK;
+}
+
+extern "C" int cw_sync(cw_batch *b) {
+    if (!b) return fail(CW_EINVAL, "null batch");
+    NEED_DEVICE(b);
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return CW_OK;
+}
+
+extern "C" int cw_get_status(cw_batch *b, uint32_t *status) {
+    if (!b || !status) return fail(CW_EINVAL, "null argument");
+    NEED_DEVICE(b);
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipMemcpyAsync(status, b->d_status, (size_t)b->batch * 4, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return CW_OK;
+}
+extern "C" int cw_get_r1cs_first_bad(cw_batch *b, uint32_t *row) {
+    if (!b || !row) return fail(CW_EINVAL, "null argument");
+    NEED_DEVICE(b);
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipMemcpyAsync(row, b->d_first_bad, (size_t)b->batch * 4, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return CW_OK;
+}
+
+extern "C" int cw_get_witness(cw_batch *b, uint32_t instance, uint8_t *out) {
+    if (!b || !out) return fail(CW_EINVAL, "null argument");
+    if (instance >= b->batch) return fail(CW_EINVAL, "instance out of range");
+    NEED_DEVICE(b);
+    if (!b->ran) return fail(CW_ESTATE, "cw_get_witness before cw_run");
+    cw_circuit *c = b->c;
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(cwk_gather(b->stream, b->d_V, b->d_w2s, c->n_witness, b->Bp, instance, b->d_gather));
+    HIPCHK(hipMemcpyAsync(out, b->d_gather, (size_t)c->n_witness * 32, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return CW_OK;
+}
+
+extern "C" int cw_get_signal(cw_batch *b, uint32_t instance, uint32_t slot, uint8_t out[32]) {
+    if (!b || !out) return fail(CW_EINVAL, "null argument");
+    if (instance >= b->batch || slot >= b->c->n_signals) return fail(CW_EINVAL, "instance or slot out of range");
+    NEED_DEVICE(b);
+    HIPCHK(hipSetDevice(b->device));
+    const uint8_t *V = (const uint8_t *)b->d_V;
+    size_t base = ((size_t)slot * 2 * b->Bp + instance) * 16;
+    HIPCHK(hipMemcpyAsync(out, V + base, 16, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(out + 16, V + base + (size_t)b->Bp * 16, 16, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return CW_OK;
+}
+
+// writeBinWitness (main.cpp:288-334)
+extern "C" int cw_write_wtns(cw_batch *b, uint32_t instance, const char *path) {
+    if (!b || !path) return fail(CW_EINVAL, "null argument");
+    cw_circuit *c = b->c;
+    std::vector<uint8_t> w((size_t)c->n_witness * 32);
+    int rc = cw_get_witness(b, instance, w.data());
+    if (rc) return rc;
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(CW_EIO, std::string("cannot open for writing: ") + path);
+    uint32_t version = 2, nsec = 2, id1 = 1, n8 = 32, id2 = 2, nw = c->n_witness;
+    uint64_t len1 = 8 + n8, len2 = (uint64_t)n8 * nw;
+    fwrite("wtns", 4, 1, f);
+    fwrite(&version, 4, 1, f);
+    fwrite(&nsec, 4, 1, f);
+    fwrite(&id1, 4, 1, f);
+    fwrite(&len1, 8, 1, f);
+    fwrite(&n8, 4, 1, f);
+    fwrite(c->q.w, 32, 1, f);
+    fwrite(&nw, 4, 1, f);
+    fwrite(&id2, 4, 1, f);
+    fwrite(&len2, 8, 1, f);
+    fwrite(w.data(), 1, w.size(), f);
+    fclose(f);
+    return CW_OK;
+}
+
+extern "C" void *cw_device_values(cw_batch *b, uint64_t *n_bytes, uint32_t *padded_batch) {
+    if (!b) return nullptr;
+    if (n_bytes) *n_bytes = b->v_bytes;
+    if (padded_batch) *padded_batch = b->Bp;
+    return b->d_V;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// field micro-benchmark and unit-test hook
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int cw_fp_mul_bench(const uint8_t prime_le32[32], int device, uint32_t n, uint32_t iters, const uint8_t *a,
+                               const uint8_t *b, uint8_t *out, float *ms) {
+    if (!prime_le32 || !a || !b || !out || n == 0) return fail(CW_EINVAL, "bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(CW_EDEVICE, "no HIP device available");
+    HIPCHK(hipSetDevice(device));
+    U256 q;
+    memcpy(q.w, prime_le32, 32);
+    FpParams P = make_params(q);
+    void *da, *db, *dout;
+    size_t bytes = (size_t)n * 32;
+    HIPCHK(hipMalloc(&da, bytes));
+    HIPCHK(hipMalloc(&db, bytes));
+    HIPCHK(hipMalloc(&dout, bytes));
+    HIPCHK(hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(db, b, bytes, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(cwk_mulbench(nullptr, da, db, dout, n, 1, P));   // warm-up
+    HIPCHK(hipEventRecord(e0, nullptr));
+    HIPCHK(cwk_mulbench(nullptr, da, db, dout, n, iters, P));
+    HIPCHK(hipEventRecord(e1, nullptr));
+    HIPCHK(hipEventSynchronize(e1));
+    float t = 0;
+    HIPCHK(hipEventElapsedTime(&t, e0, e1));
+    if (ms) *ms = t;
+    HIPCHK(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(da);
+    hipFree(db);
+    hipFree(dout);
+    return CW_OK;
+}
+
+extern "C" int cw_fp_op(const uint8_t prime_le32[32], int device, uint32_t dop, uint32_t n, const uint8_t *a,
+                        const uint8_t *b, const uint8_t *c, uint8_t *out, uint32_t *status) {
+    if (!prime_le32 || !a || !b || !c || !out || !status || n == 0) return fail(CW_EINVAL, "bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(CW_EDEVICE, "no HIP device available");
+    HIPCHK(hipSetDevice(device));
+    U256 q;
+    memcpy(q.w, prime_le32, 32);
+    FpParams P = make_params(q);
+    void *da, *db, *dc, *dout;
+    uint32_t *dst;
+    size_t bytes = (size_t)n * 32;
+    HIPCHK(hipMalloc(&da, bytes));
+    HIPCHK(hipMalloc(&db, bytes));
+    HIPCHK(hipMalloc(&dc, bytes));
+    HIPCHK(hipMalloc(&dout, bytes));
+    HIPCHK(hipMalloc((void **)&dst, (size_t)n * 4));
+    HIPCHK(hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(db, b, bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dc, c, bytes, hipMemcpyHostToDevice));
+    HIPCHK(cwk_fpop(nullptr, dop, da, db, dc, dout, dst, n, P));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(status, dst, (size_t)n * 4, hipMemcpyDeviceToHost));
+    hipFree(da);
+    hipFree(db);
+    hipFree(dc);
+    hipFree(dout);
+    hipFree(dst);
+    return CW_OK;
+}

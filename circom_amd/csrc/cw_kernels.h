@@ -1,0 +1,20 @@
+// cw_kernels.h — launch wrappers implemented in cw_kernels.hip
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include "cw_tape.h"
+
+hipError_t cwk_init(hipStream_t s, void *V, uint32_t Bp, uint32_t *status, uint32_t *first_bad);
+hipError_t cwk_ingest(hipStream_t s, const void *in, void *V, uint32_t input_start, uint32_t n_in, uint32_t batch,
+                      uint32_t Bp);
+hipError_t cwk_eval(hipStream_t s, bool full, const CwRow *rows, uint64_t n_rows, void *V, const uint32_t *consts,
+                    uint32_t tmp_base, uint32_t Bp, uint32_t batch, uint32_t *status, const FpParams &P);
+hipError_t cwk_r1cs(hipStream_t s, const uint32_t *ptr, const uint32_t *tslot, const uint32_t *tcoef, const uint32_t *ctab,
+                    uint32_t n_cons, uint32_t rows_per_block, const void *V, uint32_t Bp, uint32_t batch, uint32_t *status,
+                    uint32_t *first_bad, const FpParams &P);
+hipError_t cwk_gather(hipStream_t s, const void *V, const uint32_t *w2s, uint32_t n_wit, uint32_t Bp, uint32_t instance,
+                      void *out);
+hipError_t cwk_mulbench(hipStream_t s, const void *a, const void *b, void *out, uint32_t n, uint32_t iters,
+                        const FpParams &P);
+hipError_t cwk_fpop(hipStream_t s, uint32_t op, const void *a, const void *b, const void *c, void *out, uint32_t *status,
+                    uint32_t n, const FpParams &P);

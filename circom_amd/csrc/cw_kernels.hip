@@ -1,0 +1,330 @@
+// cw_kernels.hip — HIP kernels of the batched witness calculator (gfx950 / CDNA4).
+//
+// Data layout in HBM: the value table V holds every signal (and spill temps) of every
+// instance as structure-of-arrays:  element (slot s, instance i) = two 16-byte halves
+//     lo: V[(2*s + 0) * Bp + i]      hi: V[(2*s + 1) * Bp + i]            (uint4 units)
+// so a wave's 64 lanes read/write 1 KiB contiguous per half (global_load/store_dwordx4, fully
+// coalesced).  One witness instance per lane; the schedule (tape) is wave-uniform and is fetched
+// with scalar loads; constants are wave-uniform too (SGPRs).
+#include <hip/hip_runtime.h>
+#include "cw_kernels.h"
+#include "fp256.hip.h"
+
+#define CW_BLOCK 256
+
+// ---- value-table access --------------------------------------------------------------------------
+__device__ __forceinline__ fe v_load(const uint4 *__restrict__ V, uint32_t slot, uint32_t Bp, uint32_t i) {
+    size_t base = (size_t)slot * 2 * Bp + i;
+    uint4 lo = V[base];
+    uint4 hi = V[base + Bp];
+    fe r;
+    r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
+    r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+    return r;
+}
+__device__ __forceinline__ void v_store(uint4 *__restrict__ V, uint32_t slot, uint32_t Bp, uint32_t i, const fe &x) {
+    size_t base = (size_t)slot * 2 * Bp + i;
+    V[base] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    V[base + Bp] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+}
+__device__ __forceinline__ fe aos_load(const uint4 *p, uint32_t i) {
+    uint4 lo = p[2 * (size_t)i], hi = p[2 * (size_t)i + 1];
+    fe r;
+    r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
+    r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+    return r;
+}
+__device__ __forceinline__ fe c_load(const uint32_t *__restrict__ consts, uint32_t idx) {
+    return fe_from(consts + (size_t)idx * 8);
+}
+
+// ---- init: slot 0 = 1 (calcwit.cpp:34), status = 0 -----------------------------------------------
+__global__ void __launch_bounds__(CW_BLOCK) cw_init_kernel(uint4 *V, uint32_t Bp, uint32_t *status, uint32_t *first_bad) {
+    uint32_t i = blockIdx.x * CW_BLOCK + threadIdx.x;
+    if (i >= Bp) return;
+    v_store(V, 0, Bp, i, fe_small(1));
+    status[i] = 0;
+    first_bad[i] = 0xFFFFFFFFu;
+}
+
+// ---- ingest: AoS canonical inputs [batch][n_in][32 B] -> SoA input slots ----------------------------
+// (setInputSignal's `signalValues[si] = val`, calcwit.cpp:93, for the whole batch)
+__global__ void __launch_bounds__(CW_BLOCK) cw_ingest_kernel(const uint4 *__restrict__ in, uint4 *__restrict__ V,
+                                                              uint32_t input_start, uint32_t n_in, uint32_t batch,
+                                                              uint32_t Bp) {
+    uint32_t i = blockIdx.x * CW_BLOCK + threadIdx.x;
+    uint32_t k = blockIdx.y;
+    if (i >= batch) return;
+    size_t src = ((size_t)i * n_in + k) * 2;
+    size_t dst = (size_t)(input_start + k) * 2 * Bp + i;
+    V[dst] = in[src];
+    V[dst + Bp] = in[src + 1];
+}
+
+// ---- schedule evaluation (the hot path) ---------------------------------------------------------------
+// One lane = one instance; every lane walks the same schedule.  FULL selects the variant that also
+// carries the slow-path operators (INV/IDIV/MOD/POW); schedules without them run the lean variant,
+// whose register footprint is that of one Montgomery product.
+template <bool FULL>
+__global__ void __launch_bounds__(CW_BLOCK)
+cw_eval_kernel(const CwRow *__restrict__ rows, uint64_t n_rows, uint4 *V, const uint32_t *__restrict__ consts,
+               uint32_t tmp_base, uint32_t Bp, uint32_t batch, uint32_t *__restrict__ status, FpParams P) {
+    const uint32_t i = blockIdx.x * CW_BLOCK + threadIdx.x;
+    if (i >= batch) return;
+    uint32_t st = 0;
+    for (uint64_t r = 0; r < n_rows; r++) {
+        const CwRow row = rows[r];
+        const uint32_t op = row.w0 & 0xFF;
+        const uint32_t dk = (row.w0 >> 8) & 3, ak = (row.w0 >> 10) & 3, bk = (row.w0 >> 12) & 3;
+        const uint32_t dslot = row.dst + (dk == K_TMP ? tmp_base : 0);
+        fe a, b;
+        if (ak == K_CONST) a = c_load(consts, row.a);
+        else a = v_load(V, row.a + (ak == K_TMP ? tmp_base : 0), Bp, i);
+        const bool unary = (op == D_COPY) | (op == D_NEG) | (op == D_BNOT) | (op == D_LNOT) | (op == D_INV) |
+                           (op == D_ASSERT_NZ);
+        if (!unary) {
+            if (bk == K_CONST) b = c_load(consts, row.b);
+            else b = v_load(V, row.b + (bk == K_TMP ? tmp_base : 0), Bp, i);
+        } else {
+            b = fe_zero();
+        }
+        fe d;
+        bool has_d = true;
+        switch (op) {
+        case D_COPY: d = a; break;
+        case D_ADD: d = fe_add(a, b, P); break;
+        case D_SUB: d = fe_sub(a, b, P); break;
+        case D_NEG: d = fe_neg(a, P); break;
+        case D_MMUL: d = fe_mmul(a, b, P); break;
+        case D_SHL: d = fe_shl(a, b, P); break;
+        case D_SHR: d = fe_shr(a, b, P); break;
+        case D_BAND: d = fe_band(a, b, P); break;
+        case D_BOR: d = fe_bor(a, b, P); break;
+        case D_BXOR: d = fe_bxor(a, b, P); break;
+        case D_BNOT: d = fe_bnot(a, P); break;
+        case D_LT: d = fe_small(fe_lt(a, b, P)); break;
+        case D_GT: d = fe_small(fe_lt(b, a, P)); break;
+        case D_LEQ: d = fe_small(!fe_lt(b, a, P)); break;
+        case D_GEQ: d = fe_small(!fe_lt(a, b, P)); break;
+        case D_EQ: d = fe_small(fe_eq(a, b)); break;
+        case D_NEQ: d = fe_small(!fe_eq(a, b)); break;
+        case D_LAND: d = fe_small(!fe_is_zero(a) & !fe_is_zero(b)); break;
+        case D_LOR: d = fe_small(!fe_is_zero(a) | !fe_is_zero(b)); break;
+        case D_LNOT: d = fe_small(fe_is_zero(a)); break;
+        case D_SELECT: {
+            // cond = a, then-value = b, else-value in the following EXT row
+            r++;
+            const CwRow ext = rows[r];
+            const uint32_t ck = (ext.w0 >> 10) & 3;
+            fe c;
+            if (ck == K_CONST) c = c_load(consts, ext.a);
+            else c = v_load(V, ext.a + (ck == K_TMP ? tmp_base : 0), Bp, i);
+            const bool t = !fe_is_zero(a);
+            for (int k = 0; k < 8; k++) d.v[k] = t ? b.v[k] : c.v[k];
+            break;
+        }
+        case D_ASSERT_EQ:
+            if (!fe_eq(a, b) && st == 0) st = CW_ST_ASSERT_FAILED | ((uint32_t)r << 8);
+            has_d = false;
+            break;
+        case D_ASSERT_NZ:
+            if (fe_is_zero(a) && st == 0) st = CW_ST_ASSERT_FAILED | ((uint32_t)r << 8);
+            has_d = false;
+            break;
+        default:
+            if (FULL) {
+                switch (op) {
+                case D_INV: d = fe_pow_uniform(a, P.qm2, P); break;
+                case D_POW: d = fe_pow(a, b, P); break;
+                case D_IDIV:
+                case D_MOD: {
+                    fe qq, rr;
+                    if (fe_is_zero(b)) {
+                        if (st == 0) st = CW_ST_ARITH | ((uint32_t)r << 8);
+                        d = fe_zero();
+                    } else {
+                        fe_divmod(a, b, &qq, &rr);
+                        d = (op == D_IDIV) ? qq : rr;
+                    }
+                    break;
+                }
+                default: has_d = false; break;
+                }
+            } else {
+                has_d = false;
+            }
+            break;
+        }
+        if (has_d) v_store(V, dslot, Bp, i, d);
+    }
+    if (st) status[i] = st;
+}
+
+// ---- R1CS check:  (A.w) * (B.w) == C.w  for every constraint row and instance ---------------------------
+// Terms are CSR: for row c the A/B/C term ranges are ptr[3c..3c+3]; each term = (value slot, coefficient
+// id).  Coefficient ids 0/1 mean +1/-1 (add/sub fast path); others index ctab, which holds c*R mod q so
+// that one MMUL gives w*c on canonical w.
+__global__ void __launch_bounds__(CW_BLOCK)
+cw_r1cs_kernel(const uint32_t *__restrict__ ptr, const uint32_t *__restrict__ tslot, const uint32_t *__restrict__ tcoef,
+               const uint32_t *__restrict__ ctab, uint32_t n_cons, uint32_t rows_per_block, const uint4 *__restrict__ V,
+               uint32_t Bp, uint32_t batch, uint32_t *status, uint32_t *first_bad, FpParams P) {
+    const uint32_t i = blockIdx.x * CW_BLOCK + threadIdx.x;
+    if (i >= batch) return;
+    uint32_t c0 = blockIdx.y * rows_per_block;
+    uint32_t c1 = min(c0 + rows_per_block, n_cons);
+    uint32_t bad = 0xFFFFFFFFu;
+    for (uint32_t c = c0; c < c1; c++) {
+        fe acc[3];
+        for (int part = 0; part < 3; part++) {
+            fe s = fe_zero();
+            const uint32_t t0 = ptr[3 * c + part], t1 = ptr[3 * c + part + 1];
+            for (uint32_t t = t0; t < t1; t++) {
+                const fe w = v_load(V, tslot[t], Bp, i);
+                const uint32_t ci = tcoef[t];
+                if (ci == 0) s = fe_add(s, w, P);
+                else if (ci == 1) s = fe_sub(s, w, P);
+                else s = fe_add(s, fe_mmul(w, c_load(ctab, ci), P), P);
+            }
+            acc[part] = s;
+        }
+        const bool lin = (ptr[3 * c] == ptr[3 * c + 1]) | (ptr[3 * c + 1] == ptr[3 * c + 2]);
+        bool ok;
+        if (lin) {
+            ok = fe_is_zero(acc[2]);
+        } else {
+            const fe lhs = fe_mmul(acc[0], acc[1], P);          // A*B / R
+            const fe rhs = fe_mmul(acc[2], fe_small(1), P);     // C / R
+            ok = fe_eq(lhs, rhs);
+        }
+        if (!ok && c < bad) bad = c;
+    }
+    if (bad != 0xFFFFFFFFu) {
+        atomicMin(&first_bad[i], bad);
+        atomicOr(&status[i], CW_ST_R1CS_FAILED);
+    }
+}
+
+// ---- egress: one instance's witness as [n_witness][32 B] (getWitness + Fr_toLongNormal, main.cpp:326-332) ----
+__global__ void __launch_bounds__(CW_BLOCK)
+cw_gather_kernel(const uint4 *__restrict__ V, const uint32_t *__restrict__ w2s, uint32_t n_wit, uint32_t Bp,
+                 uint32_t instance, uint4 *__restrict__ out) {
+    uint32_t k = blockIdx.x * CW_BLOCK + threadIdx.x;
+    if (k >= n_wit) return;
+    size_t base = (size_t)w2s[k] * 2 * Bp + instance;
+    out[2 * (size_t)k] = V[base];
+    out[2 * (size_t)k + 1] = V[base + Bp];
+}
+
+// ---- Fp multiplication micro-benchmark: iters dependent Montgomery products per lane --------------------
+__global__ void __launch_bounds__(CW_BLOCK)
+cw_mulbench_kernel(const uint4 *__restrict__ a, const uint4 *__restrict__ b, uint4 *__restrict__ out, uint32_t n,
+                   uint32_t iters, FpParams P) {
+    uint32_t i = blockIdx.x * CW_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    fe x = aos_load(a, i), y = aos_load(b, i);   // AoS operands: element i = uint4[2i], uint4[2i+1]
+    for (uint32_t k = 0; k < iters; k++) x = fe_mmul(x, y, P);
+    out[2 * (size_t)i] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    out[2 * (size_t)i + 1] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+}
+
+// ---- element-wise single-operator kernel (unit-test hook for the device field functions) ------------------
+__global__ void __launch_bounds__(CW_BLOCK)
+cw_fpop_kernel(uint32_t op, const uint4 *a_, const uint4 *b_, const uint4 *c_, uint4 *out, uint32_t *status, uint32_t n,
+               FpParams P) {
+    uint32_t i = blockIdx.x * CW_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    fe a = aos_load(a_, i), b = aos_load(b_, i), c = aos_load(c_, i);
+    fe d = fe_zero();
+    uint32_t st = 0;
+    switch (op) {
+    case D_COPY: d = a; break;
+    case D_ADD: d = fe_add(a, b, P); break;
+    case D_SUB: d = fe_sub(a, b, P); break;
+    case D_NEG: d = fe_neg(a, P); break;
+    case D_MMUL: d = fe_mmul(a, b, P); break;
+    case D_INV: d = fe_pow_uniform(a, P.qm2, P); break;
+    case D_POW: d = fe_pow(a, b, P); break;
+    case D_IDIV:
+    case D_MOD: {
+        fe qq, rr;
+        if (fe_is_zero(b)) { st = CW_ST_ARITH; }
+        else { fe_divmod(a, b, &qq, &rr); d = (op == D_IDIV) ? qq : rr; }
+        break;
+    }
+    case D_SHL: d = fe_shl(a, b, P); break;
+    case D_SHR: d = fe_shr(a, b, P); break;
+    case D_BAND: d = fe_band(a, b, P); break;
+    case D_BOR: d = fe_bor(a, b, P); break;
+    case D_BXOR: d = fe_bxor(a, b, P); break;
+    case D_BNOT: d = fe_bnot(a, P); break;
+    case D_LT: d = fe_small(fe_lt(a, b, P)); break;
+    case D_GT: d = fe_small(fe_lt(b, a, P)); break;
+    case D_LEQ: d = fe_small(!fe_lt(b, a, P)); break;
+    case D_GEQ: d = fe_small(!fe_lt(a, b, P)); break;
+    case D_EQ: d = fe_small(fe_eq(a, b)); break;
+    case D_NEQ: d = fe_small(!fe_eq(a, b)); break;
+    case D_LAND: d = fe_small(!fe_is_zero(a) & !fe_is_zero(b)); break;
+    case D_LOR: d = fe_small(!fe_is_zero(a) | !fe_is_zero(b)); break;
+    case D_LNOT: d = fe_small(fe_is_zero(a)); break;
+    case D_SELECT: { bool t = !fe_is_zero(a); for (int k = 0; k < 8; k++) d.v[k] = t ? b.v[k] : c.v[k]; break; }
+    case D_ASSERT_EQ: if (!fe_eq(a, b)) st = CW_ST_ASSERT_FAILED; break;
+    case D_ASSERT_NZ: if (fe_is_zero(a)) st = CW_ST_ASSERT_FAILED; break;
+    default: break;
+    }
+    out[2 * (size_t)i] = make_uint4(d.v[0], d.v[1], d.v[2], d.v[3]);
+    out[2 * (size_t)i + 1] = make_uint4(d.v[4], d.v[5], d.v[6], d.v[7]);
+    status[i] = st;
+}
+
+// ---- launch wrappers -----------------------------------------------------------------------------------------
+static inline dim3 blocks_for(uint32_t n) { return dim3((n + CW_BLOCK - 1) / CW_BLOCK); }
+
+hipError_t cwk_init(hipStream_t s, void *V, uint32_t Bp, uint32_t *status, uint32_t *first_bad) {
+    hipLaunchKernelGGL(cw_init_kernel, blocks_for(Bp), dim3(CW_BLOCK), 0, s, (uint4 *)V, Bp, status, first_bad);
+    return hipGetLastError();
+}
+hipError_t cwk_ingest(hipStream_t s, const void *in, void *V, uint32_t input_start, uint32_t n_in, uint32_t batch,
+                      uint32_t Bp) {
+    if (n_in == 0) return hipSuccess;
+    dim3 g((batch + CW_BLOCK - 1) / CW_BLOCK, n_in);
+    hipLaunchKernelGGL(cw_ingest_kernel, g, dim3(CW_BLOCK), 0, s, (const uint4 *)in, (uint4 *)V, input_start, n_in, batch,
+                       Bp);
+    return hipGetLastError();
+}
+hipError_t cwk_eval(hipStream_t s, bool full, const CwRow *rows, uint64_t n_rows, void *V, const uint32_t *consts,
+                    uint32_t tmp_base, uint32_t Bp, uint32_t batch, uint32_t *status, const FpParams &P) {
+    if (full)
+        hipLaunchKernelGGL(cw_eval_kernel<true>, blocks_for(batch), dim3(CW_BLOCK), 0, s, rows, n_rows, (uint4 *)V, consts,
+                           tmp_base, Bp, batch, status, P);
+    else
+        hipLaunchKernelGGL(cw_eval_kernel<false>, blocks_for(batch), dim3(CW_BLOCK), 0, s, rows, n_rows, (uint4 *)V, consts,
+                           tmp_base, Bp, batch, status, P);
+    return hipGetLastError();
+}
+hipError_t cwk_r1cs(hipStream_t s, const uint32_t *ptr, const uint32_t *tslot, const uint32_t *tcoef, const uint32_t *ctab,
+                    uint32_t n_cons, uint32_t rows_per_block, const void *V, uint32_t Bp, uint32_t batch, uint32_t *status,
+                    uint32_t *first_bad, const FpParams &P) {
+    if (n_cons == 0) return hipSuccess;
+    dim3 g((batch + CW_BLOCK - 1) / CW_BLOCK, (n_cons + rows_per_block - 1) / rows_per_block);
+    hipLaunchKernelGGL(cw_r1cs_kernel, g, dim3(CW_BLOCK), 0, s, ptr, tslot, tcoef, ctab, n_cons, rows_per_block,
+                       (const uint4 *)V, Bp, batch, status, first_bad, P);
+    return hipGetLastError();
+}
+hipError_t cwk_gather(hipStream_t s, const void *V, const uint32_t *w2s, uint32_t n_wit, uint32_t Bp, uint32_t instance,
+                      void *out) {
+    hipLaunchKernelGGL(cw_gather_kernel, blocks_for(n_wit), dim3(CW_BLOCK), 0, s, (const uint4 *)V, w2s, n_wit, Bp,
+                       instance, (uint4 *)out);
+    return hipGetLastError();
+}
+hipError_t cwk_mulbench(hipStream_t s, const void *a, const void *b, void *out, uint32_t n, uint32_t iters,
+                        const FpParams &P) {
+    hipLaunchKernelGGL(cw_mulbench_kernel, blocks_for(n), dim3(CW_BLOCK), 0, s, (const uint4 *)a, (const uint4 *)b,
+                       (uint4 *)out, n, iters, P);
+    return hipGetLastError();
+}
+hipError_t cwk_fpop(hipStream_t s, uint32_t op, const void *a, const void *b, const void *c, void *out, uint32_t *status,
+                    uint32_t n, const FpParams &P) {
+    hipLaunchKernelGGL(cw_fpop_kernel, blocks_for(n), dim3(CW_BLOCK), 0, s, op, (const uint4 *)a, (const uint4 *)b,
+                       (const uint4 *)c, (uint4 *)out, status, n, P);
+    return hipGetLastError();
+}

@@ -1,0 +1,328 @@
+// fp256.hip.h — device arithmetic on 256-bit prime-field elements for gfx950 (CDNA4).
+//
+// The reference's native field library is x86-64 (`mulx/adcx/adox`, <prime>/fr.asm) or GMP mpn_*
+// (generic/fr.cpp:19-376).  CDNA4 has no 64x64 multiplier and no carry flags across lanes' 64-bit
+// ops, so the design is re-done for the VALU: elements are 8 x u32 limbs in VGPRs, products go
+// through v_mad_u64_u32 (32x32+64 -> 64), carry chains through v_add_co/v_addc_co.  One witness
+// instance per lane; the modulus and its constants are wave-uniform (SGPRs, struct FpParams).
+//
+// Semantics follow generic/fr.cpp (cited per function); everything operates on raw residues in
+// [0,q): whether a residue is "canonical" or "Montgomery" is the schedule's business (lower.py).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "cw_tape.h"
+
+struct fe { uint32_t v[8]; };
+
+#define FE_UNROLL _Pragma("unroll")
+
+__device__ __forceinline__ fe fe_zero() {
+    fe r;
+    FE_UNROLL for (int i = 0; i < 8; i++) r.v[i] = 0;
+    return r;
+}
+__device__ __forceinline__ fe fe_small(uint32_t x) {
+    fe r = fe_zero();
+    r.v[0] = x;
+    return r;
+}
+__device__ __forceinline__ fe fe_from(const uint32_t *p) {
+    fe r;
+    FE_UNROLL for (int i = 0; i < 8; i++) r.v[i] = p[i];
+    return r;
+}
+__device__ __forceinline__ bool fe_is_zero(const fe &a) {
+    uint32_t o = 0;
+    FE_UNROLL for (int i = 0; i < 8; i++) o |= a.v[i];
+    return o == 0;
+}
+__device__ __forceinline__ bool fe_eq(const fe &a, const fe &b) {
+    uint32_t o = 0;
+    FE_UNROLL for (int i = 0; i < 8; i++) o |= a.v[i] ^ b.v[i];
+    return o == 0;
+}
+// a < b as unsigned 256-bit integers (Fr_rawCmp, generic/fr.cpp:263)
+__device__ __forceinline__ bool fe_ltu(const fe &a, const uint32_t *b) {
+    int64_t br = 0;
+    FE_UNROLL for (int i = 0; i < 8; i++) {
+        int64_t d = (int64_t)a.v[i] - (int64_t)b[i] + br;
+        br = d >> 32;
+    }
+    return br != 0;
+}
+__device__ __forceinline__ bool fe_ltu(const fe &a, const fe &b) { return fe_ltu(a, b.v); }
+// a > b
+__device__ __forceinline__ bool fe_gtu(const fe &a, const uint32_t *b) {
+    int64_t br = 0;
+    FE_UNROLL for (int i = 0; i < 8; i++) {
+        int64_t d = (int64_t)b[i] - (int64_t)a.v[i] + br;
+        br = d >> 32;
+    }
+    return br != 0;
+}
+
+// r = a - q if a >= q else a   (the single conditional subtraction of fr.cpp:24-27,297-301)
+__device__ __forceinline__ fe fe_csub_q(const fe &a, const FpParams &P) {
+    fe t;
+    int64_t br = 0;
+    FE_UNROLL for (int i = 0; i < 8; i++) {
+        int64_t d = (int64_t)a.v[i] - (int64_t)P.q[i] + br;
+        t.v[i] = (uint32_t)d;
+        br = d >> 32;
+    }
+    fe r;
+    FE_UNROLL for (int i = 0; i < 8; i++) r.v[i] = br ? a.v[i] : t.v[i];
+    return r;
+}
+
+// Fr_rawAdd, generic/fr.cpp:19-27
+__device__ __forceinline__ fe fe_add(const fe &a, const fe &b, const FpParams &P) {
+    fe s, t;
+    uint64_t c = 0;
+    FE_UNROLL for (int i = 0; i < 8; i++) {
+        c += (uint64_t)a.v[i] + b.v[i];
+        s.v[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    int64_t br = 0;
+    FE_UNROLL for (int i = 0; i < 8; i++) {
+        int64_t d = (int64_t)s.v[i] - (int64_t)P.q[i] + br;
+        t.v[i] = (uint32_t)d;
+        br = d >> 32;
+    }
+    bool use_t = (c != 0) | (br == 0);
+    fe r;
+    FE_UNROLL for (int i = 0; i < 8; i++) r.v[i] = use_t ? t.v[i] : s.v[i];
+    return r;
+}
+
+// Fr_rawSub, generic/fr.cpp:39-47
+__device__ __forceinline__ fe fe_sub(const fe &a, const fe &b, const FpParams &P) {
+    fe d;
+    int64_t br = 0;
+    FE_UNROLL for (int i = 0; i < 8; i++) {
+        int64_t x = (int64_t)a.v[i] - (int64_t)b.v[i] + br;
+        d.v[i] = (uint32_t)x;
+        br = x >> 32;
+    }
+    uint32_t m = br ? 0xFFFFFFFFu : 0u;
+    uint64_t c = 0;
+    fe r;
+    FE_UNROLL for (int i = 0; i < 8; i++) {
+        c += (uint64_t)d.v[i] + (P.q[i] & m);
+        r.v[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    return r;
+}
+
+// Fr_rawNeg, generic/fr.cpp:76-86
+__device__ __forceinline__ fe fe_neg(const fe &a, const FpParams &P) {
+    bool z = fe_is_zero(a);
+    fe r;
+    int64_t br = 0;
+    FE_UNROLL for (int i = 0; i < 8; i++) {
+        int64_t x = (int64_t)P.q[i] - (int64_t)a.v[i] + br;
+        r.v[i] = z ? 0u : (uint32_t)x;
+        br = x >> 32;
+    }
+    return r;
+}
+
+// Montgomery product a*b*2^-256 mod q — Fr_rawMMul (generic/fr.cpp:110-164, <prime>/fr.asm:365).
+// CIOS over 8 x 32-bit limbs: 8 rounds of (t += a*b[i]; m = t0*np; t = (t + m*q) >> 32).
+// 64 + 64 + 8 multiplies; every multiply-accumulate is one v_mad_u64_u32.
+__device__ __forceinline__ fe fe_mmul(const fe &a, const fe &b, const FpParams &P) {
+    uint32_t t[9];
+    FE_UNROLL for (int i = 0; i < 9; i++) t[i] = 0;
+    FE_UNROLL for (int i = 0; i < 8; i++) {
+        uint64_t c = 0;
+        const uint32_t bi = b.v[i];
+        FE_UNROLL for (int j = 0; j < 8; j++) {
+            uint64_t p = (uint64_t)a.v[j] * bi + t[j] + c;
+            t[j] = (uint32_t)p;
+            c = p >> 32;
+        }
+        uint64_t s = (uint64_t)t[8] + c;
+        t[8] = (uint32_t)s;
+        uint32_t t9 = (uint32_t)(s >> 32);
+        const uint32_t m = t[0] * P.np;
+        c = ((uint64_t)m * P.q[0] + t[0]) >> 32;
+        FE_UNROLL for (int j = 1; j < 8; j++) {
+            uint64_t p = (uint64_t)m * P.q[j] + t[j] + c;
+            t[j - 1] = (uint32_t)p;
+            c = p >> 32;
+        }
+        s = (uint64_t)t[8] + c;
+        t[7] = (uint32_t)s;
+        t[8] = t9 + (uint32_t)(s >> 32);
+    }
+    // result < 2q; one conditional subtraction (carry limb t[8] can only be set if q > 2^255)
+    fe r, u;
+    int64_t br = 0;
+    FE_UNROLL for (int i = 0; i < 8; i++) {
+        int64_t d = (int64_t)t[i] - (int64_t)P.q[i] + br;
+        u.v[i] = (uint32_t)d;
+        br = d >> 32;
+    }
+    bool use_u = (t[8] != 0) | (br == 0);
+    FE_UNROLL for (int i = 0; i < 8; i++) r.v[i] = use_u ? u.v[i] : t[i];
+    return r;
+}
+
+// ---- bitwise operators on canonical values (Fr_rawAnd/Or/Xor/Not, generic/fr.cpp:293-327,366-376) ----
+__device__ __forceinline__ fe fe_mask_wrap(fe r, const FpParams &P) {
+    r.v[7] &= P.topmask;
+    return fe_csub_q(r, P);
+}
+__device__ __forceinline__ fe fe_band(const fe &a, const fe &b, const FpParams &P) {
+    fe r;
+    FE_UNROLL for (int i = 0; i < 8; i++) r.v[i] = a.v[i] & b.v[i];
+    return fe_mask_wrap(r, P);
+}
+__device__ __forceinline__ fe fe_bor(const fe &a, const fe &b, const FpParams &P) {
+    fe r;
+    FE_UNROLL for (int i = 0; i < 8; i++) r.v[i] = a.v[i] | b.v[i];
+    return fe_mask_wrap(r, P);
+}
+__device__ __forceinline__ fe fe_bxor(const fe &a, const fe &b, const FpParams &P) {
+    fe r;
+    FE_UNROLL for (int i = 0; i < 8; i++) r.v[i] = a.v[i] ^ b.v[i];
+    return fe_mask_wrap(r, P);
+}
+__device__ __forceinline__ fe fe_bnot(const fe &a, const FpParams &P) {
+    fe r;
+    FE_UNROLL for (int i = 0; i < 8; i++) r.v[i] = ~a.v[i];
+    return fe_mask_wrap(r, P);
+}
+
+// 256-bit logical shifts by s in [0,255] (Fr_rawShl/Shr, generic/fr.cpp:329-364): barrel shifter,
+// branch-free so a lane-varying amount costs the same as a uniform one.
+__device__ __forceinline__ fe fe_shl_raw(const fe &a, uint32_t s) {
+    const bool s4 = s & 128, s2 = s & 64, s1 = s & 32;
+    fe t, u, w;
+    FE_UNROLL for (int i = 0; i < 8; i++) t.v[i] = s4 ? ((i >= 4) ? a.v[(i >= 4) ? i - 4 : 0] : 0u) : a.v[i];
+    FE_UNROLL for (int i = 0; i < 8; i++) u.v[i] = s2 ? ((i >= 2) ? t.v[(i >= 2) ? i - 2 : 0] : 0u) : t.v[i];
+    FE_UNROLL for (int i = 0; i < 8; i++) w.v[i] = s1 ? ((i >= 1) ? u.v[(i >= 1) ? i - 1 : 0] : 0u) : u.v[i];
+    const uint32_t bs = s & 31;
+    fe r;
+    FE_UNROLL for (int i = 7; i >= 1; i--)
+        r.v[i] = (uint32_t)((((uint64_t)w.v[i] << 32) | w.v[i - 1]) << bs >> 32);
+    r.v[0] = w.v[0] << bs;
+    return r;
+}
+__device__ __forceinline__ fe fe_shr_raw(const fe &a, uint32_t s) {
+    const bool s4 = s & 128, s2 = s & 64, s1 = s & 32;
+    fe t, u, w;
+    FE_UNROLL for (int i = 0; i < 8; i++) t.v[i] = s4 ? ((i + 4 < 8) ? a.v[(i + 4 < 8) ? i + 4 : 0] : 0u) : a.v[i];
+    FE_UNROLL for (int i = 0; i < 8; i++) u.v[i] = s2 ? ((i + 2 < 8) ? t.v[(i + 2 < 8) ? i + 2 : 0] : 0u) : t.v[i];
+    FE_UNROLL for (int i = 0; i < 8; i++) w.v[i] = s1 ? ((i + 1 < 8) ? u.v[(i + 1 < 8) ? i + 1 : 0] : 0u) : u.v[i];
+    const uint32_t bs = s & 31;
+    fe r;
+    FE_UNROLL for (int i = 0; i < 7; i++)
+        r.v[i] = (uint32_t)((((uint64_t)w.v[i + 1] << 32) | w.v[i]) >> bs);
+    r.v[7] = w.v[7] >> bs;
+    return r;
+}
+
+// classify a shift amount y (canonical): returns 0 = forward by *amt, 1 = reversed by *amt, 2 = result 0
+// (Fr_shl/Fr_shr + *_big_shift, generic/fr.cpp:2157-2307: y < qbits forward; else k = q - y reversed
+//  if k < qbits; else 0)
+__device__ __forceinline__ int fe_shift_kind(const fe &y, const FpParams &P, uint32_t *amt) {
+    uint32_t hi = 0;
+    FE_UNROLL for (int i = 1; i < 8; i++) hi |= y.v[i];
+    if (hi == 0 && y.v[0] < P.qbits) { *amt = y.v[0]; return 0; }
+    // k = q - y
+    uint32_t k0 = 0, khi = 0;
+    int64_t br = 0;
+    FE_UNROLL for (int i = 0; i < 8; i++) {
+        int64_t d = (int64_t)P.q[i] - (int64_t)y.v[i] + br;
+        if (i == 0) k0 = (uint32_t)d; else khi |= (uint32_t)d;
+        br = d >> 32;
+    }
+    if (khi == 0 && k0 < P.qbits) { *amt = k0; return 1; }
+    *amt = 0;
+    return 2;
+}
+__device__ __forceinline__ fe fe_shl(const fe &x, const fe &y, const FpParams &P) {
+    uint32_t amt;
+    int k = fe_shift_kind(y, P, &amt);
+    fe l = fe_mask_wrap(fe_shl_raw(x, amt), P);
+    fe r = fe_shr_raw(x, amt);
+    fe o;
+    FE_UNROLL for (int i = 0; i < 8; i++) o.v[i] = (k == 0) ? l.v[i] : ((k == 1) ? r.v[i] : 0u);
+    return o;
+}
+__device__ __forceinline__ fe fe_shr(const fe &x, const fe &y, const FpParams &P) {
+    uint32_t amt;
+    int k = fe_shift_kind(y, P, &amt);
+    fe l = fe_mask_wrap(fe_shl_raw(x, amt), P);
+    fe r = fe_shr_raw(x, amt);
+    fe o;
+    FE_UNROLL for (int i = 0; i < 8; i++) o.v[i] = (k == 0) ? r.v[i] : ((k == 1) ? l.v[i] : 0u);
+    return o;
+}
+
+// relational operators compare val(x) = x - q if x > half else x   (rltL1L2, generic/fr.cpp:1208-1218)
+__device__ __forceinline__ bool fe_lt(const fe &x, const fe &y, const FpParams &P) {
+    bool nx = fe_gtu(x, P.half), ny = fe_gtu(y, P.half);
+    bool ltu = fe_ltu(x, y);
+    return (nx != ny) ? nx : ltu;
+}
+
+// ---- slow-path operators (only in the "full" kernel) -----------------------------------------
+// x^e for a wave-uniform exponent e (8 limbs), x canonical -> canonical.  Used for INV = x^(q-2)
+// (mpz_invert semantics incl. inv(0) = 0: generic/fr.cpp:2895-2906).
+__device__ __noinline__ fe fe_pow_uniform(const fe &x, const uint32_t *e, const FpParams &P) {
+    fe xm = fe_mmul(x, fe_from(P.r2), P);        // to Montgomery
+    fe r = fe_from(P.one_m);
+    for (int i = 255; i >= 0; i--) {
+        r = fe_mmul(r, r, P);
+        if ((e[i >> 5] >> (i & 31)) & 1) r = fe_mmul(r, xm, P);
+    }
+    return fe_mmul(r, fe_small(1), P);            // from Montgomery
+}
+// x^y with a per-lane exponent (Fr_pow / mpz_powm, generic/fr.cpp:2877-2893; 0^0 = 1)
+__device__ __noinline__ fe fe_pow(const fe &x, const fe &y, const FpParams &P) {
+    fe xm = fe_mmul(x, fe_from(P.r2), P);
+    fe r = fe_from(P.one_m);
+    FE_UNROLL for (int w = 7; w >= 0; w--) {
+        const uint32_t ew = y.v[w];
+        for (int b = 31; b >= 0; b--) {
+            r = fe_mmul(r, r, P);
+            fe rx = fe_mmul(r, xm, P);
+            bool bit = (ew >> b) & 1;
+            FE_UNROLL for (int k = 0; k < 8; k++) r.v[k] = bit ? rx.v[k] : r.v[k];
+        }
+    }
+    return fe_mmul(r, fe_small(1), P);
+}
+// floor(x / y), x mod y on canonical integers (Fr_idiv/Fr_mod via mpz_fdiv_q/r, generic/fr.cpp:2835-2875).
+// Restoring shift-subtract division; y == 0 is reported by the caller.
+__device__ __noinline__ void fe_divmod(const fe &x, const fe &y, fe *quo, fe *rem) {
+    fe q = fe_zero(), r = fe_zero();
+    FE_UNROLL for (int w = 7; w >= 0; w--) {
+        const uint32_t xw = x.v[w];
+        uint32_t qw = 0;
+        for (int b = 31; b >= 0; b--) {
+            // r = (r << 1) | bit(x)
+            FE_UNROLL for (int k = 7; k >= 1; k--) r.v[k] = (r.v[k] << 1) | (r.v[k - 1] >> 31);
+            r.v[0] = (r.v[0] << 1) | ((xw >> b) & 1);
+            // if r >= y: r -= y, set quotient bit
+            fe d;
+            int64_t br = 0;
+            FE_UNROLL for (int k = 0; k < 8; k++) {
+                int64_t t = (int64_t)r.v[k] - (int64_t)y.v[k] + br;
+                d.v[k] = (uint32_t)t;
+                br = t >> 32;
+            }
+            bool ge = (br == 0);
+            FE_UNROLL for (int k = 0; k < 8; k++) r.v[k] = ge ? d.v[k] : r.v[k];
+            qw |= (ge ? 1u : 0u) << b;
+        }
+        q.v[w] = qw;
+    }
+    *quo = q;
+    *rem = r;
+}

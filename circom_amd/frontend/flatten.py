@@ -1,0 +1,164 @@
+"""Flatten the traced component tree into one circuit-wide signal table, op list and constraint list.
+
+Mirrors what the reference's construction phase exports at `--O0`:
+  * global signal numbering = preorder walk of the component tree, slot 0 = the constant 1, main's
+    block starts at 1 (dag/src/lib.rs:328-371, dag/src/witness_producer.rs:3-19, calcwit.cpp:34);
+    at --O0 the witness list is the identity over all signals ("--O0 identity"),
+  * constraints in tree preorder: a node's own constraints, then each child's subtree
+    (matches the golden `basic.circom --O0` listing in mkdocs/docs/circom-language/formats/constraints-json.md),
+  * the witness code in *execution* order: a child's code is spliced in at the point where the parent
+    stores its last input (store_bucket.rs:660-735).
+"""
+from __future__ import annotations
+
+import sys
+
+import numpy as np
+
+from .. import opcodes as O
+from .dsl import Program, TemplateInstance, CONST_KEY, _prod
+
+K_SIG, K_TMP = O.K_SIG, O.K_TMP
+
+
+class FlatCircuit:
+    def __init__(self, prog: Program):
+        self.prog = prog
+        self.prime = prog.prime
+        self.fp = prog.fp
+        m = prog.main
+        self.n_signals = 1 + m.n_total
+        self.n_components = m.n_components
+        self.constants = prog.constants
+        self.n_outputs = m.n_out
+        self.n_pub_in = prog.n_public_inputs
+        self.n_prv_in = m.n_in - self.n_pub_in
+        self.main_input_start = 1 + m.n_out                   # get_main_input_signal_start, c_elements/mod.rs:156-158
+        self.n_main_inputs = m.n_in
+        self.inputs = [(n, 1 + off, size) for n, off, size in m.input_names]
+        self.input_dims = {n: d for n, d, o in m.decls["i"]}
+        # component table in preorder
+        self.comp_inst = []
+        self.comp_sigstart = []
+        self.comp_father = []
+        self.comp_name = []
+        self._flatten()
+
+    # ------------------------------------------------------------------------------------------
+    def _flatten(self):
+        sys.setrecursionlimit(max(10000, sys.getrecursionlimit()))
+        chunks = {k: [] for k in ("op", "dk", "dv", "ak", "av", "bk", "bv", "ck", "cv")}
+        cons = []
+        # per-instance cached pieces
+        cache = {}
+
+        def prep(inst: TemplateInstance):
+            c = inst.code
+            op = c["op"]
+            runs = np.nonzero(op == O.RUN)[0]
+            segs = []
+            start = 0
+            bounds = list(runs) + [len(op)]
+            for r in bounds:
+                if r > start:
+                    sl = slice(start, r)
+                    seg = {"op": op[sl]}
+                    for kk, vv in (("dk", "dv"), ("ak", "av"), ("bk", "bv"), ("ck", "cv")):
+                        k = c[kk][sl]
+                        seg[kk] = k
+                        seg[vv] = c[vv][sl]
+                        seg[vv + "_s"] = (k == K_SIG).astype(np.int64)
+                        seg[vv + "_t"] = (k == K_TMP).astype(np.int64)
+                    segs.append(("seg", seg))
+                if r < len(op):
+                    segs.append(("run", int(c["av"][r])))
+                start = r + 1
+            cache[inst.id] = segs
+            return segs
+
+        # Component numbering must be preorder over the *sorted* child table, while code order follows
+        # execution.  Do it in two passes: (1) number + record constraints in preorder, (2) emit code.
+        order = []  # (inst, base, father, name)
+
+        def number(inst, base, father, name):
+            me = len(order)
+            order.append((inst, base, father, name))
+            for a, b, c in inst.constraints:
+                cons.append((self._reloc(a, base), self._reloc(b, base), self._reloc(c, base)))
+            for cname, cidx, cinst, soff, coff in inst.children:
+                assert len(order) == me + coff
+                number(cinst, base + soff, me, cname + "".join("[%d]" % i for i in cidx))
+
+        number(self.prog.main, 1, 0, "main")
+        for inst, base, father, name in order:
+            self.comp_inst.append(inst.id)
+            self.comp_sigstart.append(base)
+            self.comp_father.append(father)
+            self.comp_name.append(name)
+        # temp bases per component (preorder)
+        tbase = np.zeros(len(order) + 1, dtype=np.int64)
+        for i, (inst, _, _, _) in enumerate(order):
+            tbase[i + 1] = tbase[i] + inst.n_temps
+        self.n_temps = int(tbase[-1])
+
+        def emit(ci):
+            inst, base, _, _ = order[ci]
+            tb = int(tbase[ci])
+            segs = cache.get(inst.id)
+            if segs is None:
+                segs = prep(inst)
+            for kind, item in segs:
+                if kind == "seg":
+                    chunks["op"].append(item["op"])
+                    for kk, vv in (("dk", "dv"), ("ak", "av"), ("bk", "bv"), ("ck", "cv")):
+                        chunks[kk].append(item[kk])
+                        chunks[vv].append(item[vv] + base * item[vv + "_s"] + tb * item[vv + "_t"])
+                else:
+                    emit(ci + inst.children[item][4])
+
+        emit(0)
+        self.code = {k: (np.concatenate(v) if v else np.zeros(0, dtype=np.int64)) for k, v in chunks.items()}
+        self.constraints = cons
+
+    @staticmethod
+    def _reloc(d, base):
+        return {(0 if k == CONST_KEY else k + base): v for k, v in d.items()}
+
+    # ------------------------------------------------------------------------------------------
+    def signal_names(self):
+        """Qualified names in .sym order (constraint_writers/src/sym_writer.rs; docs formats/sym.md)."""
+        names = ["one"] + [None] * (self.n_signals - 1)
+        insts = self.prog.inst_list
+
+        def arr_names(prefix, name, dims):
+            if not dims:
+                yield prefix + name
+                return
+            idx = [0] * len(dims)
+            total = _prod(dims)
+            for _ in range(total):
+                yield prefix + name + "".join("[%d]" % i for i in idx)
+                for d in range(len(dims) - 1, -1, -1):
+                    idx[d] += 1
+                    if idx[d] < dims[d]:
+                        break
+                    idx[d] = 0
+
+        # rebuild full qualified component paths
+        paths = [None] * len(self.comp_inst)
+        for ci in range(len(self.comp_inst)):
+            f = self.comp_father[ci]
+            paths[ci] = "main" if ci == 0 else paths[f] + "." + self.comp_name[ci]
+        for ci, iid in enumerate(self.comp_inst):
+            inst = insts[iid]
+            base = self.comp_sigstart[ci]
+            pre = paths[ci] + "."
+            for cat in ("o", "i", "m"):
+                for name, dims, off in inst.decls[cat]:
+                    for j, nm in enumerate(arr_names(pre, name, dims)):
+                        names[base + off + j] = nm
+        return names
+
+
+def flatten(prog: Program) -> FlatCircuit:
+    return FlatCircuit(prog)

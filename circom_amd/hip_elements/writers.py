@@ -1,0 +1,182 @@
+"""File emitters of the hip_elements back-end.
+
+  write_dat   `<name>.dat`  byte-for-byte the reference layout (c_code_generator.rs:575-679,818-865;
+              reader main.cpp:22-124): input hash map, witness->signal list, constant table.  The same
+              file feeds the reference C++ runtime (oracle) and the HIP runtime.
+  write_tape  `<name>.cwt`  the batched schedule for the HIP kernels (new; layout below).
+  write_r1cs  `<name>.r1cs` iden3 binary R1CS exactly as constraint_writers/src/r1cs_writer.rs lays it
+              out (section order 2,1,3 as dag/src/r1cs_porting.rs:13-46 writes it).
+  write_sym   `<name>.sym`  (constraint_writers sym format, docs formats/sym.md).
+  write_wtns  `.wtns` v2   (main.cpp:288-334 = witness_calculator.js:212-276).
+"""
+from __future__ import annotations
+
+import struct
+
+import numpy as np
+
+from ..frontend.flatten import FlatCircuit
+from .lower import Tape
+
+FNV_OFFSET = 0xCBF29CE484222325
+FNV_PRIME = 0x100000001B3
+M64 = (1 << 64) - 1
+
+
+def fnv1a(s: str) -> int:
+    """64-bit FNV-1a (calcwit.cpp:17-24 == components/mod.rs:50-55)."""
+    h = FNV_OFFSET
+    for c in s.encode():
+        h ^= c
+        h = (h * FNV_PRIME) & M64
+    return h
+
+
+def hashmap_size(n_input_names: int) -> int:
+    """c_elements/mod.rs:167-169: max(2^ceil(log2 n), 256)."""
+    n = 1
+    while n < n_input_names:
+        n *= 2
+    return max(n, 256)
+
+
+def build_hash_map(inputs, size):
+    """generate_hash_map, c_code_generator.rs:575-587 (linear probing, empty = signalid 0)."""
+    tab = [(0, 0, 0)] * size
+    for name, start, sz in inputs:
+        h = fnv1a(name)
+        p = h % size
+        while tab[p][1] != 0:
+            p = (p + 1) % size
+        tab[p] = (h, start, sz)
+    return tab
+
+
+def dat_constant(v: int, fp) -> bytes:
+    """One 40-byte FrElement of the constant table (c_code_generator.rs:616-679)."""
+    q = fp.q
+    n = v % q
+    nn = n - q if n > q // 2 else n
+    if -2147483648 <= nn <= 2147483647:
+        head = struct.pack("<I", nn & 0xFFFFFFFF) + struct.pack("<I", 0x40000000)
+    else:
+        head = struct.pack("<I", 0) + struct.pack("<I", 0xC0000000)
+    return head + ((n * fp.R) % q).to_bytes(8 * fp.n64, "little")
+
+
+def write_dat(path, fc: FlatCircuit, witness2signal=None):
+    size = hashmap_size(len(fc.inputs))
+    tab = build_hash_map(fc.inputs, size)
+    if witness2signal is None:
+        witness2signal = np.arange(fc.n_signals, dtype=np.uint64)
+    with open(path, "wb") as f:
+        f.write(b"".join(struct.pack("<QQQ", *e) for e in tab))
+        f.write(np.asarray(witness2signal, dtype="<u8").tobytes())
+        f.write(b"".join(dat_constant(v, fc.fp) for v in fc.constants))
+    return size
+
+
+TAPE_MAGIC = b"CWTP"
+TAPE_VERSION = 1
+
+
+def write_tape(path, tape: Tape):
+    """`.cwt` layout (little endian):
+         0  "CWTP" | u32 version | u32 n64 | u32 reserved
+        16  prime, n64*8 bytes
+            u32 n_signals, n_tslots, n_witness, n_consts, n_rows(lo), n_rows(hi), main_input_start,
+                n_main_inputs, n_input_names, hashmap_size, 0, 0            (12 x u32)
+            rows       n_rows x 4 x u32
+            consts     n_consts x n64*8 bytes (raw residues as the schedule expects them)
+            witness2signal  n_witness x u32
+            input names: per name  u32 len | bytes | u32 start | u32 size
+    """
+    n64 = (tape.q.bit_length() + 63) // 64
+    with open(path, "wb") as f:
+        f.write(TAPE_MAGIC + struct.pack("<III", TAPE_VERSION, n64, 0))
+        f.write(tape.q.to_bytes(8 * n64, "little"))
+        nrows = len(tape.rows)
+        f.write(struct.pack("<12I", tape.n_signals, tape.n_tslots, tape.n_witness, len(tape.consts),
+                            nrows & 0xFFFFFFFF, nrows >> 32, tape.main_input_start, tape.n_main_inputs,
+                            len(tape.inputs), hashmap_size(len(tape.inputs)), 0, 0))
+        f.write(np.ascontiguousarray(tape.rows, dtype="<u4").tobytes())
+        f.write(b"".join(c.to_bytes(8 * n64, "little") for c in tape.consts))
+        f.write(np.asarray(tape.witness2signal, dtype="<u4").tobytes())
+        for name, start, size in tape.inputs:
+            b = name.encode()
+            f.write(struct.pack("<I", len(b)) + b + struct.pack("<II", start, size))
+
+
+def _le_key(k: int) -> bytes:
+    # r1cs_writer.rs:49-72 orders wire ids by their little-endian byte strings
+    return k.to_bytes(max(1, (k.bit_length() + 7) // 8), "little")
+
+
+def _lc_block(lc: dict, fs: int) -> bytes:
+    items = sorted(((k, v) for k, v in lc.items() if v), key=lambda kv: _le_key(kv[0]))
+    out = [struct.pack("<I", len(items))]
+    for k, v in items:
+        out.append(struct.pack("<I", k) + v.to_bytes(fs, "little"))
+    return b"".join(out)
+
+
+def write_r1cs(path, fc: FlatCircuit, wire_of_signal=None):
+    """wire_of_signal: optional map signal id -> wire id (identity at --O0)."""
+    q = fc.fp.q
+    bits = q.bit_length()
+    fs = bits // 8 if bits % 64 == 0 else (bits // 64 + 1) * 8      # dag/src/r1cs_porting.rs:7-11
+    cons = []
+    for a, b, c in fc.constraints:
+        if wire_of_signal is not None:
+            a = {wire_of_signal[k]: v for k, v in a.items()}
+            b = {wire_of_signal[k]: v for k, v in b.items()}
+            c = {wire_of_signal[k]: v for k, v in c.items()}
+        cons.append(_lc_block(a, fs) + _lc_block(b, fs) + _lc_block(c, fs))
+    n_wires = fc.n_signals
+    sec2 = b"".join(cons)
+    sec1 = struct.pack("<I", fs) + q.to_bytes(fs, "little") + struct.pack(
+        "<IIIIQI", n_wires, fc.n_outputs, fc.n_pub_in, fc.n_prv_in, n_wires, len(cons))
+    sec3 = np.arange(n_wires, dtype="<u8").tobytes()
+    with open(path, "wb") as f:
+        f.write(b"r1cs" + struct.pack("<II", 1, 3))
+        for typ, body in ((2, sec2), (1, sec1), (3, sec3)):
+            f.write(struct.pack("<IQ", typ, len(body)))
+            f.write(body)
+
+
+def write_sym(path, fc: FlatCircuit):
+    names = fc.signal_names()
+    # component ids of the .sym file: tree post-order (docs formats/sym.md: main.c = 0, main = 1)
+    n = len(fc.comp_inst)
+    children = [[] for _ in range(n)]
+    for ci in range(1, n):
+        children[fc.comp_father[ci]].append(ci)
+    post = [0] * n
+    counter = 0
+    stack = [(0, 0)]
+    while stack:
+        node, k = stack.pop()
+        if k < len(children[node]):
+            stack.append((node, k + 1))
+            stack.append((children[node][k], 0))
+        else:
+            post[node] = counter
+            counter += 1
+    comp_of = np.zeros(fc.n_signals, dtype=np.int64)
+    insts = fc.prog.inst_list
+    for ci in range(n):
+        base = fc.comp_sigstart[ci]
+        comp_of[base:base + insts[fc.comp_inst[ci]].n_local] = post[ci]
+    with open(path, "w") as f:
+        for s in range(1, fc.n_signals):
+            f.write("%d,%d,%d,%s\n" % (s, s, comp_of[s], names[s]))
+
+
+def wtns_bytes(q: int, values) -> bytes:
+    """values: iterable of canonical ints (witness order)."""
+    n8 = 8 * ((q.bit_length() + 63) // 64)
+    vals = list(values)
+    out = [b"wtns", struct.pack("<II", 2, 2), struct.pack("<IQ", 1, 8 + n8), struct.pack("<I", n8),
+           q.to_bytes(n8, "little"), struct.pack("<I", len(vals)), struct.pack("<IQ", 2, n8 * len(vals))]
+    out += [v.to_bytes(n8, "little") for v in vals]
+    return b"".join(out)

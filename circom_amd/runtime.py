@@ -1,0 +1,236 @@
+"""ctypes binding of the C ABI (include/circom_amd.h -> circom_amd/lib/libcircom_amd.so).
+
+Host-side mirror of the reference's runtime objects: `Circuit` ~ Circom_Circuit (circom.hpp:36-43),
+`Batch` ~ Circom_CalcWit (calcwit.hpp:17-66) for B instances.  There is no CPU fallback: if the HIP
+library is missing or no GPU is present, computing calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "lib" / "libcircom_amd.so"
+
+ST_OK, ST_ASSERT_FAILED, ST_ARITH, ST_R1CS_FAILED = 0, 1, 2, 4
+
+
+class CwError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("circom_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+def build_library(force: bool = False) -> Path:
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [_HERE / "csrc" / n for n in ("cw_kernels.hip", "cw_host.cpp", "cw_kernels.h", "cw_tape.h", "fp256.hip.h")]
+    if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= s.stat().st_mtime for s in srcs):
+        return LIB_PATH
+    subprocess.run(["make", "-C", str(_HERE / "csrc")], check=True, capture_output=True)
+    return LIB_PATH
+
+
+_lib = None
+
+_SIGS = {
+    "cw_last_error": (C.c_char_p, []),
+    "cw_version": (C.c_char_p, []),
+    "cw_load": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "cw_free": (None, [C.c_void_p]),
+    "cw_n_signals": (C.c_uint32, [C.c_void_p]),
+    "cw_n_witness": (C.c_uint32, [C.c_void_p]),
+    "cw_n_inputs": (C.c_uint32, [C.c_void_p]),
+    "cw_input_start": (C.c_uint32, [C.c_void_p]),
+    "cw_n_constraints": (C.c_uint32, [C.c_void_p]),
+    "cw_n_rows": (C.c_uint64, [C.c_void_p]),
+    "cw_n_mmul": (C.c_uint64, [C.c_void_p]),
+    "cw_prime": (None, [C.c_void_p, C.c_char_p]),
+    "cw_input_size": (C.c_int64, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint32)]),
+    "cw_batch_create": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "cw_batch_free": (None, [C.c_void_p]),
+    "cw_batch_size": (C.c_uint32, [C.c_void_p]),
+    "cw_set_input_signal": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p]),
+    "cw_set_inputs_json": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p]),
+    "cw_set_inputs": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cw_set_inputs_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cw_get_staged_input": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p]),
+    "cw_remaining_inputs": (C.c_int64, [C.c_void_p, C.c_uint32]),
+    "cw_run": (C.c_int, [C.c_void_p]),
+    "cw_check_r1cs": (C.c_int, [C.c_void_p]),
+    "cw_sync": (C.c_int, [C.c_void_p]),
+    "cw_get_status": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cw_get_witness": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    "cw_get_signal": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p]),
+    "cw_write_wtns": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p]),
+    "cw_get_r1cs_first_bad": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cw_device_values": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    "cw_fp_mul_bench": (C.c_int, [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.POINTER(C.c_float)]),
+    "cw_fp_op": (C.c_int, [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                           C.c_void_p, C.c_void_p]),
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise CwError(-4, "HIP extension %s is not built (run __graft_entry__.build()); "
+                              "there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise CwError(rc, lib().cw_last_error().decode())
+
+
+def fe_to_bytes(values, n=None) -> bytes:
+    return b"".join(int(v).to_bytes(32, "little") for v in values)
+
+
+def bytes_to_ints(buf: bytes):
+    return [int.from_bytes(buf[i:i + 32], "little") for i in range(0, len(buf), 32)]
+
+
+class Circuit:
+    def __init__(self, tape_path, dat_path=None, r1cs_path=None):
+        h = C.c_void_p()
+        enc = lambda p: None if p is None else os.fsencode(str(p))
+        _chk(lib().cw_load(enc(tape_path), enc(dat_path), enc(r1cs_path), C.byref(h)))
+        self.h = h
+        L = lib()
+        self.n_signals = L.cw_n_signals(h)
+        self.n_witness = L.cw_n_witness(h)
+        self.n_inputs = L.cw_n_inputs(h)
+        self.input_start = L.cw_input_start(h)
+        self.n_constraints = L.cw_n_constraints(h)
+        self.n_rows = L.cw_n_rows(h)
+        self.n_mmul = L.cw_n_mmul(h)
+        buf = C.create_string_buffer(32)
+        L.cw_prime(h, buf)
+        self.q = int.from_bytes(buf.raw, "little")
+
+    def input_size(self, name: str):
+        start = C.c_uint32()
+        n = lib().cw_input_size(self.h, name.encode(), C.byref(start))
+        return (None, None) if n < 0 else (start.value, n)
+
+    def close(self):
+        if self.h:
+            lib().cw_free(self.h)
+            self.h = None
+
+    def batch(self, batch: int, device: int = 0, stream=None) -> "Batch":
+        return Batch(self, batch, device, stream)
+
+
+class Batch:
+    def __init__(self, circuit: Circuit, batch: int, device: int = 0, stream=None):
+        self.circuit = circuit
+        self.n = batch
+        h = C.c_void_p()
+        _chk(lib().cw_batch_create(circuit.h, device, batch, C.c_void_p(stream or 0), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib().cw_batch_free(self.h)
+            self.h = None
+
+    # -- inputs -------------------------------------------------------------------------------------
+    def set_input_signal(self, instance: int, name: str, idx: int, value: int):
+        _chk(lib().cw_set_input_signal(self.h, instance, name.encode(), idx, int(value).to_bytes(32, "little")))
+
+    def set_inputs_json(self, instance: int, text: str):
+        _chk(lib().cw_set_inputs_json(self.h, instance, text.encode()))
+
+    def set_inputs(self, arr):
+        """arr: uint8 array [batch, n_inputs, 32] (canonical LE) or a list of lists of ints."""
+        if not isinstance(arr, np.ndarray):
+            arr = np.frombuffer(b"".join(fe_to_bytes(row) for row in arr), dtype=np.uint8)
+        arr = np.ascontiguousarray(arr, dtype=np.uint8)
+        assert arr.size == self.n * self.circuit.n_inputs * 32, "input array has the wrong size"
+        _chk(lib().cw_set_inputs(self.h, arr.ctypes.data_as(C.c_void_p)))
+
+    def set_inputs_device(self, dptr: int):
+        _chk(lib().cw_set_inputs_device(self.h, C.c_void_p(dptr)))
+
+    def staged_input(self, instance: int, k: int) -> int:
+        buf = C.create_string_buffer(32)
+        _chk(lib().cw_get_staged_input(self.h, instance, k, buf))
+        return int.from_bytes(buf.raw, "little")
+
+    def remaining_inputs(self, instance: int) -> int:
+        return lib().cw_remaining_inputs(self.h, instance)
+
+    # -- compute ------------------------------------------------------------------------------------
+    def run(self):
+        _chk(lib().cw_run(self.h))
+
+    def check_r1cs(self):
+        _chk(lib().cw_check_r1cs(self.h))
+
+    def sync(self):
+        _chk(lib().cw_sync(self.h))
+
+    # -- results ------------------------------------------------------------------------------------
+    def status(self) -> np.ndarray:
+        out = np.zeros(self.n, dtype=np.uint32)
+        _chk(lib().cw_get_status(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def r1cs_first_bad(self) -> np.ndarray:
+        out = np.zeros(self.n, dtype=np.uint32)
+        _chk(lib().cw_get_r1cs_first_bad(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def witness_bytes(self, instance: int) -> bytes:
+        out = np.zeros(self.circuit.n_witness * 32, dtype=np.uint8)
+        _chk(lib().cw_get_witness(self.h, instance, out.ctypes.data_as(C.c_void_p)))
+        return out.tobytes()
+
+    def witness(self, instance: int):
+        return bytes_to_ints(self.witness_bytes(instance))
+
+    def signal(self, instance: int, slot: int) -> int:
+        buf = C.create_string_buffer(32)
+        _chk(lib().cw_get_signal(self.h, instance, slot, buf))
+        return int.from_bytes(buf.raw, "little")
+
+    def write_wtns(self, instance: int, path):
+        _chk(lib().cw_write_wtns(self.h, instance, os.fsencode(str(path))))
+
+
+def fp_mul_bench(q: int, a: np.ndarray, b: np.ndarray, iters: int, device: int = 0):
+    """a, b: uint8 [n,32].  Returns (out uint8 [n,32], milliseconds)."""
+    n = a.shape[0]
+    out = np.zeros_like(a)
+    ms = C.c_float()
+    _chk(lib().cw_fp_mul_bench(q.to_bytes(32, "little"), device, n, iters, a.ctypes.data_as(C.c_void_p),
+                               b.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.byref(ms)))
+    return out, ms.value
+
+
+def fp_op(q: int, dop: int, a, b, c, device: int = 0):
+    """Element-wise device op on lists of ints; returns (list of ints, status array)."""
+    n = len(a)
+    A = np.frombuffer(fe_to_bytes(a), dtype=np.uint8)
+    B = np.frombuffer(fe_to_bytes(b), dtype=np.uint8)
+    Cc = np.frombuffer(fe_to_bytes(c), dtype=np.uint8)
+    out = np.zeros(n * 32, dtype=np.uint8)
+    st = np.zeros(n, dtype=np.uint32)
+    _chk(lib().cw_fp_op(q.to_bytes(32, "little"), device, dop, n, A.ctypes.data_as(C.c_void_p),
+                        B.ctypes.data_as(C.c_void_p), Cc.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                        st.ctypes.data_as(C.c_void_p)))
+    return bytes_to_ints(out.tobytes()), st

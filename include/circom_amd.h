@@ -1,0 +1,121 @@
+/* circom_amd.h — C ABI of the MI355X-native batched witness calculator for circom circuits.
+ *
+ * Drop-in boundary.  circom has no plugin registry; the emitted C++ calculator is
+ * reached through four concrete seams.  Each entry point below names the reference interface it
+ * replaces (paths relative to the iden3/circom tree, v2.2.3):
+ *
+ *   seam 3 (runtime)   code_producers/src/c_elements/common/calcwit.hpp:17-66  class Circom_CalcWit
+ *                      code_producers/src/c_elements/common/circom.hpp:36-43,79-87  Circom_Circuit + get_*()
+ *   seam 4 (process)   code_producers/src/c_elements/common/main.cpp:22-124 loadCircuit,
+ *                      :243-286 loadJson, :288-334 writeBinWitness, :336-373 main
+ *
+ * Differences forced by batching: one `cw_batch` holds B independent instances (the reference runs one
+ * process per input); a failed `===`/assert does not abort (assert_bucket.rs:75-77) but is reported in
+ * the per-instance status word; everything is plain pointers + sizes, caller owns host buffers, the
+ * library owns device memory.  All functions return 0 on success or a negative CW_E* code;
+ * cw_last_error() gives the message (thread-local).  No function is thread-safe on the same handle.
+ */
+#ifndef CIRCOM_AMD_H
+#define CIRCOM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CW_OK 0
+#define CW_EIO (-1)        /* file missing / unreadable / malformed */
+#define CW_EINVAL (-2)     /* bad argument */
+#define CW_EINPUT (-3)     /* input error: signal not found / assigned twice / wrong count (calcwit.cpp:51-97) */
+#define CW_EDEVICE (-4)    /* HIP error */
+#define CW_ESTATE (-5)     /* call out of order (e.g. run before all inputs are set) */
+
+typedef struct cw_circuit cw_circuit; /* replaces Circom_Circuit (circom.hpp:36-43) + compiled-in tables */
+typedef struct cw_batch cw_batch;     /* replaces Circom_CalcWit (calcwit.hpp:17-66), x B instances */
+
+/* instance status word (cw_get_status) */
+#define CW_ST_OK 0u
+#define CW_ST_ASSERT_FAILED 1u /* a `===` / assert() did not hold; bits 8.. = schedule row */
+#define CW_ST_ARITH 2u         /* `\` or `%` by zero (reference: GMP abort, generic/fr.cpp:2835-2875) */
+#define CW_ST_R1CS_FAILED 4u   /* set by cw_check_r1cs */
+
+const char *cw_last_error(void);
+const char *cw_version(void);
+
+/* ---- circuit (loadCircuit, main.cpp:22-124; the nine get_*() of circom.hpp:79-87) -------------- */
+/* tape_path: <name>.cwt (hip_elements schedule); dat_path: <name>.dat (reference layout, hash map +
+ * witness list are read from it; may be NULL -> taken from the tape); r1cs_path: <name>.r1cs or NULL. */
+int cw_load(const char *tape_path, const char *dat_path, const char *r1cs_path, cw_circuit **out);
+void cw_free(cw_circuit *c);
+uint32_t cw_n_signals(const cw_circuit *c);          /* get_total_signal_no() */
+uint32_t cw_n_witness(const cw_circuit *c);          /* get_size_of_witness() */
+uint32_t cw_n_inputs(const cw_circuit *c);           /* get_main_input_signal_no() */
+uint32_t cw_input_start(const cw_circuit *c);        /* get_main_input_signal_start() */
+uint32_t cw_n_constraints(const cw_circuit *c);      /* from the .r1cs header, 0 if none loaded */
+uint64_t cw_n_rows(const cw_circuit *c);             /* schedule length */
+uint64_t cw_n_mmul(const cw_circuit *c);             /* Montgomery multiplications per instance in the schedule */
+void cw_prime(const cw_circuit *c, uint8_t le32[32]); /* Fr_q (fr.hpp) */
+/* getInputSignalSize(h) (calcwit.cpp:99-102): size of input `name`, or -1 */
+int64_t cw_input_size(const cw_circuit *c, const char *name, uint32_t *start_slot);
+
+/* ---- batch (Circom_CalcWit ctor calcwit.cpp:26-45) -------------------------------------------------- */
+/* device: HIP device ordinal; batch: number of instances; stream: a hipStream_t (as void*) all work of
+ * this batch is enqueued on, NULL = the null stream.  device < 0 creates a host-only batch: inputs can be
+ * staged and validated, every computing call fails with CW_EDEVICE (there is no CPU fallback). */
+int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *stream, cw_batch **out);
+void cw_batch_free(cw_batch *b);
+uint32_t cw_batch_size(const cw_batch *b);
+
+/* setInputSignal(h, i, val) (calcwit.cpp:77-97) for one instance; `name` is hashed with FNV-1a
+ * (calcwit.cpp:17-24).  val = canonical 32-byte little-endian value, reduced mod q by the caller. */
+int cw_set_input_signal(cw_batch *b, uint32_t instance, const char *name, uint32_t idx, const uint8_t val[32]);
+/* loadJson (main.cpp:243-286, value grammar json2FrElements :144-188, nesting qualify_input :221-241)
+ * for one instance from JSON text. */
+int cw_set_inputs_json(cw_batch *b, uint32_t instance, const char *json_text);
+/* Bulk: all instances at once, [batch][n_inputs][32] canonical LE values in main-input slot order
+ * (slot = cw_input_start() + k).  Marks every input of every instance as set. */
+int cw_set_inputs(cw_batch *b, const uint8_t *le32);
+/* Same, but `d_le32` is a DEVICE pointer (HBM-resident inputs; no host copy). */
+int cw_set_inputs_device(cw_batch *b, const void *d_le32);
+/* read back input k (slot cw_input_start()+k) of one instance as staged by the two per-signal setters */
+int cw_get_staged_input(cw_batch *b, uint32_t instance, uint32_t k, uint8_t out[32]);
+/* getRemaingInputsToBeSet() (calcwit.hpp:50-52) of one instance */
+int64_t cw_remaining_inputs(const cw_batch *b, uint32_t instance);
+
+/* run(ctx) (calcwit.cpp:6,71-75) for all instances: ingest + schedule evaluation, asynchronous on the
+ * batch's stream.  Fails with CW_ESTATE if some instance still has unset inputs (main.cpp:352-355). */
+int cw_run(cw_batch *b);
+/* A*w o B*w = C*w over the loaded .r1cs for all instances (second kernel of the north-star). */
+int cw_check_r1cs(cw_batch *b);
+int cw_sync(cw_batch *b);
+
+/* results (synchronise the stream first) */
+int cw_get_status(cw_batch *b, uint32_t *status /* [batch] */);
+/* getWitness(i) + Fr_toLongNormal for all witness positions (main.cpp:326-332): [n_witness][32] */
+int cw_get_witness(cw_batch *b, uint32_t instance, uint8_t *out);
+/* one signal of one instance (signalValues[slot]) */
+int cw_get_signal(cw_batch *b, uint32_t instance, uint32_t slot, uint8_t out[32]);
+/* writeBinWitness (main.cpp:288-334) */
+int cw_write_wtns(cw_batch *b, uint32_t instance, const char *path);
+/* first violated constraint per instance after cw_check_r1cs: [batch], 0xFFFFFFFF = none */
+int cw_get_r1cs_first_bad(cw_batch *b, uint32_t *row);
+
+/* raw device pointers for zero-copy consumers (provers): value table, layout in DESIGN.md */
+void *cw_device_values(cw_batch *b, uint64_t *n_bytes, uint32_t *padded_batch);
+
+/* ---- field micro-benchmark + unit-test hooks (Fr_* seam 2: bn128/fr.hpp:28-81) --------------------- */
+/* n lanes x iters dependent Montgomery multiplications on the device; out[i] = a[i]*b[i]^iters (raw
+ * Montgomery domain).  a,b,out: host [n][32].  ms: kernel time from HIP events. */
+int cw_fp_mul_bench(const uint8_t prime_le32[32], int device, uint32_t n, uint32_t iters, const uint8_t *a,
+                    const uint8_t *b, uint8_t *out, float *ms);
+/* Element-wise device evaluation of one schedule opcode (D_* numbering of cw_tape.h) on n operand
+ * pairs — the unit-test hook for the device field functions.  status[n] receives CW_ST_* bits. */
+int cw_fp_op(const uint8_t prime_le32[32], int device, uint32_t dop, uint32_t n, const uint8_t *a, const uint8_t *b,
+             const uint8_t *c, uint8_t *out, uint32_t *status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CIRCOM_AMD_H */

@@ -1,0 +1,158 @@
+"""CPU oracle: evaluate a flattened circuit's op list on Python ints (one instance at a time).
+
+TEST INFRASTRUCTURE ONLY.  Restates what the reference's emitted `<name>.cpp` does when `run(ctx)`
+executes: each op is the corresponding Fr_* call (compute_bucket.rs:315-341) with the
+semantics of oracle/field.py; COPY is Fr_copy (store_bucket.rs:641-643); ASSERT_EQ is the `===`
+run-time check (assert_bucket.rs:70-89), reported instead of aborting.
+Pure-Python loops: use for small cases only (the C oracle / oracle/_ref binary cover large ones).
+"""
+from __future__ import annotations
+
+from .field import Field, FieldError
+
+# operator numbering of circom_amd/opcodes.py (kept literal here so the oracle has no product import)
+COPY, ADD, SUB, MUL, DIV, IDIV, MOD, POW, NEG = range(9)
+SHL, SHR, BAND, BOR, BXOR, BNOT = range(9, 15)
+LT, GT, LEQ, GEQ, EQ, NEQ, LAND, LOR, LNOT = range(15, 24)
+SELECT, ASSERT_EQ, ASSERT_NZ, RUN = range(24, 28)
+K_SIG, K_TMP, K_CONST, K_NONE = 0, 1, 2, 3
+
+_BIN = {ADD: "add", SUB: "sub", MUL: "mul", DIV: "div", IDIV: "idiv", MOD: "mod", POW: "pow",
+        SHL: "shl", SHR: "shr", BAND: "band", BOR: "bor", BXOR: "bxor", LT: "lt", GT: "gt",
+        LEQ: "leq", GEQ: "geq", EQ: "eq", NEQ: "neq", LAND: "land", LOR: "lor"}
+_UN = {NEG: "neg", BNOT: "bnot", LNOT: "lnot"}
+
+
+def eval_flat(q: int, n_signals: int, n_temps: int, constants, code, inputs: dict):
+    """inputs: {signal slot: canonical value}.  Returns (signals list, failed_row or None)."""
+    f = Field(q)
+    sig = [0] * n_signals
+    sig[0] = 1
+    for k, v in inputs.items():
+        sig[k] = v % q
+    tmp = [0] * max(n_temps, 1)
+    op_, dk, dv = code["op"], code["dk"], code["dv"]
+    ak, av, bk, bv, ck, cv = code["ak"], code["av"], code["bk"], code["bv"], code["ck"], code["cv"]
+    bins = {k: getattr(f, v) for k, v in _BIN.items()}
+    uns = {k: getattr(f, v) for k, v in _UN.items()}
+
+    def rd(k, v):
+        if k == K_SIG:
+            return sig[v]
+        if k == K_TMP:
+            return tmp[v]
+        return constants[v]
+
+    failed = None
+    for i in range(len(op_)):
+        op = int(op_[i])
+        a = rd(int(ak[i]), int(av[i]))
+        if op in bins:
+            try:
+                r = bins[op](a, rd(int(bk[i]), int(bv[i])))
+            except FieldError:
+                if failed is None:
+                    failed = i
+                r = 0
+        elif op == COPY:
+            r = a
+        elif op in uns:
+            r = uns[op](a)
+        elif op == SELECT:
+            r = rd(int(bk[i]), int(bv[i])) if a != 0 else rd(int(ck[i]), int(cv[i]))
+        elif op == ASSERT_EQ:
+            if a != rd(int(bk[i]), int(bv[i])) and failed is None:
+                failed = i
+            continue
+        elif op == ASSERT_NZ:
+            if a == 0 and failed is None:
+                failed = i
+            continue
+        else:
+            raise ValueError("bad op %d" % op)
+        if dk[i] == K_SIG:
+            sig[int(dv[i])] = r
+        else:
+            tmp[int(dv[i])] = r
+    return sig, failed
+
+
+def check_r1cs(q: int, constraints, w) -> int | None:
+    """First violated constraint index of A*B - C = 0 over witness w (wire 0 = 1), else None."""
+    for i, (a, b, c) in enumerate(constraints):
+        va = sum(co * w[k] for k, co in a.items()) % q
+        vb = sum(co * w[k] for k, co in b.items()) % q
+        vc = sum(co * w[k] for k, co in c.items()) % q
+        if (va * vb - vc) % q:
+            return i
+    return None
+
+
+# ---- lowered (device) schedule: same row format the HIP kernel consumes ---------------------------------
+# D_* numbering of circom_amd/csrc/cw_tape.h
+(D_COPY, D_ADD, D_SUB, D_NEG, D_MMUL, D_INV, D_IDIV, D_MOD, D_POW, D_SHL, D_SHR, D_BAND, D_BOR, D_BXOR,
+ D_BNOT, D_LT, D_GT, D_LEQ, D_GEQ, D_EQ, D_NEQ, D_LAND, D_LOR, D_LNOT, D_SELECT, D_EXT, D_ASSERT_EQ,
+ D_ASSERT_NZ) = range(28)
+_DBIN = {D_ADD: "add", D_SUB: "sub", D_IDIV: "idiv", D_MOD: "mod", D_POW: "pow", D_SHL: "shl", D_SHR: "shr",
+         D_BAND: "band", D_BOR: "bor", D_BXOR: "bxor", D_LT: "lt", D_GT: "gt", D_LEQ: "leq", D_GEQ: "geq",
+         D_EQ: "eq", D_NEQ: "neq", D_LAND: "land", D_LOR: "lor"}
+_DUN = {D_NEG: "neg", D_BNOT: "bnot", D_LNOT: "lnot", D_INV: "inv"}
+
+
+def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict):
+    """Evaluate a lowered schedule (rows: (n,4) uint32 array as in the .cwt file) for one instance.
+    Returns (signal values, status) with status = 0 | 1 + (row << 8) like the kernel."""
+    f = Field(q)
+    sig = [0] * n_signals
+    sig[0] = 1
+    for k, v in inputs.items():
+        sig[k] = v % q
+    tmp = [0] * max(n_tslots, 1)
+    bins = {k: getattr(f, v) for k, v in _DBIN.items()}
+    uns = {k: getattr(f, v) for k, v in _DUN.items()}
+
+    def rd(k, v):
+        return sig[v] if k == 0 else (tmp[v] if k == 1 else consts[v])
+
+    status = 0
+    r = 0
+    n = len(rows)
+    while r < n:
+        w0, dst, a_, b_ = (int(x) for x in rows[r])
+        op, dk, ak, bk = w0 & 0xFF, (w0 >> 8) & 3, (w0 >> 10) & 3, (w0 >> 12) & 3
+        a = rd(ak, a_)
+        res = None
+        if op == D_MMUL:
+            res = f.mmul(a, rd(bk, b_))
+        elif op in bins:
+            try:
+                res = bins[op](a, rd(bk, b_))
+            except FieldError:
+                if status == 0:
+                    status = 2 | (r << 8)
+                res = 0
+        elif op == D_COPY:
+            res = a
+        elif op in uns:
+            res = uns[op](a)
+        elif op == D_SELECT:
+            b = rd(bk, b_)
+            r += 1
+            e0, _, ea, _ = (int(x) for x in rows[r])
+            c = rd((e0 >> 10) & 3, ea)
+            res = b if a != 0 else c
+        elif op == D_ASSERT_EQ:
+            if a != rd(bk, b_) and status == 0:
+                status = 1 | (r << 8)
+        elif op == D_ASSERT_NZ:
+            if a == 0 and status == 0:
+                status = 1 | (r << 8)
+        else:
+            raise ValueError("bad device op %d" % op)
+        if res is not None:
+            if dk == 0:
+                sig[dst] = res
+            else:
+                tmp[dst] = res
+        r += 1
+    return sig, status

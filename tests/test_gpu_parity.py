@@ -1,0 +1,208 @@
+"""GPU parity tests (run on a real MI355X through the C ABI): HIP path vs the CPU oracle, bit-exact."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from circom_amd import runtime as rt
+from circom_amd.compiler import compile_program
+from circom_amd.frontend.dsl import Program, template
+from circom_amd.circuits.basic import Multiplier2, BasicMain, IsZero, Num2Bits
+from circom_amd.circuits.poseidon import Poseidon
+from circom_amd.circuits.poseidon_constants import poseidon_hash
+from circom_amd.hip_elements import lower as L
+from circom_amd.hip_elements.writers import wtns_bytes
+from oracle.field import Field, PRIMES, FieldError
+from oracle.tape_eval import eval_flat, check_r1cs
+
+pytestmark = pytest.mark.gpu
+
+
+def _edges(f):
+    q = f.q
+    e = [0, 1, 2, 3, 31, 32, 33, 63, 64, 65, 127, 128, 253, 254, 255, 256, f.half, f.half + 1, f.half - 1, q - 1, q - 2,
+         (1 << 31) - 1, 1 << 31, (1 << 32) - 1, 1 << 32, 1 << 63, (1 << 64) - 1, 1 << 64, (1 << 128) - 1, 1 << 128,
+         q - (1 << 31), q - 253, q - 254, q - 255, q - 64, q - 32, q - 1 - (1 << 200), 1 << (f.bits - 1),
+         (1 << (f.bits - 1)) - 1, f.mask % q, (1 << 224) - 1, 1 << 224]
+    return [x % q for x in e]
+
+
+@pytest.mark.parametrize("prime", ["bn128", "bls12381"])
+def test_device_field_ops_match_oracle(prime):
+    f = Field(PRIMES[prime])
+    rng = random.Random(7)
+    edges = _edges(f)
+    rand = [rng.randrange(f.q) for _ in range(300)] + [rng.randrange(1 << 40) for _ in range(50)]
+    A = [a for a in edges for _ in edges] + [rng.choice(rand + edges) for _ in range(3000)]
+    B = [b for _ in edges for b in edges] + [rng.choice(rand + edges) for _ in range(3000)]
+    Cc = [rng.choice(rand + edges) for _ in A]
+    ops = {L.D_ADD: f.add, L.D_SUB: f.sub, L.D_MMUL: f.mmul, L.D_SHL: f.shl, L.D_SHR: f.shr, L.D_BAND: f.band,
+           L.D_BOR: f.bor, L.D_BXOR: f.bxor, L.D_LT: f.lt, L.D_GT: f.gt, L.D_LEQ: f.leq, L.D_GEQ: f.geq, L.D_EQ: f.eq,
+           L.D_NEQ: f.neq, L.D_LAND: f.land, L.D_LOR: f.lor, L.D_POW: f.pow}
+    for dop, fn in ops.items():
+        got, st = rt.fp_op(f.q, dop, A, B, Cc)
+        want = [fn(a, b) for a, b in zip(A, B)]
+        bad = [i for i in range(len(A)) if got[i] != want[i]]
+        assert not bad, (prime, L.D_NAMES[dop], hex(A[bad[0]]), hex(B[bad[0]]), hex(got[bad[0]]), hex(want[bad[0]]))
+    for dop, fn in {L.D_NEG: f.neg, L.D_BNOT: f.bnot, L.D_LNOT: f.lnot, L.D_INV: f.inv, L.D_COPY: lambda x: x}.items():
+        got, st = rt.fp_op(f.q, dop, A, B, Cc)
+        want = [fn(a) for a in A]
+        assert got == want, (prime, L.D_NAMES[dop])
+    for dop, fn in {L.D_IDIV: f.idiv, L.D_MOD: f.mod}.items():
+        got, st = rt.fp_op(f.q, dop, A, B, Cc)
+        for i, (a, b) in enumerate(zip(A, B)):
+            if b == 0:
+                assert st[i] == rt.ST_ARITH
+            else:
+                assert st[i] == 0 and got[i] == fn(a, b), (prime, L.D_NAMES[dop], hex(a), hex(b))
+    got, st = rt.fp_op(f.q, L.D_SELECT, A, B, Cc)
+    assert got == [b if a else c for a, b, c in zip(A, B, Cc)]
+    got, st = rt.fp_op(f.q, L.D_ASSERT_EQ, A, B, Cc)
+    assert list(st) == [0 if a == b else rt.ST_ASSERT_FAILED for a, b in zip(A, B)]
+
+
+def _compile(tmp_path, prog, name):
+    cp = compile_program(prog, str(tmp_path), name)
+    return cp, rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
+
+
+def _oracle(cp, inputs_by_slot):
+    fc = cp.flat
+    return eval_flat(fc.fp.q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inputs_by_slot)
+
+
+def test_multiplier2_docs_vector_and_random(tmp_path):
+    cp, c = _compile(tmp_path, Program(Multiplier2()), "multiplier2")
+    b = c.batch(1)
+    b.set_inputs_json(0, '{"a": "3", "b": "11"}')
+    b.run(); b.check_r1cs(); b.sync()
+    assert b.status()[0] == 0 and b.witness(0) == [1, 33, 3, 11]
+    p = tmp_path / "out.wtns"
+    b.write_wtns(0, p)
+    assert p.read_bytes() == wtns_bytes(c.q, [1, 33, 3, 11])
+    assert len(p.read_bytes()) == 204
+    b.close()
+    rng = np.random.default_rng(0)
+    n = 1000
+    ins = [[int.from_bytes(rng.bytes(32), "little") % c.q for _ in range(2)] for _ in range(n)]
+    b = c.batch(n)
+    b.set_inputs(ins)
+    b.run(); b.check_r1cs(); b.sync()
+    assert (b.status() == 0).all()
+    for i in range(0, n, 37):
+        assert b.witness(i) == [1, ins[i][0] * ins[i][1] % c.q, ins[i][0], ins[i][1]]
+    b.close(); c.close()
+
+
+def test_basic_main_golden_and_json_forms(tmp_path):
+    cp, c = _compile(tmp_path, Program(BasicMain()), "basic")
+    b = c.batch(3)
+    b.set_inputs_json(0, '{"in": ["5", "7"]}')
+    b.set_inputs_json(1, '{"in": ["0x10", "0b101"]}')
+    b.set_input_signal(2, "in", 1, 9)
+    b.set_input_signal(2, "in", 0, c.q - 1)
+    b.run(); b.check_r1cs(); b.sync()
+    assert (b.status() == 0).all()
+    for i, (x, y) in enumerate([(5, 7), (16, 5), (c.q - 1, 9)]):
+        want, failed = _oracle(cp, {2: x, 3: y})
+        assert failed is None and b.witness(i) == want
+    b.close(); c.close()
+
+
+def test_poseidon2_batch_bit_exact(tmp_path):
+    cp, c = _compile(tmp_path, Program(Poseidon(2)), "poseidon2")
+    rng = np.random.default_rng(1)
+    n = 4096 + 37          # ragged: not a multiple of the block size
+    ins = [[int.from_bytes(rng.bytes(32), "little") % c.q for _ in range(2)] for _ in range(n)]
+    ins[0] = [1, 2]
+    ins[1] = [0, 0]
+    ins[2] = [c.q - 1, c.q - 1]
+    b = c.batch(n)
+    b.set_inputs(ins)
+    b.run(); b.check_r1cs(); b.sync()
+    assert (b.status() == 0).all()
+    assert b.signal(0, 1) == 7853200120776062878684798364095072458815029376092732009249414926327459813530
+    # every instance: hash output vs the plain-integer Poseidon
+    for i in range(0, n, 16):
+        assert b.signal(i, 1) == poseidon_hash(c.q, ins[i]), i
+    # sampled instances: the whole witness, byte for byte
+    for i in (0, 1, 2, 255, 256, 4095, 4096, n - 1):
+        want, failed = _oracle(cp, {2: ins[i][0], 3: ins[i][1]})
+        assert failed is None
+        assert b.witness_bytes(i) == b"".join(v.to_bytes(32, "little") for v in want), i
+        assert check_r1cs(c.q, cp.flat.constraints, want) is None
+    b.close(); c.close()
+
+
+def test_asserts_and_slow_path_ops(tmp_path):
+    # Num2Bits(8): in < 256 passes, in >= 256 trips `lc1 === in`; IsZero exercises select + div (INV)
+    cp, c = _compile(tmp_path, Program(Num2Bits(8)), "n2b")
+    vals = [0, 1, 255, 256, 1000, c.q - 1, 170]
+    b = c.batch(len(vals))
+    b.set_inputs([[v] for v in vals])
+    b.run(); b.check_r1cs(); b.sync()
+    st = b.status()
+    for i, v in enumerate(vals):
+        want, failed = _oracle(cp, {cp.flat.main_input_start: v})
+        if failed is None:
+            assert st[i] == 0 and b.witness(i) == want
+        else:
+            assert st[i] & rt.ST_ASSERT_FAILED and st[i] & rt.ST_R1CS_FAILED, (v, st[i])
+    b.close(); c.close()
+    cp, c = _compile(tmp_path, Program(IsZero()), "iszero")
+    vals = [0, 1, 2, c.q - 1, 12345678901234567890]
+    b = c.batch(len(vals))
+    b.set_inputs([[v] for v in vals])
+    b.run(); b.check_r1cs(); b.sync()
+    assert (b.status() == 0).all()
+    for i, v in enumerate(vals):
+        want, failed = _oracle(cp, {2: v})
+        assert b.witness(i) == want and want[1] == int(v == 0)
+    b.close(); c.close()
+
+
+@template
+def BadMul(c):
+    a = c.input("a")
+    b = c.input("b")
+    out = c.output("out")
+    c.hint(out, a * b + 1)                      # witness code disagrees with the constraint
+    c.enforce(out, a * b, runtime_check=False)  # constraint only (no run-time assert)
+
+
+def test_r1cs_check_flags_a_corrupted_witness(tmp_path):
+    cp, c = _compile(tmp_path, Program(BadMul()), "badmul")
+    b = c.batch(300)
+    b.set_inputs([[i + 1, i + 2] for i in range(300)])
+    b.run(); b.check_r1cs(); b.sync()
+    st = b.status()
+    assert ((st & rt.ST_R1CS_FAILED) != 0).all() and ((st & rt.ST_ASSERT_FAILED) == 0).all()
+    assert (b.r1cs_first_bad() == 0).all()
+    b.close(); c.close()
+
+
+def test_run_refuses_missing_inputs(tmp_path):
+    cp, c = _compile(tmp_path, Program(Multiplier2()), "m2")
+    b = c.batch(2)
+    b.set_inputs_json(0, '{"a": 1, "b": 2}')
+    with pytest.raises(rt.CwError) as e:
+        b.run()
+    assert "Not all inputs have been set" in str(e.value)
+    b.close(); c.close()
+
+
+@pytest.mark.parametrize("prime", ["bn128", "bls12381"])
+def test_fp_mul_chain_matches_oracle(prime):
+    f = Field(PRIMES[prime])
+    rng = np.random.default_rng(5)
+    n, iters = 4096, 64
+    a = np.frombuffer(b"".join((int.from_bytes(rng.bytes(32), "little") % f.q).to_bytes(32, "little") for _ in range(n)), dtype=np.uint8).reshape(n, 32).copy()
+    bb = np.frombuffer(b"".join((int.from_bytes(rng.bytes(32), "little") % f.q).to_bytes(32, "little") for _ in range(n)), dtype=np.uint8).reshape(n, 32).copy()
+    out, ms = rt.fp_mul_bench(f.q, a, bb, iters)
+    for i in range(0, n, 97):
+        x = int.from_bytes(a[i].tobytes(), "little")
+        y = int.from_bytes(bb[i].tobytes(), "little")
+        for _ in range(iters):
+            x = f.mmul(x, y)
+        assert int.from_bytes(out[i].tobytes(), "little") == x
