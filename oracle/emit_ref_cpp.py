@@ -1,0 +1,183 @@
+"""Emit a reference-style `<name>.cpp` for a traced circuit so that the *reference's own C++ runtime*
+(main.cpp / calcwit.cpp / generic fr.cpp, compiled by oracle/Makefile) computes the witness.
+
+TEST INFRASTRUCTURE ONLY.  The Rust compiler that normally emits this file cannot be built here; this is
+a restatement of its emission rules (SURVEY Appendix A derives them):
+  prologue + get_*() table ......... compiler/src/circuit_design/circuit.rs:420-493
+  <T>_<id>_create .................. circuit_design/template.rs:177-279
+  <T>_<id>_run ..................... circuit_design/template.rs:281-472 (sub-components created at the top,
+                                     translate.rs:1960; children in sorted order)
+  Store / sub-component trigger .... intermediate_representation/store_bucket.rs:442-851
+  Compute -> Fr_* .................. compute_bucket.rs:315-341
+  Assert ........................... assert_bucket.rs:70-89
+  run() ............................ circuit.rs:526-561
+Differences (do not change computed values): loops are already unrolled by the trace, so bodies are
+straight-line; long bodies are split into chunk functions to keep g++ compile time linear.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+
+# operator numbering of circom_amd/opcodes.py (literal: the oracle has no product import)
+COPY, ADD, SUB, MUL, DIV, IDIV, MOD, POW, NEG = range(9)
+SHL, SHR, BAND, BOR, BXOR, BNOT = range(9, 15)
+LT, GT, LEQ, GEQ, EQ, NEQ, LAND, LOR, LNOT = range(15, 24)
+SELECT, ASSERT_EQ, ASSERT_NZ, RUN = range(24, 28)
+K_SIG, K_TMP, K_CONST, K_NONE = 0, 1, 2, 3
+SYM = {ADD: "Fr_add", SUB: "Fr_sub", MUL: "Fr_mul", DIV: "Fr_div", IDIV: "Fr_idiv", MOD: "Fr_mod", POW: "Fr_pow",
+       SHL: "Fr_shl", SHR: "Fr_shr", BAND: "Fr_band", BOR: "Fr_bor", BXOR: "Fr_bxor", LT: "Fr_lt", GT: "Fr_gt",
+       LEQ: "Fr_leq", GEQ: "Fr_geq", EQ: "Fr_eq", NEQ: "Fr_neq", LAND: "Fr_land", LOR: "Fr_lor"}
+SYM1 = {NEG: "Fr_neg", BNOT: "Fr_bnot", LNOT: "Fr_lnot", COPY: "Fr_copy"}
+
+CHUNK = 1500
+ARGS_DECL = "Circom_CalcWit* ctx, FrElement* signalValues, FrElement* circuitConstants, FrElement* expaux, u64 mySignalStart, u32* mySubcomponents, u64 myId"
+ARGS_CALL = "ctx, signalValues, circuitConstants, expaux, mySignalStart, mySubcomponents, myId"
+
+
+def _child_of(inst, off):
+    """(child index in sorted table, offset inside the child) for a subtree offset >= n_local."""
+    ch = inst.children
+    lo, hi = 0, len(ch) - 1
+    while lo < hi:
+        mid = (lo + hi + 1) // 2
+        if ch[mid][3] <= off:
+            lo = mid
+        else:
+            hi = mid - 1
+    return lo, off - ch[lo][3]
+
+
+def _ref(inst, k, v):
+    if k == K_SIG:
+        if v < inst.n_local:
+            return "&signalValues[mySignalStart + %d]" % v
+        ci, o = _child_of(inst, v)
+        return "&ctx->signalValues[ctx->componentMemory[mySubcomponents[%d]].signalStart + %d]" % (ci, o)
+    if k == K_TMP:
+        return "&expaux[%d]" % v
+    if k == K_CONST:
+        return "&circuitConstants[%d]" % v
+    raise ValueError(k)
+
+
+def _emit_instance(inst, out):
+    h = inst.header
+    code = inst.code
+    n = len(code["op"])
+    op = code["op"].tolist()
+    dk, dv = code["dk"].tolist(), code["dv"].tolist()
+    ak, av = code["ak"].tolist(), code["av"].tolist()
+    bk, bv = code["bk"].tolist(), code["bv"].tolist()
+    ck, cv = code["ck"].tolist(), code["cv"].tolist()
+    stmts = []
+    for i in range(n):
+        o = op[i]
+        if o == RUN:
+            ci = av[i]
+            child = inst.children[ci][2]
+            if child.n_in == 0:
+                continue        # ran at creation (template.rs:274-278)
+            stmts.append("assert(!(ctx->componentMemory[mySubcomponents[%d]].inputCounter)); %s_run(mySubcomponents[%d],ctx);"
+                         % (ci, child.header, ci))
+            continue
+        if o == ASSERT_EQ or o == ASSERT_NZ:
+            if o == ASSERT_EQ:
+                cond = "Fr_eq(&aux_assert,%s,%s);" % (_ref(inst, ak[i], av[i]), _ref(inst, bk[i], bv[i]))
+                test = "&aux_assert"
+            else:
+                cond = ""
+                test = _ref(inst, ak[i], av[i])
+            stmts.append("{ FrElement aux_assert; %s if (!Fr_isTrue(%s)) { std::cout << \"Failed assert in template/function \" "
+                         "<< \"%s\" << \" op %d\" << std::endl; std::cout << \"Followed trace of components: \" << "
+                         "ctx->getTrace(myId) << std::endl; assert(false); } }" % (cond, test, inst.name, i))
+            continue
+        dst = _ref(inst, dk[i], dv[i])
+        if o in SYM:
+            s = "%s(%s,%s,%s);" % (SYM[o], dst, _ref(inst, ak[i], av[i]), _ref(inst, bk[i], bv[i]))
+        elif o in SYM1:
+            s = "%s(%s,%s);" % (SYM1[o], dst, _ref(inst, ak[i], av[i]))
+        elif o == SELECT:
+            s = "if (Fr_isTrue(%s)) { Fr_copy(%s,%s); } else { Fr_copy(%s,%s); }" % (
+                _ref(inst, ak[i], av[i]), dst, _ref(inst, bk[i], bv[i]), dst, _ref(inst, ck[i], cv[i]))
+        else:
+            raise ValueError("op %d" % o)
+        if dk[i] == K_SIG and dv[i] >= inst.n_local:
+            ci, _ = _child_of(inst, dv[i])
+            s += " ctx->componentMemory[mySubcomponents[%d]].inputCounter -= 1;" % ci   # store_bucket.rs:663-670
+        stmts.append(s)
+
+    nsub = len(inst.children)
+    # ---- create (template.rs:177-279) ----
+    out.append("void %s_create(uint soffset,uint coffset,Circom_CalcWit* ctx,std::string componentName,uint componentFather){" % h)
+    out.append("ctx->componentMemory[coffset].templateId = %d;" % inst.id)
+    out.append("ctx->componentMemory[coffset].templateName = \"%s\";" % inst.name)
+    out.append("ctx->componentMemory[coffset].signalStart = soffset;")
+    out.append("ctx->componentMemory[coffset].inputCounter = %d;" % inst.n_in)
+    out.append("ctx->componentMemory[coffset].componentName = componentName;")
+    out.append("ctx->componentMemory[coffset].idFather = componentFather;")
+    out.append("ctx->componentMemory[coffset].subcomponents = new uint[%d]%s;" % (nsub, "{0}" if nsub else ""))
+    if inst.n_in == 0:
+        out.append("%s_run(coffset,ctx);" % h)
+    out.append("}")
+    # ---- body chunks ----
+    chunks = [stmts[i:i + CHUNK] for i in range(0, len(stmts), CHUNK)] or [[]]
+    for ci, ch in enumerate(chunks):
+        out.append("static void %s_body%d(%s){" % (h, ci, ARGS_DECL))
+        out.extend(ch)
+        out.append("}")
+    # ---- run (template.rs:281-472) ----
+    out.append("void %s_run(uint ctx_index,Circom_CalcWit* ctx){" % h)
+    out.append("FrElement* circuitConstants = ctx->circuitConstants;")
+    out.append("FrElement* signalValues = ctx->signalValues;")
+    out.append("std::vector<FrElement> expaux_v(%d);" % max(inst.n_temps, 1))
+    out.append("FrElement* expaux = expaux_v.data();")
+    out.append("u64 mySignalStart = ctx->componentMemory[ctx_index].signalStart;")
+    out.append("u64 myId = ctx_index;")
+    out.append("u32* mySubcomponents = ctx->componentMemory[ctx_index].subcomponents;")
+    for k, (cname, cidx, cinst, soff, coff) in enumerate(inst.children):
+        nm = cname + "".join("[%d]" % i for i in cidx)
+        out.append("mySubcomponents[%d] = ctx_index + %d; %s_create(mySignalStart + %d, ctx_index + %d, ctx, \"%s\", myId);"
+                   % (k, coff, cinst.header, soff, coff, nm))
+    for ci in range(len(chunks)):
+        out.append("%s_body%d(%s);" % (h, ci, ARGS_CALL))
+    out.append("for (uint i = 0; i < %d; i++){" % nsub)
+    out.append("uint index_subc = ctx->componentMemory[ctx_index].subcomponents[i];")
+    out.append("if (index_subc != 0){ assert(!(ctx->componentMemory[index_subc].inputCounter)); release_memory_component(ctx,index_subc); }")
+    out.append("}")
+    out.append("}")
+
+
+def emit(fc, path, hashmap_size: int):
+    """fc: circom_amd FlatCircuit (duck-typed: .prog.inst_list, .prog.main, sizes)."""
+    prog = fc.prog
+    insts = prog.inst_list
+    out = ["#include <stdio.h>", "#include <iostream>", "#include <vector>", "#include <assert.h>",
+           "#include \"circom.hpp\"", "#include \"calcwit.hpp\""]
+    for t in insts:
+        out.append("void %s_create(uint soffset,uint coffset,Circom_CalcWit* ctx,std::string componentName,uint componentFather);" % t.header)
+        out.append("void %s_run(uint ctx_index,Circom_CalcWit* ctx);" % t.header)
+    out.append("Circom_TemplateFunction _functionTable[%d] = { %s };" % (len(insts), ", ".join(t.header + "_run" for t in insts)))
+    out.append("Circom_TemplateFunction _functionTableParallel[%d] = { %s };" % (len(insts), ", ".join("NULL" for _ in insts)))
+    m = prog.main
+    out.append("uint get_main_input_signal_start() {return %d;}" % fc.main_input_start)
+    out.append("uint get_main_input_signal_no() {return %d;}" % fc.n_main_inputs)
+    out.append("uint get_total_signal_no() {return %d;}" % fc.n_signals)
+    out.append("uint get_number_of_components() {return %d;}" % fc.n_components)
+    out.append("uint get_size_of_input_hashmap() {return %d;}" % hashmap_size)
+    out.append("uint get_size_of_witness() {return %d;}" % fc.n_signals)
+    out.append("uint get_size_of_constants() {return %d;}" % len(fc.constants))
+    out.append("uint get_size_of_io_map() {return 0;}")
+    out.append("uint get_size_of_bus_field_map() {return 0;}")
+    # generate_function_release_memory_component, c_code_generator.rs:914-933
+    out.append("void release_memory_component(Circom_CalcWit* ctx, uint pos) {{ if (pos != 0){{ if(ctx->componentMemory[pos].subcomponents) "
+               "delete []ctx->componentMemory[pos].subcomponents; ctx->componentMemory[pos].subcomponents = NULL; }} }}")
+    out.append("// function declarations")
+    out.append("// template declarations")
+    for t in insts:
+        _emit_instance(t, out)
+    out.append("void run(Circom_CalcWit* ctx){")
+    out.append("%s_create(1,0,ctx,\"main\",0);" % m.header)
+    if m.n_in > 0:
+        out.append("%s_run(0,ctx);" % m.header)
+    out.append("}")
+    Path(path).write_text("\n".join(out) + "\n")

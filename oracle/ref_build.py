@@ -1,0 +1,144 @@
+"""Build and drive the reference-derived oracle binaries (TEST INFRASTRUCTURE ONLY).
+
+For a compiled circuit (circom_amd.compiler.Compiled) this module
+  * emits the reference-style <name>.cpp (emit_ref_cpp.py) + copies the .dat next to it under
+    oracle/_ref/<prime>/, and compiles `<name>` (the reference's main.cpp CLI: `./name in.json out.wtns`)
+    and `<name>_loop` (oracle/ref_loop.cpp) with oracle/Makefile — only possible where the reference tree
+    is present; the GPU box uses the prebuilt binaries that travel inside oracle/_ref/,
+  * runs them to produce .wtns files / timings.
+"""
+from __future__ import annotations
+
+import json
+import os
+import shutil
+import subprocess
+import tempfile
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+REF_ROOT = Path(os.environ.get("CIRCOM_REF", "/root/reference"))
+
+
+def ref_dir(prime: str) -> Path:
+    return ROOT / "_ref" / prime
+
+
+def binaries(prime: str, name: str):
+    d = ref_dir(prime)
+    return d / name, d / (name + "_loop")
+
+
+def build_circuit(cp, force=False):
+    """cp: Compiled.  Returns (cli_binary, loop_binary) or raises if it cannot be built."""
+    from . import emit_ref_cpp
+    from circom_amd.hip_elements.writers import hashmap_size
+    prime = cp.flat.prime
+    d = ref_dir(prime)
+    cli, loop = binaries(prime, cp.name)
+    names = d / (cp.name + ".names")
+    if cli.exists() and loop.exists() and names.exists() and not force:
+        return cli, loop
+    if not REF_ROOT.exists():
+        raise RuntimeError("oracle/_ref/%s/%s is not prebuilt and the reference tree is absent" % (prime, cp.name))
+    d.mkdir(parents=True, exist_ok=True)
+    emit_ref_cpp.emit(cp.flat, d / (cp.name + ".cpp"), hashmap_size(len(cp.flat.inputs)))
+    shutil.copyfile(cp.dat_path, d / (cp.name + ".dat"))
+    shutil.copyfile(cp.dat_path, d / (cp.name + "_loop.dat"))
+    names.write_text("".join("%s %d\n" % (n, sz) for n, _, sz in cp.flat.inputs))
+    for target in ("circuit", "loop"):
+        subprocess.run(["make", "-C", str(ROOT), target, "PRIME=" + prime, "NAME=" + cp.name, "REF=" + str(REF_ROOT)],
+                       check=True, capture_output=True)
+    return cli, loop
+
+
+def run_cli(cp, input_json: str, out_wtns: Path):
+    """The reference CLI exactly as a user runs it (main.cpp:336-373)."""
+    cli, _ = binaries(cp.flat.prime, cp.name)
+    with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+        f.write(input_json)
+        p = f.name
+    try:
+        r = subprocess.run([str(cli), p, str(out_wtns)], capture_output=True, text=True)
+    finally:
+        os.unlink(p)
+    return r
+
+
+def run_loop(cp, inputs_bytes: bytes, n: int, reps: int = 1, wtns_prefix: str = "", stride: int = 1, procs: int = 1):
+    """inputs_bytes: [n][n_inputs][32].  Returns the parsed JSON of each process."""
+    prime = cp.flat.prime
+    _, loop = binaries(prime, cp.name)
+    d = ref_dir(prime)
+    with tempfile.TemporaryDirectory() as td:
+        per = (n + procs - 1) // procs
+        n_in = cp.flat.n_main_inputs
+        ps = []
+        for k in range(procs):
+            lo, hi = k * per, min(n, (k + 1) * per)
+            if lo >= hi:
+                break
+            fn = os.path.join(td, "in%d.bin" % k)
+            with open(fn, "wb") as f:
+                f.write(inputs_bytes[lo * n_in * 32:hi * n_in * 32])
+            cmd = [str(loop), str(d / (cp.name + "_loop.dat")), fn, str(d / (cp.name + ".names")), str(hi - lo), str(reps)]
+            if wtns_prefix:
+                cmd += [wtns_prefix if procs == 1 else wtns_prefix + "p%d_" % k, str(stride)]
+            ps.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        outs = []
+        for p in ps:
+            o, e = p.communicate()
+            if p.returncode != 0:
+                raise RuntimeError("ref_loop failed (rc=%d): %s" % (p.returncode, e[-500:]))
+            outs.append(json.loads(o.strip().splitlines()[-1]))
+    return outs
+
+
+def time_reference(cp, workload: str, seconds_budget: float = 15.0):
+    """cpu_baseline for bench.py: reference runtime + reference generic (no-asm, GMP) field library,
+    compute-only loop, one process per host core, bounded sample."""
+    import numpy as np
+    cli, loop = binaries(cp.flat.prime, cp.name)
+    if not (loop.exists()):
+        build_circuit(cp)
+    cores = os.cpu_count() or 1
+    q = cp.flat.fp.q
+    n_in = cp.flat.n_main_inputs
+    rng = np.random.default_rng(1)
+    def gen(n):
+        if workload.startswith("sha256"):
+            arr = np.zeros((n, n_in, 32), dtype=np.uint8)
+            arr[:, :, 0] = rng.integers(0, 2, size=(n, n_in), dtype=np.uint8)
+            return arr.tobytes()
+        vals = [int.from_bytes(rng.bytes(32), "little") % q for _ in range(n * n_in)]
+        return b"".join(v.to_bytes(32, "little") for v in vals)
+    # calibrate on one core, then size the sample to ~seconds_budget/2 of wall time on all cores
+    n0 = 8
+    t = run_loop(cp, gen(n0), n0, 1)[0]
+    per = t["seconds"] / n0
+    n_per_core = max(4, int(seconds_budget * 0.5 / max(per, 1e-6)))
+    n_per_core = min(n_per_core, 20000)
+    n = n_per_core * cores
+    t0 = time.perf_counter()
+    outs = run_loop(cp, gen(n_per_core) * cores, n, 1, procs=cores)
+    wall = time.perf_counter() - t0
+    agg = sum(o["witnesses_per_s"] for o in outs)
+    return {"value": agg, "unit": "witnesses/s", "cores": cores, "kind": "reference",
+            "per_core": agg / cores,
+            "sample": "%d instances (%d per core x %d cores) of %s through the reference C++ runtime "
+                      "(common/calcwit.cpp + generic/fr.cpp --no_asm GMP build), compute-only in-process loop, "
+                      "wall %.1f s" % (n, n_per_core, cores, workload, wall)}
+
+
+def build_default_circuits():
+    """Called from __graft_entry__.build(): prebuild the oracle binaries the GPU-side tests/bench use."""
+    import tempfile as _t
+    from circom_amd.compiler import compile_program
+    from circom_amd.frontend.dsl import Program
+    from circom_amd.circuits.basic import Multiplier2
+    from circom_amd.circuits.poseidon import Poseidon
+    d = _t.mkdtemp(prefix="cw_refbuild_")
+    for name, prog in (("multiplier2", Program(Multiplier2())), ("poseidon2", Program(Poseidon(2)))):
+        cp = compile_program(prog, d, name, sym=False)
+        build_circuit(cp)
