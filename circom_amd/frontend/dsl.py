@@ -191,7 +191,11 @@ class Expr:
     def __and__(self, o): return self._bin(O.BAND, o)
     def __rand__(self, o): return self._bin(O.BAND, o, True)
     def __or__(self, o): return self._bin(O.BOR, o)
+    def __ror__(self, o): return self._bin(O.BOR, o, True)
     def __xor__(self, o): return self._bin(O.BXOR, o)
+    def __rxor__(self, o): return self._bin(O.BXOR, o, True)
+    def __rlshift__(self, o): return self._bin(O.SHL, o, True)
+    def __rrshift__(self, o): return self._bin(O.SHR, o, True)
     def __neg__(self): return self.ctx.emit1(O.NEG, self)
     def __invert__(self): return self.ctx.emit1(O.BNOT, self)
     # relational operators are methods (Python's rich comparisons must return bool for dict keys etc.)

@@ -139,6 +139,8 @@ def build_default_circuits():
     from circom_amd.circuits.basic import Multiplier2
     from circom_amd.circuits.poseidon import Poseidon
     d = _t.mkdtemp(prefix="cw_refbuild_")
-    for name, prog in (("multiplier2", Program(Multiplier2())), ("poseidon2", Program(Poseidon(2)))):
+    from circom_amd.circuits.sha256 import Sha256
+    for name, prog in (("multiplier2", Program(Multiplier2())), ("poseidon2", Program(Poseidon(2))),
+                       ("sha256_512", Program(Sha256(512)))):
         cp = compile_program(prog, d, name, sym=False)
         build_circuit(cp)
