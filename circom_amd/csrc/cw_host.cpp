@@ -151,17 +151,23 @@ static FpParams make_params(const U256 &q) {
     for (int i = 0; i < 4; i++) half.w[i] = (q.w[i] >> 1) | (i < 3 ? (q.w[i + 1] << 63) : 0);
     memcpy(P.half, half.w, 32);
     U256 one{{1, 0, 0, 0}};
-    U256 r1 = shlmod(one, 256, q);      // R mod q
-    U256 r2 = shlmod(r1, 256, q);       // R^2 mod q
+    U256 r1 = shlmod(one, CW_RBITS, q);      // R' mod q
+    U256 r2 = shlmod(r1, CW_RBITS, q);       // R'^2 mod q
     memcpy(P.one_m, r1.w, 32);
     memcpy(P.r2, r2.w, 32);
     U256 two{{2, 0, 0, 0}}, qm2;
     u256_sub(qm2, q, two);
     memcpy(P.qm2, qm2.w, 32);
-    // np = -q^-1 mod 2^32 by Newton iteration
+    // np29 = -q^-1 mod 2^29 by Newton iteration
     uint32_t q0 = (uint32_t)q.w[0], inv = 1;
     for (int i = 0; i < 5; i++) inv *= 2 - q0 * inv;
-    P.np = (uint32_t)(0u - inv);
+    P.np29 = (uint32_t)(0u - inv) & 0x1FFFFFFFu;
+    for (int k = 0; k < 9; k++) {
+        unsigned bit = 29 * k, w = bit / 64, sh = bit % 64;
+        uint64_t v = q.w[w] >> sh;
+        if (sh > 35 && w + 1 < 4) v |= q.w[w + 1] << (64 - sh);
+        P.q29[k] = (uint32_t)(v & 0x1FFFFFFFu);
+    }
     P.qbits = u256_bits(q);
     unsigned topbits = P.qbits - 224;             // bits used in the top 32-bit limb
     P.topmask = topbits >= 32 ? 0xFFFFFFFFu : ((1u << topbits) - 1);
@@ -361,7 +367,7 @@ static int load_r1cs(cw_circuit *c, const char *path) {
                     auto it = cid.find(key);
                     if (it == cid.end()) {
                         id = (uint32_t)(c->r_ctab.size() / 8);
-                        U256 cm = shlmod(co, 256, c->q);
+                        U256 cm = shlmod(co, CW_RBITS, c->q);
                         uint32_t limbs[8];
                         memcpy(limbs, cm.w, 32);
                         c->r_ctab.insert(c->r_ctab.end(), limbs, limbs + 8);

@@ -222,7 +222,10 @@ cw_mulbench_kernel(const uint4 *__restrict__ a, const uint4 *__restrict__ b, uin
     uint32_t i = blockIdx.x * CW_BLOCK + threadIdx.x;
     if (i >= n) return;
     fe x = aos_load(a, i), y = aos_load(b, i);   // AoS operands: element i = uint4[2i], uint4[2i+1]
-    for (uint32_t k = 0; k < iters; k++) x = fe_mmul(x, y, P);
+    fe29 x29 = fe_to29(x);
+    const fe29 y29 = fe_to29(y);
+    for (uint32_t k = 0; k < iters; k++) x29 = fe29_mmul(x29, y29, P);
+    x = fe_from29(x29);
     out[2 * (size_t)i] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
     out[2 * (size_t)i + 1] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
 }

@@ -20,16 +20,19 @@ struct CwRow {       // 16 bytes, read with one scalar dwordx4 load
 };
 
 // Field parameters, passed by value as a kernel argument (lands in SGPRs).
+// The device Montgomery radix is R' = 2^261 (9 limbs x 29 bits, see fp256.hip.h), NOT the reference's
+// R = 2^256: which radix a residue is scaled by is private to the schedule (lower.py pre-scales constants).
+#define CW_RBITS 261
 struct FpParams {
     uint32_t q[8];      // modulus, little-endian 32-bit limbs
     uint32_t half[8];   // (q-1)/2 : val(x) = x - q iff x > half   (generic/fr.cpp:9)
-    uint32_t r2[8];     // R^2 mod q, R = 2^256                      (Fr_rawR2, generic/fr.cpp:14)
-    uint32_t one_m[8];  // R mod q  (1 in Montgomery form)
+    uint32_t r2[8];     // R'^2 mod q                                 (role of Fr_rawR2, generic/fr.cpp:14)
+    uint32_t one_m[8];  // R' mod q  (1 in Montgomery form)
     uint32_t qm2[8];    // q - 2 (Fermat exponent for INV)
-    uint32_t np;        // -q^-1 mod 2^32
+    uint32_t q29[9];    // modulus as 9 x 29-bit limbs
+    uint32_t np29;      // -q^-1 mod 2^29
     uint32_t qbits;     // bit length of q
     uint32_t topmask;   // mask of the top limb = lboMask >> 32     (generic/fr.cpp:16)
-    uint32_t pad;
 };
 
 #define CW_ST_ASSERT_FAILED 1u

@@ -1,10 +1,11 @@
 // fp256.hip.h — device arithmetic on 256-bit prime-field elements for gfx950 (CDNA4).
 //
 // The reference's native field library is x86-64 (`mulx/adcx/adox`, <prime>/fr.asm) or GMP mpn_*
-// (generic/fr.cpp:19-376).  CDNA4 has no 64x64 multiplier and no carry flags across lanes' 64-bit
-// ops, so the design is re-done for the VALU: elements are 8 x u32 limbs in VGPRs, products go
-// through v_mad_u64_u32 (32x32+64 -> 64), carry chains through v_add_co/v_addc_co.  One witness
-// instance per lane; the modulus and its constants are wave-uniform (SGPRs, struct FpParams).
+// (generic/fr.cpp:19-376).  CDNA4 has no 64x64 multiplier and no carry flag chained across
+// instructions for free, so the design is re-done for the VALU: stored elements are 8 x u32 limbs
+// (canonical, what .wtns wants); add/sub/bitwise/compare work on those directly; products switch to
+// 9 x 29-bit limbs with lazy carries so that every partial product is one v_mad_u64_u32 (see fe29_mmul).
+// One witness instance per lane; the modulus and its constants are wave-uniform (SGPRs, struct FpParams).
 //
 // Semantics follow generic/fr.cpp (cited per function); everything operates on raw residues in
 // [0,q): whether a residue is "canonical" or "Montgomery" is the schedule's business (lower.py).
@@ -130,45 +131,74 @@ __device__ __forceinline__ fe fe_neg(const fe &a, const FpParams &P) {
     return r;
 }
 
-// Montgomery product a*b*2^-256 mod q — Fr_rawMMul (generic/fr.cpp:110-164, <prime>/fr.asm:365).
-// CIOS over 8 x 32-bit limbs: 8 rounds of (t += a*b[i]; m = t0*np; t = (t + m*q) >> 32).
-// 64 + 64 + 8 multiplies; every multiply-accumulate is one v_mad_u64_u32.
-__device__ __forceinline__ fe fe_mmul(const fe &a, const fe &b, const FpParams &P) {
-    uint32_t t[9];
-    FE_UNROLL for (int i = 0; i < 9; i++) t[i] = 0;
-    FE_UNROLL for (int i = 0; i < 8; i++) {
-        uint64_t c = 0;
-        const uint32_t bi = b.v[i];
-        FE_UNROLL for (int j = 0; j < 8; j++) {
-            uint64_t p = (uint64_t)a.v[j] * bi + t[j] + c;
-            t[j] = (uint32_t)p;
-            c = p >> 32;
-        }
-        uint64_t s = (uint64_t)t[8] + c;
-        t[8] = (uint32_t)s;
-        uint32_t t9 = (uint32_t)(s >> 32);
-        const uint32_t m = t[0] * P.np;
-        c = ((uint64_t)m * P.q[0] + t[0]) >> 32;
-        FE_UNROLL for (int j = 1; j < 8; j++) {
-            uint64_t p = (uint64_t)m * P.q[j] + t[j] + c;
-            t[j - 1] = (uint32_t)p;
-            c = p >> 32;
-        }
-        s = (uint64_t)t[8] + c;
-        t[7] = (uint32_t)s;
-        t[8] = t9 + (uint32_t)(s >> 32);
+// ---- Montgomery product  a*b*R'^-1 mod q,  R' = 2^261 ------------------------------------------------
+// Role of Fr_rawMMul (generic/fr.cpp:110-164, <prime>/fr.asm:365), re-designed for the CDNA4 VALU.
+// Measured on gfx950 (tools/ubench_valu): v_mad_u64_u32 issues at ~the same rate as a plain 32-bit add,
+// so the cost of a multi-limb product is its INSTRUCTION COUNT, and carry handling (add_co/addc/mov
+// pairs) is what dominated a 8x32-bit CIOS (589 VALU instructions, only 136 of them multiplies).
+// Hence: 9 limbs of 29 bits with LAZY carries.  Every partial product is < 2^58 and each 64-bit column
+// accumulator takes at most 9 (a*b) + 9 (m*q) of them plus one carry (< 2^63): a column update is
+// exactly ONE v_mad_u64_u32 and carries are resolved once per row (shift+add) instead of per product.
+// The radix change (2^261 instead of the reference's 2^256) is invisible outside the schedule: slots
+// hold canonical residues, the lowering pre-scales constants by R' (hip_elements/lower.py).
+#define FE29_MASK 0x1FFFFFFFu
+struct fe29 { uint32_t l[9]; };
+
+__device__ __forceinline__ fe29 fe_to29(const fe &a) {
+    fe29 r;
+    FE_UNROLL for (int k = 0; k < 9; k++) {
+        const int bit = 29 * k, w = bit >> 5, sh = bit & 31;
+        uint32_t v;
+        if (sh == 0) v = a.v[w];
+        else if (w + 1 < 8) v = __builtin_amdgcn_alignbit(a.v[w + 1], a.v[w], sh);
+        else v = a.v[w] >> sh;
+        r.l[k] = v & FE29_MASK;
     }
-    // result < 2q; one conditional subtraction (carry limb t[8] can only be set if q > 2^255)
-    fe r, u;
-    int64_t br = 0;
-    FE_UNROLL for (int i = 0; i < 8; i++) {
-        int64_t d = (int64_t)t[i] - (int64_t)P.q[i] + br;
-        u.v[i] = (uint32_t)d;
-        br = d >> 32;
-    }
-    bool use_u = (t[8] != 0) | (br == 0);
-    FE_UNROLL for (int i = 0; i < 8; i++) r.v[i] = use_u ? u.v[i] : t[i];
     return r;
+}
+__device__ __forceinline__ fe fe_from29(const fe29 &a) {
+    fe r;
+    FE_UNROLL for (int w = 0; w < 8; w++) {
+        const int bit = 32 * w, k = bit / 29, o = bit - 29 * k;      // word w starts at bit o of limb k
+        uint32_t v = a.l[k] >> o;
+        v |= a.l[k + 1] << (29 - o);                                  // o <= 21: two limbs always cover the word
+        r.v[w] = v;
+    }
+    return r;
+}
+
+// operands and result as 29-bit limbs, all < q
+__device__ __forceinline__ fe29 fe29_mmul(const fe29 &a, const fe29 &b, const FpParams &P) {
+    uint64_t acc[18];
+    FE_UNROLL for (int i = 0; i < 18; i++) acc[i] = 0;
+    FE_UNROLL for (int i = 0; i < 9; i++) {
+        const uint32_t bi = b.l[i];
+        FE_UNROLL for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)a.l[j] * bi;
+        const uint32_t m = ((uint32_t)acc[i] * P.np29) & FE29_MASK;
+        FE_UNROLL for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)m * P.q29[j];
+        acc[i + 1] += acc[i] >> 29;                                   // low 29 bits of acc[i] are now zero
+    }
+    // normalise columns 9..17 into limbs, then one conditional subtraction of q (result < 2q)
+    fe29 r;
+    uint64_t c = 0;
+    FE_UNROLL for (int k = 0; k < 9; k++) {
+        c += acc[9 + k];
+        r.l[k] = (uint32_t)c & FE29_MASK;
+        c >>= 29;
+    }
+    fe29 d;
+    int32_t br = 0;
+    FE_UNROLL for (int k = 0; k < 9; k++) {
+        int32_t t = (int32_t)r.l[k] - (int32_t)P.q29[k] + br;
+        d.l[k] = (uint32_t)t & FE29_MASK;
+        br = t >> 31;
+    }
+    FE_UNROLL for (int k = 0; k < 9; k++) r.l[k] = br ? r.l[k] : d.l[k];
+    return r;
+}
+
+__device__ __forceinline__ fe fe_mmul(const fe &a, const fe &b, const FpParams &P) {
+    return fe_from29(fe29_mmul(fe_to29(a), fe_to29(b), P));
 }
 
 // ---- bitwise operators on canonical values (Fr_rawAnd/Or/Xor/Not, generic/fr.cpp:293-327,366-376) ----
@@ -275,28 +305,28 @@ __device__ __forceinline__ bool fe_lt(const fe &x, const fe &y, const FpParams &
 // x^e for a wave-uniform exponent e (8 limbs), x canonical -> canonical.  Used for INV = x^(q-2)
 // (mpz_invert semantics incl. inv(0) = 0: generic/fr.cpp:2895-2906).
 __device__ __noinline__ fe fe_pow_uniform(const fe &x, const uint32_t *e, const FpParams &P) {
-    fe xm = fe_mmul(x, fe_from(P.r2), P);        // to Montgomery
-    fe r = fe_from(P.one_m);
+    const fe29 xm = fe29_mmul(fe_to29(x), fe_to29(fe_from(P.r2)), P);      // to Montgomery
+    fe29 r = fe_to29(fe_from(P.one_m));
     for (int i = 255; i >= 0; i--) {
-        r = fe_mmul(r, r, P);
-        if ((e[i >> 5] >> (i & 31)) & 1) r = fe_mmul(r, xm, P);
+        r = fe29_mmul(r, r, P);
+        if ((e[i >> 5] >> (i & 31)) & 1) r = fe29_mmul(r, xm, P);
     }
-    return fe_mmul(r, fe_small(1), P);            // from Montgomery
+    return fe_from29(fe29_mmul(r, fe_to29(fe_small(1)), P));              // from Montgomery
 }
 // x^y with a per-lane exponent (Fr_pow / mpz_powm, generic/fr.cpp:2877-2893; 0^0 = 1)
 __device__ __noinline__ fe fe_pow(const fe &x, const fe &y, const FpParams &P) {
-    fe xm = fe_mmul(x, fe_from(P.r2), P);
-    fe r = fe_from(P.one_m);
+    const fe29 xm = fe29_mmul(fe_to29(x), fe_to29(fe_from(P.r2)), P);
+    fe29 r = fe_to29(fe_from(P.one_m));
     FE_UNROLL for (int w = 7; w >= 0; w--) {
         const uint32_t ew = y.v[w];
         for (int b = 31; b >= 0; b--) {
-            r = fe_mmul(r, r, P);
-            fe rx = fe_mmul(r, xm, P);
-            bool bit = (ew >> b) & 1;
-            FE_UNROLL for (int k = 0; k < 8; k++) r.v[k] = bit ? rx.v[k] : r.v[k];
+            r = fe29_mmul(r, r, P);
+            const fe29 rx = fe29_mmul(r, xm, P);
+            const bool bit = (ew >> b) & 1;
+            FE_UNROLL for (int k = 0; k < 9; k++) r.l[k] = bit ? rx.l[k] : r.l[k];
         }
     }
-    return fe_mmul(r, fe_small(1), P);
+    return fe_from29(fe29_mmul(r, fe_to29(fe_small(1)), P));
 }
 // floor(x / y), x mod y on canonical integers (Fr_idiv/Fr_mod via mpz_fdiv_q/r, generic/fr.cpp:2835-2875).
 // Restoring shift-subtract division; y == 0 is reported by the caller.

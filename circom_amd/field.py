@@ -39,6 +39,10 @@ class Fp:
         self.R = 1 << (64 * self.n64)
         self.Rinv = pow(self.R, -1, q)
         self.R2 = (self.R * self.R) % q
+        # device Montgomery radix R' = 2^261 (9 x 29-bit limbs, csrc/fp256.hip.h); only the schedule knows it
+        self.RDEV_BITS = 261
+        self.Rdev = (1 << self.RDEV_BITS) % q
+        self.Rdev2 = (self.Rdev * self.Rdev) % q
         # -q^-1 mod 2^32 / 2^64 (c_code_generator.rs:1093-1094 computes the 64-bit one)
         self.np64 = (-pow(q, -1, 1 << 64)) % (1 << 64)
         self.np32 = (-pow(q, -1, 1 << 32)) % (1 << 32)

@@ -59,6 +59,7 @@ class Tape:
         self.main_input_start = 0
         self.n_main_inputs = 0
         self.stats = {}
+        self.rbits = 261            # Montgomery radix exponent of MMUL rows
 
 
 def _dce(code, n_temps):
@@ -103,7 +104,7 @@ def lower(fc: FlatCircuit, witness_map=None) -> Tape:
             dconsts.append(v)
         return i
 
-    R, R2 = fp.R % q, fp.R2
+    R, R2 = fp.Rdev, fp.Rdev2        # device radix R' = 2^261
     # virtual temps: flat temp ids, plus fresh ones for expansion intermediates
     next_tmp = [fc.n_temps]
 

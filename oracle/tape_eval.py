@@ -99,10 +99,11 @@ _DBIN = {D_ADD: "add", D_SUB: "sub", D_IDIV: "idiv", D_MOD: "mod", D_POW: "pow",
 _DUN = {D_NEG: "neg", D_BNOT: "bnot", D_LNOT: "lnot", D_INV: "inv"}
 
 
-def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict):
+def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict, rbits: int = 261):
     """Evaluate a lowered schedule (rows: (n,4) uint32 array as in the .cwt file) for one instance.
     Returns (signal values, status) with status = 0 | 1 + (row << 8) like the kernel."""
     f = Field(q)
+    rinv = pow(1 << rbits, -1, q)        # MMUL = a*b*R'^-1 with the schedule's radix (device: R' = 2^261)
     sig = [0] * n_signals
     sig[0] = 1
     for k, v in inputs.items():
@@ -123,7 +124,7 @@ def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict)
         a = rd(ak, a_)
         res = None
         if op == D_MMUL:
-            res = f.mmul(a, rd(bk, b_))
+            res = a * rd(bk, b_) * rinv % q
         elif op in bins:
             try:
                 res = bins[op](a, rd(bk, b_))

@@ -37,7 +37,8 @@ def test_device_field_ops_match_oracle(prime):
     A = [a for a in edges for _ in edges] + [rng.choice(rand + edges) for _ in range(3000)]
     B = [b for _ in edges for b in edges] + [rng.choice(rand + edges) for _ in range(3000)]
     Cc = [rng.choice(rand + edges) for _ in A]
-    ops = {L.D_ADD: f.add, L.D_SUB: f.sub, L.D_MMUL: f.mmul, L.D_SHL: f.shl, L.D_SHR: f.shr, L.D_BAND: f.band,
+    rinv = pow(1 << 261, -1, f.q)          # device Montgomery radix R' = 2^261 (csrc/fp256.hip.h)
+    ops = {L.D_ADD: f.add, L.D_SUB: f.sub, L.D_MMUL: lambda a, b: a * b * rinv % f.q, L.D_SHL: f.shl, L.D_SHR: f.shr, L.D_BAND: f.band,
            L.D_BOR: f.bor, L.D_BXOR: f.bxor, L.D_LT: f.lt, L.D_GT: f.gt, L.D_LEQ: f.leq, L.D_GEQ: f.geq, L.D_EQ: f.eq,
            L.D_NEQ: f.neq, L.D_LAND: f.land, L.D_LOR: f.lor, L.D_POW: f.pow}
     for dop, fn in ops.items():
@@ -204,5 +205,5 @@ def test_fp_mul_chain_matches_oracle(prime):
         x = int.from_bytes(a[i].tobytes(), "little")
         y = int.from_bytes(bb[i].tobytes(), "little")
         for _ in range(iters):
-            x = f.mmul(x, y)
+            x = x * y * pow(1 << 261, -1, f.q) % f.q
         assert int.from_bytes(out[i].tobytes(), "little") == x
