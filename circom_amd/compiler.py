@@ -23,12 +23,17 @@ class Compiled:
     tape: Tape
 
 
-def compile_program(prog: Program, outdir: str, name: str, sym: bool = True) -> Compiled:
+DEFAULT_STRANDS = (1, 4, 16)
+
+
+def compile_program(prog: Program, outdir: str, name: str, sym: bool = True, strands=DEFAULT_STRANDS) -> Compiled:
+    """strands: strand counts to lower the schedule for (one variant each; the runtime picks per batch)."""
     os.makedirs(outdir, exist_ok=True)
     fc = flatten(prog)
-    tape = lower(fc)
+    tapes = [lower(fc, n_strands=s) for s in strands]
+    tape = tapes[0]
     p = lambda ext: os.path.join(outdir, name + ext)
-    writers.write_tape(p(".cwt"), tape)
+    writers.write_tape(p(".cwt"), tapes)
     writers.write_dat(p(".dat"), fc)
     writers.write_r1cs(p(".r1cs"), fc)
     if sym:

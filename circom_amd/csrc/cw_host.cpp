@@ -181,13 +181,19 @@ struct HashEntry {
     uint64_t hash, signalid, signalsize;   // HashSignalInfo, circom.hpp:17-21
 };
 
+struct Variant {               // one lowering of the schedule for a given strand count
+    uint32_t n_strands = 1, n_tslots = 0;
+    std::vector<CwRow> rows;
+    std::vector<uint32_t> stream_off;
+};
+
 struct cw_circuit {
     U256 q;
     FpParams P;
-    uint32_t n_signals = 0, n_tslots = 0, n_witness = 0, n_consts = 0, input_start = 0, n_inputs = 0;
+    uint32_t n_signals = 0, n_witness = 0, n_consts = 0, input_start = 0, n_inputs = 0;
     uint64_t n_rows = 0, n_mmul = 0;
     bool need_full = false;
-    std::vector<CwRow> rows;
+    std::vector<Variant> variants;
     std::vector<uint32_t> consts;          // n_consts * 8
     std::vector<uint32_t> w2s;
     std::vector<HashEntry> hashmap;
@@ -223,26 +229,22 @@ static int load_tape(cw_circuit *c, const char *path) {
     if (!read_file(path, b)) return fail(CW_EIO, std::string("tape file not found: ") + path);
     if (b.size() < 16 + 32 + 48 || memcmp(b.data(), "CWTP", 4)) return fail(CW_EIO, "bad tape magic");
     const uint32_t *h = (const uint32_t *)(b.data() + 4);
-    if (h[0] != 1) return fail(CW_EIO, "unsupported tape version");
+    if (h[0] != 2) return fail(CW_EIO, "unsupported tape version");
     if (h[1] != 4) return fail(CW_EIO, "only 4x64-bit primes are supported (bn128, bls12381, ...)");
+    uint32_t n_variants = h[2];
     size_t off = 16;
     memcpy(c->q.w, b.data() + off, 32);
     off += 32;
     const uint32_t *m = (const uint32_t *)(b.data() + off);
     off += 48;
     c->n_signals = m[0];
-    c->n_tslots = m[1];
-    c->n_witness = m[2];
-    c->n_consts = m[3];
-    c->n_rows = (uint64_t)m[4] | ((uint64_t)m[5] << 32);
-    c->input_start = m[6];
-    c->n_inputs = m[7];
-    uint32_t n_names = m[8], hsize = m[9];
-    size_t need = off + c->n_rows * 16 + (size_t)c->n_consts * 32 + (size_t)c->n_witness * 4;
-    if (b.size() < need) return fail(CW_EIO, "tape file truncated");
-    c->rows.resize(c->n_rows);
-    memcpy(c->rows.data(), b.data() + off, c->n_rows * 16);
-    off += c->n_rows * 16;
+    c->n_witness = m[1];
+    c->n_consts = m[2];
+    c->input_start = m[3];
+    c->n_inputs = m[4];
+    uint32_t n_names = m[5], hsize = m[6];
+    if (m[7] != CW_RBITS) return fail(CW_EIO, "tape was lowered for a different Montgomery radix");
+    if (b.size() < off + (size_t)c->n_consts * 32 + (size_t)c->n_witness * 4) return fail(CW_EIO, "tape file truncated");
     c->consts.resize((size_t)c->n_consts * 8);
     memcpy(c->consts.data(), b.data() + off, (size_t)c->n_consts * 32);
     off += (size_t)c->n_consts * 32;
@@ -262,6 +264,39 @@ static int load_tape(cw_circuit *c, const char *path) {
         off += 8;
         c->input_names[name] = {ss[0], ss[1]};
     }
+    if (n_variants == 0) return fail(CW_EIO, "tape holds no schedule");
+    for (uint32_t v = 0; v < n_variants; v++) {
+        if (off + 16 > b.size()) return fail(CW_EIO, "tape variant truncated");
+        uint32_t vh[4];
+        memcpy(vh, b.data() + off, 16);
+        off += 16;
+        Variant var;
+        var.n_strands = vh[0];
+        var.n_tslots = vh[1];
+        uint32_t nrows = vh[2];
+        if (var.n_strands == 0 || var.n_strands > 16) return fail(CW_EIO, "tape variant: bad strand count");
+        size_t need = (size_t)(var.n_strands + 1) * 4 + (size_t)nrows * 16;
+        if (off + need > b.size()) return fail(CW_EIO, "tape variant truncated");
+        var.stream_off.resize(var.n_strands + 1);
+        memcpy(var.stream_off.data(), b.data() + off, (size_t)(var.n_strands + 1) * 4);
+        off += (size_t)(var.n_strands + 1) * 4;
+        var.rows.resize(nrows);
+        memcpy(var.rows.data(), b.data() + off, (size_t)nrows * 16);
+        off += (size_t)nrows * 16;
+        if (var.stream_off[var.n_strands] != nrows) return fail(CW_EIO, "tape variant: bad stream offsets");
+        uint64_t mm = 0;
+        for (auto &r : var.rows) {
+            uint32_t op = r.w0 & 0xFF;
+            if (op >= D_NOPS) return fail(CW_EIO, "tape contains an unknown opcode");
+            if (op == D_MMUL) mm++;
+            if (op == D_INV || op == D_IDIV || op == D_MOD || op == D_POW) c->need_full = true;
+        }
+        if (v == 0) {
+            c->n_rows = nrows;
+            c->n_mmul = mm;
+        }
+        c->variants.push_back(std::move(var));
+    }
     // hash map as generate_hash_map builds it (c_code_generator.rs:575-587); replaced by the .dat's if given
     c->hashmap.assign(hsize, HashEntry{0, 0, 0});
     // insertion order must be the reference's (main input list order = slot order)
@@ -273,12 +308,6 @@ static int load_tape(cw_circuit *c, const char *path) {
         size_t p = hsh % hsize;
         while (c->hashmap[p].signalid != 0) p = (p + 1) % hsize;
         c->hashmap[p] = HashEntry{hsh, o.first, c->input_names[o.second].second};
-    }
-    for (auto &r : c->rows) {
-        uint32_t op = r.w0 & 0xFF;
-        if (op >= D_NOPS) return fail(CW_EIO, "tape contains an unknown opcode");
-        if (op == D_MMUL) c->n_mmul++;
-        if (op == D_INV || op == D_IDIV || op == D_MOD || op == D_POW) c->need_full = true;
     }
     c->P = make_params(c->q);
     return CW_OK;
@@ -441,6 +470,8 @@ struct cw_batch {
     void *d_V = nullptr;
     size_t v_bytes = 0;
     CwRow *d_rows = nullptr;
+    const Variant *var = nullptr;
+    uint32_t *d_stream_off = nullptr;
     uint32_t *d_consts = nullptr, *d_w2s = nullptr, *d_status = nullptr, *d_first_bad = nullptr;
     uint32_t *d_rptr = nullptr, *d_rslot = nullptr, *d_rcoef = nullptr, *d_rctab = nullptr;
     void *d_in = nullptr;          // AoS staging [batch][n_in][32]
@@ -469,7 +500,7 @@ extern "C" void cw_batch_free(cw_batch *b) {
     }
     hipSetDevice(b->device);
     hipStreamSynchronize(b->stream);
-    void *ptrs[] = {b->d_V, b->d_rows, b->d_consts, b->d_w2s, b->d_status, b->d_first_bad,
+    void *ptrs[] = {b->d_V, b->d_rows, b->d_stream_off, b->d_consts, b->d_w2s, b->d_status, b->d_first_bad,
                     b->d_rptr, b->d_rslot, b->d_rcoef, b->d_rctab, b->d_in, b->d_gather};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -500,7 +531,21 @@ extern "C" int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *
     b->batch = batch;
     b->Bp = (batch + 255) / 256 * 256;
     b->stream = (hipStream_t)stream;
-    size_t slots = (size_t)c->n_signals + c->n_tslots;
+    // pick the schedule variant: as many strands as it takes to put >= ~4 waves on every SIMD (1024 SIMDs),
+    // but no more (barriers are not free).  CW_STRANDS overrides.
+    {
+        uint64_t groups = (batch + 63) / 64;
+        uint32_t want = (uint32_t)std::max<uint64_t>(1, 4096 / groups);
+        if (const char *e = getenv("CW_STRANDS")) want = (uint32_t)std::max(1, atoi(e));
+        const Variant *best = &c->variants[0];
+        for (auto &v : c->variants) {
+            bool better = (v.n_strands <= want && v.n_strands > best->n_strands) ||
+                          (best->n_strands > want && v.n_strands < best->n_strands);
+            if (better) best = &v;
+        }
+        b->var = best;
+    }
+    size_t slots = (size_t)c->n_signals + b->var->n_tslots;
     b->v_bytes = slots * 2 * b->Bp * 16;
     hipError_t e = hipMalloc(&b->d_V, b->v_bytes);
     if (e != hipSuccess) {
@@ -516,7 +561,8 @@ extern "C" int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *
             return fail(CW_EDEVICE, std::string(#x ": ") + hipGetErrorString(e2)); \
         }                                                                   \
     } while (0)
-    TRY(upload(&b->d_rows, c->rows, b->stream));
+    TRY(upload(&b->d_rows, b->var->rows, b->stream));
+    TRY(upload(&b->d_stream_off, b->var->stream_off, b->stream));
     TRY(upload(&b->d_consts, c->consts, b->stream));
     TRY(upload(&b->d_w2s, c->w2s, b->stream));
     TRY(hipMalloc((void **)&b->d_status, (size_t)b->Bp * 4));
@@ -536,6 +582,7 @@ extern "C" int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *
     return CW_OK;
 }
 extern "C" uint32_t cw_batch_size(const cw_batch *b) { return b->batch; }
+extern "C" uint32_t cw_batch_strands(const cw_batch *b) { return b->var ? b->var->n_strands : 0; }
 
 static int ensure_host_staging(cw_batch *b) {
     size_t n = (size_t)b->batch * b->c->n_inputs;
@@ -828,8 +875,8 @@ extern "C" int cw_run(cw_batch *b) {
     const void *in = b->ext_in ? b->ext_in : b->d_in;
     HIPCHK(cwk_init(b->stream, b->d_V, b->Bp, b->d_status, b->d_first_bad));
     HIPCHK(cwk_ingest(b->stream, in, b->d_V, c->input_start, c->n_inputs, b->batch, b->Bp));
-    HIPCHK(cwk_eval(b->stream, c->need_full, b->d_rows, c->n_rows, b->d_V, b->d_consts, c->n_signals, b->Bp, b->batch,
-                    b->d_status, c->P));
+    HIPCHK(cwk_eval(b->stream, c->need_full, b->d_rows, b->d_stream_off, b->var->n_strands, b->d_V, b->d_consts,
+                    c->n_signals, b->Bp, b->batch, b->d_status, c->P));
     b->ran = true;
     return CW_OK;
 }

@@ -62,31 +62,75 @@ __global__ void __launch_bounds__(CW_BLOCK) cw_ingest_kernel(const uint4 *__rest
 }
 
 // ---- schedule evaluation (the hot path) ---------------------------------------------------------------
-// One lane = one instance; every lane walks the same schedule.  FULL selects the variant that also
-// carries the slow-path operators (INV/IDIV/MOD/POW); schedules without them run the lean variant,
-// whose register footprint is that of one Montgomery product.
+// One lane = one instance.  A workgroup = S waves ("strands") that all work on the SAME 64 instances,
+// each walking its own row stream of the schedule; strands exchange values through the value table and
+// meet at BARRIER rows (hip_elements/lower.py pass C).  S = 1 for large batches (instance parallelism
+// alone fills the chip), S up to 16 for the small batches of the BASELINE configs.
+// Latency hiding inside a strand: (1) operands of row r+1 are fetched before row r executes
+// (one-row-ahead software prefetch; legal because the lowering encodes any operand produced by the
+// preceding row as kind PREV = register forwarding), (2) pure copies never load: they are extra
+// destinations (ALSO rows) of the row that produced the value.
+// FULL selects the variant that also carries the slow-path operators (INV/IDIV/MOD/POW).
+struct Opnds { fe a, b; };
+
+__device__ __forceinline__ void fetch_operands(const CwRow &row, const uint4 *V, const uint32_t *__restrict__ consts,
+                                               uint32_t tmp_base, uint32_t Bp, uint32_t i, fe &a, fe &b) {
+    const uint32_t op = row.w0 & 0xFF;
+    if (op >= D_EXT && op != D_ASSERT_EQ && op != D_ASSERT_NZ) return;      // EXT / ALSO / BARRIER: no operands
+    const uint32_t ak = (row.w0 >> 10) & 3, bk = (row.w0 >> 12) & 3;
+    if (ak == K_CONST) a = c_load(consts, row.a);
+    else if (ak != K_PREV) a = v_load(V, row.a + (ak == K_TMP ? tmp_base : 0), Bp, i);
+    const bool unary = (op == D_COPY) | (op == D_NEG) | (op == D_BNOT) | (op == D_LNOT) | (op == D_INV) |
+                       (op == D_ASSERT_NZ);
+    if (!unary) {
+        if (bk == K_CONST) b = c_load(consts, row.b);
+        else if (bk != K_PREV) b = v_load(V, row.b + (bk == K_TMP ? tmp_base : 0), Bp, i);
+    }
+}
+
 template <bool FULL>
-__global__ void __launch_bounds__(CW_BLOCK)
-cw_eval_kernel(const CwRow *__restrict__ rows, uint64_t n_rows, uint4 *V, const uint32_t *__restrict__ consts,
-               uint32_t tmp_base, uint32_t Bp, uint32_t batch, uint32_t *__restrict__ status, FpParams P) {
-    const uint32_t i = blockIdx.x * CW_BLOCK + threadIdx.x;
-    if (i >= batch) return;
+__global__ void __launch_bounds__(1024)
+cw_eval_kernel(const CwRow *__restrict__ rows, const uint32_t *__restrict__ stream_off, uint4 *V,
+               const uint32_t *__restrict__ consts, uint32_t tmp_base, uint32_t Bp, uint32_t batch,
+               uint32_t *status, FpParams P) {
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t i = blockIdx.x * 64 + (threadIdx.x & 63);       // < Bp (Bp is a multiple of 256 >= batch)
+    uint32_t r = stream_off[wave];
+    const uint32_t end = stream_off[wave + 1];
     uint32_t st = 0;
-    for (uint64_t r = 0; r < n_rows; r++) {
-        const CwRow row = rows[r];
+    fe prev = fe_zero();
+    fe na = fe_zero(), nb = fe_zero();
+    CwRow nrow = rows[r < end ? r : 0];
+    if (r < end) fetch_operands(nrow, V, consts, tmp_base, Bp, i, na, nb);
+    while (r < end) {
+        const CwRow row = nrow;
         const uint32_t op = row.w0 & 0xFF;
         const uint32_t dk = (row.w0 >> 8) & 3, ak = (row.w0 >> 10) & 3, bk = (row.w0 >> 12) & 3;
-        const uint32_t dslot = row.dst + (dk == K_TMP ? tmp_base : 0);
-        fe a, b;
-        if (ak == K_CONST) a = c_load(consts, row.a);
-        else a = v_load(V, row.a + (ak == K_TMP ? tmp_base : 0), Bp, i);
-        const bool unary = (op == D_COPY) | (op == D_NEG) | (op == D_BNOT) | (op == D_LNOT) | (op == D_INV) |
-                           (op == D_ASSERT_NZ);
-        if (!unary) {
-            if (bk == K_CONST) b = c_load(consts, row.b);
-            else b = v_load(V, row.b + (bk == K_TMP ? tmp_base : 0), Bp, i);
-        } else {
-            b = fe_zero();
+        const uint32_t next = r + (op == D_SELECT ? 2u : 1u);
+        if (op == D_BARRIER) {
+            __syncthreads();                                         // nothing is prefetched across a barrier
+            r = next;
+            if (r < end) {
+                nrow = rows[r];
+                fetch_operands(nrow, V, consts, tmp_base, Bp, i, na, nb);
+            }
+            continue;
+        }
+        fe a = (ak == K_PREV) ? prev : na;
+        fe b = (bk == K_PREV) ? prev : nb;
+        CwRow ext;
+        if (op == D_SELECT) ext = rows[r + 1];
+        if (next < end) {                                            // prefetch the next row's operands
+            nrow = rows[next];
+            fetch_operands(nrow, V, consts, tmp_base, Bp, i, na, nb);
+        }
+        if (op == D_ALSO) {
+            const uint32_t n = (row.w0 >> 16) & 3;
+            v_store(V, row.dst + (dk == K_TMP ? tmp_base : 0), Bp, i, prev);
+            if (n > 1) v_store(V, row.a + (ak == K_TMP ? tmp_base : 0), Bp, i, prev);
+            if (n > 2) v_store(V, row.b + (bk == K_TMP ? tmp_base : 0), Bp, i, prev);
+            r = next;
+            continue;
         }
         fe d;
         bool has_d = true;
@@ -112,9 +156,7 @@ cw_eval_kernel(const CwRow *__restrict__ rows, uint64_t n_rows, uint4 *V, const 
         case D_LOR: d = fe_small(!fe_is_zero(a) | !fe_is_zero(b)); break;
         case D_LNOT: d = fe_small(fe_is_zero(a)); break;
         case D_SELECT: {
-            // cond = a, then-value = b, else-value in the following EXT row
-            r++;
-            const CwRow ext = rows[r];
+            // cond = a, then-value = b, else-value in the following EXT row (always read from memory)
             const uint32_t ck = (ext.w0 >> 10) & 3;
             fe c;
             if (ck == K_CONST) c = c_load(consts, ext.a);
@@ -124,11 +166,11 @@ cw_eval_kernel(const CwRow *__restrict__ rows, uint64_t n_rows, uint4 *V, const 
             break;
         }
         case D_ASSERT_EQ:
-            if (!fe_eq(a, b) && st == 0) st = CW_ST_ASSERT_FAILED | ((uint32_t)r << 8);
+            if (!fe_eq(a, b) && st == 0) st = CW_ST_ASSERT_FAILED | (r << 8);
             has_d = false;
             break;
         case D_ASSERT_NZ:
-            if (fe_is_zero(a) && st == 0) st = CW_ST_ASSERT_FAILED | ((uint32_t)r << 8);
+            if (fe_is_zero(a) && st == 0) st = CW_ST_ASSERT_FAILED | (r << 8);
             has_d = false;
             break;
         default:
@@ -140,7 +182,7 @@ cw_eval_kernel(const CwRow *__restrict__ rows, uint64_t n_rows, uint4 *V, const 
                 case D_MOD: {
                     fe qq, rr;
                     if (fe_is_zero(b)) {
-                        if (st == 0) st = CW_ST_ARITH | ((uint32_t)r << 8);
+                        if (st == 0) st = CW_ST_ARITH | (r << 8);
                         d = fe_zero();
                     } else {
                         fe_divmod(a, b, &qq, &rr);
@@ -155,9 +197,13 @@ cw_eval_kernel(const CwRow *__restrict__ rows, uint64_t n_rows, uint4 *V, const 
             }
             break;
         }
-        if (has_d) v_store(V, dslot, Bp, i, d);
+        if (has_d) {
+            prev = d;
+            if (dk != KD_NONE) v_store(V, row.dst + (dk == K_TMP ? tmp_base : 0), Bp, i, d);
+        }
+        r = next;
     }
-    if (st) status[i] = st;
+    if (st && i < batch) atomicCAS(&status[i], 0u, st);
 }
 
 // ---- R1CS check:  (A.w) * (B.w) == C.w  for every constraint row and instance ---------------------------
@@ -294,14 +340,16 @@ hipError_t cwk_ingest(hipStream_t s, const void *in, void *V, uint32_t input_sta
                        Bp);
     return hipGetLastError();
 }
-hipError_t cwk_eval(hipStream_t s, bool full, const CwRow *rows, uint64_t n_rows, void *V, const uint32_t *consts,
-                    uint32_t tmp_base, uint32_t Bp, uint32_t batch, uint32_t *status, const FpParams &P) {
+hipError_t cwk_eval(hipStream_t s, bool full, const CwRow *rows, const uint32_t *stream_off, uint32_t n_strands, void *V,
+                    const uint32_t *consts, uint32_t tmp_base, uint32_t Bp, uint32_t batch, uint32_t *status,
+                    const FpParams &P) {
+    dim3 grid((batch + 63) / 64), block(64 * n_strands);
     if (full)
-        hipLaunchKernelGGL(cw_eval_kernel<true>, blocks_for(batch), dim3(CW_BLOCK), 0, s, rows, n_rows, (uint4 *)V, consts,
-                           tmp_base, Bp, batch, status, P);
+        hipLaunchKernelGGL(cw_eval_kernel<true>, grid, block, 0, s, rows, stream_off, (uint4 *)V, consts, tmp_base, Bp, batch,
+                           status, P);
     else
-        hipLaunchKernelGGL(cw_eval_kernel<false>, blocks_for(batch), dim3(CW_BLOCK), 0, s, rows, n_rows, (uint4 *)V, consts,
-                           tmp_base, Bp, batch, status, P);
+        hipLaunchKernelGGL(cw_eval_kernel<false>, grid, block, 0, s, rows, stream_off, (uint4 *)V, consts, tmp_base, Bp, batch,
+                           status, P);
     return hipGetLastError();
 }
 hipError_t cwk_r1cs(hipStream_t s, const uint32_t *ptr, const uint32_t *tslot, const uint32_t *tcoef, const uint32_t *ctab,

@@ -6,11 +6,12 @@
 enum : uint32_t {
     D_COPY = 0, D_ADD, D_SUB, D_NEG, D_MMUL, D_INV, D_IDIV, D_MOD, D_POW, D_SHL, D_SHR, D_BAND, D_BOR, D_BXOR,
     D_BNOT, D_LT, D_GT, D_LEQ, D_GEQ, D_EQ, D_NEQ, D_LAND, D_LOR, D_LNOT, D_SELECT, D_EXT, D_ASSERT_EQ,
-    D_ASSERT_NZ, D_NOPS
+    D_ASSERT_NZ, D_ALSO, D_BARRIER, D_NOPS
 };
 
-// operand kinds (2 bits each in row.w0: dst<<8, a<<10, b<<12)
-enum : uint32_t { K_SIG = 0, K_TMP = 1, K_CONST = 2 };
+// operand kinds (2 bits each in row.w0: dst<<8, a<<10, b<<12); ALSO rows: bits 16-17 = number of dsts
+enum : uint32_t { K_SIG = 0, K_TMP = 1, K_CONST = 2, K_PREV = 3 };
+enum : uint32_t { KD_NONE = 2 };   // destination kind "no store" (value only forwarded through PREV)
 
 struct CwRow {       // 16 bytes, read with one scalar dwordx4 load
     uint32_t w0;     // op | dk<<8 | ak<<10 | bk<<12

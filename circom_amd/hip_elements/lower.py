@@ -2,9 +2,9 @@
 
 This is the new back-end the north-star adds beside `c_elements`/`wasm_elements`
 (code_producers/src/c_elements/mod.rs:6-39 is the producer it parallels): instead of emitting a
-per-template C++/WASM program that interprets one input, it emits ONE straight-line schedule over
-global value slots that the fixed HIP kernels (circom_amd/csrc/) evaluate for thousands of
-instances at once (outer loop = schedule step, inner = instance/lane).
+per-template C++/WASM program that interprets one input, it emits ONE schedule over global value slots
+that the fixed HIP kernels (circom_amd/csrc/) evaluate for thousands of instances at once
+(outer loop = schedule step, inner = instance/lane).
 
 Representation policy ("N policy"): every value slot holds the CANONICAL residue in [0,q) as
 8 x u32 limbs.  Rationale (vs. the reference's tagged short/long/Montgomery union, fr.hpp:17-21):
@@ -12,13 +12,27 @@ Representation policy ("N policy"): every value slot holds the CANONICAL residue
   * bitwise/relational/shift operators are defined on canonical values,
   * add/sub are representation-agnostic,
   * a product with a compile-time constant is ONE raw Montgomery multiplication when the constant
-    is pre-scaled by R here (MMUL(x, c*R) = x*c), and a product of two run-time values is
-    MMUL(MMUL(x,y), R^2).
-Raw device ops therefore include MMUL (a*b*R^-1 mod q) and the lowering owns all scaling.
+    is pre-scaled by the device radix R' here (MMUL(x, c*R') = x*c), and a product of two run-time
+    values is MMUL(MMUL(x,y), R'^2).
 
-Schedule rows are 4 x u32: w0 = op | dk<<8 | ak<<10 | bk<<12, then dst, a, b.  Operand kinds:
-0 = signal slot, 1 = temp slot, 2 = constant-table index.  SELECT carries its third operand in a
-following EXT row.
+Passes:
+  A expand      flat ops -> device ops over virtual temps (owns all Montgomery scaling)
+  B alias       every `x <== y` that only copies a value becomes an extra destination of the row that
+                produces y (at --O0 ~40% of all signals are such copies: component wiring).  The copy
+                costs one more store (the algorithmic 32 B) instead of a load + a dependent store.
+  C schedule    S parallel strands (waves of one workgroup working on the SAME 64 instances): rows are
+                levelled by dependency depth, distributed over strands with producer affinity, and
+                separated by workgroup barriers.  S = 1 keeps program order and needs no barrier.
+  D slots       temp slot allocation by liveness (per row for S = 1, per barrier epoch for S > 1);
+                a temp whose every use is forwarded through the register (kind PREV) gets no slot.
+  E encode      rows are 4 x u32: w0 = op | dk<<8 | ak<<10 | bk<<12 | n<<16, then dst, a, b.
+                operand kinds: 0 signal slot, 1 temp slot, 2 constant index, 3 PREV (the previous
+                value-producing row of the same strand, forwarded in registers);
+                destination kinds: 0 signal, 1 temp, 2 none.  ALSO rows carry up to 3 extra
+                destinations of the preceding row; SELECT carries its third operand in an EXT row.
+  Invariant the kernel's one-row-ahead operand prefetch relies on: a row never reads FROM MEMORY a
+  slot that the immediately preceding rows of its strand (back to and including the last
+  value-producing row) write; such operands are always encoded as PREV.
 """
 from __future__ import annotations
 
@@ -30,17 +44,21 @@ from ..frontend.flatten import FlatCircuit
 # device opcodes (csrc/cw_tape.h must match)
 (D_COPY, D_ADD, D_SUB, D_NEG, D_MMUL, D_INV, D_IDIV, D_MOD, D_POW, D_SHL, D_SHR, D_BAND, D_BOR, D_BXOR,
  D_BNOT, D_LT, D_GT, D_LEQ, D_GEQ, D_EQ, D_NEQ, D_LAND, D_LOR, D_LNOT, D_SELECT, D_EXT, D_ASSERT_EQ,
- D_ASSERT_NZ) = range(28)
+ D_ASSERT_NZ, D_ALSO, D_BARRIER) = range(30)
 D_NAMES = ["copy", "add", "sub", "neg", "mmul", "inv", "idiv", "mod", "pow", "shl", "shr", "band", "bor",
            "bxor", "bnot", "lt", "gt", "leq", "geq", "eq", "neq", "land", "lor", "lnot", "select", "ext",
-           "assert_eq", "assert_nz"]
+           "assert_eq", "assert_nz", "also", "barrier"]
 
 K_SIG, K_TMP, K_CONST, K_NONE = O.K_SIG, O.K_TMP, O.K_CONST, O.K_NONE
+KD_NONE = 2      # destination kind "no store"
+KO_PREV = 3      # operand kind "previous result of this strand"
 
 _DIRECT = {O.COPY: D_COPY, O.ADD: D_ADD, O.SUB: D_SUB, O.NEG: D_NEG, O.IDIV: D_IDIV, O.MOD: D_MOD,
            O.POW: D_POW, O.SHL: D_SHL, O.SHR: D_SHR, O.BAND: D_BAND, O.BOR: D_BOR, O.BXOR: D_BXOR,
            O.BNOT: D_BNOT, O.LT: D_LT, O.GT: D_GT, O.LEQ: D_LEQ, O.GEQ: D_GEQ, O.EQ: D_EQ, O.NEQ: D_NEQ,
            O.LAND: D_LAND, O.LOR: D_LOR, O.LNOT: D_LNOT, O.ASSERT_EQ: D_ASSERT_EQ, O.ASSERT_NZ: D_ASSERT_NZ}
+_COST = {D_MMUL: 10.0, D_INV: 4000.0, D_POW: 6000.0, D_IDIV: 8000.0, D_MOD: 8000.0}
+_NO_VALUE = (D_ASSERT_EQ, D_ASSERT_NZ)
 
 
 class Tape:
@@ -52,7 +70,9 @@ class Tape:
         self.n_signals = 0
         self.n_tslots = 0
         self.n_witness = 0
-        self.rows = None            # (n,4) uint32
+        self.rows = None            # (n,4) uint32, all strands concatenated
+        self.stream_off = None      # uint32[n_strands+1] row offsets of each strand
+        self.n_strands = 1
         self.consts = []            # raw residues (python ints)
         self.witness2signal = None  # uint32[n_witness]
         self.inputs = []            # (name, slot, size)
@@ -80,7 +100,19 @@ def _dce(code, n_temps):
     return keep
 
 
-def lower(fc: FlatCircuit, witness_map=None) -> Tape:
+class _Row:
+    __slots__ = ("op", "dk", "dv", "ak", "av", "bk", "bv", "ck", "cv", "extra", "level", "strand")
+
+    def __init__(self, op, dk, dv, ak, av, bk=K_NONE, bv=0, ck=K_NONE, cv=0):
+        self.op, self.dk, self.dv = op, dk, dv
+        self.ak, self.av, self.bk, self.bv, self.ck, self.cv = ak, av, bk, bv, ck, cv
+        self.extra = None        # list of (kind, id) extra destinations
+        self.level = 0
+        self.strand = 0
+
+
+def _expand(fc: FlatCircuit):
+    """Pass A."""
     fp = fc.fp
     q = fp.q
     code = fc.code
@@ -92,9 +124,7 @@ def lower(fc: FlatCircuit, witness_map=None) -> Tape:
     bk = code["bk"][idx].tolist(); bv = code["bv"][idx].tolist()
     ck = code["ck"][idx].tolist(); cv = code["cv"][idx].tolist()
     consts_in = fc.constants
-
-    dconsts = []
-    dconst_id = {}
+    dconsts, dconst_id = [], {}
 
     def cid(v):
         i = dconst_id.get(v)
@@ -104,121 +134,292 @@ def lower(fc: FlatCircuit, witness_map=None) -> Tape:
             dconsts.append(v)
         return i
 
-    R, R2 = fp.Rdev, fp.Rdev2        # device radix R' = 2^261
-    # virtual temps: flat temp ids, plus fresh ones for expansion intermediates
-    next_tmp = [fc.n_temps]
+    R, R2 = fp.Rdev, fp.Rdev2
+    nxt = [fc.n_temps]
 
     def fresh():
-        t = next_tmp[0]
-        next_tmp[0] += 1
+        t = nxt[0]
+        nxt[0] += 1
         return t
 
-    rows = []   # (dop, dk, dv, ak, av, bk, bv) with virtual temps; consts already device ids
-
-    def opnd(k, v, scale=1):
-        """flat operand -> device operand; constants become device-constant ids (optionally pre-scaled)."""
+    def opnd(k, v):
         if k == K_CONST:
-            return K_CONST, cid((consts_in[v] * scale) % q)
+            return K_CONST, cid(consts_in[v] % q)
         return k, v
 
-    n_mmul = 0
+    rows = []
     for i in range(len(op)):
         o = op[i]
         if o == O.MUL:
             a_c, b_c = ak[i] == K_CONST, bk[i] == K_CONST
             if a_c or b_c:
-                # x * c  ->  MMUL(x, c*R)
                 if a_c:
-                    xk, xv = bk[i], bv[i]
-                    c = consts_in[av[i]]
+                    xk, xv, c = bk[i], bv[i], consts_in[av[i]]
                 else:
-                    xk, xv = ak[i], av[i]
-                    c = consts_in[bv[i]]
-                rows.append((D_MMUL, dk[i], dv[i], xk, xv, K_CONST, cid((c * R) % q)))
-                n_mmul += 1
+                    xk, xv, c = ak[i], av[i], consts_in[bv[i]]
+                rows.append(_Row(D_MMUL, dk[i], dv[i], xk, xv, K_CONST, cid((c * R) % q)))
             else:
                 t = fresh()
-                rows.append((D_MMUL, K_TMP, t, ak[i], av[i], bk[i], bv[i]))
-                rows.append((D_MMUL, dk[i], dv[i], K_TMP, t, K_CONST, cid(R2)))
-                n_mmul += 2
+                rows.append(_Row(D_MMUL, K_TMP, t, ak[i], av[i], bk[i], bv[i]))
+                rows.append(_Row(D_MMUL, dk[i], dv[i], K_TMP, t, K_CONST, cid(R2)))
         elif o == O.DIV:
             # a / b = a * inv(b); inv(0) = 0 (generic/fr.cpp:2895-2912)
             t = fresh()
             kb, vb = opnd(bk[i], bv[i])
-            rows.append((D_INV, K_TMP, t, kb, vb, K_NONE, 0))
+            rows.append(_Row(D_INV, K_TMP, t, kb, vb))
             if ak[i] == K_CONST:
-                rows.append((D_MMUL, dk[i], dv[i], K_TMP, t, K_CONST, cid((consts_in[av[i]] * R) % q)))
-                n_mmul += 1
+                rows.append(_Row(D_MMUL, dk[i], dv[i], K_TMP, t, K_CONST, cid((consts_in[av[i]] * R) % q)))
             else:
                 t2 = fresh()
-                rows.append((D_MMUL, K_TMP, t2, ak[i], av[i], K_TMP, t))
-                rows.append((D_MMUL, dk[i], dv[i], K_TMP, t2, K_CONST, cid(R2)))
-                n_mmul += 2
+                rows.append(_Row(D_MMUL, K_TMP, t2, ak[i], av[i], K_TMP, t))
+                rows.append(_Row(D_MMUL, dk[i], dv[i], K_TMP, t2, K_CONST, cid(R2)))
         elif o == O.SELECT:
             ka, va = opnd(ak[i], av[i])
             kb, vb = opnd(bk[i], bv[i])
             kc, vc = opnd(ck[i], cv[i])
-            rows.append((D_SELECT, dk[i], dv[i], ka, va, kb, vb))
-            rows.append((D_EXT, K_NONE, 0, kc, vc, K_NONE, 0))
+            rows.append(_Row(D_SELECT, dk[i], dv[i], ka, va, kb, vb, kc, vc))
         else:
-            d = _DIRECT[o]
             ka, va = opnd(ak[i], av[i])
             kb, vb = opnd(bk[i], bv[i]) if bk[i] != K_NONE else (K_NONE, 0)
-            rows.append((d, dk[i], dv[i], ka, va, kb, vb))
+            rows.append(_Row(_DIRECT[o], dk[i] if dk[i] != K_NONE else KD_NONE, dv[i], ka, va, kb, vb))
+    return rows, dconsts, nxt[0]
 
-    # ---- temp slot allocation (linear scan over virtual temps) ---------------------------------
-    nrows = len(rows)
-    last_use = {}
-    for r in range(nrows):
-        _, _, _, ka, va, kb, vb = rows[r]
-        if ka == K_TMP:
-            last_use[va] = r
-        if kb == K_TMP:
-            last_use[vb] = r
-    free = []
+
+def _alias(rows, n_signals):
+    """Pass B.  Value ids: signal s -> s, virtual temp t -> n_signals + t."""
+    def vid(k, v):
+        return v if k == K_SIG else n_signals + v
+
+    producer = {}
+    root = {}
+
+    def find(x):
+        while x in root:
+            x = root[x]
+        return x
+
+    out = []
+    n_elided = 0
+    for r in rows:
+        # canonicalise operands to the root of their alias class
+        for kk, vv in (("ak", "av"), ("bk", "bv"), ("ck", "cv")):
+            k = getattr(r, kk)
+            if k == K_SIG or k == K_TMP:
+                x = find(vid(k, getattr(r, vv)))
+                if x < n_signals:
+                    setattr(r, kk, K_SIG); setattr(r, vv, x)
+                else:
+                    setattr(r, kk, K_TMP); setattr(r, vv, x - n_signals)
+        if r.op == D_COPY and r.dk == K_SIG and r.ak in (K_SIG, K_TMP):
+            src = vid(r.ak, r.av)
+            p = producer.get(src)
+            if p is not None:
+                if p.extra is None:
+                    p.extra = []
+                p.extra.append((K_SIG, r.dv))
+                root[r.dv] = src
+                n_elided += 1
+                continue
+        if r.dk in (K_SIG, K_TMP):
+            producer[vid(r.dk, r.dv)] = r
+        out.append(r)
+    return out, n_elided
+
+
+def _schedule(rows, n_signals, n_strands):
+    """Pass C.  Returns list of streams; each stream is a list whose items are _Row or the string 'B'."""
+    if n_strands <= 1:
+        for r in rows:
+            r.strand = 0
+        return [list(rows)], 0
+
+    def vid(k, v):
+        return v if k == K_SIG else n_signals + v
+
+    prod_level = {}
+    prod_strand = {}
+    levels = []
+    for r in rows:
+        lv = 0
+        for k, v in ((r.ak, r.av), (r.bk, r.bv), (r.ck, r.cv)):
+            if k == K_SIG or k == K_TMP:
+                pl = prod_level.get(vid(k, v))
+                if pl is not None and pl + 1 > lv:
+                    lv = pl + 1
+        r.level = lv
+        if r.dk in (K_SIG, K_TMP):
+            prod_level[vid(r.dk, r.dv)] = lv
+        while len(levels) <= lv:
+            levels.append([])
+        levels[lv].append(r)
+    streams = [[] for _ in range(n_strands)]
+    for lv, lrows in enumerate(levels):
+        total = sum(_COST.get(r.op, 1.5) + (0.5 * len(r.extra) if r.extra else 0) for r in lrows)
+        cap = total / n_strands * 1.15 + 10.0
+        load = [0.0] * n_strands
+        for r in lrows:
+            cost = _COST.get(r.op, 1.5) + (0.5 * len(r.extra) if r.extra else 0)
+            pref = None
+            for k, v in ((r.ak, r.av), (r.bk, r.bv)):
+                if k == K_SIG or k == K_TMP:
+                    x = vid(k, v)
+                    if prod_level.get(x) == lv - 1:
+                        pref = prod_strand.get(x)
+                        break
+            if pref is None or load[pref] + cost > cap:
+                pref = min(range(n_strands), key=load.__getitem__)
+            r.strand = pref
+            load[pref] += cost
+            streams[pref].append(r)
+            if r.dk in (K_SIG, K_TMP):
+                prod_strand[vid(r.dk, r.dv)] = pref
+        if lv + 1 < len(levels):
+            for s in streams:
+                s.append("B")
+    return streams, len(levels) - 1
+
+
+def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
+    q = fc.fp.q
+    n_signals = fc.n_signals
+    rows, dconsts, n_vtemps = _expand(fc)
+    n_expanded = len(rows)
+    rows, n_elided = _alias(rows, n_signals)
+    streams, n_barriers = _schedule(rows, n_signals, n_strands)
+
+    # ---- pass D: which temps need a slot, and liveness ---------------------------------------------------
+    # time unit: row position for one strand, barrier epoch for several
+    multi = n_strands > 1
+    uses_mem = {}       # vtemp -> True if some use is not PREV-forwarded
+    last_use = {}       # vtemp -> last time it is read from memory
+    def_time = {}
+    plan = []           # per stream: list of (row | 'B', prev_flags(a,b), time)
+    for s in streams:
+        prev_val = None          # ('T'|'S', id) of the last value-producing row
+        epoch = 0
+        items = []
+        for pos, r in enumerate(s):
+            if r == "B":
+                epoch += 1
+                items.append(("B", None, epoch))
+                continue
+            t = epoch if multi else pos
+            fl = []
+            for k, v in ((r.ak, r.av), (r.bk, r.bv)):
+                is_prev = prev_val is not None and (k, v) == prev_val
+                fl.append(is_prev)
+                if k == K_TMP and not is_prev:
+                    uses_mem[v] = True
+                    last_use[v] = max(last_use.get(v, -1), t)
+            if r.ck == K_TMP:          # SELECT's third operand is always read from memory
+                uses_mem[r.cv] = True
+                last_use[r.cv] = max(last_use.get(r.cv, -1), t)
+            items.append((r, tuple(fl), t))
+            if r.op not in _NO_VALUE:
+                prev_val = (r.dk, r.dv) if r.dk in (K_SIG, K_TMP) else None
+                if r.dk == K_TMP:
+                    def_time[r.dv] = t
+            if r.extra:
+                for k, v in r.extra:
+                    if k == K_TMP:
+                        def_time[v] = t
+        plan.append(items)
+
+    # slot allocation in definition-time order
     slot_of = {}
     n_tslots = 0
-    out = np.zeros((nrows, 4), dtype=np.uint32)
-    for r in range(nrows):
-        d, kd, vd, ka, va, kb, vb = rows[r]
-        sa = slot_of[va] if ka == K_TMP else va
-        sb = slot_of[vb] if kb == K_TMP else vb
-        # release operands whose last use is this row *before* allocating dst: dst may reuse the slot
-        # (kernels read all operands before writing)
-        if ka == K_TMP and last_use.get(va) == r:
-            free.append(slot_of.pop(va))
-        if kb == K_TMP and vb != va and last_use.get(vb) == r and vb in slot_of:
-            free.append(slot_of.pop(vb))
-        if kd == K_TMP:
-            if vd in last_use:
-                if free:
-                    s = free.pop()
-                else:
-                    s = n_tslots
-                    n_tslots += 1
-                slot_of[vd] = s
-                sd = s
+    if multi:
+        # a slot freed by a last read in epoch e may be rewritten from epoch e+1 on (a barrier lies between)
+        by_time = sorted((t, v) for v, t in def_time.items() if uses_mem.get(v))
+        free_at = {}        # epoch -> list of slots that become free once that epoch is over
+        free = []
+        cur = -1
+        for t, v in by_time:
+            while cur < t - 1:
+                cur += 1
+                free.extend(free_at.pop(cur, ()))
+            if free:
+                sl = free.pop()
             else:
-                sd = 0  # dead temp cannot happen after DCE except for SELECT/EXT pairs
-        else:
-            sd = vd
-        kd_ = 0 if kd == K_NONE else kd
-        ka_ = 0 if ka == K_NONE else ka
-        kb_ = 0 if kb == K_NONE else kb
-        out[r, 0] = d | (kd_ << 8) | (ka_ << 10) | (kb_ << 12)
-        out[r, 1] = sd
-        out[r, 2] = sa
-        out[r, 3] = sb
+                sl = n_tslots
+                n_tslots += 1
+            slot_of[v] = sl
+            free_at.setdefault(last_use[v], []).append(sl)
+    else:
+        free = []
+        release = {}        # position -> temps whose last use is there
+        for v, t in last_use.items():
+            release.setdefault(t, []).append(v)
+        for (r, fl, t) in plan[0]:
+            # operands are read before the destination is written: release first, then allocate
+            for v in release.get(t, ()):
+                if v in slot_of:
+                    free.append(slot_of[v])
+            if r != "B" and r.dk == K_TMP and uses_mem.get(r.dv):
+                if free:
+                    sl = free.pop()
+                else:
+                    sl = n_tslots
+                    n_tslots += 1
+                slot_of[r.dv] = sl
+
+    # ---- pass E: encode ---------------------------------------------------------------------------------------
+    enc = []
+    stream_off = [0]
+    n_also = n_prev = 0
+    for items in plan:
+        for (r, fl, t) in items:
+            if r == "B":
+                enc.append((D_BARRIER, 0, 0, 0))
+                continue
+
+            def o_enc(k, v, is_prev):
+                if is_prev:
+                    return KO_PREV, 0
+                if k == K_TMP:
+                    return K_TMP, slot_of[v]
+                if k == K_NONE:
+                    return 0, 0
+                return k, v
+
+            ka, va = o_enc(r.ak, r.av, fl[0])
+            kb, vb = o_enc(r.bk, r.bv, fl[1])
+            n_prev += fl[0] + fl[1]
+            if r.dk == K_TMP:
+                if uses_mem.get(r.dv):
+                    kd, vd = K_TMP, slot_of[r.dv]
+                else:
+                    kd, vd = KD_NONE, 0
+            elif r.dk == K_SIG:
+                kd, vd = K_SIG, r.dv
+            else:
+                kd, vd = KD_NONE, 0
+            enc.append((r.op | (kd << 8) | (ka << 10) | (kb << 12), vd, va, vb))
+            if r.op == D_SELECT:
+                kc, vc = o_enc(r.ck, r.cv, False)
+                enc.append((D_EXT | (kc << 10), 0, vc, 0))
+            if r.extra:
+                ex = [(k, (slot_of[v] if k == K_TMP else v)) for k, v in r.extra if k == K_SIG or uses_mem.get(v)]
+                for j in range(0, len(ex), 3):
+                    grp = ex[j:j + 3]
+                    kk = [g[0] for g in grp] + [0] * (3 - len(grp))
+                    vv = [g[1] for g in grp] + [0] * (3 - len(grp))
+                    enc.append((D_ALSO | (kk[0] << 8) | (kk[1] << 10) | (kk[2] << 12) | (len(grp) << 16), vv[0], vv[1], vv[2]))
+                    n_also += 1
+        stream_off.append(len(enc))
+    out = np.asarray(enc, dtype=np.uint32).reshape(-1, 4)
 
     t = Tape()
     t.prime = fc.prime
     t.q = q
-    t.n_signals = fc.n_signals
+    t.n_signals = n_signals
     t.n_tslots = n_tslots
     t.rows = out
+    t.stream_off = np.asarray(stream_off, dtype=np.uint32)
+    t.n_strands = n_strands
     t.consts = dconsts
     if witness_map is None:
-        witness_map = np.arange(fc.n_signals, dtype=np.uint32)     # --O0: identity (SURVEY Appendix D)
+        witness_map = np.arange(n_signals, dtype=np.uint32)     # --O0: identity (SURVEY Appendix D)
     t.witness2signal = np.asarray(witness_map, dtype=np.uint32)
     t.n_witness = len(t.witness2signal)
     t.inputs = list(fc.inputs)
@@ -226,11 +427,16 @@ def lower(fc: FlatCircuit, witness_map=None) -> Tape:
     t.n_main_inputs = fc.n_main_inputs
     dops = out[:, 0] & 0xFF
     t.stats = {
-        "rows": nrows,
+        "rows": int(len(out)),
         "mmul": int((dops == D_MMUL).sum()),
         "addsub": int(((dops == D_ADD) | (dops == D_SUB) | (dops == D_NEG)).sum()),
         "copy": int((dops == D_COPY).sum()),
+        "copies_elided": n_elided,
+        "also_rows": n_also,
+        "prev_operands": n_prev,
         "inv": int((dops == D_INV).sum()),
+        "barriers": n_barriers,
+        "strands": n_strands,
         "temp_slots": n_tslots,
         "consts": len(dconsts),
     }

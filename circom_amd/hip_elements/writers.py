@@ -77,34 +77,42 @@ def write_dat(path, fc: FlatCircuit, witness2signal=None):
 
 
 TAPE_MAGIC = b"CWTP"
-TAPE_VERSION = 1
+TAPE_VERSION = 2
 
 
-def write_tape(path, tape: Tape):
-    """`.cwt` layout (little endian):
-         0  "CWTP" | u32 version | u32 n64 | u32 reserved
+def write_tape(path, tapes):
+    """`.cwt` layout (little endian).  `tapes` = one Tape or a list of Tapes of the SAME circuit lowered with
+    different strand counts (the runtime picks the variant that fills the chip for the batch at hand).
+         0  "CWTP" | u32 version | u32 n64 | u32 n_variants
         16  prime, n64*8 bytes
-            u32 n_signals, n_tslots, n_witness, n_consts, n_rows(lo), n_rows(hi), main_input_start,
-                n_main_inputs, n_input_names, hashmap_size, 0, 0            (12 x u32)
-            rows       n_rows x 4 x u32
-            consts     n_consts x n64*8 bytes (raw residues as the schedule expects them)
+            12 x u32: n_signals, n_witness, n_consts, main_input_start, n_main_inputs, n_input_names,
+                      hashmap_size, rbits (Montgomery radix exponent of MMUL rows), 0, 0, 0, 0
+            consts          n_consts x n64*8 bytes (raw residues as the schedule expects them)
             witness2signal  n_witness x u32
-            input names: per name  u32 len | bytes | u32 start | u32 size
+            input names     per name  u32 len | bytes | u32 start | u32 size
+            per variant     u32 n_strands | u32 n_tslots | u32 n_rows | u32 0
+                            stream_off (n_strands+1) x u32 | rows n_rows x 4 x u32
     """
-    n64 = (tape.q.bit_length() + 63) // 64
+    if isinstance(tapes, Tape):
+        tapes = [tapes]
+    t0 = tapes[0]
+    n64 = (t0.q.bit_length() + 63) // 64
+    for t in tapes[1:]:
+        assert t.consts == t0.consts and t.n_signals == t0.n_signals, "variants must come from the same circuit"
     with open(path, "wb") as f:
-        f.write(TAPE_MAGIC + struct.pack("<III", TAPE_VERSION, n64, 0))
-        f.write(tape.q.to_bytes(8 * n64, "little"))
-        nrows = len(tape.rows)
-        f.write(struct.pack("<12I", tape.n_signals, tape.n_tslots, tape.n_witness, len(tape.consts),
-                            nrows & 0xFFFFFFFF, nrows >> 32, tape.main_input_start, tape.n_main_inputs,
-                            len(tape.inputs), hashmap_size(len(tape.inputs)), 0, 0))
-        f.write(np.ascontiguousarray(tape.rows, dtype="<u4").tobytes())
-        f.write(b"".join(c.to_bytes(8 * n64, "little") for c in tape.consts))
-        f.write(np.asarray(tape.witness2signal, dtype="<u4").tobytes())
-        for name, start, size in tape.inputs:
+        f.write(TAPE_MAGIC + struct.pack("<III", TAPE_VERSION, n64, len(tapes)))
+        f.write(t0.q.to_bytes(8 * n64, "little"))
+        f.write(struct.pack("<12I", t0.n_signals, t0.n_witness, len(t0.consts), t0.main_input_start, t0.n_main_inputs,
+                            len(t0.inputs), hashmap_size(len(t0.inputs)), t0.rbits, 0, 0, 0, 0))
+        f.write(b"".join(c.to_bytes(8 * n64, "little") for c in t0.consts))
+        f.write(np.asarray(t0.witness2signal, dtype="<u4").tobytes())
+        for name, start, size in t0.inputs:
             b = name.encode()
             f.write(struct.pack("<I", len(b)) + b + struct.pack("<II", start, size))
+        for t in tapes:
+            f.write(struct.pack("<4I", t.n_strands, t.n_tslots, len(t.rows), 0))
+            f.write(np.asarray(t.stream_off, dtype="<u4").tobytes())
+            f.write(np.ascontiguousarray(t.rows, dtype="<u4").tobytes())
 
 
 def _le_key(k: int) -> bytes:

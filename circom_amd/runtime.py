@@ -53,6 +53,7 @@ _SIGS = {
     "cw_batch_create": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.POINTER(C.c_void_p)]),
     "cw_batch_free": (None, [C.c_void_p]),
     "cw_batch_size": (C.c_uint32, [C.c_void_p]),
+    "cw_batch_strands": (C.c_uint32, [C.c_void_p]),
     "cw_set_input_signal": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p]),
     "cw_set_inputs_json": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p]),
     "cw_set_inputs": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -142,6 +143,7 @@ class Batch:
         h = C.c_void_p()
         _chk(lib().cw_batch_create(circuit.h, device, batch, C.c_void_p(stream or 0), C.byref(h)))
         self.h = h
+        self.strands = lib().cw_batch_strands(h)
 
     def close(self):
         if self.h:

@@ -67,6 +67,8 @@ int64_t cw_input_size(const cw_circuit *c, const char *name, uint32_t *start_slo
 int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *stream, cw_batch **out);
 void cw_batch_free(cw_batch *b);
 uint32_t cw_batch_size(const cw_batch *b);
+/* strands (waves cooperating on the same 64 instances) of the schedule variant picked for this batch */
+uint32_t cw_batch_strands(const cw_batch *b);
 
 /* setInputSignal(h, i, val) (calcwit.cpp:77-97) for one instance; `name` is hashed with FNV-1a
  * (calcwit.cpp:17-24).  val = canonical 32-byte little-endian value, reduced mod q by the caller. */

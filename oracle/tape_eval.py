@@ -92,16 +92,27 @@ def check_r1cs(q: int, constraints, w) -> int | None:
 # D_* numbering of circom_amd/csrc/cw_tape.h
 (D_COPY, D_ADD, D_SUB, D_NEG, D_MMUL, D_INV, D_IDIV, D_MOD, D_POW, D_SHL, D_SHR, D_BAND, D_BOR, D_BXOR,
  D_BNOT, D_LT, D_GT, D_LEQ, D_GEQ, D_EQ, D_NEQ, D_LAND, D_LOR, D_LNOT, D_SELECT, D_EXT, D_ASSERT_EQ,
- D_ASSERT_NZ) = range(28)
+ D_ASSERT_NZ, D_ALSO, D_BARRIER) = range(30)
 _DBIN = {D_ADD: "add", D_SUB: "sub", D_IDIV: "idiv", D_MOD: "mod", D_POW: "pow", D_SHL: "shl", D_SHR: "shr",
          D_BAND: "band", D_BOR: "bor", D_BXOR: "bxor", D_LT: "lt", D_GT: "gt", D_LEQ: "leq", D_GEQ: "geq",
          D_EQ: "eq", D_NEQ: "neq", D_LAND: "land", D_LOR: "lor"}
-_DUN = {D_NEG: "neg", D_BNOT: "bnot", D_LNOT: "lnot", D_INV: "inv"}
+_DUN = {D_NEG: "neg", D_BNOT: "bnot", D_LNOT: "lnot", D_INV: "inv", D_COPY: None}
 
 
-def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict, rbits: int = 261):
-    """Evaluate a lowered schedule (rows: (n,4) uint32 array as in the .cwt file) for one instance.
-    Returns (signal values, status) with status = 0 | 1 + (row << 8) like the kernel."""
+class ScheduleHazard(Exception):
+    """The schedule violates the executor's memory model (race between strands / stale prefetch)."""
+
+
+def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict, rbits: int = 261,
+              stream_off=None):
+    """Evaluate a lowered schedule exactly the way cw_eval_kernel does, for one instance:
+      * every strand (stream) walks its own rows; strands meet at BARRIER rows,
+      * operands of row r+1 are fetched BEFORE row r stores its result (one-row-ahead prefetch), except
+        kind-3 operands, which are the previous value-producing row's result held in a register,
+      * ALSO rows store that register to extra destinations.
+    Strands of one epoch are simulated one after the other; any cross-strand read-after-write or
+    write-after-read inside an epoch is reported as a ScheduleHazard (on the GPU it would be a race).
+    Returns (signal values, status) with status = 0 | bits + (row << 8) like the kernel."""
     f = Field(q)
     rinv = pow(1 << rbits, -1, q)        # MMUL = a*b*R'^-1 with the schedule's radix (device: R' = 2^261)
     sig = [0] * n_signals
@@ -110,50 +121,122 @@ def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict,
         sig[k] = v % q
     tmp = [0] * max(n_tslots, 1)
     bins = {k: getattr(f, v) for k, v in _DBIN.items()}
-    uns = {k: getattr(f, v) for k, v in _DUN.items()}
+    uns = {k: (getattr(f, v) if v else (lambda x: x)) for k, v in _DUN.items()}
+    rows = [tuple(int(x) for x in r) for r in rows]
+    if stream_off is None:
+        stream_off = [0, len(rows)]
+    ns = len(stream_off) - 1
+    pc = [int(stream_off[s]) for s in range(ns)]
+    end = [int(stream_off[s + 1]) for s in range(ns)]
+    prev = [0] * ns
+    status = [0]
+    writer = {}      # (kind, slot) -> (epoch, strand) of the last write
+    reader = {}      # (kind, slot) -> set of (epoch, strand) readers in the current epoch
+    epoch = 0
 
-    def rd(k, v):
-        return sig[v] if k == 0 else (tmp[v] if k == 1 else consts[v])
+    def mem_read(s, k, v):
+        key = (k, v)
+        w = writer.get(key)
+        if w is not None and w[0] == epoch and w[1] != s:
+            raise ScheduleHazard("strand %d reads %s written by strand %d in the same epoch" % (s, key, w[1]))
+        reader.setdefault(key, set()).add(s)
+        return sig[v] if k == 0 else tmp[v]
 
-    status = 0
-    r = 0
-    n = len(rows)
-    while r < n:
-        w0, dst, a_, b_ = (int(x) for x in rows[r])
-        op, dk, ak, bk = w0 & 0xFF, (w0 >> 8) & 3, (w0 >> 10) & 3, (w0 >> 12) & 3
-        a = rd(ak, a_)
-        res = None
-        if op == D_MMUL:
-            res = a * rd(bk, b_) * rinv % q
-        elif op in bins:
-            try:
-                res = bins[op](a, rd(bk, b_))
-            except FieldError:
-                if status == 0:
-                    status = 2 | (r << 8)
-                res = 0
-        elif op == D_COPY:
-            res = a
-        elif op in uns:
-            res = uns[op](a)
-        elif op == D_SELECT:
-            b = rd(bk, b_)
-            r += 1
-            e0, _, ea, _ = (int(x) for x in rows[r])
-            c = rd((e0 >> 10) & 3, ea)
-            res = b if a != 0 else c
-        elif op == D_ASSERT_EQ:
-            if a != rd(bk, b_) and status == 0:
-                status = 1 | (r << 8)
-        elif op == D_ASSERT_NZ:
-            if a == 0 and status == 0:
-                status = 1 | (r << 8)
+    def fetch(s, k, v):
+        if k == 2:
+            return consts[v]
+        if k == 3:
+            return None               # PREV: resolved at execution time
+        return mem_read(s, k, v)
+
+    def mem_write(s, k, v, val):
+        key = (k, v)
+        rs = reader.get(key)
+        if rs and (rs - {s}):
+            raise ScheduleHazard("strand %d overwrites %s read by another strand in the same epoch" % (s, key))
+        w = writer.get(key)
+        if w is not None and w[0] == epoch and w[1] != s:
+            raise ScheduleHazard("two strands write %s in the same epoch" % (key,))
+        writer[key] = (epoch, s)
+        if k == 0:
+            sig[v] = val
         else:
-            raise ValueError("bad device op %d" % op)
-        if res is not None:
-            if dk == 0:
-                sig[dst] = res
+            tmp[v] = val
+
+    def operands_of(s, r):
+        w0, _, a_, b_ = rows[r]
+        op = w0 & 0xFF
+        if op in (D_ALSO, D_BARRIER, D_EXT):
+            return None, None
+        ak, bk = (w0 >> 10) & 3, (w0 >> 12) & 3
+        a = fetch(s, ak, a_)
+        b = None if op in _DUN or op == D_ASSERT_NZ else fetch(s, bk, b_)
+        return a, b
+
+    def run_strand(s):
+        """run strand s up to (and over) its next BARRIER; returns False when the stream ended"""
+        r = pc[s]
+        if r >= end[s]:
+            return False
+        pre = operands_of(s, r)
+        while r < end[s]:
+            w0, dst, a_, b_ = rows[r]
+            op, dk, ak, bk = w0 & 0xFF, (w0 >> 8) & 3, (w0 >> 10) & 3, (w0 >> 12) & 3
+            a, b = pre
+            step = 2 if op == D_SELECT else 1
+            nxt = r + step
+            if op == D_BARRIER:            # nothing is prefetched across a barrier
+                pc[s] = r + 1
+                return True
+            pre = operands_of(s, nxt) if nxt < end[s] else (None, None)    # prefetch BEFORE this row's stores
+            if op == D_ALSO:
+                n = (w0 >> 16) & 3
+                for kk, vv in ((dk, dst), (ak, a_), (bk, b_))[:n]:
+                    mem_write(s, kk, vv, prev[s])
+                r = nxt
+                continue
+            if ak == 3:
+                a = prev[s]
+            if bk == 3:
+                b = prev[s]
+            res = None
+            if op == D_MMUL:
+                res = a * b * rinv % q
+            elif op in bins:
+                try:
+                    res = bins[op](a, b)
+                except FieldError:
+                    if status[0] == 0:
+                        status[0] = 2 | (r << 8)
+                    res = 0
+            elif op in uns:
+                res = uns[op](a)
+            elif op == D_SELECT:
+                e0, _, ea, _ = rows[r + 1]
+                c = fetch(s, (e0 >> 10) & 3, ea)
+                res = b if a != 0 else c
+            elif op == D_ASSERT_EQ:
+                if a != b and status[0] == 0:
+                    status[0] = 1 | (r << 8)
+            elif op == D_ASSERT_NZ:
+                if a == 0 and status[0] == 0:
+                    status[0] = 1 | (r << 8)
             else:
-                tmp[dst] = res
-        r += 1
-    return sig, status
+                raise ValueError("bad device op %d" % op)
+            if res is not None:
+                prev[s] = res
+                if dk != 2:
+                    mem_write(s, dk, dst, res)
+            r = nxt
+        pc[s] = r
+        return False
+
+    alive = True
+    while alive:
+        alive = False
+        for s in range(ns):
+            if run_strand(s):
+                alive = True
+        epoch += 1
+        reader.clear()
+    return sig, status[0]

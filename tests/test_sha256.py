@@ -44,12 +44,12 @@ def test_sha256_lowered_schedule_matches(sha64):
     t = lower(fc)
     inp = {fc.main_input_start + i: b for i, b in enumerate(_bits(b"GPU->wtn"))}
     a, failed = eval_flat(fc.fp.q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp)
-    b, st = eval_rows(fc.fp.q, t.n_signals, t.n_tslots, t.consts, t.rows, inp)
+    b, st = eval_rows(fc.fp.q, t.n_signals, t.n_tslots, t.consts, t.rows, inp, stream_off=t.stream_off)
     assert failed is None and st == 0 and a == b
     # non-bit inputs: the circuit does not constrain its inputs; values must still agree until an assert trips
     inp[fc.main_input_start + 3] = 7
     a, failed = eval_flat(fc.fp.q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp)
-    b, st = eval_rows(fc.fp.q, t.n_signals, t.n_tslots, t.consts, t.rows, inp)
+    b, st = eval_rows(fc.fp.q, t.n_signals, t.n_tslots, t.consts, t.rows, inp, stream_off=t.stream_off)
     assert (failed is None) == (st == 0)
     if failed is None:
         assert a == b
