@@ -182,9 +182,9 @@ struct HashEntry {
 };
 
 struct Variant {               // one lowering of the schedule for a given strand count
-    uint32_t n_strands = 1, n_tslots = 0;
+    uint32_t n_strands = 1, n_tslots = 0, n_lds = 0;
     std::vector<CwRow> rows;
-    std::vector<uint32_t> stream_off;
+    std::vector<uint32_t> stream_off, extras, extra_off;
 };
 
 struct cw_circuit {
@@ -229,7 +229,7 @@ static int load_tape(cw_circuit *c, const char *path) {
     if (!read_file(path, b)) return fail(CW_EIO, std::string("tape file not found: ") + path);
     if (b.size() < 16 + 32 + 48 || memcmp(b.data(), "CWTP", 4)) return fail(CW_EIO, "bad tape magic");
     const uint32_t *h = (const uint32_t *)(b.data() + 4);
-    if (h[0] != 2) return fail(CW_EIO, "unsupported tape version");
+    if (h[0] != 3) return fail(CW_EIO, "unsupported tape version");
     if (h[1] != 4) return fail(CW_EIO, "only 4x64-bit primes are supported (bn128, bls12381, ...)");
     uint32_t n_variants = h[2];
     size_t off = 16;
@@ -266,23 +266,32 @@ static int load_tape(cw_circuit *c, const char *path) {
     }
     if (n_variants == 0) return fail(CW_EIO, "tape holds no schedule");
     for (uint32_t v = 0; v < n_variants; v++) {
-        if (off + 16 > b.size()) return fail(CW_EIO, "tape variant truncated");
-        uint32_t vh[4];
-        memcpy(vh, b.data() + off, 16);
-        off += 16;
+        if (off + 32 > b.size()) return fail(CW_EIO, "tape variant truncated");
+        uint32_t vh[8];
+        memcpy(vh, b.data() + off, 32);
+        off += 32;
         Variant var;
         var.n_strands = vh[0];
         var.n_tslots = vh[1];
-        uint32_t nrows = vh[2];
+        uint32_t nrows = vh[2], nextras = vh[3];
+        var.n_lds = vh[4];
         if (var.n_strands == 0 || var.n_strands > 16) return fail(CW_EIO, "tape variant: bad strand count");
-        size_t need = (size_t)(var.n_strands + 1) * 4 + (size_t)nrows * 16;
+        if (var.n_lds > 72) return fail(CW_EIO, "tape variant: too many LDS slots");
+        size_t need = (size_t)(var.n_strands + 1) * 8 + (size_t)nrows * 16 + (size_t)nextras * 4;
         if (off + need > b.size()) return fail(CW_EIO, "tape variant truncated");
         var.stream_off.resize(var.n_strands + 1);
         memcpy(var.stream_off.data(), b.data() + off, (size_t)(var.n_strands + 1) * 4);
         off += (size_t)(var.n_strands + 1) * 4;
+        var.extra_off.resize(var.n_strands + 1);
+        memcpy(var.extra_off.data(), b.data() + off, (size_t)(var.n_strands + 1) * 4);
+        off += (size_t)(var.n_strands + 1) * 4;
         var.rows.resize(nrows);
         memcpy(var.rows.data(), b.data() + off, (size_t)nrows * 16);
         off += (size_t)nrows * 16;
+        var.extras.resize(nextras);
+        memcpy(var.extras.data(), b.data() + off, (size_t)nextras * 4);
+        off += (size_t)nextras * 4;
+        if (var.extra_off[var.n_strands] + 4 != nextras) return fail(CW_EIO, "tape variant: bad extra offsets");
         if (var.stream_off[var.n_strands] != nrows) return fail(CW_EIO, "tape variant: bad stream offsets");
         uint64_t mm = 0;
         for (auto &r : var.rows) {
@@ -471,7 +480,7 @@ struct cw_batch {
     size_t v_bytes = 0;
     CwRow *d_rows = nullptr;
     const Variant *var = nullptr;
-    uint32_t *d_stream_off = nullptr;
+    uint32_t *d_stream_off = nullptr, *d_extras = nullptr, *d_extra_off = nullptr;
     uint32_t *d_consts = nullptr, *d_w2s = nullptr, *d_status = nullptr, *d_first_bad = nullptr;
     uint32_t *d_rptr = nullptr, *d_rslot = nullptr, *d_rcoef = nullptr, *d_rctab = nullptr;
     void *d_in = nullptr;          // AoS staging [batch][n_in][32]
@@ -500,7 +509,7 @@ extern "C" void cw_batch_free(cw_batch *b) {
     }
     hipSetDevice(b->device);
     hipStreamSynchronize(b->stream);
-    void *ptrs[] = {b->d_V, b->d_rows, b->d_stream_off, b->d_consts, b->d_w2s, b->d_status, b->d_first_bad,
+    void *ptrs[] = {b->d_V, b->d_rows, b->d_stream_off, b->d_extras, b->d_extra_off, b->d_consts, b->d_w2s, b->d_status, b->d_first_bad,
                     b->d_rptr, b->d_rslot, b->d_rcoef, b->d_rctab, b->d_in, b->d_gather};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -563,6 +572,8 @@ extern "C" int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *
     } while (0)
     TRY(upload(&b->d_rows, b->var->rows, b->stream));
     TRY(upload(&b->d_stream_off, b->var->stream_off, b->stream));
+    TRY(upload(&b->d_extras, b->var->extras, b->stream));
+    TRY(upload(&b->d_extra_off, b->var->extra_off, b->stream));
     TRY(upload(&b->d_consts, c->consts, b->stream));
     TRY(upload(&b->d_w2s, c->w2s, b->stream));
     TRY(hipMalloc((void **)&b->d_status, (size_t)b->Bp * 4));
@@ -875,8 +886,8 @@ extern "C" int cw_run(cw_batch *b) {
     const void *in = b->ext_in ? b->ext_in : b->d_in;
     HIPCHK(cwk_init(b->stream, b->d_V, b->Bp, b->d_status, b->d_first_bad));
     HIPCHK(cwk_ingest(b->stream, in, b->d_V, c->input_start, c->n_inputs, b->batch, b->Bp));
-    HIPCHK(cwk_eval(b->stream, c->need_full, b->d_rows, b->d_stream_off, b->var->n_strands, b->d_V, b->d_consts,
-                    c->n_signals, b->Bp, b->batch, b->d_status, c->P));
+    HIPCHK(cwk_eval(b->stream, c->need_full, b->d_rows, b->d_stream_off, b->d_extras, b->d_extra_off, b->var->n_strands,
+                    b->var->n_lds, b->d_V, b->d_consts, c->n_signals, b->Bp, b->batch, b->d_status, c->P));
     b->ran = true;
     return CW_OK;
 }

@@ -63,75 +63,105 @@ __global__ void __launch_bounds__(CW_BLOCK) cw_ingest_kernel(const uint4 *__rest
 
 // ---- schedule evaluation (the hot path) ---------------------------------------------------------------
 // One lane = one instance.  A workgroup = S waves ("strands") that all work on the SAME 64 instances,
-// each walking its own row stream of the schedule; strands exchange values through the value table and
-// meet at BARRIER rows (hip_elements/lower.py pass C).  S = 1 for large batches (instance parallelism
-// alone fills the chip), S up to 16 for the small batches of the BASELINE configs.
-// Latency hiding inside a strand: (1) operands of row r+1 are fetched before row r executes
-// (one-row-ahead software prefetch; legal because the lowering encodes any operand produced by the
-// preceding row as kind PREV = register forwarding), (2) pure copies never load: they are extra
-// destinations (ALSO rows) of the row that produced the value.
-// FULL selects the variant that also carries the slow-path operators (INV/IDIV/MOD/POW).
-struct Opnds { fe a, b; };
+// each walking its own row stream of the schedule; strands hand values to each other through LDS slots
+// (or, when the LDS pool is exhausted, the value table) and meet at BARRIER rows
+// (hip_elements/lower.py passes C/D).  S = 1 for large batches (instance parallelism alone fills the
+// chip), S up to 16 for the small batches of the BASELINE configs.
+// Latency hiding inside a strand:
+//  (1) operands of row r+1 are fetched before row r executes (one-row-ahead software prefetch; legal
+//      because the lowering encodes any operand produced by the preceding row as kind PREV = register
+//      forwarding).  The fetch is branch-free — one pointer select, two unconditional 16-byte loads per
+//      operand — so the loaded registers ARE the loop-carried registers and nothing forces an early wait;
+//  (2) pure copies never load: they are extra destinations of the row that produced the value, taken
+//      from the strand's extra-destination table (scalar loads issued before the row's arithmetic);
+//  (3) a LIGHT barrier only orders LDS traffic (s_waitcnt lgkmcnt(0) + s_barrier): global stores stay in
+//      flight across it.  Only FULL barriers (hand-off through global memory) drain vmcnt.
+// FULL_OPS selects the variant that also carries the slow-path operators (INV/IDIV/MOD/POW).
+extern __shared__ uint4 cw_lds[];       // [slot][2 halves][64 lanes] x 16 B
 
-__device__ __forceinline__ void fetch_operands(const CwRow &row, const uint4 *V, const uint32_t *__restrict__ consts,
-                                               uint32_t tmp_base, uint32_t Bp, uint32_t i, fe &a, fe &b) {
-    const uint32_t op = row.w0 & 0xFF;
-    if (op >= D_EXT && op != D_ASSERT_EQ && op != D_ASSERT_NZ) return;      // EXT / ALSO / BARRIER: no operands
-    const uint32_t ak = (row.w0 >> 10) & 3, bk = (row.w0 >> 12) & 3;
-    if (ak == K_CONST) a = c_load(consts, row.a);
-    else if (ak != K_PREV) a = v_load(V, row.a + (ak == K_TMP ? tmp_base : 0), Bp, i);
-    const bool unary = (op == D_COPY) | (op == D_NEG) | (op == D_BNOT) | (op == D_LNOT) | (op == D_INV) |
-                       (op == D_ASSERT_NZ);
-    if (!unary) {
-        if (bk == K_CONST) b = c_load(consts, row.b);
-        else if (bk != K_PREV) b = v_load(V, row.b + (bk == K_TMP ? tmp_base : 0), Bp, i);
-    }
+__device__ __forceinline__ fe lds_load(uint32_t slot, uint32_t lane) {
+    const uint4 lo = cw_lds[(slot * 2 + 0) * 64 + lane], hi = cw_lds[(slot * 2 + 1) * 64 + lane];
+    fe r;
+    r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
+    r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+    return r;
+}
+__device__ __forceinline__ void lds_store(uint32_t slot, uint32_t lane, const fe &x) {
+    cw_lds[(slot * 2 + 0) * 64 + lane] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    cw_lds[(slot * 2 + 1) * 64 + lane] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
 }
 
-template <bool FULL>
+// branch-free operand fetch from global memory: value-table slot, constant (all lanes read the same 32 B),
+// or a harmless dummy (slot 0) for kinds that are resolved at execution time (PREV, LDS, none)
+__device__ __forceinline__ fe fetch_global(uint32_t kind, uint32_t idx, const uint4 *V, const uint4 *consts4,
+                                           uint32_t tmp_base, uint32_t Bp, uint32_t i) {
+    const bool is_val = kind <= K_TMP;
+    const bool is_const = kind == K_CONST;
+    const uint32_t slot = is_val ? idx + (kind == K_TMP ? tmp_base : 0u) : 0u;
+    const uint4 *p = is_const ? consts4 + (size_t)idx * 2 : V + ((size_t)slot * 2 * Bp + i);
+    const size_t step = is_const ? 1 : Bp;
+    const uint4 lo = p[0], hi = p[step];
+    fe r;
+    r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
+    r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+    return r;
+}
+
+template <bool FULL_OPS>
 __global__ void __launch_bounds__(1024)
-cw_eval_kernel(const CwRow *__restrict__ rows, const uint32_t *__restrict__ stream_off, uint4 *V,
+cw_eval_kernel(const CwRow *__restrict__ rows, const uint32_t *__restrict__ stream_off,
+               const uint32_t *__restrict__ extras, const uint32_t *__restrict__ extra_off, uint4 *V,
                const uint32_t *__restrict__ consts, uint32_t tmp_base, uint32_t Bp, uint32_t batch,
                uint32_t *status, FpParams P) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t i = blockIdx.x * 64 + (threadIdx.x & 63);       // < Bp (Bp is a multiple of 256 >= batch)
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t i = blockIdx.x * 64 + lane;                     // < Bp (Bp is a multiple of 256 >= batch)
+    const uint4 *consts4 = (const uint4 *)consts;
     uint32_t r = stream_off[wave];
     const uint32_t end = stream_off[wave + 1];
+    uint32_t xp = extra_off[wave];
     uint32_t st = 0;
     fe prev = fe_zero();
-    fe na = fe_zero(), nb = fe_zero();
     CwRow nrow = rows[r < end ? r : 0];
-    if (r < end) fetch_operands(nrow, V, consts, tmp_base, Bp, i, na, nb);
+    fe na = fetch_global((nrow.w0 >> SH_AK) & 7, nrow.a, V, consts4, tmp_base, Bp, i);
+    fe nb = fetch_global((nrow.w0 >> SH_BK) & 7, nrow.b, V, consts4, tmp_base, Bp, i);
     while (r < end) {
         const CwRow row = nrow;
         const uint32_t op = row.w0 & 0xFF;
-        const uint32_t dk = (row.w0 >> 8) & 3, ak = (row.w0 >> 10) & 3, bk = (row.w0 >> 12) & 3;
+        const uint32_t dk = (row.w0 >> SH_DK) & 7, ak = (row.w0 >> SH_AK) & 7, bk = (row.w0 >> SH_BK) & 7;
+        const uint32_t nx = (row.w0 >> SH_NX) & 0xFFF;
         const uint32_t next = r + (op == D_SELECT ? 2u : 1u);
-        if (op == D_BARRIER) {
-            __syncthreads();                                         // nothing is prefetched across a barrier
+        if (op == D_BARRIER) {                                       // nothing is prefetched across a barrier
+            if (row.dst) {
+                __syncthreads();                                     // FULL: also drains this wave's global stores
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // LDS writes of this wave are done ...
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // ... before any wave reads them
+            }
             r = next;
             if (r < end) {
                 nrow = rows[r];
-                fetch_operands(nrow, V, consts, tmp_base, Bp, i, na, nb);
+                na = fetch_global((nrow.w0 >> SH_AK) & 7, nrow.a, V, consts4, tmp_base, Bp, i);
+                nb = fetch_global((nrow.w0 >> SH_BK) & 7, nrow.b, V, consts4, tmp_base, Bp, i);
             }
             continue;
         }
-        fe a = (ak == K_PREV) ? prev : na;
-        fe b = (bk == K_PREV) ? prev : nb;
+        fe a = na, b = nb;
+        // first extra destinations: scalar loads issued now, consumed after the arithmetic
+        // (unconditional: the table is padded by 4 entries, so the four scalar loads batch into one wait)
+        const uint32_t x0 = extras[xp], x1 = extras[xp + 1], x2 = extras[xp + 2], x3 = extras[xp + 3];
         CwRow ext;
         if (op == D_SELECT) ext = rows[r + 1];
-        if (next < end) {                                            // prefetch the next row's operands
+        if (next < end) {                                            // prefetch the next row and its operands
             nrow = rows[next];
-            fetch_operands(nrow, V, consts, tmp_base, Bp, i, na, nb);
+            na = fetch_global((nrow.w0 >> SH_AK) & 7, nrow.a, V, consts4, tmp_base, Bp, i);
+            nb = fetch_global((nrow.w0 >> SH_BK) & 7, nrow.b, V, consts4, tmp_base, Bp, i);
         }
-        if (op == D_ALSO) {
-            const uint32_t n = (row.w0 >> 16) & 3;
-            v_store(V, row.dst + (dk == K_TMP ? tmp_base : 0), Bp, i, prev);
-            if (n > 1) v_store(V, row.a + (ak == K_TMP ? tmp_base : 0), Bp, i, prev);
-            if (n > 2) v_store(V, row.b + (bk == K_TMP ? tmp_base : 0), Bp, i, prev);
-            r = next;
-            continue;
-        }
+        if (ak == K_PREV) a = prev;
+        else if (ak == K_LDS) a = lds_load(row.a, lane);
+        if (bk == K_PREV) b = prev;
+        else if (bk == K_LDS) b = lds_load(row.b, lane);
         fe d;
         bool has_d = true;
         switch (op) {
@@ -156,11 +186,11 @@ cw_eval_kernel(const CwRow *__restrict__ rows, const uint32_t *__restrict__ stre
         case D_LOR: d = fe_small(!fe_is_zero(a) | !fe_is_zero(b)); break;
         case D_LNOT: d = fe_small(fe_is_zero(a)); break;
         case D_SELECT: {
-            // cond = a, then-value = b, else-value in the following EXT row (always read from memory)
-            const uint32_t ck = (ext.w0 >> 10) & 3;
+            // cond = a, then-value = b, else-value in the following EXT row (read at execution time)
+            const uint32_t ck = (ext.w0 >> SH_AK) & 7;
             fe c;
-            if (ck == K_CONST) c = c_load(consts, ext.a);
-            else c = v_load(V, ext.a + (ck == K_TMP ? tmp_base : 0), Bp, i);
+            if (ck == K_LDS) c = lds_load(ext.a, lane);
+            else c = fetch_global(ck, ext.a, V, consts4, tmp_base, Bp, i);
             const bool t = !fe_is_zero(a);
             for (int k = 0; k < 8; k++) d.v[k] = t ? b.v[k] : c.v[k];
             break;
@@ -174,7 +204,7 @@ cw_eval_kernel(const CwRow *__restrict__ rows, const uint32_t *__restrict__ stre
             has_d = false;
             break;
         default:
-            if (FULL) {
+            if (FULL_OPS) {
                 switch (op) {
                 case D_INV: d = fe_pow_uniform(a, P.qm2, P); break;
                 case D_POW: d = fe_pow(a, b, P); break;
@@ -199,8 +229,15 @@ cw_eval_kernel(const CwRow *__restrict__ rows, const uint32_t *__restrict__ stre
         }
         if (has_d) {
             prev = d;
-            if (dk != KD_NONE) v_store(V, row.dst + (dk == K_TMP ? tmp_base : 0), Bp, i, d);
+            if (dk == K_LDS) lds_store(row.dst, lane, d);
+            else if (dk != KD_NONE) v_store(V, row.dst + (dk == K_TMP ? tmp_base : 0), Bp, i, d);
+            for (uint32_t e = 0; e < nx; e++) {
+                const uint32_t x = e == 0 ? x0 : e == 1 ? x1 : e == 2 ? x2 : e == 3 ? x3 : extras[xp + e];
+                if (x & X_LDS) lds_store(x & 0x3FFFFFFFu, lane, d);
+                else v_store(V, (x & 0x3FFFFFFFu) + ((x & X_TMP) ? tmp_base : 0u), Bp, i, d);
+            }
         }
+        xp += nx;
         r = next;
     }
     if (st && i < batch) atomicCAS(&status[i], 0u, st);
@@ -340,16 +377,22 @@ hipError_t cwk_ingest(hipStream_t s, const void *in, void *V, uint32_t input_sta
                        Bp);
     return hipGetLastError();
 }
-hipError_t cwk_eval(hipStream_t s, bool full, const CwRow *rows, const uint32_t *stream_off, uint32_t n_strands, void *V,
-                    const uint32_t *consts, uint32_t tmp_base, uint32_t Bp, uint32_t batch, uint32_t *status,
-                    const FpParams &P) {
+hipError_t cwk_eval(hipStream_t s, bool full, const CwRow *rows, const uint32_t *stream_off, const uint32_t *extras,
+                    const uint32_t *extra_off, uint32_t n_strands, uint32_t n_lds, void *V, const uint32_t *consts,
+                    uint32_t tmp_base, uint32_t Bp, uint32_t batch, uint32_t *status, const FpParams &P) {
     dim3 grid((batch + 63) / 64), block(64 * n_strands);
+    const size_t lds_bytes = (size_t)n_lds * 2048;
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = full ? hipFuncSetAttribute((const void *)cw_eval_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
+                            : hipFuncSetAttribute((const void *)cw_eval_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
     if (full)
-        hipLaunchKernelGGL(cw_eval_kernel<true>, grid, block, 0, s, rows, stream_off, (uint4 *)V, consts, tmp_base, Bp, batch,
-                           status, P);
+        hipLaunchKernelGGL(cw_eval_kernel<true>, grid, block, lds_bytes, s, rows, stream_off, extras, extra_off, (uint4 *)V,
+                           consts, tmp_base, Bp, batch, status, P);
     else
-        hipLaunchKernelGGL(cw_eval_kernel<false>, grid, block, 0, s, rows, stream_off, (uint4 *)V, consts, tmp_base, Bp, batch,
-                           status, P);
+        hipLaunchKernelGGL(cw_eval_kernel<false>, grid, block, lds_bytes, s, rows, stream_off, extras, extra_off, (uint4 *)V,
+                           consts, tmp_base, Bp, batch, status, P);
     return hipGetLastError();
 }
 hipError_t cwk_r1cs(hipStream_t s, const uint32_t *ptr, const uint32_t *tslot, const uint32_t *tcoef, const uint32_t *ctab,

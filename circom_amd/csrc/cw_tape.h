@@ -9,12 +9,21 @@ enum : uint32_t {
     D_ASSERT_NZ, D_ALSO, D_BARRIER, D_NOPS
 };
 
-// operand kinds (2 bits each in row.w0: dst<<8, a<<10, b<<12); ALSO rows: bits 16-17 = number of dsts
-enum : uint32_t { K_SIG = 0, K_TMP = 1, K_CONST = 2, K_PREV = 3 };
-enum : uint32_t { KD_NONE = 2 };   // destination kind "no store" (value only forwarded through PREV)
+// row.w0 = op[0:8) | dk[8:11) | ak[11:14) | bk[14:17) | n_extra[17:29)
+#define SH_DK 8
+#define SH_AK 11
+#define SH_BK 14
+#define SH_NX 17
+// operand kinds: value-table signal slot, value-table temp slot, constant index, PREV (result of the previous
+// value-producing row of the strand, forwarded in registers), LDS slot of the workgroup
+enum : uint32_t { K_SIG = 0, K_TMP = 1, K_CONST = 2, K_PREV = 3, K_LDS = 4 };
+enum : uint32_t { KD_NONE = 2 };   // destination kind "no store" (value only forwarded); 0/1/4 as above
+// extra-destination table entries: slot number | flags
+#define X_TMP 0x80000000u
+#define X_LDS 0x40000000u
 
 struct CwRow {       // 16 bytes, read with one scalar dwordx4 load
-    uint32_t w0;     // op | dk<<8 | ak<<10 | bk<<12
+    uint32_t w0;     // see SH_* above; BARRIER rows: dst = 1 -> also drain global stores
     uint32_t dst;
     uint32_t a;
     uint32_t b;

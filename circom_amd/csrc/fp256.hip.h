@@ -236,9 +236,10 @@ __device__ __forceinline__ fe fe_shl_raw(const fe &a, uint32_t s) {
     FE_UNROLL for (int i = 0; i < 8; i++) u.v[i] = s2 ? ((i >= 2) ? t.v[(i >= 2) ? i - 2 : 0] : 0u) : t.v[i];
     FE_UNROLL for (int i = 0; i < 8; i++) w.v[i] = s1 ? ((i >= 1) ? u.v[(i >= 1) ? i - 1 : 0] : 0u) : u.v[i];
     const uint32_t bs = s & 31;
+    const uint32_t rs = (32u - bs) & 31u;                 // v_alignbit(hi, lo, rs) = low 32 bits of (hi:lo) >> rs
     fe r;
     FE_UNROLL for (int i = 7; i >= 1; i--)
-        r.v[i] = (uint32_t)((((uint64_t)w.v[i] << 32) | w.v[i - 1]) << bs >> 32);
+        r.v[i] = bs ? __builtin_amdgcn_alignbit(w.v[i], w.v[i - 1], rs) : w.v[i];
     r.v[0] = w.v[0] << bs;
     return r;
 }
@@ -250,8 +251,7 @@ __device__ __forceinline__ fe fe_shr_raw(const fe &a, uint32_t s) {
     FE_UNROLL for (int i = 0; i < 8; i++) w.v[i] = s1 ? ((i + 1 < 8) ? u.v[(i + 1 < 8) ? i + 1 : 0] : 0u) : u.v[i];
     const uint32_t bs = s & 31;
     fe r;
-    FE_UNROLL for (int i = 0; i < 7; i++)
-        r.v[i] = (uint32_t)((((uint64_t)w.v[i + 1] << 32) | w.v[i]) >> bs);
+    FE_UNROLL for (int i = 0; i < 7; i++) r.v[i] = __builtin_amdgcn_alignbit(w.v[i + 1], w.v[i], bs);
     r.v[7] = w.v[7] >> bs;
     return r;
 }

@@ -25,11 +25,18 @@ Passes:
                 separated by workgroup barriers.  S = 1 keeps program order and needs no barrier.
   D slots       temp slot allocation by liveness (per row for S = 1, per barrier epoch for S > 1);
                 a temp whose every use is forwarded through the register (kind PREV) gets no slot.
-  E encode      rows are 4 x u32: w0 = op | dk<<8 | ak<<10 | bk<<12 | n<<16, then dst, a, b.
+  D slots       cross-strand values get an LDS slot of the workgroup while they are live (hand-off in ~100
+                cycles, and the barrier does not have to drain global stores); when the LDS pool is
+                exhausted the hand-off goes through global memory and the barrier after the producing
+                epoch is marked FULL (waits for vmcnt(0)).  Global temp slots by liveness; a temp whose
+                every use is PREV/LDS gets none.
+  E encode      rows are 4 x u32: w0 = op[0:8) | dk[8:11) | ak[11:14) | bk[14:17) | n_extra[17:29), then dst, a, b.
                 operand kinds: 0 signal slot, 1 temp slot, 2 constant index, 3 PREV (the previous
-                value-producing row of the same strand, forwarded in registers);
-                destination kinds: 0 signal, 1 temp, 2 none.  ALSO rows carry up to 3 extra
-                destinations of the preceding row; SELECT carries its third operand in an EXT row.
+                value-producing row of the same strand, forwarded in registers), 4 LDS slot;
+                destination kinds: 0 signal, 1 temp, 2 none, 4 LDS.  The n_extra further destinations
+                of a row (elided copies, LDS hand-off copy) are consecutive entries of the strand's
+                extra-destination table; SELECT carries its third operand in an EXT row; BARRIER rows
+                carry dst = 1 when they must also drain global stores.
   Invariant the kernel's one-row-ahead operand prefetch relies on: a row never reads FROM MEMORY a
   slot that the immediately preceding rows of its strand (back to and including the last
   value-producing row) write; such operands are always encoded as PREV.
@@ -72,6 +79,9 @@ class Tape:
         self.n_witness = 0
         self.rows = None            # (n,4) uint32, all strands concatenated
         self.stream_off = None      # uint32[n_strands+1] row offsets of each strand
+        self.extras = None          # uint32[]: extra destinations, in stream/row order
+        self.extra_off = None       # uint32[n_strands+1]: first extra-destination entry of each strand
+        self.n_lds = 0              # LDS value slots the workgroup needs
         self.n_strands = 1
         self.consts = []            # raw residues (python ints)
         self.witness2signal = None  # uint32[n_witness]
@@ -185,6 +195,75 @@ def _expand(fc: FlatCircuit):
     return rows, dconsts, nxt[0]
 
 
+def _reassociate(rows, n_vtemps):
+    """Pass A2: re-balance chains of field additions into trees.
+
+    Field addition is associative and commutative, so `(((x0+x1)+x2)+...)+xn` (what `lin += in[j][k]*e2`
+    loops of circomlib's BinSum/Num2Bits trace into) can be summed as a balanced tree: identical value, depth
+    log2(n) instead of n.  Only intermediate sums that are single-use temporaries are touched.  The tree is
+    emitted at the position of the chain's last row (all leaves are defined before it)."""
+    uses = {}
+    for r in rows:
+        for k, v in ((r.ak, r.av), (r.bk, r.bv), (r.ck, r.cv)):
+            if k == K_TMP:
+                uses[v] = uses.get(v, 0) + 1
+    prod = {}
+    for idx, r in enumerate(rows):
+        if r.dk == K_TMP:
+            prod[r.dv] = idx
+    absorbed = [False] * len(rows)
+    trees = {}
+    nxt = n_vtemps
+    for idx in range(len(rows) - 1, -1, -1):
+        r = rows[idx]
+        if absorbed[idx] or r.op != D_ADD:
+            continue
+        leaves = []
+        took = []
+        stack = [(r.bk, r.bv), (r.ak, r.av)]       # DFS, left operand first
+        while stack:
+            k, v = stack.pop()
+            if k == K_TMP and uses.get(v) == 1:
+                pi = prod.get(v)
+                if pi is not None and not absorbed[pi] and rows[pi].op == D_ADD and rows[pi].extra is None:
+                    pr = rows[pi]
+                    took.append(pi)
+                    stack.append((pr.bk, pr.bv))
+                    stack.append((pr.ak, pr.av))
+                    continue
+            leaves.append((k, v))
+        if len(took) < 2:
+            continue
+        for pi in took:
+            absorbed[pi] = True
+        # balanced pairwise reduction
+        new_rows = []
+        cur = leaves
+        while len(cur) > 2:
+            nx = []
+            for j in range(0, len(cur) - 1, 2):
+                t = nxt
+                nxt += 1
+                new_rows.append(_Row(D_ADD, K_TMP, t, cur[j][0], cur[j][1], cur[j + 1][0], cur[j + 1][1]))
+                nx.append((K_TMP, t))
+            if len(cur) % 2:
+                nx.append(cur[-1])
+            cur = nx
+        root = _Row(D_ADD, r.dk, r.dv, cur[0][0], cur[0][1], cur[1][0], cur[1][1])
+        root.extra = r.extra
+        new_rows.append(root)
+        trees[idx] = new_rows
+    out = []
+    for idx, r in enumerate(rows):
+        if absorbed[idx]:
+            continue
+        if idx in trees:
+            out.extend(trees[idx])
+        else:
+            out.append(r)
+    return out, nxt
+
+
 def _alias(rows, n_signals):
     """Pass B.  Value ids: signal s -> s, virtual temp t -> n_signals + t."""
     def vid(k, v):
@@ -279,61 +358,100 @@ def _schedule(rows, n_signals, n_strands):
     return streams, len(levels) - 1
 
 
+def lds_slots_for(n_strands: int) -> int:
+    """LDS value slots (64 lanes x 32 B = 2 KiB each) a workgroup of `n_strands` waves may use: 144 KiB per CU
+    shared by the 16/n_strands workgroups that fit a CU."""
+    return 0 if n_strands <= 1 else (72 * n_strands) // 16
+
+
+# row word 0 layout:  op[0:8) | dk[8:11) | ak[11:14) | bk[14:17) | n_extra[17:29)
+SH_DK, SH_AK, SH_BK, SH_NX = 8, 11, 14, 17
+MAX_EXTRA = 4095
+K_LDS = 4             # operand / destination kind: LDS slot of the workgroup (cross-strand hand-off)
+X_TMP, X_LDS = 1 << 31, 1 << 30       # flags of an entry of the extra-destination table
+
+
 def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
     q = fc.fp.q
     n_signals = fc.n_signals
     rows, dconsts, n_vtemps = _expand(fc)
-    n_expanded = len(rows)
+    if n_strands > 1:      # one strand prefers the original chains (register forwarding, no extra temps)
+        rows, n_vtemps = _reassociate(rows, n_vtemps)
     rows, n_elided = _alias(rows, n_signals)
-    streams, n_barriers = _schedule(rows, n_signals, n_strands)
-
-    # ---- pass D: which temps need a slot, and liveness ---------------------------------------------------
-    # time unit: row position for one strand, barrier epoch for several
+    streams, n_levels = _schedule(rows, n_signals, n_strands)
     multi = n_strands > 1
-    uses_mem = {}       # vtemp -> True if some use is not PREV-forwarded
-    last_use = {}       # vtemp -> last time it is read from memory
-    def_time = {}
-    plan = []           # per stream: list of (row | 'B', prev_flags(a,b), time)
-    for s in streams:
-        prev_val = None          # ('T'|'S', id) of the last value-producing row
+
+    def vid(k, v):
+        return v if k == K_SIG else n_signals + v
+
+    # ---- pass D1: walk the streams; find PREV-forwarded operands, cross-strand flows, liveness ---------------------
+    # time unit: row position for one strand, barrier epoch for several
+    prod_strand, def_time = {}, {}
+    plan = []           # per stream: list of [row | 'B', (prev_a, prev_b), time]
+    for si, s in enumerate(streams):
+        prev_val = None
         epoch = 0
         items = []
         for pos, r in enumerate(s):
             if r == "B":
                 epoch += 1
-                items.append(("B", None, epoch))
+                items.append(["B", None, epoch])
                 continue
             t = epoch if multi else pos
-            fl = []
-            for k, v in ((r.ak, r.av), (r.bk, r.bv)):
-                is_prev = prev_val is not None and (k, v) == prev_val
-                fl.append(is_prev)
-                if k == K_TMP and not is_prev:
-                    uses_mem[v] = True
-                    last_use[v] = max(last_use.get(v, -1), t)
-            if r.ck == K_TMP:          # SELECT's third operand is always read from memory
-                uses_mem[r.cv] = True
-                last_use[r.cv] = max(last_use.get(r.cv, -1), t)
-            items.append((r, tuple(fl), t))
+            fl = tuple(prev_val is not None and (k, v) == prev_val for k, v in ((r.ak, r.av), (r.bk, r.bv)))
+            items.append([r, fl, t])
             if r.op not in _NO_VALUE:
                 prev_val = (r.dk, r.dv) if r.dk in (K_SIG, K_TMP) else None
-                if r.dk == K_TMP:
-                    def_time[r.dv] = t
-            if r.extra:
-                for k, v in r.extra:
-                    if k == K_TMP:
-                        def_time[v] = t
+                if r.dk in (K_SIG, K_TMP):
+                    prod_strand[vid(r.dk, r.dv)] = si
+                    def_time[vid(r.dk, r.dv)] = t
         plan.append(items)
+    mem_last = {}       # value id -> last time it is read from memory by its OWN strand (or any strand if S = 1)
+    x_last = {}         # value id -> last epoch it is read by ANOTHER strand
+    for si, items in enumerate(plan):
+        for r, fl, t in items:
+            if r == "B":
+                continue
+            ops = [(r.ak, r.av, fl[0]), (r.bk, r.bv, fl[1]), (r.ck, r.cv, False)]
+            for k, v, is_prev in ops:
+                if k not in (K_SIG, K_TMP) or is_prev:
+                    continue
+                x = vid(k, v)
+                if multi and x in prod_strand and prod_strand[x] != si:
+                    x_last[x] = max(x_last.get(x, -1), t)
+                else:
+                    mem_last[x] = max(mem_last.get(x, -1), t)
 
-    # slot allocation in definition-time order
+    # ---- pass D2: LDS slots for cross-strand values; barriers that must also drain global stores -----------------
+    n_lds = lds_slots_for(n_strands)
+    lds_of = {}
+    full_after = set()          # epochs whose closing barrier must wait for global stores (vmcnt(0))
+    n_lds_used = 0
+    if multi:
+        free = list(range(n_lds - 1, -1, -1))
+        release = {}            # epoch -> slots that become reusable once that epoch is over
+        by_def = sorted((def_time[x], x) for x in x_last)
+        cur = -1
+        for t, x in by_def:
+            while cur < t - 1:
+                cur += 1
+                free.extend(release.pop(cur, ()))
+            if free:
+                sl = free.pop()
+                lds_of[x] = sl
+                n_lds_used = max(n_lds_used, sl + 1)
+                release.setdefault(x_last[x], []).append(sl)
+            else:
+                full_after.add(t)                       # hand-off through global memory
+                mem_last[x] = max(mem_last.get(x, -1), x_last[x])
+
+    # ---- pass D3: global temp slots (only temps that are actually read from global memory) ------------------------
     slot_of = {}
     n_tslots = 0
+    tmp_last = {x - n_signals: t for x, t in mem_last.items() if x >= n_signals}
     if multi:
-        # a slot freed by a last read in epoch e may be rewritten from epoch e+1 on (a barrier lies between)
-        by_time = sorted((t, v) for v, t in def_time.items() if uses_mem.get(v))
-        free_at = {}        # epoch -> list of slots that become free once that epoch is over
-        free = []
-        cur = -1
+        by_time = sorted((def_time[n_signals + v], v) for v in tmp_last)
+        free_at, free, cur = {}, [], -1
         for t, v in by_time:
             while cur < t - 1:
                 cur += 1
@@ -344,18 +462,17 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
                 sl = n_tslots
                 n_tslots += 1
             slot_of[v] = sl
-            free_at.setdefault(last_use[v], []).append(sl)
+            free_at.setdefault(tmp_last[v], []).append(sl)
     else:
         free = []
-        release = {}        # position -> temps whose last use is there
-        for v, t in last_use.items():
+        release = {}
+        for v, t in tmp_last.items():
             release.setdefault(t, []).append(v)
         for (r, fl, t) in plan[0]:
-            # operands are read before the destination is written: release first, then allocate
-            for v in release.get(t, ()):
+            for v in release.get(t, ()):        # operands are read before the destination is written
                 if v in slot_of:
                     free.append(slot_of[v])
-            if r != "B" and r.dk == K_TMP and uses_mem.get(r.dv):
+            if r != "B" and r.dk == K_TMP and r.dv in tmp_last:
                 if free:
                     sl = free.pop()
                 else:
@@ -363,21 +480,26 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
                     n_tslots += 1
                 slot_of[r.dv] = sl
 
-    # ---- pass E: encode ---------------------------------------------------------------------------------------
+    # ---- pass E: encode ------------------------------------------------------------------------------------------------
     enc = []
+    extras = []
     stream_off = [0]
-    n_also = n_prev = 0
-    for items in plan:
+    extra_off = [0]
+    n_prev = n_ldsops = 0
+    for si, items in enumerate(plan):
         for (r, fl, t) in items:
             if r == "B":
-                enc.append((D_BARRIER, 0, 0, 0))
+                enc.append((D_BARRIER, 1 if (t - 1) in full_after else 0, 0, 0))
                 continue
 
             def o_enc(k, v, is_prev):
                 if is_prev:
                     return KO_PREV, 0
-                if k == K_TMP:
-                    return K_TMP, slot_of[v]
+                if k in (K_SIG, K_TMP):
+                    x = vid(k, v)
+                    if x in lds_of and prod_strand.get(x) != si:
+                        return K_LDS, lds_of[x]
+                    return (K_TMP, slot_of[v]) if k == K_TMP else (K_SIG, v)
                 if k == K_NONE:
                     return 0, 0
                 return k, v
@@ -385,28 +507,33 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
             ka, va = o_enc(r.ak, r.av, fl[0])
             kb, vb = o_enc(r.bk, r.bv, fl[1])
             n_prev += fl[0] + fl[1]
+            n_ldsops += (ka == K_LDS) + (kb == K_LDS)
+            ex = []
             if r.dk == K_TMP:
-                if uses_mem.get(r.dv):
-                    kd, vd = K_TMP, slot_of[r.dv]
-                else:
-                    kd, vd = KD_NONE, 0
+                kd, vd = (K_TMP, slot_of[r.dv]) if r.dv in slot_of else (KD_NONE, 0)
             elif r.dk == K_SIG:
                 kd, vd = K_SIG, r.dv
             else:
                 kd, vd = KD_NONE, 0
-            enc.append((r.op | (kd << 8) | (ka << 10) | (kb << 12), vd, va, vb))
+            if r.dk in (K_SIG, K_TMP) and vid(r.dk, r.dv) in lds_of:
+                if kd == KD_NONE:
+                    kd, vd = K_LDS, lds_of[vid(r.dk, r.dv)]
+                else:
+                    ex.append(X_LDS | lds_of[vid(r.dk, r.dv)])
+            if r.extra:
+                for k, v in r.extra:
+                    if k == K_SIG:
+                        ex.append(v)
+                    elif v in slot_of:
+                        ex.append(X_TMP | slot_of[v])
+            assert len(ex) <= MAX_EXTRA, "fan-out of one value exceeds the extra-destination field"
+            enc.append((r.op | (kd << SH_DK) | (ka << SH_AK) | (kb << SH_BK) | (len(ex) << SH_NX), vd, va, vb))
+            extras.extend(ex)
             if r.op == D_SELECT:
                 kc, vc = o_enc(r.ck, r.cv, False)
-                enc.append((D_EXT | (kc << 10), 0, vc, 0))
-            if r.extra:
-                ex = [(k, (slot_of[v] if k == K_TMP else v)) for k, v in r.extra if k == K_SIG or uses_mem.get(v)]
-                for j in range(0, len(ex), 3):
-                    grp = ex[j:j + 3]
-                    kk = [g[0] for g in grp] + [0] * (3 - len(grp))
-                    vv = [g[1] for g in grp] + [0] * (3 - len(grp))
-                    enc.append((D_ALSO | (kk[0] << 8) | (kk[1] << 10) | (kk[2] << 12) | (len(grp) << 16), vv[0], vv[1], vv[2]))
-                    n_also += 1
+                enc.append((D_EXT | (kc << SH_AK), 0, vc, 0))
         stream_off.append(len(enc))
+        extra_off.append(len(extras))
     out = np.asarray(enc, dtype=np.uint32).reshape(-1, 4)
 
     t = Tape()
@@ -416,6 +543,9 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
     t.n_tslots = n_tslots
     t.rows = out
     t.stream_off = np.asarray(stream_off, dtype=np.uint32)
+    t.extras = np.asarray(extras + [0, 0, 0, 0], dtype=np.uint32)    # padded: the kernel always reads 4 ahead
+    t.extra_off = np.asarray(extra_off, dtype=np.uint32)
+    t.n_lds = n_lds_used
     t.n_strands = n_strands
     t.consts = dconsts
     if witness_map is None:
@@ -432,10 +562,13 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
         "addsub": int(((dops == D_ADD) | (dops == D_SUB) | (dops == D_NEG)).sum()),
         "copy": int((dops == D_COPY).sum()),
         "copies_elided": n_elided,
-        "also_rows": n_also,
+        "extra_dsts": len(extras),
         "prev_operands": n_prev,
+        "lds_operands": n_ldsops,
+        "lds_slots": n_lds_used,
         "inv": int((dops == D_INV).sum()),
-        "barriers": n_barriers,
+        "barriers": n_levels,
+        "full_barriers": len(full_after),
         "strands": n_strands,
         "temp_slots": n_tslots,
         "consts": len(dconsts),

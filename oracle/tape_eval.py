@@ -92,7 +92,7 @@ def check_r1cs(q: int, constraints, w) -> int | None:
 # D_* numbering of circom_amd/csrc/cw_tape.h
 (D_COPY, D_ADD, D_SUB, D_NEG, D_MMUL, D_INV, D_IDIV, D_MOD, D_POW, D_SHL, D_SHR, D_BAND, D_BOR, D_BXOR,
  D_BNOT, D_LT, D_GT, D_LEQ, D_GEQ, D_EQ, D_NEQ, D_LAND, D_LOR, D_LNOT, D_SELECT, D_EXT, D_ASSERT_EQ,
- D_ASSERT_NZ, D_ALSO, D_BARRIER) = range(30)
+ D_ASSERT_NZ, D_ALSO, D_BARRIER) = range(30)      # D_ALSO is no longer emitted (extra-destination table)
 _DBIN = {D_ADD: "add", D_SUB: "sub", D_IDIV: "idiv", D_MOD: "mod", D_POW: "pow", D_SHL: "shl", D_SHR: "shr",
          D_BAND: "band", D_BOR: "bor", D_BXOR: "bxor", D_LT: "lt", D_GT: "gt", D_LEQ: "leq", D_GEQ: "geq",
          D_EQ: "eq", D_NEQ: "neq", D_LAND: "land", D_LOR: "lor"}
@@ -103,15 +103,23 @@ class ScheduleHazard(Exception):
     """The schedule violates the executor's memory model (race between strands / stale prefetch)."""
 
 
+SH_DK, SH_AK, SH_BK, SH_NX = 8, 11, 14, 17
+K_PREV, K_LDS, KD_NONE = 3, 4, 2
+X_TMP, X_LDS = 1 << 31, 1 << 30
+
+
 def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict, rbits: int = 261,
-              stream_off=None):
+              stream_off=None, extras=None, extra_off=None, n_lds: int = 0):
     """Evaluate a lowered schedule exactly the way cw_eval_kernel does, for one instance:
       * every strand (stream) walks its own rows; strands meet at BARRIER rows,
       * operands of row r+1 are fetched BEFORE row r stores its result (one-row-ahead prefetch), except
         kind-3 operands, which are the previous value-producing row's result held in a register,
-      * ALSO rows store that register to extra destinations.
+      * a row's n_extra further destinations come from the strand's extra-destination table,
+      * LDS slots hand values between strands; a LIGHT barrier orders LDS traffic only, a FULL barrier
+        (dst = 1) also makes earlier global stores of other strands visible.
     Strands of one epoch are simulated one after the other; any cross-strand read-after-write or
-    write-after-read inside an epoch is reported as a ScheduleHazard (on the GPU it would be a race).
+    write-after-read inside an epoch, and any cross-strand global read not separated from its write by a
+    FULL barrier, is reported as a ScheduleHazard (on the GPU it would be a race).
     Returns (signal values, status) with status = 0 | bits + (row << 8) like the kernel."""
     f = Field(q)
     rinv = pow(1 << rbits, -1, q)        # MMUL = a*b*R'^-1 with the schedule's radix (device: R' = 2^261)
@@ -120,33 +128,45 @@ def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict,
     for k, v in inputs.items():
         sig[k] = v % q
     tmp = [0] * max(n_tslots, 1)
+    lds = [0] * max(n_lds, 1)
     bins = {k: getattr(f, v) for k, v in _DBIN.items()}
     uns = {k: (getattr(f, v) if v else (lambda x: x)) for k, v in _DUN.items()}
     rows = [tuple(int(x) for x in r) for r in rows]
     if stream_off is None:
         stream_off = [0, len(rows)]
     ns = len(stream_off) - 1
+    if extras is None:
+        extras, extra_off = [], [0] * (ns + 1)
+    extras = [int(x) for x in extras]
+    xp = [int(extra_off[s]) for s in range(ns)]
     pc = [int(stream_off[s]) for s in range(ns)]
     end = [int(stream_off[s + 1]) for s in range(ns)]
     prev = [0] * ns
     status = [0]
     writer = {}      # (kind, slot) -> (epoch, strand) of the last write
-    reader = {}      # (kind, slot) -> set of (epoch, strand) readers in the current epoch
-    epoch = 0
+    reader = {}      # (kind, slot) -> set of strands that read it in the current epoch
+    state = {"epoch": 0, "last_full": -1}
+
+    def store_of(k):
+        return sig if k == 0 else (tmp if k == 1 else lds)
 
     def mem_read(s, k, v):
         key = (k, v)
         w = writer.get(key)
-        if w is not None and w[0] == epoch and w[1] != s:
-            raise ScheduleHazard("strand %d reads %s written by strand %d in the same epoch" % (s, key, w[1]))
+        if w is not None and w[1] != s:
+            if w[0] == state["epoch"]:
+                raise ScheduleHazard("strand %d reads %s written by strand %d in the same epoch" % (s, key, w[1]))
+            if k != K_LDS and w[0] > state["last_full"]:
+                raise ScheduleHazard("strand %d reads global %s written by strand %d with no FULL barrier in between"
+                                     % (s, key, w[1]))
         reader.setdefault(key, set()).add(s)
-        return sig[v] if k == 0 else tmp[v]
+        return store_of(k)[v]
 
     def fetch(s, k, v):
         if k == 2:
             return consts[v]
-        if k == 3:
-            return None               # PREV: resolved at execution time
+        if k == K_PREV:
+            return None               # resolved at execution time
         return mem_read(s, k, v)
 
     def mem_write(s, k, v, val):
@@ -155,49 +175,40 @@ def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict,
         if rs and (rs - {s}):
             raise ScheduleHazard("strand %d overwrites %s read by another strand in the same epoch" % (s, key))
         w = writer.get(key)
-        if w is not None and w[0] == epoch and w[1] != s:
+        if w is not None and w[0] == state["epoch"] and w[1] != s:
             raise ScheduleHazard("two strands write %s in the same epoch" % (key,))
-        writer[key] = (epoch, s)
-        if k == 0:
-            sig[v] = val
-        else:
-            tmp[v] = val
+        writer[key] = (state["epoch"], s)
+        store_of(k)[v] = val
 
     def operands_of(s, r):
         w0, _, a_, b_ = rows[r]
         op = w0 & 0xFF
-        if op in (D_ALSO, D_BARRIER, D_EXT):
+        if op in (D_BARRIER, D_EXT):
             return None, None
-        ak, bk = (w0 >> 10) & 3, (w0 >> 12) & 3
+        ak, bk = (w0 >> SH_AK) & 7, (w0 >> SH_BK) & 7
         a = fetch(s, ak, a_)
         b = None if op in _DUN or op == D_ASSERT_NZ else fetch(s, bk, b_)
         return a, b
 
     def run_strand(s):
-        """run strand s up to (and over) its next BARRIER; returns False when the stream ended"""
+        """run strand s up to (and over) its next BARRIER; returns 'light'/'full' or None when the stream ended"""
         r = pc[s]
         if r >= end[s]:
-            return False
+            return None
         pre = operands_of(s, r)
         while r < end[s]:
             w0, dst, a_, b_ = rows[r]
-            op, dk, ak, bk = w0 & 0xFF, (w0 >> 8) & 3, (w0 >> 10) & 3, (w0 >> 12) & 3
+            op, dk, ak, bk = w0 & 0xFF, (w0 >> SH_DK) & 7, (w0 >> SH_AK) & 7, (w0 >> SH_BK) & 7
+            nx = (w0 >> SH_NX) & 0xFFF
             a, b = pre
-            step = 2 if op == D_SELECT else 1
-            nxt = r + step
+            nxt = r + (2 if op == D_SELECT else 1)
             if op == D_BARRIER:            # nothing is prefetched across a barrier
                 pc[s] = r + 1
-                return True
+                return "full" if dst == 1 else "light"
             pre = operands_of(s, nxt) if nxt < end[s] else (None, None)    # prefetch BEFORE this row's stores
-            if op == D_ALSO:
-                n = (w0 >> 16) & 3
-                for kk, vv in ((dk, dst), (ak, a_), (bk, b_))[:n]:
-                    mem_write(s, kk, vv, prev[s])
-                r = nxt
-                continue
-            if ak == 3:
+            if ak == K_PREV:
                 a = prev[s]
-            if bk == 3:
+            if bk == K_PREV:
                 b = prev[s]
             res = None
             if op == D_MMUL:
@@ -213,7 +224,7 @@ def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict,
                 res = uns[op](a)
             elif op == D_SELECT:
                 e0, _, ea, _ = rows[r + 1]
-                c = fetch(s, (e0 >> 10) & 3, ea)
+                c = fetch(s, (e0 >> SH_AK) & 7, ea)
                 res = b if a != 0 else c
             elif op == D_ASSERT_EQ:
                 if a != b and status[0] == 0:
@@ -225,18 +236,41 @@ def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict,
                 raise ValueError("bad device op %d" % op)
             if res is not None:
                 prev[s] = res
-                if dk != 2:
+                if dk != KD_NONE:
                     mem_write(s, dk, dst, res)
+                for e in extras[xp[s]:xp[s] + nx]:
+                    if e & X_LDS:
+                        mem_write(s, K_LDS, e & 0x3FFFFFFF, res)
+                    elif e & X_TMP:
+                        mem_write(s, 1, e & 0x3FFFFFFF, res)
+                    else:
+                        mem_write(s, 0, e, res)
+            elif nx:
+                raise ValueError("extra destinations on a row without a value")
+            xp[s] += nx
             r = nxt
         pc[s] = r
-        return False
+        return None
 
     alive = True
     while alive:
         alive = False
+        kinds = set()
         for s in range(ns):
-            if run_strand(s):
+            k = run_strand(s)
+            if k:
                 alive = True
-        epoch += 1
+                kinds.add(k)
+        if len(kinds) > 1:
+            raise ScheduleHazard("strands disagree on the barrier kind closing epoch %d" % state["epoch"])
+        if "full" in kinds:
+            state["last_full"] = state["epoch"]
+        state["epoch"] += 1
         reader.clear()
     return sig, status[0]
+
+
+def eval_tape(tape, inputs: dict):
+    """Convenience wrapper over a circom_amd.hip_elements.lower.Tape (duck-typed)."""
+    return eval_rows(tape.q, tape.n_signals, tape.n_tslots, tape.consts, tape.rows, inputs, tape.rbits,
+                     tape.stream_off, tape.extras, tape.extra_off, tape.n_lds)

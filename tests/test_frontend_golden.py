@@ -12,7 +12,7 @@ from circom_amd.hip_elements import writers
 from circom_amd.circuits.basic import BasicMain, Multiplier2, Num2Bits, IsZero
 from circom_amd.field import fp_for
 from oracle.field import Field, PRIMES
-from oracle.tape_eval import eval_flat, eval_rows, check_r1cs
+from oracle.tape_eval import eval_flat, eval_rows, eval_tape, check_r1cs
 
 Q = PRIMES["bn128"]
 QM1 = str(Q - 1)
@@ -115,7 +115,7 @@ def test_lowered_schedule_equals_flat_semantics():
             if trial == 0:
                 inp = {s: 0 for s in slots}
             a, failed = eval_flat(Q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp)
-            b, st = eval_rows(Q, t.n_signals, t.n_tslots, t.consts, t.rows, inp, stream_off=t.stream_off)
+            b, st = eval_tape(t, inp)
             assert a == b and (st == 0) == (failed is None)
             if failed is None:
                 assert check_r1cs(Q, fc.constraints, a) is None
@@ -150,5 +150,5 @@ def test_strand_schedules_are_race_free_and_equivalent():
             for trial in range(2):
                 inp = {s: (rng.randrange(1 << 16) if small else rng.randrange(Q)) for s in slots}
                 a, failed = eval_flat(Q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp)
-                b, st = eval_rows(Q, t.n_signals, t.n_tslots, t.consts, t.rows, inp, stream_off=t.stream_off)
+                b, st = eval_tape(t, inp)
                 assert a == b and (st == 0) == (failed is None), (prog.main.name, S)

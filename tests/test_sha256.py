@@ -12,7 +12,7 @@ from circom_amd.hip_elements.lower import lower
 from circom_amd.circuits.sha256 import Sha256
 from circom_amd.hip_elements.writers import wtns_bytes
 from oracle import ref_build
-from oracle.tape_eval import eval_flat, eval_rows, check_r1cs
+from oracle.tape_eval import eval_flat, eval_rows, eval_tape, check_r1cs
 
 
 def _bits(msg: bytes):
@@ -44,12 +44,12 @@ def test_sha256_lowered_schedule_matches(sha64):
     t = lower(fc)
     inp = {fc.main_input_start + i: b for i, b in enumerate(_bits(b"GPU->wtn"))}
     a, failed = eval_flat(fc.fp.q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp)
-    b, st = eval_rows(fc.fp.q, t.n_signals, t.n_tslots, t.consts, t.rows, inp, stream_off=t.stream_off)
+    b, st = eval_tape(t, inp)
     assert failed is None and st == 0 and a == b
     # non-bit inputs: the circuit does not constrain its inputs; values must still agree until an assert trips
     inp[fc.main_input_start + 3] = 7
     a, failed = eval_flat(fc.fp.q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp)
-    b, st = eval_rows(fc.fp.q, t.n_signals, t.n_tslots, t.consts, t.rows, inp, stream_off=t.stream_off)
+    b, st = eval_tape(t, inp)
     assert (failed is None) == (st == 0)
     if failed is None:
         assert a == b
