@@ -129,12 +129,8 @@ def main():
         elapsed = float(t.item())
 
     # correctness gate + the one data-path collective: gather per-instance status words on rank 0
-    status = torch.from_numpy(batch.status().astype(np.int32)).to(dev)
-    if dist:
-        gathered = [torch.empty_like(status) for _ in range(world)] if rank == 0 else None
-        dist.gather(status, gathered, dst=0)
-        if rank == 0:
-            status = torch.cat(gathered)
+    from circom_amd.sharding import gather_status
+    status = gather_status(torch.from_numpy(batch.status().astype(np.int32)).to(dev), dist, rank, world)
     n_bad = int((status != 0).sum().item()) if rank == 0 else 0
 
     gen_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / args.steps

@@ -1,0 +1,56 @@
+"""The N>1 path of bench.py on CPU: two processes over gloo shard a batch and gather the status words."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _worker(rank, world, port, total, out_dir):
+    sys.path.insert(0, str(ROOT))
+    from circom_amd.sharding import shard_range, gather_status
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(total, rank, world)
+    # a fake per-instance status: instance id in the low bits, one deliberately failing instance per rank
+    st = torch.arange(lo, hi, dtype=torch.int32) * 8
+    st[0] += 1
+    got = gather_status(st, dist, rank, world)
+    if rank == 0:
+        torch.save(got, os.path.join(out_dir, "gathered.pt"))
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_ranges_cover_batch():
+    from circom_amd.sharding import shard_range
+    for total in (0, 1, 7, 8192, 65537):
+        for world in (1, 2, 3, 8):
+            parts = [shard_range(total, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == total
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_gloo_status_gather(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    total = 1001           # ragged on purpose
+    mp.spawn(_worker, args=(2, port, total, str(tmp_path)), nprocs=2, join=True)
+    got = torch.load(tmp_path / "gathered.pt")
+    want = torch.arange(0, total, dtype=torch.int32) * 8
+    want[0] += 1
+    want[501] += 1
+    assert torch.equal(got, want)
