@@ -121,16 +121,20 @@ cw_eval_kernel(const CwRow *__restrict__ rows, const uint32_t *__restrict__ stre
     const uint32_t end = stream_off[wave + 1];
     uint32_t xp = extra_off[wave];
     uint32_t st = 0;
+    uint64_t selmask = 0;                                          // lane mask latched by D_SELECT
     fe prev = fe_zero();
-    CwRow nrow = rows[r < end ? r : 0];
-    fe na = fetch_global((nrow.w0 >> SH_AK) & 7, nrow.a, V, consts4, tmp_base, Bp, i);
-    fe nb = fetch_global((nrow.w0 >> SH_BK) & 7, nrow.b, V, consts4, tmp_base, Bp, i);
+    // software pipeline: row r is executed while the operands of row r+1 are in flight and the row word of
+    // r+2 is being fetched.  `cur`/`ca`/`cb` = row being executed, `nxt` = row whose operands are requested next.
+    const CwRow zero_row = {D_BARRIER + 100u, 0, 0, 0};           // harmless filler past the end of the stream
+    CwRow cur = r < end ? rows[r] : zero_row;
+    CwRow nxt = r + 1 < end ? rows[r + 1] : zero_row;
+    fe ca = fetch_global((cur.w0 >> SH_AK) & 7, cur.a, V, consts4, tmp_base, Bp, i);
+    fe cb = fetch_global((cur.w0 >> SH_BK) & 7, cur.b, V, consts4, tmp_base, Bp, i);
     while (r < end) {
-        const CwRow row = nrow;
+        const CwRow row = cur;
         const uint32_t op = row.w0 & 0xFF;
         const uint32_t dk = (row.w0 >> SH_DK) & 7, ak = (row.w0 >> SH_AK) & 7, bk = (row.w0 >> SH_BK) & 7;
         const uint32_t nx = (row.w0 >> SH_NX) & 0xFFF;
-        const uint32_t next = r + (op == D_SELECT ? 2u : 1u);
         if (op == D_BARRIER) {                                       // nothing is prefetched across a barrier
             if (row.dst) {
                 __syncthreads();                                     // FULL: also drains this wave's global stores
@@ -139,25 +143,25 @@ cw_eval_kernel(const CwRow *__restrict__ rows, const uint32_t *__restrict__ stre
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // ... before any wave reads them
             }
-            r = next;
-            if (r < end) {
-                nrow = rows[r];
-                na = fetch_global((nrow.w0 >> SH_AK) & 7, nrow.a, V, consts4, tmp_base, Bp, i);
-                nb = fetch_global((nrow.w0 >> SH_BK) & 7, nrow.b, V, consts4, tmp_base, Bp, i);
-            }
+            r++;
+            cur = nxt;
+            nxt = r + 1 < end ? rows[r + 1] : zero_row;
+            ca = fetch_global((cur.w0 >> SH_AK) & 7, cur.a, V, consts4, tmp_base, Bp, i);
+            cb = fetch_global((cur.w0 >> SH_BK) & 7, cur.b, V, consts4, tmp_base, Bp, i);
             continue;
         }
-        fe a = na, b = nb;
-        // first extra destinations: scalar loads issued now, consumed after the arithmetic
+        // request the next row's operands first (two rows' loads in flight), then the row word after it
+        const bool next_is_barrier = (nxt.w0 & 0xFF) == D_BARRIER;
+        fe na = ca, nb = cb;
+        if (!next_is_barrier) {
+            na = fetch_global((nxt.w0 >> SH_AK) & 7, nxt.a, V, consts4, tmp_base, Bp, i);
+            nb = fetch_global((nxt.w0 >> SH_BK) & 7, nxt.b, V, consts4, tmp_base, Bp, i);
+        }
+        const CwRow nn = r + 2 < end ? rows[r + 2] : zero_row;
+        // extra destinations: scalar loads issued now, consumed after the arithmetic
         // (unconditional: the table is padded by 4 entries, so the four scalar loads batch into one wait)
         const uint32_t x0 = extras[xp], x1 = extras[xp + 1], x2 = extras[xp + 2], x3 = extras[xp + 3];
-        CwRow ext;
-        if (op == D_SELECT) ext = rows[r + 1];
-        if (next < end) {                                            // prefetch the next row and its operands
-            nrow = rows[next];
-            na = fetch_global((nrow.w0 >> SH_AK) & 7, nrow.a, V, consts4, tmp_base, Bp, i);
-            nb = fetch_global((nrow.w0 >> SH_BK) & 7, nrow.b, V, consts4, tmp_base, Bp, i);
-        }
+        fe a = ca, b = cb;
         if (ak == K_PREV) a = prev;
         else if (ak == K_LDS) a = lds_load(row.a, lane);
         if (bk == K_PREV) b = prev;
@@ -170,6 +174,8 @@ cw_eval_kernel(const CwRow *__restrict__ rows, const uint32_t *__restrict__ stre
         case D_SUB: d = fe_sub(a, b, P); break;
         case D_NEG: d = fe_neg(a, P); break;
         case D_MMUL: d = fe_mmul(a, b, P); break;
+        case D_MUL2: d = fe_mul2(a, b, P); break;
+        case D_MADD: d = fe_add(fe_mmul(a, b, P), prev, P); break;
         case D_SHL: d = fe_shl(a, b, P); break;
         case D_SHR: d = fe_shr(a, b, P); break;
         case D_BAND: d = fe_band(a, b, P); break;
@@ -185,14 +191,13 @@ cw_eval_kernel(const CwRow *__restrict__ rows, const uint32_t *__restrict__ stre
         case D_LAND: d = fe_small(!fe_is_zero(a) & !fe_is_zero(b)); break;
         case D_LOR: d = fe_small(!fe_is_zero(a) | !fe_is_zero(b)); break;
         case D_LNOT: d = fe_small(fe_is_zero(a)); break;
-        case D_SELECT: {
-            // cond = a, then-value = b, else-value in the following EXT row (read at execution time)
-            const uint32_t ck = (ext.w0 >> SH_AK) & 7;
-            fe c;
-            if (ck == K_LDS) c = lds_load(ext.a, lane);
-            else c = fetch_global(ck, ext.a, V, consts4, tmp_base, Bp, i);
-            const bool t = !fe_is_zero(a);
-            for (int k = 0; k < 8; k++) d.v[k] = t ? b.v[k] : c.v[k];
+        case D_SELECT:                                               // latch cond != 0; the EXT row selects
+            selmask = __ballot(!fe_is_zero(a));
+            has_d = false;
+            break;
+        case D_EXT: {
+            const bool t = (selmask >> lane) & 1;
+            for (int k = 0; k < 8; k++) d.v[k] = t ? a.v[k] : b.v[k];
             break;
         }
         case D_ASSERT_EQ:
@@ -238,7 +243,11 @@ cw_eval_kernel(const CwRow *__restrict__ rows, const uint32_t *__restrict__ stre
             }
         }
         xp += nx;
-        r = next;
+        r++;
+        cur = nxt;
+        nxt = nn;
+        ca = na;
+        cb = nb;
     }
     if (st && i < batch) atomicCAS(&status[i], 0u, st);
 }
@@ -328,6 +337,8 @@ cw_fpop_kernel(uint32_t op, const uint4 *a_, const uint4 *b_, const uint4 *c_, u
     case D_SUB: d = fe_sub(a, b, P); break;
     case D_NEG: d = fe_neg(a, P); break;
     case D_MMUL: d = fe_mmul(a, b, P); break;
+    case D_MUL2: d = fe_mul2(a, b, P); break;
+    case D_MADD: d = fe_add(fe_mmul(a, b, P), c, P); break;
     case D_INV: d = fe_pow_uniform(a, P.qm2, P); break;
     case D_POW: d = fe_pow(a, b, P); break;
     case D_IDIV:

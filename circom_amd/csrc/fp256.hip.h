@@ -200,6 +200,11 @@ __device__ __forceinline__ fe29 fe29_mmul(const fe29 &a, const fe29 &b, const Fp
 __device__ __forceinline__ fe fe_mmul(const fe &a, const fe &b, const FpParams &P) {
     return fe_from29(fe29_mmul(fe_to29(a), fe_to29(b), P));
 }
+// canonical product a*b mod q = MMUL(MMUL(a,b), R'^2); the intermediate never leaves the 29-bit limb form
+__device__ __forceinline__ fe fe_mul2(const fe &a, const fe &b, const FpParams &P) {
+    const fe29 t = fe29_mmul(fe_to29(a), fe_to29(b), P);
+    return fe_from29(fe29_mmul(t, fe_to29(fe_from(P.r2)), P));
+}
 
 // ---- bitwise operators on canonical values (Fr_rawAnd/Or/Xor/Not, generic/fr.cpp:293-327,366-376) ----
 __device__ __forceinline__ fe fe_mask_wrap(fe r, const FpParams &P) {

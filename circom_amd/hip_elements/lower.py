@@ -51,10 +51,13 @@ from ..frontend.flatten import FlatCircuit
 # device opcodes (csrc/cw_tape.h must match)
 (D_COPY, D_ADD, D_SUB, D_NEG, D_MMUL, D_INV, D_IDIV, D_MOD, D_POW, D_SHL, D_SHR, D_BAND, D_BOR, D_BXOR,
  D_BNOT, D_LT, D_GT, D_LEQ, D_GEQ, D_EQ, D_NEQ, D_LAND, D_LOR, D_LNOT, D_SELECT, D_EXT, D_ASSERT_EQ,
- D_ASSERT_NZ, D_ALSO, D_BARRIER) = range(30)
+ D_ASSERT_NZ, D_ALSO, D_BARRIER, D_MUL2, D_MADD) = range(32)
 D_NAMES = ["copy", "add", "sub", "neg", "mmul", "inv", "idiv", "mod", "pow", "shl", "shr", "band", "bor",
            "bxor", "bnot", "lt", "gt", "leq", "geq", "eq", "neq", "land", "lor", "lnot", "select", "ext",
-           "assert_eq", "assert_nz", "also", "barrier"]
+           "assert_eq", "assert_nz", "also", "barrier", "mul2", "madd"]
+# D_MUL2: d = a*b on canonical values  (= MMUL(MMUL(a,b), R'^2), the intermediate stays in registers)
+# D_MADD: d = MMUL(a,b) + PREV          (multiply-accumulate of `lc += coeff * signal` chains)
+# D_SELECT: latches the lane mask cond != 0 (no value); the following D_EXT row yields mask ? a : b
 
 K_SIG, K_TMP, K_CONST, K_NONE = O.K_SIG, O.K_TMP, O.K_CONST, O.K_NONE
 KD_NONE = 2      # destination kind "no store"
@@ -64,8 +67,8 @@ _DIRECT = {O.COPY: D_COPY, O.ADD: D_ADD, O.SUB: D_SUB, O.NEG: D_NEG, O.IDIV: D_I
            O.POW: D_POW, O.SHL: D_SHL, O.SHR: D_SHR, O.BAND: D_BAND, O.BOR: D_BOR, O.BXOR: D_BXOR,
            O.BNOT: D_BNOT, O.LT: D_LT, O.GT: D_GT, O.LEQ: D_LEQ, O.GEQ: D_GEQ, O.EQ: D_EQ, O.NEQ: D_NEQ,
            O.LAND: D_LAND, O.LOR: D_LOR, O.LNOT: D_LNOT, O.ASSERT_EQ: D_ASSERT_EQ, O.ASSERT_NZ: D_ASSERT_NZ}
-_COST = {D_MMUL: 10.0, D_INV: 4000.0, D_POW: 6000.0, D_IDIV: 8000.0, D_MOD: 8000.0}
-_NO_VALUE = (D_ASSERT_EQ, D_ASSERT_NZ)
+_COST = {D_MMUL: 10.0, D_MUL2: 19.0, D_MADD: 11.0, D_INV: 4000.0, D_POW: 6000.0, D_IDIV: 8000.0, D_MOD: 8000.0}
+_NO_VALUE = (D_ASSERT_EQ, D_ASSERT_NZ, D_SELECT)
 
 
 class Tape:
@@ -169,9 +172,7 @@ def _expand(fc: FlatCircuit):
                     xk, xv, c = ak[i], av[i], consts_in[bv[i]]
                 rows.append(_Row(D_MMUL, dk[i], dv[i], xk, xv, K_CONST, cid((c * R) % q)))
             else:
-                t = fresh()
-                rows.append(_Row(D_MMUL, K_TMP, t, ak[i], av[i], bk[i], bv[i]))
-                rows.append(_Row(D_MMUL, dk[i], dv[i], K_TMP, t, K_CONST, cid(R2)))
+                rows.append(_Row(D_MUL2, dk[i], dv[i], ak[i], av[i], bk[i], bv[i]))
         elif o == O.DIV:
             # a / b = a * inv(b); inv(0) = 0 (generic/fr.cpp:2895-2912)
             t = fresh()
@@ -180,14 +181,13 @@ def _expand(fc: FlatCircuit):
             if ak[i] == K_CONST:
                 rows.append(_Row(D_MMUL, dk[i], dv[i], K_TMP, t, K_CONST, cid((consts_in[av[i]] * R) % q)))
             else:
-                t2 = fresh()
-                rows.append(_Row(D_MMUL, K_TMP, t2, ak[i], av[i], K_TMP, t))
-                rows.append(_Row(D_MMUL, dk[i], dv[i], K_TMP, t2, K_CONST, cid(R2)))
+                rows.append(_Row(D_MUL2, dk[i], dv[i], ak[i], av[i], K_TMP, t))
         elif o == O.SELECT:
             ka, va = opnd(ak[i], av[i])
             kb, vb = opnd(bk[i], bv[i])
             kc, vc = opnd(ck[i], cv[i])
-            rows.append(_Row(D_SELECT, dk[i], dv[i], ka, va, kb, vb, kc, vc))
+            rows.append(_Row(D_SELECT, KD_NONE, 0, ka, va))
+            rows.append(_Row(D_EXT, dk[i], dv[i], kb, vb, kc, vc))
         else:
             ka, va = opnd(ak[i], av[i])
             kb, vb = opnd(bk[i], bv[i]) if bk[i] != K_NONE else (K_NONE, 0)
@@ -264,6 +264,38 @@ def _reassociate(rows, n_vtemps):
     return out, nxt
 
 
+def _fuse_madd(rows):
+    """Pass B2 (single strand only): [x = value] [t = MMUL(a,b)] [d = x + t]  ->  [x] [d = MADD(a,b)] where the
+    addend is implicitly PREV (= x).  `t` must be a single-use temp and `x` must be produced by the row right
+    before the MMUL (so that it is still in the forwarding register)."""
+    uses = {}
+    for r in rows:
+        for k, v in ((r.ak, r.av), (r.bk, r.bv), (r.ck, r.cv)):
+            if k == K_TMP:
+                uses[v] = uses.get(v, 0) + 1
+    out = []
+    i, n, fused = 0, len(rows), 0
+    while i < n:
+        r = rows[i]
+        if (r.op == D_MMUL and r.dk == K_TMP and uses.get(r.dv) == 1 and r.extra is None and i + 1 < n and out):
+            add, x = rows[i + 1], out[-1]
+            if add.op == D_ADD and x.op not in _NO_VALUE and x.dk in (K_SIG, K_TMP):
+                t_op, x_op = (K_TMP, r.dv), (x.dk, x.dv)
+                ops = ((add.ak, add.av), (add.bk, add.bv))
+                # x must not itself feed the product (it is only available as PREV, which MADD uses as addend)
+                feeds = (r.ak, r.av) == x_op or (r.bk, r.bv) == x_op
+                if not feeds and (ops == (x_op, t_op) or ops == (t_op, x_op)):
+                    m = _Row(D_MADD, add.dk, add.dv, r.ak, r.av, r.bk, r.bv)      # addend = PREV (the row before)
+                    m.extra = add.extra
+                    out.append(m)
+                    fused += 1
+                    i += 2
+                    continue
+        out.append(r)
+        i += 1
+    return out, fused
+
+
 def _alias(rows, n_signals):
     """Pass B.  Value ids: signal s -> s, virtual temp t -> n_signals + t."""
     def vid(k, v):
@@ -318,43 +350,60 @@ def _schedule(rows, n_signals, n_strands):
     prod_level = {}
     prod_strand = {}
     levels = []
-    for r in rows:
+    # SELECT latches a per-strand lane mask consumed by the EXT row that follows: schedule the pair as a unit
+    units = []
+    i = 0
+    while i < len(rows):
+        if rows[i].op == D_SELECT:
+            units.append((rows[i], rows[i + 1]))
+            i += 2
+        else:
+            units.append((rows[i],))
+            i += 1
+    for unit in units:
         lv = 0
-        for k, v in ((r.ak, r.av), (r.bk, r.bv), (r.ck, r.cv)):
-            if k == K_SIG or k == K_TMP:
-                pl = prod_level.get(vid(k, v))
-                if pl is not None and pl + 1 > lv:
-                    lv = pl + 1
-        r.level = lv
-        if r.dk in (K_SIG, K_TMP):
-            prod_level[vid(r.dk, r.dv)] = lv
+        for r in unit:
+            for k, v in ((r.ak, r.av), (r.bk, r.bv), (r.ck, r.cv)):
+                if k == K_SIG or k == K_TMP:
+                    pl = prod_level.get(vid(k, v))
+                    if pl is not None and pl + 1 > lv:
+                        lv = pl + 1
+        for r in unit:
+            r.level = lv
+            if r.dk in (K_SIG, K_TMP):
+                prod_level[vid(r.dk, r.dv)] = lv
         while len(levels) <= lv:
             levels.append([])
-        levels[lv].append(r)
+        levels[lv].append(unit)
     streams = [[] for _ in range(n_strands)]
-    for lv, lrows in enumerate(levels):
-        total = sum(_COST.get(r.op, 1.5) + (0.5 * len(r.extra) if r.extra else 0) for r in lrows)
+
+    def ucost(unit):
+        return sum(_COST.get(r.op, 1.5) + (0.5 * len(r.extra) if r.extra else 0) for r in unit)
+
+    for lv, lunits in enumerate(levels):
+        total = sum(ucost(u) for u in lunits)
         cap = total / n_strands * 1.15 + 10.0
         load = [0.0] * n_strands
-        for r in lrows:
-            cost = _COST.get(r.op, 1.5) + (0.5 * len(r.extra) if r.extra else 0)
+        for unit in lunits:
+            cost = ucost(unit)
             pref = None
-            for k, v in ((r.ak, r.av), (r.bk, r.bv)):
-                if k == K_SIG or k == K_TMP:
-                    x = vid(k, v)
-                    if prod_level.get(x) == lv - 1:
-                        pref = prod_strand.get(x)
-                        break
+            for r in unit:
+                for k, v in ((r.ak, r.av), (r.bk, r.bv)):
+                    if pref is None and (k == K_SIG or k == K_TMP):
+                        x = vid(k, v)
+                        if prod_level.get(x) == lv - 1:
+                            pref = prod_strand.get(x)
             if pref is None or load[pref] + cost > cap:
                 pref = min(range(n_strands), key=load.__getitem__)
-            r.strand = pref
             load[pref] += cost
-            streams[pref].append(r)
-            if r.dk in (K_SIG, K_TMP):
-                prod_strand[vid(r.dk, r.dv)] = pref
+            for r in unit:
+                r.strand = pref
+                streams[pref].append(r)
+                if r.dk in (K_SIG, K_TMP):
+                    prod_strand[vid(r.dk, r.dv)] = pref
         if lv + 1 < len(levels):
-            for s in streams:
-                s.append("B")
+            for st in streams:
+                st.append("B")
     return streams, len(levels) - 1
 
 
@@ -378,6 +427,9 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
     if n_strands > 1:      # one strand prefers the original chains (register forwarding, no extra temps)
         rows, n_vtemps = _reassociate(rows, n_vtemps)
     rows, n_elided = _alias(rows, n_signals)
+    n_madd = 0
+    if n_strands == 1:
+        rows, n_madd = _fuse_madd(rows)
     streams, n_levels = _schedule(rows, n_signals, n_strands)
     multi = n_strands > 1
 
@@ -529,9 +581,6 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
             assert len(ex) <= MAX_EXTRA, "fan-out of one value exceeds the extra-destination field"
             enc.append((r.op | (kd << SH_DK) | (ka << SH_AK) | (kb << SH_BK) | (len(ex) << SH_NX), vd, va, vb))
             extras.extend(ex)
-            if r.op == D_SELECT:
-                kc, vc = o_enc(r.ck, r.cv, False)
-                enc.append((D_EXT | (kc << SH_AK), 0, vc, 0))
         stream_off.append(len(enc))
         extra_off.append(len(extras))
     out = np.asarray(enc, dtype=np.uint32).reshape(-1, 4)
@@ -566,6 +615,8 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
         "prev_operands": n_prev,
         "lds_operands": n_ldsops,
         "lds_slots": n_lds_used,
+        "mul2": int((dops == D_MUL2).sum()),
+        "madd": n_madd,
         "inv": int((dops == D_INV).sum()),
         "barriers": n_levels,
         "full_barriers": len(full_after),

@@ -92,7 +92,7 @@ def check_r1cs(q: int, constraints, w) -> int | None:
 # D_* numbering of circom_amd/csrc/cw_tape.h
 (D_COPY, D_ADD, D_SUB, D_NEG, D_MMUL, D_INV, D_IDIV, D_MOD, D_POW, D_SHL, D_SHR, D_BAND, D_BOR, D_BXOR,
  D_BNOT, D_LT, D_GT, D_LEQ, D_GEQ, D_EQ, D_NEQ, D_LAND, D_LOR, D_LNOT, D_SELECT, D_EXT, D_ASSERT_EQ,
- D_ASSERT_NZ, D_ALSO, D_BARRIER) = range(30)      # D_ALSO is no longer emitted (extra-destination table)
+ D_ASSERT_NZ, D_ALSO, D_BARRIER, D_MUL2, D_MADD) = range(32)     # D_ALSO is no longer emitted
 _DBIN = {D_ADD: "add", D_SUB: "sub", D_IDIV: "idiv", D_MOD: "mod", D_POW: "pow", D_SHL: "shl", D_SHR: "shr",
          D_BAND: "band", D_BOR: "bor", D_BXOR: "bxor", D_LT: "lt", D_GT: "gt", D_LEQ: "leq", D_GEQ: "geq",
          D_EQ: "eq", D_NEQ: "neq", D_LAND: "land", D_LOR: "lor"}
@@ -142,6 +142,7 @@ def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict,
     pc = [int(stream_off[s]) for s in range(ns)]
     end = [int(stream_off[s + 1]) for s in range(ns)]
     prev = [0] * ns
+    sel = [False] * ns
     status = [0]
     writer = {}      # (kind, slot) -> (epoch, strand) of the last write
     reader = {}      # (kind, slot) -> set of strands that read it in the current epoch
@@ -183,11 +184,11 @@ def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict,
     def operands_of(s, r):
         w0, _, a_, b_ = rows[r]
         op = w0 & 0xFF
-        if op in (D_BARRIER, D_EXT):
+        if op == D_BARRIER:
             return None, None
         ak, bk = (w0 >> SH_AK) & 7, (w0 >> SH_BK) & 7
         a = fetch(s, ak, a_)
-        b = None if op in _DUN or op == D_ASSERT_NZ else fetch(s, bk, b_)
+        b = None if op in _DUN or op in (D_ASSERT_NZ, D_SELECT) else fetch(s, bk, b_)
         return a, b
 
     def run_strand(s):
@@ -201,7 +202,7 @@ def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict,
             op, dk, ak, bk = w0 & 0xFF, (w0 >> SH_DK) & 7, (w0 >> SH_AK) & 7, (w0 >> SH_BK) & 7
             nx = (w0 >> SH_NX) & 0xFFF
             a, b = pre
-            nxt = r + (2 if op == D_SELECT else 1)
+            nxt = r + 1
             if op == D_BARRIER:            # nothing is prefetched across a barrier
                 pc[s] = r + 1
                 return "full" if dst == 1 else "light"
@@ -213,6 +214,10 @@ def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict,
             res = None
             if op == D_MMUL:
                 res = a * b * rinv % q
+            elif op == D_MUL2:
+                res = a * b % q
+            elif op == D_MADD:
+                res = (a * b * rinv + prev[s]) % q
             elif op in bins:
                 try:
                     res = bins[op](a, b)
@@ -223,9 +228,9 @@ def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict,
             elif op in uns:
                 res = uns[op](a)
             elif op == D_SELECT:
-                e0, _, ea, _ = rows[r + 1]
-                c = fetch(s, (e0 >> SH_AK) & 7, ea)
-                res = b if a != 0 else c
+                sel[s] = a != 0               # latched lane mask; no value
+            elif op == D_EXT:
+                res = a if sel[s] else b
             elif op == D_ASSERT_EQ:
                 if a != b and status[0] == 0:
                     status[0] = 1 | (r << 8)

@@ -38,7 +38,7 @@ def test_device_field_ops_match_oracle(prime):
     B = [b for _ in edges for b in edges] + [rng.choice(rand + edges) for _ in range(3000)]
     Cc = [rng.choice(rand + edges) for _ in A]
     rinv = pow(1 << 261, -1, f.q)          # device Montgomery radix R' = 2^261 (csrc/fp256.hip.h)
-    ops = {L.D_ADD: f.add, L.D_SUB: f.sub, L.D_MMUL: lambda a, b: a * b * rinv % f.q, L.D_SHL: f.shl, L.D_SHR: f.shr, L.D_BAND: f.band,
+    ops = {L.D_ADD: f.add, L.D_SUB: f.sub, L.D_MMUL: lambda a, b: a * b * rinv % f.q, L.D_MUL2: f.mul, L.D_SHL: f.shl, L.D_SHR: f.shr, L.D_BAND: f.band,
            L.D_BOR: f.bor, L.D_BXOR: f.bxor, L.D_LT: f.lt, L.D_GT: f.gt, L.D_LEQ: f.leq, L.D_GEQ: f.geq, L.D_EQ: f.eq,
            L.D_NEQ: f.neq, L.D_LAND: f.land, L.D_LOR: f.lor, L.D_POW: f.pow}
     for dop, fn in ops.items():
@@ -57,6 +57,8 @@ def test_device_field_ops_match_oracle(prime):
                 assert st[i] == rt.ST_ARITH
             else:
                 assert st[i] == 0 and got[i] == fn(a, b), (prime, L.D_NAMES[dop], hex(a), hex(b))
+    got, st = rt.fp_op(f.q, L.D_MADD, A, B, Cc)
+    assert got == [(a * b * rinv + c) % f.q for a, b, c in zip(A, B, Cc)]
     got, st = rt.fp_op(f.q, L.D_SELECT, A, B, Cc)
     assert got == [b if a else c for a, b, c in zip(A, B, Cc)]
     got, st = rt.fp_op(f.q, L.D_ASSERT_EQ, A, B, Cc)
