@@ -200,7 +200,7 @@ struct cw_circuit {
     std::map<std::string, std::pair<uint32_t, uint32_t>> input_names;   // name -> (start, size)
     // r1cs (CSR)
     uint32_t n_constraints = 0;
-    std::vector<uint32_t> r_ptr, r_slot, r_coef, r_ctab;
+    std::vector<uint32_t> r_ptr, r_slot, r_coef, r_ctab, r_orig;
 };
 
 static uint64_t fnv1a(const char *s, size_t n) {   // calcwit.cpp:17-24
@@ -419,6 +419,53 @@ static int load_r1cs(cw_circuit *c, const char *path) {
             c->r_ptr.push_back((uint32_t)c->r_slot.size());
         }
     }
+    // ---- processing order: by the schedule position at which a row's youngest wire is produced ----------------
+    // (variant 0 = one strand = program order).  A wire is then re-read by the check shortly after another row
+    // touched it, while it is still in L2, instead of three times from HBM.
+    std::vector<uint32_t> defpos(c->n_signals, 0);
+    {
+        const Variant &v0 = c->variants[0];
+        size_t xp = 0;
+        for (size_t r = 0; r < v0.rows.size(); r++) {
+            const CwRow &row = v0.rows[r];
+            uint32_t op = row.w0 & 0xFF, dk = (row.w0 >> SH_DK) & 7, nx = (row.w0 >> SH_NX) & 0xFFF;
+            if (op == D_BARRIER) continue;
+            if (dk == K_SIG && row.dst < c->n_signals) defpos[row.dst] = (uint32_t)r + 1;
+            for (uint32_t e = 0; e < nx; e++) {
+                uint32_t x = v0.extras[xp + e];
+                if (!(x & (X_TMP | X_LDS)) && x < c->n_signals) defpos[x] = (uint32_t)r + 1;
+            }
+            xp += nx;
+        }
+    }
+    std::vector<uint64_t> key(n_cons);
+    for (uint32_t k = 0; k < n_cons; k++) {
+        uint32_t mx = 0;
+        for (uint32_t t = c->r_ptr[3 * k]; t < c->r_ptr[3 * k + 3]; t++) mx = std::max(mx, defpos[c->r_slot[t]]);
+        key[k] = ((uint64_t)mx << 32) | k;
+    }
+    std::sort(key.begin(), key.end());
+    std::vector<uint32_t> n_ptr(1, 0), n_slot, n_coef;
+    n_slot.reserve(c->r_slot.size());
+    n_coef.reserve(c->r_coef.size());
+    c->r_orig.resize(n_cons);
+    for (uint32_t j = 0; j < n_cons; j++) {
+        uint32_t k = (uint32_t)key[j];
+        for (int part = 0; part < 3; part++) {
+            for (uint32_t t = c->r_ptr[3 * k + part]; t < c->r_ptr[3 * k + part + 1]; t++) {
+                n_slot.push_back(c->r_slot[t]);
+                n_coef.push_back(c->r_coef[t]);
+            }
+            n_ptr.push_back((uint32_t)n_slot.size());
+        }
+        uint32_t a0 = c->r_ptr[3 * k], a1 = c->r_ptr[3 * k + 1], b1 = c->r_ptr[3 * k + 2], c1 = c->r_ptr[3 * k + 3];
+        bool eq2 = (a0 == a1) && (a1 == b1) && (c1 - b1 == 2) &&
+                   ((c->r_coef[b1] == 0 && c->r_coef[b1 + 1] == 1) || (c->r_coef[b1] == 1 && c->r_coef[b1 + 1] == 0));
+        c->r_orig[j] = k | (eq2 ? 0x80000000u : 0u);
+    }
+    c->r_ptr.swap(n_ptr);
+    c->r_slot.swap(n_slot);
+    c->r_coef.swap(n_coef);
     return CW_OK;
 }
 
@@ -483,7 +530,7 @@ struct cw_batch {
     const Variant *var = nullptr;
     uint32_t *d_stream_off = nullptr, *d_extras = nullptr, *d_extra_off = nullptr;
     uint32_t *d_consts = nullptr, *d_w2s = nullptr, *d_status = nullptr, *d_first_bad = nullptr;
-    uint32_t *d_rptr = nullptr, *d_rslot = nullptr, *d_rcoef = nullptr, *d_rctab = nullptr;
+    uint32_t *d_rptr = nullptr, *d_rslot = nullptr, *d_rcoef = nullptr, *d_rctab = nullptr, *d_rorig = nullptr;
     void *d_in = nullptr;          // AoS staging [batch][n_in][32]
     void *d_gather = nullptr;      // [n_witness][32]
     const void *ext_in = nullptr;  // caller-owned device inputs (cw_set_inputs_device)
@@ -511,7 +558,7 @@ extern "C" void cw_batch_free(cw_batch *b) {
     hipSetDevice(b->device);
     hipStreamSynchronize(b->stream);
     void *ptrs[] = {b->d_V, b->d_rows, b->d_stream_off, b->d_extras, b->d_extra_off, b->d_consts, b->d_w2s, b->d_status, b->d_first_bad,
-                    b->d_rptr, b->d_rslot, b->d_rcoef, b->d_rctab, b->d_in, b->d_gather};
+                    b->d_rptr, b->d_rslot, b->d_rcoef, b->d_rctab, b->d_rorig, b->d_in, b->d_gather};
     for (void *p : ptrs)
         if (p) hipFree(p);
     delete b;
@@ -584,6 +631,7 @@ extern "C" int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *
         TRY(upload(&b->d_rslot, c->r_slot, b->stream));
         TRY(upload(&b->d_rcoef, c->r_coef, b->stream));
         TRY(upload(&b->d_rctab, c->r_ctab, b->stream));
+        TRY(upload(&b->d_rorig, c->r_orig, b->stream));
     }
     TRY(hipMalloc(&b->d_in, std::max<size_t>((size_t)batch * c->n_inputs * 32, 32)));
     TRY(hipMalloc(&b->d_gather, std::max<size_t>((size_t)c->n_witness * 32, 32)));
@@ -901,8 +949,8 @@ extern "C" int cw_check_r1cs(cw_batch *b) {
     if (c->n_constraints == 0) return fail(CW_ESTATE, "no .r1cs was loaded for this circuit");
     HIPCHK(hipSetDevice(b->device));
     uint32_t rows_per_block = 64;
-    HIPCHK(cwk_r1cs(b->stream, b->d_rptr, b->d_rslot, b->d_rcoef, b->d_rctab, c->n_constraints, rows_per_block, b->d_V,
-                    b->Bp, b->batch, b->d_status, b->d_first_bad, c->P));
+    HIPCHK(cwk_r1cs(b->stream, b->d_rptr, b->d_rslot, b->d_rcoef, b->d_rctab, b->d_rorig, c->n_constraints,
+                    rows_per_block, b->d_V, b->Bp, b->batch, b->d_status, b->d_first_bad, c->P));
     return CW_OK;
 }
 

@@ -253,44 +253,54 @@ cw_eval_kernel(const CwRow *__restrict__ rows, const uint32_t *__restrict__ stre
 }
 
 // ---- R1CS check:  (A.w) * (B.w) == C.w  for every constraint row and instance ---------------------------
-// Terms are CSR: for row c the A/B/C term ranges are ptr[3c..3c+3]; each term = (value slot, coefficient
-// id).  Coefficient ids 0/1 mean +1/-1 (add/sub fast path); others index ctab, which holds c*R mod q so
-// that one MMUL gives w*c on canonical w.
-__global__ void __launch_bounds__(CW_BLOCK)
+// One wave = 64 instances x one chunk of constraint rows (uniform control flow, term tables through scalar
+// loads).  Terms are CSR: for row c the A/B/C term ranges are ptr[3c..3c+3]; each term = (value slot,
+// coefficient id).  Coefficient ids 0/1 mean +1/-1 (add/sub); others index ctab, which holds c*R' mod q so
+// that one MMUL gives w*c on canonical w.  The host orders the rows by the time their youngest wire is
+// produced by the schedule (temporal locality: a wire is re-read while still in L2) and tags pure
+// equalities x - y = 0 (component wiring, ~75 % of the rows at --O0), which are checked by comparison.
+// `orig` maps the processing order back to the constraint index of the .r1cs file for reporting.
+__device__ __forceinline__ fe r1cs_dot(const uint32_t *__restrict__ tslot, const uint32_t *__restrict__ tcoef,
+                                       const uint32_t *__restrict__ ctab, uint32_t t0, uint32_t t1, const uint4 *V,
+                                       uint32_t Bp, uint32_t i, const FpParams &P) {
+    fe s = fe_zero();
+    for (uint32_t t = t0; t < t1; t++) {
+        const fe w = v_load(V, tslot[t], Bp, i);
+        const uint32_t ci = tcoef[t];
+        if (ci == 0) s = fe_add(s, w, P);
+        else if (ci == 1) s = fe_sub(s, w, P);
+        else s = fe_add(s, fe_mmul(w, c_load(ctab, ci), P), P);
+    }
+    return s;
+}
+
+__global__ void __launch_bounds__(64)
 cw_r1cs_kernel(const uint32_t *__restrict__ ptr, const uint32_t *__restrict__ tslot, const uint32_t *__restrict__ tcoef,
-               const uint32_t *__restrict__ ctab, uint32_t n_cons, uint32_t rows_per_block, const uint4 *__restrict__ V,
-               uint32_t Bp, uint32_t batch, uint32_t *status, uint32_t *first_bad, FpParams P) {
-    const uint32_t i = blockIdx.x * CW_BLOCK + threadIdx.x;
-    if (i >= batch) return;
-    uint32_t c0 = blockIdx.y * rows_per_block;
-    uint32_t c1 = min(c0 + rows_per_block, n_cons);
+               const uint32_t *__restrict__ ctab, const uint32_t *__restrict__ orig, uint32_t n_cons,
+               uint32_t rows_per_block, const uint4 *__restrict__ V, uint32_t Bp, uint32_t batch, uint32_t *status,
+               uint32_t *first_bad, FpParams P) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;               // < Bp
+    const uint32_t c0 = blockIdx.y * rows_per_block;
+    const uint32_t c1 = min(c0 + rows_per_block, n_cons);
     uint32_t bad = 0xFFFFFFFFu;
     for (uint32_t c = c0; c < c1; c++) {
-        fe acc[3];
-        for (int part = 0; part < 3; part++) {
-            fe s = fe_zero();
-            const uint32_t t0 = ptr[3 * c + part], t1 = ptr[3 * c + part + 1];
-            for (uint32_t t = t0; t < t1; t++) {
-                const fe w = v_load(V, tslot[t], Bp, i);
-                const uint32_t ci = tcoef[t];
-                if (ci == 0) s = fe_add(s, w, P);
-                else if (ci == 1) s = fe_sub(s, w, P);
-                else s = fe_add(s, fe_mmul(w, c_load(ctab, ci), P), P);
-            }
-            acc[part] = s;
-        }
-        const bool lin = (ptr[3 * c] == ptr[3 * c + 1]) | (ptr[3 * c + 1] == ptr[3 * c + 2]);
+        const uint32_t pa = ptr[3 * c], pb = ptr[3 * c + 1], pc = ptr[3 * c + 2], pe = ptr[3 * c + 3];
+        const uint32_t tag = orig[c];                                // bit 31: pure equality of two wires
         bool ok;
-        if (lin) {
-            ok = fe_is_zero(acc[2]);
+        if (tag >> 31) {
+            ok = fe_eq(v_load(V, tslot[pc], Bp, i), v_load(V, tslot[pc + 1], Bp, i));
+        } else if (pa == pb || pb == pc) {                           // A or B empty: linear row, C must vanish
+            ok = fe_is_zero(r1cs_dot(tslot, tcoef, ctab, pc, pe, V, Bp, i, P));
         } else {
-            const fe lhs = fe_mmul(acc[0], acc[1], P);          // A*B / R
-            const fe rhs = fe_mmul(acc[2], fe_small(1), P);     // C / R
-            ok = fe_eq(lhs, rhs);
+            const fe A = r1cs_dot(tslot, tcoef, ctab, pa, pb, V, Bp, i, P);
+            const fe B = r1cs_dot(tslot, tcoef, ctab, pb, pc, V, Bp, i, P);
+            const fe C = r1cs_dot(tslot, tcoef, ctab, pc, pe, V, Bp, i, P);
+            ok = fe_eq(fe_mmul(A, B, P), fe_mmul(C, fe_small(1), P));   // A*B/R' == C/R'
         }
-        if (!ok && c < bad) bad = c;
+        const uint32_t oc = tag & 0x7FFFFFFFu;
+        if (!ok && oc < bad) bad = oc;
     }
-    if (bad != 0xFFFFFFFFu) {
+    if (bad != 0xFFFFFFFFu && i < batch) {
         atomicMin(&first_bad[i], bad);
         atomicOr(&status[i], CW_ST_R1CS_FAILED);
     }
@@ -407,11 +417,11 @@ hipError_t cwk_eval(hipStream_t s, bool full, const CwRow *rows, const uint32_t 
     return hipGetLastError();
 }
 hipError_t cwk_r1cs(hipStream_t s, const uint32_t *ptr, const uint32_t *tslot, const uint32_t *tcoef, const uint32_t *ctab,
-                    uint32_t n_cons, uint32_t rows_per_block, const void *V, uint32_t Bp, uint32_t batch, uint32_t *status,
-                    uint32_t *first_bad, const FpParams &P) {
+                    const uint32_t *orig, uint32_t n_cons, uint32_t rows_per_block, const void *V, uint32_t Bp,
+                    uint32_t batch, uint32_t *status, uint32_t *first_bad, const FpParams &P) {
     if (n_cons == 0) return hipSuccess;
-    dim3 g((batch + CW_BLOCK - 1) / CW_BLOCK, (n_cons + rows_per_block - 1) / rows_per_block);
-    hipLaunchKernelGGL(cw_r1cs_kernel, g, dim3(CW_BLOCK), 0, s, ptr, tslot, tcoef, ctab, n_cons, rows_per_block,
+    dim3 g((batch + 63) / 64, (n_cons + rows_per_block - 1) / rows_per_block);
+    hipLaunchKernelGGL(cw_r1cs_kernel, g, dim3(64), 0, s, ptr, tslot, tcoef, ctab, orig, n_cons, rows_per_block,
                        (const uint4 *)V, Bp, batch, status, first_bad, P);
     return hipGetLastError();
 }
