@@ -297,7 +297,7 @@ static int load_tape(cw_circuit *c, const char *path) {
         for (auto &r : var.rows) {
             uint32_t op = r.w0 & 0xFF;
             if (op >= D_NOPS) return fail(CW_EIO, "tape contains an unknown opcode");
-            if (op == D_MMUL || op == D_MADD) mm++;
+            if (op == D_MMUL || op == D_MADD || op == D_MULC || op == D_MADDC) mm++;
             if (op == D_MUL2) mm += 2;
             if (op == D_INV || op == D_IDIV || op == D_MOD || op == D_POW) c->need_full = true;
         }

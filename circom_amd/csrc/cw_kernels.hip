@@ -174,8 +174,18 @@ cw_eval_kernel(const CwRow *__restrict__ rows, const uint32_t *__restrict__ stre
         case D_SUB: d = fe_sub(a, b, P); break;
         case D_NEG: d = fe_neg(a, P); break;
         case D_MMUL: d = fe_mmul(a, b, P); break;
-        case D_MUL2: d = fe_mul2(a, b, P); break;
+        case D_MUL2: d = fe_mul2_auto(a, b, P); break;
         case D_MADD: d = fe_add(fe_mmul(a, b, P), prev, P); break;
+        case D_MULC:
+        case D_MADDC: {
+            // operand b = c*R'; consts[row.b+1] = |val(c)| when the lowering flagged c as a small integer
+            const uint32_t cs = (row.w0 >> SH_FLAG) & 3;
+            uint64_t cmag = 0;
+            if (cs) cmag = ((uint64_t)consts[(size_t)(row.b + 1) * 8 + 1] << 32) | consts[(size_t)(row.b + 1) * 8];
+            d = fe_mulc_auto(a, b, cs != 0, cmag, cs == 2, P);
+            if (op == D_MADDC) d = fe_add(d, prev, P);
+            break;
+        }
         case D_SHL: d = fe_shl(a, b, P); break;
         case D_SHR: d = fe_shr(a, b, P); break;
         case D_BAND: d = fe_band(a, b, P); break;
@@ -347,7 +357,7 @@ cw_fpop_kernel(uint32_t op, const uint4 *a_, const uint4 *b_, const uint4 *c_, u
     case D_SUB: d = fe_sub(a, b, P); break;
     case D_NEG: d = fe_neg(a, P); break;
     case D_MMUL: d = fe_mmul(a, b, P); break;
-    case D_MUL2: d = fe_mul2(a, b, P); break;
+    case D_MUL2: d = fe_mul2_auto(a, b, P); break;       // includes the per-wave short path
     case D_MADD: d = fe_add(fe_mmul(a, b, P), c, P); break;
     case D_INV: d = fe_pow_uniform(a, P.qm2, P); break;
     case D_POW: d = fe_pow(a, b, P); break;

@@ -6,14 +6,15 @@
 enum : uint32_t {
     D_COPY = 0, D_ADD, D_SUB, D_NEG, D_MMUL, D_INV, D_IDIV, D_MOD, D_POW, D_SHL, D_SHR, D_BAND, D_BOR, D_BXOR,
     D_BNOT, D_LT, D_GT, D_LEQ, D_GEQ, D_EQ, D_NEQ, D_LAND, D_LOR, D_LNOT, D_SELECT, D_EXT, D_ASSERT_EQ,
-    D_ASSERT_NZ, D_ALSO, D_BARRIER, D_MUL2, D_MADD, D_NOPS
+    D_ASSERT_NZ, D_ALSO, D_BARRIER, D_MUL2, D_MADD, D_MULC, D_MADDC, D_NOPS
 };
 
-// row.w0 = op[0:8) | dk[8:11) | ak[11:14) | bk[14:17) | n_extra[17:29)
+// row.w0 = op[0:8) | dk[8:11) | ak[11:14) | bk[14:17) | n_extra[17:29) | const flags[29:31)
 #define SH_DK 8
 #define SH_AK 11
 #define SH_BK 14
 #define SH_NX 17
+#define SH_FLAG 29   // D_MULC/D_MADDC: 1 = constant is a small positive integer, 2 = small negative
 // operand kinds: value-table signal slot, value-table temp slot, constant index, PREV (result of the previous
 // value-producing row of the strand, forwarded in registers), LDS slot of the workgroup
 enum : uint32_t { K_SIG = 0, K_TMP = 1, K_CONST = 2, K_PREV = 3, K_LDS = 4 };

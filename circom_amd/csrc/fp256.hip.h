@@ -206,6 +206,72 @@ __device__ __forceinline__ fe fe_mul2(const fe &a, const fe &b, const FpParams &
     return fe_from29(fe29_mmul(t, fe_to29(fe_from(P.r2)), P));
 }
 
+// ---- run-time short path for products of small signed values -------------------------------------------
+// The reference keeps small values as int32 "short" elements and multiplies them with one imul
+// (mul_s1s2, generic/fr.cpp:416-439); bit-heavy circuits (SHA-256, Num2Bits, comparators) run almost
+// entirely on that path.  The device representation is uniform (canonical 256-bit), so the short path is
+// selected PER WAVE at run time: if every lane's operands are "signed small" (x < 2^64 or q - x < 2^64) the
+// product is a 64x64 -> 128-bit multiply (4 v_mad_u64_u32) plus one conditional q - p; otherwise the wave
+// takes the generic Montgomery path.  Both paths produce the same canonical residue, so the choice never
+// changes a result.
+__device__ __forceinline__ uint32_t fe_hi_or(const fe &x) { return x.v[2] | x.v[3] | x.v[4] | x.v[5] | x.v[6] | x.v[7]; }
+
+// decode x as sign * mag with mag < 2^64; returns false for lanes where that is impossible
+__device__ __forceinline__ bool fe_signed_small(const fe &x, const FpParams &P, uint64_t *mag, bool *neg) {
+    const bool pos = fe_hi_or(x) == 0;
+    fe d;
+    int64_t br = 0;
+    FE_UNROLL for (int i = 0; i < 8; i++) {
+        int64_t t = (int64_t)P.q[i] - (int64_t)x.v[i] + br;
+        d.v[i] = (uint32_t)t;
+        br = t >> 32;
+    }
+    const bool ng = fe_hi_or(d) == 0;
+    *mag = pos ? (((uint64_t)x.v[1] << 32) | x.v[0]) : (((uint64_t)d.v[1] << 32) | d.v[0]);
+    *neg = !pos;
+    return pos | ng;
+}
+// sign * (ma * mb) as a canonical residue
+__device__ __forceinline__ fe fe_small_product(uint64_t ma, uint64_t mb, bool neg, const FpParams &P) {
+    const uint32_t a0 = (uint32_t)ma, a1 = (uint32_t)(ma >> 32), b0 = (uint32_t)mb, b1 = (uint32_t)(mb >> 32);
+    uint64_t t = (uint64_t)a0 * b0;
+    fe p = fe_zero();
+    p.v[0] = (uint32_t)t;
+    t = (uint64_t)a0 * b1 + (t >> 32);
+    const uint64_t t2 = (uint64_t)a1 * b0 + (uint32_t)t;
+    p.v[1] = (uint32_t)t2;
+    t = (uint64_t)a1 * b1 + (t >> 32) + (t2 >> 32);
+    p.v[2] = (uint32_t)t;
+    p.v[3] = (uint32_t)(t >> 32);
+    const fe n = fe_neg(p, P);                         // q - p, and 0 for p = 0
+    fe r;
+    FE_UNROLL for (int i = 0; i < 8; i++) r.v[i] = neg ? n.v[i] : p.v[i];
+    return r;
+}
+// canonical a*b with the short path
+__device__ __forceinline__ fe fe_mul2_auto(const fe &a, const fe &b, const FpParams &P) {
+    if (__all((fe_hi_or(a) | fe_hi_or(b)) == 0)) {    // every lane: both operands < 2^64
+        return fe_small_product(((uint64_t)a.v[1] << 32) | a.v[0], ((uint64_t)b.v[1] << 32) | b.v[0], false, P);
+    }
+    uint64_t ma, mb;
+    bool na, nb;
+    const bool ok = fe_signed_small(a, P, &ma, &na) & fe_signed_small(b, P, &mb, &nb);
+    if (__all(ok)) return fe_small_product(ma, mb, na != nb, P);
+    return fe_mul2(a, b, P);
+}
+// canonical a*c for a compile-time constant: bm = c*R' (generic path), (cmag, cneg) = |val(c)| when small
+__device__ __forceinline__ fe fe_mulc_auto(const fe &a, const fe &bm, bool c_small, uint64_t cmag, bool cneg,
+                                           const FpParams &P) {
+    if (c_small) {
+        if (__all(fe_hi_or(a) == 0)) return fe_small_product(((uint64_t)a.v[1] << 32) | a.v[0], cmag, cneg, P);
+        uint64_t ma;
+        bool na;
+        const bool ok = fe_signed_small(a, P, &ma, &na);
+        if (__all(ok)) return fe_small_product(ma, cmag, na != cneg, P);
+    }
+    return fe_mmul(a, bm, P);
+}
+
 // ---- bitwise operators on canonical values (Fr_rawAnd/Or/Xor/Not, generic/fr.cpp:293-327,366-376) ----
 __device__ __forceinline__ fe fe_mask_wrap(fe r, const FpParams &P) {
     r.v[7] &= P.topmask;

@@ -51,10 +51,15 @@ from ..frontend.flatten import FlatCircuit
 # device opcodes (csrc/cw_tape.h must match)
 (D_COPY, D_ADD, D_SUB, D_NEG, D_MMUL, D_INV, D_IDIV, D_MOD, D_POW, D_SHL, D_SHR, D_BAND, D_BOR, D_BXOR,
  D_BNOT, D_LT, D_GT, D_LEQ, D_GEQ, D_EQ, D_NEQ, D_LAND, D_LOR, D_LNOT, D_SELECT, D_EXT, D_ASSERT_EQ,
- D_ASSERT_NZ, D_ALSO, D_BARRIER, D_MUL2, D_MADD) = range(32)
+ D_ASSERT_NZ, D_ALSO, D_BARRIER, D_MUL2, D_MADD, D_MULC, D_MADDC) = range(34)
 D_NAMES = ["copy", "add", "sub", "neg", "mmul", "inv", "idiv", "mod", "pow", "shl", "shr", "band", "bor",
            "bxor", "bnot", "lt", "gt", "leq", "geq", "eq", "neq", "land", "lor", "lnot", "select", "ext",
-           "assert_eq", "assert_nz", "also", "barrier", "mul2", "madd"]
+           "assert_eq", "assert_nz", "also", "barrier", "mul2", "madd", "mulc", "maddc"]
+# D_MULC : d = a * c on canonical values, c a compile-time constant.  Operand b = index of a constant PAIR:
+#          [b] = c*R' (so that MMUL(a,[b]) = a*c), [b+1] = |val(c)| when c is a small signed integer.  Word-0
+#          flags CS_POS / CS_NEG say so; the kernel then multiplies small run-time values directly
+#          (the reference's short-int path, fr.cpp:416-439, chosen per wave at run time).
+# D_MADDC: d = a * c + PREV, same operand convention.
 # D_MUL2: d = a*b on canonical values  (= MMUL(MMUL(a,b), R'^2), the intermediate stays in registers)
 # D_MADD: d = MMUL(a,b) + PREV          (multiply-accumulate of `lc += coeff * signal` chains)
 # D_SELECT: latches the lane mask cond != 0 (no value); the following D_EXT row yields mask ? a : b
@@ -67,7 +72,7 @@ _DIRECT = {O.COPY: D_COPY, O.ADD: D_ADD, O.SUB: D_SUB, O.NEG: D_NEG, O.IDIV: D_I
            O.POW: D_POW, O.SHL: D_SHL, O.SHR: D_SHR, O.BAND: D_BAND, O.BOR: D_BOR, O.BXOR: D_BXOR,
            O.BNOT: D_BNOT, O.LT: D_LT, O.GT: D_GT, O.LEQ: D_LEQ, O.GEQ: D_GEQ, O.EQ: D_EQ, O.NEQ: D_NEQ,
            O.LAND: D_LAND, O.LOR: D_LOR, O.LNOT: D_LNOT, O.ASSERT_EQ: D_ASSERT_EQ, O.ASSERT_NZ: D_ASSERT_NZ}
-_COST = {D_MMUL: 10.0, D_MUL2: 19.0, D_MADD: 11.0, D_INV: 4000.0, D_POW: 6000.0, D_IDIV: 8000.0, D_MOD: 8000.0}
+_COST = {D_MMUL: 10.0, D_MUL2: 19.0, D_MADD: 11.0, D_MULC: 10.0, D_MADDC: 11.0, D_INV: 4000.0, D_POW: 6000.0, D_IDIV: 8000.0, D_MOD: 8000.0}
 _NO_VALUE = (D_ASSERT_EQ, D_ASSERT_NZ, D_SELECT)
 
 
@@ -114,12 +119,13 @@ def _dce(code, n_temps):
 
 
 class _Row:
-    __slots__ = ("op", "dk", "dv", "ak", "av", "bk", "bv", "ck", "cv", "extra", "level", "strand")
+    __slots__ = ("op", "dk", "dv", "ak", "av", "bk", "bv", "ck", "cv", "extra", "level", "strand", "flag")
 
     def __init__(self, op, dk, dv, ak, av, bk=K_NONE, bv=0, ck=K_NONE, cv=0):
         self.op, self.dk, self.dv = op, dk, dv
         self.ak, self.av, self.bk, self.bv, self.ck, self.cv = ak, av, bk, bv, ck, cv
         self.extra = None        # list of (kind, id) extra destinations
+        self.flag = 0            # D_MULC/D_MADDC: 1 = constant is a small positive integer, 2 = small negative
         self.level = 0
         self.strand = 0
 
@@ -149,6 +155,26 @@ def _expand(fc: FlatCircuit):
 
     R, R2 = fp.Rdev, fp.Rdev2
     nxt = [fc.n_temps]
+    pair_id = {}
+    small_flag = {}
+
+    def cpair(c):
+        """constant pair for D_MULC/D_MADDC: scaled value, then the magnitude of the signed value if small"""
+        c %= q
+        i = pair_id.get(c)
+        if i is None:
+            mag, flag = 0, 0
+            if c < (1 << 63):
+                mag, flag = c, 1
+            elif q - c < (1 << 63):
+                mag, flag = q - c, 2
+            i = len(dconsts)
+            dconsts.append((c * R) % q)
+            dconsts.append(mag)
+            pair_id[c] = i
+            small_flag[i] = flag
+        return i, small_flag[i]
+
 
     def fresh():
         t = nxt[0]
@@ -170,7 +196,10 @@ def _expand(fc: FlatCircuit):
                     xk, xv, c = bk[i], bv[i], consts_in[av[i]]
                 else:
                     xk, xv, c = ak[i], av[i], consts_in[bv[i]]
-                rows.append(_Row(D_MMUL, dk[i], dv[i], xk, xv, K_CONST, cid((c * R) % q)))
+                ci, fl = cpair(c)
+                r_ = _Row(D_MULC, dk[i], dv[i], xk, xv, K_CONST, ci)
+                r_.flag = fl
+                rows.append(r_)
             else:
                 rows.append(_Row(D_MUL2, dk[i], dv[i], ak[i], av[i], bk[i], bv[i]))
         elif o == O.DIV:
@@ -277,7 +306,7 @@ def _fuse_madd(rows):
     i, n, fused = 0, len(rows), 0
     while i < n:
         r = rows[i]
-        if (r.op == D_MMUL and r.dk == K_TMP and uses.get(r.dv) == 1 and r.extra is None and i + 1 < n and out):
+        if (r.op in (D_MMUL, D_MULC) and r.dk == K_TMP and uses.get(r.dv) == 1 and r.extra is None and i + 1 < n and out):
             add, x = rows[i + 1], out[-1]
             if add.op == D_ADD and x.op not in _NO_VALUE and x.dk in (K_SIG, K_TMP):
                 t_op, x_op = (K_TMP, r.dv), (x.dk, x.dv)
@@ -285,7 +314,8 @@ def _fuse_madd(rows):
                 # x must not itself feed the product (it is only available as PREV, which MADD uses as addend)
                 feeds = (r.ak, r.av) == x_op or (r.bk, r.bv) == x_op
                 if not feeds and (ops == (x_op, t_op) or ops == (t_op, x_op)):
-                    m = _Row(D_MADD, add.dk, add.dv, r.ak, r.av, r.bk, r.bv)      # addend = PREV (the row before)
+                    m = _Row(D_MADD if r.op == D_MMUL else D_MADDC, add.dk, add.dv, r.ak, r.av, r.bk, r.bv)  # addend = PREV
+                    m.flag = r.flag
                     m.extra = add.extra
                     out.append(m)
                     fused += 1
@@ -413,8 +443,8 @@ def lds_slots_for(n_strands: int) -> int:
     return 0 if n_strands <= 1 else (72 * n_strands) // 16
 
 
-# row word 0 layout:  op[0:8) | dk[8:11) | ak[11:14) | bk[14:17) | n_extra[17:29)
-SH_DK, SH_AK, SH_BK, SH_NX = 8, 11, 14, 17
+# row word 0 layout:  op[0:8) | dk[8:11) | ak[11:14) | bk[14:17) | n_extra[17:29) | const-small flags[29:31)
+SH_DK, SH_AK, SH_BK, SH_NX, SH_FLAG = 8, 11, 14, 17, 29
 MAX_EXTRA = 4095
 K_LDS = 4             # operand / destination kind: LDS slot of the workgroup (cross-strand hand-off)
 X_TMP, X_LDS = 1 << 31, 1 << 30       # flags of an entry of the extra-destination table
@@ -579,7 +609,8 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
                     elif v in slot_of:
                         ex.append(X_TMP | slot_of[v])
             assert len(ex) <= MAX_EXTRA, "fan-out of one value exceeds the extra-destination field"
-            enc.append((r.op | (kd << SH_DK) | (ka << SH_AK) | (kb << SH_BK) | (len(ex) << SH_NX), vd, va, vb))
+            enc.append((r.op | (kd << SH_DK) | (ka << SH_AK) | (kb << SH_BK) | (len(ex) << SH_NX) | (r.flag << SH_FLAG),
+                        vd, va, vb))
             extras.extend(ex)
         stream_off.append(len(enc))
         extra_off.append(len(extras))
@@ -616,6 +647,7 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
         "lds_operands": n_ldsops,
         "lds_slots": n_lds_used,
         "mul2": int((dops == D_MUL2).sum()),
+        "mulc": int(((dops == D_MULC) | (dops == D_MADDC)).sum()),
         "madd": n_madd,
         "inv": int((dops == D_INV).sum()),
         "barriers": n_levels,

@@ -92,7 +92,7 @@ def check_r1cs(q: int, constraints, w) -> int | None:
 # D_* numbering of circom_amd/csrc/cw_tape.h
 (D_COPY, D_ADD, D_SUB, D_NEG, D_MMUL, D_INV, D_IDIV, D_MOD, D_POW, D_SHL, D_SHR, D_BAND, D_BOR, D_BXOR,
  D_BNOT, D_LT, D_GT, D_LEQ, D_GEQ, D_EQ, D_NEQ, D_LAND, D_LOR, D_LNOT, D_SELECT, D_EXT, D_ASSERT_EQ,
- D_ASSERT_NZ, D_ALSO, D_BARRIER, D_MUL2, D_MADD) = range(32)     # D_ALSO is no longer emitted
+ D_ASSERT_NZ, D_ALSO, D_BARRIER, D_MUL2, D_MADD, D_MULC, D_MADDC) = range(34)     # D_ALSO is no longer emitted
 _DBIN = {D_ADD: "add", D_SUB: "sub", D_IDIV: "idiv", D_MOD: "mod", D_POW: "pow", D_SHL: "shl", D_SHR: "shr",
          D_BAND: "band", D_BOR: "bor", D_BXOR: "bxor", D_LT: "lt", D_GT: "gt", D_LEQ: "leq", D_GEQ: "geq",
          D_EQ: "eq", D_NEQ: "neq", D_LAND: "land", D_LOR: "lor"}
@@ -218,6 +218,17 @@ def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict,
                 res = a * b % q
             elif op == D_MADD:
                 res = (a * b * rinv + prev[s]) % q
+            elif op in (D_MULC, D_MADDC):
+                # operand b = scaled constant c*R'; [b+1] = |val(c)| with flags in word 0 (checked for consistency)
+                flag = (w0 >> 29) & 3
+                res = a * b * rinv % q
+                if flag:
+                    mag = consts[b_ + 1]
+                    c_plain = mag if flag == 1 else (q - mag) % q
+                    if mag >= (1 << 63) or (a * c_plain) % q != res:
+                        raise ScheduleHazard("constant pair of row %d is inconsistent" % r)
+                if op == D_MADDC:
+                    res = (res + prev[s]) % q
             elif op in bins:
                 try:
                     res = bins[op](a, b)

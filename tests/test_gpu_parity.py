@@ -65,6 +65,27 @@ def test_device_field_ops_match_oracle(prime):
     assert list(st) == [0 if a == b else rt.ST_ASSERT_FAILED for a, b in zip(A, B)]
 
 
+@pytest.mark.parametrize("prime", ["bn128", "bls12381"])
+def test_device_short_path_products(prime):
+    """Waves whose 64 lanes all hold signed-small operands take the 64x64-bit short path (fe_mul2_auto):
+    same canonical result as the Montgomery path, including the +-(2^64-1) boundaries, zero and mixed signs;
+    one large lane anywhere in a wave sends that wave down the generic path."""
+    f = Field(PRIMES[prime])
+    q = f.q
+    small = [0, 1, 2, 3, (1 << 31) - 1, 1 << 31, (1 << 32) - 1, 1 << 32, (1 << 63) - 1, 1 << 63, (1 << 64) - 1,
+             q - 1, q - 2, q - (1 << 32), q - (1 << 63), q - ((1 << 64) - 1)]
+    edge = [1 << 64, q - (1 << 64), q >> 1, 12345678901234567890123456789]       # not signed-small
+    rng = random.Random(3)
+    A = [a for a in small for _ in small]                 # 256 lanes = 4 waves, all signed-small
+    B = [b for _ in small for b in small]
+    A += [rng.choice(small) for _ in range(192)] + [rng.choice(small + edge) for _ in range(320)]
+    B += [rng.choice(small) for _ in range(192)] + [rng.choice(small + edge) for _ in range(320)]
+    got, st = rt.fp_op(q, L.D_MUL2, A, B, A)
+    want = [f.mul(a, b) for a, b in zip(A, B)]
+    bad = [i for i in range(len(A)) if got[i] != want[i]]
+    assert not bad, (prime, hex(A[bad[0]]), hex(B[bad[0]]), hex(got[bad[0]]), hex(want[bad[0]]))
+
+
 def _compile(tmp_path, prog, name):
     cp = compile_program(prog, str(tmp_path), name)
     return cp, rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
