@@ -648,7 +648,8 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
         "lds_slots": n_lds_used,
         "mul2": int((dops == D_MUL2).sum()),
         "mulc": int(((dops == D_MULC) | (dops == D_MADDC)).sum()),
-        "madd": n_madd,
+        "madd": int((dops == D_MADD).sum()),
+        "fused_madd": n_madd,
         "inv": int((dops == D_INV).sum()),
         "barriers": n_levels,
         "full_barriers": len(full_after),
