@@ -1,0 +1,127 @@
+"""More circuits on the same path: the BLS12-381 scalar field (`--prime bls12381`, BASELINE config 5's prime) and
+a depth-20 Poseidon Merkle inclusion proof (the Merkle half of BASELINE config 4)."""
+import random
+
+import numpy as np
+import pytest
+
+from circom_amd.compiler import compile_program
+from circom_amd.frontend.dsl import Program
+from circom_amd.frontend.flatten import flatten
+from circom_amd.hip_elements.lower import lower
+from circom_amd.hip_elements.writers import wtns_bytes
+from circom_amd.circuits.basic import Num2Bits, IsZero, Multiplier2
+from circom_amd.circuits.poseidon import Poseidon
+from circom_amd.circuits.poseidon_constants import poseidon_hash
+from circom_amd.circuits.merkle import MerkleTreeInclusionProof
+from oracle import ref_build
+from oracle.field import PRIMES
+from oracle.tape_eval import eval_flat, eval_tape, check_r1cs
+
+
+def _merkle_case(q, depth, rng):
+    leaf = rng.randrange(q)
+    idx = [rng.randrange(2) for _ in range(depth)]
+    sib = [rng.randrange(q) for _ in range(depth)]
+    h = leaf
+    for i in range(depth):
+        h = poseidon_hash(q, [sib[i], h] if idx[i] else [h, sib[i]])
+    return leaf, idx, sib, h
+
+
+def test_merkle_depth20_root_r1cs_and_schedules():
+    q = PRIMES["bn128"]
+    fc = flatten(Program(MerkleTreeInclusionProof(20)))
+    assert fc.inputs == [("leaf", 2, 1), ("pathIndices", 3, 20), ("siblings", 23, 20)]
+    rng = random.Random(4)
+    leaf, idx, sib, root = _merkle_case(q, 20, rng)
+    inp = {2: leaf}
+    inp.update({3 + i: b for i, b in enumerate(idx)})
+    inp.update({23 + i: s for i, s in enumerate(sib)})
+    sig, failed = eval_flat(q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp)
+    assert failed is None and sig[1] == root
+    assert check_r1cs(q, fc.constraints, sig) is None
+    for S in (1, 4):
+        t = lower(fc, n_strands=S)
+        got, st = eval_tape(t, inp)
+        assert st == 0 and got == sig
+    inp[3] = 2                                   # a non-boolean path index trips its `===`
+    sig2, failed = eval_flat(q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp)
+    assert failed is not None
+
+
+def test_bls12381_prime_reference_runtime_parity(tmp_path, ref_dir_bls12381):
+    """`--prime bls12381`: same circuits over the BLS12-381 scalar field; the reference runtime rendered for that
+    prime (oracle/_ref/bls12381) must produce the oracle's .wtns byte for byte."""
+    q = PRIMES["bls12381"]
+    rng = random.Random(12)
+    for prog, name, cases in ((Program(Multiplier2(), prime="bls12381"), "multiplier2_bls", [[3, 11], [q - 1, q - 2]]),
+                              (Program(Num2Bits(16), prime="bls12381"), "num2bits16_bls", [[0], [65535], [43690]]),
+                              (Program(IsZero(), prime="bls12381"), "iszero_bls", [[0], [5], [q - 1]]),
+                              (Program(Poseidon(2), prime="bls12381"), "poseidon2_bls",
+                               [[1, 2], [rng.randrange(q), rng.randrange(q)]])):
+        cp = compile_program(prog, str(tmp_path), name, sym=False, strands=(1, 4))
+        fc = cp.flat
+        assert fc.fp.q == q
+        try:
+            ref_build.build_circuit(cp)
+        except RuntimeError as e:
+            pytest.skip(str(e))
+        raw = b"".join(v.to_bytes(32, "little") for row in cases for v in row)
+        pre = str(tmp_path / (name + "_"))
+        ref_build.run_loop(cp, raw, len(cases), 1, wtns_prefix=pre)
+        for i, row in enumerate(cases):
+            inp = {fc.main_input_start + k: v for k, v in enumerate(row)}
+            want, failed = eval_flat(q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp)
+            assert failed is None
+            assert open(pre + "%d.wtns" % i, "rb").read() == wtns_bytes(q, want), (name, row)
+            for t in cp_tapes(fc):
+                got, st = eval_tape(t, inp)
+                assert st == 0 and got == want
+            if name == "poseidon2_bls":
+                assert want[1] == poseidon_hash(q, row)
+
+
+def cp_tapes(fc):
+    return [lower(fc, n_strands=s) for s in (1, 4)]
+
+
+@pytest.mark.gpu
+def test_gpu_bls12381_and_merkle(tmp_path):
+    from circom_amd import runtime as rt
+    q = PRIMES["bls12381"]
+    rng = random.Random(31)
+    cp = compile_program(Program(Poseidon(2), prime="bls12381"), str(tmp_path), "poseidon2_bls", sym=False)
+    c = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
+    assert c.q == q
+    n = 300
+    ins = [[rng.randrange(q), rng.randrange(q)] for _ in range(n)]
+    b = c.batch(n)
+    b.set_inputs(ins)
+    b.run(); b.check_r1cs(); b.sync()
+    assert (b.status() == 0).all()
+    fc = cp.flat
+    for i in (0, 63, 64, 299):
+        want, failed = eval_flat(q, fc.n_signals, fc.n_temps, fc.constants, fc.code, {2: ins[i][0], 3: ins[i][1]})
+        assert b.witness(i) == want
+    b.close(); c.close()
+    # Merkle depth 20, bn128, a batch with one bad path index
+    q = PRIMES["bn128"]
+    cp = compile_program(Program(MerkleTreeInclusionProof(20)), str(tmp_path), "merkle20", sym=False)
+    c = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
+    n = 200
+    cases = [_merkle_case(q, 20, rng) for _ in range(n)]
+    rows = [[leaf] + idx + sib for leaf, idx, sib, _ in cases]
+    rows[7][1] = 2
+    b = c.batch(n)
+    b.set_inputs(rows)
+    b.run(); b.check_r1cs(); b.sync()
+    st = b.status()
+    assert st[7] & rt.ST_ASSERT_FAILED and (np.delete(st, 7) == 0).all()
+    for i in (0, 1, 100, 199):
+        assert b.signal(i, 1) == cases[i][3]
+    fc = cp.flat
+    inp = {2 + k: v for k, v in enumerate(rows[5])}
+    want, failed = eval_flat(q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp)
+    assert failed is None and b.witness(5) == want
+    b.close(); c.close()
