@@ -526,14 +526,16 @@ struct cw_batch {
     hipStream_t stream = nullptr;
     void *d_V = nullptr;
     size_t v_bytes = 0;
-    CwRow *d_rows = nullptr;
+    CwDRow *d_rows = nullptr;
     const Variant *var = nullptr;
-    uint32_t *d_stream_off = nullptr, *d_extras = nullptr, *d_extra_off = nullptr;
+    uint32_t *d_stream_off = nullptr, *d_extra_off = nullptr;
+    uint64_t *d_extras = nullptr;
     uint32_t *d_consts = nullptr, *d_w2s = nullptr, *d_status = nullptr, *d_first_bad = nullptr;
     uint32_t *d_rptr = nullptr, *d_rslot = nullptr, *d_rcoef = nullptr, *d_rctab = nullptr, *d_rorig = nullptr;
     void *d_in = nullptr;          // AoS staging [batch][n_in][32]
     void *d_gather = nullptr;      // [n_witness][32]
     const void *ext_in = nullptr;  // caller-owned device inputs (cw_set_inputs_device)
+    std::vector<uint32_t> h_stream_begin;
     std::vector<uint8_t> h_in;     // host staging for per-signal assignment
     std::vector<uint8_t> assigned; // [batch][n_in] flags (inputSignalAssigned, calcwit.cpp:28-32)
     std::vector<uint32_t> remaining;
@@ -618,10 +620,73 @@ extern "C" int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *
             return fail(CW_EDEVICE, std::string(#x ": ") + hipGetErrorString(e2)); \
         }                                                                   \
     } while (0)
-    TRY(upload(&b->d_rows, b->var->rows, b->stream));
-    TRY(upload(&b->d_stream_off, b->var->stream_off, b->stream));
-    TRY(upload(&b->d_extras, b->var->extras, b->stream));
-    TRY(upload(&b->d_extra_off, b->var->extra_off, b->stream));
+    {
+        // resolve the schedule for this batch: slot numbers -> byte offsets (CwDRow), streams padded with NOPs
+        const Variant &v = *b->var;
+        const uint64_t stride = (uint64_t)2 * b->Bp * 16;            // bytes per value slot
+        auto resolve = [&](uint32_t kind, uint32_t idx) -> uint64_t {
+            switch (kind) {
+            case K_SIG: return (uint64_t)idx * stride;
+            case K_TMP: return ((uint64_t)c->n_signals + idx) * stride;
+            case K_CONST: return (uint64_t)idx * 32;
+            case K_LDS: return (uint64_t)idx * 2048;
+            default: return 0;
+            }
+        };
+        std::vector<CwDRow> drows;
+        std::vector<uint32_t> doff(1, 0);
+        drows.reserve(v.rows.size() + 3 * v.n_strands);
+        for (uint32_t st = 0; st < v.n_strands; st++) {
+            for (uint32_t r = v.stream_off[st]; r < v.stream_off[st + 1]; r++) {
+                const CwRow &row = v.rows[r];
+                uint32_t op = row.w0 & 0xFF, dk = (row.w0 >> SH_DK) & 7, ak = (row.w0 >> SH_AK) & 7,
+                         bk = (row.w0 >> SH_BK) & 7;
+                CwDRow d;
+                d.w0 = row.w0;
+                if (op == D_BARRIER) {
+                    d.aux = row.dst;
+                    d.dst_off = d.a_off = d.b_off = 0;
+                } else {
+                    d.aux = r;                                       // schedule row, reported in the status word
+                    d.dst_off = dk == KD_NONE ? 0 : resolve(dk, row.dst);
+                    d.a_off = resolve(ak, row.a);
+                    d.b_off = resolve(bk, row.b);
+                }
+                drows.push_back(d);
+            }
+            doff.push_back((uint32_t)drows.size());
+            for (int k = 0; k < 3; k++) drows.push_back(CwDRow{D_NOP, 0, 0, 0, 0});
+        }
+        std::vector<uint64_t> dex(v.extras.size());
+        for (size_t k = 0; k < v.extras.size(); k++) {
+            uint32_t x = v.extras[k];
+            if (x & X_LDS) dex[k] = (1ull << 63) | ((uint64_t)(x & 0x3FFFFFFFu) * 2048);
+            else dex[k] = resolve((x & X_TMP) ? K_TMP : K_SIG, x & 0x3FFFFFFFu);
+        }
+        // stream offsets now refer to the padded array: stream s starts at doff[s] + 3*s ... keep explicit table
+        std::vector<uint32_t> soff(v.n_strands + 1);
+        for (uint32_t st = 0; st <= v.n_strands; st++) soff[st] = 0;
+        {
+            uint32_t pos = 0;
+            for (uint32_t st = 0; st < v.n_strands; st++) {
+                soff[st] = pos;
+                pos += (v.stream_off[st + 1] - v.stream_off[st]) + 3;
+            }
+            soff[v.n_strands] = pos;
+        }
+        b->h_stream_begin = soff;
+        // the kernel needs [begin, end) of real rows per stream: pass begin in stream_off[s] and end in a second table
+        std::vector<uint32_t> tab(2 * v.n_strands);
+        for (uint32_t st = 0; st < v.n_strands; st++) {
+            tab[2 * st] = soff[st];
+            tab[2 * st + 1] = soff[st] + (v.stream_off[st + 1] - v.stream_off[st]);
+        }
+        TRY(upload(&b->d_rows, drows, b->stream));
+        TRY(upload(&b->d_stream_off, tab, b->stream));
+        TRY(upload(&b->d_extras, dex, b->stream));
+        TRY(upload(&b->d_extra_off, v.extra_off, b->stream));
+        TRY(hipStreamSynchronize(b->stream));                        // host vectors go out of scope
+    }
     TRY(upload(&b->d_consts, c->consts, b->stream));
     TRY(upload(&b->d_w2s, c->w2s, b->stream));
     TRY(hipMalloc((void **)&b->d_status, (size_t)b->Bp * 4));
@@ -936,7 +1001,7 @@ extern "C" int cw_run(cw_batch *b) {
     HIPCHK(cwk_init(b->stream, b->d_V, b->Bp, b->d_status, b->d_first_bad));
     HIPCHK(cwk_ingest(b->stream, in, b->d_V, c->input_start, c->n_inputs, b->batch, b->Bp));
     HIPCHK(cwk_eval(b->stream, c->need_full, b->d_rows, b->d_stream_off, b->d_extras, b->d_extra_off, b->var->n_strands,
-                    b->var->n_lds, b->d_V, b->d_consts, c->n_signals, b->Bp, b->batch, b->d_status, c->P));
+                    b->var->n_lds, b->d_V, b->d_consts, b->Bp, b->batch, b->d_status, c->P));
     b->ran = true;
     return CW_OK;
 }

@@ -79,185 +79,213 @@ __global__ void __launch_bounds__(CW_BLOCK) cw_ingest_kernel(const uint4 *__rest
 // FULL_OPS selects the variant that also carries the slow-path operators (INV/IDIV/MOD/POW).
 extern __shared__ uint4 cw_lds[];       // [slot][2 halves][64 lanes] x 16 B
 
-__device__ __forceinline__ fe lds_load(uint32_t slot, uint32_t lane) {
-    const uint4 lo = cw_lds[(slot * 2 + 0) * 64 + lane], hi = cw_lds[(slot * 2 + 1) * 64 + lane];
+struct EvalCtx {                         // per-wave constants of the interpreter
+    const char *Vb;                      // value table, bytes
+    const char *Cb;                      // constant table, bytes
+    uint32_t vlo, vhi;                   // this lane's byte offsets of the lo/hi half inside a value slot
+    uint32_t lane16;                     // lane * 16 (LDS)
+};
+
+__device__ __forceinline__ fe lds_load_off(uint32_t slot_off, const EvalCtx &c) {
+    const char *p = (const char *)cw_lds + slot_off + c.lane16;
+    const uint4 lo = *(const uint4 *)p, hi = *(const uint4 *)(p + 1024);
     fe r;
     r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
     r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
     return r;
 }
-__device__ __forceinline__ void lds_store(uint32_t slot, uint32_t lane, const fe &x) {
-    cw_lds[(slot * 2 + 0) * 64 + lane] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
-    cw_lds[(slot * 2 + 1) * 64 + lane] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+__device__ __forceinline__ void lds_store_off(uint32_t slot_off, const EvalCtx &c, const fe &x) {
+    char *p = (char *)cw_lds + slot_off + c.lane16;
+    *(uint4 *)p = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    *(uint4 *)(p + 1024) = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
 }
-
-// branch-free operand fetch from global memory: value-table slot, constant (all lanes read the same 32 B),
-// or a harmless dummy (slot 0) for kinds that are resolved at execution time (PREV, LDS, none)
-__device__ __forceinline__ fe fetch_global(uint32_t kind, uint32_t idx, const uint4 *V, const uint4 *consts4,
-                                           uint32_t tmp_base, uint32_t Bp, uint32_t i) {
-    const bool is_val = kind <= K_TMP;
+// branch-free operand fetch: wave-uniform base (SGPR pair) + per-lane 32-bit offset (saddr addressing).
+// Constants: every lane reads the same 32 B.  Kinds resolved at execution time (PREV, LDS) read slot 0.
+__device__ __forceinline__ fe fetch_off(uint32_t kind, uint64_t off, const EvalCtx &c) {
     const bool is_const = kind == K_CONST;
-    const uint32_t slot = is_val ? idx + (kind == K_TMP ? tmp_base : 0u) : 0u;
-    const uint4 *p = is_const ? consts4 + (size_t)idx * 2 : V + ((size_t)slot * 2 * Bp + i);
-    const size_t step = is_const ? 1 : Bp;
-    const uint4 lo = p[0], hi = p[step];
+    const char *base = (is_const ? c.Cb : c.Vb) + off;
+    const uint32_t o_lo = is_const ? 0u : c.vlo, o_hi = is_const ? 16u : c.vhi;
+    const uint4 lo = *(const uint4 *)(base + o_lo), hi = *(const uint4 *)(base + o_hi);
     fe r;
     r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
     r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
     return r;
 }
+__device__ __forceinline__ void store_off(uint64_t off, const EvalCtx &c, const fe &x) {
+    char *base = (char *)c.Vb + off;
+    *(uint4 *)(base + c.vlo) = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    *(uint4 *)(base + c.vhi) = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+}
 
+// One interpreter step: executes `row` with operands (xa, xb) while the operands of `nrow` are requested into
+// (ya, yb).  The loop calls it twice per iteration with the two register sets swapped (no rotation moves).
+template <bool FULL_OPS>
+__device__ __forceinline__ void eval_step(const CwDRow &row, const fe &xa, const fe &xb, const CwDRow &nrow, fe &ya,
+                                          fe &yb, fe &prev, uint64_t &selmask, uint32_t &st, uint32_t r,
+                                          const uint64_t *__restrict__ extras, uint32_t &xp, const EvalCtx &c,
+                                          const FpParams &P) {
+    const uint32_t op = row.w0 & 0xFF;
+    const uint32_t dk = (row.w0 >> SH_DK) & 7, ak = (row.w0 >> SH_AK) & 7, bk = (row.w0 >> SH_BK) & 7;
+    const uint32_t nx = (row.w0 >> SH_NX) & 0xFFF;
+    if (op == D_BARRIER) {                                           // nothing is prefetched across a barrier
+        if (row.aux) {
+            __syncthreads();                                         // FULL: also drains this wave's global stores
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // LDS writes of this wave are done ...
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // ... before any wave reads them
+        }
+        ya = fetch_off((nrow.w0 >> SH_AK) & 7, nrow.a_off, c);
+        yb = fetch_off((nrow.w0 >> SH_BK) & 7, nrow.b_off, c);
+        return;
+    }
+    // request the next row's operands first (two rows' loads in flight)
+    ya = fetch_off((nrow.w0 >> SH_AK) & 7, nrow.a_off, c);
+    yb = fetch_off((nrow.w0 >> SH_BK) & 7, nrow.b_off, c);
+    // extra destinations: scalar loads issued now, consumed after the arithmetic (table padded by 4 entries)
+    const uint64_t x0 = extras[xp], x1 = extras[xp + 1], x2 = extras[xp + 2], x3 = extras[xp + 3];
+    fe a = xa, b = xb;
+    if (ak == K_PREV) a = prev;
+    else if (ak == K_LDS) a = lds_load_off((uint32_t)row.a_off, c);
+    if (bk == K_PREV) b = prev;
+    else if (bk == K_LDS) b = lds_load_off((uint32_t)row.b_off, c);
+    fe d;
+    bool has_d = true;
+    switch (op) {
+    case D_COPY: d = a; break;
+    case D_ADD: d = fe_add(a, b, P); break;
+    case D_SUB: d = fe_sub(a, b, P); break;
+    case D_NEG: d = fe_neg(a, P); break;
+    case D_MMUL: d = fe_mmul(a, b, P); break;
+    case D_MUL2: d = fe_mul2_auto(a, b, P); break;
+    case D_MADD: d = fe_add(fe_mmul(a, b, P), prev, P); break;
+    case D_MULC:
+    case D_MADDC: {
+        // operand b = c*R'; the constant after it = |val(c)| when the lowering flagged c as a small integer
+        const uint32_t cs = (row.w0 >> SH_FLAG) & 3;
+        uint64_t cmag = 0;
+        if (cs) cmag = *(const uint64_t *)(c.Cb + row.b_off + 32);
+        d = fe_mulc_auto(a, b, cs != 0, cmag, cs == 2, P);
+        if (op == D_MADDC) d = fe_add(d, prev, P);
+        break;
+    }
+    case D_SHL: d = fe_shl(a, b, P); break;
+    case D_SHR: d = fe_shr(a, b, P); break;
+    case D_BAND: d = fe_band(a, b, P); break;
+    case D_BOR: d = fe_bor(a, b, P); break;
+    case D_BXOR: d = fe_bxor(a, b, P); break;
+    case D_BNOT: d = fe_bnot(a, P); break;
+    case D_LT: d = fe_small(fe_lt(a, b, P)); break;
+    case D_GT: d = fe_small(fe_lt(b, a, P)); break;
+    case D_LEQ: d = fe_small(!fe_lt(b, a, P)); break;
+    case D_GEQ: d = fe_small(!fe_lt(a, b, P)); break;
+    case D_EQ: d = fe_small(fe_eq(a, b)); break;
+    case D_NEQ: d = fe_small(!fe_eq(a, b)); break;
+    case D_LAND: d = fe_small(!fe_is_zero(a) & !fe_is_zero(b)); break;
+    case D_LOR: d = fe_small(!fe_is_zero(a) | !fe_is_zero(b)); break;
+    case D_LNOT: d = fe_small(fe_is_zero(a)); break;
+    case D_SELECT:                                                   // latch cond != 0; the EXT row selects
+        selmask = __ballot(!fe_is_zero(a));
+        has_d = false;
+        break;
+    case D_EXT: {
+        const bool t = (selmask >> (c.lane16 >> 4)) & 1;
+        for (int k = 0; k < 8; k++) d.v[k] = t ? a.v[k] : b.v[k];
+        break;
+    }
+    case D_ASSERT_EQ:
+        if (!fe_eq(a, b) && st == 0) st = CW_ST_ASSERT_FAILED | (row.aux << 8);
+        has_d = false;
+        break;
+    case D_ASSERT_NZ:
+        if (fe_is_zero(a) && st == 0) st = CW_ST_ASSERT_FAILED | (row.aux << 8);
+        has_d = false;
+        break;
+    default:
+        if (FULL_OPS) {
+            switch (op) {
+            case D_INV: d = fe_pow_uniform(a, P.qm2, P); break;
+            case D_POW: d = fe_pow(a, b, P); break;
+            case D_IDIV:
+            case D_MOD: {
+                fe qq, rr;
+                if (fe_is_zero(b)) {
+                    if (st == 0) st = CW_ST_ARITH | (row.aux << 8);
+                    d = fe_zero();
+                } else {
+                    fe_divmod(a, b, &qq, &rr);
+                    d = (op == D_IDIV) ? qq : rr;
+                }
+                break;
+            }
+            default: has_d = false; break;
+            }
+        } else {
+            has_d = false;
+        }
+        break;
+    }
+    if (has_d) {
+        prev = d;
+        if (dk == K_LDS) lds_store_off((uint32_t)row.dst_off, c, d);
+        else if (dk != KD_NONE) store_off(row.dst_off, c, d);
+        for (uint32_t e = 0; e < nx; e++) {
+            const uint64_t x = e == 0 ? x0 : e == 1 ? x1 : e == 2 ? x2 : e == 3 ? x3 : extras[xp + e];
+            if (x >> 63) lds_store_off((uint32_t)x, c, d);
+            else store_off(x, c, d);
+        }
+    }
+    xp += nx;
+}
+
+// ---- schedule evaluation (the hot path) ---------------------------------------------------------------
+// One lane = one instance.  A workgroup = S waves ("strands") that all work on the SAME 64 instances,
+// each walking its own row stream of the schedule; strands hand values to each other through LDS slots
+// (or, when the LDS pool is exhausted, the value table) and meet at BARRIER rows
+// (hip_elements/lower.py passes C/D).  S = 1 for large batches (instance parallelism alone fills the
+// chip), S up to 16 for the small batches of the BASELINE configs.
+// The kernel is VALU/SALU-issue bound (profiles/), so the interpreter is kept lean:
+//  * rows are pre-resolved on the host for this batch (CwDRow: byte offsets instead of slot numbers), so an
+//    operand address is one scalar 64-bit add and the load uses scalar-base + lane-offset addressing;
+//  * operands of row r+1 are requested before row r executes, into the OTHER of two register sets (the loop
+//    body is two interpreter steps with the sets swapped: no rotation moves).  Legal because the lowering
+//    encodes any operand produced by the preceding row as kind PREV = register forwarding;
+//  * pure copies never load: they are extra destinations of the row that produced the value;
+//  * a LIGHT barrier only orders LDS traffic; only FULL barriers (hand-off through global memory) drain vmcnt;
+//  * products of small signed values take the per-wave short path (fp256.hip.h).
+// FULL_OPS selects the variant that also carries the slow-path operators (INV/IDIV/MOD/POW).
 template <bool FULL_OPS>
 __global__ void __launch_bounds__(1024)
-cw_eval_kernel(const CwRow *__restrict__ rows, const uint32_t *__restrict__ stream_off,
-               const uint32_t *__restrict__ extras, const uint32_t *__restrict__ extra_off, uint4 *V,
-               const uint32_t *__restrict__ consts, uint32_t tmp_base, uint32_t Bp, uint32_t batch,
-               uint32_t *status, FpParams P) {
+cw_eval_kernel(const CwDRow *__restrict__ rows, const uint32_t *__restrict__ stream_off,
+               const uint64_t *__restrict__ extras, const uint32_t *__restrict__ extra_off, uint4 *V,
+               const uint32_t *__restrict__ consts, uint32_t Bp, uint32_t batch, uint32_t *status, FpParams P) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t i = blockIdx.x * 64 + lane;                     // < Bp (Bp is a multiple of 256 >= batch)
-    const uint4 *consts4 = (const uint4 *)consts;
-    uint32_t r = stream_off[wave];
-    const uint32_t end = stream_off[wave + 1];
+    EvalCtx c;
+    c.Vb = (const char *)V;
+    c.Cb = (const char *)consts;
+    c.vlo = i * 16u;
+    c.vhi = i * 16u + Bp * 16u;
+    c.lane16 = lane * 16u;
+    // every stream is padded with 3 NOP rows, so rows[r+1..r+3] are always readable
+    uint32_t r = stream_off[2 * wave];
+    const uint32_t end = stream_off[2 * wave + 1];
     uint32_t xp = extra_off[wave];
     uint32_t st = 0;
-    uint64_t selmask = 0;                                          // lane mask latched by D_SELECT
+    uint64_t selmask = 0;
     fe prev = fe_zero();
-    // software pipeline: row r is executed while the operands of row r+1 are in flight and the row word of
-    // r+2 is being fetched.  `cur`/`ca`/`cb` = row being executed, `nxt` = row whose operands are requested next.
-    const CwRow zero_row = {D_BARRIER + 100u, 0, 0, 0};           // harmless filler past the end of the stream
-    CwRow cur = r < end ? rows[r] : zero_row;
-    CwRow nxt = r + 1 < end ? rows[r + 1] : zero_row;
-    fe ca = fetch_global((cur.w0 >> SH_AK) & 7, cur.a, V, consts4, tmp_base, Bp, i);
-    fe cb = fetch_global((cur.w0 >> SH_BK) & 7, cur.b, V, consts4, tmp_base, Bp, i);
+    CwDRow r0 = rows[r], r1 = rows[r + 1];
+    fe a0 = fetch_off((r0.w0 >> SH_AK) & 7, r0.a_off, c), b0 = fetch_off((r0.w0 >> SH_BK) & 7, r0.b_off, c);
+    fe a1, b1;
     while (r < end) {
-        const CwRow row = cur;
-        const uint32_t op = row.w0 & 0xFF;
-        const uint32_t dk = (row.w0 >> SH_DK) & 7, ak = (row.w0 >> SH_AK) & 7, bk = (row.w0 >> SH_BK) & 7;
-        const uint32_t nx = (row.w0 >> SH_NX) & 0xFFF;
-        if (op == D_BARRIER) {                                       // nothing is prefetched across a barrier
-            if (row.dst) {
-                __syncthreads();                                     // FULL: also drains this wave's global stores
-            } else {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // LDS writes of this wave are done ...
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // ... before any wave reads them
-            }
-            r++;
-            cur = nxt;
-            nxt = r + 1 < end ? rows[r + 1] : zero_row;
-            ca = fetch_global((cur.w0 >> SH_AK) & 7, cur.a, V, consts4, tmp_base, Bp, i);
-            cb = fetch_global((cur.w0 >> SH_BK) & 7, cur.b, V, consts4, tmp_base, Bp, i);
-            continue;
-        }
-        // request the next row's operands first (two rows' loads in flight), then the row word after it
-        const bool next_is_barrier = (nxt.w0 & 0xFF) == D_BARRIER;
-        fe na = ca, nb = cb;
-        if (!next_is_barrier) {
-            na = fetch_global((nxt.w0 >> SH_AK) & 7, nxt.a, V, consts4, tmp_base, Bp, i);
-            nb = fetch_global((nxt.w0 >> SH_BK) & 7, nxt.b, V, consts4, tmp_base, Bp, i);
-        }
-        const CwRow nn = r + 2 < end ? rows[r + 2] : zero_row;
-        // extra destinations: scalar loads issued now, consumed after the arithmetic
-        // (unconditional: the table is padded by 4 entries, so the four scalar loads batch into one wait)
-        const uint32_t x0 = extras[xp], x1 = extras[xp + 1], x2 = extras[xp + 2], x3 = extras[xp + 3];
-        fe a = ca, b = cb;
-        if (ak == K_PREV) a = prev;
-        else if (ak == K_LDS) a = lds_load(row.a, lane);
-        if (bk == K_PREV) b = prev;
-        else if (bk == K_LDS) b = lds_load(row.b, lane);
-        fe d;
-        bool has_d = true;
-        switch (op) {
-        case D_COPY: d = a; break;
-        case D_ADD: d = fe_add(a, b, P); break;
-        case D_SUB: d = fe_sub(a, b, P); break;
-        case D_NEG: d = fe_neg(a, P); break;
-        case D_MMUL: d = fe_mmul(a, b, P); break;
-        case D_MUL2: d = fe_mul2_auto(a, b, P); break;
-        case D_MADD: d = fe_add(fe_mmul(a, b, P), prev, P); break;
-        case D_MULC:
-        case D_MADDC: {
-            // operand b = c*R'; consts[row.b+1] = |val(c)| when the lowering flagged c as a small integer
-            const uint32_t cs = (row.w0 >> SH_FLAG) & 3;
-            uint64_t cmag = 0;
-            if (cs) cmag = ((uint64_t)consts[(size_t)(row.b + 1) * 8 + 1] << 32) | consts[(size_t)(row.b + 1) * 8];
-            d = fe_mulc_auto(a, b, cs != 0, cmag, cs == 2, P);
-            if (op == D_MADDC) d = fe_add(d, prev, P);
-            break;
-        }
-        case D_SHL: d = fe_shl(a, b, P); break;
-        case D_SHR: d = fe_shr(a, b, P); break;
-        case D_BAND: d = fe_band(a, b, P); break;
-        case D_BOR: d = fe_bor(a, b, P); break;
-        case D_BXOR: d = fe_bxor(a, b, P); break;
-        case D_BNOT: d = fe_bnot(a, P); break;
-        case D_LT: d = fe_small(fe_lt(a, b, P)); break;
-        case D_GT: d = fe_small(fe_lt(b, a, P)); break;
-        case D_LEQ: d = fe_small(!fe_lt(b, a, P)); break;
-        case D_GEQ: d = fe_small(!fe_lt(a, b, P)); break;
-        case D_EQ: d = fe_small(fe_eq(a, b)); break;
-        case D_NEQ: d = fe_small(!fe_eq(a, b)); break;
-        case D_LAND: d = fe_small(!fe_is_zero(a) & !fe_is_zero(b)); break;
-        case D_LOR: d = fe_small(!fe_is_zero(a) | !fe_is_zero(b)); break;
-        case D_LNOT: d = fe_small(fe_is_zero(a)); break;
-        case D_SELECT:                                               // latch cond != 0; the EXT row selects
-            selmask = __ballot(!fe_is_zero(a));
-            has_d = false;
-            break;
-        case D_EXT: {
-            const bool t = (selmask >> lane) & 1;
-            for (int k = 0; k < 8; k++) d.v[k] = t ? a.v[k] : b.v[k];
-            break;
-        }
-        case D_ASSERT_EQ:
-            if (!fe_eq(a, b) && st == 0) st = CW_ST_ASSERT_FAILED | (r << 8);
-            has_d = false;
-            break;
-        case D_ASSERT_NZ:
-            if (fe_is_zero(a) && st == 0) st = CW_ST_ASSERT_FAILED | (r << 8);
-            has_d = false;
-            break;
-        default:
-            if (FULL_OPS) {
-                switch (op) {
-                case D_INV: d = fe_pow_uniform(a, P.qm2, P); break;
-                case D_POW: d = fe_pow(a, b, P); break;
-                case D_IDIV:
-                case D_MOD: {
-                    fe qq, rr;
-                    if (fe_is_zero(b)) {
-                        if (st == 0) st = CW_ST_ARITH | (r << 8);
-                        d = fe_zero();
-                    } else {
-                        fe_divmod(a, b, &qq, &rr);
-                        d = (op == D_IDIV) ? qq : rr;
-                    }
-                    break;
-                }
-                default: has_d = false; break;
-                }
-            } else {
-                has_d = false;
-            }
-            break;
-        }
-        if (has_d) {
-            prev = d;
-            if (dk == K_LDS) lds_store(row.dst, lane, d);
-            else if (dk != KD_NONE) v_store(V, row.dst + (dk == K_TMP ? tmp_base : 0), Bp, i, d);
-            for (uint32_t e = 0; e < nx; e++) {
-                const uint32_t x = e == 0 ? x0 : e == 1 ? x1 : e == 2 ? x2 : e == 3 ? x3 : extras[xp + e];
-                if (x & X_LDS) lds_store(x & 0x3FFFFFFFu, lane, d);
-                else v_store(V, (x & 0x3FFFFFFFu) + ((x & X_TMP) ? tmp_base : 0u), Bp, i, d);
-            }
-        }
-        xp += nx;
-        r++;
-        cur = nxt;
-        nxt = nn;
-        ca = na;
-        cb = nb;
+        CwDRow r2 = rows[r + 2];
+        eval_step<FULL_OPS>(r0, a0, b0, r1, a1, b1, prev, selmask, st, r, extras, xp, c, P);
+        r0 = rows[r + 3];
+        eval_step<FULL_OPS>(r1, a1, b1, r2, a0, b0, prev, selmask, st, r + 1, extras, xp, c, P);
+        r1 = r0;
+        r0 = r2;
+        r += 2;
     }
     if (st && i < batch) atomicCAS(&status[i], 0u, st);
 }
@@ -408,9 +436,9 @@ hipError_t cwk_ingest(hipStream_t s, const void *in, void *V, uint32_t input_sta
                        Bp);
     return hipGetLastError();
 }
-hipError_t cwk_eval(hipStream_t s, bool full, const CwRow *rows, const uint32_t *stream_off, const uint32_t *extras,
+hipError_t cwk_eval(hipStream_t s, bool full, const CwDRow *rows, const uint32_t *stream_off, const uint64_t *extras,
                     const uint32_t *extra_off, uint32_t n_strands, uint32_t n_lds, void *V, const uint32_t *consts,
-                    uint32_t tmp_base, uint32_t Bp, uint32_t batch, uint32_t *status, const FpParams &P) {
+                    uint32_t Bp, uint32_t batch, uint32_t *status, const FpParams &P) {
     dim3 grid((batch + 63) / 64), block(64 * n_strands);
     const size_t lds_bytes = (size_t)n_lds * 2048;
     if (lds_bytes > 64 * 1024) {
@@ -420,10 +448,10 @@ hipError_t cwk_eval(hipStream_t s, bool full, const CwRow *rows, const uint32_t 
     }
     if (full)
         hipLaunchKernelGGL(cw_eval_kernel<true>, grid, block, lds_bytes, s, rows, stream_off, extras, extra_off, (uint4 *)V,
-                           consts, tmp_base, Bp, batch, status, P);
+                           consts, Bp, batch, status, P);
     else
         hipLaunchKernelGGL(cw_eval_kernel<false>, grid, block, lds_bytes, s, rows, stream_off, extras, extra_off, (uint4 *)V,
-                           consts, tmp_base, Bp, batch, status, P);
+                           consts, Bp, batch, status, P);
     return hipGetLastError();
 }
 hipError_t cwk_r1cs(hipStream_t s, const uint32_t *ptr, const uint32_t *tslot, const uint32_t *tcoef, const uint32_t *ctab,

@@ -30,6 +30,18 @@ struct CwRow {       // 16 bytes, read with one scalar dwordx4 load
     uint32_t b;
 };
 
+// Device row: a CwRow resolved for one batch (cw_batch_create): operands as byte offsets, so the kernel forms an
+// address with one 64-bit scalar add.  SIG/TMP: offset of the lo half of the slot inside the value table
+// (hi half = +Bp*16); CONST: offset into the constant table; LDS: byte offset of the slot inside the
+// workgroup's LDS block (slot * 2048).  Extra-destination entries are 64-bit: value-table byte offset, or
+// bit 63 + LDS byte offset.  Streams are padded with 3 D_NOP rows.
+struct CwDRow {      // 32 bytes, one scalar dwordx8 load
+    uint32_t w0;     // as CwRow.w0
+    uint32_t aux;    // BARRIER: 1 = FULL
+    uint64_t dst_off, a_off, b_off;
+};
+#define D_NOP 255u
+
 // Field parameters, passed by value as a kernel argument (lands in SGPRs).
 // The device Montgomery radix is R' = 2^261 (9 limbs x 29 bits, see fp256.hip.h), NOT the reference's
 // R = 2^256: which radix a residue is scaled by is private to the schedule (lower.py pre-scales constants).
