@@ -136,12 +136,32 @@ def main():
     gen_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / args.steps
     chk_ms = sum(e[1].elapsed_time(e[2]) for e in evs) / args.steps
 
+    # Fp mul/s half of the metric: device micro-benchmark, 2^20 lanes x 512 dependent Montgomery products
+    fp_mul_per_s = None
+    if rank == 0:
+        rng = np.random.default_rng(5)
+        n = 1 << 20
+        a = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+        b = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+        a[:, 31] &= 0x1F
+        b[:, 31] &= 0x1F
+        _, ms = rt.fp_mul_bench(circ.q, a, b, 512, device=local_rank)
+        fp_mul_per_s = n * 512 / (ms * 1e-3)
+
     if rank == 0:
         total_witnesses = B * world * args.steps
         value = total_witnesses / elapsed
         n_in, n_wit = circ.n_inputs, circ.n_witness
         alg_bytes = 32.0 * (n_in + n_wit) * B          # B_gen of SURVEY §8d, per launch
         achieved = alg_bytes / (gen_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
+        # tools/summarize_prof.py: (2*FETCH_SIZE + WRITE_SIZE) KiB with the gfx950 FETCH_SIZE correction)
+        traffic = None
+        try:
+            tj = json.load(open(ROOT / "profiles" / "traffic.json"))
+            traffic = tj.get("%s:%d" % (args.workload, B), {}).get("cw_eval_kernel")
+        except Exception:
+            pass
         out = {
             "metric": "witnesses/sec (batched inputs)",
             "value": value,
@@ -160,10 +180,13 @@ def main():
                        "schedule_rows": circ.n_rows, "fp_mul_per_witness": circ.n_mmul,
                        "parallelism": "instances sharded x%d, status gather only" % world},
             "roofline": {"bound": "hbm", "kernel": "cw_eval_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": gen_ms,
-                         "fp_mul_per_s": circ.n_mmul * B / (gen_ms * 1e-3)},
+                         "strands": batch.strands,
+                         "fp_mul_per_s_in_kernel": circ.n_mmul * B / (gen_ms * 1e-3)},
+            "fp_mul_per_s": fp_mul_per_s,
             "r1cs_check_ms": chk_ms,
+            "r1cs_check_gbs": 32.0 * n_wit * B / (chk_ms * 1e-3) / 1e9,
             "failed_instances": n_bad,
             "cpu_baseline": None,
         }

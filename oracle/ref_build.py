@@ -117,6 +117,8 @@ def time_reference(cp, workload: str, seconds_budget: float = 15.0):
     n0 = 8
     t = run_loop(cp, gen(n0), n0, 1)[0]
     per = t["seconds"] / n0
+    n1 = max(8, min(20000, int(2.0 / max(per, 1e-6))))          # ~2 s on ONE core, machine otherwise idle
+    single = run_loop(cp, gen(n1), n1, 1)[0]["witnesses_per_s"]
     n_per_core = max(4, int(seconds_budget * 0.5 / max(per, 1e-6)))
     n_per_core = min(n_per_core, 20000)
     n = n_per_core * cores
@@ -125,7 +127,7 @@ def time_reference(cp, workload: str, seconds_budget: float = 15.0):
     wall = time.perf_counter() - t0
     agg = sum(o["witnesses_per_s"] for o in outs)
     return {"value": agg, "unit": "witnesses/s", "cores": cores, "kind": "reference",
-            "per_core": agg / cores,
+            "per_core": agg / cores, "single_core_alone": single,
             "sample": "%d instances (%d per core x %d cores) of %s through the reference C++ runtime "
                       "(common/calcwit.cpp + generic/fr.cpp --no_asm GMP build), compute-only in-process loop, "
                       "wall %.1f s" % (n, n_per_core, cores, workload, wall)}

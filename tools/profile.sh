@@ -1,7 +1,7 @@
 # Collect the rocprofv3 evidence for profiles/: kernel trace + stats, then PMC passes (each in its own run).
-# usage (on the GPU box): bash tools/profile.sh <tag> [bench args...]
+# usage (on the GPU box): bash tools/profile.sh <tag> <workload:batch> [bench args...]
 set -x
-TAG=$1; shift
+TAG=$1; KEY=$2; shift; shift
 R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -12,6 +12,6 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write 
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/pmc_sq.log 2>&1
 find $OUT -name "*.csv" | head -30
 for f in $(find $OUT/trace -name "*kernel_stats.csv"); do echo "== $f"; head -12 $f; done
-python $R/tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1; cat $OUT/summary.txt
+python $R/tools/summarize_prof.py $OUT "$KEY" $R/gpurun_out/traffic.json > $OUT/summary.txt 2>&1; cat $OUT/summary.txt
 # keep the merged-back payload small
 find $OUT -name "*.csv" -size +4M -delete

@@ -39,3 +39,31 @@ for tag in ("pmc_fetch", "pmc_write", "pmc_sq"):
             if "cw_" not in k:
                 continue
             print("  %-50s %s" % (k[:50], "  ".join("%s=%.4g" % (c, sum(v) / len(v)) for c, v in cs.items())))
+
+# traffic.json for bench.py: HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB (gfx950: FETCH_SIZE counts
+# 64 B per 128-B request on wide coalesced reads; WRITE_SIZE as reported)
+if len(sys.argv) > 3:
+    import json
+    key, out = sys.argv[2], sys.argv[3]
+    fetch, write = {}, {}
+    for tag, dst in (("pmc_fetch", fetch), ("pmc_write", write)):
+        tmp = defaultdict(list)
+        for r in rows(tag + "/**/*counter_collection.csv"):
+            try:
+                tmp[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+            except (KeyError, ValueError):
+                pass
+        for k, v in tmp.items():
+            dst[k] = sum(v) / len(v)
+    res = {}
+    for k in fetch:
+        short = "cw_eval_kernel" if "cw_eval_kernel" in k else ("cw_r1cs_kernel" if "cw_r1cs" in k else None)
+        if short:
+            res[short] = (2 * fetch[k] + write.get(k, 0.0)) * 1024.0
+    try:
+        cur = json.load(open(out))
+    except Exception:
+        cur = {}
+    cur[key] = res
+    json.dump(cur, open(out, "w"), indent=1, sort_keys=True)
+    print("traffic", key, res)
