@@ -412,18 +412,26 @@ def _schedule(rows, n_signals, n_strands):
 
     for lv, lunits in enumerate(levels):
         total = sum(ucost(u) for u in lunits)
-        cap = total / n_strands * 1.15 + 10.0
+        cap = total / n_strands * AFFINITY_SLACK + 10.0
         load = [0.0] * n_strands
         for unit in lunits:
             cost = ucost(unit)
-            pref = None
+            # affinity: the strand that produced most of the unit's operands (most recent level first) keeps the
+            # data flow inside one wave (register/own-store forwarding instead of a cross-strand hand-off)
+            votes = {}
             for r in unit:
-                for k, v in ((r.ak, r.av), (r.bk, r.bv)):
-                    if pref is None and (k == K_SIG or k == K_TMP):
+                for k, v in ((r.ak, r.av), (r.bk, r.bv), (r.ck, r.cv)):
+                    if k == K_SIG or k == K_TMP:
                         x = vid(k, v)
-                        if prod_level.get(x) == lv - 1:
-                            pref = prod_strand.get(x)
-            if pref is None or load[pref] + cost > cap:
+                        ps = prod_strand.get(x)
+                        if ps is not None:
+                            votes[ps] = votes.get(ps, 0) + (4 if prod_level.get(x) == lv - 1 else 1)
+            pref = None
+            for ps, _ in sorted(votes.items(), key=lambda kv: -kv[1]):
+                if load[ps] + cost <= cap:
+                    pref = ps
+                    break
+            if pref is None:
                 pref = min(range(n_strands), key=load.__getitem__)
             load[pref] += cost
             for r in unit:
@@ -435,6 +443,10 @@ def _schedule(rows, n_signals, n_strands):
             for st in streams:
                 st.append("B")
     return streams, len(levels) - 1
+
+
+FULL_PERIOD = 8        # every FULL_PERIOD-th barrier also drains global stores
+AFFINITY_SLACK = 1.25  # a strand may take this much more than the average load of a level to keep data local
 
 
 def lds_slots_for(n_strands: int) -> int:
@@ -488,8 +500,13 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
                     prod_strand[vid(r.dk, r.dv)] = si
                     def_time[vid(r.dk, r.dv)] = t
         plan.append(items)
-    mem_last = {}       # value id -> last time it is read from memory by its OWN strand (or any strand if S = 1)
-    x_last = {}         # value id -> last epoch it is read by ANOTHER strand
+    # Cross-strand flows.  A value produced in epoch d by one strand and read by another must be visible to the
+    # reader: either through an LDS slot (LIGHT barriers suffice) or through the value table, which needs a FULL
+    # barrier (vmcnt(0)) between the store and the load.  Every FULL_PERIOD-th barrier is FULL anyway, so reads that
+    # happen after the next periodic FULL barrier go through the value table for free; only the short-range reads
+    # before it need an LDS slot (and only until that barrier: bounded LDS lifetime).
+    mem_last = {}       # value id -> last time it is read from the value table
+    x_uses = {}         # value id -> sorted epochs at which ANOTHER strand reads it
     for si, items in enumerate(plan):
         for r, fl, t in items:
             if r == "B":
@@ -500,32 +517,46 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
                     continue
                 x = vid(k, v)
                 if multi and x in prod_strand and prod_strand[x] != si:
-                    x_last[x] = max(x_last.get(x, -1), t)
+                    x_uses.setdefault(x, []).append(t)
                 else:
                     mem_last[x] = max(mem_last.get(x, -1), t)
 
-    # ---- pass D2: LDS slots for cross-strand values; barriers that must also drain global stores -----------------
+    # ---- pass D2: LDS slots for short-range cross-strand reads; which barriers are FULL ------------------------------
     n_lds = lds_slots_for(n_strands)
-    lds_of = {}
+    lds_of, lds_until = {}, {}
     full_after = set()          # epochs whose closing barrier must wait for global stores (vmcnt(0))
     n_lds_used = 0
     if multi:
+        K = FULL_PERIOD
+        n_epochs = n_levels + 1
+        full_after.update(e for e in range(n_epochs) if (e + 1) % K == 0)
+
+        def next_full(d):       # first epoch >= d whose closing barrier is periodic-FULL
+            return d + (K - 1 - d % K)
+
         free = list(range(n_lds - 1, -1, -1))
         release = {}            # epoch -> slots that become reusable once that epoch is over
-        by_def = sorted((def_time[x], x) for x in x_last)
         cur = -1
-        for t, x in by_def:
+        for t, x in sorted((def_time[x], x) for x in x_uses):
             while cur < t - 1:
                 cur += 1
                 free.extend(release.pop(cur, ()))
+            b = next_full(t)
+            near = [u for u in x_uses[x] if u <= b]
+            far = [u for u in x_uses[x] if u > b]
+            if far:
+                mem_last[x] = max(mem_last.get(x, -1), max(far))
+            if not near:
+                continue
             if free:
                 sl = free.pop()
                 lds_of[x] = sl
+                lds_until[x] = max(near)
                 n_lds_used = max(n_lds_used, sl + 1)
-                release.setdefault(x_last[x], []).append(sl)
+                release.setdefault(max(near), []).append(sl)
             else:
-                full_after.add(t)                       # hand-off through global memory
-                mem_last[x] = max(mem_last.get(x, -1), x_last[x])
+                full_after.add(t)                       # hand-off through the value table right away
+                mem_last[x] = max(mem_last.get(x, -1), max(near))
 
     # ---- pass D3: global temp slots (only temps that are actually read from global memory) ------------------------
     slot_of = {}
@@ -579,7 +610,7 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
                     return KO_PREV, 0
                 if k in (K_SIG, K_TMP):
                     x = vid(k, v)
-                    if x in lds_of and prod_strand.get(x) != si:
+                    if x in lds_of and prod_strand.get(x) != si and t <= lds_until[x]:
                         return K_LDS, lds_of[x]
                     return (K_TMP, slot_of[v]) if k == K_TMP else (K_SIG, v)
                 if k == K_NONE:
