@@ -184,7 +184,7 @@ struct HashEntry {
 struct Variant {               // one lowering of the schedule for a given strand count
     uint32_t n_strands = 1, n_tslots = 0, n_lds = 0;
     std::vector<CwRow> rows;
-    std::vector<uint32_t> stream_off, extras, extra_off;
+    std::vector<uint32_t> stream_off, extras, extra_off, term_off, terms;   // terms: 4 x u32 each
 };
 
 struct cw_circuit {
@@ -229,7 +229,7 @@ static int load_tape(cw_circuit *c, const char *path) {
     if (!read_file(path, b)) return fail(CW_EIO, std::string("tape file not found: ") + path);
     if (b.size() < 16 + 32 + 48 || memcmp(b.data(), "CWTP", 4)) return fail(CW_EIO, "bad tape magic");
     const uint32_t *h = (const uint32_t *)(b.data() + 4);
-    if (h[0] != 3) return fail(CW_EIO, "unsupported tape version");
+    if (h[0] != 4) return fail(CW_EIO, "unsupported tape version");
     if (h[1] != 4) return fail(CW_EIO, "only 4x64-bit primes are supported (bn128, bls12381, ...)");
     uint32_t n_variants = h[2];
     size_t off = 16;
@@ -273,11 +273,11 @@ static int load_tape(cw_circuit *c, const char *path) {
         Variant var;
         var.n_strands = vh[0];
         var.n_tslots = vh[1];
-        uint32_t nrows = vh[2], nextras = vh[3];
+        uint32_t nrows = vh[2], nextras = vh[3], nterms = vh[5];
         var.n_lds = vh[4];
         if (var.n_strands == 0 || var.n_strands > 16) return fail(CW_EIO, "tape variant: bad strand count");
         if (var.n_lds > 72) return fail(CW_EIO, "tape variant: too many LDS slots");
-        size_t need = (size_t)(var.n_strands + 1) * 8 + (size_t)nrows * 16 + (size_t)nextras * 4;
+        size_t need = (size_t)(var.n_strands + 1) * 12 + (size_t)nrows * 16 + (size_t)nextras * 4 + (size_t)nterms * 16;
         if (off + need > b.size()) return fail(CW_EIO, "tape variant truncated");
         var.stream_off.resize(var.n_strands + 1);
         memcpy(var.stream_off.data(), b.data() + off, (size_t)(var.n_strands + 1) * 4);
@@ -285,12 +285,19 @@ static int load_tape(cw_circuit *c, const char *path) {
         var.extra_off.resize(var.n_strands + 1);
         memcpy(var.extra_off.data(), b.data() + off, (size_t)(var.n_strands + 1) * 4);
         off += (size_t)(var.n_strands + 1) * 4;
+        var.term_off.resize(var.n_strands + 1);
+        memcpy(var.term_off.data(), b.data() + off, (size_t)(var.n_strands + 1) * 4);
+        off += (size_t)(var.n_strands + 1) * 4;
         var.rows.resize(nrows);
         memcpy(var.rows.data(), b.data() + off, (size_t)nrows * 16);
         off += (size_t)nrows * 16;
         var.extras.resize(nextras);
         memcpy(var.extras.data(), b.data() + off, (size_t)nextras * 4);
         off += (size_t)nextras * 4;
+        var.terms.resize((size_t)nterms * 4);
+        memcpy(var.terms.data(), b.data() + off, (size_t)nterms * 16);
+        off += (size_t)nterms * 16;
+        if (var.term_off[var.n_strands] + 1 != nterms) return fail(CW_EIO, "tape variant: bad term offsets");
         if (var.extra_off[var.n_strands] + 4 != nextras) return fail(CW_EIO, "tape variant: bad extra offsets");
         if (var.stream_off[var.n_strands] != nrows) return fail(CW_EIO, "tape variant: bad stream offsets");
         uint64_t mm = 0;
@@ -529,7 +536,8 @@ struct cw_batch {
     CwDRow *d_rows = nullptr;
     const Variant *var = nullptr;
     uint32_t *d_stream_off = nullptr, *d_extra_off = nullptr;
-    uint64_t *d_extras = nullptr;
+    uint64_t *d_extras = nullptr, *d_terms = nullptr;
+    uint32_t *d_term_off = nullptr;
     uint32_t *d_consts = nullptr, *d_w2s = nullptr, *d_status = nullptr, *d_first_bad = nullptr;
     uint32_t *d_rptr = nullptr, *d_rslot = nullptr, *d_rcoef = nullptr, *d_rctab = nullptr, *d_rorig = nullptr;
     void *d_in = nullptr;          // AoS staging [batch][n_in][32]
@@ -559,7 +567,7 @@ extern "C" void cw_batch_free(cw_batch *b) {
     }
     hipSetDevice(b->device);
     hipStreamSynchronize(b->stream);
-    void *ptrs[] = {b->d_V, b->d_rows, b->d_stream_off, b->d_extras, b->d_extra_off, b->d_consts, b->d_w2s, b->d_status, b->d_first_bad,
+    void *ptrs[] = {b->d_V, b->d_rows, b->d_stream_off, b->d_extras, b->d_extra_off, b->d_terms, b->d_term_off, b->d_consts, b->d_w2s, b->d_status, b->d_first_bad,
                     b->d_rptr, b->d_rslot, b->d_rcoef, b->d_rctab, b->d_rorig, b->d_in, b->d_gather};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -646,6 +654,16 @@ extern "C" int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *
                 if (op == D_BARRIER) {
                     d.aux = row.dst;
                     d.dst_off = d.a_off = d.b_off = 0;
+                } else if (op == D_LINSUM) {
+                    d.aux = row.a;                                   // number of terms
+                    d.dst_off = dk == KD_NONE ? 0 : resolve(dk, row.dst);
+                    d.a_off = 0;
+                    d.b_off = resolve(bk, row.b);                    // constant term c0 (kind CONST) or nothing
+                } else if (op == D_BIT) {
+                    d.aux = row.b;                                   // bit index k
+                    d.dst_off = dk == KD_NONE ? 0 : resolve(dk, row.dst);
+                    d.a_off = resolve(ak, row.a);
+                    d.b_off = 0;
                 } else {
                     d.aux = r;                                       // schedule row, reported in the status word
                     d.dst_off = dk == KD_NONE ? 0 : resolve(dk, row.dst);
@@ -656,6 +674,13 @@ extern "C" int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *
             }
             doff.push_back((uint32_t)drows.size());
             for (int k = 0; k < 3; k++) drows.push_back(CwDRow{D_NOP, 0, 0, 0, 0});
+        }
+        // LINSUM terms: {kind<<61 | byte offset, sign<<63 | |coef|}
+        std::vector<uint64_t> dterms(v.terms.size() / 2);
+        for (size_t k = 0; k + 3 < v.terms.size(); k += 4) {
+            uint32_t kw = v.terms[k], kind = kw & 7;
+            dterms[k / 2] = ((uint64_t)kind << 61) | resolve(kind, v.terms[k + 1]);
+            dterms[k / 2 + 1] = ((uint64_t)(kw >> 31) << 63) | ((uint64_t)v.terms[k + 3] << 32) | v.terms[k + 2];
         }
         std::vector<uint64_t> dex(v.extras.size());
         for (size_t k = 0; k < v.extras.size(); k++) {
@@ -685,6 +710,8 @@ extern "C" int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *
         TRY(upload(&b->d_stream_off, tab, b->stream));
         TRY(upload(&b->d_extras, dex, b->stream));
         TRY(upload(&b->d_extra_off, v.extra_off, b->stream));
+        TRY(upload(&b->d_terms, dterms, b->stream));
+        TRY(upload(&b->d_term_off, v.term_off, b->stream));
         TRY(hipStreamSynchronize(b->stream));                        // host vectors go out of scope
     }
     TRY(upload(&b->d_consts, c->consts, b->stream));
@@ -1000,8 +1027,9 @@ extern "C" int cw_run(cw_batch *b) {
     const void *in = b->ext_in ? b->ext_in : b->d_in;
     HIPCHK(cwk_init(b->stream, b->d_V, b->Bp, b->d_status, b->d_first_bad));
     HIPCHK(cwk_ingest(b->stream, in, b->d_V, c->input_start, c->n_inputs, b->batch, b->Bp));
-    HIPCHK(cwk_eval(b->stream, c->need_full, b->d_rows, b->d_stream_off, b->d_extras, b->d_extra_off, b->var->n_strands,
-                    b->var->n_lds, b->d_V, b->d_consts, b->Bp, b->batch, b->d_status, c->P));
+    HIPCHK(cwk_eval(b->stream, c->need_full, b->d_rows, b->d_stream_off, b->d_extras, b->d_extra_off, b->d_terms,
+                    b->d_term_off, b->var->n_strands, b->var->n_lds, b->d_V, b->d_consts, b->Bp, b->batch, b->d_status,
+                    c->P));
     b->ran = true;
     return CW_OK;
 }

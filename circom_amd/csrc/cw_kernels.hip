@@ -82,6 +82,8 @@ extern __shared__ uint4 cw_lds[];       // [slot][2 halves][64 lanes] x 16 B
 struct EvalCtx {                         // per-wave constants of the interpreter
     const char *Vb;                      // value table, bytes
     const char *Cb;                      // constant table, bytes
+    const uint64_t *terms;               // D_LINSUM term table of this strand ...
+    uint32_t tp;                         // ... and the running position in it
     uint32_t vlo, vhi;                   // this lane's byte offsets of the lo/hi half inside a value slot
     uint32_t lane16;                     // lane * 16 (LDS)
 };
@@ -117,12 +119,83 @@ __device__ __forceinline__ void store_off(uint64_t off, const EvalCtx &c, const 
     *(uint4 *)(base + c.vhi) = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
 }
 
+// ---- D_LINSUM: d = c0 + sum_i coef_i * x_i, small signed integer coefficients ------------------------------
+// The common case (every lane's x_i is a small non-negative integer: bits, partial sums) accumulates the
+// 64x64-bit products in two unsigned 192-bit accumulators (positive / negative terms) with no modular
+// reduction at all; a lane holding anything else sends the wave through the generic field path for that
+// term.  Result = g + P - N reduced once.  Terms are read at execution time, one ahead of their use.
+struct Acc192 { uint64_t w0, w1, w2; };
+__device__ __forceinline__ void acc192_add(Acc192 &a, uint64_t lo, uint64_t hi) {
+    const uint64_t s0 = a.w0 + lo;
+    const uint64_t c0 = s0 < lo;
+    const uint64_t s1 = a.w1 + hi;
+    const uint64_t c1 = s1 < hi;
+    const uint64_t s1b = s1 + c0;
+    const uint64_t c1b = s1b < c0;
+    a.w0 = s0;
+    a.w1 = s1b;
+    a.w2 += c1 + c1b;
+}
+__device__ __forceinline__ fe acc192_to_fe(const Acc192 &a) {
+    fe r = fe_zero();
+    r.v[0] = (uint32_t)a.w0; r.v[1] = (uint32_t)(a.w0 >> 32);
+    r.v[2] = (uint32_t)a.w1; r.v[3] = (uint32_t)(a.w1 >> 32);
+    r.v[4] = (uint32_t)a.w2; r.v[5] = (uint32_t)(a.w2 >> 32);
+    return r;
+}
+__device__ __forceinline__ fe term_load(uint64_t t0, const fe &prev, const EvalCtx &c) {
+    const uint32_t kind = (uint32_t)(t0 >> 61);
+    const uint64_t off = t0 & 0x1FFFFFFFFFFFFFFFull;
+    if (kind == K_PREV) return prev;
+    if (kind == K_LDS) return lds_load_off((uint32_t)off, c);
+    return fetch_off(K_SIG, off, c);
+}
+__device__ __forceinline__ fe eval_linsum(uint32_t n, const fe &c0, const fe &prev, EvalCtx &c, const FpParams &P) {
+    fe g = c0;
+    Acc192 pos = {0, 0, 0}, neg = {0, 0, 0};
+    const uint64_t *tt = c.terms + (size_t)c.tp * 2;
+    uint64_t t0 = tt[0], t1 = tt[1];
+    fe x = term_load(t0, prev, c);
+    for (uint32_t k = 0; k < n; k++) {
+        const fe xc = x;
+        const uint64_t cf = t1;
+        // request the next term (the table is padded by one entry)
+        t0 = tt[2 * (k + 1)];
+        t1 = tt[2 * (k + 1) + 1];
+        if (k + 1 < n) x = term_load(t0, prev, c);
+        const uint64_t mag = cf & 0x7FFFFFFFFFFFFFFFull;
+        const bool cneg = cf >> 63;
+        if (__all(fe_hi_or(xc) == 0)) {
+            // 64x64 -> 128-bit product, accumulated without reduction
+            const uint32_t a0 = xc.v[0], a1 = xc.v[1], b0 = (uint32_t)mag, b1 = (uint32_t)(mag >> 32);
+            uint64_t t = (uint64_t)a0 * b0;
+            const uint32_t r0 = (uint32_t)t;
+            t = (uint64_t)a0 * b1 + (t >> 32);
+            const uint64_t t2 = (uint64_t)a1 * b0 + (uint32_t)t;
+            const uint64_t hi = (uint64_t)a1 * b1 + (t >> 32) + (t2 >> 32);
+            const uint64_t lo = ((uint64_t)(uint32_t)t2 << 32) | r0;
+            if (cneg) acc192_add(neg, lo, hi);
+            else acc192_add(pos, lo, hi);
+        } else {
+            // generic: coef * x in the field (coef as a canonical element)
+            fe cm = fe_zero();
+            cm.v[0] = (uint32_t)mag;
+            cm.v[1] = (uint32_t)(mag >> 32);
+            const fe p = fe_mul2_auto(xc, cm, P);
+            g = cneg ? fe_sub(g, p, P) : fe_add(g, p, P);
+        }
+    }
+    c.tp += n;
+    g = fe_add(g, acc192_to_fe(pos), P);
+    return fe_sub(g, acc192_to_fe(neg), P);
+}
+
 // One interpreter step: executes `row` with operands (xa, xb) while the operands of `nrow` are requested into
 // (ya, yb).  The loop calls it twice per iteration with the two register sets swapped (no rotation moves).
 template <bool FULL_OPS>
 __device__ __forceinline__ void eval_step(const CwDRow &row, const fe &xa, const fe &xb, const CwDRow &nrow, fe &ya,
                                           fe &yb, fe &prev, uint64_t &selmask, uint32_t &st, uint32_t r,
-                                          const uint64_t *__restrict__ extras, uint32_t &xp, const EvalCtx &c,
+                                          const uint64_t *__restrict__ extras, uint32_t &xp, EvalCtx &c,
                                           const FpParams &P) {
     const uint32_t op = row.w0 & 0xFF;
     const uint32_t dk = (row.w0 >> SH_DK) & 7, ak = (row.w0 >> SH_AK) & 7, bk = (row.w0 >> SH_BK) & 7;
@@ -167,6 +240,14 @@ __device__ __forceinline__ void eval_step(const CwDRow &row, const fe &xa, const
         if (cs) cmag = *(const uint64_t *)(c.Cb + row.b_off + 32);
         d = fe_mulc_auto(a, b, cs != 0, cmag, cs == 2, P);
         if (op == D_MADDC) d = fe_add(d, prev, P);
+        break;
+    }
+    case D_LINSUM: d = eval_linsum(row.aux, bk == K_CONST ? b : fe_zero(), prev, c, P); break;
+    case D_BIT: {                                                    // (a >> k) & 1, k = row.aux (wave-uniform)
+        const uint32_t k = row.aux, w = k >> 5;
+        const uint32_t limb = w == 0 ? a.v[0] : w == 1 ? a.v[1] : w == 2 ? a.v[2] : w == 3 ? a.v[3] : w == 4 ? a.v[4]
+                              : w == 5 ? a.v[5] : w == 6 ? a.v[6] : a.v[7];
+        d = fe_small(k < 256 ? (limb >> (k & 31)) & 1u : 0u);
         break;
     }
     case D_SHL: d = fe_shl(a, b, P); break;
@@ -257,7 +338,8 @@ __device__ __forceinline__ void eval_step(const CwDRow &row, const fe &xa, const
 template <bool FULL_OPS>
 __global__ void __launch_bounds__(1024)
 cw_eval_kernel(const CwDRow *__restrict__ rows, const uint32_t *__restrict__ stream_off,
-               const uint64_t *__restrict__ extras, const uint32_t *__restrict__ extra_off, uint4 *V,
+               const uint64_t *__restrict__ extras, const uint32_t *__restrict__ extra_off,
+               const uint64_t *__restrict__ terms, const uint32_t *__restrict__ term_off, uint4 *V,
                const uint32_t *__restrict__ consts, uint32_t Bp, uint32_t batch, uint32_t *status, FpParams P) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
@@ -268,6 +350,8 @@ cw_eval_kernel(const CwDRow *__restrict__ rows, const uint32_t *__restrict__ str
     c.vlo = i * 16u;
     c.vhi = i * 16u + Bp * 16u;
     c.lane16 = lane * 16u;
+    c.terms = terms;
+    c.tp = term_off[wave];
     // every stream is padded with 3 NOP rows, so rows[r+1..r+3] are always readable
     uint32_t r = stream_off[2 * wave];
     const uint32_t end = stream_off[2 * wave + 1];
@@ -437,8 +521,9 @@ hipError_t cwk_ingest(hipStream_t s, const void *in, void *V, uint32_t input_sta
     return hipGetLastError();
 }
 hipError_t cwk_eval(hipStream_t s, bool full, const CwDRow *rows, const uint32_t *stream_off, const uint64_t *extras,
-                    const uint32_t *extra_off, uint32_t n_strands, uint32_t n_lds, void *V, const uint32_t *consts,
-                    uint32_t Bp, uint32_t batch, uint32_t *status, const FpParams &P) {
+                    const uint32_t *extra_off, const uint64_t *terms, const uint32_t *term_off, uint32_t n_strands,
+                    uint32_t n_lds, void *V, const uint32_t *consts, uint32_t Bp, uint32_t batch, uint32_t *status,
+                    const FpParams &P) {
     dim3 grid((batch + 63) / 64), block(64 * n_strands);
     const size_t lds_bytes = (size_t)n_lds * 2048;
     if (lds_bytes > 64 * 1024) {
@@ -447,11 +532,11 @@ hipError_t cwk_eval(hipStream_t s, bool full, const CwDRow *rows, const uint32_t
         if (e != hipSuccess) return e;
     }
     if (full)
-        hipLaunchKernelGGL(cw_eval_kernel<true>, grid, block, lds_bytes, s, rows, stream_off, extras, extra_off, (uint4 *)V,
-                           consts, Bp, batch, status, P);
+        hipLaunchKernelGGL(cw_eval_kernel<true>, grid, block, lds_bytes, s, rows, stream_off, extras, extra_off, terms,
+                           term_off, (uint4 *)V, consts, Bp, batch, status, P);
     else
-        hipLaunchKernelGGL(cw_eval_kernel<false>, grid, block, lds_bytes, s, rows, stream_off, extras, extra_off, (uint4 *)V,
-                           consts, Bp, batch, status, P);
+        hipLaunchKernelGGL(cw_eval_kernel<false>, grid, block, lds_bytes, s, rows, stream_off, extras, extra_off, terms,
+                           term_off, (uint4 *)V, consts, Bp, batch, status, P);
     return hipGetLastError();
 }
 hipError_t cwk_r1cs(hipStream_t s, const uint32_t *ptr, const uint32_t *tslot, const uint32_t *tcoef, const uint32_t *ctab,

@@ -51,10 +51,14 @@ from ..frontend.flatten import FlatCircuit
 # device opcodes (csrc/cw_tape.h must match)
 (D_COPY, D_ADD, D_SUB, D_NEG, D_MMUL, D_INV, D_IDIV, D_MOD, D_POW, D_SHL, D_SHR, D_BAND, D_BOR, D_BXOR,
  D_BNOT, D_LT, D_GT, D_LEQ, D_GEQ, D_EQ, D_NEQ, D_LAND, D_LOR, D_LNOT, D_SELECT, D_EXT, D_ASSERT_EQ,
- D_ASSERT_NZ, D_ALSO, D_BARRIER, D_MUL2, D_MADD, D_MULC, D_MADDC) = range(34)
+ D_ASSERT_NZ, D_ALSO, D_BARRIER, D_MUL2, D_MADD, D_MULC, D_MADDC, D_LINSUM, D_BIT) = range(36)
 D_NAMES = ["copy", "add", "sub", "neg", "mmul", "inv", "idiv", "mod", "pow", "shl", "shr", "band", "bor",
            "bxor", "bnot", "lt", "gt", "leq", "geq", "eq", "neq", "land", "lor", "lnot", "select", "ext",
-           "assert_eq", "assert_nz", "also", "barrier", "mul2", "madd", "mulc", "maddc"]
+           "assert_eq", "assert_nz", "also", "barrier", "mul2", "madd", "mulc", "maddc", "linsum", "bit"]
+# D_LINSUM: d = c0 + sum_i coef_i * x_i with small signed integer coefficients (|coef| < 2^63): field `a` = number of
+#           terms, operand b = constant c0 (or none); the terms (operand, coefficient) are consecutive entries of
+#           the strand's term table.  One row replaces the 2n-1 MULC/ADD/SUB rows `lin += in[j][k] * e2` loops trace into.
+# D_BIT   : d = (a >> k) & 1, k = small constant in field b (a raw number, not a constant index)
 # D_MULC : d = a * c on canonical values, c a compile-time constant.  Operand b = index of a constant PAIR:
 #          [b] = c*R' (so that MMUL(a,[b]) = a*c), [b+1] = |val(c)| when c is a small signed integer.  Word-0
 #          flags CS_POS / CS_NEG say so; the kernel then multiplies small run-time values directly
@@ -90,6 +94,8 @@ class Tape:
         self.extras = None          # uint32[]: extra destinations, in stream/row order
         self.extra_off = None       # uint32[n_strands+1]: first extra-destination entry of each strand
         self.n_lds = 0              # LDS value slots the workgroup needs
+        self.terms = None           # uint32[n,4]: D_LINSUM terms (kind|sign, index, |coef| lo, hi), stream/row order
+        self.term_off = None        # uint32[n_strands+1]
         self.n_strands = 1
         self.consts = []            # raw residues (python ints)
         self.witness2signal = None  # uint32[n_witness]
@@ -119,15 +125,63 @@ def _dce(code, n_temps):
 
 
 class _Row:
-    __slots__ = ("op", "dk", "dv", "ak", "av", "bk", "bv", "ck", "cv", "extra", "level", "strand", "flag")
+    __slots__ = ("op", "dk", "dv", "ak", "av", "bk", "bv", "ck", "cv", "extra", "level", "strand", "flag", "coef", "terms")
 
     def __init__(self, op, dk, dv, ak, av, bk=K_NONE, bv=0, ck=K_NONE, cv=0):
         self.op, self.dk, self.dv = op, dk, dv
         self.ak, self.av, self.bk, self.bv, self.ck, self.cv = ak, av, bk, bv, ck, cv
         self.extra = None        # list of (kind, id) extra destinations
         self.flag = 0            # D_MULC/D_MADDC: 1 = constant is a small positive integer, 2 = small negative
+        self.coef = None         # D_MULC: the plain constant (python int, canonical)
+        self.terms = None        # D_LINSUM: list of [kind, id, signed coefficient]
         self.level = 0
         self.strand = 0
+
+
+def _proved_asserts(code, constants):
+    """Range analysis for the commonest run-time check of bit-level circuits: `out * (out - 1) === 0` right after
+    `out <-- (x >> k) & 1` (circomlib BinSum / Num2Bits / comparators).  `y & 1` is 0 or 1 for EVERY y, so the
+    product is identically zero and the assert can never fire: it is dropped from the schedule (the R1CS check
+    kernel still verifies the constraint itself).  Returns a boolean mask of ASSERT_EQ rows proved true."""
+    op = code["op"]
+    n = len(op)
+    dk, dv = code["dk"], code["dv"]
+    ak, av, bk, bv = code["ak"], code["av"], code["bk"], code["bv"]
+    proved = np.zeros(n, dtype=bool)
+    is_bit = {}          # (kind, id) -> True for values known to be 0/1
+    prod = {}            # temp id -> row that defines it
+    one = {i for i, c in enumerate(constants) if c == 1}
+    zero = {i for i, c in enumerate(constants) if c == 0}
+
+    def bit(k, v):
+        if k == K_CONST:
+            return v in one or v in zero
+        return is_bit.get((int(k), int(v)), False)
+
+    for i in range(n):
+        o = op[i]
+        if o == O.BAND and ((bk[i] == K_CONST and bv[i] in one) or (ak[i] == K_CONST and av[i] in one)):
+            is_bit[(int(dk[i]), int(dv[i]))] = True
+        elif o == O.COPY and bit(ak[i], av[i]):
+            is_bit[(int(dk[i]), int(dv[i]))] = True
+        elif o in (O.LT, O.GT, O.LEQ, O.GEQ, O.EQ, O.NEQ, O.LAND, O.LOR, O.LNOT):
+            is_bit[(int(dk[i]), int(dv[i]))] = True
+        if dk[i] == K_TMP:
+            prod[int(dv[i])] = i
+        if o == O.ASSERT_EQ:
+            # ASSERT_EQ(t, 0) with t = MUL(x, SUB(x, 1)), x a bit
+            for (tk, tv, zk, zv) in ((ak[i], av[i], bk[i], bv[i]), (bk[i], bv[i], ak[i], av[i])):
+                if zk == K_CONST and zv in zero and tk == K_TMP and int(tv) in prod:
+                    m = prod[int(tv)]
+                    if op[m] != O.MUL:
+                        continue
+                    for (xk, xv, yk, yv) in ((ak[m], av[m], bk[m], bv[m]), (bk[m], bv[m], ak[m], av[m])):
+                        if yk == K_TMP and int(yv) in prod and bit(xk, xv):
+                            sb = prod[int(yv)]
+                            if (op[sb] == O.SUB and (ak[sb], av[sb]) == (xk, xv) and bk[sb] == K_CONST
+                                    and bv[sb] in one):
+                                proved[i] = True
+    return proved
 
 
 def _expand(fc: FlatCircuit):
@@ -135,7 +189,12 @@ def _expand(fc: FlatCircuit):
     fp = fc.fp
     q = fp.q
     code = fc.code
+    proved = _proved_asserts(code, fc.constants)
+    if proved.any():
+        code = dict(code)
+        code["op"] = np.where(proved, np.uint8(O.RUN), code["op"])      # RUN rows are ignored by DCE and expansion
     keep = _dce(code, fc.n_temps)
+    keep &= ~proved
     idx = np.nonzero(keep)[0]
     op = code["op"][idx].tolist()
     dk = code["dk"][idx].tolist(); dv = code["dv"][idx].tolist()
@@ -144,6 +203,7 @@ def _expand(fc: FlatCircuit):
     ck = code["ck"][idx].tolist(); cv = code["cv"][idx].tolist()
     consts_in = fc.constants
     dconsts, dconst_id = [], {}
+    plain = {}          # device constant id -> canonical value (only for constants used as plain operands)
 
     def cid(v):
         i = dconst_id.get(v)
@@ -151,6 +211,7 @@ def _expand(fc: FlatCircuit):
             i = len(dconsts)
             dconst_id[v] = i
             dconsts.append(v)
+            plain[i] = v
         return i
 
     R, R2 = fp.Rdev, fp.Rdev2
@@ -199,6 +260,7 @@ def _expand(fc: FlatCircuit):
                 ci, fl = cpair(c)
                 r_ = _Row(D_MULC, dk[i], dv[i], xk, xv, K_CONST, ci)
                 r_.flag = fl
+                r_.coef = c % q
                 rows.append(r_)
             else:
                 rows.append(_Row(D_MUL2, dk[i], dv[i], ak[i], av[i], bk[i], bv[i]))
@@ -221,7 +283,104 @@ def _expand(fc: FlatCircuit):
             ka, va = opnd(ak[i], av[i])
             kb, vb = opnd(bk[i], bv[i]) if bk[i] != K_NONE else (K_NONE, 0)
             rows.append(_Row(_DIRECT[o], dk[i] if dk[i] != K_NONE else KD_NONE, dv[i], ka, va, kb, vb))
-    return rows, dconsts, nxt[0]
+    _expand.n_proved = int(proved.sum())
+    return rows, dconsts, nxt[0], cid, plain
+
+
+def _value_operands(r):
+    """every (kind, id) a row reads, including D_LINSUM terms"""
+    ops = [(r.ak, r.av), (r.bk, r.bv), (r.ck, r.cv)]
+    if r.terms:
+        ops.extend((t[0], t[1]) for t in r.terms)
+    return ops
+
+
+def _fuse_linear(rows, consts_plain, q, cid):
+    """Pass A3: collapse trees of ADD / SUB / NEG / MULC-by-small-constant over single-use temporaries into one
+    D_LINSUM row (the value is the same linear combination; field addition is associative and commutative).
+    Also BAND(SHR(x, k), 1) -> D_BIT.  `consts_plain[i]` = canonical value of device constant i (None for scaled)."""
+    uses = {}
+    for r in rows:
+        for k, v in _value_operands(r):
+            if k == K_TMP:
+                uses[v] = uses.get(v, 0) + 1
+    prod = {}
+    for idx, r in enumerate(rows):
+        if r.dk == K_TMP:
+            prod[r.dv] = idx
+    absorbed = [False] * len(rows)
+    repl = {}
+    half = q >> 1
+
+    def sval(c):            # signed value of a canonical constant
+        return c - q if c > half else c
+
+    n_lin = n_bit = 0
+    for idx in range(len(rows) - 1, -1, -1):
+        r = rows[idx]
+        if absorbed[idx]:
+            continue
+        if r.op == D_BAND and r.bk == K_CONST and consts_plain.get(r.bv) == 1 and r.ak == K_TMP and uses.get(r.av) == 1:
+            pi = prod.get(r.av)
+            if pi is not None and not absorbed[pi] and rows[pi].op == D_SHR and rows[pi].bk == K_CONST \
+                    and rows[pi].extra is None:
+                kk = consts_plain.get(rows[pi].bv)
+                if kk is not None and kk < 256:
+                    absorbed[pi] = True
+                    nr = _Row(D_BIT, r.dk, r.dv, rows[pi].ak, rows[pi].av, K_NONE, kk)
+                    nr.extra = r.extra
+                    repl[idx] = nr
+                    n_bit += 1
+                    continue
+        if r.op not in (D_ADD, D_SUB):
+            continue
+        terms, took, c0, ok = [], [], 0, True
+        stack = [(r.bk, r.bv, -1 if r.op == D_SUB else 1), (r.ak, r.av, 1)]
+        while stack and ok:
+            k, v, cf = stack.pop()
+            if k == K_CONST:
+                cv_ = consts_plain.get(v)
+                if cv_ is None:
+                    ok = False
+                else:
+                    c0 += cf * sval(cv_)
+                continue
+            if k == K_TMP and uses.get(v) == 1:
+                pi = prod.get(v)
+                if pi is not None and not absorbed[pi] and rows[pi].extra is None:
+                    pr = rows[pi]
+                    if pr.op == D_ADD or pr.op == D_SUB:
+                        took.append(pi)
+                        stack.append((pr.bk, pr.bv, -cf if pr.op == D_SUB else cf))
+                        stack.append((pr.ak, pr.av, cf))
+                        continue
+                    if pr.op == D_NEG:
+                        took.append(pi)
+                        stack.append((pr.ak, pr.av, -cf))
+                        continue
+                    if pr.op == D_MULC and pr.flag:
+                        took.append(pi)
+                        stack.append((pr.ak, pr.av, cf * sval(pr.coef)))
+                        continue
+            terms.append([k, v, cf])
+        if not ok or len(took) < 3 or len(terms) > 4000 or any(abs(t[2]) >= (1 << 63) for t in terms) \
+                or abs(c0) >= (1 << 200):
+            continue
+        for pi in took:
+            absorbed[pi] = True
+        nr = _Row(D_LINSUM, r.dk, r.dv, K_NONE, len(terms))
+        if c0 % q:
+            nr.bk, nr.bv = K_CONST, cid(c0 % q)
+        nr.terms = terms
+        nr.extra = r.extra
+        repl[idx] = nr
+        n_lin += 1
+    out = []
+    for idx, r in enumerate(rows):
+        if absorbed[idx]:
+            continue
+        out.append(repl.get(idx, r))
+    return out, n_lin, n_bit
 
 
 def _reassociate(rows, n_vtemps):
@@ -233,7 +392,7 @@ def _reassociate(rows, n_vtemps):
     emitted at the position of the chain's last row (all leaves are defined before it)."""
     uses = {}
     for r in rows:
-        for k, v in ((r.ak, r.av), (r.bk, r.bv), (r.ck, r.cv)):
+        for k, v in _value_operands(r):
             if k == K_TMP:
                 uses[v] = uses.get(v, 0) + 1
     prod = {}
@@ -299,7 +458,7 @@ def _fuse_madd(rows):
     before the MMUL (so that it is still in the forwarding register)."""
     uses = {}
     for r in rows:
-        for k, v in ((r.ak, r.av), (r.bk, r.bv), (r.ck, r.cv)):
+        for k, v in _value_operands(r):
             if k == K_TMP:
                 uses[v] = uses.get(v, 0) + 1
     out = []
@@ -351,6 +510,14 @@ def _alias(rows, n_signals):
                     setattr(r, kk, K_SIG); setattr(r, vv, x)
                 else:
                     setattr(r, kk, K_TMP); setattr(r, vv, x - n_signals)
+        if r.terms:
+            for t in r.terms:
+                if t[0] == K_SIG or t[0] == K_TMP:
+                    x = find(vid(t[0], t[1]))
+                    if x < n_signals:
+                        t[0], t[1] = K_SIG, x
+                    else:
+                        t[0], t[1] = K_TMP, x - n_signals
         if r.op == D_COPY and r.dk == K_SIG and r.ak in (K_SIG, K_TMP):
             src = vid(r.ak, r.av)
             p = producer.get(src)
@@ -393,7 +560,7 @@ def _schedule(rows, n_signals, n_strands):
     for unit in units:
         lv = 0
         for r in unit:
-            for k, v in ((r.ak, r.av), (r.bk, r.bv), (r.ck, r.cv)):
+            for k, v in _value_operands(r):
                 if k == K_SIG or k == K_TMP:
                     pl = prod_level.get(vid(k, v))
                     if pl is not None and pl + 1 > lv:
@@ -408,7 +575,8 @@ def _schedule(rows, n_signals, n_strands):
     streams = [[] for _ in range(n_strands)]
 
     def ucost(unit):
-        return sum(_COST.get(r.op, 1.5) + (0.5 * len(r.extra) if r.extra else 0) for r in unit)
+        return sum(_COST.get(r.op, 1.5) + (0.5 * len(r.extra) if r.extra else 0) + (0.4 * len(r.terms) if r.terms else 0)
+                   for r in unit)
 
     for lv, lunits in enumerate(levels):
         total = sum(ucost(u) for u in lunits)
@@ -420,7 +588,7 @@ def _schedule(rows, n_signals, n_strands):
             # data flow inside one wave (register/own-store forwarding instead of a cross-strand hand-off)
             votes = {}
             for r in unit:
-                for k, v in ((r.ak, r.av), (r.bk, r.bv), (r.ck, r.cv)):
+                for k, v in _value_operands(r):
                     if k == K_SIG or k == K_TMP:
                         x = vid(k, v)
                         ps = prod_strand.get(x)
@@ -465,7 +633,8 @@ X_TMP, X_LDS = 1 << 31, 1 << 30       # flags of an entry of the extra-destinati
 def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
     q = fc.fp.q
     n_signals = fc.n_signals
-    rows, dconsts, n_vtemps = _expand(fc)
+    rows, dconsts, n_vtemps, cid, plain = _expand(fc)
+    rows, n_lin, n_bit = _fuse_linear(rows, plain, q, cid)
     if n_strands > 1:      # one strand prefers the original chains (register forwarding, no extra temps)
         rows, n_vtemps = _reassociate(rows, n_vtemps)
     rows, n_elided = _alias(rows, n_signals)
@@ -493,6 +662,8 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
                 continue
             t = epoch if multi else pos
             fl = tuple(prev_val is not None and (k, v) == prev_val for k, v in ((r.ak, r.av), (r.bk, r.bv)))
+            if r.terms:     # per-term PREV flags ride along as a third element
+                fl = fl + (tuple(prev_val is not None and (tm[0], tm[1]) == prev_val for tm in r.terms),)
             items.append([r, fl, t])
             if r.op not in _NO_VALUE:
                 prev_val = (r.dk, r.dv) if r.dk in (K_SIG, K_TMP) else None
@@ -512,6 +683,8 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
             if r == "B":
                 continue
             ops = [(r.ak, r.av, fl[0]), (r.bk, r.bv, fl[1]), (r.ck, r.cv, False)]
+            if r.terms:
+                ops.extend((tm[0], tm[1], pf) for tm, pf in zip(r.terms, fl[2]))
             for k, v, is_prev in ops:
                 if k not in (K_SIG, K_TMP) or is_prev:
                     continue
@@ -596,8 +769,10 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
     # ---- pass E: encode ------------------------------------------------------------------------------------------------
     enc = []
     extras = []
+    terms = []          # (kind, index, signed coefficient) in stream/row order
     stream_off = [0]
     extra_off = [0]
+    term_off = [0]
     n_prev = n_ldsops = 0
     for si, items in enumerate(plan):
         for (r, fl, t) in items:
@@ -617,9 +792,21 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
                     return 0, 0
                 return k, v
 
-            ka, va = o_enc(r.ak, r.av, fl[0])
-            kb, vb = o_enc(r.bk, r.bv, fl[1])
-            n_prev += fl[0] + fl[1]
+            if r.op == D_LINSUM:
+                ka, va = 0, len(r.terms)
+                kb, vb = (K_CONST, r.bv) if r.bk == K_CONST else (0, 0)
+                for tm, pf in zip(r.terms, fl[2]):
+                    tk, tv = o_enc(tm[0], tm[1], pf)
+                    terms.append((tk, tv, tm[2]))
+                    n_prev += pf
+            elif r.op == D_BIT:
+                ka, va = o_enc(r.ak, r.av, fl[0])
+                kb, vb = 0, r.bv
+                n_prev += fl[0]
+            else:
+                ka, va = o_enc(r.ak, r.av, fl[0])
+                kb, vb = o_enc(r.bk, r.bv, fl[1])
+                n_prev += fl[0] + fl[1]
             n_ldsops += (ka == K_LDS) + (kb == K_LDS)
             ex = []
             if r.dk == K_TMP:
@@ -645,6 +832,7 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
             extras.extend(ex)
         stream_off.append(len(enc))
         extra_off.append(len(extras))
+        term_off.append(len(terms))
     out = np.asarray(enc, dtype=np.uint32).reshape(-1, 4)
 
     t = Tape()
@@ -656,6 +844,13 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
     t.stream_off = np.asarray(stream_off, dtype=np.uint32)
     t.extras = np.asarray(extras + [0, 0, 0, 0], dtype=np.uint32)    # padded: the kernel always reads 4 ahead
     t.extra_off = np.asarray(extra_off, dtype=np.uint32)
+    # term table: 4 x u32 per term = kind, index, |coef| lo, |coef| hi with the sign in bit 31 of the kind word
+    tt = np.zeros((len(terms) + 1, 4), dtype=np.uint32)
+    for j, (tk, tv, cf) in enumerate(terms):
+        m = abs(cf)
+        tt[j] = (tk | (0x80000000 if cf < 0 else 0), tv, m & 0xFFFFFFFF, m >> 32)
+    t.terms = tt
+    t.term_off = np.asarray(term_off, dtype=np.uint32)
     t.n_lds = n_lds_used
     t.n_strands = n_strands
     t.consts = dconsts
@@ -673,12 +868,14 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
         "addsub": int(((dops == D_ADD) | (dops == D_SUB) | (dops == D_NEG)).sum()),
         "copy": int((dops == D_COPY).sum()),
         "copies_elided": n_elided,
+        "asserts_proved": getattr(_expand, "n_proved", 0),
         "extra_dsts": len(extras),
         "prev_operands": n_prev,
         "lds_operands": n_ldsops,
         "lds_slots": n_lds_used,
         "mul2": int((dops == D_MUL2).sum()),
         "mulc": int(((dops == D_MULC) | (dops == D_MADDC)).sum()),
+        "linsum": n_lin, "linsum_terms": len(terms), "bit": n_bit,
         "madd": int((dops == D_MADD).sum()),
         "fused_madd": n_madd,
         "inv": int((dops == D_INV).sum()),

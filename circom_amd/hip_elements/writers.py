@@ -77,7 +77,7 @@ def write_dat(path, fc: FlatCircuit, witness2signal=None):
 
 
 TAPE_MAGIC = b"CWTP"
-TAPE_VERSION = 3
+TAPE_VERSION = 4
 
 
 def write_tape(path, tapes):
@@ -90,9 +90,9 @@ def write_tape(path, tapes):
             consts          n_consts x n64*8 bytes (raw residues as the schedule expects them)
             witness2signal  n_witness x u32
             input names     per name  u32 len | bytes | u32 start | u32 size
-            per variant     u32 n_strands | u32 n_tslots | u32 n_rows | u32 n_extras | u32 n_lds | 3 x u32 0
-                            stream_off (n_strands+1) x u32 | extra_off (n_strands+1) x u32
-                            rows n_rows x 4 x u32 | extras n_extras x u32
+            per variant     u32 n_strands | u32 n_tslots | u32 n_rows | u32 n_extras | u32 n_lds | u32 n_terms | 2 x u32 0
+                            stream_off | extra_off | term_off      ((n_strands+1) x u32 each)
+                            rows n_rows x 4 x u32 | extras n_extras x u32 | terms n_terms x 4 x u32
     """
     if isinstance(tapes, Tape):
         tapes = [tapes]
@@ -111,11 +111,13 @@ def write_tape(path, tapes):
             b = name.encode()
             f.write(struct.pack("<I", len(b)) + b + struct.pack("<II", start, size))
         for t in tapes:
-            f.write(struct.pack("<8I", t.n_strands, t.n_tslots, len(t.rows), len(t.extras), t.n_lds, 0, 0, 0))
+            f.write(struct.pack("<8I", t.n_strands, t.n_tslots, len(t.rows), len(t.extras), t.n_lds, len(t.terms), 0, 0))
             f.write(np.asarray(t.stream_off, dtype="<u4").tobytes())
             f.write(np.asarray(t.extra_off, dtype="<u4").tobytes())
+            f.write(np.asarray(t.term_off, dtype="<u4").tobytes())
             f.write(np.ascontiguousarray(t.rows, dtype="<u4").tobytes())
             f.write(np.asarray(t.extras, dtype="<u4").tobytes())
+            f.write(np.ascontiguousarray(t.terms, dtype="<u4").tobytes())
 
 
 def _le_key(k: int) -> bytes:
