@@ -297,7 +297,7 @@ static int load_tape(cw_circuit *c, const char *path) {
         var.terms.resize((size_t)nterms * 4);
         memcpy(var.terms.data(), b.data() + off, (size_t)nterms * 16);
         off += (size_t)nterms * 16;
-        if (var.term_off[var.n_strands] + 1 != nterms) return fail(CW_EIO, "tape variant: bad term offsets");
+        if (var.term_off[var.n_strands] + 4 != nterms) return fail(CW_EIO, "tape variant: bad term offsets");
         if (var.extra_off[var.n_strands] + 4 != nextras) return fail(CW_EIO, "tape variant: bad extra offsets");
         if (var.stream_off[var.n_strands] != nrows) return fail(CW_EIO, "tape variant: bad stream offsets");
         uint64_t mm = 0;

@@ -150,40 +150,47 @@ __device__ __forceinline__ fe term_load(uint64_t t0, const fe &prev, const EvalC
     if (kind == K_LDS) return lds_load_off((uint32_t)off, c);
     return fetch_off(K_SIG, off, c);
 }
+__device__ __forceinline__ void linsum_term(const fe &xc, uint64_t cf, fe &g, Acc192 &pos, Acc192 &neg, const FpParams &P) {
+    const uint64_t mag = cf & 0x7FFFFFFFFFFFFFFFull;
+    const bool cneg = cf >> 63;
+    if (__all(fe_hi_or(xc) == 0)) {
+        // 64x64 -> 128-bit product, accumulated without reduction
+        const uint32_t a0 = xc.v[0], a1 = xc.v[1], b0 = (uint32_t)mag, b1 = (uint32_t)(mag >> 32);
+        uint64_t t = (uint64_t)a0 * b0;
+        const uint32_t r0 = (uint32_t)t;
+        t = (uint64_t)a0 * b1 + (t >> 32);
+        const uint64_t t2 = (uint64_t)a1 * b0 + (uint32_t)t;
+        const uint64_t hi = (uint64_t)a1 * b1 + (t >> 32) + (t2 >> 32);
+        const uint64_t lo = ((uint64_t)(uint32_t)t2 << 32) | r0;
+        if (cneg) acc192_add(neg, lo, hi);
+        else acc192_add(pos, lo, hi);
+    } else if (mag) {
+        // generic: coef * x in the field (coef as a canonical element)
+        fe cm = fe_zero();
+        cm.v[0] = (uint32_t)mag;
+        cm.v[1] = (uint32_t)(mag >> 32);
+        const fe p = fe_mul2_auto(xc, cm, P);
+        g = cneg ? fe_sub(g, p, P) : fe_add(g, p, P);
+    }
+}
+// Terms are processed four at a time: one scalar load brings the four table entries, the four operand loads are
+// issued together (memory-level parallelism), then the products are accumulated.  Entries past the row's last
+// term (the table is padded by 4) are neutralised by a zero coefficient.
 __device__ __forceinline__ fe eval_linsum(uint32_t n, const fe &c0, const fe &prev, EvalCtx &c, const FpParams &P) {
     fe g = c0;
     Acc192 pos = {0, 0, 0}, neg = {0, 0, 0};
     const uint64_t *tt = c.terms + (size_t)c.tp * 2;
-    uint64_t t0 = tt[0], t1 = tt[1];
-    fe x = term_load(t0, prev, c);
-    for (uint32_t k = 0; k < n; k++) {
-        const fe xc = x;
-        const uint64_t cf = t1;
-        // request the next term (the table is padded by one entry)
-        t0 = tt[2 * (k + 1)];
-        t1 = tt[2 * (k + 1) + 1];
-        if (k + 1 < n) x = term_load(t0, prev, c);
-        const uint64_t mag = cf & 0x7FFFFFFFFFFFFFFFull;
-        const bool cneg = cf >> 63;
-        if (__all(fe_hi_or(xc) == 0)) {
-            // 64x64 -> 128-bit product, accumulated without reduction
-            const uint32_t a0 = xc.v[0], a1 = xc.v[1], b0 = (uint32_t)mag, b1 = (uint32_t)(mag >> 32);
-            uint64_t t = (uint64_t)a0 * b0;
-            const uint32_t r0 = (uint32_t)t;
-            t = (uint64_t)a0 * b1 + (t >> 32);
-            const uint64_t t2 = (uint64_t)a1 * b0 + (uint32_t)t;
-            const uint64_t hi = (uint64_t)a1 * b1 + (t >> 32) + (t2 >> 32);
-            const uint64_t lo = ((uint64_t)(uint32_t)t2 << 32) | r0;
-            if (cneg) acc192_add(neg, lo, hi);
-            else acc192_add(pos, lo, hi);
-        } else {
-            // generic: coef * x in the field (coef as a canonical element)
-            fe cm = fe_zero();
-            cm.v[0] = (uint32_t)mag;
-            cm.v[1] = (uint32_t)(mag >> 32);
-            const fe p = fe_mul2_auto(xc, cm, P);
-            g = cneg ? fe_sub(g, p, P) : fe_add(g, p, P);
-        }
+    for (uint32_t k = 0; k < n; k += 4) {
+        const uint64_t a0 = tt[2 * k], c0_ = tt[2 * k + 1], a1 = tt[2 * k + 2], c1 = tt[2 * k + 3];
+        const uint64_t a2 = tt[2 * k + 4], c2 = tt[2 * k + 5], a3 = tt[2 * k + 6], c3 = tt[2 * k + 7];
+        const fe x0 = term_load(a0, prev, c);
+        const fe x1 = term_load(a1, prev, c);
+        const fe x2 = term_load(a2, prev, c);
+        const fe x3 = term_load(a3, prev, c);
+        linsum_term(x0, c0_, g, pos, neg, P);
+        linsum_term(x1, k + 1 < n ? c1 : 0, g, pos, neg, P);
+        linsum_term(x2, k + 2 < n ? c2 : 0, g, pos, neg, P);
+        linsum_term(x3, k + 3 < n ? c3 : 0, g, pos, neg, P);
     }
     c.tp += n;
     g = fe_add(g, acc192_to_fe(pos), P);

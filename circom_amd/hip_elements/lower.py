@@ -845,7 +845,7 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
     t.extras = np.asarray(extras + [0, 0, 0, 0], dtype=np.uint32)    # padded: the kernel always reads 4 ahead
     t.extra_off = np.asarray(extra_off, dtype=np.uint32)
     # term table: 4 x u32 per term = kind, index, |coef| lo, |coef| hi with the sign in bit 31 of the kind word
-    tt = np.zeros((len(terms) + 1, 4), dtype=np.uint32)
+    tt = np.zeros((len(terms) + 4, 4), dtype=np.uint32)      # padded: the kernel reads terms four at a time
     for j, (tk, tv, cf) in enumerate(terms):
         m = abs(cf)
         tt[j] = (tk | (0x80000000 if cf < 0 else 0), tv, m & 0xFFFFFFFF, m >> 32)
