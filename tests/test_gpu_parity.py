@@ -28,7 +28,7 @@ def _edges(f):
     return [x % q for x in e]
 
 
-@pytest.mark.parametrize("prime", ["bn128", "bls12381"])
+@pytest.mark.parametrize("prime", ["bn128", "bls12381", "bls12377", "grumpkin", "pallas", "vesta", "secq256r1"])
 def test_device_field_ops_match_oracle(prime):
     f = Field(PRIMES[prime])
     rng = random.Random(7)

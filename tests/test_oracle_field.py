@@ -69,9 +69,12 @@ def _edge_values(f: Field):
     return [x % q for x in e]
 
 
-@pytest.mark.parametrize("prime", ["bn128", "bls12381"])
+@pytest.mark.parametrize("prime", ["bn128", "bls12381", "pallas", "secq256r1"])
 def test_field_py_matches_compiled_reference(prime, request):
-    ref_dir = request.getfixturevalue("ref_dir_" + prime)
+    # bn128 / bls12381: the BASELINE primes; pallas: another 255-bit prime; secq256r1: the one prime whose top limb
+    # forces the reference's `cannotOptimize` Montgomery variant (generic/fr.cpp:115-163)
+    from conftest import ensure_ref
+    ref_dir = ensure_ref(prime)
     ref = RefFr(ref_dir / "libfr_shim.so")
     f = Field(PRIMES[prime])
     assert ref.q == f.q
