@@ -125,3 +125,72 @@ def test_gpu_bls12381_and_merkle(tmp_path):
     want, failed = eval_flat(q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp)
     assert failed is None and b.witness(5) == want
     b.close(); c.close()
+
+
+# ---- BabyJubjub scalar multiplication: drives DIV/INV (slow-path kernel variant) at scale ---------------------------
+def _ed_add(p1, p2, q):
+    from circom_amd.circuits.babyjub import A, D
+    x1, y1 = p1
+    x2, y2 = p2
+    t = D * x1 * x2 * y1 * y2 % q
+    return ((x1 * y2 + y1 * x2) * pow(1 + t, -1, q) % q, (y1 * y2 - A * x1 * x2) * pow(1 - t, -1, q) % q)
+
+
+def _ed_mul(k, p, q):
+    acc = (0, 1)
+    for i in range(k.bit_length() - 1, -1, -1):
+        acc = _ed_add(acc, acc, q)
+        if (k >> i) & 1:
+            acc = _ed_add(acc, p, q)
+    return acc
+
+
+def test_babyjub_scalar_mul_vs_integer_arithmetic():
+    from circom_amd.circuits.babyjub import ScalarMulBits, BASE8
+    q = PRIMES["bn128"]
+    n = 16
+    fc = flatten(Program(ScalarMulBits(n)))
+    rng = random.Random(8)
+    for k in (0, 1, 2, 0xFFFF, rng.randrange(1 << n)):
+        inp = {fc.main_input_start + i: (k >> i) & 1 for i in range(n)}
+        inp[fc.main_input_start + n] = BASE8[0]
+        inp[fc.main_input_start + n + 1] = BASE8[1]
+        sig, failed = eval_flat(q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp)
+        assert failed is None and (sig[1], sig[2]) == _ed_mul(k, BASE8, q)
+        assert check_r1cs(q, fc.constraints, sig) is None
+        for S in (1, 4):
+            t = lower(fc, n_strands=S)
+            got, st = eval_tape(t, inp)
+            assert st == 0 and got == sig
+    # a point off the curve trips BabyCheck's `===`
+    inp[fc.main_input_start + n] = 5
+    sig, failed = eval_flat(q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp)
+    assert failed is not None
+
+
+@pytest.mark.gpu
+def test_gpu_babyjub_scalar_mul(tmp_path):
+    from circom_amd import runtime as rt
+    from circom_amd.circuits.babyjub import ScalarMulBits, BASE8
+    q = PRIMES["bn128"]
+    n = 32
+    cp = compile_program(Program(ScalarMulBits(n)), str(tmp_path), "smul32", sym=False)
+    c = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
+    rng = random.Random(5)
+    B = 200
+    ks = [rng.randrange(1 << n) for _ in range(B)]
+    ks[0], ks[1] = 0, (1 << n) - 1
+    rows = [[(k >> i) & 1 for i in range(n)] + list(BASE8) for k in ks]
+    rows[9][n] = 7                                            # instance 9: point not on the curve
+    b = c.batch(B)
+    b.set_inputs(rows)
+    b.run(); b.check_r1cs(); b.sync()
+    st = b.status()
+    assert st[9] & rt.ST_ASSERT_FAILED and (np.delete(st, 9) == 0).all()
+    for i in (0, 1, 2, 100, 199):
+        assert (b.signal(i, 1), b.signal(i, 2)) == _ed_mul(ks[i], BASE8, q), i
+    fc = cp.flat
+    inp = {fc.main_input_start + k: v for k, v in enumerate(rows[3])}
+    want, failed = eval_flat(q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp)
+    assert failed is None and b.witness(3) == want
+    b.close(); c.close()
