@@ -195,6 +195,7 @@ struct cw_circuit {
     bool need_full = false;
     std::vector<Variant> variants;
     std::vector<uint32_t> consts;          // n_consts * 8
+    std::vector<uint32_t> lconsts;         // n_lconsts * 12 (29-bit limbs)
     std::vector<uint32_t> w2s;
     std::vector<HashEntry> hashmap;
     std::map<std::string, std::pair<uint32_t, uint32_t>> input_names;   // name -> (start, size)
@@ -229,7 +230,7 @@ static int load_tape(cw_circuit *c, const char *path) {
     if (!read_file(path, b)) return fail(CW_EIO, std::string("tape file not found: ") + path);
     if (b.size() < 16 + 32 + 48 || memcmp(b.data(), "CWTP", 4)) return fail(CW_EIO, "bad tape magic");
     const uint32_t *h = (const uint32_t *)(b.data() + 4);
-    if (h[0] != 4) return fail(CW_EIO, "unsupported tape version");
+    if (h[0] != 5) return fail(CW_EIO, "unsupported tape version");
     if (h[1] != 4) return fail(CW_EIO, "only 4x64-bit primes are supported (bn128, bls12381, ...)");
     uint32_t n_variants = h[2];
     size_t off = 16;
@@ -244,10 +245,25 @@ static int load_tape(cw_circuit *c, const char *path) {
     c->n_inputs = m[4];
     uint32_t n_names = m[5], hsize = m[6];
     if (m[7] != CW_RBITS) return fail(CW_EIO, "tape was lowered for a different Montgomery radix");
-    if (b.size() < off + (size_t)c->n_consts * 32 + (size_t)c->n_witness * 4) return fail(CW_EIO, "tape file truncated");
+    uint32_t n_lconsts = m[8];
+    if (b.size() < off + ((size_t)c->n_consts + n_lconsts) * 32 + (size_t)c->n_witness * 4)
+        return fail(CW_EIO, "tape file truncated");
     c->consts.resize((size_t)c->n_consts * 8);
     memcpy(c->consts.data(), b.data() + off, (size_t)c->n_consts * 32);
     off += (size_t)c->n_consts * 32;
+    // D_DOTC constants: kept as 9 x 29-bit limbs (+3 pad words = 48 B per entry, 16-byte aligned for scalar loads)
+    c->lconsts.assign((size_t)std::max<uint32_t>(n_lconsts, 1) * 12, 0);
+    for (uint32_t k = 0; k < n_lconsts; k++) {
+        uint64_t w[5] = {0, 0, 0, 0, 0};
+        memcpy(w, b.data() + off + (size_t)k * 32, 32);
+        for (int l = 0; l < 9; l++) {
+            unsigned bit = 29 * l, wi = bit / 64, sh = bit % 64;
+            uint64_t v = w[wi] >> sh;
+            if (sh > 35) v |= w[wi + 1] << (64 - sh);
+            c->lconsts[(size_t)k * 12 + l] = (uint32_t)(v & 0x1FFFFFFFu);
+        }
+    }
+    off += (size_t)n_lconsts * 32;
     c->w2s.resize(c->n_witness);
     memcpy(c->w2s.data(), b.data() + off, (size_t)c->n_witness * 4);
     off += (size_t)c->n_witness * 4;
@@ -298,6 +314,19 @@ static int load_tape(cw_circuit *c, const char *path) {
         memcpy(var.terms.data(), b.data() + off, (size_t)nterms * 16);
         off += (size_t)nterms * 16;
         if (var.term_off[var.n_strands] + 4 != nterms) return fail(CW_EIO, "tape variant: bad term offsets");
+        {   // DOTC terms must index the limb-form constant table
+            size_t tpos = 0;
+            for (auto &r : var.rows) {
+                uint32_t op = r.w0 & 0xFF;
+                if (op == D_LINSUM || op == D_DOTC) {
+                    if (tpos + r.a > nterms) return fail(CW_EIO, "tape variant: term list overruns the table");
+                    if (op == D_DOTC)
+                        for (uint32_t t = 0; t < r.a; t++)
+                            if (var.terms[(tpos + t) * 4 + 2] >= n_lconsts) return fail(CW_EIO, "tape variant: bad constant index");
+                    tpos += r.a;
+                }
+            }
+        }
         if (var.extra_off[var.n_strands] + 4 != nextras) return fail(CW_EIO, "tape variant: bad extra offsets");
         if (var.stream_off[var.n_strands] != nrows) return fail(CW_EIO, "tape variant: bad stream offsets");
         uint64_t mm = 0;
@@ -538,6 +567,7 @@ struct cw_batch {
     uint32_t *d_stream_off = nullptr, *d_extra_off = nullptr;
     uint64_t *d_extras = nullptr, *d_terms = nullptr;
     uint32_t *d_term_off = nullptr;
+    uint32_t *d_lconsts = nullptr;
     uint32_t *d_consts = nullptr, *d_w2s = nullptr, *d_status = nullptr, *d_first_bad = nullptr;
     uint32_t *d_rptr = nullptr, *d_rslot = nullptr, *d_rcoef = nullptr, *d_rctab = nullptr, *d_rorig = nullptr;
     void *d_in = nullptr;          // AoS staging [batch][n_in][32]
@@ -567,7 +597,7 @@ extern "C" void cw_batch_free(cw_batch *b) {
     }
     hipSetDevice(b->device);
     hipStreamSynchronize(b->stream);
-    void *ptrs[] = {b->d_V, b->d_rows, b->d_stream_off, b->d_extras, b->d_extra_off, b->d_terms, b->d_term_off, b->d_consts, b->d_w2s, b->d_status, b->d_first_bad,
+    void *ptrs[] = {b->d_V, b->d_rows, b->d_stream_off, b->d_extras, b->d_extra_off, b->d_terms, b->d_term_off, b->d_lconsts, b->d_consts, b->d_w2s, b->d_status, b->d_first_bad,
                     b->d_rptr, b->d_rslot, b->d_rcoef, b->d_rctab, b->d_rorig, b->d_in, b->d_gather};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -654,7 +684,7 @@ extern "C" int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *
                 if (op == D_BARRIER) {
                     d.aux = row.dst;
                     d.dst_off = d.a_off = d.b_off = 0;
-                } else if (op == D_LINSUM) {
+                } else if (op == D_LINSUM || op == D_DOTC) {
                     d.aux = row.a;                                   // number of terms
                     d.dst_off = dk == KD_NONE ? 0 : resolve(dk, row.dst);
                     d.a_off = 0;
@@ -680,6 +710,7 @@ extern "C" int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *
         for (size_t k = 0; k + 3 < v.terms.size(); k += 4) {
             uint32_t kw = v.terms[k], kind = kw & 7;
             dterms[k / 2] = ((uint64_t)kind << 61) | resolve(kind, v.terms[k + 1]);
+            // LINSUM: sign | |coef| ; DOTC: index into the limb-form constant table (the kernel multiplies by 48)
             dterms[k / 2 + 1] = ((uint64_t)(kw >> 31) << 63) | ((uint64_t)v.terms[k + 3] << 32) | v.terms[k + 2];
         }
         std::vector<uint64_t> dex(v.extras.size());
@@ -715,6 +746,7 @@ extern "C" int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *
         TRY(hipStreamSynchronize(b->stream));                        // host vectors go out of scope
     }
     TRY(upload(&b->d_consts, c->consts, b->stream));
+    TRY(upload(&b->d_lconsts, c->lconsts, b->stream));
     TRY(upload(&b->d_w2s, c->w2s, b->stream));
     TRY(hipMalloc((void **)&b->d_status, (size_t)b->Bp * 4));
     TRY(hipMalloc((void **)&b->d_first_bad, (size_t)b->Bp * 4));
@@ -1028,8 +1060,8 @@ extern "C" int cw_run(cw_batch *b) {
     HIPCHK(cwk_init(b->stream, b->d_V, b->Bp, b->d_status, b->d_first_bad));
     HIPCHK(cwk_ingest(b->stream, in, b->d_V, c->input_start, c->n_inputs, b->batch, b->Bp));
     HIPCHK(cwk_eval(b->stream, c->need_full, b->d_rows, b->d_stream_off, b->d_extras, b->d_extra_off, b->d_terms,
-                    b->d_term_off, b->var->n_strands, b->var->n_lds, b->d_V, b->d_consts, b->Bp, b->batch, b->d_status,
-                    c->P));
+                    b->d_term_off, b->var->n_strands, b->var->n_lds, b->d_V, b->d_consts, b->d_lconsts, b->Bp, b->batch,
+                    b->d_status, c->P));
     b->ran = true;
     return CW_OK;
 }

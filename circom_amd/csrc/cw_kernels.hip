@@ -82,7 +82,8 @@ extern __shared__ uint4 cw_lds[];       // [slot][2 halves][64 lanes] x 16 B
 struct EvalCtx {                         // per-wave constants of the interpreter
     const char *Vb;                      // value table, bytes
     const char *Cb;                      // constant table, bytes
-    const uint64_t *terms;               // D_LINSUM term table of this strand ...
+    const uint32_t *Lb;                  // limb-form constant table (D_DOTC), 12 words per entry
+    const uint64_t *terms;               // D_LINSUM / D_DOTC term table of this strand ...
     uint32_t tp;                         // ... and the running position in it
     uint32_t vlo, vhi;                   // this lane's byte offsets of the lo/hi half inside a value slot
     uint32_t lane16;                     // lane * 16 (LDS)
@@ -197,6 +198,32 @@ __device__ __forceinline__ fe eval_linsum(uint32_t n, const fe &c0, const fe &pr
     return fe_sub(g, acc192_to_fe(neg), P);
 }
 
+// ---- D_DOTC: d = c0 + sum_i coef_i * x_i with field-sized coefficients --------------------------------------------
+// Up to four products x_i * (coef_i R') are accumulated as unreduced 29-bit-limb columns and reduced ONCE
+// (81 multiply-adds per term + 90 for the reduction, instead of a full Montgomery product and a modular
+// addition per term).  The constants come from the limb-form table through scalar loads.
+__device__ __forceinline__ fe eval_dotc(uint32_t n, const fe &c0, const fe &prev, EvalCtx &c, const FpParams &P) {
+    fe res = c0;
+    const uint64_t *tt = c.terms + (size_t)c.tp * 2;
+    for (uint32_t k = 0; k < n; k += 4) {
+        const uint64_t a0 = tt[2 * k], i0 = tt[2 * k + 1], a1 = tt[2 * k + 2], i1 = tt[2 * k + 3];
+        const uint64_t a2 = tt[2 * k + 4], i2 = tt[2 * k + 5], a3 = tt[2 * k + 6], i3 = tt[2 * k + 7];
+        const fe x0 = term_load(a0, prev, c);
+        const fe x1 = term_load(a1, prev, c);
+        const fe x2 = term_load(a2, prev, c);
+        const fe x3 = term_load(a3, prev, c);
+        uint64_t acc[18];
+        for (int j = 0; j < 18; j++) acc[j] = 0;
+        fe29_mac(acc, fe_to29(x0), c.Lb + (size_t)(uint32_t)i0 * 12);
+        if (k + 1 < n) fe29_mac(acc, fe_to29(x1), c.Lb + (size_t)(uint32_t)i1 * 12);
+        if (k + 2 < n) fe29_mac(acc, fe_to29(x2), c.Lb + (size_t)(uint32_t)i2 * 12);
+        if (k + 3 < n) fe29_mac(acc, fe_to29(x3), c.Lb + (size_t)(uint32_t)i3 * 12);
+        res = fe_add(res, fe_from29(fe29_reduce(acc, P)), P);
+    }
+    c.tp += n;
+    return res;
+}
+
 // One interpreter step: executes `row` with operands (xa, xb) while the operands of `nrow` are requested into
 // (ya, yb).  The loop calls it twice per iteration with the two register sets swapped (no rotation moves).
 template <bool FULL_OPS>
@@ -250,6 +277,7 @@ __device__ __forceinline__ void eval_step(const CwDRow &row, const fe &xa, const
         break;
     }
     case D_LINSUM: d = eval_linsum(row.aux, bk == K_CONST ? b : fe_zero(), prev, c, P); break;
+    case D_DOTC: d = eval_dotc(row.aux, bk == K_CONST ? b : fe_zero(), prev, c, P); break;
     case D_BIT: {                                                    // (a >> k) & 1, k = row.aux (wave-uniform)
         const uint32_t k = row.aux, w = k >> 5;
         const uint32_t limb = w == 0 ? a.v[0] : w == 1 ? a.v[1] : w == 2 ? a.v[2] : w == 3 ? a.v[3] : w == 4 ? a.v[4]
@@ -347,7 +375,8 @@ __global__ void __launch_bounds__(1024)
 cw_eval_kernel(const CwDRow *__restrict__ rows, const uint32_t *__restrict__ stream_off,
                const uint64_t *__restrict__ extras, const uint32_t *__restrict__ extra_off,
                const uint64_t *__restrict__ terms, const uint32_t *__restrict__ term_off, uint4 *V,
-               const uint32_t *__restrict__ consts, uint32_t Bp, uint32_t batch, uint32_t *status, FpParams P) {
+               const uint32_t *__restrict__ consts, const uint32_t *__restrict__ lconsts, uint32_t Bp, uint32_t batch,
+               uint32_t *status, FpParams P) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t i = blockIdx.x * 64 + lane;                     // < Bp (Bp is a multiple of 256 >= batch)
@@ -357,6 +386,7 @@ cw_eval_kernel(const CwDRow *__restrict__ rows, const uint32_t *__restrict__ str
     c.vlo = i * 16u;
     c.vhi = i * 16u + Bp * 16u;
     c.lane16 = lane * 16u;
+    c.Lb = lconsts;
     c.terms = terms;
     c.tp = term_off[wave];
     // every stream is padded with 3 NOP rows, so rows[r+1..r+3] are always readable
@@ -529,8 +559,8 @@ hipError_t cwk_ingest(hipStream_t s, const void *in, void *V, uint32_t input_sta
 }
 hipError_t cwk_eval(hipStream_t s, bool full, const CwDRow *rows, const uint32_t *stream_off, const uint64_t *extras,
                     const uint32_t *extra_off, const uint64_t *terms, const uint32_t *term_off, uint32_t n_strands,
-                    uint32_t n_lds, void *V, const uint32_t *consts, uint32_t Bp, uint32_t batch, uint32_t *status,
-                    const FpParams &P) {
+                    uint32_t n_lds, void *V, const uint32_t *consts, const uint32_t *lconsts, uint32_t Bp, uint32_t batch,
+                    uint32_t *status, const FpParams &P) {
     dim3 grid((batch + 63) / 64), block(64 * n_strands);
     const size_t lds_bytes = (size_t)n_lds * 2048;
     if (lds_bytes > 64 * 1024) {
@@ -540,10 +570,10 @@ hipError_t cwk_eval(hipStream_t s, bool full, const CwDRow *rows, const uint32_t
     }
     if (full)
         hipLaunchKernelGGL(cw_eval_kernel<true>, grid, block, lds_bytes, s, rows, stream_off, extras, extra_off, terms,
-                           term_off, (uint4 *)V, consts, Bp, batch, status, P);
+                           term_off, (uint4 *)V, consts, lconsts, Bp, batch, status, P);
     else
         hipLaunchKernelGGL(cw_eval_kernel<false>, grid, block, lds_bytes, s, rows, stream_off, extras, extra_off, terms,
-                           term_off, (uint4 *)V, consts, Bp, batch, status, P);
+                           term_off, (uint4 *)V, consts, lconsts, Bp, batch, status, P);
     return hipGetLastError();
 }
 hipError_t cwk_r1cs(hipStream_t s, const uint32_t *ptr, const uint32_t *tslot, const uint32_t *tcoef, const uint32_t *ctab,

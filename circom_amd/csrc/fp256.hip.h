@@ -197,6 +197,40 @@ __device__ __forceinline__ fe29 fe29_mmul(const fe29 &a, const fe29 &b, const Fp
     return r;
 }
 
+// ---- dot products with one reduction ---------------------------------------------------------------------------
+// acc (17 columns + carry) += a * c, the 81 unreduced partial products; c = wave-uniform limbs (SGPRs)
+__device__ __forceinline__ void fe29_mac(uint64_t acc[18], const fe29 &a, const uint32_t *c29) {
+    FE_UNROLL for (int i = 0; i < 9; i++) {
+        const uint32_t ci = c29[i];
+        FE_UNROLL for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)a.l[j] * ci;
+    }
+}
+// Montgomery reduction of such an accumulator: (acc * R'^-1) mod q, valid while every column stays < 2^64, i.e. for
+// up to 4 accumulated products (45 terms of < 2^58 each per column)
+__device__ __forceinline__ fe29 fe29_reduce(uint64_t acc[18], const FpParams &P) {
+    FE_UNROLL for (int i = 0; i < 9; i++) {
+        const uint32_t m = ((uint32_t)acc[i] * P.np29) & FE29_MASK;
+        FE_UNROLL for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)m * P.q29[j];
+        acc[i + 1] += acc[i] >> 29;
+    }
+    fe29 r;
+    uint64_t c = 0;
+    FE_UNROLL for (int k = 0; k < 9; k++) {
+        c += acc[9 + k];
+        r.l[k] = (uint32_t)c & FE29_MASK;
+        c >>= 29;
+    }
+    fe29 d;
+    int32_t br = 0;
+    FE_UNROLL for (int k = 0; k < 9; k++) {
+        int32_t t = (int32_t)r.l[k] - (int32_t)P.q29[k] + br;
+        d.l[k] = (uint32_t)t & FE29_MASK;
+        br = t >> 31;
+    }
+    FE_UNROLL for (int k = 0; k < 9; k++) r.l[k] = br ? r.l[k] : d.l[k];
+    return r;
+}
+
 __device__ __forceinline__ fe fe_mmul(const fe &a, const fe &b, const FpParams &P) {
     return fe_from29(fe29_mmul(fe_to29(a), fe_to29(b), P));
 }

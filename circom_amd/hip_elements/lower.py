@@ -51,10 +51,14 @@ from ..frontend.flatten import FlatCircuit
 # device opcodes (csrc/cw_tape.h must match)
 (D_COPY, D_ADD, D_SUB, D_NEG, D_MMUL, D_INV, D_IDIV, D_MOD, D_POW, D_SHL, D_SHR, D_BAND, D_BOR, D_BXOR,
  D_BNOT, D_LT, D_GT, D_LEQ, D_GEQ, D_EQ, D_NEQ, D_LAND, D_LOR, D_LNOT, D_SELECT, D_EXT, D_ASSERT_EQ,
- D_ASSERT_NZ, D_ALSO, D_BARRIER, D_MUL2, D_MADD, D_MULC, D_MADDC, D_LINSUM, D_BIT) = range(36)
+ D_ASSERT_NZ, D_ALSO, D_BARRIER, D_MUL2, D_MADD, D_MULC, D_MADDC, D_LINSUM, D_BIT, D_DOTC) = range(37)
 D_NAMES = ["copy", "add", "sub", "neg", "mmul", "inv", "idiv", "mod", "pow", "shl", "shr", "band", "bor",
            "bxor", "bnot", "lt", "gt", "leq", "geq", "eq", "neq", "land", "lor", "lnot", "select", "ext",
-           "assert_eq", "assert_nz", "also", "barrier", "mul2", "madd", "mulc", "maddc", "linsum", "bit"]
+           "assert_eq", "assert_nz", "also", "barrier", "mul2", "madd", "mulc", "maddc", "linsum", "bit", "dotc"]
+# D_DOTC  : d = c0 + sum_i coef_i * x_i with ARBITRARY field coefficients: like D_LINSUM, but the second word of a
+#           term indexes the limb-form constant table (coef_i * R' as 9 x 29-bit limbs); the kernel accumulates the
+#           unreduced 29-bit-limb products of up to 4 terms and performs ONE Montgomery reduction for them
+#           (Poseidon's MDS row = 3 products + 1 reduction instead of 3 full Montgomery multiplications + 2 adds).
 # D_LINSUM: d = c0 + sum_i coef_i * x_i with small signed integer coefficients (|coef| < 2^63): field `a` = number of
 #           terms, operand b = constant c0 (or none); the terms (operand, coefficient) are consecutive entries of
 #           the strand's term table.  One row replaces the 2n-1 MULC/ADD/SUB rows `lin += in[j][k] * e2` loops trace into.
@@ -76,7 +80,7 @@ _DIRECT = {O.COPY: D_COPY, O.ADD: D_ADD, O.SUB: D_SUB, O.NEG: D_NEG, O.IDIV: D_I
            O.POW: D_POW, O.SHL: D_SHL, O.SHR: D_SHR, O.BAND: D_BAND, O.BOR: D_BOR, O.BXOR: D_BXOR,
            O.BNOT: D_BNOT, O.LT: D_LT, O.GT: D_GT, O.LEQ: D_LEQ, O.GEQ: D_GEQ, O.EQ: D_EQ, O.NEQ: D_NEQ,
            O.LAND: D_LAND, O.LOR: D_LOR, O.LNOT: D_LNOT, O.ASSERT_EQ: D_ASSERT_EQ, O.ASSERT_NZ: D_ASSERT_NZ}
-_COST = {D_MMUL: 10.0, D_MUL2: 19.0, D_MADD: 11.0, D_MULC: 10.0, D_MADDC: 11.0, D_INV: 4000.0, D_POW: 6000.0, D_IDIV: 8000.0, D_MOD: 8000.0}
+_COST = {D_MMUL: 10.0, D_MUL2: 19.0, D_MADD: 11.0, D_MULC: 10.0, D_MADDC: 11.0, D_DOTC: 6.0, D_INV: 4000.0, D_POW: 6000.0, D_IDIV: 8000.0, D_MOD: 8000.0}
 _NO_VALUE = (D_ASSERT_EQ, D_ASSERT_NZ, D_SELECT)
 
 
@@ -96,6 +100,7 @@ class Tape:
         self.n_lds = 0              # LDS value slots the workgroup needs
         self.terms = None           # uint32[n,4]: D_LINSUM terms (kind|sign, index, |coef| lo, hi), stream/row order
         self.term_off = None        # uint32[n_strands+1]
+        self.lconsts = []           # constants of D_DOTC terms (coef * R' mod q), stored by the runtime as 29-bit limbs
         self.n_strands = 1
         self.consts = []            # raw residues (python ints)
         self.witness2signal = None  # uint32[n_witness]
@@ -358,17 +363,23 @@ def _fuse_linear(rows, consts_plain, q, cid):
                         took.append(pi)
                         stack.append((pr.ak, pr.av, -cf))
                         continue
-                    if pr.op == D_MULC and pr.flag:
+                    if pr.op == D_MULC:
                         took.append(pi)
+                        # exact integer product of signed representatives; reduced mod q when it leaves the small range
                         stack.append((pr.ak, pr.av, cf * sval(pr.coef)))
                         continue
             terms.append([k, v, cf])
-        if not ok or len(took) < 3 or len(terms) > 4000 or any(abs(t[2]) >= (1 << 63) for t in terms) \
-                or abs(c0) >= (1 << 200):
+        if not ok or len(took) < 3 or len(terms) > 4000:
             continue
+        small = all(abs(t[2]) < (1 << 63) for t in terms)
+        if not small:
+            if len(terms) > 16:          # long sums with field-sized coefficients: leave to the MADDC chain
+                continue
+            for t in terms:
+                t[2] = sval(t[2] % q)
         for pi in took:
             absorbed[pi] = True
-        nr = _Row(D_LINSUM, r.dk, r.dv, K_NONE, len(terms))
+        nr = _Row(D_LINSUM if small else D_DOTC, r.dk, r.dv, K_NONE, len(terms))
         if c0 % q:
             nr.bk, nr.bv = K_CONST, cid(c0 % q)
         nr.terms = terms
@@ -767,9 +778,20 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
                 slot_of[r.dv] = sl
 
     # ---- pass E: encode ------------------------------------------------------------------------------------------------
+    lconsts, lconst_id = [], {}
+
+    def lcid(c):
+        v = (c % q) * fc.fp.Rdev % q
+        i = lconst_id.get(v)
+        if i is None:
+            i = len(lconsts)
+            lconst_id[v] = i
+            lconsts.append(v)
+        return i
+
     enc = []
     extras = []
-    terms = []          # (kind, index, signed coefficient) in stream/row order
+    terms = []          # (kind, index, signed coefficient | limb-constant index) in stream/row order
     stream_off = [0]
     extra_off = [0]
     term_off = [0]
@@ -792,12 +814,15 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
                     return 0, 0
                 return k, v
 
-            if r.op == D_LINSUM:
+            if r.op == D_LINSUM or r.op == D_DOTC:
                 ka, va = 0, len(r.terms)
                 kb, vb = (K_CONST, r.bv) if r.bk == K_CONST else (0, 0)
                 for tm, pf in zip(r.terms, fl[2]):
                     tk, tv = o_enc(tm[0], tm[1], pf)
-                    terms.append((tk, tv, tm[2]))
+                    if r.op == D_DOTC:
+                        terms.append((tk, tv, lcid(tm[2])))       # index of coef*R' in the limb-form constant table
+                    else:
+                        terms.append((tk, tv, tm[2]))
                     n_prev += pf
             elif r.op == D_BIT:
                 ka, va = o_enc(r.ak, r.av, fl[0])
@@ -851,6 +876,7 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
         tt[j] = (tk | (0x80000000 if cf < 0 else 0), tv, m & 0xFFFFFFFF, m >> 32)
     t.terms = tt
     t.term_off = np.asarray(term_off, dtype=np.uint32)
+    t.lconsts = lconsts
     t.n_lds = n_lds_used
     t.n_strands = n_strands
     t.consts = dconsts
@@ -875,7 +901,7 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
         "lds_slots": n_lds_used,
         "mul2": int((dops == D_MUL2).sum()),
         "mulc": int(((dops == D_MULC) | (dops == D_MADDC)).sum()),
-        "linsum": n_lin, "linsum_terms": len(terms), "bit": n_bit,
+        "linsum": n_lin, "linsum_terms": len(terms), "bit": n_bit, "dotc": int((dops == D_DOTC).sum()),
         "madd": int((dops == D_MADD).sum()),
         "fused_madd": n_madd,
         "inv": int((dops == D_INV).sum()),

@@ -77,7 +77,7 @@ def write_dat(path, fc: FlatCircuit, witness2signal=None):
 
 
 TAPE_MAGIC = b"CWTP"
-TAPE_VERSION = 4
+TAPE_VERSION = 5
 
 
 def write_tape(path, tapes):
@@ -86,8 +86,9 @@ def write_tape(path, tapes):
          0  "CWTP" | u32 version | u32 n64 | u32 n_variants
         16  prime, n64*8 bytes
             12 x u32: n_signals, n_witness, n_consts, main_input_start, n_main_inputs, n_input_names,
-                      hashmap_size, rbits (Montgomery radix exponent of MMUL rows), 0, 0, 0, 0
+                      hashmap_size, rbits (Montgomery radix exponent of MMUL rows), n_lconsts, 0, 0, 0
             consts          n_consts x n64*8 bytes (raw residues as the schedule expects them)
+            lconsts         n_lconsts x n64*8 bytes (coef*R' of D_DOTC terms; the runtime keeps them as 29-bit limbs)
             witness2signal  n_witness x u32
             input names     per name  u32 len | bytes | u32 start | u32 size
             per variant     u32 n_strands | u32 n_tslots | u32 n_rows | u32 n_extras | u32 n_lds | u32 n_terms | 2 x u32 0
@@ -100,12 +101,14 @@ def write_tape(path, tapes):
     n64 = (t0.q.bit_length() + 63) // 64
     for t in tapes[1:]:
         assert t.consts == t0.consts and t.n_signals == t0.n_signals, "variants must come from the same circuit"
+        assert t.lconsts == t0.lconsts, "variants must share the limb-form constant table"
     with open(path, "wb") as f:
         f.write(TAPE_MAGIC + struct.pack("<III", TAPE_VERSION, n64, len(tapes)))
         f.write(t0.q.to_bytes(8 * n64, "little"))
         f.write(struct.pack("<12I", t0.n_signals, t0.n_witness, len(t0.consts), t0.main_input_start, t0.n_main_inputs,
-                            len(t0.inputs), hashmap_size(len(t0.inputs)), t0.rbits, 0, 0, 0, 0))
+                            len(t0.inputs), hashmap_size(len(t0.inputs)), t0.rbits, len(t0.lconsts), 0, 0, 0))
         f.write(b"".join(c.to_bytes(8 * n64, "little") for c in t0.consts))
+        f.write(b"".join(c.to_bytes(8 * n64, "little") for c in t0.lconsts))
         f.write(np.asarray(t0.witness2signal, dtype="<u4").tobytes())
         for name, start, size in t0.inputs:
             b = name.encode()

@@ -92,7 +92,7 @@ def check_r1cs(q: int, constraints, w) -> int | None:
 # D_* numbering of circom_amd/csrc/cw_tape.h
 (D_COPY, D_ADD, D_SUB, D_NEG, D_MMUL, D_INV, D_IDIV, D_MOD, D_POW, D_SHL, D_SHR, D_BAND, D_BOR, D_BXOR,
  D_BNOT, D_LT, D_GT, D_LEQ, D_GEQ, D_EQ, D_NEQ, D_LAND, D_LOR, D_LNOT, D_SELECT, D_EXT, D_ASSERT_EQ,
- D_ASSERT_NZ, D_ALSO, D_BARRIER, D_MUL2, D_MADD, D_MULC, D_MADDC, D_LINSUM, D_BIT) = range(36)   # D_ALSO unused
+ D_ASSERT_NZ, D_ALSO, D_BARRIER, D_MUL2, D_MADD, D_MULC, D_MADDC, D_LINSUM, D_BIT, D_DOTC) = range(37)   # D_ALSO unused
 _DBIN = {D_ADD: "add", D_SUB: "sub", D_IDIV: "idiv", D_MOD: "mod", D_POW: "pow", D_SHL: "shl", D_SHR: "shr",
          D_BAND: "band", D_BOR: "bor", D_BXOR: "bxor", D_LT: "lt", D_GT: "gt", D_LEQ: "leq", D_GEQ: "geq",
          D_EQ: "eq", D_NEQ: "neq", D_LAND: "land", D_LOR: "lor"}
@@ -109,7 +109,7 @@ X_TMP, X_LDS = 1 << 31, 1 << 30
 
 
 def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict, rbits: int = 261,
-              stream_off=None, extras=None, extra_off=None, n_lds: int = 0, terms=None, term_off=None):
+              stream_off=None, extras=None, extra_off=None, n_lds: int = 0, terms=None, term_off=None, lconsts=()):
     """Evaluate a lowered schedule exactly the way cw_eval_kernel does, for one instance:
       * every strand (stream) walks its own rows; strands meet at BARRIER rows,
       * operands of row r+1 are fetched BEFORE row r stores its result (one-row-ahead prefetch), except
@@ -188,8 +188,8 @@ def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict,
     def operands_of(s, r):
         w0, _, a_, b_ = rows[r]
         op = w0 & 0xFF
-        if op == D_BARRIER or op == D_LINSUM:
-            return None, None                      # LINSUM reads its terms at execution time
+        if op == D_BARRIER or op == D_LINSUM or op == D_DOTC:
+            return None, None                      # LINSUM / DOTC read their terms at execution time
         if op == D_BIT:
             return fetch(s, (w0 >> SH_AK) & 7, a_), None
         ak, bk = (w0 >> SH_AK) & 7, (w0 >> SH_BK) & 7
@@ -253,6 +253,14 @@ def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict,
                     acc += -cf * x if tk >> 31 else cf * x
                 tp[s] += a_
                 res = acc % q
+            elif op == D_DOTC:
+                acc = consts[b_] if bk == 2 else 0
+                for (tk, tv, lo, hi) in terms[tp[s]:tp[s] + a_]:
+                    kind = tk & 7
+                    x = prev[s] if kind == K_PREV else mem_read(s, kind, tv)
+                    acc += x * lconsts[lo] * rinv           # limb-table constant = coef * R'
+                tp[s] += a_
+                res = acc % q
             elif op == D_BIT:
                 res = (a >> b_) & 1 if b_ < 256 else 0
             elif op == D_SELECT:
@@ -306,4 +314,4 @@ def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict,
 def eval_tape(tape, inputs: dict):
     """Convenience wrapper over a circom_amd.hip_elements.lower.Tape (duck-typed)."""
     return eval_rows(tape.q, tape.n_signals, tape.n_tslots, tape.consts, tape.rows, inputs, tape.rbits,
-                     tape.stream_off, tape.extras, tape.extra_off, tape.n_lds, tape.terms, tape.term_off)
+                     tape.stream_off, tape.extras, tape.extra_off, tape.n_lds, tape.terms, tape.term_off, tape.lconsts)
