@@ -335,6 +335,7 @@ static int load_tape(cw_circuit *c, const char *path) {
             if (op >= D_NOPS) return fail(CW_EIO, "tape contains an unknown opcode");
             if (op == D_MMUL || op == D_MADD || op == D_MULC || op == D_MADDC) mm++;
             if (op == D_MUL2) mm += 2;
+            if (op == D_DOTC || op == D_LINSUM) mm += r.a;           // one product per term
             if (op == D_INV || op == D_IDIV || op == D_MOD || op == D_POW) c->need_full = true;
         }
         if (v == 0) {

@@ -174,24 +174,19 @@ __device__ __forceinline__ void linsum_term(const fe &xc, uint64_t cf, fe &g, Ac
         g = cneg ? fe_sub(g, p, P) : fe_add(g, p, P);
     }
 }
-// Terms are processed four at a time: one scalar load brings the four table entries, the four operand loads are
-// issued together (memory-level parallelism), then the products are accumulated.  Entries past the row's last
-// term (the table is padded by 4) are neutralised by a zero coefficient.
+// Terms are processed two at a time: one scalar load brings the two table entries, both operand loads are in
+// flight together, then the products are accumulated.  The entry past the row's last term (the table is padded)
+// is neutralised by a zero coefficient.
 __device__ __forceinline__ fe eval_linsum(uint32_t n, const fe &c0, const fe &prev, EvalCtx &c, const FpParams &P) {
     fe g = c0;
     Acc192 pos = {0, 0, 0}, neg = {0, 0, 0};
     const uint64_t *tt = c.terms + (size_t)c.tp * 2;
-    for (uint32_t k = 0; k < n; k += 4) {
+    for (uint32_t k = 0; k < n; k += 2) {
         const uint64_t a0 = tt[2 * k], c0_ = tt[2 * k + 1], a1 = tt[2 * k + 2], c1 = tt[2 * k + 3];
-        const uint64_t a2 = tt[2 * k + 4], c2 = tt[2 * k + 5], a3 = tt[2 * k + 6], c3 = tt[2 * k + 7];
         const fe x0 = term_load(a0, prev, c);
         const fe x1 = term_load(a1, prev, c);
-        const fe x2 = term_load(a2, prev, c);
-        const fe x3 = term_load(a3, prev, c);
         linsum_term(x0, c0_, g, pos, neg, P);
         linsum_term(x1, k + 1 < n ? c1 : 0, g, pos, neg, P);
-        linsum_term(x2, k + 2 < n ? c2 : 0, g, pos, neg, P);
-        linsum_term(x3, k + 3 < n ? c3 : 0, g, pos, neg, P);
     }
     c.tp += n;
     g = fe_add(g, acc192_to_fe(pos), P);
@@ -205,20 +200,18 @@ __device__ __forceinline__ fe eval_linsum(uint32_t n, const fe &c0, const fe &pr
 __device__ __forceinline__ fe eval_dotc(uint32_t n, const fe &c0, const fe &prev, EvalCtx &c, const FpParams &P) {
     fe res = c0;
     const uint64_t *tt = c.terms + (size_t)c.tp * 2;
-    for (uint32_t k = 0; k < n; k += 4) {
-        const uint64_t a0 = tt[2 * k], i0 = tt[2 * k + 1], a1 = tt[2 * k + 2], i1 = tt[2 * k + 3];
-        const uint64_t a2 = tt[2 * k + 4], i2 = tt[2 * k + 5], a3 = tt[2 * k + 6], i3 = tt[2 * k + 7];
-        const fe x0 = term_load(a0, prev, c);
-        const fe x1 = term_load(a1, prev, c);
-        const fe x2 = term_load(a2, prev, c);
-        const fe x3 = term_load(a3, prev, c);
-        uint64_t acc[18];
-        for (int j = 0; j < 18; j++) acc[j] = 0;
-        fe29_mac(acc, fe_to29(x0), c.Lb + (size_t)(uint32_t)i0 * 12);
-        if (k + 1 < n) fe29_mac(acc, fe_to29(x1), c.Lb + (size_t)(uint32_t)i1 * 12);
-        if (k + 2 < n) fe29_mac(acc, fe_to29(x2), c.Lb + (size_t)(uint32_t)i2 * 12);
-        if (k + 3 < n) fe29_mac(acc, fe_to29(x3), c.Lb + (size_t)(uint32_t)i3 * 12);
-        res = fe_add(res, fe_from29(fe29_reduce(acc, P)), P);
+    uint64_t acc[18];
+    for (int j = 0; j < 18; j++) acc[j] = 0;
+    fe x = term_load(tt[0], prev, c);
+    for (uint32_t k = 0; k < n; k++) {
+        const fe29 xc = fe_to29(x);
+        const uint32_t ci = (uint32_t)tt[2 * k + 1];
+        if (k + 1 < n) x = term_load(tt[2 * k + 2], prev, c);       // next operand in flight during the 81 MACs
+        fe29_mac(acc, xc, c.Lb + (size_t)ci * 12);
+        if ((k & 3) == 3 || k + 1 == n) {                            // at most 4 products per reduction (column bound)
+            res = fe_add(res, fe_from29(fe29_reduce(acc, P)), P);
+            for (int j = 0; j < 18; j++) acc[j] = 0;
+        }
     }
     c.tp += n;
     return res;

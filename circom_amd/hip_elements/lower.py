@@ -646,6 +646,22 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
     n_signals = fc.n_signals
     rows, dconsts, n_vtemps, cid, plain = _expand(fc)
     rows, n_lin, n_bit = _fuse_linear(rows, plain, q, cid)
+    # limb-form constant table of the D_DOTC terms, interned in program order (identical for every strand count)
+    lconsts, lconst_id = [], {}
+
+    def lcid(c):
+        v = (c % q) * fc.fp.Rdev % q
+        i = lconst_id.get(v)
+        if i is None:
+            i = len(lconsts)
+            lconst_id[v] = i
+            lconsts.append(v)
+        return i
+
+    for r in rows:
+        if r.op == D_DOTC:
+            for tm in r.terms:
+                lcid(tm[2])
     if n_strands > 1:      # one strand prefers the original chains (register forwarding, no extra temps)
         rows, n_vtemps = _reassociate(rows, n_vtemps)
     rows, n_elided = _alias(rows, n_signals)
@@ -778,16 +794,6 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
                 slot_of[r.dv] = sl
 
     # ---- pass E: encode ------------------------------------------------------------------------------------------------
-    lconsts, lconst_id = [], {}
-
-    def lcid(c):
-        v = (c % q) * fc.fp.Rdev % q
-        i = lconst_id.get(v)
-        if i is None:
-            i = len(lconsts)
-            lconst_id[v] = i
-            lconsts.append(v)
-        return i
 
     enc = []
     extras = []

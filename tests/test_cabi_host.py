@@ -36,7 +36,8 @@ def test_load_reports_circuit_shape(tmp_path):
     assert (c.n_signals, c.n_witness, c.n_inputs, c.input_start, c.n_constraints) == (1108, 1108, 2, 2, 1105)
     assert c.q == Q and c.input_size("inputs") == (2, 2) and c.input_size("nope") == (None, None)
     st = cp.tape.stats
-    assert c.n_mmul == st["mmul"] + st["madd"] + st["mulc"] + 2 * st["mul2"] == 1071     # Montgomery products per witness
+    # field multiplications per witness: 81 S-boxes x 3 products (2 Montgomery products each) + 65 x 9 MDS products
+    assert c.n_mmul == st["mmul"] + st["madd"] + st["mulc"] + 2 * st["mul2"] + st["linsum_terms"] == 1071
     c.close()
     with pytest.raises(rt.CwError):
         rt.Circuit(str(tmp_path / "missing.cwt"))
