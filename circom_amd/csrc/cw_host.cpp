@@ -183,6 +183,7 @@ struct HashEntry {
 
 struct Variant {               // one lowering of the schedule for a given strand count
     uint32_t n_strands = 1, n_tslots = 0, n_lds = 0;
+    bool wide_linsum = false;      // schedule dominated by long small-coefficient sums -> 4 operand loads in flight
     std::vector<CwRow> rows;
     std::vector<uint32_t> stream_off, extras, extra_off, term_off, terms;   // terms: 4 x u32 each
 };
@@ -315,7 +316,7 @@ static int load_tape(cw_circuit *c, const char *path) {
         off += (size_t)nterms * 16;
         if (var.term_off[var.n_strands] + 4 != nterms) return fail(CW_EIO, "tape variant: bad term offsets");
         {   // DOTC terms must index the limb-form constant table
-            size_t tpos = 0;
+            size_t tpos = 0, lin_terms = 0;
             for (auto &r : var.rows) {
                 uint32_t op = r.w0 & 0xFF;
                 if (op == D_LINSUM || op == D_DOTC) {
@@ -323,9 +324,11 @@ static int load_tape(cw_circuit *c, const char *path) {
                     if (op == D_DOTC)
                         for (uint32_t t = 0; t < r.a; t++)
                             if (var.terms[(tpos + t) * 4 + 2] >= n_lconsts) return fail(CW_EIO, "tape variant: bad constant index");
+                    if (op == D_LINSUM) lin_terms += r.a;
                     tpos += r.a;
                 }
             }
+            var.wide_linsum = lin_terms * 4 > (size_t)nrows;        // more than a quarter of a term per row on average
         }
         if (var.extra_off[var.n_strands] + 4 != nextras) return fail(CW_EIO, "tape variant: bad extra offsets");
         if (var.stream_off[var.n_strands] != nrows) return fail(CW_EIO, "tape variant: bad stream offsets");
@@ -1060,7 +1063,7 @@ extern "C" int cw_run(cw_batch *b) {
     const void *in = b->ext_in ? b->ext_in : b->d_in;
     HIPCHK(cwk_init(b->stream, b->d_V, b->Bp, b->d_status, b->d_first_bad));
     HIPCHK(cwk_ingest(b->stream, in, b->d_V, c->input_start, c->n_inputs, b->batch, b->Bp));
-    HIPCHK(cwk_eval(b->stream, c->need_full, b->d_rows, b->d_stream_off, b->d_extras, b->d_extra_off, b->d_terms,
+    HIPCHK(cwk_eval(b->stream, c->need_full, b->var->wide_linsum, b->d_rows, b->d_stream_off, b->d_extras, b->d_extra_off, b->d_terms,
                     b->d_term_off, b->var->n_strands, b->var->n_lds, b->d_V, b->d_consts, b->d_lconsts, b->Bp, b->batch,
                     b->d_status, c->P));
     b->ran = true;

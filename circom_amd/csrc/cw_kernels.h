@@ -7,10 +7,10 @@
 hipError_t cwk_init(hipStream_t s, void *V, uint32_t Bp, uint32_t *status, uint32_t *first_bad);
 hipError_t cwk_ingest(hipStream_t s, const void *in, void *V, uint32_t input_start, uint32_t n_in, uint32_t batch,
                       uint32_t Bp);
-hipError_t cwk_eval(hipStream_t s, bool full, const CwDRow *rows, const uint32_t *stream_off, const uint64_t *extras,
-                    const uint32_t *extra_off, const uint64_t *terms, const uint32_t *term_off, uint32_t n_strands,
-                    uint32_t n_lds, void *V, const uint32_t *consts, const uint32_t *lconsts, uint32_t Bp, uint32_t batch,
-                    uint32_t *status, const FpParams &P);
+hipError_t cwk_eval(hipStream_t s, bool full, bool wide_linsum, const CwDRow *rows, const uint32_t *stream_off,
+                    const uint64_t *extras, const uint32_t *extra_off, const uint64_t *terms, const uint32_t *term_off,
+                    uint32_t n_strands, uint32_t n_lds, void *V, const uint32_t *consts, const uint32_t *lconsts,
+                    uint32_t Bp, uint32_t batch, uint32_t *status, const FpParams &P);
 hipError_t cwk_r1cs(hipStream_t s, const uint32_t *ptr, const uint32_t *tslot, const uint32_t *tcoef, const uint32_t *ctab,
                     const uint32_t *orig, uint32_t n_cons, uint32_t rows_per_block, const void *V, uint32_t Bp,
                     uint32_t batch, uint32_t *status, uint32_t *first_bad, const FpParams &P);

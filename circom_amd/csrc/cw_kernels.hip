@@ -174,19 +174,31 @@ __device__ __forceinline__ void linsum_term(const fe &xc, uint64_t cf, fe &g, Ac
         g = cneg ? fe_sub(g, p, P) : fe_add(g, p, P);
     }
 }
-// Terms are processed two at a time: one scalar load brings the two table entries, both operand loads are in
-// flight together, then the products are accumulated.  The entry past the row's last term (the table is padded)
-// is neutralised by a zero coefficient.
+// Terms are processed W at a time (W = 2 or 4): one scalar load brings the table entries, the W operand loads are in
+// flight together (memory-level parallelism), then the products are accumulated.  Entries past the row's last
+// term (the table is padded by 4) are neutralised by a zero coefficient.  W = 4 costs 16 more live registers: it is
+// used for schedules dominated by long small-coefficient sums (bit-level circuits), W = 2 otherwise.
+template <int W>
 __device__ __forceinline__ fe eval_linsum(uint32_t n, const fe &c0, const fe &prev, EvalCtx &c, const FpParams &P) {
     fe g = c0;
     Acc192 pos = {0, 0, 0}, neg = {0, 0, 0};
     const uint64_t *tt = c.terms + (size_t)c.tp * 2;
-    for (uint32_t k = 0; k < n; k += 2) {
+    for (uint32_t k = 0; k < n; k += W) {
         const uint64_t a0 = tt[2 * k], c0_ = tt[2 * k + 1], a1 = tt[2 * k + 2], c1 = tt[2 * k + 3];
         const fe x0 = term_load(a0, prev, c);
         const fe x1 = term_load(a1, prev, c);
-        linsum_term(x0, c0_, g, pos, neg, P);
-        linsum_term(x1, k + 1 < n ? c1 : 0, g, pos, neg, P);
+        if (W == 4) {
+            const uint64_t a2 = tt[2 * k + 4], c2 = tt[2 * k + 5], a3 = tt[2 * k + 6], c3 = tt[2 * k + 7];
+            const fe x2 = term_load(a2, prev, c);
+            const fe x3 = term_load(a3, prev, c);
+            linsum_term(x0, c0_, g, pos, neg, P);
+            linsum_term(x1, k + 1 < n ? c1 : 0, g, pos, neg, P);
+            linsum_term(x2, k + 2 < n ? c2 : 0, g, pos, neg, P);
+            linsum_term(x3, k + 3 < n ? c3 : 0, g, pos, neg, P);
+        } else {
+            linsum_term(x0, c0_, g, pos, neg, P);
+            linsum_term(x1, k + 1 < n ? c1 : 0, g, pos, neg, P);
+        }
     }
     c.tp += n;
     g = fe_add(g, acc192_to_fe(pos), P);
@@ -219,7 +231,7 @@ __device__ __forceinline__ fe eval_dotc(uint32_t n, const fe &c0, const fe &prev
 
 // One interpreter step: executes `row` with operands (xa, xb) while the operands of `nrow` are requested into
 // (ya, yb).  The loop calls it twice per iteration with the two register sets swapped (no rotation moves).
-template <bool FULL_OPS>
+template <bool FULL_OPS, int LW>
 __device__ __forceinline__ void eval_step(const CwDRow &row, const fe &xa, const fe &xb, const CwDRow &nrow, fe &ya,
                                           fe &yb, fe &prev, uint64_t &selmask, uint32_t &st, uint32_t r,
                                           const uint64_t *__restrict__ extras, uint32_t &xp, EvalCtx &c,
@@ -269,7 +281,7 @@ __device__ __forceinline__ void eval_step(const CwDRow &row, const fe &xa, const
         if (op == D_MADDC) d = fe_add(d, prev, P);
         break;
     }
-    case D_LINSUM: d = eval_linsum(row.aux, bk == K_CONST ? b : fe_zero(), prev, c, P); break;
+    case D_LINSUM: d = eval_linsum<LW>(row.aux, bk == K_CONST ? b : fe_zero(), prev, c, P); break;
     case D_DOTC: d = eval_dotc(row.aux, bk == K_CONST ? b : fe_zero(), prev, c, P); break;
     case D_BIT: {                                                    // (a >> k) & 1, k = row.aux (wave-uniform)
         const uint32_t k = row.aux, w = k >> 5;
@@ -363,7 +375,7 @@ __device__ __forceinline__ void eval_step(const CwDRow &row, const fe &xa, const
 //  * a LIGHT barrier only orders LDS traffic; only FULL barriers (hand-off through global memory) drain vmcnt;
 //  * products of small signed values take the per-wave short path (fp256.hip.h).
 // FULL_OPS selects the variant that also carries the slow-path operators (INV/IDIV/MOD/POW).
-template <bool FULL_OPS>
+template <bool FULL_OPS, int LW>
 __global__ void __launch_bounds__(1024)
 cw_eval_kernel(const CwDRow *__restrict__ rows, const uint32_t *__restrict__ stream_off,
                const uint64_t *__restrict__ extras, const uint32_t *__restrict__ extra_off,
@@ -394,9 +406,9 @@ cw_eval_kernel(const CwDRow *__restrict__ rows, const uint32_t *__restrict__ str
     fe a1, b1;
     while (r < end) {
         CwDRow r2 = rows[r + 2];
-        eval_step<FULL_OPS>(r0, a0, b0, r1, a1, b1, prev, selmask, st, r, extras, xp, c, P);
+        eval_step<FULL_OPS, LW>(r0, a0, b0, r1, a1, b1, prev, selmask, st, r, extras, xp, c, P);
         r0 = rows[r + 3];
-        eval_step<FULL_OPS>(r1, a1, b1, r2, a0, b0, prev, selmask, st, r + 1, extras, xp, c, P);
+        eval_step<FULL_OPS, LW>(r1, a1, b1, r2, a0, b0, prev, selmask, st, r + 1, extras, xp, c, P);
         r1 = r0;
         r0 = r2;
         r += 2;
@@ -550,23 +562,23 @@ hipError_t cwk_ingest(hipStream_t s, const void *in, void *V, uint32_t input_sta
                        Bp);
     return hipGetLastError();
 }
-hipError_t cwk_eval(hipStream_t s, bool full, const CwDRow *rows, const uint32_t *stream_off, const uint64_t *extras,
-                    const uint32_t *extra_off, const uint64_t *terms, const uint32_t *term_off, uint32_t n_strands,
-                    uint32_t n_lds, void *V, const uint32_t *consts, const uint32_t *lconsts, uint32_t Bp, uint32_t batch,
-                    uint32_t *status, const FpParams &P) {
+hipError_t cwk_eval(hipStream_t s, bool full, bool wide_linsum, const CwDRow *rows, const uint32_t *stream_off,
+                    const uint64_t *extras, const uint32_t *extra_off, const uint64_t *terms, const uint32_t *term_off,
+                    uint32_t n_strands, uint32_t n_lds, void *V, const uint32_t *consts, const uint32_t *lconsts,
+                    uint32_t Bp, uint32_t batch, uint32_t *status, const FpParams &P) {
     dim3 grid((batch + 63) / 64), block(64 * n_strands);
     const size_t lds_bytes = (size_t)n_lds * 2048;
+    typedef void (*kern_t)(const CwDRow *, const uint32_t *, const uint64_t *, const uint32_t *, const uint64_t *,
+                           const uint32_t *, uint4 *, const uint32_t *, const uint32_t *, uint32_t, uint32_t, uint32_t *,
+                           FpParams);
+    kern_t k = full ? (wide_linsum ? (kern_t)cw_eval_kernel<true, 4> : (kern_t)cw_eval_kernel<true, 2>)
+                    : (wide_linsum ? (kern_t)cw_eval_kernel<false, 4> : (kern_t)cw_eval_kernel<false, 2>);
     if (lds_bytes > 64 * 1024) {
-        hipError_t e = full ? hipFuncSetAttribute((const void *)cw_eval_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
-                            : hipFuncSetAttribute((const void *)cw_eval_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
-    if (full)
-        hipLaunchKernelGGL(cw_eval_kernel<true>, grid, block, lds_bytes, s, rows, stream_off, extras, extra_off, terms,
-                           term_off, (uint4 *)V, consts, lconsts, Bp, batch, status, P);
-    else
-        hipLaunchKernelGGL(cw_eval_kernel<false>, grid, block, lds_bytes, s, rows, stream_off, extras, extra_off, terms,
-                           term_off, (uint4 *)V, consts, lconsts, Bp, batch, status, P);
+    hipLaunchKernelGGL(k, grid, block, lds_bytes, s, rows, stream_off, extras, extra_off, terms, term_off, (uint4 *)V,
+                       consts, lconsts, Bp, batch, status, P);
     return hipGetLastError();
 }
 hipError_t cwk_r1cs(hipStream_t s, const uint32_t *ptr, const uint32_t *tslot, const uint32_t *tcoef, const uint32_t *ctab,
