@@ -418,8 +418,8 @@ static int load_r1cs(cw_circuit *c, const char *path) {
     c->n_constraints = n_cons;
     c->r_ptr.assign(1, 0);
     c->r_ptr.reserve((size_t)n_cons * 3 + 1);
-    // coefficient table: id 0 = +1, id 1 = -1, others = c*R' mod q as 9 x 29-bit limbs (12 words per entry)
-    c->r_ctab.assign(24, 0);
+    // coefficient table: id 0 = +1, id 1 = -1, others = c*R mod q
+    c->r_ctab.assign(16, 0);
     U256 one{{1, 0, 0, 0}}, minus1;
     u256_sub(minus1, c->q, one);
     std::map<std::array<uint64_t, 4>, uint32_t> cid;
@@ -445,17 +445,11 @@ static int load_r1cs(cw_circuit *c, const char *path) {
                     std::array<uint64_t, 4> key{co.w[0], co.w[1], co.w[2], co.w[3]};
                     auto it = cid.find(key);
                     if (it == cid.end()) {
-                        id = (uint32_t)(c->r_ctab.size() / 12);
+                        id = (uint32_t)(c->r_ctab.size() / 8);
                         U256 cm = shlmod(co, CW_RBITS, c->q);
-                        uint64_t w5[5] = {cm.w[0], cm.w[1], cm.w[2], cm.w[3], 0};
-                        uint32_t limbs[12] = {0};
-                        for (int l = 0; l < 9; l++) {
-                            unsigned bit = 29 * l, wi = bit / 64, sh = bit % 64;
-                            uint64_t v = w5[wi] >> sh;
-                            if (sh > 35) v |= w5[wi + 1] << (64 - sh);
-                            limbs[l] = (uint32_t)(v & 0x1FFFFFFFu);
-                        }
-                        c->r_ctab.insert(c->r_ctab.end(), limbs, limbs + 12);
+                        uint32_t limbs[8];
+                        memcpy(limbs, cm.w, 32);
+                        c->r_ctab.insert(c->r_ctab.end(), limbs, limbs + 8);
                         cid[key] = id;
                     } else id = it->second;
                 }

@@ -427,27 +427,14 @@ cw_eval_kernel(const CwDRow *__restrict__ rows, const uint32_t *__restrict__ str
 __device__ __forceinline__ fe r1cs_dot(const uint32_t *__restrict__ tslot, const uint32_t *__restrict__ tcoef,
                                        const uint32_t *__restrict__ ctab, uint32_t t0, uint32_t t1, const uint4 *V,
                                        uint32_t Bp, uint32_t i, const FpParams &P) {
-    // +-1 coefficients: modular add/sub.  Other coefficients (ctab = c*R' as 29-bit limbs): the unreduced limb
-    // products of up to 4 terms share one Montgomery reduction (same scheme as D_DOTC in the evaluation kernel).
     fe s = fe_zero();
-    uint64_t acc[18];
-    for (int j = 0; j < 18; j++) acc[j] = 0;
-    uint32_t pending = 0;
     for (uint32_t t = t0; t < t1; t++) {
         const fe w = v_load(V, tslot[t], Bp, i);
         const uint32_t ci = tcoef[t];
         if (ci == 0) s = fe_add(s, w, P);
         else if (ci == 1) s = fe_sub(s, w, P);
-        else {
-            fe29_mac(acc, fe_to29(w), ctab + (size_t)ci * 12);
-            if (++pending == 4) {
-                s = fe_add(s, fe_from29(fe29_reduce(acc, P)), P);
-                for (int j = 0; j < 18; j++) acc[j] = 0;
-                pending = 0;
-            }
-        }
+        else s = fe_add(s, fe_mmul(w, c_load(ctab, ci), P), P);
     }
-    if (pending) s = fe_add(s, fe_from29(fe29_reduce(acc, P)), P);
     return s;
 }
 
