@@ -382,7 +382,10 @@ cw_eval_kernel(const CwDRow *__restrict__ rows, const uint32_t *__restrict__ str
                const uint64_t *__restrict__ terms, const uint32_t *__restrict__ term_off, uint4 *V,
                const uint32_t *__restrict__ consts, const uint32_t *__restrict__ lconsts, uint32_t Bp, uint32_t batch,
                uint32_t *status, FpParams P) {
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // strand executed by this wave: rotated by the workgroup index, so that the strand carrying the critical chain
+    // (the same one in every workgroup) does not land on the same SIMD of the CU in all co-resident workgroups
+    const uint32_t nstr = blockDim.x >> 6;
+    const uint32_t wave = (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) + blockIdx.x) % nstr;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t i = blockIdx.x * 64 + lane;                     // < Bp (Bp is a multiple of 256 >= batch)
     EvalCtx c;
