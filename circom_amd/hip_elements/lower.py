@@ -80,7 +80,7 @@ _DIRECT = {O.COPY: D_COPY, O.ADD: D_ADD, O.SUB: D_SUB, O.NEG: D_NEG, O.IDIV: D_I
            O.POW: D_POW, O.SHL: D_SHL, O.SHR: D_SHR, O.BAND: D_BAND, O.BOR: D_BOR, O.BXOR: D_BXOR,
            O.BNOT: D_BNOT, O.LT: D_LT, O.GT: D_GT, O.LEQ: D_LEQ, O.GEQ: D_GEQ, O.EQ: D_EQ, O.NEQ: D_NEQ,
            O.LAND: D_LAND, O.LOR: D_LOR, O.LNOT: D_LNOT, O.ASSERT_EQ: D_ASSERT_EQ, O.ASSERT_NZ: D_ASSERT_NZ}
-_COST = {D_MMUL: 10.0, D_MUL2: 19.0, D_MADD: 11.0, D_MULC: 10.0, D_MADDC: 11.0, D_DOTC: 6.0, D_INV: 4000.0, D_POW: 6000.0, D_IDIV: 8000.0, D_MOD: 8000.0}
+_COST = {D_MMUL: 10.0, D_MUL2: 20.0, D_MADD: 11.0, D_MULC: 10.0, D_MADDC: 11.0, D_INV: 4000.0, D_POW: 6000.0, D_IDIV: 8000.0, D_MOD: 8000.0}
 _NO_VALUE = (D_ASSERT_EQ, D_ASSERT_NZ, D_SELECT)
 
 
@@ -585,14 +585,29 @@ def _schedule(rows, n_signals, n_strands):
         levels[lv].append(unit)
     streams = [[] for _ in range(n_strands)]
 
-    def ucost(unit):
-        return sum(_COST.get(r.op, 1.5) + (0.5 * len(r.extra) if r.extra else 0) + (0.4 * len(r.terms) if r.terms else 0)
-                   for r in unit)
+    def ucost(unit):      # ~ VALU instructions / 32
+        c = 0.0
+        for r in unit:
+            if r.op == D_DOTC:
+                c += 5.0 + 4.5 * len(r.terms)
+            elif r.op == D_LINSUM:
+                c += 3.0 + 1.2 * len(r.terms)
+            else:
+                c += _COST.get(r.op, 2.0)
+            if r.extra:
+                c += 0.5 * len(r.extra)
+        return c
 
+    # A barrier is only needed in front of a level that reads, from ANOTHER strand, a value produced since the last
+    # barrier; levels whose cross-strand inputs are all older run on without synchronising (dependent rows of one
+    # strand simply follow each other in its stream).
+    fresh = {}          # value id -> producing strand, for values produced since the last barrier
+    n_barriers = 0
     for lv, lunits in enumerate(levels):
         total = sum(ucost(u) for u in lunits)
-        cap = total / n_strands * AFFINITY_SLACK + 10.0
+        cap = total / n_strands * AFFINITY_SLACK + 4.0
         load = [0.0] * n_strands
+        placed = []
         for unit in lunits:
             cost = ucost(unit)
             # affinity: the strand that produced most of the unit's operands (most recent level first) keeps the
@@ -613,15 +628,26 @@ def _schedule(rows, n_signals, n_strands):
             if pref is None:
                 pref = min(range(n_strands), key=load.__getitem__)
             load[pref] += cost
+            placed.append((unit, pref))
+        need = False
+        for unit, pref in placed:
+            for r in unit:
+                for k, v in _value_operands(r):
+                    if (k == K_SIG or k == K_TMP) and fresh.get(vid(k, v), pref) != pref:
+                        need = True
+        if need:
+            for st in streams:
+                st.append("B")
+            fresh.clear()
+            n_barriers += 1
+        for unit, pref in placed:
             for r in unit:
                 r.strand = pref
                 streams[pref].append(r)
                 if r.dk in (K_SIG, K_TMP):
                     prod_strand[vid(r.dk, r.dv)] = pref
-        if lv + 1 < len(levels):
-            for st in streams:
-                st.append("B")
-    return streams, len(levels) - 1
+                    fresh[vid(r.dk, r.dv)] = pref
+    return streams, n_barriers
 
 
 FULL_PERIOD = 8        # every FULL_PERIOD-th barrier also drains global stores
