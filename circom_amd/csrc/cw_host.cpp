@@ -16,6 +16,7 @@
 
 #include "../../include/circom_amd.h"
 #include "cw_kernels.h"
+#include "cw_r1cs_plan.h"
 
 typedef unsigned __int128 u128;
 
@@ -439,19 +440,21 @@ static int load_r1cs(cw_circuit *c, const char *path) {
                 p += 36;
                 if (wire >= n_wires) return fail(CW_EIO, "r1cs wire id out of range");
                 uint32_t id;
+                const bool on_one = (c->w2s[wire] == 0);           // the constant-1 wire: coefficient * 1 needs no multiply
                 if (u256_cmp(co, one) == 0) id = 0;
                 else if (u256_cmp(co, minus1) == 0) id = 1;
                 else {
-                    std::array<uint64_t, 4> key{co.w[0], co.w[1], co.w[2], co.w[3]};
+                    std::array<uint64_t, 4> key{co.w[0], co.w[1], co.w[2], co.w[3] ^ (on_one ? (1ull << 63) : 0)};
                     auto it = cid.find(key);
                     if (it == cid.end()) {
                         id = (uint32_t)(c->r_ctab.size() / 8);
-                        U256 cm = shlmod(co, CW_RBITS, c->q);
+                        U256 cm = on_one ? co : shlmod(co, CW_RBITS, c->q);
                         uint32_t limbs[8];
                         memcpy(limbs, cm.w, 32);
                         c->r_ctab.insert(c->r_ctab.end(), limbs, limbs + 8);
                         cid[key] = id;
                     } else id = it->second;
+                    if (on_one) id |= cwplan::COEF_CONST;
                 }
                 c->r_slot.push_back(c->w2s[wire]);     // wire id = witness position -> value slot
                 c->r_coef.push_back(id);
@@ -556,6 +559,34 @@ extern "C" int64_t cw_input_size(const cw_circuit *c, const char *name, uint32_t
     return (int64_t)c->hashmap[p].signalsize;
 }
 
+// Staging plan parameters of the R1CS check for a batch: enough (instance group x chunk) workgroups for ~3
+// rounds over the chip at the occupancy the LDS entries leave (160 KB / (entries x 2 KiB) waves per CU).
+static void r1cs_plan_defaults(uint32_t batch, uint32_t *chunks, uint32_t *entries) {
+    uint32_t e = 10;
+    if (const char *s = getenv("CW_R1CS_ENTRIES")) e = (uint32_t)std::max(1, atoi(s));
+    e = std::min<uint32_t>(std::max<uint32_t>(e, cwplan::DEPTH + 2), 64);
+    uint64_t groups = ((uint64_t)batch + 63) / 64;
+    uint32_t ch = (uint32_t)std::max<uint64_t>(1, (6144 + groups - 1) / groups);
+    if (const char *s = getenv("CW_R1CS_CHUNKS")) ch = (uint32_t)std::max(1, atoi(s));
+    *chunks = ch;
+    *entries = e;
+}
+
+extern "C" int cw_r1cs_plan_stats(const cw_circuit *c, uint32_t batch, uint32_t chunks, uint32_t entries, uint64_t out[8]) {
+    if (!c || !out) return fail(CW_EINVAL, "null argument");
+    if (c->n_constraints == 0) return fail(CW_ESTATE, "no .r1cs was loaded for this circuit");
+    uint32_t dc, de;
+    r1cs_plan_defaults(batch ? batch : 65536, &dc, &de);
+    if (!chunks) chunks = dc;
+    if (!entries) entries = de;
+    cwplan::Plan p = cwplan::build(c->r_ptr, c->r_slot, c->r_coef, c->r_orig, c->n_signals, chunks, entries);
+    std::string err = cwplan::verify(p, c->r_slot);
+    if (!err.empty()) return fail(CW_ESTATE, ("r1cs plan: " + err).c_str());
+    uint64_t v[8] = {p.n_chunks, p.n_loads, p.n_terms, p.n_filler, p.n_unique, p.entries, cwplan::DEPTH, 0};
+    memcpy(out, v, sizeof v);
+    return CW_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // batch
 // ---------------------------------------------------------------------------------------------------------
@@ -573,7 +604,9 @@ struct cw_batch {
     uint32_t *d_term_off = nullptr;
     uint32_t *d_lconsts = nullptr;
     uint32_t *d_consts = nullptr, *d_w2s = nullptr, *d_status = nullptr, *d_first_bad = nullptr;
-    uint32_t *d_rptr = nullptr, *d_rslot = nullptr, *d_rcoef = nullptr, *d_rctab = nullptr, *d_rorig = nullptr;
+    // R1CS check plan (cw_r1cs_plan.h) on the device; r1_entries != 0 selects the LDS-staged kernel
+    uint32_t *d_rctab = nullptr, *d_pchunk = nullptr, *d_prec = nullptr, *d_pterms = nullptr, *d_prow = nullptr;
+    uint32_t r1_chunks = 0, r1_entries = 0;
     void *d_in = nullptr;          // AoS staging [batch][n_in][32]
     void *d_gather = nullptr;      // [n_witness][32]
     const void *ext_in = nullptr;  // caller-owned device inputs (cw_set_inputs_device)
@@ -602,7 +635,8 @@ extern "C" void cw_batch_free(cw_batch *b) {
     hipSetDevice(b->device);
     hipStreamSynchronize(b->stream);
     void *ptrs[] = {b->d_V, b->d_rows, b->d_stream_off, b->d_extras, b->d_extra_off, b->d_terms, b->d_term_off, b->d_lconsts, b->d_consts, b->d_w2s, b->d_status, b->d_first_bad,
-                    b->d_rptr, b->d_rslot, b->d_rcoef, b->d_rctab, b->d_rorig, b->d_in, b->d_gather};
+                    b->d_rctab, b->d_pchunk, b->d_prec, b->d_pterms, b->d_prow,
+                    b->d_in, b->d_gather};
     for (void *p : ptrs)
         if (p) hipFree(p);
     delete b;
@@ -633,10 +667,11 @@ extern "C" int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *
     b->Bp = (batch + 255) / 256 * 256;
     b->stream = (hipStream_t)stream;
     // pick the schedule variant: as many strands as it takes to put >= ~4 waves on every SIMD (1024 SIMDs),
-    // but no more (barriers are not free).  CW_STRANDS overrides.
+    // but no more (barriers are not free).  Measured crossover on Poseidon(2): S=4 wins up to 2048 groups,
+    // S=1 from 4096 groups on.  CW_STRANDS overrides.
     {
         uint64_t groups = (batch + 63) / 64;
-        uint32_t want = (uint32_t)std::max<uint64_t>(1, 4096 / groups);
+        uint32_t want = (uint32_t)std::max<uint64_t>(1, 8192 / groups);
         if (const char *e = getenv("CW_STRANDS")) want = (uint32_t)std::max(1, atoi(e));
         const Variant *best = &c->variants[0];
         for (auto &v : c->variants) {
@@ -755,11 +790,25 @@ extern "C" int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *
     TRY(hipMalloc((void **)&b->d_status, (size_t)b->Bp * 4));
     TRY(hipMalloc((void **)&b->d_first_bad, (size_t)b->Bp * 4));
     if (c->n_constraints) {
-        TRY(upload(&b->d_rptr, c->r_ptr, b->stream));
-        TRY(upload(&b->d_rslot, c->r_slot, b->stream));
-        TRY(upload(&b->d_rcoef, c->r_coef, b->stream));
         TRY(upload(&b->d_rctab, c->r_ctab, b->stream));
-        TRY(upload(&b->d_rorig, c->r_orig, b->stream));
+        const char *mode = getenv("CW_R1CS_MODE");
+        cwplan::Plan p;
+        if (mode && !strcmp(mode, "staged")) {
+            uint32_t chunks, entries;
+            r1cs_plan_defaults(batch, &chunks, &entries);
+            p = cwplan::build(c->r_ptr, c->r_slot, c->r_coef, c->r_orig, c->n_signals, chunks, entries);
+            TRY(upload(&b->d_prec, p.rec, b->stream));
+            b->r1_entries = p.entries;
+        } else {
+            uint32_t tpc = 192;
+            if (const char *e = getenv("CW_R1CS_TERMS")) tpc = (uint32_t)std::max(8, atoi(e));
+            p = cwplan::build_stream(c->r_ptr, c->r_slot, c->r_coef, c->r_orig, tpc);
+        }
+        TRY(upload(&b->d_pchunk, p.chunk, b->stream));
+        TRY(upload(&b->d_pterms, p.terms, b->stream));
+        TRY(upload(&b->d_prow, p.row_orig, b->stream));
+        TRY(hipStreamSynchronize(b->stream));                        // the plan goes out of scope
+        b->r1_chunks = p.n_chunks;
     }
     TRY(hipMalloc(&b->d_in, std::max<size_t>((size_t)batch * c->n_inputs * 32, 32)));
     TRY(hipMalloc(&b->d_gather, std::max<size_t>((size_t)c->n_witness * 32, 32)));
@@ -1077,9 +1126,12 @@ extern "C" int cw_check_r1cs(cw_batch *b) {
     if (!b->ran) return fail(CW_ESTATE, "cw_check_r1cs before cw_run");
     if (c->n_constraints == 0) return fail(CW_ESTATE, "no .r1cs was loaded for this circuit");
     HIPCHK(hipSetDevice(b->device));
-    uint32_t rows_per_block = 64;
-    HIPCHK(cwk_r1cs(b->stream, b->d_rptr, b->d_rslot, b->d_rcoef, b->d_rctab, b->d_rorig, c->n_constraints,
-                    rows_per_block, b->d_V, b->Bp, b->batch, b->d_status, b->d_first_bad, c->P));
+    if (b->r1_entries)
+        HIPCHK(cwk_r1cs_staged(b->stream, b->d_pchunk, b->r1_chunks, b->d_prec, b->d_pterms, b->d_rctab, b->d_prow,
+                               b->r1_entries, b->d_V, b->Bp, b->batch, b->d_status, b->d_first_bad, c->P));
+    else
+        HIPCHK(cwk_r1cs(b->stream, b->d_pchunk, b->r1_chunks, b->d_pterms, b->d_rctab, b->d_prow, b->d_V, b->Bp, b->batch,
+                        b->d_status, b->d_first_bad, c->P));
     return CW_OK;
 }
 

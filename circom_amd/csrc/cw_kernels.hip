@@ -420,57 +420,150 @@ cw_eval_kernel(const CwDRow *__restrict__ rows, const uint32_t *__restrict__ str
 }
 
 // ---- R1CS check:  (A.w) * (B.w) == C.w  for every constraint row and instance ---------------------------
-// One wave = 64 instances x one chunk of constraint rows (uniform control flow, term tables through scalar
-// loads).  Terms are CSR: for row c the A/B/C term ranges are ptr[3c..3c+3]; each term = (value slot,
-// coefficient id).  Coefficient ids 0/1 mean +1/-1 (add/sub); others index ctab, which holds c*R' mod q so
-// that one MMUL gives w*c on canonical w.  The host orders the rows by the time their youngest wire is
-// produced by the schedule (temporal locality: a wire is re-read while still in L2) and tags pure
+// One single-wave workgroup = 64 instances x one chunk of constraint rows (uniform control flow).  The host
+// flattens the rows into a term stream (cw_r1cs_plan.h): word 0 = value slot | accumulator (A/B/C) | row-end
+// kind, word 1 = coefficient id.  Coefficient ids 0/1 mean +1/-1 (add/sub); other ids index ctab, which holds
+// c*R' mod q so that one MMUL gives w*c on canonical w; a term on the constant-1 wire carries the canonical
+// coefficient instead and costs no multiplication.  The host orders the rows by the time their youngest wire
+// is produced by the schedule (temporal locality: a wire is re-read while still in L2) and marks pure
 // equalities x - y = 0 (component wiring, ~75 % of the rows at --O0), which are checked by comparison.
-// `orig` maps the processing order back to the constraint index of the .r1cs file for reporting.
-__device__ __forceinline__ fe r1cs_dot(const uint32_t *__restrict__ tslot, const uint32_t *__restrict__ tcoef,
-                                       const uint32_t *__restrict__ ctab, uint32_t t0, uint32_t t1, const uint4 *V,
-                                       uint32_t Bp, uint32_t i, const FpParams &P) {
-    fe s = fe_zero();
-    for (uint32_t t = t0; t < t1; t++) {
-        const fe w = v_load(V, tslot[t], Bp, i);
-        const uint32_t ci = tcoef[t];
-        if (ci == 0) s = fe_add(s, w, P);
-        else if (ci == 1) s = fe_sub(s, w, P);
-        else s = fe_add(s, fe_mmul(w, c_load(ctab, ci), P), P);
+// Terms are scalar-loaded and their wires fetched one term ahead of use, so a wave keeps two value loads in
+// flight.  `row_orig` maps the processing order back to the constraint index of the .r1cs file.
+// `cur` accumulates the part (A, B or C) being read; the last term of A or B (bit 31) files it under its name,
+// C stays in `cur`.  Written with selects so that A/B stay in registers (an `if (part == ..)` ladder over
+// three accumulators is turned into an indexed stack array).
+struct R1State {
+    fe A, B, cur;
+    uint32_t row, bad;
+};
+__device__ __forceinline__ fe fe_pick(bool c, const fe &a, const fe &b) {
+    fe r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) r.v[k] = c ? a.v[k] : b.v[k];
+    return r;
+}
+__device__ __forceinline__ void r1_term(const fe &wv, uint32_t w0, uint32_t ci, R1State &s,
+                                        const uint32_t *__restrict__ ctab, const uint32_t *__restrict__ row_orig,
+                                        const FpParams &P) {
+    const uint32_t acc = (w0 >> 27) & 3u, endk = (w0 >> 29) & 3u;
+    bool ok = true;
+    if (endk == 3) ok = fe_eq(s.cur, wv);                           // second wire of a pure equality row: x == y
+    else if (acc == 3) s.cur = wv;                                  // its first wire
+    else {
+        fe w = wv;
+        if (ci >> 31) w = c_load(ctab, ci & 0x7FFFFFFFu);           // coefficient on the constant-1 wire
+        else if (ci >= 2) w = fe_mmul(w, c_load(ctab, ci), P);
+        s.cur = (ci == 1) ? fe_sub(s.cur, w, P) : fe_add(s.cur, w, P);
+        if ((w0 >> 31) && acc != 2) {                               // last term of part A or B
+            s.A = fe_pick(acc == 0, s.cur, s.A);
+            s.B = fe_pick(acc == 1, s.cur, s.B);
+            s.cur = fe_zero();
+        }
+        if (endk == 2) ok = fe_is_zero(s.cur);                      // A or B empty: linear row, C must vanish
+        else if (endk == 1) ok = fe_eq(fe_mmul(s.A, s.B, P), fe_mmul(s.cur, fe_small(1), P));   // A*B/R' == C/R'
     }
-    return s;
+    if (endk) {
+        if (__any(!ok)) {
+            const uint32_t oc = row_orig[s.row];
+            if (!ok && oc < s.bad) s.bad = oc;
+        }
+        s.row++;
+        s.A = fe_zero(); s.B = fe_zero(); s.cur = fe_zero();
+    }
+}
+__device__ __forceinline__ void r1_finish(const R1State &s, uint32_t i, uint32_t batch, uint32_t *status, uint32_t *first_bad) {
+    if (s.bad != 0xFFFFFFFFu && i < batch) {
+        atomicMin(&first_bad[i], s.bad);
+        atomicOr(&status[i], CW_ST_R1CS_FAILED);
+    }
 }
 
 __global__ void __launch_bounds__(64)
-cw_r1cs_kernel(const uint32_t *__restrict__ ptr, const uint32_t *__restrict__ tslot, const uint32_t *__restrict__ tcoef,
-               const uint32_t *__restrict__ ctab, const uint32_t *__restrict__ orig, uint32_t n_cons,
-               uint32_t rows_per_block, const uint4 *__restrict__ V, uint32_t Bp, uint32_t batch, uint32_t *status,
-               uint32_t *first_bad, FpParams P) {
+cw_r1cs_stream_kernel(const uint4 *__restrict__ chunk, const uint2 *__restrict__ terms, const uint32_t *__restrict__ ctab,
+                      const uint32_t *__restrict__ row_orig, const uint4 *__restrict__ V, uint32_t Bp, uint32_t batch,
+                      uint32_t *status, uint32_t *first_bad, FpParams P) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;               // < Bp
-    const uint32_t c0 = blockIdx.y * rows_per_block;
-    const uint32_t c1 = min(c0 + rows_per_block, n_cons);
-    uint32_t bad = 0xFFFFFFFFu;
-    for (uint32_t c = c0; c < c1; c++) {
-        const uint32_t pa = ptr[3 * c], pb = ptr[3 * c + 1], pc = ptr[3 * c + 2], pe = ptr[3 * c + 3];
-        const uint32_t tag = orig[c];                                // bit 31: pure equality of two wires
-        bool ok;
-        if (tag >> 31) {
-            ok = fe_eq(v_load(V, tslot[pc], Bp, i), v_load(V, tslot[pc + 1], Bp, i));
-        } else if (pa == pb || pb == pc) {                           // A or B empty: linear row, C must vanish
-            ok = fe_is_zero(r1cs_dot(tslot, tcoef, ctab, pc, pe, V, Bp, i, P));
-        } else {
-            const fe A = r1cs_dot(tslot, tcoef, ctab, pa, pb, V, Bp, i, P);
-            const fe B = r1cs_dot(tslot, tcoef, ctab, pb, pc, V, Bp, i, P);
-            const fe C = r1cs_dot(tslot, tcoef, ctab, pc, pe, V, Bp, i, P);
-            ok = fe_eq(fe_mmul(A, B, P), fe_mmul(C, fe_small(1), P));   // A*B/R' == C/R'
+    const uint4 ch = chunk[blockIdx.y];                             // first term, n terms, -, first row
+    const uint2 *tp = terms + ch.x;                                 // the stream is padded: tp[n] is readable
+    R1State s;
+    s.A = fe_zero(); s.B = fe_zero(); s.cur = fe_zero();
+    s.row = ch.w; s.bad = 0xFFFFFFFFu;
+    uint2 t0 = tp[0];
+    fe w0 = v_load(V, t0.x & 0x3FFFFFFu, Bp, i);
+    // the next term's wire is in flight while this one is accumulated (two terms ahead costs 16 more VGPRs, which
+    // drops a wave per SIMD, and measured no faster)
+    for (uint32_t k = 0; k < ch.y; k++) {
+        const uint2 t1 = tp[k + 1];
+        const fe w1 = v_load(V, t1.x & 0x3FFFFFFu, Bp, i);
+        r1_term(w0, t0.x, t0.y, s, ctab, row_orig, P);
+        t0 = t1; w0 = w1;
+    }
+    r1_finish(s, i, batch, status, first_bad);
+}
+
+// ---- R1CS check, staged through LDS (plan: cw_r1cs_plan.h) -------------------------------------------------
+// One single-wave workgroup = 64 instances x one chunk of rows.  Every distinct wire of the chunk is copied
+// global -> LDS once by the LDS-DMA path (global_load_lds_dwordx4: no VGPRs, no VALU, lane-linear 1 KiB per
+// half), R1_DEPTH wires ahead of its first use; terms read LDS only.  The host chose the LDS entry of every
+// load (Belady under the in-flight hazard rule) so the kernel has no tags and no misses.  hipcc does not count
+// asm memory operations, so the wait is ours: after issuing load j+DEPTH, vmcnt(2*DEPTH) means load j landed.
+#define R1_DEPTH 4
+static_assert(R1_DEPTH == 4, "keep in sync with cwplan::DEPTH and the s_waitcnt immediate below");
+
+__device__ __forceinline__ void r1_issue(uint32_t lw, uint64_t vbase, uint64_t slot_bytes, uint64_t half_bytes,
+                                         uint32_t voff, uint32_t lds_base) {
+    const uint32_t slot = lw & 0x3FFFFFFu, e = lw >> 26;
+    const uint64_t lo = vbase + (uint64_t)slot * slot_bytes, hi = lo + half_bytes;
+    const uint32_t dlo = lds_base + e * 2048u, dhi = dlo + 1024u;
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
+                 "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(dlo), "s"(dhi), "s"(lo), "s"(hi)
+                 : "memory");
+}
+
+__global__ void __launch_bounds__(64)
+cw_r1cs_staged_kernel(const uint4 *__restrict__ chunk, const uint2 *__restrict__ rec, const uint2 *__restrict__ terms,
+                      const uint32_t *__restrict__ ctab, const uint32_t *__restrict__ row_orig,
+                      const uint4 *__restrict__ V, uint32_t Bp, uint32_t batch, uint32_t *status, uint32_t *first_bad,
+                      FpParams P) {
+    extern __shared__ uint4 r1_lds[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t i = blockIdx.x * 64 + lane;                      // < Bp
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)r1_lds;
+    const uint4 ch = chunk[blockIdx.y];                             // first record, n loads, first term, first row
+    const uint64_t vbase = (uint64_t)V + (uint64_t)blockIdx.x * 1024u;   // this group's 64 x 16 B window of a half-row
+    const uint64_t half_bytes = (uint64_t)Bp * 16u, slot_bytes = 2 * half_bytes;
+    const uint32_t voff = lane * 16u;
+    const uint2 *rp = rec + ch.x;
+#pragma unroll
+    for (int d = 0; d < R1_DEPTH; d++) r1_issue(rp[d].x, vbase, slot_bytes, half_bytes, voff, lds_base);
+    rp += R1_DEPTH;
+    const uint2 *tp = terms + ch.z;
+    R1State s;
+    s.A = fe_zero(); s.B = fe_zero(); s.cur = fe_zero();
+    s.row = ch.w; s.bad = 0xFFFFFFFFu;
+    uint2 tw = tp[0];
+    for (uint32_t j = 0; j < ch.y; j++) {
+        const uint2 r = rp[j];
+        r1_issue(r.x, vbase, slot_bytes, half_bytes, voff, lds_base);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // 2 * R1_DEPTH: load j is in LDS
+        for (uint32_t k = 0; k < r.y; k++) {
+            const uint2 nx = *++tp;                                 // next term's words while this one computes
+            const uint32_t e = tw.x & 0x3FFFFFFu;
+            const uint4 lo = r1_lds[e * 128u + lane], hi = r1_lds[e * 128u + 64u + lane];
+            fe w;
+            w.v[0] = lo.x; w.v[1] = lo.y; w.v[2] = lo.z; w.v[3] = lo.w;
+            w.v[4] = hi.x; w.v[5] = hi.y; w.v[6] = hi.z; w.v[7] = hi.w;
+            r1_term(w, tw.x, tw.y, s, ctab, row_orig, P);
+            tw = nx;
         }
-        const uint32_t oc = tag & 0x7FFFFFFFu;
-        if (!ok && oc < bad) bad = oc;
     }
-    if (bad != 0xFFFFFFFFu && i < batch) {
-        atomicMin(&first_bad[i], bad);
-        atomicOr(&status[i], CW_ST_R1CS_FAILED);
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // padding loads must not outlive the wave's LDS
+    r1_finish(s, i, batch, status, first_bad);
 }
 
 // ---- egress: one instance's witness as [n_witness][32 B] (getWitness + Fr_toLongNormal, main.cpp:326-332) ----
@@ -584,13 +677,28 @@ hipError_t cwk_eval(hipStream_t s, bool full, bool wide_linsum, const CwDRow *ro
                        consts, lconsts, Bp, batch, status, P);
     return hipGetLastError();
 }
-hipError_t cwk_r1cs(hipStream_t s, const uint32_t *ptr, const uint32_t *tslot, const uint32_t *tcoef, const uint32_t *ctab,
-                    const uint32_t *orig, uint32_t n_cons, uint32_t rows_per_block, const void *V, uint32_t Bp,
-                    uint32_t batch, uint32_t *status, uint32_t *first_bad, const FpParams &P) {
-    if (n_cons == 0) return hipSuccess;
-    dim3 g((batch + 63) / 64, (n_cons + rows_per_block - 1) / rows_per_block);
-    hipLaunchKernelGGL(cw_r1cs_kernel, g, dim3(64), 0, s, ptr, tslot, tcoef, ctab, orig, n_cons, rows_per_block,
+hipError_t cwk_r1cs(hipStream_t s, const uint32_t *chunk, uint32_t n_chunks, const uint32_t *terms, const uint32_t *ctab,
+                    const uint32_t *row_orig, const void *V, uint32_t Bp, uint32_t batch, uint32_t *status,
+                    uint32_t *first_bad, const FpParams &P) {
+    if (n_chunks == 0) return hipSuccess;
+    dim3 g((batch + 63) / 64, n_chunks);
+    hipLaunchKernelGGL(cw_r1cs_stream_kernel, g, dim3(64), 0, s, (const uint4 *)chunk, (const uint2 *)terms, ctab, row_orig,
                        (const uint4 *)V, Bp, batch, status, first_bad, P);
+    return hipGetLastError();
+}
+hipError_t cwk_r1cs_staged(hipStream_t s, const uint32_t *chunk, uint32_t n_chunks, const uint32_t *rec, const uint32_t *terms,
+                           const uint32_t *ctab, const uint32_t *row_orig, uint32_t entries, const void *V, uint32_t Bp,
+                           uint32_t batch, uint32_t *status, uint32_t *first_bad, const FpParams &P) {
+    if (n_chunks == 0) return hipSuccess;
+    const uint32_t lds_bytes = entries * 2048u;
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)cw_r1cs_staged_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    dim3 g((batch + 63) / 64, n_chunks);
+    hipLaunchKernelGGL(cw_r1cs_staged_kernel, g, dim3(64), lds_bytes, s, (const uint4 *)chunk, (const uint2 *)rec,
+                       (const uint2 *)terms, ctab, row_orig, (const uint4 *)V, Bp, batch, status, first_bad, P);
     return hipGetLastError();
 }
 hipError_t cwk_gather(hipStream_t s, const void *V, const uint32_t *w2s, uint32_t n_wit, uint32_t Bp, uint32_t instance,

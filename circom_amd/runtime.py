@@ -68,6 +68,7 @@ _SIGS = {
     "cw_get_signal": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p]),
     "cw_write_wtns": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p]),
     "cw_get_r1cs_first_bad": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cw_r1cs_plan_stats": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "cw_device_values": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "cw_fp_mul_bench": (C.c_int, [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.POINTER(C.c_float)]),
@@ -131,6 +132,13 @@ class Circuit:
         if self.h:
             lib().cw_free(self.h)
             self.h = None
+
+    def r1cs_plan_stats(self, batch: int = 65536, chunks: int = 0, entries: int = 0) -> dict:
+        """Build + hazard-check the R1CS kernel's LDS staging plan on the host (no GPU needed)."""
+        out = (C.c_uint64 * 8)()
+        _chk(lib().cw_r1cs_plan_stats(self.h, batch, chunks, entries, out))
+        keys = ("chunks", "loads", "terms", "filler_loads", "distinct_wires", "entries", "depth")
+        return dict(zip(keys, [int(x) for x in out]))
 
     def batch(self, batch: int, device: int = 0, stream=None) -> "Batch":
         return Batch(self, batch, device, stream)

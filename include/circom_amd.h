@@ -103,6 +103,10 @@ int cw_get_signal(cw_batch *b, uint32_t instance, uint32_t slot, uint8_t out[32]
 int cw_write_wtns(cw_batch *b, uint32_t instance, const char *path);
 /* first violated constraint per instance after cw_check_r1cs: [batch], 0xFFFFFFFF = none */
 int cw_get_r1cs_first_bad(cw_batch *b, uint32_t *row);
+/* host-only: build and hazard-check the LDS staging plan of the R1CS check kernel for `chunks` row chunks
+   and `entries` 2-KiB LDS entries per wave (0 = the defaults cw_batch_create would pick for `batch`).
+   out[8] = {chunks, loads, terms, filler loads, distinct wires, entries, prefetch depth, 0}. */
+int cw_r1cs_plan_stats(const cw_circuit *c, uint32_t batch, uint32_t chunks, uint32_t entries, uint64_t out[8]);
 
 /* raw device pointers for zero-copy consumers (provers): value table, layout in DESIGN.md */
 void *cw_device_values(cw_batch *b, uint64_t *n_bytes, uint32_t *padded_batch);

@@ -206,6 +206,41 @@ def test_r1cs_check_flags_a_corrupted_witness(tmp_path):
     b.close(); c.close()
 
 
+@template
+def FlakyChain(c, n):
+    # x[k+1] = x[k]^2 + b, but the witness code of link (a mod n) adds 1: every instance breaks a different row
+    a = c.input("a")
+    b = c.input("b")
+    out = c.output("out")
+    x = c.signal("x", n + 1)
+    c.set(x[0], a + b)
+    for k in range(n):
+        c.hint(x[k + 1], x[k] * x[k] + b + (a % n).eq(k))
+        c.enforce(x[k + 1], x[k] * x[k] + b, runtime_check=False)
+    c.set(out, x[n] * 3 + x[1])
+
+
+@pytest.mark.parametrize("mode", ["stream", "staged"])
+def test_r1cs_check_reports_the_first_violated_row_per_instance(tmp_path, mode, monkeypatch):
+    monkeypatch.setenv("CW_R1CS_MODE", mode)
+    monkeypatch.setenv("CW_R1CS_CHUNKS", "5")          # several chunks: the failing row moves across them
+    monkeypatch.setenv("CW_R1CS_TERMS", "40")
+    n = 100
+    cp, c = _compile(tmp_path, Program(FlakyChain(n)), "flaky")
+    B = 300
+    ins = [[i, 1000 + 7 * i] for i in range(B)]
+    b = c.batch(B)
+    b.set_inputs(ins)
+    b.run(); b.check_r1cs(); b.sync()
+    st, fb = b.status(), b.r1cs_first_bad()
+    for i in range(B):
+        w = b.witness(i)
+        want = check_r1cs(c.q, cp.flat.constraints, w)
+        assert want is not None
+        assert (st[i] & rt.ST_R1CS_FAILED) and fb[i] == want, (i, fb[i], want)
+    b.close(); c.close()
+
+
 def test_run_refuses_missing_inputs(tmp_path):
     cp, c = _compile(tmp_path, Program(Multiplier2()), "m2")
     b = c.batch(2)

@@ -10,7 +10,7 @@ from circom_amd import runtime as rt
 from bench import synth_inputs
 import os
 d=tempfile.mkdtemp()
-for name, prog, B, strands in (("poseidon2", Program(Poseidon(2)), 65536, (1,2,4,8)), ("sha256_512", Program(Sha256(512)), 4096, (8,16)), ("sha256_512", None, 8192, (8,16))):
+for name, prog, B, strands in (("poseidon2", Program(Poseidon(2)), 65536, (2,3,4,6)), ("sha256_512", Program(Sha256(512)), 4096, (8,12,16)), ("sha256_512", None, 8192, (8,16))):
     if prog is not None:
         cp=compile_program(prog, d, name, sym=False, strands=strands)
     c=rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
