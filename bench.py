@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """bench.py — witnesses/sec of the batched HIP witness calculator (see BASELINE.json).
 
+Workloads: poseidon2 (default, BASELINE configs[1]), sha256_<bits> (configs[2]), semaphore<levels> (configs[3]).
+
 A "step" = one pass of the hot path over one batch of synthetic inputs that are already resident in
 HBM: ingest (AoS -> SoA input slots) + schedule evaluation (witness generation) + R1CS check.
 Multi-GPU: one process per GPU (torch.distributed / RCCL), instances are sharded (weak scaling,
@@ -35,6 +37,9 @@ def build_workload(name: str, outdir: str):
         from circom_amd.circuits.sha256 import Sha256
         nbits = int(name.split("_")[1])
         return compile_program(Program(Sha256(nbits)), outdir, name, sym=False)
+    if name.startswith("semaphore"):
+        from circom_amd.circuits.eddsa import SemaphoreStyle
+        return compile_program(Program(SemaphoreStyle(int(name[len("semaphore"):] or 20))), outdir, name, sym=False)
     raise SystemExit("unknown workload " + name)
 
 
@@ -46,6 +51,17 @@ def synth_inputs(name: str, q: int, batch: int, n_inputs: int, seed: int):
         arr = np.zeros((batch, n_inputs, 32), dtype=np.uint8)
         arr[:, :, 0] = bits
         return arr
+    if name.startswith("semaphore"):
+        # valid EdDSA signatures + Merkle paths must be synthesised on the host: 64 distinct
+        # (key, message, signature, path) vectors, tiled over the batch (the schedule is data-independent)
+        import random
+        from circom_amd.circuits import eddsa_host as H
+        r = random.Random(seed)
+        levels = int(name[len("semaphore"):] or 20)
+        pool = [H.semaphore_inputs(q, levels, r)[0] for _ in range(min(batch, 64))]
+        one = np.frombuffer(b"".join(v.to_bytes(32, "little") for row in pool for v in row),
+                            dtype=np.uint8).reshape(len(pool), n_inputs, 32)
+        return np.ascontiguousarray(np.tile(one, ((batch + len(pool) - 1) // len(pool), 1, 1))[:batch])
     # uniform field elements: 256 random bits reduced mod q
     raw = rng.integers(0, 256, size=(batch, n_inputs, 32), dtype=np.uint8)
     vals = [int.from_bytes(raw[i, k].tobytes(), "little") % q for i in range(batch) for k in range(n_inputs)]

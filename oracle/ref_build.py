@@ -111,6 +111,14 @@ def time_reference(cp, workload: str, seconds_budget: float = 15.0):
             arr = np.zeros((n, n_in, 32), dtype=np.uint8)
             arr[:, :, 0] = rng.integers(0, 2, size=(n, n_in), dtype=np.uint8)
             return arr.tobytes()
+        if workload.startswith("semaphore"):
+            # random inputs would trip the circuit's `===` (the reference aborts): valid signatures, tiled
+            import random
+            from circom_amd.circuits import eddsa_host as H
+            r = random.Random(1)
+            pool = [b"".join(v.to_bytes(32, "little") for v in H.semaphore_inputs(q, int(workload[9:] or 20), r)[0])
+                    for _ in range(min(n, 16))]
+            return b"".join(pool[i % len(pool)] for i in range(n))
         vals = [int.from_bytes(rng.bytes(32), "little") % q for _ in range(n * n_in)]
         return b"".join(v.to_bytes(32, "little") for v in vals)
     # calibrate on one core, then size the sample to ~seconds_budget/2 of wall time on all cores
@@ -142,7 +150,8 @@ def build_default_circuits():
     from circom_amd.circuits.poseidon import Poseidon
     d = _t.mkdtemp(prefix="cw_refbuild_")
     from circom_amd.circuits.sha256 import Sha256
+    from circom_amd.circuits.eddsa import SemaphoreStyle
     for name, prog in (("multiplier2", Program(Multiplier2())), ("poseidon2", Program(Poseidon(2))),
-                       ("sha256_512", Program(Sha256(512)))):
+                       ("sha256_512", Program(Sha256(512))), ("semaphore20", Program(SemaphoreStyle(20)))):
         cp = compile_program(prog, d, name, sym=False)
         build_circuit(cp)
