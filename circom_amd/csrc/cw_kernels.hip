@@ -325,7 +325,7 @@ __device__ __forceinline__ void eval_step(const CwDRow &row, const fe &xa, const
     default:
         if (FULL_OPS) {
             switch (op) {
-            case D_INV: d = fe_pow_uniform(a, P.qm2, P); break;
+            case D_INV: d = fe_inv(a, P); break;
             case D_POW: d = fe_pow(a, b, P); break;
             case D_IDIV:
             case D_MOD: {
@@ -609,7 +609,7 @@ cw_fpop_kernel(uint32_t op, const uint4 *a_, const uint4 *b_, const uint4 *c_, u
     case D_MMUL: d = fe_mmul(a, b, P); break;
     case D_MUL2: d = fe_mul2_auto(a, b, P); break;       // includes the per-wave short path
     case D_MADD: d = fe_add(fe_mmul(a, b, P), c, P); break;
-    case D_INV: d = fe_pow_uniform(a, P.qm2, P); break;
+    case D_INV: d = fe_inv(a, P); break;
     case D_POW: d = fe_pow(a, b, P); break;
     case D_IDIV:
     case D_MOD: {

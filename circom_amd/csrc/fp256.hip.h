@@ -407,16 +407,142 @@ __device__ __forceinline__ bool fe_lt(const fe &x, const fe &y, const FpParams &
 }
 
 // ---- slow-path operators (only in the "full" kernel) -----------------------------------------
-// x^e for a wave-uniform exponent e (8 limbs), x canonical -> canonical.  Used for INV = x^(q-2)
-// (mpz_invert semantics incl. inv(0) = 0: generic/fr.cpp:2895-2906).
-__device__ __noinline__ fe fe_pow_uniform(const fe &x, const uint32_t *e, const FpParams &P) {
-    const fe29 xm = fe29_mmul(fe_to29(x), fe_to29(fe_from(P.r2)), P);      // to Montgomery
-    fe29 r = fe_to29(fe_from(P.one_m));
-    for (int i = 255; i >= 0; i--) {
-        r = fe29_mmul(r, r, P);
-        if ((e[i >> 5] >> (i & 31)) & 1) r = fe29_mmul(r, xm, P);
+// Modular inverse, canonical -> canonical, inv(0) = 0 (Fr_inv -> mpz_invert, generic/fr.cpp:2895-2906).
+// Lanes cannot branch independently without serialising the wave, so this is a constant-time binary extended
+// GCD in the style of Pornin's "Optimized Binary GCD for Modular Inversion": INV_K = 30 halving steps at a
+// time run on 64-bit approximations of (a, b) (low 30 bits exact + top 34 bits of the longer one) and yield
+// update factors |f| + |g| <= 2^30, which are then applied to the full-width values
+//     a, b <- |f0 a + g0 b| / 2^30, |f1 a + g1 b| / 2^30            (exact divisions)
+//     u, v <- +-(f0 u + g0 v) / 2^30,  +-(f1 u + g1 v) / 2^30  mod q (Montgomery-style division)
+// keeping a = u*y, b = v*y (mod q).  After ceil((2*qbits - 1) / 30) rounds (17 for a 254-bit prime) b = 1 and
+// v = 1/y: ~22 K VALU instructions instead of ~100 K for the Fermat power y^(q-2).
+// oracle/bingcd_model.py restates this routine limb for limb; tests pin both against pow(y, -1, q).
+#define INV_K 30
+struct w9 { uint32_t v[9]; };
+
+// f*x + g*y as a 288-bit two's complement value (wrap-around).  Signed factors are offset to unsigned ones:
+// f x + g y = (f + 2^30) x + (g + 2^30) y - 2^30 (x + y).
+__device__ __forceinline__ w9 inv_lincomb(const fe &x, const fe &y, int32_t f, int32_t g) {
+    const uint32_t fp = (uint32_t)(f + (1 << INV_K)), gp = (uint32_t)(g + (1 << INV_K));
+    w9 U;
+    uint64_t c = 0;
+    FE_UNROLL for (int i = 0; i < 8; i++) { c += (uint64_t)x.v[i] * fp; U.v[i] = (uint32_t)c; c >>= 32; }
+    U.v[8] = (uint32_t)c;
+    c = 0;
+    FE_UNROLL for (int i = 0; i < 8; i++) { c += (uint64_t)y.v[i] * gp + U.v[i]; U.v[i] = (uint32_t)c; c >>= 32; }
+    U.v[8] += (uint32_t)c;
+    uint32_t S[9];
+    c = 0;
+    FE_UNROLL for (int i = 0; i < 8; i++) { c += (uint64_t)x.v[i] + y.v[i]; S[i] = (uint32_t)c; c >>= 32; }
+    S[8] = (uint32_t)c;
+    w9 D;
+    uint32_t prev = 0, br = 0;
+    FE_UNROLL for (int i = 0; i < 9; i++) {
+        const uint32_t w = __builtin_amdgcn_alignbit(S[i], prev, 32 - INV_K);     // (S << 30) limb i
+        prev = S[i];
+        const uint64_t t = (uint64_t)U.v[i] - w - br;
+        D.v[i] = (uint32_t)t;
+        br = (uint32_t)(t >> 32) & 1u;
     }
-    return fe_from29(fe29_mmul(r, fe_to29(fe_small(1)), P));              // from Montgomery
+    return D;
+}
+__device__ __forceinline__ void inv_cond_neg(w9 &d, bool neg) {
+    const uint32_t m = neg ? 0xFFFFFFFFu : 0u;
+    uint64_t c = neg ? 1u : 0u;
+    FE_UNROLL for (int i = 0; i < 9; i++) { c += (uint64_t)(d.v[i] ^ m); d.v[i] = (uint32_t)c; c >>= 32; }
+}
+// 64-bit approximations: both exact if max(len a, len b) <= 64, else low 30 bits | top 34 bits at that length
+__device__ __forceinline__ void inv_approx(const fe &a, const fe &b, uint64_t &xa, uint64_t &xb) {
+    int t = 0;                                                      // index of the top non-zero limb of a | b
+    uint32_t top = a.v[0] | b.v[0];
+    FE_UNROLL for (int i = 1; i < 8; i++) {
+        const uint32_t o = a.v[i] | b.v[i];
+        t = o ? i : t;
+        top = o ? o : top;
+    }
+    const int n = 32 * t + 32 - __clz(top | 1u);                    // bit length (>= 1)
+    const int s = n - 34;                                           // top window starts at bit s
+    const int w = s >> 5;                                           // (only used when n > 64, i.e. s >= 31, w >= 0)
+    const uint32_t sh = (uint32_t)s & 31u;
+    uint32_t a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
+    FE_UNROLL for (int i = 0; i < 8; i++) {
+        a0 = (w == i) ? a.v[i] : a0;     b0 = (w == i) ? b.v[i] : b0;
+        a1 = (w + 1 == i) ? a.v[i] : a1; b1 = (w + 1 == i) ? b.v[i] : b1;
+        a2 = (w + 2 == i) ? a.v[i] : a2; b2 = (w + 2 == i) ? b.v[i] : b2;
+    }
+    const uint32_t alo = __builtin_amdgcn_alignbit(a1, a0, sh), ahi = __builtin_amdgcn_alignbit(a2, a1, sh) & 3u;
+    const uint32_t blo = __builtin_amdgcn_alignbit(b1, b0, sh), bhi = __builtin_amdgcn_alignbit(b2, b1, sh) & 3u;
+    const uint64_t ta = (((uint64_t)ahi << 32 | alo) << INV_K) | (a.v[0] & 0x3FFFFFFFu);
+    const uint64_t tb = (((uint64_t)bhi << 32 | blo) << INV_K) | (b.v[0] & 0x3FFFFFFFu);
+    const bool exact = n <= 64;
+    xa = exact ? ((uint64_t)a.v[1] << 32 | a.v[0]) : ta;
+    xb = exact ? ((uint64_t)b.v[1] << 32 | b.v[0]) : tb;
+}
+__device__ __noinline__ fe fe_inv(const fe &y, const FpParams &P) {
+    fe a = y, b = fe_from(P.q), u = fe_small(1), v = fe_zero();
+    uint32_t ninv = 1;                                              // -q^-1 mod 2^30 (wave-uniform, scalar unit)
+    for (int i = 0; i < 5; i++) ninv *= 2u - P.q[0] * ninv;
+    ninv = (0u - ninv) & 0x3FFFFFFFu;
+    w9 qs;                                                          // q << 30
+    {
+        uint32_t prev = 0;
+        FE_UNROLL for (int i = 0; i < 8; i++) { qs.v[i] = __builtin_amdgcn_alignbit(P.q[i], prev, 32 - INV_K); prev = P.q[i]; }
+        qs.v[8] = prev >> (32 - INV_K);
+    }
+    const int rounds = (2 * (int)P.qbits - 1 + INV_K - 1) / INV_K;
+    for (int r = 0; r < rounds; r++) {
+        // 2*qbits - 1 halvings is the worst case; ~1.4*qbits is typical.  Once a == 0 further rounds leave (b, v)
+        // unchanged, so the wave stops as soon as every active lane is done.
+        if (__all(fe_is_zero(a))) break;
+        uint64_t xa, xb;
+        inv_approx(a, b, xa, xb);
+        int32_t f0 = 1, g0 = 0, f1 = 0, g1 = 1;
+        for (int j = 0; j < INV_K; j++) {
+            const bool odd = xa & 1u;
+            const bool sw = odd & (xa < xb);
+            const uint64_t ta = sw ? xb : xa, tb = sw ? xa : xb;
+            const int32_t tf0 = sw ? f1 : f0, tf1 = sw ? f0 : f1, tg0 = sw ? g1 : g0, tg1 = sw ? g0 : g1;
+            xa = (ta - (odd ? tb : 0ull)) >> 1;
+            xb = tb;
+            f0 = tf0 - (odd ? tf1 : 0);
+            g0 = tg0 - (odd ? tg1 : 0);
+            f1 = (int32_t)((uint32_t)tf1 << 1);
+            g1 = (int32_t)((uint32_t)tg1 << 1);
+        }
+        fe na, nb, nu, nv;
+        FE_UNROLL for (int h = 0; h < 2; h++) {
+            const int32_t f = h ? f1 : f0, g = h ? g1 : g0;
+            w9 d = inv_lincomb(a, b, f, g);
+            const bool neg = d.v[8] >> 31;
+            inv_cond_neg(d, neg);
+            fe &oa = h ? nb : na;
+            FE_UNROLL for (int i = 0; i < 8; i++) oa.v[i] = __builtin_amdgcn_alignbit(d.v[i + 1], d.v[i], INV_K);
+            w9 e = inv_lincomb(u, v, f, g);
+            inv_cond_neg(e, neg);
+            uint64_t c = 0;                                         // + q 2^30: non-negative, < 2^31 q
+            FE_UNROLL for (int i = 0; i < 9; i++) { c += (uint64_t)e.v[i] + qs.v[i]; e.v[i] = (uint32_t)c; c >>= 32; }
+            const uint32_t k = (e.v[0] * ninv) & 0x3FFFFFFFu;       // + k q: the low 30 bits vanish
+            c = 0;
+            FE_UNROLL for (int i = 0; i < 8; i++) { c += (uint64_t)P.q[i] * k + e.v[i]; e.v[i] = (uint32_t)c; c >>= 32; }
+            e.v[8] += (uint32_t)c;
+            uint32_t t[9];                                          // / 2^30: < 3 q
+            FE_UNROLL for (int i = 0; i < 8; i++) t[i] = __builtin_amdgcn_alignbit(e.v[i + 1], e.v[i], INV_K);
+            t[8] = e.v[8] >> INV_K;
+            FE_UNROLL for (int pass = 0; pass < 2; pass++) {          // two conditional subtractions of q
+                uint32_t d2[9], br = 0;
+                FE_UNROLL for (int i = 0; i < 9; i++) {
+                    const uint64_t x = (uint64_t)t[i] - (i < 8 ? P.q[i] : 0u) - br;
+                    d2[i] = (uint32_t)x;
+                    br = (uint32_t)(x >> 32) & 1u;
+                }
+                FE_UNROLL for (int i = 0; i < 9; i++) t[i] = br ? t[i] : d2[i];
+            }
+            fe &ou = h ? nv : nu;
+            FE_UNROLL for (int i = 0; i < 8; i++) ou.v[i] = t[i];
+        }
+        a = na; b = nb; u = nu; v = nv;
+    }
+    return v;
 }
 // x^y with a per-lane exponent (Fr_pow / mpz_powm, generic/fr.cpp:2877-2893; 0^0 = 1)
 __device__ __noinline__ fe fe_pow(const fe &x, const fe &y, const FpParams &P) {

@@ -80,7 +80,7 @@ _DIRECT = {O.COPY: D_COPY, O.ADD: D_ADD, O.SUB: D_SUB, O.NEG: D_NEG, O.IDIV: D_I
            O.POW: D_POW, O.SHL: D_SHL, O.SHR: D_SHR, O.BAND: D_BAND, O.BOR: D_BOR, O.BXOR: D_BXOR,
            O.BNOT: D_BNOT, O.LT: D_LT, O.GT: D_GT, O.LEQ: D_LEQ, O.GEQ: D_GEQ, O.EQ: D_EQ, O.NEQ: D_NEQ,
            O.LAND: D_LAND, O.LOR: D_LOR, O.LNOT: D_LNOT, O.ASSERT_EQ: D_ASSERT_EQ, O.ASSERT_NZ: D_ASSERT_NZ}
-_COST = {D_MMUL: 10.0, D_MUL2: 20.0, D_MADD: 11.0, D_MULC: 10.0, D_MADDC: 11.0, D_INV: 4000.0, D_POW: 6000.0, D_IDIV: 8000.0, D_MOD: 8000.0}
+_COST = {D_MMUL: 10.0, D_MUL2: 20.0, D_MADD: 11.0, D_MULC: 10.0, D_MADDC: 11.0, D_INV: 1000.0, D_POW: 6000.0, D_IDIV: 8000.0, D_MOD: 8000.0}
 _NO_VALUE = (D_ASSERT_EQ, D_ASSERT_NZ, D_SELECT)
 
 
@@ -463,6 +463,137 @@ def _reassociate(rows, n_vtemps):
     return out, nxt
 
 
+INV_WINDOW = 96      # same-level inversions at most this many rows apart are batched
+INV_GROUP = 8        # members per batch
+
+
+def _batch_inversions(rows, n_vtemps, cid):
+    """Pass A4: Montgomery's trick.  k independent inversions (same dependency level, close together in program
+    order: the two denominators of a BabyAdd, the lambdas of parallel ladder segments, ...) become ONE inversion
+    of their running product plus 3(k-1) multiplications:
+        p_i = e_1 ... e_i,   t = 1/p_k,   1/e_i = t_i * p_(i-1),   t_(i-1) = t_i * e_i.
+    The reference's inverse maps 0 to 0 (mpz_invert fails, generic/fr.cpp:2895-2906), and a zero member would
+    poison the product, so each member enters as e = d + [d == 0] and leaves as 1/e - [d == 0].
+    Consumers of an early member that sit before the last member in program order are moved behind the batch
+    (the rows are in SSA form, so any order that respects the data flow computes the same values)."""
+    level = {}
+    inv_idx = []
+    for idx, r in enumerate(rows):
+        lv = 0
+        for k, v in _value_operands(r):
+            if k == K_SIG or k == K_TMP:
+                lv = max(lv, level.get((k, v), -1) + 1)
+        if r.dk in (K_SIG, K_TMP):
+            level[(r.dk, r.dv)] = lv
+        if r.op == D_INV and r.extra is None:
+            inv_idx.append((idx, lv))
+    open_group = {}                      # level -> current group (list of row indices)
+    groups = []
+    for idx, lv in inv_idx:
+        g = open_group.get(lv)
+        if g is None or idx - g[0] > INV_WINDOW or len(g) >= INV_GROUP:
+            g = []
+            groups.append(g)
+            open_group[lv] = g
+        g.append(idx)
+    member = {}
+    for g in groups:
+        if len(g) >= 2:
+            for idx in g:
+                member[idx] = g
+    if not member:
+        return rows, n_vtemps, 0
+    nxt = [n_vtemps]
+
+    def tmp():
+        t = nxt[0]
+        nxt[0] += 1
+        return (K_TMP, t)
+
+    zero = (K_CONST, cid(0))
+    out = []
+    pending = set()                      # values whose producer has not been emitted yet
+    deferred = []
+    arrived = {}
+
+    def emit_batch(g):
+        mem = [rows[i] for i in g]
+        z, e = [], []
+        for r in mem:
+            zi, ei = tmp(), tmp()
+            out.append(_Row(D_EQ, zi[0], zi[1], r.ak, r.av, zero[0], zero[1]))
+            out.append(_Row(D_ADD, ei[0], ei[1], r.ak, r.av, zi[0], zi[1]))
+            z.append(zi)
+            e.append(ei)
+        pref = [e[0]]
+        for i in range(1, len(mem)):
+            pi = tmp()
+            out.append(_Row(D_MUL2, pi[0], pi[1], pref[-1][0], pref[-1][1], e[i][0], e[i][1]))
+            pref.append(pi)
+        t = tmp()
+        out.append(_Row(D_INV, t[0], t[1], pref[-1][0], pref[-1][1]))
+        inv = [None] * len(mem)
+        for i in range(len(mem) - 1, 0, -1):
+            ri = tmp()
+            out.append(_Row(D_MUL2, ri[0], ri[1], t[0], t[1], pref[i - 1][0], pref[i - 1][1]))
+            inv[i] = ri
+            if i > 1:
+                t2 = tmp()
+                out.append(_Row(D_MUL2, t2[0], t2[1], t[0], t[1], e[i][0], e[i][1]))
+                t = t2
+            else:
+                t2 = tmp()
+                out.append(_Row(D_MUL2, t2[0], t2[1], t[0], t[1], e[1][0], e[1][1]))
+                t = t2
+        inv[0] = t
+        for r, ri, zi in zip(mem, inv, z):
+            out.append(_Row(D_SUB, r.dk, r.dv, ri[0], ri[1], zi[0], zi[1]))
+
+    def dsts(unit):
+        for r in unit:
+            if r.dk in (K_SIG, K_TMP):
+                yield (r.dk, r.dv)
+            if r.extra:
+                for x in r.extra:
+                    yield x
+
+    def process(unit, idx):
+        blocked = any((k, v) in pending for r in unit for k, v in _value_operands(r))
+        if blocked:
+            deferred.append((unit, idx))
+            pending.update(dsts(unit))
+            return
+        g = member.get(idx) if len(unit) == 1 and unit[0].op == D_INV else None
+        if g is None:
+            out.extend(unit)
+            return
+        arrived[id(g)] = arrived.get(id(g), 0) + 1
+        pending.update(dsts(unit))
+        if arrived[id(g)] < len(g):
+            return
+        emit_batch(g)
+        for i in g:
+            pending.discard((rows[i].dk, rows[i].dv))
+        q = list(deferred)
+        del deferred[:]
+        for u, ui in q:
+            for d in dsts(u):
+                pending.discard(d)
+        for u, ui in q:
+            process(u, ui)
+
+    i = 0
+    while i < len(rows):
+        if rows[i].op == D_SELECT:
+            process((rows[i], rows[i + 1]), i)
+            i += 2
+        else:
+            process((rows[i],), i)
+            i += 1
+    assert not deferred and not pending
+    return out, nxt[0], sum(1 for g in groups if len(g) >= 2)
+
+
 def _fuse_madd(rows):
     """Pass B2 (single strand only): [x = value] [t = MMUL(a,b)] [d = x + t]  ->  [x] [d = MADD(a,b)] where the
     addend is implicitly PREV (= x).  `t` must be a single-use temp and `x` must be produced by the row right
@@ -671,6 +802,7 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
     q = fc.fp.q
     n_signals = fc.n_signals
     rows, dconsts, n_vtemps, cid, plain = _expand(fc)
+    rows, n_vtemps, n_inv_batches = _batch_inversions(rows, n_vtemps, cid)
     rows, n_lin, n_bit = _fuse_linear(rows, plain, q, cid)
     # limb-form constant table of the D_DOTC terms, interned in program order (identical for every strand count)
     lconsts, lconst_id = [], {}
@@ -937,6 +1069,7 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
         "madd": int((dops == D_MADD).sum()),
         "fused_madd": n_madd,
         "inv": int((dops == D_INV).sum()),
+        "inv_batches": n_inv_batches,
         "barriers": n_levels,
         "full_barriers": len(full_after),
         "strands": n_strands,

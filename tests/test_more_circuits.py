@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from circom_amd.compiler import compile_program
-from circom_amd.frontend.dsl import Program
+from circom_amd.frontend.dsl import Program, template
 from circom_amd.frontend.flatten import flatten
 from circom_amd.hip_elements.lower import lower
 from circom_amd.hip_elements.writers import wtns_bytes
@@ -193,4 +193,82 @@ def test_gpu_babyjub_scalar_mul(tmp_path):
     inp = {fc.main_input_start + k: v for k, v in enumerate(rows[3])}
     want, failed = eval_flat(q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp)
     assert failed is None and b.witness(3) == want
+    b.close(); c.close()
+
+
+# ---- batched inversions (Montgomery's trick in the lowering): zero members keep the reference's inv(0) = 0 -------------
+@template
+def ThreeDivs(c):
+    a = c.input("a", 3)
+    b = c.input("b", 3)
+    out = c.output("out", 3)
+    chained = c.output("chained")
+    for i in range(3):
+        c.hint(out[i], a[i] / (b[i] - 5))                  # three independent divisions at one level: one batch
+    c.hint(chained, (out[0] + 1) / (out[1] + out[2] + 2))  # depends on the batch: must be moved behind it
+
+
+def test_batched_inversions_match_reference_semantics_for_zero_denominators(tmp_path, ref_dir_bn128):
+    q = PRIMES["bn128"]
+    fc = flatten(Program(ThreeDivs()))
+    for S in (1, 4):
+        t = lower(fc, n_strands=S)
+        assert t.stats["inv_batches"] == 1 and t.stats["inv"] == 2      # 4 divisions -> 2 inversions
+    rng = random.Random(12)
+    cases = []
+    for zeros in range(8):
+        a = [rng.randrange(q) for _ in range(3)]
+        b = [5 if (zeros >> i) & 1 else rng.randrange(q) for i in range(3)]
+        cases.append(a + b)
+    cases.append([1, 2, 3, 6, 6, 6])
+    cases.append([0, 0, 0, 4, q - 1, 3])
+    tapes = [lower(fc, n_strands=S) for S in (1, 4)]
+    wants = []
+    for row in cases:
+        inp = {fc.main_input_start + k: v for k, v in enumerate(row)}
+        sig, failed = eval_flat(q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp)
+        assert failed is None
+        for i in range(3):
+            d = (row[3 + i] - 5) % q
+            assert sig[1 + i] == (row[i] * pow(d, -1, q) % q if d else 0)
+        for t in tapes:
+            got, st = eval_tape(t, inp)
+            assert st == 0 and got == sig
+        wants.append(sig)
+    # the reference's own runtime agrees (Fr_div of a zero denominator gives 0, generic/fr.cpp:2895-2912)
+    from oracle import ref_build
+    from circom_amd.hip_elements.writers import wtns_bytes
+    cp = compile_program(Program(ThreeDivs()), str(tmp_path), "threedivs", sym=False)
+    try:
+        ref_build.build_circuit(cp)
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    raw = b"".join(v.to_bytes(32, "little") for row in cases for v in row)
+    pre = str(tmp_path / "r_")
+    ref_build.run_loop(cp, raw, len(cases), 1, wtns_prefix=pre)
+    for i, want in enumerate(wants):
+        assert open(pre + "%d.wtns" % i, "rb").read() == wtns_bytes(q, want), i
+
+
+@pytest.mark.gpu
+def test_gpu_batched_inversions_with_zero_denominators(tmp_path):
+    from circom_amd import runtime as rt
+    q = PRIMES["bn128"]
+    cp = compile_program(Program(ThreeDivs()), str(tmp_path), "threedivs", sym=False)
+    fc = cp.flat
+    rng = random.Random(13)
+    rows = []
+    for k in range(256):
+        a = [rng.randrange(q) for _ in range(3)]
+        b = [5 if (k >> i) & 1 and k < 64 else rng.randrange(q) for i in range(3)]
+        rows.append(a + b)
+    c = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
+    b = c.batch(len(rows))
+    b.set_inputs(rows)
+    b.run(); b.sync()
+    assert (b.status() == 0).all()
+    for i in list(range(0, 16)) + [63, 64, 200, 255]:
+        inp = {fc.main_input_start + k: v for k, v in enumerate(rows[i])}
+        want, failed = eval_flat(q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp)
+        assert failed is None and b.witness(i) == want, i
     b.close(); c.close()
