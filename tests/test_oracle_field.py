@@ -115,3 +115,18 @@ def test_field_py_matches_compiled_reference(prime, request):
     for s, base in (("123456789012345678901234567890123456789012345678901234567890123456789012345678901234567890", 10),
                     ("ff" * 40, 16), ("1011" * 70, 2), ("7654321" * 20, 8), ("0", 10), ("-5", 10)):
         assert ref.str2element(s, base) == f.from_str(s, base)
+
+
+def test_device_inversion_model_matches_pow():
+    """oracle/bingcd_model.py restates the device's constant-time binary-GCD inverse limb for limb (with the
+    identities it relies on as assertions); it must agree with pow(y, -1, q) and map 0 to 0 like mpz_invert."""
+    import random
+    from oracle.bingcd_model import inv_mod
+    rng = random.Random(3)
+    for name, q in PRIMES.items():
+        if q.bit_length() < 200:
+            continue
+        vals = [0, 1, 2, 3, q - 1, q - 2, (q - 1) // 2, (q + 1) // 2, 1 << 64, (1 << 64) - 1, 1 << 128, (1 << 253) % q]
+        vals += [rng.randrange(q) for _ in range(150)] + [rng.randrange(1 << 40) for _ in range(30)]
+        for y in vals:
+            assert inv_mod(y, q) == (pow(y, -1, q) if y else 0), (name, hex(y))
