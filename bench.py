@@ -198,8 +198,13 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "cw_eval_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": gen_ms,
-                         "strands": batch.strands,
+                         "strands": batch.strands, "lanes_per_workgroup": batch.lanes,
                          "fp_mul_per_s_in_kernel": circ.n_mmul * B / (gen_ms * 1e-3)},
+            # second bound of SURVEY §8d (integer carry chains, no MFMA): Fp products per second inside the
+            # evaluation kernel against the device's measured Fp-multiply peak (micro-benchmark below)
+            "roofline_valu": {"bound": "valu", "kernel": "cw_eval_kernel", "unit": "Fp-mul/s",
+                              "achieved": circ.n_mmul * B / (gen_ms * 1e-3), "peak": fp_mul_per_s,
+                              "frac": (circ.n_mmul * B / (gen_ms * 1e-3)) / fp_mul_per_s if fp_mul_per_s else None},
             "fp_mul_per_s": fp_mul_per_s,
             "r1cs_check_ms": chk_ms,
             "r1cs_check_gbs": 32.0 * n_wit * B / (chk_ms * 1e-3) / 1e9,

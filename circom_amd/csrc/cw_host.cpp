@@ -156,9 +156,6 @@ static FpParams make_params(const U256 &q) {
     U256 r2 = shlmod(r1, CW_RBITS, q);       // R'^2 mod q
     memcpy(P.one_m, r1.w, 32);
     memcpy(P.r2, r2.w, 32);
-    U256 two{{2, 0, 0, 0}}, qm2;
-    u256_sub(qm2, q, two);
-    memcpy(P.qm2, qm2.w, 32);
     // np29 = -q^-1 mod 2^29 by Newton iteration
     uint32_t q0 = (uint32_t)q.w[0], inv = 1;
     for (int i = 0; i < 5; i++) inv *= 2 - q0 * inv;
@@ -593,7 +590,7 @@ extern "C" int cw_r1cs_plan_stats(const cw_circuit *c, uint32_t batch, uint32_t 
 struct cw_batch {
     cw_circuit *c = nullptr;
     int device = 0;
-    uint32_t batch = 0, Bp = 0;
+    uint32_t batch = 0, Bp = 0, lanes = 64;
     hipStream_t stream = nullptr;
     void *d_V = nullptr;
     size_t v_bytes = 0;
@@ -609,6 +606,8 @@ struct cw_batch {
     uint32_t r1_chunks = 0, r1_entries = 0;
     void *d_in = nullptr;          // AoS staging [batch][n_in][32]
     void *d_gather = nullptr;      // [n_witness][32]
+    void *d_bulk = nullptr;        // staging of cw_get_witnesses: [bulk_rows][n_witness][32]
+    uint32_t bulk_rows = 0;
     const void *ext_in = nullptr;  // caller-owned device inputs (cw_set_inputs_device)
     std::vector<uint32_t> h_stream_begin;
     std::vector<uint8_t> h_in;     // host staging for per-signal assignment
@@ -636,7 +635,7 @@ extern "C" void cw_batch_free(cw_batch *b) {
     hipStreamSynchronize(b->stream);
     void *ptrs[] = {b->d_V, b->d_rows, b->d_stream_off, b->d_extras, b->d_extra_off, b->d_terms, b->d_term_off, b->d_lconsts, b->d_consts, b->d_w2s, b->d_status, b->d_first_bad,
                     b->d_rctab, b->d_pchunk, b->d_prec, b->d_pterms, b->d_prow,
-                    b->d_in, b->d_gather};
+                    b->d_in, b->d_gather, b->d_bulk};
     for (void *p : ptrs)
         if (p) hipFree(p);
     delete b;
@@ -680,6 +679,15 @@ extern "C" int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *
             if (better) best = &v;
         }
         b->var = best;
+        // instances per workgroup: a small batch of a long schedule is spread over more workgroups (more CUs, each
+        // with its own path to memory) by leaving the upper lanes of the waves idle, until ~4 waves per SIMD exist
+        uint32_t lanes = 64;
+        while (lanes > 16 && ((uint64_t)batch + lanes - 1) / lanes * best->n_strands < 4096) lanes >>= 1;
+        if (const char *e = getenv("CW_LANES")) {
+            int v = atoi(e);
+            if (v == 16 || v == 32 || v == 64) lanes = (uint32_t)v;
+        }
+        b->lanes = lanes;
     }
     size_t slots = (size_t)c->n_signals + b->var->n_tslots;
     b->v_bytes = slots * 2 * b->Bp * 16;
@@ -820,6 +828,7 @@ extern "C" int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *
 }
 extern "C" uint32_t cw_batch_size(const cw_batch *b) { return b->batch; }
 extern "C" uint32_t cw_batch_strands(const cw_batch *b) { return b->var ? b->var->n_strands : 0; }
+extern "C" uint32_t cw_batch_lanes(const cw_batch *b) { return b->lanes; }
 
 static int ensure_host_staging(cw_batch *b) {
     size_t n = (size_t)b->batch * b->c->n_inputs;
@@ -1114,7 +1123,7 @@ extern "C" int cw_run(cw_batch *b) {
     HIPCHK(cwk_ingest(b->stream, in, b->d_V, c->input_start, c->n_inputs, b->batch, b->Bp));
     HIPCHK(cwk_eval(b->stream, c->need_full, b->var->wide_linsum, b->d_rows, b->d_stream_off, b->d_extras, b->d_extra_off, b->d_terms,
                     b->d_term_off, b->var->n_strands, b->var->n_lds, b->d_V, b->d_consts, b->d_lconsts, b->Bp, b->batch,
-                    b->d_status, c->P));
+                    b->lanes, b->d_status, c->P));
     b->ran = true;
     return CW_OK;
 }
@@ -1170,6 +1179,34 @@ extern "C" int cw_get_witness(cw_batch *b, uint32_t instance, uint8_t *out) {
     HIPCHK(cwk_gather(b->stream, b->d_V, b->d_w2s, c->n_witness, b->Bp, instance, b->d_gather));
     HIPCHK(hipMemcpyAsync(out, b->d_gather, (size_t)c->n_witness * 32, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
+    return CW_OK;
+}
+
+// Bulk form: `count` instances starting at `first`, [count][n_witness][32 B], transposed on the device and
+// copied in pieces of at most 256 MiB through a staging buffer that is allocated on first use.
+extern "C" int cw_get_witnesses(cw_batch *b, uint32_t first, uint32_t count, uint8_t *out) {
+    if (!b || !out) return fail(CW_EINVAL, "null argument");
+    if ((uint64_t)first + count > b->batch) return fail(CW_EINVAL, "instance range out of the batch");
+    NEED_DEVICE(b);
+    if (!b->ran) return fail(CW_ESTATE, "cw_get_witnesses before cw_run");
+    cw_circuit *c = b->c;
+    HIPCHK(hipSetDevice(b->device));
+    const size_t row = (size_t)c->n_witness * 32;
+    uint32_t per = (uint32_t)std::max<size_t>(1, std::min<size_t>(count, ((size_t)256 << 20) / std::max<size_t>(row, 1)));
+    per = std::max<uint32_t>(64, per / 64 * 64);
+    if (b->bulk_rows < per) {
+        if (b->d_bulk) hipFree(b->d_bulk);
+        b->d_bulk = nullptr;
+        b->bulk_rows = 0;
+        HIPCHK(hipMalloc(&b->d_bulk, (size_t)per * row));
+        b->bulk_rows = per;
+    }
+    for (uint32_t done = 0; done < count; done += per) {
+        const uint32_t n = std::min(per, count - done);
+        HIPCHK(cwk_gather_many(b->stream, b->d_V, b->d_w2s, c->n_witness, b->Bp, first + done, n, b->d_bulk));
+        HIPCHK(hipMemcpyAsync(out + (size_t)done * row, b->d_bulk, (size_t)n * row, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+    }
     return CW_OK;
 }
 

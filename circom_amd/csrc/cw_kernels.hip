@@ -77,6 +77,32 @@ __global__ void __launch_bounds__(CW_BLOCK) cw_ingest_kernel(const uint4 *__rest
 //  (3) a LIGHT barrier only orders LDS traffic (s_waitcnt lgkmcnt(0) + s_barrier): global stores stay in
 //      flight across it.  Only FULL barriers (hand-off through global memory) drain vmcnt.
 // FULL_OPS selects the variant that also carries the slow-path operators (INV/IDIV/MOD/POW).
+// -DCW_PROFILE (tools/profile_ops.sh, never the product build): workgroup 0 accumulates the shader-clock time of
+// every interpreter step per (strand, opcode), operand waits included.
+#ifdef CW_PROFILE
+__device__ unsigned long long cw_prof[16 * 64 * 2];
+#define CW_PROF_BEGIN() prof_t0 = __builtin_readcyclecounter()
+#define CW_PROF_END(row)                                                                              \
+    do {                                                                                              \
+        if (blockIdx.x == 0 && lane == 0 && wave < 16) {                                              \
+            const uint64_t prof_t1 = __builtin_readcyclecounter();                                    \
+            const uint32_t prof_k = (wave * 64 + ((row).w0 & 63u)) * 2;                               \
+            atomicAdd(&cw_prof[prof_k], (unsigned long long)(prof_t1 - prof_t0));                     \
+            atomicAdd(&cw_prof[prof_k + 1], 1ull);                                                    \
+        }                                                                                             \
+    } while (0)
+extern "C" int cw_debug_profile(unsigned long long *out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(cw_prof), sizeof(cw_prof)) != hipSuccess) return -1;
+    if (reset) {
+        static unsigned long long zero[16 * 64 * 2];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(cw_prof), zero, sizeof(zero)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#else
+#define CW_PROF_BEGIN()
+#define CW_PROF_END(row)
+#endif
 extern __shared__ uint4 cw_lds[];       // [slot][2 halves][64 lanes] x 16 B
 
 struct EvalCtx {                         // per-wave constants of the interpreter
@@ -115,6 +141,9 @@ __device__ __forceinline__ fe fetch_off(uint32_t kind, uint64_t off, const EvalC
     return r;
 }
 __device__ __forceinline__ void store_off(uint64_t off, const EvalCtx &c, const fe &x) {
+#ifdef CW_EXPERIMENT_NOSTORE       // timing experiment only (tools/profile_ops.sh): results are garbage
+    return;
+#endif
     char *base = (char *)c.Vb + off;
     *(uint4 *)(base + c.vlo) = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
     *(uint4 *)(base + c.vhi) = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
@@ -350,10 +379,15 @@ __device__ __forceinline__ void eval_step(const CwDRow &row, const fe &xa, const
         prev = d;
         if (dk == K_LDS) lds_store_off((uint32_t)row.dst_off, c, d);
         else if (dk != KD_NONE) store_off(row.dst_off, c, d);
-        for (uint32_t e = 0; e < nx; e++) {
-            const uint64_t x = e == 0 ? x0 : e == 1 ? x1 : e == 2 ? x2 : e == 3 ? x3 : extras[xp + e];
-            if (x >> 63) lds_store_off((uint32_t)x, c, d);
-            else store_off(x, c, d);
+        // the first four table entries were requested before the arithmetic; longer fan-outs (a bit wired into dozens
+        // of sub-components) fetch four entries per scalar load instead of waiting for one entry at a time
+        uint64_t y0 = x0, y1 = x1, y2 = x2, y3 = x3;
+        for (uint32_t e = 0; e < nx; e += 4) {
+            if (e) { y0 = extras[xp + e]; y1 = extras[xp + e + 1]; y2 = extras[xp + e + 2]; y3 = extras[xp + e + 3]; }
+            if (y0 >> 63) lds_store_off((uint32_t)y0, c, d); else store_off(y0, c, d);
+            if (e + 1 < nx) { if (y1 >> 63) lds_store_off((uint32_t)y1, c, d); else store_off(y1, c, d); }
+            if (e + 2 < nx) { if (y2 >> 63) lds_store_off((uint32_t)y2, c, d); else store_off(y2, c, d); }
+            if (e + 3 < nx) { if (y3 >> 63) lds_store_off((uint32_t)y3, c, d); else store_off(y3, c, d); }
         }
     }
     xp += nx;
@@ -381,13 +415,17 @@ cw_eval_kernel(const CwDRow *__restrict__ rows, const uint32_t *__restrict__ str
                const uint64_t *__restrict__ extras, const uint32_t *__restrict__ extra_off,
                const uint64_t *__restrict__ terms, const uint32_t *__restrict__ term_off, uint4 *V,
                const uint32_t *__restrict__ consts, const uint32_t *__restrict__ lconsts, uint32_t Bp, uint32_t batch,
-               uint32_t *status, FpParams P) {
+               uint32_t lanes, uint32_t *status, FpParams P) {
     // strand executed by this wave: rotated by the workgroup index, so that the strand carrying the critical chain
     // (the same one in every workgroup) does not land on the same SIMD of the CU in all co-resident workgroups
     const uint32_t nstr = blockDim.x >> 6;
     const uint32_t wave = (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) + blockIdx.x) % nstr;
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t i = blockIdx.x * 64 + lane;                     // < Bp (Bp is a multiple of 256 >= batch)
+    // `lanes` (64, 32 or 16) instances per workgroup: small batches of long schedules are spread over more
+    // workgroups (= more CUs, each with its own path to memory) by leaving the upper lanes of every wave idle.
+    // The idle lanes are masked off for the whole kernel; every wave still reaches every barrier.
+    if (lane < lanes) {
+    const uint32_t i = blockIdx.x * lanes + lane;                  // < Bp (Bp is a multiple of 256 >= batch)
     EvalCtx c;
     c.Vb = (const char *)V;
     c.Cb = (const char *)consts;
@@ -407,16 +445,23 @@ cw_eval_kernel(const CwDRow *__restrict__ rows, const uint32_t *__restrict__ str
     CwDRow r0 = rows[r], r1 = rows[r + 1];
     fe a0 = fetch_off((r0.w0 >> SH_AK) & 7, r0.a_off, c), b0 = fetch_off((r0.w0 >> SH_BK) & 7, r0.b_off, c);
     fe a1, b1;
+    uint64_t prof_t0 = 0;
+    (void)prof_t0;
     while (r < end) {
         CwDRow r2 = rows[r + 2];
+        CW_PROF_BEGIN();
         eval_step<FULL_OPS, LW>(r0, a0, b0, r1, a1, b1, prev, selmask, st, r, extras, xp, c, P);
+        CW_PROF_END(r0);
         r0 = rows[r + 3];
+        CW_PROF_BEGIN();
         eval_step<FULL_OPS, LW>(r1, a1, b1, r2, a0, b0, prev, selmask, st, r + 1, extras, xp, c, P);
+        CW_PROF_END(r1);
         r1 = r0;
         r0 = r2;
         r += 2;
     }
     if (st && i < batch) atomicCAS(&status[i], 0u, st);
+    }
 }
 
 // ---- R1CS check:  (A.w) * (B.w) == C.w  for every constraint row and instance ---------------------------
@@ -577,6 +622,33 @@ cw_gather_kernel(const uint4 *__restrict__ V, const uint32_t *__restrict__ w2s, 
     out[2 * (size_t)k + 1] = V[base + Bp];
 }
 
+// ---- bulk egress: witnesses of `count` consecutive instances as [count][n_witness][32 B] ----------------------
+// SoA -> AoS transpose through LDS: a 256-thread block moves a tile of 64 instances x 32 witness elements.
+// Reads are coalesced along instances (the table's layout), writes along the witness index (the output's).
+__global__ void __launch_bounds__(256)
+cw_gather_many_kernel(const uint4 *__restrict__ V, const uint32_t *__restrict__ w2s, uint32_t n_wit, uint32_t Bp,
+                      uint32_t first, uint32_t count, uint4 *__restrict__ out) {
+    __shared__ uint4 tile[32][2][65];                               // [element][half][instance] (+1: bank spread)
+    const uint32_t k0 = blockIdx.x * 32, i0 = blockIdx.y * 64;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;  // 4 waves
+    for (uint32_t e = wv; e < 32; e += 4) {
+        const uint32_t k = k0 + e;
+        if (k < n_wit && i0 + lane < count) {
+            const size_t base = (size_t)w2s[k] * 2 * Bp + first + i0 + lane;
+            tile[e][0][lane] = V[base];
+            tile[e][1][lane] = V[base + Bp];
+        }
+    }
+    __syncthreads();
+    // 64 consecutive 16-byte pieces of one instance's row = 32 elements x 2 halves
+    const uint32_t piece = threadIdx.x & 63, e = piece >> 1, h = piece & 1;
+    for (uint32_t ii = wv; ii < 64; ii += 4) {
+        const uint32_t k = k0 + e;
+        if (k < n_wit && i0 + ii < count)
+            out[((size_t)(i0 + ii) * n_wit + k) * 2 + h] = tile[e][h][ii];
+    }
+}
+
 // ---- Fp multiplication micro-benchmark: iters dependent Montgomery products per lane --------------------
 __global__ void __launch_bounds__(CW_BLOCK)
 cw_mulbench_kernel(const uint4 *__restrict__ a, const uint4 *__restrict__ b, uint4 *__restrict__ out, uint32_t n,
@@ -661,12 +733,12 @@ hipError_t cwk_ingest(hipStream_t s, const void *in, void *V, uint32_t input_sta
 hipError_t cwk_eval(hipStream_t s, bool full, bool wide_linsum, const CwDRow *rows, const uint32_t *stream_off,
                     const uint64_t *extras, const uint32_t *extra_off, const uint64_t *terms, const uint32_t *term_off,
                     uint32_t n_strands, uint32_t n_lds, void *V, const uint32_t *consts, const uint32_t *lconsts,
-                    uint32_t Bp, uint32_t batch, uint32_t *status, const FpParams &P) {
-    dim3 grid((batch + 63) / 64), block(64 * n_strands);
+                    uint32_t Bp, uint32_t batch, uint32_t lanes, uint32_t *status, const FpParams &P) {
+    dim3 grid((batch + lanes - 1) / lanes), block(64 * n_strands);
     const size_t lds_bytes = (size_t)n_lds * 2048;
     typedef void (*kern_t)(const CwDRow *, const uint32_t *, const uint64_t *, const uint32_t *, const uint64_t *,
-                           const uint32_t *, uint4 *, const uint32_t *, const uint32_t *, uint32_t, uint32_t, uint32_t *,
-                           FpParams);
+                           const uint32_t *, uint4 *, const uint32_t *, const uint32_t *, uint32_t, uint32_t, uint32_t,
+                           uint32_t *, FpParams);
     kern_t k = full ? (wide_linsum ? (kern_t)cw_eval_kernel<true, 4> : (kern_t)cw_eval_kernel<true, 2>)
                     : (wide_linsum ? (kern_t)cw_eval_kernel<false, 4> : (kern_t)cw_eval_kernel<false, 2>);
     if (lds_bytes > 64 * 1024) {
@@ -674,7 +746,7 @@ hipError_t cwk_eval(hipStream_t s, bool full, bool wide_linsum, const CwDRow *ro
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k, grid, block, lds_bytes, s, rows, stream_off, extras, extra_off, terms, term_off, (uint4 *)V,
-                       consts, lconsts, Bp, batch, status, P);
+                       consts, lconsts, Bp, batch, lanes, status, P);
     return hipGetLastError();
 }
 hipError_t cwk_r1cs(hipStream_t s, const uint32_t *chunk, uint32_t n_chunks, const uint32_t *terms, const uint32_t *ctab,
@@ -705,6 +777,14 @@ hipError_t cwk_gather(hipStream_t s, const void *V, const uint32_t *w2s, uint32_
                       void *out) {
     hipLaunchKernelGGL(cw_gather_kernel, blocks_for(n_wit), dim3(CW_BLOCK), 0, s, (const uint4 *)V, w2s, n_wit, Bp,
                        instance, (uint4 *)out);
+    return hipGetLastError();
+}
+hipError_t cwk_gather_many(hipStream_t s, const void *V, const uint32_t *w2s, uint32_t n_wit, uint32_t Bp, uint32_t first,
+                           uint32_t count, void *out) {
+    if (!count || !n_wit) return hipSuccess;
+    dim3 g((n_wit + 31) / 32, (count + 63) / 64);
+    hipLaunchKernelGGL(cw_gather_many_kernel, g, dim3(256), 0, s, (const uint4 *)V, w2s, n_wit, Bp, first, count,
+                       (uint4 *)out);
     return hipGetLastError();
 }
 hipError_t cwk_mulbench(hipStream_t s, const void *a, const void *b, void *out, uint32_t n, uint32_t iters,

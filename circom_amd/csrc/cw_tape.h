@@ -51,7 +51,6 @@ struct FpParams {
     uint32_t half[8];   // (q-1)/2 : val(x) = x - q iff x > half   (generic/fr.cpp:9)
     uint32_t r2[8];     // R'^2 mod q                                 (role of Fr_rawR2, generic/fr.cpp:14)
     uint32_t one_m[8];  // R' mod q  (1 in Montgomery form)
-    uint32_t qm2[8];    // q - 2 (Fermat exponent for INV)
     uint32_t q29[9];    // modulus as 9 x 29-bit limbs
     uint32_t np29;      // -q^-1 mod 2^29
     uint32_t qbits;     // bit length of q

@@ -43,6 +43,8 @@ Passes:
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from .. import opcodes as O
@@ -594,6 +596,40 @@ def _batch_inversions(rows, n_vtemps, cid):
     return out, nxt[0], sum(1 for g in groups if len(g) >= 2)
 
 
+LINSUM_SPLIT_MIN = 24     # D_LINSUM rows with at least this many terms are split across strands (S > 1)
+
+
+def _split_linsums(rows, n_vtemps, n_strands):
+    """Pass A5 (multi-strand schedules): a long D_LINSUM (the 32-bit adders of SHA-256 are sums of 64-160 bit
+    terms) is one row of one strand whose operands arrive four at a time, i.e. tens of memory latencies in
+    series on the critical path.  It becomes `n` partial sums of consecutive terms, which the scheduler spreads
+    over the strands, plus one short sum of the partials: same linear combination, same value."""
+    out = []
+    nxt = n_vtemps
+    n_split = 0
+    for r in rows:
+        if r.op != D_LINSUM or len(r.terms) < LINSUM_SPLIT_MIN:
+            out.append(r)
+            continue
+        parts = min(n_strands, max(2, len(r.terms) // 8))
+        per = -(-len(r.terms) // parts)
+        per = (per + 3) // 4 * 4                       # operands are fetched four at a time
+        partial = []
+        for k in range(0, len(r.terms), per):
+            chunk = r.terms[k:k + per]
+            pr = _Row(D_LINSUM, K_TMP, nxt, K_NONE, len(chunk))
+            pr.terms = chunk
+            out.append(pr)
+            partial.append([K_TMP, nxt, 1])
+            nxt += 1
+        fr = _Row(D_LINSUM, r.dk, r.dv, K_NONE, len(partial), r.bk, r.bv)
+        fr.terms = partial
+        fr.extra = r.extra
+        out.append(fr)
+        n_split += 1
+    return out, nxt, n_split
+
+
 def _fuse_madd(rows):
     """Pass B2 (single strand only): [x = value] [t = MMUL(a,b)] [d = x + t]  ->  [x] [d = MADD(a,b)] where the
     addend is implicitly PREV (= x).  `t` must be a single-use temp and `x` must be produced by the row right
@@ -716,9 +752,10 @@ def _schedule(rows, n_signals, n_strands):
         levels[lv].append(unit)
     streams = [[] for _ in range(n_strands)]
 
-    def ucost(unit):      # ~ VALU instructions / 32
+    def ucost(unit):      # ~ VALU instructions / 32, plus a fixed part per row (operand fetch + dispatch latency)
         c = 0.0
         for r in unit:
+            c += ROW_OVERHEAD
             if r.op == D_DOTC:
                 c += 5.0 + 4.5 * len(r.terms)
             elif r.op == D_LINSUM:
@@ -726,7 +763,7 @@ def _schedule(rows, n_signals, n_strands):
             else:
                 c += _COST.get(r.op, 2.0)
             if r.extra:
-                c += 0.5 * len(r.extra)
+                c += EXTRA_COST * len(r.extra)
         return c
 
     # A barrier is only needed in front of a level that reads, from ANOTHER strand, a value produced since the last
@@ -781,6 +818,8 @@ def _schedule(rows, n_signals, n_strands):
     return streams, n_barriers
 
 
+ROW_OVERHEAD = float(os.environ.get("CW_ROW_OVERHEAD", "4"))   # scheduler cost units charged to every row
+EXTRA_COST = float(os.environ.get("CW_EXTRA_COST", "2"))     # ... and to every extra destination (two 1-KiB stores)
 FULL_PERIOD = 8        # every FULL_PERIOD-th barrier also drains global stores
 AFFINITY_SLACK = 1.25  # a strand may take this much more than the average load of a level to keep data local
 
@@ -820,8 +859,10 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
         if r.op == D_DOTC:
             for tm in r.terms:
                 lcid(tm[2])
+    n_split = 0
     if n_strands > 1:      # one strand prefers the original chains (register forwarding, no extra temps)
         rows, n_vtemps = _reassociate(rows, n_vtemps)
+        rows, n_vtemps, n_split = _split_linsums(rows, n_vtemps, n_strands)
     rows, n_elided = _alias(rows, n_signals)
     n_madd = 0
     if n_strands == 1:
@@ -1070,6 +1111,7 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
         "fused_madd": n_madd,
         "inv": int((dops == D_INV).sum()),
         "inv_batches": n_inv_batches,
+        "linsum_splits": n_split,
         "barriers": n_levels,
         "full_barriers": len(full_after),
         "strands": n_strands,

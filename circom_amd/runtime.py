@@ -54,6 +54,7 @@ _SIGS = {
     "cw_batch_free": (None, [C.c_void_p]),
     "cw_batch_size": (C.c_uint32, [C.c_void_p]),
     "cw_batch_strands": (C.c_uint32, [C.c_void_p]),
+    "cw_batch_lanes": (C.c_uint32, [C.c_void_p]),
     "cw_set_input_signal": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p]),
     "cw_set_inputs_json": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p]),
     "cw_set_inputs": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -65,6 +66,7 @@ _SIGS = {
     "cw_sync": (C.c_int, [C.c_void_p]),
     "cw_get_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cw_get_witness": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    "cw_get_witnesses": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "cw_get_signal": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p]),
     "cw_write_wtns": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p]),
     "cw_get_r1cs_first_bad": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -152,6 +154,7 @@ class Batch:
         _chk(lib().cw_batch_create(circuit.h, device, batch, C.c_void_p(stream or 0), C.byref(h)))
         self.h = h
         self.strands = lib().cw_batch_strands(h)
+        self.lanes = lib().cw_batch_lanes(h)
 
     def close(self):
         if self.h:
@@ -212,6 +215,13 @@ class Batch:
 
     def witness(self, instance: int):
         return bytes_to_ints(self.witness_bytes(instance))
+
+    def witnesses(self, first: int = 0, count: int | None = None) -> np.ndarray:
+        """[count][n_witness][32] uint8, canonical little-endian values (bulk egress, one device transpose)."""
+        count = self.n - first if count is None else count
+        out = np.zeros((count, self.circuit.n_witness, 32), dtype=np.uint8)
+        _chk(lib().cw_get_witnesses(self.h, first, count, out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def signal(self, instance: int, slot: int) -> int:
         buf = C.create_string_buffer(32)

@@ -69,6 +69,8 @@ void cw_batch_free(cw_batch *b);
 uint32_t cw_batch_size(const cw_batch *b);
 /* strands (waves cooperating on the same 64 instances) of the schedule variant picked for this batch */
 uint32_t cw_batch_strands(const cw_batch *b);
+/* instances per workgroup (64, 32 or 16) the evaluation kernel uses for this batch */
+uint32_t cw_batch_lanes(const cw_batch *b);
 
 /* setInputSignal(h, i, val) (calcwit.cpp:77-97) for one instance; `name` is hashed with FNV-1a
  * (calcwit.cpp:17-24).  val = canonical 32-byte little-endian value, reduced mod q by the caller. */
@@ -97,6 +99,8 @@ int cw_sync(cw_batch *b);
 int cw_get_status(cw_batch *b, uint32_t *status /* [batch] */);
 /* getWitness(i) + Fr_toLongNormal for all witness positions (main.cpp:326-332): [n_witness][32] */
 int cw_get_witness(cw_batch *b, uint32_t instance, uint8_t *out);
+/* bulk form for provers: `count` instances from `first`, [count][n_witness][32], one device-side transpose */
+int cw_get_witnesses(cw_batch *b, uint32_t first, uint32_t count, uint8_t *out);
 /* one signal of one instance (signalValues[slot]) */
 int cw_get_signal(cw_batch *b, uint32_t instance, uint32_t slot, uint8_t out[32]);
 /* writeBinWitness (main.cpp:288-334) */

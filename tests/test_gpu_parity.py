@@ -186,6 +186,25 @@ def test_asserts_and_slow_path_ops(tmp_path):
     b.close(); c.close()
 
 
+def test_bulk_witness_egress_equals_per_instance_egress(tmp_path):
+    cp, c = _compile(tmp_path, Program(Poseidon(2)), "poseidon2")
+    B = 333                                         # not a multiple of the 64-instance tile
+    rng = np.random.default_rng(9)
+    ins = [[int.from_bytes(rng.bytes(32), "little") % c.q for _ in range(2)] for _ in range(B)]
+    b = c.batch(B)
+    b.set_inputs(ins)
+    b.run(); b.sync()
+    allw = b.witnesses()
+    assert allw.shape == (B, c.n_witness, 32)
+    for i in (0, 1, 63, 64, 65, 200, B - 1):
+        assert allw[i].tobytes() == b.witness_bytes(i), i
+    part = b.witnesses(100, 70)
+    assert part.tobytes() == allw[100:170].tobytes()
+    with pytest.raises(rt.CwError):
+        b.witnesses(300, 40)
+    b.close(); c.close()
+
+
 @template
 def BadMul(c):
     a = c.input("a")

@@ -1,0 +1,47 @@
+"""Time cw_run / cw_check_r1cs on prebuilt schedules: python tools/tape_bench.py <dir> <name> <batch> [steps]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from circom_amd import runtime as rt
+if os.environ.get("CW_LIB"):
+    from pathlib import Path
+    rt.LIB_PATH = Path(os.environ["CW_LIB"]).resolve()
+d, name, B = sys.argv[1], sys.argv[2], int(sys.argv[3])
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+c = rt.Circuit(os.path.join(d, name + ".cwt"), os.path.join(d, name + ".dat"), os.path.join(d, name + ".r1cs"))
+rng = np.random.default_rng(1)
+if name.startswith("sha"):
+    arr = np.zeros((B, c.n_inputs, 32), dtype=np.uint8); arr[:, :, 0] = rng.integers(0, 2, size=(B, c.n_inputs), dtype=np.uint8)
+else:
+    arr = rng.integers(0, 256, size=(B, c.n_inputs, 32), dtype=np.uint8); arr[:, :, 31] &= 0x0F
+stream = torch.cuda.current_stream()
+b = c.batch(B, device=0, stream=stream.cuda_stream)
+din = torch.from_numpy(arr).cuda()
+b.set_inputs_device(din.data_ptr())
+b.run(); b.check_r1cs(); torch.cuda.synchronize()
+ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+for e in ev:
+    e[0].record(stream); b.run(); e[1].record(stream); b.check_r1cs(); e[2].record(stream)
+torch.cuda.synchronize()
+print("TB %s %s B=%d S=%d L=%d eval %.3f ms r1cs %.3f ms" % (d, name, B, b.strands, b.lanes, sum(e[0].elapsed_time(e[1]) for e in ev) / steps, sum(e[1].elapsed_time(e[2]) for e in ev) / steps))
+
+if os.environ.get("CW_LIB"):
+    import ctypes
+    from circom_amd.hip_elements.lower import D_NAMES
+    buf = (ctypes.c_ulonglong * (16 * 64 * 2))()
+    L = rt.lib()
+    if hasattr(L, "cw_debug_profile") and L.cw_debug_profile(buf, 0) == 0:
+        tot = {}
+        for w in range(16):
+            line = []
+            for op in range(64):
+                t, n = buf[(w * 64 + op) * 2], buf[(w * 64 + op) * 2 + 1]
+                if n:
+                    nm = D_NAMES[op] if op < len(D_NAMES) else str(op)
+                    line.append((t, nm, n))
+                    a = tot.setdefault(nm, [0, 0]); a[0] += t; a[1] += n
+            if line:
+                s_ = sum(x[0] for x in line)
+                print("PROF strand %2d total %.2f Mclk: " % (w, s_ / 1e6) + "  ".join("%s %.0f%% (%d x %.0f)" % (nm, 100.0 * t / s_, n, t / n) for t, nm, n in sorted(line, reverse=True)[:7]))
+        s_ = sum(v[0] for v in tot.values())
+        print("PROF all strands: " + "  ".join("%s %.1f%% (avg %.0f clk)" % (k, 100.0 * v[0] / s_, v[0] / v[1]) for k, v in sorted(tot.items(), key=lambda kv: -kv[1][0])))
