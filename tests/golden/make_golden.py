@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/reference_wtns.json by RUNNING THE REFERENCE's own C++ witness calculator
+(common/main.cpp + calcwit.cpp + rendered generic/fr.cpp, compiled from /root/reference by oracle/Makefile) on fixed
+inputs, in the container that has the reference tree.  The GPU box has no reference tree; the fixtures travel.
+
+For every case the file records the inputs (decimal strings, main-component declaration order), the SHA-256 of the
+reference's `.wtns` file, its length, and the first witness values (constant 1, outputs, inputs).  Small circuits
+also keep the whole `.wtns` (hex).  tests/test_golden_wtns.py checks the Python oracle (CPU) and the HIP path (GPU)
+against these bytes.
+
+    python tests/golden/make_golden.py          # rewrites reference_wtns.json
+"""
+import hashlib
+import json
+import os
+import random
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from circom_amd.compiler import compile_program           # noqa: E402
+from circom_amd.frontend.dsl import Program                # noqa: E402
+from oracle import ref_build                               # noqa: E402
+from oracle.field import PRIMES                            # noqa: E402
+
+
+def cases():
+    """name -> (builder of the Program, prime, list of input rows)"""
+    from circom_amd.circuits.basic import Multiplier2, Num2Bits, IsZero
+    from circom_amd.circuits.poseidon import Poseidon
+    from circom_amd.circuits.sha256 import Sha256
+    from circom_amd.circuits.eddsa import SemaphoreStyle
+    from circom_amd.circuits import eddsa_host as H
+    q = PRIMES["bn128"]
+    qb = PRIMES["bls12381"]
+    rng = random.Random(20250923)
+    out = {}
+    out["multiplier2"] = (lambda: Program(Multiplier2()), "bn128",
+                          [[3, 11], [0, 0], [q - 1, q - 1], [rng.randrange(q), rng.randrange(q)]])
+    out["multiplier2_bls12381"] = (lambda: Program(Multiplier2(), prime="bls12381"), "bls12381",
+                                   [[3, 11], [qb - 1, 2], [rng.randrange(qb), rng.randrange(qb)]])
+    out["poseidon2"] = (lambda: Program(Poseidon(2)), "bn128",
+                        [[1, 2], [0, 0], [q - 1, q - 1], [5, 2 ** 31 - 1], [rng.randrange(q), rng.randrange(q)]])
+    out["poseidon2_bls12381"] = (lambda: Program(Poseidon(2), prime="bls12381"), "bls12381",
+                                 [[1, 2], [rng.randrange(qb), rng.randrange(qb)]])
+    out["num2bits16"] = (lambda: Program(Num2Bits(16)), "bn128", [[0], [1], [43690], [65535]])
+    out["iszero"] = (lambda: Program(IsZero()), "bn128", [[0], [1], [q - 1], [rng.randrange(q)]])
+    out["sha256_512"] = (lambda: Program(Sha256(512)), "bn128",
+                         [[0] * 512, [1] * 512, [rng.randrange(2) for _ in range(512)]])
+    r2 = random.Random(77)
+    out["semaphore20"] = (lambda: Program(SemaphoreStyle(20)), "bn128",
+                          [H.semaphore_inputs(q, 20, r2)[0] for _ in range(2)])
+    return out
+
+
+def main():
+    result = {"generator": "tests/golden/make_golden.py", "runtime": "reference common/{main,calcwit}.cpp + generic/fr.cpp (GMP, no asm)",
+              "cases": {}}
+    for name, (mk, prime, rows) in cases().items():
+        d = tempfile.mkdtemp(prefix="golden_")
+        cp = compile_program(mk(), d, name.replace("_bls12381", ""), sym=False, strands=(1,))
+        ref_build.build_circuit(cp)
+        raw = b"".join(int(v).to_bytes(32, "little") for r in rows for v in r)
+        pre = os.path.join(d, "g_")
+        ref_build.run_loop(cp, raw, len(rows), 1, wtns_prefix=pre)
+        entries = []
+        for i, r in enumerate(rows):
+            b = open(pre + "%d.wtns" % i, "rb").read()
+            nw = int.from_bytes(b[72:76], "little")
+            head = [str(int.from_bytes(b[88 + 32 * k:120 + 32 * k], "little")) for k in range(min(nw, 8))]
+            e = {"inputs": [str(v) for v in r], "wtns_sha256": hashlib.sha256(b).hexdigest(), "wtns_len": len(b),
+                 "n_witness": nw, "witness_head": head}
+            if len(b) <= 4096:
+                e["wtns_hex"] = b.hex()
+            entries.append(e)
+        result["cases"][name] = {"prime": prime, "vectors": entries}
+        print(name, len(rows), "vectors", entries[0]["wtns_len"], "bytes each")
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_wtns.json"), "w") as f:
+        json.dump(result, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -186,6 +186,28 @@ def test_asserts_and_slow_path_ops(tmp_path):
     b.close(); c.close()
 
 
+@pytest.mark.parametrize("lanes", ["16", "32", "64"])
+@pytest.mark.parametrize("strands", ["1", "4", "16"])
+def test_every_strand_count_and_lane_width_gives_the_same_witnesses(tmp_path, lanes, strands, monkeypatch):
+    """cw_batch_create picks S and the instances per workgroup from the batch size; force every combination."""
+    monkeypatch.setenv("CW_LANES", lanes)
+    monkeypatch.setenv("CW_STRANDS", strands)
+    cp, c = _compile(tmp_path, Program(Poseidon(2)), "poseidon2")
+    B = 200
+    rng = np.random.default_rng(int(lanes) + int(strands))
+    ins = [[int.from_bytes(rng.bytes(32), "little") % c.q for _ in range(2)] for _ in range(B)]
+    b = c.batch(B)
+    assert (b.lanes, b.strands) == (int(lanes), int(strands))
+    b.set_inputs(ins)
+    b.run(); b.check_r1cs(); b.sync()
+    assert (b.status() == 0).all()
+    for i in (0, 15, 16, 31, 32, 63, 64, 65, 199):
+        assert b.signal(i, 1) == poseidon_hash(c.q, ins[i]), i
+    want, failed = eval_flat(c.q, cp.flat.n_signals, cp.flat.n_temps, cp.flat.constants, cp.flat.code, {2: ins[77][0], 3: ins[77][1]})
+    assert failed is None and b.witness(77) == want
+    b.close(); c.close()
+
+
 def test_bulk_witness_egress_equals_per_instance_egress(tmp_path):
     cp, c = _compile(tmp_path, Program(Poseidon(2)), "poseidon2")
     B = 333                                         # not a multiple of the 64-instance tile
