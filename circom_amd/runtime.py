@@ -25,10 +25,15 @@ class CwError(RuntimeError):
         self.code = code
 
 
+CLI_PATH = _HERE / "bin" / "cw_witness"     # process-level drop-in (csrc/cw_cli.cpp), built with the library
+
+
 def build_library(force: bool = False) -> Path:
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [_HERE / "csrc" / n for n in ("cw_kernels.hip", "cw_host.cpp", "cw_kernels.h", "cw_tape.h", "fp256.hip.h")]
-    if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= s.stat().st_mtime for s in srcs):
+    srcs = [_HERE / "csrc" / n for n in ("cw_kernels.hip", "cw_host.cpp", "cw_cli.cpp", "cw_kernels.h", "cw_tape.h",
+                                         "cw_r1cs_plan.h", "fp256.hip.h")]
+    outs = [LIB_PATH, CLI_PATH]
+    if not force and all(o.exists() and all(o.stat().st_mtime >= s.stat().st_mtime for s in srcs) for o in outs):
         return LIB_PATH
     subprocess.run(["make", "-C", str(_HERE / "csrc")], check=True, capture_output=True)
     return LIB_PATH

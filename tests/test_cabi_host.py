@@ -111,3 +111,23 @@ def test_json_nested_objects_are_qualified(tmp_path):
     b.set_inputs_json(0, '{"p": {"x": 1, "y": [2, 3]}, "pts": [{"v": 4}, {"v": 5}]}')
     assert [b.staged_input(0, k) for k in range(5)] == [1, 2, 3, 4, 5]
     b.close(); c.close()
+
+
+def test_cli_exists_and_fails_loudly_without_a_gpu(tmp_path):
+    """The process-level drop-in (csrc/cw_cli.cpp) is a client of the C ABI: on a box without a GPU it must report
+    the device error and exit non-zero — there is no CPU fallback to fall into."""
+    import subprocess
+    import torch
+    from circom_amd.compiler import compile_program
+    from circom_amd.frontend.dsl import Program
+    from circom_amd.circuits.basic import Multiplier2
+    assert rt.CLI_PATH.exists()
+    r = subprocess.run([str(rt.CLI_PATH)], capture_output=True, text=True)
+    assert r.returncode == 2 and "Usage" in r.stderr
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the computing path is covered by the -m gpu tests")
+    compile_program(Program(Multiplier2()), str(tmp_path), "multiplier2")
+    (tmp_path / "in.json").write_text('{"a": "3", "b": "11"}')
+    r = subprocess.run([str(rt.CLI_PATH), str(tmp_path / "multiplier2"), str(tmp_path / "in.json"), str(tmp_path / "o.wtns")],
+                       capture_output=True, text=True)
+    assert r.returncode == 2 and r.stderr.strip() and not (tmp_path / "o.wtns").exists()

@@ -306,3 +306,30 @@ def test_fp_mul_chain_matches_oracle(prime):
         for _ in range(iters):
             x = x * y * pow(1 << 261, -1, f.q) % f.q
         assert int.from_bytes(out[i].tobytes(), "little") == x
+
+
+def test_process_level_cli_matches_reference_cli_contract(tmp_path):
+    """`cw_witness <name> input.json out.wtns` = the reference's `./<name> input.json out.wtns` (main.cpp:336-373);
+    a JSON array runs as one batch.  Golden bytes come from the reference runtime (tests/golden)."""
+    import json
+    import subprocess
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_wtns.json")))["cases"]
+    assert rt.CLI_PATH.exists(), "cw_witness was not built (make -C circom_amd/csrc)"
+    cp = compile_program(Program(Multiplier2()), str(tmp_path), "multiplier2")
+    vec = gold["multiplier2"]["vectors"][0]
+    (tmp_path / "in.json").write_text(json.dumps({"a": vec["inputs"][0], "b": vec["inputs"][1]}))
+    r = subprocess.run([str(rt.CLI_PATH), str(tmp_path / "multiplier2"), str(tmp_path / "in.json"), str(tmp_path / "o.wtns")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "o.wtns").read_bytes().hex() == vec["wtns_hex"]
+    # a batch: JSON array, one .wtns per instance; Num2Bits(16) rejects 65536 (instance 2) like the reference's assert
+    cp = compile_program(Program(Num2Bits(16)), str(tmp_path), "num2bits16")
+    vecs = gold["num2bits16"]["vectors"]
+    rows = [{"in": vecs[0]["inputs"][0]}, {"in": vecs[2]["inputs"][0]}, {"in": "65536"}, {"in": vecs[3]["inputs"][0]}]
+    (tmp_path / "many.json").write_text(json.dumps(rows))
+    r = subprocess.run([str(rt.CLI_PATH), str(tmp_path / "num2bits16"), str(tmp_path / "many.json"), str(tmp_path / "w_%d.wtns")],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "instance 2: Failed assert" in r.stderr
+    for k, v in ((0, vecs[0]), (1, vecs[2]), (3, vecs[3])):
+        assert (tmp_path / ("w_%d.wtns" % k)).read_bytes().hex() == v["wtns_hex"]
+    assert not (tmp_path / "w_2.wtns").exists()
