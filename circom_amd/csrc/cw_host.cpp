@@ -602,7 +602,7 @@ struct cw_batch {
     uint32_t *d_lconsts = nullptr;
     uint32_t *d_consts = nullptr, *d_w2s = nullptr, *d_status = nullptr, *d_first_bad = nullptr;
     // R1CS check plan (cw_r1cs_plan.h) on the device; r1_entries != 0 selects the LDS-staged kernel
-    uint32_t *d_rctab = nullptr, *d_pchunk = nullptr, *d_prec = nullptr, *d_pterms = nullptr, *d_prow = nullptr;
+    uint32_t *d_rctab = nullptr, *d_rctab29 = nullptr, *d_pchunk = nullptr, *d_prec = nullptr, *d_pterms = nullptr, *d_prow = nullptr;
     uint32_t r1_chunks = 0, r1_entries = 0;
     void *d_in = nullptr;          // AoS staging [batch][n_in][32]
     void *d_gather = nullptr;      // [n_witness][32]
@@ -634,7 +634,7 @@ extern "C" void cw_batch_free(cw_batch *b) {
     hipSetDevice(b->device);
     hipStreamSynchronize(b->stream);
     void *ptrs[] = {b->d_V, b->d_rows, b->d_stream_off, b->d_extras, b->d_extra_off, b->d_terms, b->d_term_off, b->d_lconsts, b->d_consts, b->d_w2s, b->d_status, b->d_first_bad,
-                    b->d_rctab, b->d_pchunk, b->d_prec, b->d_pterms, b->d_prow,
+                    b->d_rctab, b->d_rctab29, b->d_pchunk, b->d_prec, b->d_pterms, b->d_prow,
                     b->d_in, b->d_gather, b->d_bulk};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -799,6 +799,20 @@ extern "C" int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *
     TRY(hipMalloc((void **)&b->d_first_bad, (size_t)b->Bp * 4));
     if (c->n_constraints) {
         TRY(upload(&b->d_rctab, c->r_ctab, b->stream));
+        {   // the same coefficients as 9 x 29-bit limbs, the form the multiplier consumes
+            std::vector<uint32_t> t29(c->r_ctab.size() / 8 * 9);
+            for (size_t e = 0; e < c->r_ctab.size() / 8; e++) {
+                uint64_t w[4];
+                memcpy(w, &c->r_ctab[e * 8], 32);
+                for (int k = 0; k < 9; k++) {
+                    unsigned bit = 29 * k, wi = bit / 64, sh = bit % 64;
+                    uint64_t v = w[wi] >> sh;
+                    if (sh > 35 && wi + 1 < 4) v |= w[wi + 1] << (64 - sh);
+                    t29[e * 9 + k] = (uint32_t)(v & 0x1FFFFFFFu);
+                }
+            }
+            TRY(upload(&b->d_rctab29, t29, b->stream));
+        }
         const char *mode = getenv("CW_R1CS_MODE");
         cwplan::Plan p;
         if (mode && !strcmp(mode, "staged")) {
@@ -1136,10 +1150,10 @@ extern "C" int cw_check_r1cs(cw_batch *b) {
     if (c->n_constraints == 0) return fail(CW_ESTATE, "no .r1cs was loaded for this circuit");
     HIPCHK(hipSetDevice(b->device));
     if (b->r1_entries)
-        HIPCHK(cwk_r1cs_staged(b->stream, b->d_pchunk, b->r1_chunks, b->d_prec, b->d_pterms, b->d_rctab, b->d_prow,
+        HIPCHK(cwk_r1cs_staged(b->stream, b->d_pchunk, b->r1_chunks, b->d_prec, b->d_pterms, b->d_rctab, b->d_rctab29, b->d_prow,
                                b->r1_entries, b->d_V, b->Bp, b->batch, b->d_status, b->d_first_bad, c->P));
     else
-        HIPCHK(cwk_r1cs(b->stream, b->d_pchunk, b->r1_chunks, b->d_pterms, b->d_rctab, b->d_prow, b->d_V, b->Bp, b->batch,
+        HIPCHK(cwk_r1cs(b->stream, b->d_pchunk, b->r1_chunks, b->d_pterms, b->d_rctab, b->d_rctab29, b->d_prow, b->d_V, b->Bp, b->batch,
                         b->d_status, b->d_first_bad, c->P));
     return CW_OK;
 }

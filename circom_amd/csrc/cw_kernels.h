@@ -12,10 +12,10 @@ hipError_t cwk_eval(hipStream_t s, bool full, bool wide_linsum, const CwDRow *ro
                     uint32_t n_strands, uint32_t n_lds, void *V, const uint32_t *consts, const uint32_t *lconsts,
                     uint32_t Bp, uint32_t batch, uint32_t lanes, uint32_t *status, const FpParams &P);
 hipError_t cwk_r1cs(hipStream_t s, const uint32_t *chunk, uint32_t n_chunks, const uint32_t *terms, const uint32_t *ctab,
-                    const uint32_t *row_orig, const void *V, uint32_t Bp, uint32_t batch, uint32_t *status,
+                    const uint32_t *ctab29, const uint32_t *row_orig, const void *V, uint32_t Bp, uint32_t batch, uint32_t *status,
                     uint32_t *first_bad, const FpParams &P);
 hipError_t cwk_r1cs_staged(hipStream_t s, const uint32_t *chunk, uint32_t n_chunks, const uint32_t *rec, const uint32_t *terms,
-                           const uint32_t *ctab, const uint32_t *row_orig, uint32_t entries, const void *V, uint32_t Bp,
+                           const uint32_t *ctab, const uint32_t *ctab29, const uint32_t *row_orig, uint32_t entries, const void *V, uint32_t Bp,
                            uint32_t batch, uint32_t *status, uint32_t *first_bad, const FpParams &P);
 hipError_t cwk_gather(hipStream_t s, const void *V, const uint32_t *w2s, uint32_t n_wit, uint32_t Bp, uint32_t instance,
                       void *out);

@@ -488,8 +488,8 @@ __device__ __forceinline__ fe fe_pick(bool c, const fe &a, const fe &b) {
     return r;
 }
 __device__ __forceinline__ void r1_term(const fe &wv, uint32_t w0, uint32_t ci, R1State &s,
-                                        const uint32_t *__restrict__ ctab, const uint32_t *__restrict__ row_orig,
-                                        const FpParams &P) {
+                                        const uint32_t *__restrict__ ctab, const uint32_t *__restrict__ ctab29,
+                                        const uint32_t *__restrict__ row_orig, const FpParams &P) {
     const uint32_t acc = (w0 >> 27) & 3u, endk = (w0 >> 29) & 3u;
     bool ok = true;
     if (endk == 3) ok = fe_eq(s.cur, wv);                           // second wire of a pure equality row: x == y
@@ -497,7 +497,11 @@ __device__ __forceinline__ void r1_term(const fe &wv, uint32_t w0, uint32_t ci, 
     else {
         fe w = wv;
         if (ci >> 31) w = c_load(ctab, ci & 0x7FFFFFFFu);           // coefficient on the constant-1 wire
-        else if (ci >= 2) w = fe_mmul(w, c_load(ctab, ci), P);
+        else if (ci >= 2) {                                         // w * c: ctab29 holds c*R' as 9 x 29-bit limbs
+            fe29 cc;
+            FE_UNROLL for (int k = 0; k < 9; k++) cc.l[k] = ctab29[(size_t)ci * 9 + k];
+            w = fe_from29(fe29_mmul(fe_to29(w), cc, P));
+        }
         s.cur = (ci == 1) ? fe_sub(s.cur, w, P) : fe_add(s.cur, w, P);
         if ((w0 >> 31) && acc != 2) {                               // last term of part A or B
             s.A = fe_pick(acc == 0, s.cur, s.A);
@@ -505,7 +509,12 @@ __device__ __forceinline__ void r1_term(const fe &wv, uint32_t w0, uint32_t ci, 
             s.cur = fe_zero();
         }
         if (endk == 2) ok = fe_is_zero(s.cur);                      // A or B empty: linear row, C must vanish
-        else if (endk == 1) ok = fe_eq(fe_mmul(s.A, s.B, P), fe_mmul(s.cur, fe_small(1), P));   // A*B/R' == C/R'
+        else if (endk == 1) {                                       // A*B == C  <=>  (A*B + (q - C)) / R' == 0 (mod q)
+            const fe29 z = fe29_mmul_add(fe_to29(s.A), fe_to29(s.B), fe_to29(fe_neg(s.cur, P)), P);
+            uint32_t o = 0;
+            FE_UNROLL for (int k = 0; k < 9; k++) o |= z.l[k];
+            ok = (o == 0);
+        }
     }
     if (endk) {
         if (__any(!ok)) {
@@ -525,7 +534,7 @@ __device__ __forceinline__ void r1_finish(const R1State &s, uint32_t i, uint32_t
 
 __global__ void __launch_bounds__(64)
 cw_r1cs_stream_kernel(const uint4 *__restrict__ chunk, const uint2 *__restrict__ terms, const uint32_t *__restrict__ ctab,
-                      const uint32_t *__restrict__ row_orig, const uint4 *__restrict__ V, uint32_t Bp, uint32_t batch,
+                      const uint32_t *__restrict__ ctab29, const uint32_t *__restrict__ row_orig, const uint4 *__restrict__ V, uint32_t Bp, uint32_t batch,
                       uint32_t *status, uint32_t *first_bad, FpParams P) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;               // < Bp
     const uint4 ch = chunk[blockIdx.y];                             // first term, n terms, -, first row
@@ -540,7 +549,7 @@ cw_r1cs_stream_kernel(const uint4 *__restrict__ chunk, const uint2 *__restrict__
     for (uint32_t k = 0; k < ch.y; k++) {
         const uint2 t1 = tp[k + 1];
         const fe w1 = v_load(V, t1.x & 0x3FFFFFFu, Bp, i);
-        r1_term(w0, t0.x, t0.y, s, ctab, row_orig, P);
+        r1_term(w0, t0.x, t0.y, s, ctab, ctab29, row_orig, P);
         t0 = t1; w0 = w1;
     }
     r1_finish(s, i, batch, status, first_bad);
@@ -572,9 +581,9 @@ __device__ __forceinline__ void r1_issue(uint32_t lw, uint64_t vbase, uint64_t s
 
 __global__ void __launch_bounds__(64)
 cw_r1cs_staged_kernel(const uint4 *__restrict__ chunk, const uint2 *__restrict__ rec, const uint2 *__restrict__ terms,
-                      const uint32_t *__restrict__ ctab, const uint32_t *__restrict__ row_orig,
-                      const uint4 *__restrict__ V, uint32_t Bp, uint32_t batch, uint32_t *status, uint32_t *first_bad,
-                      FpParams P) {
+                      const uint32_t *__restrict__ ctab, const uint32_t *__restrict__ ctab29,
+                      const uint32_t *__restrict__ row_orig, const uint4 *__restrict__ V, uint32_t Bp, uint32_t batch,
+                      uint32_t *status, uint32_t *first_bad, FpParams P) {
     extern __shared__ uint4 r1_lds[];
     const uint32_t lane = threadIdx.x;
     const uint32_t i = blockIdx.x * 64 + lane;                      // < Bp
@@ -603,7 +612,7 @@ cw_r1cs_staged_kernel(const uint4 *__restrict__ chunk, const uint2 *__restrict__
             fe w;
             w.v[0] = lo.x; w.v[1] = lo.y; w.v[2] = lo.z; w.v[3] = lo.w;
             w.v[4] = hi.x; w.v[5] = hi.y; w.v[6] = hi.z; w.v[7] = hi.w;
-            r1_term(w, tw.x, tw.y, s, ctab, row_orig, P);
+            r1_term(w, tw.x, tw.y, s, ctab, ctab29, row_orig, P);
             tw = nx;
         }
     }
@@ -750,16 +759,16 @@ hipError_t cwk_eval(hipStream_t s, bool full, bool wide_linsum, const CwDRow *ro
     return hipGetLastError();
 }
 hipError_t cwk_r1cs(hipStream_t s, const uint32_t *chunk, uint32_t n_chunks, const uint32_t *terms, const uint32_t *ctab,
-                    const uint32_t *row_orig, const void *V, uint32_t Bp, uint32_t batch, uint32_t *status,
+                    const uint32_t *ctab29, const uint32_t *row_orig, const void *V, uint32_t Bp, uint32_t batch, uint32_t *status,
                     uint32_t *first_bad, const FpParams &P) {
     if (n_chunks == 0) return hipSuccess;
     dim3 g((batch + 63) / 64, n_chunks);
-    hipLaunchKernelGGL(cw_r1cs_stream_kernel, g, dim3(64), 0, s, (const uint4 *)chunk, (const uint2 *)terms, ctab, row_orig,
+    hipLaunchKernelGGL(cw_r1cs_stream_kernel, g, dim3(64), 0, s, (const uint4 *)chunk, (const uint2 *)terms, ctab, ctab29, row_orig,
                        (const uint4 *)V, Bp, batch, status, first_bad, P);
     return hipGetLastError();
 }
 hipError_t cwk_r1cs_staged(hipStream_t s, const uint32_t *chunk, uint32_t n_chunks, const uint32_t *rec, const uint32_t *terms,
-                           const uint32_t *ctab, const uint32_t *row_orig, uint32_t entries, const void *V, uint32_t Bp,
+                           const uint32_t *ctab, const uint32_t *ctab29, const uint32_t *row_orig, uint32_t entries, const void *V, uint32_t Bp,
                            uint32_t batch, uint32_t *status, uint32_t *first_bad, const FpParams &P) {
     if (n_chunks == 0) return hipSuccess;
     const uint32_t lds_bytes = entries * 2048u;
@@ -770,7 +779,7 @@ hipError_t cwk_r1cs_staged(hipStream_t s, const uint32_t *chunk, uint32_t n_chun
     }
     dim3 g((batch + 63) / 64, n_chunks);
     hipLaunchKernelGGL(cw_r1cs_staged_kernel, g, dim3(64), lds_bytes, s, (const uint4 *)chunk, (const uint2 *)rec,
-                       (const uint2 *)terms, ctab, row_orig, (const uint4 *)V, Bp, batch, status, first_bad, P);
+                       (const uint2 *)terms, ctab, ctab29, row_orig, (const uint4 *)V, Bp, batch, status, first_bad, P);
     return hipGetLastError();
 }
 hipError_t cwk_gather(hipStream_t s, const void *V, const uint32_t *w2s, uint32_t n_wit, uint32_t Bp, uint32_t instance,

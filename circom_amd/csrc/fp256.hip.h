@@ -197,6 +197,37 @@ __device__ __forceinline__ fe29 fe29_mmul(const fe29 &a, const fe29 &b, const Fp
     return r;
 }
 
+// (a*b + c) * R'^-1 mod q with c < 2^261 given as limbs: the addend enters the low columns before the reduction.
+// Used by the R1CS check: A*B == C  <=>  (A*B + (q - C)) * R'^-1 == 0, one product instead of two.
+__device__ __forceinline__ fe29 fe29_mmul_add(const fe29 &a, const fe29 &b, const fe29 &cadd, const FpParams &P) {
+    uint64_t acc[18];
+    FE_UNROLL for (int i = 0; i < 9; i++) acc[i] = cadd.l[i];
+    FE_UNROLL for (int i = 9; i < 18; i++) acc[i] = 0;
+    FE_UNROLL for (int i = 0; i < 9; i++) {
+        const uint32_t bi = b.l[i];
+        FE_UNROLL for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)a.l[j] * bi;
+        const uint32_t m = ((uint32_t)acc[i] * P.np29) & FE29_MASK;
+        FE_UNROLL for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)m * P.q29[j];
+        acc[i + 1] += acc[i] >> 29;
+    }
+    fe29 r;
+    uint64_t c = 0;
+    FE_UNROLL for (int k = 0; k < 9; k++) {
+        c += acc[9 + k];
+        r.l[k] = (uint32_t)c & FE29_MASK;
+        c >>= 29;
+    }
+    fe29 d;
+    int32_t br = 0;
+    FE_UNROLL for (int k = 0; k < 9; k++) {
+        int32_t t = (int32_t)r.l[k] - (int32_t)P.q29[k] + br;
+        d.l[k] = (uint32_t)t & FE29_MASK;
+        br = t >> 31;
+    }
+    FE_UNROLL for (int k = 0; k < 9; k++) r.l[k] = br ? r.l[k] : d.l[k];
+    return r;
+}
+
 // ---- dot products with one reduction ---------------------------------------------------------------------------
 // acc (17 columns + carry) += a * c, the 81 unreduced partial products; c = wave-uniform limbs (SGPRs)
 __device__ __forceinline__ void fe29_mac(uint64_t acc[18], const fe29 &a, const uint32_t *c29) {
