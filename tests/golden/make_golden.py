@@ -49,6 +49,11 @@ def cases():
     out["iszero"] = (lambda: Program(IsZero()), "bn128", [[0], [1], [q - 1], [rng.randrange(q)]])
     out["sha256_512"] = (lambda: Program(Sha256(512)), "bn128",
                          [[0] * 512, [1] * 512, [rng.randrange(2) for _ in range(512)]])
+    from circom_amd.circuits.opzoo import OperatorZoo
+    half = q >> 1
+    out["opzoo"] = (lambda: Program(OperatorZoo()), "bn128",
+                    [[3, 11], [0, 0], [q - 1, q - 1], [half + 1, 255], [1 << 200, q - 3], [q - 2, 254], [12345678901234567890, 64],
+                     [rng.randrange(q), rng.randrange(q)], [rng.randrange(q), rng.randrange(256)]])
     r2 = random.Random(77)
     out["semaphore20"] = (lambda: Program(SemaphoreStyle(20)), "bn128",
                           [H.semaphore_inputs(q, 20, r2)[0] for _ in range(2)])

@@ -53,7 +53,10 @@ def test_gpu_reproduces_reference_wtns(name, tmp_path):
     vecs = GOLD["cases"][name]["vectors"]
     b = c.batch(len(vecs))
     b.set_inputs([[int(v) for v in vec["inputs"]] for vec in vecs])
-    b.run(); b.check_r1cs(); b.sync()
+    b.run()
+    if c.n_constraints:
+        b.check_r1cs()
+    b.sync()
     assert (b.status() == 0).all()
     for i, vec in enumerate(vecs):
         p = tmp_path / ("g%d.wtns" % i)
