@@ -181,6 +181,7 @@ struct HashEntry {
 
 struct Variant {               // one lowering of the schedule for a given strand count
     uint32_t n_strands = 1, n_tslots = 0, n_lds = 0;
+    uint32_t n_active = 1;         // strands that carry work (a 3-lane circuit leaves 13 of 16 strands with barriers only)
     bool wide_linsum = false;      // schedule dominated by long small-coefficient sums -> 4 operand loads in flight
     std::vector<CwRow> rows;
     std::vector<uint32_t> stream_off, extras, extra_off, term_off, terms;   // terms: 4 x u32 each
@@ -338,6 +339,15 @@ static int load_tape(cw_circuit *c, const char *path) {
             if (op == D_MUL2) mm += 2;
             if (op == D_DOTC || op == D_LINSUM) mm += r.a;           // one product per term
             if (op == D_INV || op == D_IDIV || op == D_MOD || op == D_POW) c->need_full = true;
+        }
+        var.n_active = 0;
+        for (uint32_t st = 0; st < var.n_strands; st++) {
+            bool work = false;
+            for (uint32_t r = var.stream_off[st]; r < var.stream_off[st + 1] && !work; r++) {
+                uint32_t op = var.rows[r].w0 & 0xFF;
+                work = (op != D_BARRIER && op != D_NOP);
+            }
+            var.n_active += work;
         }
         if (v == 0) {
             c->n_rows = nrows;
@@ -665,24 +675,35 @@ extern "C" int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *
     b->batch = batch;
     b->Bp = (batch + 255) / 256 * 256;
     b->stream = (hipStream_t)stream;
-    // pick the schedule variant: as many strands as it takes to put >= ~4 waves on every SIMD (1024 SIMDs),
-    // but no more (barriers are not free).  Measured crossover on Poseidon(2): S=4 wins up to 2048 groups,
-    // S=1 from 4096 groups on.  CW_STRANDS overrides.
+    // pick the schedule variant.  Up to 8192 waves (two rounds of the chip's 4096 wave slots) a variant with more
+    // strands that carry work shortens the critical path of every instance group; a variant whose extra strands
+    // only wait at barriers (Poseidon(2) has 3 independent lanes: S = 16 is S = 4 plus 12 idle waves) just takes
+    // wave slots.  Measured on Poseidon(2): 512 groups S = 4: 0.81 ms, S = 16: 1.39 ms; 2048 groups S = 4: 2.12 ms,
+    // S = 1: 2.53 ms; 4096 groups: S = 1 wins.  CW_STRANDS overrides.
     {
         uint64_t groups = (batch + 63) / 64;
-        uint32_t want = (uint32_t)std::max<uint64_t>(1, 8192 / groups);
-        if (const char *e = getenv("CW_STRANDS")) want = (uint32_t)std::max(1, atoi(e));
-        const Variant *best = &c->variants[0];
+        const Variant *best = nullptr;
         for (auto &v : c->variants) {
-            bool better = (v.n_strands <= want && v.n_strands > best->n_strands) ||
-                          (best->n_strands > want && v.n_strands < best->n_strands);
-            if (better) best = &v;
+            if (groups * v.n_strands > 8192 && v.n_strands > 1) continue;
+            if (!best || v.n_active > best->n_active || (v.n_active == best->n_active && v.n_strands < best->n_strands))
+                best = &v;
+        }
+        if (!best) best = &c->variants[0];
+        if (const char *e = getenv("CW_STRANDS")) {
+            uint32_t want = (uint32_t)std::max(1, atoi(e));
+            best = &c->variants[0];
+            for (auto &v : c->variants) {
+                bool better = (v.n_strands <= want && v.n_strands > best->n_strands) ||
+                              (best->n_strands > want && v.n_strands < best->n_strands);
+                if (better) best = &v;
+            }
         }
         b->var = best;
-        // instances per workgroup: a small batch of a long schedule is spread over more workgroups (more CUs, each
-        // with its own path to memory) by leaving the upper lanes of the waves idle, until ~4 waves per SIMD exist
+        // instances per workgroup: when there are fewer workgroups than CUs (256), a batch is spread over more of them
+        // by leaving the upper lanes of the waves idle - never beyond one workgroup per CU, because idle lanes
+        // still cost VALU issue (measured on Poseidon(2): 32 lanes are 16 % slower as soon as every CU is busy)
         uint32_t lanes = 64;
-        while (lanes > 16 && ((uint64_t)batch + lanes - 1) / lanes * best->n_strands < 4096) lanes >>= 1;
+        while (lanes > 16 && 2 * (((uint64_t)batch + lanes - 1) / lanes) <= 256) lanes >>= 1;
         if (const char *e = getenv("CW_LANES")) {
             int v = atoi(e);
             if (v == 16 || v == 32 || v == 64) lanes = (uint32_t)v;
