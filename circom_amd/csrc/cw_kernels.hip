@@ -74,8 +74,11 @@ __global__ void __launch_bounds__(CW_BLOCK) cw_ingest_kernel(const uint4 *__rest
 //      operand — so the loaded registers ARE the loop-carried registers and nothing forces an early wait;
 //  (2) pure copies never load: they are extra destinations of the row that produced the value, taken
 //      from the strand's extra-destination table (scalar loads issued before the row's arithmetic);
-//  (3) a LIGHT barrier only orders LDS traffic (s_waitcnt lgkmcnt(0) + s_barrier): global stores stay in
-//      flight across it.  Only FULL barriers (hand-off through global memory) drain vmcnt.
+//  (3) two barrier flavours are encoded: LIGHT (workgroup-scope release/acquire fences around s_barrier) where the
+//      strands only exchanged LDS slots, FULL (__syncthreads) where a value crosses strands through the value
+//      table.  On gfx950 both compile to `s_waitcnt lgkmcnt(0); s_barrier` (checked in the ISA): the waves of a
+//      workgroup share the CU's vector L1, which orders one wave's earlier store before another wave's later
+//      load, so neither drains vmcnt and global stores stay in flight across every barrier.
 // FULL_OPS selects the variant that also carries the slow-path operators (INV/IDIV/MOD/POW).
 // -DCW_PROFILE (tools/profile_ops.sh, never the product build): workgroup 0 accumulates the shader-clock time of
 // every interpreter step per (strand, opcode), operand waits included.
@@ -270,7 +273,7 @@ __device__ __forceinline__ void eval_step(const CwDRow &row, const fe &xa, const
     const uint32_t nx = (row.w0 >> SH_NX) & 0xFFF;
     if (op == D_BARRIER) {                                           // nothing is prefetched across a barrier
         if (row.aux) {
-            __syncthreads();                                         // FULL: also drains this wave's global stores
+            __syncthreads();                                         // FULL: values cross strands through the value table
         } else {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // LDS writes of this wave are done ...
             __builtin_amdgcn_s_barrier();
@@ -406,7 +409,7 @@ __device__ __forceinline__ void eval_step(const CwDRow &row, const fe &xa, const
 //    body is two interpreter steps with the sets swapped: no rotation moves).  Legal because the lowering
 //    encodes any operand produced by the preceding row as kind PREV = register forwarding;
 //  * pure copies never load: they are extra destinations of the row that produced the value;
-//  * a LIGHT barrier only orders LDS traffic; only FULL barriers (hand-off through global memory) drain vmcnt;
+//  * barriers never drain vmcnt (see (3) above): global stores stay in flight across them;
 //  * products of small signed values take the per-wave short path (fp256.hip.h).
 // FULL_OPS selects the variant that also carries the slow-path operators (INV/IDIV/MOD/POW).
 template <bool FULL_OPS, int LW>
