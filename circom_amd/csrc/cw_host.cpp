@@ -165,6 +165,9 @@ static FpParams make_params(const U256 &q) {
         uint64_t v = q.w[w] >> sh;
         if (sh > 35 && w + 1 < 4) v |= q.w[w + 1] << (64 - sh);
         P.q29[k] = (uint32_t)(v & 0x1FFFFFFFu);
+        uint64_t v2 = r2.w[w] >> sh;
+        if (sh > 35 && w + 1 < 4) v2 |= r2.w[w + 1] << (64 - sh);
+        P.r2_29[k] = (uint32_t)(v2 & 0x1FFFFFFFu);
     }
     P.qbits = u256_bits(q);
     unsigned topbits = P.qbits - 224;             // bits used in the top 32-bit limb

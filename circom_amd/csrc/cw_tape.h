@@ -52,6 +52,7 @@ struct FpParams {
     uint32_t r2[8];     // R'^2 mod q                                 (role of Fr_rawR2, generic/fr.cpp:14)
     uint32_t one_m[8];  // R' mod q  (1 in Montgomery form)
     uint32_t q29[9];    // modulus as 9 x 29-bit limbs
+    uint32_t r2_29[9];  // R'^2 mod q as 9 x 29-bit limbs (scalar operands of the second product of a canonical multiply)
     uint32_t np29;      // -q^-1 mod 2^29
     uint32_t qbits;     // bit length of q
     uint32_t topmask;   // mask of the top limb = lboMask >> 32     (generic/fr.cpp:16)

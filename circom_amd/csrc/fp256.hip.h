@@ -268,7 +268,9 @@ __device__ __forceinline__ fe fe_mmul(const fe &a, const fe &b, const FpParams &
 // canonical product a*b mod q = MMUL(MMUL(a,b), R'^2); the intermediate never leaves the 29-bit limb form
 __device__ __forceinline__ fe fe_mul2(const fe &a, const fe &b, const FpParams &P) {
     const fe29 t = fe29_mmul(fe_to29(a), fe_to29(b), P);
-    return fe_from29(fe29_mmul(t, fe_to29(fe_from(P.r2)), P));
+    fe29 r2;                                                        // wave-uniform limbs: stay in SGPRs
+    FE_UNROLL for (int k = 0; k < 9; k++) r2.l[k] = P.r2_29[k];
+    return fe_from29(fe29_mmul(t, r2, P));
 }
 
 // ---- run-time short path for products of small signed values -------------------------------------------
@@ -577,7 +579,9 @@ __device__ __noinline__ fe fe_inv(const fe &y, const FpParams &P) {
 }
 // x^y with a per-lane exponent (Fr_pow / mpz_powm, generic/fr.cpp:2877-2893; 0^0 = 1)
 __device__ __noinline__ fe fe_pow(const fe &x, const fe &y, const FpParams &P) {
-    const fe29 xm = fe29_mmul(fe_to29(x), fe_to29(fe_from(P.r2)), P);
+    fe29 r2;
+    FE_UNROLL for (int k = 0; k < 9; k++) r2.l[k] = P.r2_29[k];
+    const fe29 xm = fe29_mmul(fe_to29(x), r2, P);
     fe29 r = fe_to29(fe_from(P.one_m));
     FE_UNROLL for (int w = 7; w >= 0; w--) {
         const uint32_t ew = y.v[w];
