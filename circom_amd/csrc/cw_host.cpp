@@ -144,6 +144,14 @@ static bool str_to_fe(const char *s, size_t n, unsigned base, const U256 &q, U25
     return true;
 }
 
+// The device field code is written for the reference's 4-limb primes (bn128, bls12381, bls12377, grumpkin, pallas,
+// vesta, secq256r1: 253..256 bits, program_structure/src/utils/constants.rs:3-13).  The 64-bit Goldilocks runtime
+// (c_elements/common64, goldilocks/fr.hpp) is a different code path of the reference and is out of scope here.
+static bool prime_supported(const U256 &q) {
+    unsigned bits = u256_bits(q);
+    return bits >= 225 && bits <= 256 && (q.w[0] & 1);
+}
+
 static FpParams make_params(const U256 &q) {
     FpParams P;
     memset(&P, 0, sizeof(P));
@@ -370,6 +378,9 @@ static int load_tape(cw_circuit *c, const char *path) {
         while (c->hashmap[p].signalid != 0) p = (p + 1) % hsize;
         c->hashmap[p] = HashEntry{hsh, o.first, c->input_names[o.second].second};
     }
+    if (!prime_supported(c->q))
+        return fail(CW_EINVAL, "unsupported prime: the device field code handles the 253..256-bit primes of circom "
+                               "(4 x 64-bit limbs); the 64-bit Goldilocks runtime is out of scope");
     c->P = make_params(c->q);
     return CW_OK;
 }
@@ -1300,11 +1311,12 @@ extern "C" void *cw_device_values(cw_batch *b, uint64_t *n_bytes, uint32_t *padd
 extern "C" int cw_fp_mul_bench(const uint8_t prime_le32[32], int device, uint32_t n, uint32_t iters, const uint8_t *a,
                                const uint8_t *b, uint8_t *out, float *ms) {
     if (!prime_le32 || !a || !b || !out || n == 0) return fail(CW_EINVAL, "bad argument");
+    U256 q;
+    memcpy(q.w, prime_le32, 32);
+    if (!prime_supported(q)) return fail(CW_EINVAL, "unsupported prime (need an odd prime of 225..256 bits)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(CW_EDEVICE, "no HIP device available");
     HIPCHK(hipSetDevice(device));
-    U256 q;
-    memcpy(q.w, prime_le32, 32);
     FpParams P = make_params(q);
     void *da, *db, *dout;
     size_t bytes = (size_t)n * 32;
@@ -1336,11 +1348,12 @@ extern "C" int cw_fp_mul_bench(const uint8_t prime_le32[32], int device, uint32_
 extern "C" int cw_fp_op(const uint8_t prime_le32[32], int device, uint32_t dop, uint32_t n, const uint8_t *a,
                         const uint8_t *b, const uint8_t *c, uint8_t *out, uint32_t *status) {
     if (!prime_le32 || !a || !b || !c || !out || !status || n == 0) return fail(CW_EINVAL, "bad argument");
+    U256 q;
+    memcpy(q.w, prime_le32, 32);
+    if (!prime_supported(q)) return fail(CW_EINVAL, "unsupported prime (need an odd prime of 225..256 bits)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(CW_EDEVICE, "no HIP device available");
     HIPCHK(hipSetDevice(device));
-    U256 q;
-    memcpy(q.w, prime_le32, 32);
     FpParams P = make_params(q);
     void *da, *db, *dc, *dout;
     uint32_t *dst;

@@ -839,6 +839,10 @@ X_TMP, X_LDS = 1 << 31, 1 << 30       # flags of an entry of the extra-destinati
 
 def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
     q = fc.fp.q
+    if not 225 <= q.bit_length() <= 256:
+        raise ValueError("hip_elements targets circom's 253..256-bit primes (4 x 64-bit limbs); prime %s has %d bits "
+                         "(the 64-bit Goldilocks runtime is a separate code path of the reference, out of scope)"
+                         % (fc.prime, q.bit_length()))
     n_signals = fc.n_signals
     rows, dconsts, n_vtemps, cid, plain = _expand(fc)
     rows, n_vtemps, n_inv_batches = _batch_inversions(rows, n_vtemps, cid)

@@ -44,3 +44,19 @@ def test_truncated_and_corrupt_files_are_rejected(tmp_path):
     with pytest.raises(rt.CwError) as e:
         rt.Circuit(cp.tape_path, cp.dat_path, other.r1cs_path)
     assert "prime" in str(e.value)
+
+
+def test_small_primes_are_rejected_not_miscomputed(tmp_path):
+    """The device field code assumes circom's 253..256-bit primes (the short-path sums rely on q > 2^192); Goldilocks
+    (64-bit, a separate runtime in the reference) must be refused by the lowering and by the library."""
+    import numpy as np
+    from circom_amd.frontend.dsl import Program
+    from circom_amd.frontend.flatten import flatten
+    from circom_amd.hip_elements.lower import lower
+    from circom_amd.circuits.basic import Multiplier2
+    with pytest.raises(ValueError, match="Goldilocks"):
+        lower(flatten(Program(Multiplier2(), prime="goldilocks")))
+    gold = 0xFFFFFFFF00000001
+    a = np.zeros((4, 32), dtype=np.uint8)
+    with pytest.raises(rt.CwError, match="unsupported prime"):
+        rt.fp_mul_bench(gold, a, a, 4, device=0)
