@@ -250,6 +250,8 @@ static int load_tape(cw_circuit *c, const char *path) {
     const uint32_t *m = (const uint32_t *)(b.data() + off);
     off += 48;
     c->n_signals = m[0];
+    if (c->n_signals == 0 || c->n_signals >= (1u << cwplan::SLOT_BITS))      // slot ids travel in 26-bit fields
+        return fail(CW_EIO, "tape: signal count out of range (1 .. 2^26 - 1)");
     c->n_witness = m[1];
     c->n_consts = m[2];
     c->input_start = m[3];
