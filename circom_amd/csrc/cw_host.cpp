@@ -192,6 +192,7 @@ struct HashEntry {
 
 struct Variant {               // one lowering of the schedule for a given strand count
     uint32_t n_strands = 1, n_tslots = 0, n_lds = 0;
+    uint32_t prio_mask = 0;        // strands whose share of the work is within 20 % of the heaviest one (s_setprio)
     uint32_t n_active = 1;         // strands that carry work (a 3-lane circuit leaves 13 of 16 strands with barriers only)
     bool wide_linsum = false;      // schedule dominated by long small-coefficient sums -> 4 operand loads in flight
     std::vector<CwRow> rows;
@@ -354,14 +355,26 @@ static int load_tape(cw_circuit *c, const char *path) {
             if (op == D_INV || op == D_IDIV || op == D_MOD || op == D_POW) c->need_full = true;
         }
         var.n_active = 0;
+        std::vector<double> load(var.n_strands, 0.0);              // rough instruction counts (/32), as in lower.py
         for (uint32_t st = 0; st < var.n_strands; st++) {
-            bool work = false;
-            for (uint32_t r = var.stream_off[st]; r < var.stream_off[st + 1] && !work; r++) {
-                uint32_t op = var.rows[r].w0 & 0xFF;
-                work = (op != D_BARRIER && op != D_NOP);
+            for (uint32_t r = var.stream_off[st]; r < var.stream_off[st + 1]; r++) {
+                const uint32_t op = var.rows[r].w0 & 0xFF;
+                if (op == D_BARRIER || op == D_NOP) continue;
+                double cst = 2.0;
+                if (op == D_MUL2) cst = 20.0;
+                else if (op == D_MMUL || op == D_MULC || op == D_MADD || op == D_MADDC) cst = 10.0;
+                else if (op == D_DOTC) cst = 5.0 + 4.5 * var.rows[r].a;
+                else if (op == D_LINSUM) cst = 3.0 + 1.2 * var.rows[r].a;
+                else if (op == D_INV) cst = 1000.0;
+                else if (op == D_POW || op == D_IDIV || op == D_MOD) cst = 6000.0;
+                load[st] += cst;
             }
-            var.n_active += work;
+            var.n_active += load[st] > 0;
         }
+        const double heaviest = *std::max_element(load.begin(), load.end());
+        var.prio_mask = 0;
+        for (uint32_t st = 0; st < var.n_strands && st < 32; st++)
+            if (load[st] > 0 && load[st] >= 0.8 * heaviest) var.prio_mask |= 1u << st;
         if (v == 0) {
             c->n_rows = nrows;
             c->n_mmul = mm;
@@ -1174,7 +1187,7 @@ extern "C" int cw_run(cw_batch *b) {
     HIPCHK(cwk_ingest(b->stream, in, b->d_V, c->input_start, c->n_inputs, b->batch, b->Bp));
     HIPCHK(cwk_eval(b->stream, c->need_full, b->var->wide_linsum, b->d_rows, b->d_stream_off, b->d_extras, b->d_extra_off, b->d_terms,
                     b->d_term_off, b->var->n_strands, b->var->n_lds, b->d_V, b->d_consts, b->d_lconsts, b->Bp, b->batch,
-                    b->lanes, b->d_status, c->P));
+                    b->lanes, b->var->prio_mask, b->d_status, c->P));
     b->ran = true;
     return CW_OK;
 }

@@ -2,8 +2,8 @@ set -x
 mkdir -p gpurun_out
 rm -f gpurun_out/traffic.json
 timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
-bash tools/profile.sh r1f_poseidon2 poseidon2:65536 2>&1 | tail -25
-bash tools/profile.sh r1f_sha256_512 sha256_512:4096 --workload sha256_512 --batch 4096 2>&1 | tail -25
+bash tools/profile.sh r1g_poseidon2 poseidon2:65536 2>&1 | tail -25
+bash tools/profile.sh r1g_sha256_512 sha256_512:4096 --workload sha256_512 --batch 4096 2>&1 | tail -25
 cp gpurun_out/traffic.json profiles/traffic.json
 python bench.py 2>/dev/null | tail -1 > gpurun_out/bench_default.json; cat gpurun_out/bench_default.json
 python bench.py --workload sha256_512 --batch 4096 --steps 5 2>/dev/null | tail -1 > gpurun_out/bench_sha256_512.json; cat gpurun_out/bench_sha256_512.json
