@@ -629,7 +629,7 @@ extern "C" int cw_r1cs_plan_stats(const cw_circuit *c, uint32_t batch, uint32_t 
 struct cw_batch {
     cw_circuit *c = nullptr;
     int device = 0;
-    uint32_t batch = 0, Bp = 0, lanes = 64;
+    uint32_t batch = 0, Bp = 0, lanes = 64, prio_mask = 0;
     hipStream_t stream = nullptr;
     void *d_V = nullptr;
     size_t v_bytes = 0;
@@ -738,6 +738,8 @@ extern "C" int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *
             if (v == 16 || v == 32 || v == 64) lanes = (uint32_t)v;
         }
         b->lanes = lanes;
+        b->prio_mask = best->prio_mask;
+        if (const char *e = getenv("CW_PRIO_MASK")) b->prio_mask = (uint32_t)strtoul(e, nullptr, 0);   // diagnostics
     }
     size_t slots = (size_t)c->n_signals + b->var->n_tslots;
     b->v_bytes = slots * 2 * b->Bp * 16;
@@ -1187,7 +1189,7 @@ extern "C" int cw_run(cw_batch *b) {
     HIPCHK(cwk_ingest(b->stream, in, b->d_V, c->input_start, c->n_inputs, b->batch, b->Bp));
     HIPCHK(cwk_eval(b->stream, c->need_full, b->var->wide_linsum, b->d_rows, b->d_stream_off, b->d_extras, b->d_extra_off, b->d_terms,
                     b->d_term_off, b->var->n_strands, b->var->n_lds, b->d_V, b->d_consts, b->d_lconsts, b->Bp, b->batch,
-                    b->lanes, b->var->prio_mask, b->d_status, c->P));
+                    b->lanes, b->prio_mask, b->d_status, c->P));
     b->ran = true;
     return CW_OK;
 }
