@@ -145,9 +145,16 @@ def main():
         elapsed = float(t.item())
 
     # correctness gate + the one data-path collective: gather per-instance status words on rank 0
-    from circom_amd.sharding import gather_status
+    # (status words + public signals of every instance; full witnesses stay on the GPU that computed them)
+    from circom_amd.sharding import gather_status, gather_rows
     status = gather_status(torch.from_numpy(batch.status().astype(np.int32)).to(dev), dist, rank, world)
     n_bad = int((status != 0).sum().item()) if rank == 0 else 0
+    pub = torch.empty((B, circ.n_public, 32), dtype=torch.uint8, device=dev)
+    if circ.n_public:
+        batch.public_signals_device(pub.data_ptr())
+        torch.cuda.synchronize()
+    pub = gather_rows(pub, dist, rank, world)
+    n_pub_gathered = int(pub.shape[0]) if rank == 0 else 0
 
     gen_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / args.steps
     chk_ms = sum(e[1].elapsed_time(e[2]) for e in evs) / args.steps
@@ -209,6 +216,8 @@ def main():
             "r1cs_check_ms": chk_ms,
             "r1cs_check_gbs": 32.0 * n_wit * B / (chk_ms * 1e-3) / 1e9,
             "failed_instances": n_bad,
+            "gathered": {"status_words": int(status.numel()), "public_signal_rows": n_pub_gathered,
+                         "public_signals_per_instance": circ.n_public},
             "cpu_baseline": None,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -202,7 +202,7 @@ struct Variant {               // one lowering of the schedule for a given stran
 struct cw_circuit {
     U256 q;
     FpParams P;
-    uint32_t n_signals = 0, n_witness = 0, n_consts = 0, input_start = 0, n_inputs = 0;
+    uint32_t n_signals = 0, n_witness = 0, n_consts = 0, input_start = 0, n_inputs = 0, n_pub_in = 0;
     uint64_t n_rows = 0, n_mmul = 0;
     bool need_full = false;
     std::vector<Variant> variants;
@@ -260,6 +260,7 @@ static int load_tape(cw_circuit *c, const char *path) {
     uint32_t n_names = m[5], hsize = m[6];
     if (m[7] != CW_RBITS) return fail(CW_EIO, "tape was lowered for a different Montgomery radix");
     uint32_t n_lconsts = m[8];
+    c->n_pub_in = m[9];
     if (b.size() < off + ((size_t)c->n_consts + n_lconsts) * 32 + (size_t)c->n_witness * 4)
         return fail(CW_EIO, "tape file truncated");
     c->consts.resize((size_t)c->n_consts * 8);
@@ -567,6 +568,8 @@ extern "C" uint32_t cw_n_witness(const cw_circuit *c) { return c->n_witness; }
 extern "C" uint32_t cw_n_inputs(const cw_circuit *c) { return c->n_inputs; }
 extern "C" uint32_t cw_input_start(const cw_circuit *c) { return c->input_start; }
 extern "C" uint32_t cw_n_constraints(const cw_circuit *c) { return c->n_constraints; }
+// public signals = main's outputs then its public inputs = witness positions 1 .. n_public (r1cs header nPubOut/nPubIn)
+extern "C" uint32_t cw_n_public(const cw_circuit *c) { return c->input_start - 1 + c->n_pub_in; }
 extern "C" uint64_t cw_n_rows(const cw_circuit *c) { return c->n_rows; }
 extern "C" uint64_t cw_n_mmul(const cw_circuit *c) { return c->n_mmul; }
 extern "C" void cw_prime(const cw_circuit *c, uint8_t le32[32]) { memcpy(le32, c->q.w, 32); }
@@ -1274,6 +1277,38 @@ extern "C" int cw_get_witnesses(cw_batch *b, uint32_t first, uint32_t count, uin
         HIPCHK(hipStreamSynchronize(b->stream));
     }
     return CW_OK;
+}
+
+// Public signals of every instance, [batch][n_public][32], written to DEVICE memory: what a multi-GPU job gathers to
+// the root next to the status words and what a verifier needs (snarkjs public.json).
+extern "C" int cw_get_public_device(cw_batch *b, void *d_out) {
+    if (!b || !d_out) return fail(CW_EINVAL, "null argument");
+    NEED_DEVICE(b);
+    if (!b->ran) return fail(CW_ESTATE, "cw_get_public_device before cw_run");
+    cw_circuit *c = b->c;
+    const uint32_t np = cw_n_public(c);
+    if (np == 0) return CW_OK;
+    if (np >= c->n_witness) return fail(CW_ESTATE, "public signal count exceeds the witness");
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(cwk_gather_many(b->stream, b->d_V, b->d_w2s + 1, np, b->Bp, 0, b->batch, d_out));
+    return CW_OK;
+}
+extern "C" int cw_get_public(cw_batch *b, uint8_t *out) {
+    if (!b || !out) return fail(CW_EINVAL, "null argument");
+    NEED_DEVICE(b);
+    const size_t bytes = (size_t)b->batch * cw_n_public(b->c) * 32;
+    if (bytes == 0) return CW_OK;
+    void *d = nullptr;
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipMalloc(&d, bytes));
+    int rc = cw_get_public_device(b, d);
+    if (rc == CW_OK) {
+        hipError_t e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, b->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+        if (e != hipSuccess) rc = fail(CW_EDEVICE, hipGetErrorString(e));
+    }
+    hipFree(d);
+    return rc;
 }
 
 extern "C" int cw_get_signal(cw_batch *b, uint32_t instance, uint32_t slot, uint8_t out[32]) {

@@ -109,6 +109,7 @@ class Tape:
         self.inputs = []            # (name, slot, size)
         self.main_input_start = 0
         self.n_main_inputs = 0
+        self.n_pub_in = 0           # public inputs of main (`component main {public [...]}`); outputs are always public
         self.stats = {}
         self.rbits = 261            # Montgomery radix exponent of MMUL rows
 
@@ -1096,6 +1097,7 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
     t.inputs = list(fc.inputs)
     t.main_input_start = fc.main_input_start
     t.n_main_inputs = fc.n_main_inputs
+    t.n_pub_in = fc.n_pub_in
     dops = out[:, 0] & 0xFF
     t.stats = {
         "rows": int(len(out)),

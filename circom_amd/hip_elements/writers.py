@@ -86,7 +86,7 @@ def write_tape(path, tapes):
          0  "CWTP" | u32 version | u32 n64 | u32 n_variants
         16  prime, n64*8 bytes
             12 x u32: n_signals, n_witness, n_consts, main_input_start, n_main_inputs, n_input_names,
-                      hashmap_size, rbits (Montgomery radix exponent of MMUL rows), n_lconsts, 0, 0, 0
+                      hashmap_size, rbits (Montgomery radix exponent of MMUL rows), n_lconsts, n_public_inputs, 0, 0
             consts          n_consts x n64*8 bytes (raw residues as the schedule expects them)
             lconsts         n_lconsts x n64*8 bytes (coef*R' of D_DOTC terms; the runtime keeps them as 29-bit limbs)
             witness2signal  n_witness x u32
@@ -106,7 +106,7 @@ def write_tape(path, tapes):
         f.write(TAPE_MAGIC + struct.pack("<III", TAPE_VERSION, n64, len(tapes)))
         f.write(t0.q.to_bytes(8 * n64, "little"))
         f.write(struct.pack("<12I", t0.n_signals, t0.n_witness, len(t0.consts), t0.main_input_start, t0.n_main_inputs,
-                            len(t0.inputs), hashmap_size(len(t0.inputs)), t0.rbits, len(t0.lconsts), 0, 0, 0))
+                            len(t0.inputs), hashmap_size(len(t0.inputs)), t0.rbits, len(t0.lconsts), t0.n_pub_in, 0, 0))
         f.write(b"".join(c.to_bytes(8 * n64, "little") for c in t0.consts))
         f.write(b"".join(c.to_bytes(8 * n64, "little") for c in t0.lconsts))
         f.write(np.asarray(t0.witness2signal, dtype="<u4").tobytes())

@@ -51,6 +51,7 @@ _SIGS = {
     "cw_n_inputs": (C.c_uint32, [C.c_void_p]),
     "cw_input_start": (C.c_uint32, [C.c_void_p]),
     "cw_n_constraints": (C.c_uint32, [C.c_void_p]),
+    "cw_n_public": (C.c_uint32, [C.c_void_p]),
     "cw_n_rows": (C.c_uint64, [C.c_void_p]),
     "cw_n_mmul": (C.c_uint64, [C.c_void_p]),
     "cw_prime": (None, [C.c_void_p, C.c_char_p]),
@@ -72,6 +73,8 @@ _SIGS = {
     "cw_get_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cw_get_witness": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "cw_get_witnesses": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "cw_get_public": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cw_get_public_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cw_get_signal": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p]),
     "cw_write_wtns": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p]),
     "cw_get_r1cs_first_bad": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -124,6 +127,7 @@ class Circuit:
         self.n_inputs = L.cw_n_inputs(h)
         self.input_start = L.cw_input_start(h)
         self.n_constraints = L.cw_n_constraints(h)
+        self.n_public = L.cw_n_public(h)
         self.n_rows = L.cw_n_rows(h)
         self.n_mmul = L.cw_n_mmul(h)
         buf = C.create_string_buffer(32)
@@ -220,6 +224,16 @@ class Batch:
 
     def witness(self, instance: int):
         return bytes_to_ints(self.witness_bytes(instance))
+
+    def public_signals(self) -> np.ndarray:
+        """[batch][n_public][32] uint8: outputs then public inputs of main, for every instance."""
+        out = np.zeros((self.n, self.circuit.n_public, 32), dtype=np.uint8)
+        _chk(lib().cw_get_public(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def public_signals_device(self, d_ptr: int) -> None:
+        """Same, written to device memory at `d_ptr` (batch * n_public * 32 bytes)."""
+        _chk(lib().cw_get_public_device(self.h, C.c_void_p(d_ptr)))
 
     def witnesses(self, first: int = 0, count: int | None = None) -> np.ndarray:
         """[count][n_witness][32] uint8, canonical little-endian values (bulk egress, one device transpose)."""

@@ -54,6 +54,7 @@ uint32_t cw_n_witness(const cw_circuit *c);          /* get_size_of_witness() */
 uint32_t cw_n_inputs(const cw_circuit *c);           /* get_main_input_signal_no() */
 uint32_t cw_input_start(const cw_circuit *c);        /* get_main_input_signal_start() */
 uint32_t cw_n_constraints(const cw_circuit *c);      /* from the .r1cs header, 0 if none loaded */
+uint32_t cw_n_public(const cw_circuit *c);     /* nPubOut + nPubIn of the r1cs header */
 uint64_t cw_n_rows(const cw_circuit *c);             /* schedule length */
 uint64_t cw_n_mmul(const cw_circuit *c);             /* Montgomery multiplications per instance in the schedule */
 void cw_prime(const cw_circuit *c, uint8_t le32[32]); /* Fr_q (fr.hpp) */
@@ -101,6 +102,10 @@ int cw_get_status(cw_batch *b, uint32_t *status /* [batch] */);
 int cw_get_witness(cw_batch *b, uint32_t instance, uint8_t *out);
 /* bulk form for provers: `count` instances from `first`, [count][n_witness][32], one device-side transpose */
 int cw_get_witnesses(cw_batch *b, uint32_t first, uint32_t count, uint8_t *out);
+/* public signals (main's outputs, then its public inputs = witness positions 1..cw_n_public) of EVERY instance,
+ * [batch][n_public][32]: to host memory, or to device memory for a multi-GPU gather */
+int cw_get_public(cw_batch *b, uint8_t *out);
+int cw_get_public_device(cw_batch *b, void *d_out);
 /* one signal of one instance (signalValues[slot]) */
 int cw_get_signal(cw_batch *b, uint32_t instance, uint32_t slot, uint8_t out[32]);
 /* writeBinWitness (main.cpp:288-334) */

@@ -131,3 +131,16 @@ def test_cli_exists_and_fails_loudly_without_a_gpu(tmp_path):
     r = subprocess.run([str(rt.CLI_PATH), str(tmp_path / "multiplier2"), str(tmp_path / "in.json"), str(tmp_path / "o.wtns")],
                        capture_output=True, text=True)
     assert r.returncode == 2 and r.stderr.strip() and not (tmp_path / "o.wtns").exists()
+
+
+def test_public_signal_count_follows_the_main_declaration(tmp_path):
+    """`component main {public [a]} = Multiplier2()`: outputs are always public, `a` becomes public input (r1cs header
+    nPubOut/nPubIn, r1cs_writer.rs:245-269); cw_n_public is what a multi-GPU job gathers per instance."""
+    cp = compile_program(Program(Multiplier2()), str(tmp_path), "m2")
+    c = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
+    assert c.n_public == 1
+    c.close()
+    cp = compile_program(Program(Multiplier2(), public=["a"]), str(tmp_path), "m2pub")
+    c = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
+    assert c.n_public == 2
+    c.close()

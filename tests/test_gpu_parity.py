@@ -222,6 +222,10 @@ def test_bulk_witness_egress_equals_per_instance_egress(tmp_path):
         assert allw[i].tobytes() == b.witness_bytes(i), i
     part = b.witnesses(100, 70)
     assert part.tobytes() == allw[100:170].tobytes()
+    # public signals = witness positions 1..n_public (Poseidon: the hash output)
+    assert c.n_public == 1
+    pub = b.public_signals()
+    assert pub.shape == (B, 1, 32) and pub.tobytes() == allw[:, 1:2, :].tobytes()
     with pytest.raises(rt.CwError):
         b.witnesses(300, 40)
     b.close(); c.close()

@@ -1,4 +1,5 @@
-"""The N>1 path of bench.py on CPU: two processes over gloo shard a batch and gather the status words."""
+"""The N>1 path of bench.py on CPU: two processes over gloo shard a batch and gather the status words and the
+public signals (the one exchange of the job)."""
 import os
 import socket
 import sys
@@ -14,7 +15,7 @@ ROOT = Path(__file__).resolve().parent.parent
 
 def _worker(rank, world, port, total, out_dir):
     sys.path.insert(0, str(ROOT))
-    from circom_amd.sharding import shard_range, gather_status
+    from circom_amd.sharding import shard_range, gather_status, gather_rows
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -23,10 +24,15 @@ def _worker(rank, world, port, total, out_dir):
     st = torch.arange(lo, hi, dtype=torch.int32) * 8
     st[0] += 1
     got = gather_status(st, dist, rank, world)
+    # fake public signals: [n][2][32] bytes derived from the instance id
+    ids = torch.arange(lo, hi, dtype=torch.int64)
+    pub = ((ids[:, None, None] * 7 + torch.arange(2)[None, :, None] * 3 + torch.arange(32)[None, None, :]) % 251).to(torch.uint8)
+    gpub = gather_rows(pub, dist, rank, world)
     if rank == 0:
         torch.save(got, os.path.join(out_dir, "gathered.pt"))
+        torch.save(gpub, os.path.join(out_dir, "public.pt"))
     else:
-        assert got is None
+        assert got is None and gpub is None
     dist.barrier()
     dist.destroy_process_group()
 
@@ -54,3 +60,7 @@ def test_two_rank_gloo_status_gather(tmp_path):
     want[0] += 1
     want[501] += 1
     assert torch.equal(got, want)
+    gpub = torch.load(tmp_path / "public.pt")
+    ids = torch.arange(0, total, dtype=torch.int64)
+    wpub = ((ids[:, None, None] * 7 + torch.arange(2)[None, :, None] * 3 + torch.arange(32)[None, None, :]) % 251).to(torch.uint8)
+    assert gpub.shape == (total, 2, 32) and torch.equal(gpub, wpub)
