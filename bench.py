@@ -179,10 +179,11 @@ def main():
         achieved = alg_bytes / (gen_ms * 1e-3) / 1e9
         # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
         # tools/summarize_prof.py: (2*FETCH_SIZE + WRITE_SIZE) KiB with the gfx950 FETCH_SIZE correction)
-        traffic = None
+        traffic = traffic_chk = None
         try:
             tj = json.load(open(ROOT / "profiles" / "traffic.json"))
             traffic = tj.get("%s:%d" % (args.workload, B), {}).get("cw_eval_kernel")
+            traffic_chk = tj.get("%s:%d" % (args.workload, B), {}).get("cw_r1cs_kernel")
         except Exception:
             pass
         out = {
@@ -213,6 +214,12 @@ def main():
                               "achieved": circ.n_mmul * B / (gen_ms * 1e-3), "peak": fp_mul_per_s,
                               "frac": (circ.n_mmul * B / (gen_ms * 1e-3)) / fp_mul_per_s if fp_mul_per_s else None},
             "fp_mul_per_s": fp_mul_per_s,
+            # the second kernel against the same HBM roof: algorithmic bytes = re-read every witness element once
+            "roofline_r1cs": {"bound": "hbm", "kernel": "cw_r1cs_stream_kernel", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                              "achieved": 32.0 * n_wit * B / (chk_ms * 1e-3) / 1e9,
+                              "frac": 32.0 * n_wit * B / (chk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_chk,
+                              "moved_gbs": (traffic_chk / (chk_ms * 1e-3) / 1e9) if traffic_chk else None,
+                              "kernel_ms": chk_ms},
             "r1cs_check_ms": chk_ms,
             "r1cs_check_gbs": 32.0 * n_wit * B / (chk_ms * 1e-3) / 1e9,
             "failed_instances": n_bad,
