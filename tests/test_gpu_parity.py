@@ -46,6 +46,8 @@ def test_device_field_ops_match_oracle(prime):
         want = [fn(a, b) for a, b in zip(A, B)]
         bad = [i for i in range(len(A)) if got[i] != want[i]]
         assert not bad, (prime, L.D_NAMES[dop], hex(A[bad[0]]), hex(B[bad[0]]), hex(got[bad[0]]), hex(want[bad[0]]))
+    got, st = rt.fp_op(f.q, L.D_MUL2, A, A, Cc)          # every lane multiplies a value by itself: the squaring path
+    assert got == [a * a % f.q for a in A], (prime, "mul2 square")
     for dop, fn in {L.D_NEG: f.neg, L.D_BNOT: f.bnot, L.D_LNOT: f.lnot, L.D_INV: f.inv, L.D_COPY: lambda x: x}.items():
         got, st = rt.fp_op(f.q, dop, A, B, Cc)
         want = [fn(a) for a in A]
