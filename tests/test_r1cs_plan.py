@@ -44,3 +44,14 @@ def test_small_lds_needs_filler_loads_but_stays_correct(tmp_path):
     assert few["filler_loads"] > 0 and few["loads"] > many["loads"]
     assert few["terms"] == many["terms"] and few["distinct_wires"] == many["distinct_wires"]
     c.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_plans_of_random_circuits_are_hazard_free(tmp_path, seed):
+    from test_schedule_fuzz import _random_template
+    cp, c = _circuit(tmp_path, _random_template(seed, 60 + 30 * seed), "fuzz")
+    n_terms = sum(len(a) + len(b) + len(cc) for a, b, cc in cp.flat.constraints)
+    for chunks, entries in ((1, 6), (2, 7), (5, 10), (40, 16), (3, 64)):
+        st = c.r1cs_plan_stats(1000, chunks, entries)       # raises CwError if a term could read a stale LDS entry
+        assert st["terms"] == n_terms and st["loads"] >= st["distinct_wires"]
+    c.close()
