@@ -73,8 +73,8 @@ def main():
         entries = []
         for i, r in enumerate(rows):
             b = open(pre + "%d.wtns" % i, "rb").read()
-            nw = int.from_bytes(b[72:76], "little")
-            head = [str(int.from_bytes(b[88 + 32 * k:120 + 32 * k], "little")) for k in range(min(nw, 8))]
+            nw = int.from_bytes(b[60:64], "little")          # wtns: 12 B file header, 12 B section header, n8, q, nWitness
+            head = [str(int.from_bytes(b[76 + 32 * k:108 + 32 * k], "little")) for k in range(min(nw, 8))]
             e = {"inputs": [str(v) for v in r], "wtns_sha256": hashlib.sha256(b).hexdigest(), "wtns_len": len(b),
                  "n_witness": nw, "witness_head": head}
             if len(b) <= 4096:

@@ -52,7 +52,7 @@ def test_oracle_and_schedule_match_reference_runtime_on_every_operator(tmp_path,
         assert failed is None
         ref = open(pre + "%d.wtns" % i, "rb").read()
         if ref != wtns_bytes(q, sig):
-            refv = [int.from_bytes(ref[88 + 32 * k:120 + 32 * k], "little") for k in range(len(sig))]
+            refv = [int.from_bytes(ref[76 + 32 * k:108 + 32 * k], "little") for k in range(len(sig))]
             raise AssertionError((hex(r[0]), hex(r[1]), [NAMES[k - 1] for k in range(1, 1 + len(NAMES)) if refv[k] != sig[k]]))
         if i % 29 == 0:
             for t in tapes:

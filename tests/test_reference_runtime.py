@@ -94,3 +94,33 @@ def test_gpu_wtns_equal_reference_runtime_wtns(tmp_path):
         b.write_wtns(i, g)
         assert g.read_bytes() == open(pre + "%d.wtns" % i, "rb").read(), i
     b.close(); c.close()
+
+
+def test_json_value_forms_agree_with_the_reference_cli(tmp_path, ref_dir_bn128):
+    """loadJson / json2FrElements (main.cpp:144-188,243-286): every way of writing a number — decimal, 0x, 0b, 0o
+    strings, JSON integers, negative and fractional JSON numbers (which go through `double`), values above q —
+    gives the same field element in the reference's CLI and in cw_set_inputs_json; what one rejects the other rejects."""
+    from circom_amd import runtime as rt
+    cp = _build(tmp_path, Program(Multiplier2()), "multiplier2")
+    q = cp.flat.fp.q
+    c = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
+    forms = ['"12"', '"0x1F"', '"0xff"', '"0b101"', '"0o17"', '7', '-3', '0', '-0', '1e3', '1E2', '9007199254740993', '1.5', '2.5',
+             '3.49', '-0.4', '-7.5', '1e30', '123456789012345678901234567890', '"%d"' % (q + 5), '"%d"' % (2 ** 300),
+             '"%d"' % (q - 1), '"00012"', '"12a"', '"-1"', '""', 'true', 'null', '"0x"', '"1 2"', '[1]']
+    b = c.batch(len(forms), device=-1)
+    for i, form in enumerate(forms):
+        text = '{"a": %s, "b": "1"}' % form
+        out = tmp_path / ("j%d.wtns" % i)
+        r = ref_build.run_cli(cp, text, out)
+        try:
+            b.set_inputs_json(i, text)
+            mine = b.staged_input(i, 0)
+        except rt.CwError:
+            mine = None
+        if r.returncode == 0:
+            w = out.read_bytes()
+            ref = int.from_bytes(w[76 + 64:76 + 96], "little")           # values start at byte 76; witness = [1, c, a, b]
+            assert mine == ref, (form, mine, ref)
+        else:
+            assert mine is None, (form, mine, r.stdout[-200:], r.stderr[-200:])
+    b.close(); c.close()
