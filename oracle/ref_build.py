@@ -38,10 +38,20 @@ def build_circuit(cp, force=False):
     d = ref_dir(prime)
     cli, loop = binaries(prime, cp.name)
     names = d / (cp.name + ".names")
-    if cli.exists() and loop.exists() and names.exists() and not force:
+    # the binaries are cached by circuit NAME; the fingerprint (witness code + tables) catches a circuit that changed
+    # under the same name, so that a stale reference binary is never compared against
+    import hashlib
+    h = hashlib.sha256(open(cp.dat_path, "rb").read())          # numbering, hash map, witness list, constants
+    for k in sorted(cp.flat.code):                                # the flat witness code (independent of the lowering)
+        h.update(k.encode() + bytes(memoryview(cp.flat.code[k])))
+    fp = h.hexdigest()
+    fp_file = d / (cp.name + ".fp")
+    fresh = fp_file.exists() and fp_file.read_text().strip() == fp
+    if cli.exists() and loop.exists() and names.exists() and fresh and not force:
         return cli, loop
     if not REF_ROOT.exists():
-        raise RuntimeError("oracle/_ref/%s/%s is not prebuilt and the reference tree is absent" % (prime, cp.name))
+        raise RuntimeError("oracle/_ref/%s/%s is not prebuilt for this circuit and the reference tree is absent"
+                           % (prime, cp.name))
     d.mkdir(parents=True, exist_ok=True)
     emit_ref_cpp.emit(cp.flat, d / (cp.name + ".cpp"), hashmap_size(len(cp.flat.inputs)))
     shutil.copyfile(cp.dat_path, d / (cp.name + ".dat"))
@@ -50,6 +60,7 @@ def build_circuit(cp, force=False):
     for target in ("circuit", "loop"):
         subprocess.run(["make", "-C", str(ROOT), target, "PRIME=" + prime, "NAME=" + cp.name, "REF=" + str(REF_ROOT)],
                        check=True, capture_output=True)
+    fp_file.write_text(fp + "\n")
     return cli, loop
 
 

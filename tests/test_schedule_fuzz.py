@@ -17,6 +17,27 @@ from oracle.tape_eval import eval_flat, eval_tape, check_r1cs
 Q = PRIMES["bn128"]
 
 
+@template
+def _Sq(c):
+    x = c.input("in")
+    y = c.output("out")
+    c.set(y, x * x)
+
+
+@template
+def _Leaf(c, k):
+    # two inputs that the parent assigns at different times (the component fires when the LAST one arrives,
+    # store_bucket.rs:660-735), an inner component, an intermediate signal
+    a = c.input("a")
+    b = c.input("b")
+    out = c.output("out")
+    mid = c.signal("mid")
+    sq = c.component("sq", _Sq())
+    c.set(sq["in"], a + k)
+    c.set(mid, sq["out"] * b)
+    c.set(out, mid + a - k)
+
+
 def _random_template(seed, n_nodes):
     rng = random.Random(seed)
 
@@ -26,8 +47,19 @@ def _random_template(seed, n_nodes):
         vals = [ins[i] for i in range(4)]
         sig = c.signal("s", n_nodes)
         out = c.output("out", 3)
+        pending = []                                         # sub-components still waiting for their second input
+        n_leaf = 0
         for k in range(n_nodes):
             pick = lambda: vals[rng.randrange(len(vals))] if rng.random() < 0.5 else vals[-1 - rng.randrange(min(6, len(vals)))]
+            if pending and rng.random() < 0.3:               # complete one: it fires now, its output becomes usable
+                comp = pending.pop(rng.randrange(len(pending)))
+                c.set(comp["b"], pick())
+                vals.append(comp["out"])
+            if rng.random() < 0.08:
+                comp = c.component("leaf", _Leaf(rng.randrange(1, 4)), n_leaf)
+                n_leaf += 1
+                c.set(comp["a"], pick())
+                pending.append(comp)
             r = rng.random()
             if r < 0.22:
                 e = pick() * pick()
@@ -56,6 +88,9 @@ def _random_template(seed, n_nodes):
             else:
                 c.hint(sig[k], (pick() & pick()) ^ (pick() >> 3))
             vals.append(sig[k])
+        for comp in pending:
+            c.set(comp["b"], pick())
+            vals.append(comp["out"])
         for i in range(3):
             c.set(out[i], vals[-1 - i] + vals[rng.randrange(len(vals))] * (i + 2))
 
@@ -113,3 +148,30 @@ def test_gpu_random_circuits_match_oracle(seed, tmp_path):
             assert got[i].tobytes() == b"".join(v.to_bytes(32, "little") for v in sig), (seed, strands, i)
         b.close()
     c.close()
+
+
+@pytest.mark.parametrize("seed", [1, 5, 11, 23, 37])
+def test_random_circuits_match_the_reference_runtime(seed, tmp_path, ref_dir_bn128):
+    """The same random circuits, emitted as reference-style C++ and run by the reference's own runtime: its `.wtns`
+    must equal the oracle's bytes (pins the flat evaluation order, the operator semantics and the writers on shapes
+    no hand-written circuit has)."""
+    from circom_amd.compiler import compile_program
+    from circom_amd.hip_elements.writers import wtns_bytes
+    from oracle import ref_build
+    cp = compile_program(Program(_random_template(seed, 40 + 26 * (seed % 11))), str(tmp_path), "fuzz%d" % seed, sym=False,
+                         strands=(1,))
+    try:
+        ref_build.build_circuit(cp)
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    fc = cp.flat
+    rng = random.Random(3000 + seed)
+    rows = [[rng.randrange(Q) for _ in range(4)] for _ in range(4)] + [[rng.randrange(4) for _ in range(4)] for _ in range(3)]
+    raw = b"".join(v.to_bytes(32, "little") for r in rows for v in r)
+    pre = str(tmp_path / "r_")
+    ref_build.run_loop(cp, raw, len(rows), 1, wtns_prefix=pre)
+    for i, r in enumerate(rows):
+        inp = {fc.main_input_start + k: v for k, v in enumerate(r)}
+        sig, failed = eval_flat(Q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp)
+        assert failed is None
+        assert open(pre + "%d.wtns" % i, "rb").read() == wtns_bytes(Q, sig), (seed, i)
