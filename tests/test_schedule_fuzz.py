@@ -38,7 +38,7 @@ def _Leaf(c, k):
     c.set(out, mid + a - k)
 
 
-def _random_template(seed, n_nodes):
+def _random_template(seed, n_nodes, q=Q):
     rng = random.Random(seed)
 
     @template
@@ -73,7 +73,7 @@ def _random_template(seed, n_nodes):
                     e = e + pick() * rng.randrange(-4, 9)
                 c.set(sig[k], e)
             elif r < 0.52:                                   # field-sized coefficients
-                e = pick() * rng.randrange(Q) + pick() * rng.randrange(Q) + pick() * rng.randrange(Q) + rng.randrange(Q)
+                e = pick() * rng.randrange(q) + pick() * rng.randrange(q) + pick() * rng.randrange(q) + rng.randrange(q)
                 c.set(sig[k], e)
             elif r < 0.62:                                   # bits of a value, with the usual booleanity check
                 x = pick()
@@ -150,16 +150,20 @@ def test_gpu_random_circuits_match_oracle(seed, tmp_path):
     c.close()
 
 
-@pytest.mark.parametrize("seed", [1, 5, 11, 23, 37])
-def test_random_circuits_match_the_reference_runtime(seed, tmp_path, ref_dir_bn128):
+@pytest.mark.parametrize("seed,prime", [(1, "bn128"), (5, "bn128"), (11, "bn128"), (23, "bn128"), (37, "bn128"),
+                                        (2, "bls12381"), (9, "bls12381"), (4, "secq256r1"), (6, "bls12377")])
+def test_random_circuits_match_the_reference_runtime(seed, prime, tmp_path):
     """The same random circuits, emitted as reference-style C++ and run by the reference's own runtime: its `.wtns`
     must equal the oracle's bytes (pins the flat evaluation order, the operator semantics and the writers on shapes
     no hand-written circuit has)."""
     from circom_amd.compiler import compile_program
     from circom_amd.hip_elements.writers import wtns_bytes
+    from conftest import ensure_ref
     from oracle import ref_build
-    cp = compile_program(Program(_random_template(seed, 40 + 26 * (seed % 11))), str(tmp_path), "fuzz%d" % seed, sym=False,
-                         strands=(1,))
+    ensure_ref(prime)
+    Q = PRIMES[prime]
+    cp = compile_program(Program(_random_template(seed, 40 + 26 * (seed % 11), Q), prime=prime), str(tmp_path),
+                         "fuzz%d" % seed, sym=False, strands=(1,))
     try:
         ref_build.build_circuit(cp)
     except RuntimeError as e:
