@@ -700,12 +700,19 @@ def _alias(rows, n_signals):
         if r.op == D_COPY and r.dk == K_SIG and r.ak in (K_SIG, K_TMP):
             src = vid(r.ak, r.av)
             p = producer.get(src)
-            if p is not None:
+            if p is not None and (p.extra is None or len(p.extra) < EXTRA_CAP):
                 if p.extra is None:
                     p.extra = []
                 p.extra.append((K_SIG, r.dv))
                 root[r.dv] = src
                 n_elided += 1
+                continue
+            if p is not None:
+                # the producer's extra-destination field is full (a value wired into thousands of places): this copy
+                # stays a row of its own and takes over as the carrier of the following copies of the same value
+                producer[src] = r
+                root[r.dv] = src
+                out.append(r)
                 continue
         if r.dk in (K_SIG, K_TMP):
             producer[vid(r.dk, r.dv)] = r
@@ -834,6 +841,7 @@ def lds_slots_for(n_strands: int) -> int:
 # row word 0 layout:  op[0:8) | dk[8:11) | ak[11:14) | bk[14:17) | n_extra[17:29) | const-small flags[29:31)
 SH_DK, SH_AK, SH_BK, SH_NX, SH_FLAG = 8, 11, 14, 17, 29
 MAX_EXTRA = 4095
+EXTRA_CAP = 4000       # copies folded into one row (leaves room for the LDS hand-off entry; the field holds 4095)
 K_LDS = 4             # operand / destination kind: LDS slot of the workgroup (cross-strand hand-off)
 X_TMP, X_LDS = 1 << 31, 1 << 30       # flags of an entry of the extra-destination table
 

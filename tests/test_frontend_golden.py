@@ -152,3 +152,25 @@ def test_strand_schedules_are_race_free_and_equivalent():
                 a, failed = eval_flat(Q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp)
                 b, st = eval_tape(t, inp)
                 assert a == b and (st == 0) == (failed is None), (prog.main.name, S)
+
+
+def test_value_wired_into_thousands_of_places_overflows_the_extra_field_gracefully():
+    """One value copied 9000 times (a selector bit fed to every element of a wide mux): the copies are folded into
+    the producing row up to the capacity of its extra-destination field, the rest chain through copy rows."""
+    from circom_amd.frontend.dsl import template as _t
+
+    @_t
+    def Wide(c, n):
+        a = c.input("a"); b = c.input("b")
+        out = c.output("out", n)
+        x = c.signal("x")
+        c.set(x, a * b)
+        for i in range(n):
+            c.set(out[i], x)
+
+    fc = flatten(Program(Wide(9000)))
+    for S in (1, 4):
+        t = lower(fc, n_strands=S)
+        assert t.stats["copies_elided"] >= 8990 and t.stats["copy"] >= 2
+        got, st = eval_tape(t, {fc.main_input_start: 6, fc.main_input_start + 1: 7})
+        assert st == 0 and got[1:9001] == [42] * 9000
