@@ -272,3 +272,70 @@ def test_gpu_batched_inversions_with_zero_denominators(tmp_path):
         want, failed = eval_flat(q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp)
         assert failed is None and b.witness(i) == want, i
     b.close(); c.close()
+
+
+# ---- unusual component structures: firing order of the reference runtime ------------------------------------------------
+@template
+def _Const5(c):
+    out = c.output("out")
+    c.set(out, 5)
+
+@template
+def __AddK(c, k):
+    a = c.input("a"); out = c.output("out")
+    c.set(out, a + k)
+
+@template
+def _Pair(c):
+    x = c.input("x", 2); out = c.output("out")
+    inner = c.component("inner", _AddK(3))
+    c.set(inner["a"], x[0] * x[1])
+    c.set(out, inner["out"] + x[1])
+
+@template
+def _Odd(c):
+    a = c.input("a"); b = c.input("b")
+    out = c.output("out", 4)
+    k5 = c.component("k5", _Const5())                    # no inputs: fires at creation
+    cc = c.component("cc", _AddK(7))
+    c.set(cc["a"], 11)                                  # constant input
+    ps = [c.component("p", _Pair(), i) for i in range(3)]
+    # inputs assigned out of order and interleaved
+    c.set(ps[2]["x"][1], b)
+    c.set(ps[0]["x"][0], a)
+    c.set(ps[1]["x"][0], k5["out"])
+    c.set(ps[2]["x"][0], cc["out"])
+    c.set(ps[0]["x"][1], ps[2]["out"])
+    c.set(ps[1]["x"][1], ps[0]["out"])
+    c.set(out[0], ps[1]["out"])
+    c.set(out[1], k5["out"] + cc["out"])
+    c.set(out[2], ps[0]["out"] * ps[2]["out"])
+    c.set(out[3], a)
+
+
+
+def test_component_firing_order_matches_reference_runtime(tmp_path, ref_dir_bn128):
+    """A component without inputs (fires at creation, template.rs:274-278), one fed by constants only, an array of
+    components whose inputs are assigned out of order and interleaved (each fires when its LAST input arrives,
+    store_bucket.rs:660-735), nesting: the flattened order must be the reference runtime's."""
+    q = PRIMES["bn128"]
+    cp = compile_program(Program(_Odd()), str(tmp_path), "oddshapes", sym=False, strands=(1,))
+    fc = cp.flat
+    try:
+        ref_build.build_circuit(cp)
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    rng = random.Random(1)
+    rows = [[3, 4], [0, 0], [q - 1, 2]] + [[rng.randrange(q), rng.randrange(q)] for _ in range(3)]
+    raw = b"".join(v.to_bytes(32, "little") for r in rows for v in r)
+    pre = str(tmp_path / "r_")
+    ref_build.run_loop(cp, raw, len(rows), 1, wtns_prefix=pre)
+    t4 = lower(fc, n_strands=4)
+    for i, r in enumerate(rows):
+        inp = {fc.main_input_start + k: v for k, v in enumerate(r)}
+        sig, failed = eval_flat(q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp)
+        assert failed is None and check_r1cs(q, fc.constraints, sig) is None
+        assert open(pre + "%d.wtns" % i, "rb").read() == wtns_bytes(q, sig), i
+        got, st = eval_tape(t4, inp)
+        assert st == 0 and got == sig
+    assert eval_flat(q, fc.n_signals, fc.n_temps, fc.constants, fc.code, {fc.main_input_start: 3, fc.main_input_start + 1: 4})[0][1:5] == [1917, 23, 25201, 3]
