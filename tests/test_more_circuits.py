@@ -281,7 +281,7 @@ def _Const5(c):
     c.set(out, 5)
 
 @template
-def __AddK(c, k):
+def _AddK(c, k):
     a = c.input("a"); out = c.output("out")
     c.set(out, a + k)
 
