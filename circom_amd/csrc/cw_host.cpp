@@ -237,6 +237,66 @@ static bool read_file(const char *path, std::vector<uint8_t> &buf) {
     return got == (size_t)n;
 }
 
+// Every index a schedule variant carries is checked once at load time, so that a damaged or hostile file is rejected
+// instead of indexing out of bounds later (here, in the per-batch row resolution, or on the device).
+static const char *validate_variant(const Variant &v, uint32_t n_signals, uint32_t n_consts, uint32_t n_lconsts) {
+    const size_t nrows = v.rows.size(), nextras = v.extras.size(), nterms = v.terms.size() / 4;
+    auto mono = [&](const std::vector<uint32_t> &o, size_t limit) {
+        if (o.size() != v.n_strands + 1 || o[0] != 0) return false;
+        for (size_t i = 0; i + 1 < o.size(); i++)
+            if (o[i] > o[i + 1]) return false;
+        return (size_t)o.back() <= limit;
+    };
+    if (!mono(v.stream_off, nrows) || !mono(v.extra_off, nextras) || !mono(v.term_off, nterms)) return "offset tables are not monotone";
+    auto operand_ok = [&](uint32_t kind, uint32_t idx) {
+        switch (kind) {
+        case K_SIG: return idx < n_signals;
+        case K_TMP: return idx < v.n_tslots;
+        case K_CONST: return idx < n_consts;
+        case K_PREV: return true;
+        case K_LDS: return idx < v.n_lds;
+        default: return false;
+        }
+    };
+    for (uint32_t st = 0; st < v.n_strands; st++) {
+        size_t xp = v.extra_off[st], tp = v.term_off[st];
+        for (size_t r = v.stream_off[st]; r < v.stream_off[st + 1]; r++) {
+            const CwRow &row = v.rows[r];
+            const uint32_t op = row.w0 & 0xFF, dk = (row.w0 >> SH_DK) & 7, ak = (row.w0 >> SH_AK) & 7, bk = (row.w0 >> SH_BK) & 7;
+            const uint32_t nx = (row.w0 >> SH_NX) & 0xFFF;
+            if (op >= D_NOPS) return "unknown opcode";
+            if (op == D_BARRIER) continue;
+            if (dk == K_SIG ? row.dst >= n_signals : dk == K_TMP ? row.dst >= v.n_tslots : dk == K_LDS ? row.dst >= v.n_lds : dk != KD_NONE)
+                return "destination out of range";
+            if (op == D_LINSUM || op == D_DOTC) {
+                if (tp + row.a > v.term_off[st + 1]) return "term list overruns its strand";
+                for (uint32_t t = 0; t < row.a; t++) {
+                    const uint32_t *tm = &v.terms[(tp + t) * 4];
+                    if (!operand_ok(tm[0] & 7, tm[1]) || (tm[0] & 7) == K_CONST) return "term operand out of range";
+                    if (op == D_DOTC && tm[2] >= n_lconsts) return "term constant out of range";
+                }
+                tp += row.a;
+                if (bk == K_CONST && row.b >= n_consts) return "constant out of range";
+            } else if (op == D_BIT) {
+                if (!operand_ok(ak, row.a)) return "operand out of range";
+            } else {
+                if (!operand_ok(ak, row.a)) return "operand out of range";
+                const bool pair = (op == D_MULC || op == D_MADDC);
+                if (bk == K_CONST ? (uint64_t)row.b + (pair ? 1 : 0) >= n_consts : !operand_ok(bk, row.b)) return "operand out of range";
+            }
+            if (xp + nx > v.extra_off[st + 1]) return "extra destinations overrun their strand";
+            for (uint32_t e = 0; e < nx; e++) {
+                const uint32_t x = v.extras[xp + e];
+                if (x & X_TMP ? (x & 0x3FFFFFFFu) >= v.n_tslots : x & X_LDS ? (x & 0x3FFFFFFFu) >= v.n_lds : x >= n_signals)
+                    return "extra destination out of range";
+            }
+            xp += nx;
+        }
+        if (xp != v.extra_off[st + 1] || tp != v.term_off[st + 1]) return "strand tables do not add up";
+    }
+    return nullptr;
+}
+
 static int load_tape(cw_circuit *c, const char *path) {
     std::vector<uint8_t> b;
     if (!read_file(path, b)) return fail(CW_EIO, std::string("tape file not found: ") + path);
@@ -261,6 +321,10 @@ static int load_tape(cw_circuit *c, const char *path) {
     if (m[7] != CW_RBITS) return fail(CW_EIO, "tape was lowered for a different Montgomery radix");
     uint32_t n_lconsts = m[8];
     c->n_pub_in = m[9];
+    // shape of the main component: slot 0 is the constant 1, outputs from slot 1, inputs right after them
+    if (c->input_start == 0 || (uint64_t)c->input_start + c->n_inputs > c->n_signals || c->n_pub_in > c->n_inputs ||
+        c->n_witness == 0 || c->n_witness > c->n_signals || hsize == 0 || hsize > (1u << 26) || n_names > c->n_inputs + 1u)
+        return fail(CW_EIO, "tape header: inconsistent circuit shape");
     if (b.size() < off + ((size_t)c->n_consts + n_lconsts) * 32 + (size_t)c->n_witness * 4)
         return fail(CW_EIO, "tape file truncated");
     c->consts.resize((size_t)c->n_consts * 8);
@@ -282,6 +346,8 @@ static int load_tape(cw_circuit *c, const char *path) {
     c->w2s.resize(c->n_witness);
     memcpy(c->w2s.data(), b.data() + off, (size_t)c->n_witness * 4);
     off += (size_t)c->n_witness * 4;
+    for (uint32_t s : c->w2s)
+        if (s >= c->n_signals) return fail(CW_EIO, "tape witness list refers to a signal out of range");
     for (uint32_t i = 0; i < n_names; i++) {
         if (off + 4 > b.size()) return fail(CW_EIO, "tape names truncated");
         uint32_t len;
@@ -293,6 +359,8 @@ static int load_tape(cw_circuit *c, const char *path) {
         uint32_t ss[2];
         memcpy(ss, b.data() + off, 8);
         off += 8;
+        if (ss[0] < c->input_start || (uint64_t)ss[0] + ss[1] > (uint64_t)c->input_start + c->n_inputs)
+            return fail(CW_EIO, "tape input name refers to slots outside the main inputs");
         c->input_names[name] = {ss[0], ss[1]};
     }
     if (n_variants == 0) return fail(CW_EIO, "tape holds no schedule");
@@ -328,6 +396,9 @@ static int load_tape(cw_circuit *c, const char *path) {
         var.terms.resize((size_t)nterms * 4);
         memcpy(var.terms.data(), b.data() + off, (size_t)nterms * 16);
         off += (size_t)nterms * 16;
+        if (nterms < 4 || nextras < 4) return fail(CW_EIO, "tape variant: tables lack their padding");
+        if (const char *why = validate_variant(var, c->n_signals, c->n_consts, n_lconsts))
+            return fail(CW_EIO, std::string("tape variant: ") + why);
         if (var.term_off[var.n_strands] + 4 != nterms) return fail(CW_EIO, "tape variant: bad term offsets");
         {   // DOTC terms must index the limb-form constant table
             size_t tpos = 0, lin_terms = 0;
@@ -408,7 +479,13 @@ static int load_dat(cw_circuit *c, const char *path) {
     size_t hs = c->hashmap.size();
     size_t need = hs * 24 + (size_t)c->n_witness * 8;
     if (b.size() < need) return fail(CW_EIO, ".dat file too small for this tape");
-    for (size_t i = 0; i < hs; i++) memcpy(&c->hashmap[i], b.data() + i * 24, 24);
+    for (size_t i = 0; i < hs; i++) {
+        memcpy(&c->hashmap[i], b.data() + i * 24, 24);
+        const HashEntry &h = c->hashmap[i];                  // setInputSignal writes signalValues[signalid + idx]
+        if (h.signalid != 0 && (h.signalid < c->input_start || h.signalsize > c->n_inputs ||
+                                h.signalid + h.signalsize > (uint64_t)c->input_start + c->n_inputs))
+            return fail(CW_EIO, ".dat input hash map refers to slots outside the main inputs");
+    }
     const uint8_t *w = b.data() + hs * 24;
     for (uint32_t i = 0; i < c->n_witness; i++) {
         uint64_t s;

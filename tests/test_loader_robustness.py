@@ -1,6 +1,10 @@
 """cw_load must reject malformed artefacts with CW_EIO instead of crashing (the reference mmap()s its .dat blindly,
 main.cpp:38-56; a library serving many circuits cannot)."""
+from pathlib import Path
+
 import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
 
 from circom_amd import runtime as rt
 from circom_amd.compiler import compile_program
@@ -60,3 +64,59 @@ def test_small_primes_are_rejected_not_miscomputed(tmp_path):
     a = np.zeros((4, 32), dtype=np.uint8)
     with pytest.raises(rt.CwError, match="unsupported prime"):
         rt.fp_mul_bench(gold, a, a, 4, device=0)
+
+
+def test_mutated_files_never_crash_the_loader(tmp_path):
+    """Random byte flips, truncations and wild 32-bit values in .cwt / .dat / .r1cs: every index the files carry is
+    validated at load time (schedule operands, destinations, term and extra tables, header shape, input hash map),
+    so a damaged file is either rejected with CW_EIO or loads into something whose indices are all in range.  Run in
+    a child process: a crash of the library would take the interpreter with it."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, os, random
+sys.path.insert(0, %r)
+from circom_amd import runtime as rt
+from circom_amd.compiler import compile_program
+from circom_amd.frontend.dsl import Program
+from circom_amd.circuits.poseidon import Poseidon
+from circom_amd.circuits.basic import Num2Bits
+d = %r
+rng = random.Random(5)
+n_ok = n_bad = 0
+for name, prog, js in (("n2b", Num2Bits(8), '{"in": "5"}'), ("pos", Poseidon(2), '{"inputs": ["5", "6"]}')):
+    cp = compile_program(Program(prog), d, name, sym=False)
+    files = {k: open(p, "rb").read() for k, p in (("cwt", cp.tape_path), ("dat", cp.dat_path), ("r1cs", cp.r1cs_path))}
+    for it in range(700):
+        which = rng.choice(["cwt", "cwt", "dat", "r1cs"])
+        data = bytearray(files[which])
+        r = rng.random()
+        if r < 0.6:
+            for _ in range(rng.randrange(1, 8)):
+                data[rng.randrange(len(data))] = rng.randrange(256)
+        elif r < 0.8:
+            data = data[:rng.randrange(len(data))]
+        else:
+            pos = rng.randrange(len(data) - 4)
+            data[pos:pos + 4] = rng.choice([0xFFFFFFFF, 0x7FFFFFFF, 0x80000000, 1 << 20]).to_bytes(4, "little")
+        paths = {k: os.path.join(d, "f_" + k) for k in files}
+        for k in files:
+            open(paths[k], "wb").write(bytes(data) if k == which else files[k])
+        try:
+            c = rt.Circuit(paths["cwt"], paths["dat"], paths["r1cs"])
+        except rt.CwError:
+            n_bad += 1
+            continue
+        b = c.batch(4, device=-1)
+        for call in (lambda: b.set_inputs_json(0, js), lambda: c.r1cs_plan_stats(100, 0, 0)):
+            try:
+                call()
+            except rt.CwError:
+                pass
+        b.close(); c.close(); n_ok += 1
+print("ok", n_ok, n_bad)
+''' % (str(ROOT), str(tmp_path))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, "the loader crashed on a mutated file (exit %d)\n%s" % (r.returncode, r.stderr[-500:])
+    out = r.stdout.split()
+    assert out[0] == "ok" and int(out[2]) > 200          # most mutations are rejected, none kills the process
