@@ -323,7 +323,8 @@ static int load_tape(cw_circuit *c, const char *path) {
     c->n_pub_in = m[9];
     // shape of the main component: slot 0 is the constant 1, outputs from slot 1, inputs right after them
     if (c->input_start == 0 || (uint64_t)c->input_start + c->n_inputs > c->n_signals || c->n_pub_in > c->n_inputs ||
-        c->n_witness == 0 || c->n_witness > c->n_signals || hsize == 0 || hsize > (1u << 26) || n_names > c->n_inputs + 1u)
+        c->n_witness == 0 || c->n_witness > c->n_signals || hsize < 256 || (hsize & (hsize - 1)) ||
+        hsize > std::max<uint64_t>(256, 2 * (uint64_t)n_names) || n_names > c->n_inputs + 1u)   // max(2^ceil(log2 n), 256), mod.rs:167
         return fail(CW_EIO, "tape header: inconsistent circuit shape");
     if (b.size() < off + ((size_t)c->n_consts + n_lconsts) * 32 + (size_t)c->n_witness * 4)
         return fail(CW_EIO, "tape file truncated");
