@@ -1,19 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py — witnesses/sec of the batched HIP witness calculator (see BASELINE.json).
+"""bench.py — witnesses/sec of the batched HIP witness calculator (BASELINE.json's metric).
 
-Workloads: poseidon2 (default, BASELINE configs[1]), sha256_<bits> (configs[2]), semaphore<levels> (configs[3]).
+Default workload = the metric's: `sha256_2048`, a SHA-256 circuit of 5 compression blocks = 1 020 832 constraints at
+`--O0` (>= 1M, asserted), batch 4096 on one MI355X.  Other workloads (parity-test configurations of BASELINE.json):
+poseidon2 (configs[1], batch 65536), sha256_512 (configs[2]), semaphore<levels> (configs[3]'s circuit).
 
-A "step" = one pass of the hot path over one batch of synthetic inputs that are already resident in
-HBM: ingest (AoS -> SoA input slots) + schedule evaluation (witness generation) + R1CS check.
-Multi-GPU: one process per GPU (torch.distributed / RCCL), instances are sharded (weak scaling,
-fixed per-GPU batch); the only collective is the final gather of the per-instance status words.
+A "step" = one pass of the hot path over one batch of synthetic inputs that are already resident in HBM:
+ingest (AoS -> value-table input slots) + schedule evaluation (witness generation) + R1CS check.
+Multi-GPU: one process per GPU (torch.distributed / RCCL), instances are sharded; rank 0 compiles the circuit once
+and the other ranks load the artefacts; the only collective is the final gather of status words + public signals.
+`--total-batch N` fixes the whole job's batch (strong scaling, BASELINE config 4 = 8192 over 8 GPUs); the default is
+a fixed per-GPU batch (weak scaling).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
-kernel (schedule evaluation) and `cpu_baseline` (reference C++ runtime timed on the host cores).
+After the timed region, sampled instances AT THE BENCHMARK BATCH are compared with the oracle (reference C++ runtime
+built under oracle/_ref when present, else the Python restatement) byte for byte, and — for SHA-256 workloads — every
+instance's digest with hashlib; the JSON reports `parity_checked`.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel of the run, chosen by measured time), per-kernel
+rooflines and `cpu_baseline` (reference C++ runtime timed on the host cores, core count stated).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -25,22 +34,61 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
+DEFAULT_BATCH = {"sha256_2048": 4096, "sha256_512": 4096, "poseidon2": 65536, "semaphore20": 8192}
 
 
-def build_workload(name: str, outdir: str):
-    from circom_amd.compiler import compile_program
+def make_program(name: str):
     from circom_amd.frontend.dsl import Program
     if name == "poseidon2":
         from circom_amd.circuits.poseidon import Poseidon
-        return compile_program(Program(Poseidon(2)), outdir, "poseidon2", sym=False)
+        return Program(Poseidon(2))
     if name.startswith("sha256_"):
         from circom_amd.circuits.sha256 import Sha256
-        nbits = int(name.split("_")[1])
-        return compile_program(Program(Sha256(nbits)), outdir, name, sym=False)
+        return Program(Sha256(int(name.split("_")[1])))
     if name.startswith("semaphore"):
         from circom_amd.circuits.eddsa import SemaphoreStyle
-        return compile_program(Program(SemaphoreStyle(int(name[len("semaphore"):] or 20))), outdir, name, sym=False)
+        return Program(SemaphoreStyle(int(name[len("semaphore"):] or 20)))
     raise SystemExit("unknown workload " + name)
+
+
+def source_fingerprint() -> str:
+    """Hash of everything that shapes the kernels and the schedule: cached artefacts and committed counter figures
+    (profiles/traffic.json) are only used when they were produced by this exact source."""
+    h = hashlib.sha256()
+    files = sorted((ROOT / "circom_amd" / "csrc").glob("*")) + sorted((ROOT / "circom_amd" / "hip_elements").glob("*.py")) \
+        + sorted((ROOT / "circom_amd" / "frontend").glob("*.py")) + sorted((ROOT / "circom_amd" / "circuits").glob("*.py"))
+    for f in files:
+        if f.is_file() and f.suffix in (".hip", ".h", ".cpp", ".py"):
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def get_compiled(name: str, batch: int, cache_root: str, rank: int, dist):
+    """Rank 0 traces + lowers the circuit once (or finds the artefacts of this exact source in the cache); the other
+    ranks wait and load the files.  Every rank traces + flattens (seconds) to have the flat code for the oracle."""
+    from circom_amd import compiler
+    from circom_amd.frontend.flatten import flatten
+    from circom_amd.hip_elements import writers
+    from circom_amd.hip_elements.lower import lower
+    fp = source_fingerprint()
+    strands = compiler.strands_for(batch)
+    d = os.path.join(cache_root, "%s_s%s_%s" % (name, "-".join(map(str, strands)), fp))
+    p = lambda ext: os.path.join(d, name + ext)
+    t0 = time.perf_counter()
+    fc = flatten(make_program(name))
+    done = os.path.join(d, "done")
+    if rank == 0 and not os.path.exists(done):
+        os.makedirs(d, exist_ok=True)
+        tapes = [lower(fc, n_strands=s) for s in strands]
+        writers.write_tape(p(".cwt"), tapes)
+        writers.write_dat(p(".dat"), fc)
+        writers.write_r1cs(p(".r1cs"), fc)
+        open(done, "w").write(fp)
+    if dist:
+        dist.barrier()
+    cp = compiler.Compiled(name, d, p(".cwt"), p(".dat"), p(".r1cs"), p(".sym"), fc, None)
+    return cp, time.perf_counter() - t0
 
 
 def synth_inputs(name: str, q: int, batch: int, n_inputs: int, seed: int):
@@ -68,6 +116,60 @@ def synth_inputs(name: str, q: int, batch: int, n_inputs: int, seed: int):
     return np.frombuffer(b"".join(v.to_bytes(32, "little") for v in vals), dtype=np.uint8).reshape(batch, n_inputs, 32).copy()
 
 
+def parity_check(cp, circ, batch, h_in, workload: str, n_sample: int = 4):
+    """Oracle comparison at the benchmark batch (after the timed region).  Returns a dict for the JSON line; raises
+    AssertionError on any mismatch (a fast wrong answer is not a result)."""
+    import numpy as np
+    B = batch.n
+    picks = sorted({0, 1, B // 2, B - 1} | {(B * k) // max(n_sample, 1) for k in range(n_sample)})[:max(n_sample, 1)]
+    picks = [i for i in picks if i < B]
+    out = {"instances": picks, "oracle": None, "digests_checked": 0}
+    fc = cp.flat
+    n_in = circ.n_inputs
+    from circom_amd.hip_elements.writers import wtns_bytes
+    td = tempfile.mkdtemp(prefix="cw_parity_")
+    got = {}
+    for i in picks:                                       # through the C ABI's writeBinWitness (cw_write_wtns)
+        batch.write_wtns(i, os.path.join(td, "g_%d.wtns" % i))
+        got[i] = open(os.path.join(td, "g_%d.wtns" % i), "rb").read()
+    want = None
+    try:
+        from oracle import ref_build
+        cli, loop = ref_build.build_circuit(cp)          # cached binary if its fingerprint matches this circuit
+        if loop.exists():
+            raw = b"".join(h_in[i].tobytes() for i in picks)
+            ref_build.run_loop(cp, raw, len(picks), 1, wtns_prefix=os.path.join(td, "r_"))
+            want = {i: open(os.path.join(td, "r_%d.wtns" % k), "rb").read() for k, i in enumerate(picks)}
+            out["oracle"] = "reference C++ runtime (oracle/_ref/%s/%s_loop), full .wtns bytes" % (fc.prime, cp.name)
+    except Exception as e:      # fall back to the Python restatement below
+        out["oracle_note"] = "reference binary unusable: %s" % str(e)[:120]
+    if want is None:
+        from oracle.tape_eval import eval_flat
+        want = {}
+        for i in picks:
+            inp = {fc.main_input_start + k: int.from_bytes(h_in[i, k].tobytes(), "little") for k in range(n_in)}
+            sig, failed = eval_flat(circ.q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp)
+            assert failed is None, "oracle reports a failed assert for instance %d" % i
+            want[i] = wtns_bytes(circ.q, sig)
+        out["oracle"] = "oracle/tape_eval.eval_flat (Python restatement of the emitted calculator), full .wtns bytes"
+    for i in picks:
+        assert got[i] == want[i], "PARITY FAILURE: .wtns of instance %d differs from the oracle's" % i
+    out["wtns_sha256_first"] = hashlib.sha256(got[picks[0]]).hexdigest()
+    if workload.startswith("sha256_"):
+        # every instance's digest against hashlib (output bit k = bit 7-(k%8) of digest byte k/8, msb first)
+        pub = batch.public_signals()                     # [B][n_public][32]
+        assert not pub[:, :256, 1:].any(), "digest signals are not bits"
+        bits = pub[:, :256, 0]
+        nb = int(workload.split("_")[1])
+        msg_bits = h_in[:, :nb, 0]
+        for i in range(B):
+            msg = np.packbits(msg_bits[i]).tobytes()
+            dg = np.unpackbits(np.frombuffer(hashlib.sha256(msg).digest(), dtype=np.uint8))
+            assert (bits[i] == dg).all(), "PARITY FAILURE: digest of instance %d differs from hashlib" % i
+        out["digests_checked"] = B
+    return out
+
+
 def cpu_baseline(cp, name, seconds_budget=15.0):
     """Time the CPU checker on a bounded sample of the same workload (rank 0, N=1 only)."""
     try:
@@ -83,11 +185,15 @@ def cpu_baseline(cp, name, seconds_budget=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default=os.environ.get("CW_WORKLOAD", "poseidon2"))
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("CW_BATCH", "65536")))
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("CW_WORKLOAD", "sha256_2048"))
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("CW_BATCH", "0")), help="instances per GPU")
+    ap.add_argument("--total-batch", type=int, default=0, help="instances of the whole job (strong scaling)")
+    ap.add_argument("--cache-dir", default=os.environ.get("CW_CACHE", ""))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--fp-bench-lanes", type=int, default=1 << 24)
     args = ap.parse_args()
 
     import numpy as np
@@ -104,12 +210,27 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    tmp = tempfile.mkdtemp(prefix="cw_bench_")
-    cp = build_workload(args.workload, tmp)
+    scaling = "weak"
+    B = args.batch or DEFAULT_BATCH.get(args.workload, 4096)
+    if args.total_batch:
+        scaling = "strong"
+        from circom_amd.sharding import shard_range
+        lo, hi = shard_range(args.total_batch, rank, world)
+        B = hi - lo
+    cache_root = args.cache_dir or (str(ROOT / "gpurun_in" / "cache") if (ROOT / "gpurun_in" / "cache").is_dir()
+                                    else os.path.join(tempfile.gettempdir(), "cw_bench_cache_%d" % os.getuid()))
+    cp, compile_s = get_compiled(args.workload, B, cache_root, rank, dist)
     circ = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
-    B = args.batch
+    if args.workload == "sha256_2048":
+        assert circ.n_constraints >= 1_000_000, "the metric's workload must have >= 1M constraints"
     stream = torch.cuda.current_stream()
-    batch = circ.batch(B, device=local_rank, stream=stream.cuda_stream)
+    try:
+        batch = circ.batch(B, device=local_rank, stream=stream.cuda_stream)
+    except rt.CwError:
+        if args.batch or args.total_batch or B <= 1024:
+            raise
+        B //= 2                                              # the value table did not fit: halve the batch once
+        batch = circ.batch(B, device=local_rank, stream=stream.cuda_stream)
     # synthetic inputs, resident in HBM before the timed region (different seed per rank = different shard)
     h_in = synth_inputs(args.workload, circ.q, B, circ.n_inputs, seed=1 + rank)
     d_in = torch.from_numpy(h_in).to(dev)
@@ -149,6 +270,7 @@ def main():
     from circom_amd.sharding import gather_status, gather_rows
     status = gather_status(torch.from_numpy(batch.status().astype(np.int32)).to(dev), dist, rank, world)
     n_bad = int((status != 0).sum().item()) if rank == 0 else 0
+    n_total = int(status.numel()) if rank == 0 else 0
     pub = torch.empty((B, circ.n_public, 32), dtype=torch.uint8, device=dev)
     if circ.n_public:
         batch.public_signals_device(pub.data_ptr())
@@ -159,33 +281,54 @@ def main():
     gen_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / args.steps
     chk_ms = sum(e[1].elapsed_time(e[2]) for e in evs) / args.steps
 
-    # Fp mul/s half of the metric: device micro-benchmark, 2^20 lanes x 512 dependent Montgomery products
-    fp_mul_per_s = None
+    parity = None
+    if not args.no_parity:
+        parity = parity_check(cp, circ, batch, h_in, args.workload)       # every rank checks its own shard
+        parity["parity_checked"] = len(parity["instances"])
+
+    # Fp mul/s half of the metric: 2^24 lanes x 1024 dependent Montgomery products, bn128 and bls12381
+    fp_mul = {}
     if rank == 0:
+        from circom_amd.field import PRIMES
         rng = np.random.default_rng(5)
-        n = 1 << 20
+        n = args.fp_bench_lanes
         a = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
         b = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
         a[:, 31] &= 0x1F
         b[:, 31] &= 0x1F
-        _, ms = rt.fp_mul_bench(circ.q, a, b, 512, device=local_rank)
-        fp_mul_per_s = n * 512 / (ms * 1e-3)
+        for pname in ("bn128", "bls12381"):
+            _, ms = rt.fp_mul_bench(PRIMES[pname], a, b, 1024, device=local_rank)
+            fp_mul[pname] = n * 1024 / (ms * 1e-3)
+    fp_mul_per_s = fp_mul.get("bn128")
 
     if rank == 0:
-        total_witnesses = B * world * args.steps
+        total_witnesses = n_total * args.steps
         value = total_witnesses / elapsed
         n_in, n_wit = circ.n_inputs, circ.n_witness
-        alg_bytes = 32.0 * (n_in + n_wit) * B          # B_gen of SURVEY §8d, per launch
-        achieved = alg_bytes / (gen_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
-        # tools/summarize_prof.py: (2*FETCH_SIZE + WRITE_SIZE) KiB with the gfx950 FETCH_SIZE correction)
-        traffic = traffic_chk = None
+        alg_gen = 32.0 * (n_in + n_wit) * B            # B_gen of SURVEY §8d, per launch
+        alg_chk = 32.0 * n_wit * B                     # B_chk
+        # HBM bytes per launch + VALU-busy from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
+        # tools/summarize_prof.py) — only if those passes ran on this exact source (fingerprint), else null
+        prof = {}
         try:
             tj = json.load(open(ROOT / "profiles" / "traffic.json"))
-            traffic = tj.get("%s:%d" % (args.workload, B), {}).get("cw_eval_kernel")
-            traffic_chk = tj.get("%s:%d" % (args.workload, B), {}).get("cw_r1cs_kernel")
+            ent = tj.get("%s:%d" % (args.workload, B), {})
+            if ent.get("source") == source_fingerprint():
+                prof = ent
         except Exception:
             pass
+        gen_gbs = alg_gen / (gen_ms * 1e-3) / 1e9
+        chk_gbs = alg_chk / (chk_ms * 1e-3) / 1e9
+        roof_eval = {"bound": "hbm", "kernel": "cw_eval_kernel", "achieved": gen_gbs, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": gen_gbs / HBM_PEAK_GBS, "traffic": prof.get("cw_eval_kernel"),
+                     "valu_busy": prof.get("cw_eval_kernel_valu_busy"),
+                     "algorithmic_bytes_per_launch": alg_gen, "kernel_ms": gen_ms,
+                     "strands": batch.strands, "lanes_per_workgroup": batch.lanes,
+                     "fp_mul_per_s_in_kernel": circ.n_mmul * B / (gen_ms * 1e-3)}
+        roof_r1cs = {"bound": "hbm", "kernel": "cw_r1cs_stream_kernel", "achieved": chk_gbs, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": chk_gbs / HBM_PEAK_GBS, "traffic": prof.get("cw_r1cs_kernel"),
+                     "valu_busy": prof.get("cw_r1cs_kernel_valu_busy"),
+                     "algorithmic_bytes_per_launch": alg_chk, "kernel_ms": chk_ms}
         out = {
             "metric": "witnesses/sec (batched inputs)",
             "value": value,
@@ -195,35 +338,32 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "u256 (8xu32 limbs, Montgomery multiply)",
             "data": "synthetic",
-            "config": {"workload": "%s bn128 --O0, batch=%d per GPU" % (args.workload, B),
+            "config": {"workload": "%s bn128 --O0 (%d constraints), batch=%d per GPU" % (args.workload, circ.n_constraints, B),
                        "n_signals": circ.n_signals, "n_witness": n_wit, "n_constraints": circ.n_constraints,
                        "schedule_rows": circ.n_rows, "fp_mul_per_witness": circ.n_mmul,
-                       "parallelism": "instances sharded x%d, status gather only" % world},
-            "roofline": {"bound": "hbm", "kernel": "cw_eval_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": gen_ms,
-                         "strands": batch.strands, "lanes_per_workgroup": batch.lanes,
-                         "fp_mul_per_s_in_kernel": circ.n_mmul * B / (gen_ms * 1e-3)},
+                       "parallelism": "instances sharded x%d, status + public-signal gather only" % world,
+                       "compile_s": compile_s},
+            # the dominant kernel of THIS run (longest measured duration)
+            "roofline": roof_eval if gen_ms >= chk_ms else roof_r1cs,
+            "roofline_eval": roof_eval,
+            "roofline_r1cs": roof_r1cs,
             # second bound of SURVEY §8d (integer carry chains, no MFMA): Fp products per second inside the
-            # evaluation kernel against the device's measured Fp-multiply peak (micro-benchmark below)
+            # evaluation kernel against the device's measured Fp-multiply peak (micro-benchmark, 2^24 x 1024)
             "roofline_valu": {"bound": "valu", "kernel": "cw_eval_kernel", "unit": "Fp-mul/s",
                               "achieved": circ.n_mmul * B / (gen_ms * 1e-3), "peak": fp_mul_per_s,
                               "frac": (circ.n_mmul * B / (gen_ms * 1e-3)) / fp_mul_per_s if fp_mul_per_s else None},
             "fp_mul_per_s": fp_mul_per_s,
-            # the second kernel against the same HBM roof: algorithmic bytes = re-read every witness element once
-            "roofline_r1cs": {"bound": "hbm", "kernel": "cw_r1cs_stream_kernel", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                              "achieved": 32.0 * n_wit * B / (chk_ms * 1e-3) / 1e9,
-                              "frac": 32.0 * n_wit * B / (chk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_chk,
-                              "moved_gbs": (traffic_chk / (chk_ms * 1e-3) / 1e9) if traffic_chk else None,
-                              "kernel_ms": chk_ms},
+            "fp_mul_per_s_by_prime": fp_mul,
+            "eval_ms": gen_ms,
             "r1cs_check_ms": chk_ms,
-            "r1cs_check_gbs": 32.0 * n_wit * B / (chk_ms * 1e-3) / 1e9,
             "failed_instances": n_bad,
-            "gathered": {"status_words": int(status.numel()), "public_signal_rows": n_pub_gathered,
+            "parity": parity,
+            "parity_checked": parity["parity_checked"] if parity else 0,
+            "gathered": {"status_words": n_total, "public_signal_rows": n_pub_gathered,
                          "public_signals_per_instance": circ.n_public},
             "cpu_baseline": None,
         }

@@ -26,6 +26,17 @@ class Compiled:
 DEFAULT_STRANDS = (1, 4, 16)
 
 
+def strands_for(batch: int):
+    """The one variant cw_batch_create picks for `batch` instances (csrc/cw_host.cpp: most strands with
+    groups * S <= 8192) — lowering a 1M-constraint circuit takes about a minute per variant, so callers that know
+    their batch lower only this one."""
+    groups = (batch + 63) // 64
+    for s in (16, 4):
+        if groups * s <= 8192:
+            return (s,)
+    return (1,)
+
+
 def compile_program(prog: Program, outdir: str, name: str, sym: bool = True, strands=DEFAULT_STRANDS) -> Compiled:
     """strands: strand counts to lower the schedule for (one variant each; the runtime picks per batch)."""
     os.makedirs(outdir, exist_ok=True)

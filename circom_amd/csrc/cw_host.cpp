@@ -272,11 +272,14 @@ static const char *validate_variant(const Variant &v, uint32_t n_signals, uint32
                 if (tp + row.a > v.term_off[st + 1]) return "term list overruns its strand";
                 for (uint32_t t = 0; t < row.a; t++) {
                     const uint32_t *tm = &v.terms[(tp + t) * 4];
-                    if (!operand_ok(tm[0] & 7, tm[1]) || (tm[0] & 7) == K_CONST) return "term operand out of range";
+                    const uint32_t tk = tm[0] & 7;                    // the kinds term_load handles
+                    if (tk != K_SIG && tk != K_TMP && tk != K_PREV && tk != K_LDS) return "term operand kind";
+                    if (!operand_ok(tk, tm[1])) return "term operand out of range";
                     if (op == D_DOTC && tm[2] >= n_lconsts) return "term constant out of range";
                 }
                 tp += row.a;
-                if (bk == K_CONST && row.b >= n_consts) return "constant out of range";
+                // c0 is a constant or absent (kind 0, index 0): the kernel's prefetch dereferences whatever is encoded
+                if (bk == K_CONST ? row.b >= n_consts : (bk != 0 || row.b != 0)) return "constant out of range";
             } else if (op == D_BIT) {
                 if (!operand_ok(ak, row.a)) return "operand out of range";
             } else {
@@ -324,7 +327,8 @@ static int load_tape(cw_circuit *c, const char *path) {
     // shape of the main component: slot 0 is the constant 1, outputs from slot 1, inputs right after them
     if (c->input_start == 0 || (uint64_t)c->input_start + c->n_inputs > c->n_signals || c->n_pub_in > c->n_inputs ||
         c->n_witness == 0 || c->n_witness > c->n_signals || hsize < 256 || (hsize & (hsize - 1)) ||
-        hsize > std::max<uint64_t>(256, 2 * (uint64_t)n_names) || n_names > c->n_inputs + 1u)   // max(2^ceil(log2 n), 256), mod.rs:167
+        n_names > hsize || hsize > std::max<uint64_t>(256, 2 * (uint64_t)n_names) ||            // max(2^ceil(log2 n), 256), mod.rs:167
+        (hsize > 256 && hsize / 2 >= n_names) || n_names > c->n_inputs + 1u)
         return fail(CW_EIO, "tape header: inconsistent circuit shape");
     if (b.size() < off + ((size_t)c->n_consts + n_lconsts) * 32 + (size_t)c->n_witness * 4)
         return fail(CW_EIO, "tape file truncated");
@@ -362,7 +366,8 @@ static int load_tape(cw_circuit *c, const char *path) {
         off += 8;
         if (ss[0] < c->input_start || (uint64_t)ss[0] + ss[1] > (uint64_t)c->input_start + c->n_inputs)
             return fail(CW_EIO, "tape input name refers to slots outside the main inputs");
-        c->input_names[name] = {ss[0], ss[1]};
+        if (!c->input_names.emplace(name, std::make_pair(ss[0], ss[1])).second)
+            return fail(CW_EIO, "tape input name appears twice");
     }
     if (n_variants == 0) return fail(CW_EIO, "tape holds no schedule");
     for (uint32_t v = 0; v < n_variants; v++) {
@@ -462,8 +467,11 @@ static int load_tape(cw_circuit *c, const char *path) {
     std::sort(order.begin(), order.end());
     for (auto &o : order) {
         uint64_t hsh = fnv1a(o.second.data(), o.second.size());
-        size_t p = hsh % hsize;
-        while (c->hashmap[p].signalid != 0) p = (p + 1) % hsize;
+        size_t p = hsh % hsize, probes = 0;
+        while (c->hashmap[p].signalid != 0) {
+            if (++probes > hsize) return fail(CW_EIO, "tape input hash map is full");
+            p = (p + 1) % hsize;
+        }
         c->hashmap[p] = HashEntry{hsh, o.first, c->input_names[o.second].second};
     }
     if (!prime_supported(c->q))
@@ -483,8 +491,9 @@ static int load_dat(cw_circuit *c, const char *path) {
     for (size_t i = 0; i < hs; i++) {
         memcpy(&c->hashmap[i], b.data() + i * 24, 24);
         const HashEntry &h = c->hashmap[i];                  // setInputSignal writes signalValues[signalid + idx]
-        if (h.signalid != 0 && (h.signalid < c->input_start || h.signalsize > c->n_inputs ||
-                                h.signalid + h.signalsize > (uint64_t)c->input_start + c->n_inputs))
+        // overflow-free: signalid in [input_start, input_start + n_inputs], size <= what is left behind it
+        const uint64_t in_end = (uint64_t)c->input_start + c->n_inputs;
+        if (h.signalid != 0 && (h.signalid < c->input_start || h.signalid > in_end || h.signalsize > in_end - h.signalid))
             return fail(CW_EIO, ".dat input hash map refers to slots outside the main inputs");
     }
     const uint8_t *w = b.data() + hs * 24;
@@ -514,14 +523,16 @@ static int load_r1cs(cw_circuit *c, const char *path) {
         memcpy(&typ, b.data() + off, 4);
         memcpy(&len, b.data() + off + 4, 8);
         off += 12;
-        if (off + len > b.size()) return fail(CW_EIO, "r1cs section truncated");
+        if (len > b.size() - off) return fail(CW_EIO, "r1cs section truncated");
         if (typ < 6) {
+            if (sec[typ]) return fail(CW_EIO, "r1cs section appears twice");
             sec[typ] = b.data() + off;
             seclen[typ] = len;
         }
         off += len;
     }
     if (!sec[1] || !sec[2]) return fail(CW_EIO, "r1cs misses header or constraints section");
+    if (seclen[1] < 64) return fail(CW_EIO, "r1cs header section too short");      // 4 + 32 + 4*4 + 8 + 4
     uint32_t fs;
     memcpy(&fs, sec[1], 4);
     if (fs != 32) return fail(CW_EIO, "r1cs field size must be 32 bytes");
@@ -531,6 +542,7 @@ static int load_r1cs(cw_circuit *c, const char *path) {
     uint32_t n_wires = hdr[0], n_cons;
     memcpy(&n_cons, sec[1] + 36 + 16 + 8, 4);
     if (n_wires != c->n_witness) return fail(CW_EIO, "r1cs wire count differs from the witness size");
+    if ((uint64_t)n_cons > seclen[2] / 12) return fail(CW_EIO, "r1cs constraint count exceeds its section");   // 3 x u32 nnz each
     c->n_constraints = n_cons;
     c->r_ptr.assign(1, 0);
     c->r_ptr.reserve((size_t)n_cons * 3 + 1);
@@ -630,9 +642,16 @@ static int load_r1cs(cw_circuit *c, const char *path) {
 extern "C" int cw_load(const char *tape_path, const char *dat_path, const char *r1cs_path, cw_circuit **out) {
     if (!tape_path || !out) return fail(CW_EINVAL, "cw_load: null argument");
     cw_circuit *c = new cw_circuit();
-    int rc = load_tape(c, tape_path);
-    if (rc == CW_OK && dat_path) rc = load_dat(c, dat_path);
-    if (rc == CW_OK && r1cs_path) rc = load_r1cs(c, r1cs_path);
+    int rc;
+    try {                                   // a hostile size field must not take the host process down (no C++ exception crosses the C ABI)
+        rc = load_tape(c, tape_path);
+        if (rc == CW_OK && dat_path) rc = load_dat(c, dat_path);
+        if (rc == CW_OK && r1cs_path) rc = load_r1cs(c, r1cs_path);
+    } catch (const std::bad_alloc &) {
+        rc = fail(CW_EIO, "cw_load: a table size in the files exceeds available memory");
+    } catch (const std::exception &e) {
+        rc = fail(CW_EIO, std::string("cw_load: ") + e.what());
+    }
     if (rc != CW_OK) {
         delete c;
         return rc;
@@ -763,6 +782,7 @@ extern "C" void cw_batch_free(cw_batch *b) {
 
 extern "C" int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *stream, cw_batch **out) {
     if (!c || !out || batch == 0) return fail(CW_EINVAL, "cw_batch_create: bad argument");
+    if (batch > (1u << 26)) return fail(CW_EINVAL, "cw_batch_create: batch exceeds 2^26 instances (32-bit lane offsets)");
     if (device < 0) {
         // host-only batch: input staging and its error semantics can be exercised without a GPU;
         // anything that computes fails loudly.

@@ -53,12 +53,13 @@ __global__ void __launch_bounds__(CW_BLOCK) cw_ingest_kernel(const uint4 *__rest
                                                               uint32_t input_start, uint32_t n_in, uint32_t batch,
                                                               uint32_t Bp) {
     uint32_t i = blockIdx.x * CW_BLOCK + threadIdx.x;
-    uint32_t k = blockIdx.y;
     if (i >= batch) return;
-    size_t src = ((size_t)i * n_in + k) * 2;
-    size_t dst = (size_t)(input_start + k) * 2 * Bp + i;
-    V[dst] = in[src];
-    V[dst + Bp] = in[src + 1];
+    for (uint32_t k = blockIdx.y; k < n_in; k += gridDim.y) {      // grid.y is capped at 65535 input signals per pass
+        size_t src = ((size_t)i * n_in + k) * 2;
+        size_t dst = (size_t)(input_start + k) * 2 * Bp + i;
+        V[dst] = in[src];
+        V[dst + Bp] = in[src + 1];
+    }
 }
 
 // ---- schedule evaluation (the hot path) ---------------------------------------------------------------
@@ -539,24 +540,27 @@ __device__ __forceinline__ void r1_finish(const R1State &s, uint32_t i, uint32_t
 }
 
 __global__ void __launch_bounds__(64)
-cw_r1cs_stream_kernel(const uint4 *__restrict__ chunk, const uint2 *__restrict__ terms, const uint32_t *__restrict__ ctab,
+cw_r1cs_stream_kernel(const uint4 *__restrict__ chunk, uint32_t n_chunks, const uint2 *__restrict__ terms, const uint32_t *__restrict__ ctab,
                       const uint32_t *__restrict__ ctab29, const uint32_t *__restrict__ row_orig, const uint4 *__restrict__ V, uint32_t Bp, uint32_t batch,
                       uint32_t *status, uint32_t *first_bad, FpParams P) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;               // < Bp
-    const uint4 ch = chunk[blockIdx.y];                             // first term, n terms, -, first row
-    const uint2 *tp = terms + ch.x;                                 // the stream is padded: tp[n] is readable
     R1State s;
-    s.A = fe_zero(); s.B = fe_zero(); s.cur = fe_zero();
-    s.row = ch.w; s.bad = 0xFFFFFFFFu;
-    uint2 t0 = tp[0];
-    fe w0 = v_load(V, t0.x & 0x3FFFFFFu, Bp, i);
-    // the next term's wire is in flight while this one is accumulated (two terms ahead costs 16 more VGPRs, which
-    // drops a wave per SIMD, and measured no faster)
-    for (uint32_t k = 0; k < ch.y; k++) {
-        const uint2 t1 = tp[k + 1];
-        const fe w1 = v_load(V, t1.x & 0x3FFFFFFu, Bp, i);
-        r1_term(w0, t0.x, t0.y, s, ctab, ctab29, row_orig, P);
-        t0 = t1; w0 = w1;
+    s.bad = 0xFFFFFFFFu;
+    for (uint32_t cix = blockIdx.y; cix < n_chunks; cix += gridDim.y) {   // grid.y is capped at 65535: large systems loop
+        const uint4 ch = chunk[cix];                                // first term, n terms, -, first row
+        const uint2 *tp = terms + ch.x;                             // the stream is padded: tp[n] is readable
+        s.A = fe_zero(); s.B = fe_zero(); s.cur = fe_zero();
+        s.row = ch.w;
+        uint2 t0 = tp[0];
+        fe w0 = v_load(V, t0.x & 0x3FFFFFFu, Bp, i);
+        // the next term's wire is in flight while this one is accumulated (two terms ahead costs 16 more VGPRs, which
+        // drops a wave per SIMD, and measured no faster)
+        for (uint32_t k = 0; k < ch.y; k++) {
+            const uint2 t1 = tp[k + 1];
+            const fe w1 = v_load(V, t1.x & 0x3FFFFFFu, Bp, i);
+            r1_term(w0, t0.x, t0.y, s, ctab, ctab29, row_orig, P);
+            t0 = t1; w0 = w1;
+        }
     }
     r1_finish(s, i, batch, status, first_bad);
 }
@@ -740,7 +744,7 @@ hipError_t cwk_init(hipStream_t s, void *V, uint32_t Bp, uint32_t *status, uint3
 hipError_t cwk_ingest(hipStream_t s, const void *in, void *V, uint32_t input_start, uint32_t n_in, uint32_t batch,
                       uint32_t Bp) {
     if (n_in == 0) return hipSuccess;
-    dim3 g((batch + CW_BLOCK - 1) / CW_BLOCK, n_in);
+    dim3 g((batch + CW_BLOCK - 1) / CW_BLOCK, n_in < 65535u ? n_in : 65535u);
     hipLaunchKernelGGL(cw_ingest_kernel, g, dim3(CW_BLOCK), 0, s, (const uint4 *)in, (uint4 *)V, input_start, n_in, batch,
                        Bp);
     return hipGetLastError();
@@ -768,8 +772,8 @@ hipError_t cwk_r1cs(hipStream_t s, const uint32_t *chunk, uint32_t n_chunks, con
                     const uint32_t *ctab29, const uint32_t *row_orig, const void *V, uint32_t Bp, uint32_t batch, uint32_t *status,
                     uint32_t *first_bad, const FpParams &P) {
     if (n_chunks == 0) return hipSuccess;
-    dim3 g((batch + 63) / 64, n_chunks);
-    hipLaunchKernelGGL(cw_r1cs_stream_kernel, g, dim3(64), 0, s, (const uint4 *)chunk, (const uint2 *)terms, ctab, ctab29, row_orig,
+    dim3 g((batch + 63) / 64, n_chunks < 65535u ? n_chunks : 65535u);
+    hipLaunchKernelGGL(cw_r1cs_stream_kernel, g, dim3(64), 0, s, (const uint4 *)chunk, n_chunks, (const uint2 *)terms, ctab, ctab29, row_orig,
                        (const uint4 *)V, Bp, batch, status, first_bad, P);
     return hipGetLastError();
 }

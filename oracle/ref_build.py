@@ -106,14 +106,42 @@ def run_loop(cp, inputs_bytes: bytes, n: int, reps: int = 1, wtns_prefix: str = 
     return outs
 
 
+def host_cores():
+    """Cores this process may actually use: the scheduler affinity mask, cut by the cgroup CPU quota when one is set
+    (a container that shows 256 CPUs in os.cpu_count() may be limited to ~10 of them by /sys/fs/cgroup/cpu.max).
+    Returns (usable, affinity, quota or None)."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0])
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    usable = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    return usable, aff, quota
+
+
 def time_reference(cp, workload: str, seconds_budget: float = 15.0):
-    """cpu_baseline for bench.py: reference runtime + reference generic (no-asm, GMP) field library,
-    compute-only loop, one process per host core, bounded sample."""
+    """cpu_baseline for bench.py: reference runtime + reference generic (no-asm, GMP) field library on the host
+    cores this process can really use (host_cores()), bounded sample.  Two legs:
+      (ii) compute-only in-process loop (`run(ctx)` on pre-parsed inputs), one process per usable core -> `value`;
+      (i)  end to end as the reference is used: `./<name> input.json out.wtns`, one process per input -> `end_to_end`."""
     import numpy as np
     cli, loop = binaries(cp.flat.prime, cp.name)
     if not (loop.exists()):
         build_circuit(cp)
-    cores = os.cpu_count() or 1
+    cores, affinity, quota = host_cores()
     q = cp.flat.fp.q
     n_in = cp.flat.n_main_inputs
     rng = np.random.default_rng(1)
@@ -132,28 +160,68 @@ def time_reference(cp, workload: str, seconds_budget: float = 15.0):
             return b"".join(pool[i % len(pool)] for i in range(n))
         vals = [int.from_bytes(rng.bytes(32), "little") % q for _ in range(n * n_in)]
         return b"".join(v.to_bytes(32, "little") for v in vals)
-    # calibrate: one core on an otherwise idle machine, then a small pilot on ALL cores (the reference runtime
-    # allocates every signal and component per run, so its per-core rate drops sharply when 256 copies compete
-    # for memory), and size the sample from the loaded rate so the whole leg stays near `seconds_budget`
-    n0 = 8
+    # calibrate on one core, then a short pilot on all usable cores, and size the sample from the loaded rate
+    n0 = 2
     t = run_loop(cp, gen(n0), n0, 1)[0]
     per = t["seconds"] / n0
-    n1 = max(8, min(20000, int(2.0 / max(per, 1e-6))))          # ~2 s on ONE core
+    n1 = max(2, min(20000, int(2.0 / max(per, 1e-6))))          # ~2 s on ONE core
     single = run_loop(cp, gen(n1), n1, 1)[0]["witnesses_per_s"]
-    n_pilot = max(2, min(5000, int(0.1 / max(per, 1e-6))))
+    n_pilot = max(1, min(5000, int(0.2 / max(per, 1e-6))))
     pilot = run_loop(cp, gen(n_pilot) * cores, n_pilot * cores, 1, procs=cores)
     per_loaded = max(o["seconds"] for o in pilot) / n_pilot       # compute seconds per instance per core, all cores busy
-    n_per_core = max(2, min(20000, int(seconds_budget * 0.5 / max(per_loaded, 1e-6))))
+    n_per_core = max(1, min(20000, int(seconds_budget * 0.5 / max(per_loaded, 1e-6))))
     n = n_per_core * cores
     t0 = time.perf_counter()
     outs = run_loop(cp, gen(n_per_core) * cores, n, 1, procs=cores)
     wall = time.perf_counter() - t0
     agg = sum(o["witnesses_per_s"] for o in outs)
-    return {"value": agg, "unit": "witnesses/s", "cores": cores, "kind": "reference",
-            "per_core": agg / cores, "single_core_alone": single,
-            "sample": "%d instances (%d per core x %d cores) of %s through the reference C++ runtime "
-                      "(common/calcwit.cpp + generic/fr.cpp --no_asm GMP build), compute-only in-process loop, "
-                      "wall %.1f s" % (n, n_per_core, cores, workload, wall)}
+    res = {"value": agg, "unit": "witnesses/s", "cores": cores, "kind": "reference",
+           "per_core": agg / cores, "single_core_alone": single,
+           "cores_detail": {"os_cpu_count": os.cpu_count(), "sched_affinity": affinity, "cgroup_quota": quota},
+           "sample": "%d instances (%d per core x %d cores) of %s through the reference C++ runtime "
+                     "(common/calcwit.cpp + generic/fr.cpp --no_asm GMP build), compute-only in-process loop, "
+                     "wall %.1f s" % (n, n_per_core, cores, workload, wall)}
+    # (i) end to end: JSON parse + process start + .dat load + compute + .wtns write, `cores` processes at a time
+    try:
+        res["end_to_end"] = _time_cli(cp, gen, cores, min(8.0, seconds_budget * 0.5))
+    except Exception as e:      # a report, never a reason to fail
+        res["end_to_end"] = {"value": None, "error": str(e)[:200]}
+    return res
+
+
+def _time_cli(cp, gen, cores, budget):
+    cli, _ = binaries(cp.flat.prime, cp.name)
+    n_in = cp.flat.n_main_inputs
+    raw = gen(4)
+    with tempfile.TemporaryDirectory() as td:
+        files = []
+        for i in range(4):
+            vals = [int.from_bytes(raw[(i * n_in + k) * 32:(i * n_in + k + 1) * 32], "little") for k in range(n_in)]
+            obj, pos = {}, 0
+            for name, _, size in cp.flat.inputs:
+                dims = cp.flat.input_dims.get(name) or []
+                obj[name] = str(vals[pos]) if not dims else [str(v) for v in vals[pos:pos + size]]
+                pos += size
+            fn = os.path.join(td, "in%d.json" % i)
+            json.dump(obj, open(fn, "w"))
+            files.append(fn)
+        t0 = time.perf_counter()
+        r = subprocess.run([str(cli), files[0], os.path.join(td, "w0.wtns")], capture_output=True)
+        one = time.perf_counter() - t0
+        if r.returncode != 0:
+            raise RuntimeError("reference CLI failed: %s" % r.stderr[-200:])
+        rounds = max(1, int(budget / max(one, 1e-3) / 2))
+        t0 = time.perf_counter()
+        done = 0
+        for _ in range(rounds):
+            ps = [subprocess.Popen([str(cli), files[k % 4], os.path.join(td, "w%d.wtns" % k)], stdout=subprocess.DEVNULL,
+                                   stderr=subprocess.DEVNULL) for k in range(cores)]
+            for p_ in ps:
+                p_.wait()
+                done += 1
+        wall = time.perf_counter() - t0
+    return {"value": done / wall, "unit": "witnesses/s", "cores": cores, "seconds_per_witness_one_process": one,
+            "sample": "%d runs of `./%s input.json out.wtns` (%d at a time)" % (done, cp.name, cores)}
 
 
 def build_default_circuits():

@@ -49,6 +49,10 @@ def cases():
     out["iszero"] = (lambda: Program(IsZero()), "bn128", [[0], [1], [q - 1], [rng.randrange(q)]])
     out["sha256_512"] = (lambda: Program(Sha256(512)), "bn128",
                          [[0] * 512, [1] * 512, [rng.randrange(2) for _ in range(512)]])
+    # the BASELINE metric's workload: >= 1M constraints at --O0 (5 compression blocks)
+    r3 = random.Random(2048)
+    out["sha256_2048"] = (lambda: Program(Sha256(2048)), "bn128",
+                          [[0] * 2048, [r3.randrange(2) for _ in range(2048)], [r3.randrange(2) for _ in range(2048)]])
     from circom_amd.circuits.opzoo import OperatorZoo
     half = q >> 1
     out["opzoo"] = (lambda: Program(OperatorZoo()), "bn128",
@@ -61,9 +65,17 @@ def cases():
 
 
 def main():
+    """`make_golden.py` regenerates everything; `make_golden.py NAME...` only (re)generates the named cases and keeps
+    the other entries of the JSON as they are."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_wtns.json")
+    only = set(sys.argv[1:])
     result = {"generator": "tests/golden/make_golden.py", "runtime": "reference common/{main,calcwit}.cpp + generic/fr.cpp (GMP, no asm)",
               "cases": {}}
+    if only:
+        result = json.load(open(path))
     for name, (mk, prime, rows) in cases().items():
+        if only and name not in only:
+            continue
         d = tempfile.mkdtemp(prefix="golden_")
         cp = compile_program(mk(), d, name.replace("_bls12381", ""), sym=False, strands=(1,))
         ref_build.build_circuit(cp)
@@ -82,7 +94,7 @@ def main():
             entries.append(e)
         result["cases"][name] = {"prime": prime, "vectors": entries}
         print(name, len(rows), "vectors", entries[0]["wtns_len"], "bytes each")
-    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_wtns.json"), "w") as f:
+    with open(path, "w") as f:
         json.dump(result, f, indent=1)
 
 

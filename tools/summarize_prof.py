@@ -60,6 +60,25 @@ if len(sys.argv) > 3:
         short = "cw_eval_kernel" if "cw_eval_kernel" in k else ("cw_r1cs_kernel" if "cw_r1cs" in k else None)
         if short:
             res[short] = (2 * fetch[k] + write.get(k, 0.0)) * 1024.0
+    # VALU-busy per kernel from the SQ pass: SQ_ACTIVE_INST_VALU (quad-cycles summed over SIMDs... per dispatch) x 4
+    # / (1024 SIMDs x GRBM_GUI_ACTIVE cycles)   (north-star: "VALU-busy reported against gfx950 peak")
+    sq = defaultdict(lambda: defaultdict(list))
+    for r in rows("pmc_sq/**/*counter_collection.csv"):
+        try:
+            sq[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        except (KeyError, ValueError):
+            pass
+    for k, cs in sq.items():
+        short = "cw_eval_kernel" if "cw_eval_kernel" in k else ("cw_r1cs_kernel" if "cw_r1cs" in k else None)
+        if short and cs.get("SQ_ACTIVE_INST_VALU") and cs.get("GRBM_GUI_ACTIVE"):
+            act = sum(cs["SQ_ACTIVE_INST_VALU"]) / len(cs["SQ_ACTIVE_INST_VALU"])
+            gui = sum(cs["GRBM_GUI_ACTIVE"]) / len(cs["GRBM_GUI_ACTIVE"])
+            res[short + "_valu_busy"] = act * 4.0 / (1024.0 * gui)
+            if cs.get("SQ_WAIT_ANY") and cs.get("SQ_WAVE_CYCLES"):
+                res[short + "_wait_frac"] = sum(cs["SQ_WAIT_ANY"]) / max(sum(cs["SQ_WAVE_CYCLES"]), 1.0)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    res["source"] = bench.source_fingerprint()          # bench.py only quotes these figures for the source they were measured on
     try:
         cur = json.load(open(out))
     except Exception:
