@@ -73,15 +73,18 @@ def get_compiled(name: str, batch: int, cache_root: str, rank: int, dist):
     from circom_amd.hip_elements.lower import lower
     fp = source_fingerprint()
     strands = compiler.strands_for(batch)
-    d = os.path.join(cache_root, "%s_s%s_%s" % (name, "-".join(map(str, strands)), fp))
+    d = os.path.join(cache_root, "%s_s%s_b%s_%s" % (name, "-".join(map(str, strands)), os.environ.get("CW_BITS", "1"), fp))
     p = lambda ext: os.path.join(d, name + ext)
     t0 = time.perf_counter()
     fc = flatten(make_program(name))
     done = os.path.join(d, "done")
     if rank == 0 and not os.path.exists(done):
         os.makedirs(d, exist_ok=True)
+        bittape = None if os.environ.get("CW_BITS", "1") == "0" else compiler.lower_bitplane(fc)
+        if bittape is not None:
+            strands = (1,)                  # the 256-bit schedule only serves instances re-run with non-boolean inputs
         tapes = [lower(fc, n_strands=s) for s in strands]
-        writers.write_tape(p(".cwt"), tapes)
+        writers.write_tape(p(".cwt"), tapes, bittape)
         writers.write_dat(p(".dat"), fc)
         writers.write_r1cs(p(".r1cs"), fc)
         open(done, "w").write(fp)

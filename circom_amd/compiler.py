@@ -21,6 +21,7 @@ class Compiled:
     sym_path: str
     flat: FlatCircuit
     tape: Tape
+    bittape: object = None          # hip_elements.bitsched.BitTape when the circuit got a bit-plane program
 
 
 DEFAULT_STRANDS = (1, 4, 16)
@@ -37,16 +38,36 @@ def strands_for(batch: int):
     return (1,)
 
 
-def compile_program(prog: Program, outdir: str, name: str, sym: bool = True, strands=DEFAULT_STRANDS) -> Compiled:
+BITS_AUTO_MIN_SIGNALS = 4096
+
+
+def lower_bitplane(fc: FlatCircuit, bits="auto"):
+    """The bit-plane program of a circuit whose signals are all boolean for 0/1 inputs (SHA-256 and friends), or None.
+    bits: True = whenever the analysis succeeds, False = never, "auto" = only for circuits large enough to matter (an
+    instance whose inputs are not 0/1 is re-run by the 256-bit schedule, so tiny arithmetic circuits gain nothing)."""
+    if bits is False or (bits == "auto" and fc.n_signals < BITS_AUTO_MIN_SIGNALS) or fc.n_main_inputs == 0:
+        return None
+    from .hip_elements.bitblast import bitblast
+    from .hip_elements.bitsched import lower_bits
+    net = bitblast(fc)
+    if net is None:
+        return None
+    return lower_bits(net, fc)
+
+
+def compile_program(prog: Program, outdir: str, name: str, sym: bool = True, strands=DEFAULT_STRANDS, bits="auto") -> Compiled:
     """strands: strand counts to lower the schedule for (one variant each; the runtime picks per batch)."""
     os.makedirs(outdir, exist_ok=True)
     fc = flatten(prog)
+    bittape = lower_bitplane(fc, bits)
+    if bittape is not None and os.environ.get("CW_BITS", "1") != "0":
+        strands = (1,)                      # the 256-bit schedule only serves the instances re-run with non-boolean inputs
     tapes = [lower(fc, n_strands=s) for s in strands]
     tape = tapes[0]
     p = lambda ext: os.path.join(outdir, name + ext)
-    writers.write_tape(p(".cwt"), tapes)
+    writers.write_tape(p(".cwt"), tapes, bittape)
     writers.write_dat(p(".dat"), fc)
     writers.write_r1cs(p(".r1cs"), fc)
     if sym:
         writers.write_sym(p(".sym"), fc)
-    return Compiled(name, outdir, p(".cwt"), p(".dat"), p(".r1cs"), p(".sym"), fc, tape)
+    return Compiled(name, outdir, p(".cwt"), p(".dat"), p(".r1cs"), p(".sym"), fc, tape, bittape)

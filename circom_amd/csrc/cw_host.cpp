@@ -17,6 +17,7 @@
 #include "../../include/circom_amd.h"
 #include "cw_kernels.h"
 #include "cw_r1cs_plan.h"
+#include "cw_bits_host.h"
 
 typedef unsigned __int128 u128;
 
@@ -214,6 +215,10 @@ struct cw_circuit {
     // r1cs (CSR)
     uint32_t n_constraints = 0;
     std::vector<uint32_t> r_ptr, r_slot, r_coef, r_ctab, r_orig;
+    // bit-plane program (cw_bits.hip) when every signal of the circuit is provably boolean for 0/1 inputs
+    bool has_bits = false;
+    cwbits::Program bits;
+    std::vector<uint32_t> r_cc, r_cctab;   // per term: id of its canonical coefficient in r_cctab (8 words each)
 };
 
 static uint64_t fnv1a(const char *s, size_t n) {   // calcwit.cpp:17-24
@@ -305,7 +310,7 @@ static int load_tape(cw_circuit *c, const char *path) {
     if (!read_file(path, b)) return fail(CW_EIO, std::string("tape file not found: ") + path);
     if (b.size() < 16 + 32 + 48 || memcmp(b.data(), "CWTP", 4)) return fail(CW_EIO, "bad tape magic");
     const uint32_t *h = (const uint32_t *)(b.data() + 4);
-    if (h[0] != 5) return fail(CW_EIO, "unsupported tape version");
+    if (h[0] != 6) return fail(CW_EIO, "unsupported tape version");
     if (h[1] != 4) return fail(CW_EIO, "only 4x64-bit primes are supported (bn128, bls12381, ...)");
     uint32_t n_variants = h[2];
     size_t off = 16;
@@ -324,6 +329,8 @@ static int load_tape(cw_circuit *c, const char *path) {
     if (m[7] != CW_RBITS) return fail(CW_EIO, "tape was lowered for a different Montgomery radix");
     uint32_t n_lconsts = m[8];
     c->n_pub_in = m[9];
+    const uint32_t n_bit_programs = m[10];
+    if (n_bit_programs > 1) return fail(CW_EIO, "tape header: more than one bit-plane program");
     // shape of the main component: slot 0 is the constant 1, outputs from slot 1, inputs right after them
     if (c->input_start == 0 || (uint64_t)c->input_start + c->n_inputs > c->n_signals || c->n_pub_in > c->n_inputs ||
         c->n_witness == 0 || c->n_witness > c->n_signals || hsize < 256 || (hsize & (hsize - 1)) ||
@@ -459,6 +466,25 @@ static int load_tape(cw_circuit *c, const char *path) {
         }
         c->variants.push_back(std::move(var));
     }
+    if (n_bit_programs) {
+        // bit-plane program: 8 x u32 {ring, n_vrows, n_slots lo, hi, 0...} then n_vrows * 64 records of 8 x u32
+        if (off + 32 > b.size()) return fail(CW_EIO, "tape bit program truncated");
+        uint32_t bh[8];
+        memcpy(bh, b.data() + off, 32);
+        off += 32;
+        cwbits::Program &bp = c->bits;
+        bp.ring = bh[0];
+        bp.n_vrows = bh[1];
+        bp.n_slots = (uint64_t)bh[2] | ((uint64_t)bh[3] << 32);
+        const uint64_t words = (uint64_t)bp.n_vrows * 64 * 8;
+        if (bp.n_vrows > (1u << 24) || words * 4 > b.size() - off) return fail(CW_EIO, "tape bit program truncated");
+        bp.recs.assign((size_t)words + 3 * 64 * 8, 0);           // + 3 empty vrows: the kernel streams records 3 ahead
+        memcpy(bp.recs.data(), b.data() + off, (size_t)words * 4);
+        off += (size_t)words * 4;
+        if (const char *why = cwbits::validate(bp, c->n_signals)) return fail(CW_EIO, std::string("tape: ") + why);
+        if (bp.n_slots >= (1ull << 25)) return fail(CW_EIO, "tape: bit program too large");
+        c->has_bits = true;
+    }
     // hash map as generate_hash_map builds it (c_code_generator.rs:575-587); replaced by the .dat's if given
     c->hashmap.assign(hsize, HashEntry{0, 0, 0});
     // insertion order must be the reference's (main input list order = slot order)
@@ -550,7 +576,7 @@ static int load_r1cs(cw_circuit *c, const char *path) {
     c->r_ctab.assign(16, 0);
     U256 one{{1, 0, 0, 0}}, minus1;
     u256_sub(minus1, c->q, one);
-    std::map<std::array<uint64_t, 4>, uint32_t> cid;
+    std::map<std::array<uint64_t, 4>, uint32_t> cid, ccid;
     const uint8_t *p = sec[2], *end = sec[2] + seclen[2];
     for (uint32_t k = 0; k < n_cons; k++) {
         for (int part = 0; part < 3; part++) {
@@ -585,6 +611,20 @@ static int load_r1cs(cw_circuit *c, const char *path) {
                 }
                 c->r_slot.push_back(c->w2s[wire]);     // wire id = witness position -> value slot
                 c->r_coef.push_back(id);
+                if (c->has_bits) {                     // the bit-plane check works on canonical coefficients
+                    std::array<uint64_t, 4> ck{co.w[0], co.w[1], co.w[2], co.w[3]};
+                    auto it = ccid.find(ck);
+                    uint32_t cci;
+                    if (it == ccid.end()) {
+                        if (u256_cmp(co, c->q) >= 0) return fail(CW_EIO, "r1cs coefficient is not reduced modulo the prime");
+                        cci = (uint32_t)(c->r_cctab.size() / 8);
+                        uint32_t limbs[8];
+                        memcpy(limbs, co.w, 32);
+                        c->r_cctab.insert(c->r_cctab.end(), limbs, limbs + 8);
+                        ccid[ck] = cci;
+                    } else cci = it->second;
+                    c->r_cc.push_back(cci);
+                }
             }
             c->r_ptr.push_back((uint32_t)c->r_slot.size());
         }
@@ -615,9 +655,10 @@ static int load_r1cs(cw_circuit *c, const char *path) {
         key[k] = ((uint64_t)mx << 32) | k;
     }
     std::sort(key.begin(), key.end());
-    std::vector<uint32_t> n_ptr(1, 0), n_slot, n_coef;
+    std::vector<uint32_t> n_ptr(1, 0), n_slot, n_coef, n_cc;
     n_slot.reserve(c->r_slot.size());
     n_coef.reserve(c->r_coef.size());
+    n_cc.reserve(c->r_cc.size());
     c->r_orig.resize(n_cons);
     for (uint32_t j = 0; j < n_cons; j++) {
         uint32_t k = (uint32_t)key[j];
@@ -625,6 +666,7 @@ static int load_r1cs(cw_circuit *c, const char *path) {
             for (uint32_t t = c->r_ptr[3 * k + part]; t < c->r_ptr[3 * k + part + 1]; t++) {
                 n_slot.push_back(c->r_slot[t]);
                 n_coef.push_back(c->r_coef[t]);
+                if (c->has_bits) n_cc.push_back(c->r_cc[t]);
             }
             n_ptr.push_back((uint32_t)n_slot.size());
         }
@@ -636,6 +678,7 @@ static int load_r1cs(cw_circuit *c, const char *path) {
     c->r_ptr.swap(n_ptr);
     c->r_slot.swap(n_slot);
     c->r_coef.swap(n_coef);
+    c->r_cc.swap(n_cc);
     return CW_OK;
 }
 
@@ -753,6 +796,19 @@ struct cw_batch {
     std::vector<uint8_t> assigned; // [batch][n_in] flags (inputSignalAssigned, calcwit.cpp:28-32)
     std::vector<uint32_t> remaining;
     bool all_set = false, host_dirty = false, ran = false;
+    // ---- bit-plane mode (cw_bits.hip): one bit per signal per instance instead of a 32-byte slot ----
+    bool bitmode = false;
+    uint64_t *d_T = nullptr, *d_fbmask = nullptr;   // bit table [groups][slots]; per-group mask of instances to re-run wide
+    uint64_t t_bytes = 0;
+    uint32_t n_groups = 0;
+    uint32_t *d_brecs = nullptr;                      // the gate program
+    uint32_t *d_erecs = nullptr, *d_wchunk = nullptr, *d_wterms = nullptr, *d_wctab = nullptr, *d_wrow = nullptr;
+    uint32_t n_evrows = 0, n_wchunks = 0;
+    // instances whose inputs are not all 0/1 (or that tripped an assertion gate) are re-run by the 256-bit schedule
+    cw_batch *fb = nullptr;                           // side batch (classic variant) holding them
+    std::vector<uint32_t> fb_inst;                    // side-batch position -> instance
+    std::vector<int32_t> fb_index;                    // instance -> side-batch position or -1
+    bool resolved = false, checked = false;
 };
 
 template <typename T>
@@ -772,6 +828,10 @@ extern "C" void cw_batch_free(cw_batch *b) {
     }
     hipSetDevice(b->device);
     hipStreamSynchronize(b->stream);
+    if (b->fb) cw_batch_free(b->fb);
+    void *bptrs[] = {b->d_T, b->d_fbmask, b->d_brecs, b->d_erecs, b->d_wchunk, b->d_wterms, b->d_wctab, b->d_wrow};
+    for (void *p : bptrs)
+        if (p) hipFree(p);
     void *ptrs[] = {b->d_V, b->d_rows, b->d_stream_off, b->d_extras, b->d_extra_off, b->d_terms, b->d_term_off, b->d_lconsts, b->d_consts, b->d_w2s, b->d_status, b->d_first_bad,
                     b->d_rctab, b->d_rctab29, b->d_pchunk, b->d_prec, b->d_pterms, b->d_prow,
                     b->d_in, b->d_gather, b->d_bulk};
@@ -780,7 +840,9 @@ extern "C" void cw_batch_free(cw_batch *b) {
     delete b;
 }
 
-extern "C" int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *stream, cw_batch **out) {
+static int bits_batch_setup(cw_batch *b);
+
+static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *stream, bool allow_bits, cw_batch **out) {
     if (!c || !out || batch == 0) return fail(CW_EINVAL, "cw_batch_create: bad argument");
     if (batch > (1u << 26)) return fail(CW_EINVAL, "cw_batch_create: batch exceeds 2^26 instances (32-bit lane offsets)");
     if (device < 0) {
@@ -805,6 +867,19 @@ extern "C" int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *
     b->batch = batch;
     b->Bp = (batch + 255) / 256 * 256;
     b->stream = (hipStream_t)stream;
+    if (allow_bits && c->has_bits) {
+        // every signal is a bit: the bit-plane program replaces the 256-bit schedule (which stays in the file for the
+        // instances whose inputs turn out not to be 0/1)
+        b->bitmode = true;
+        int rc = bits_batch_setup(b);
+        if (rc != CW_OK) {
+            cw_batch_free(b);
+            return rc;
+        }
+        b->remaining.assign(batch, c->n_inputs);
+        *out = b;
+        return CW_OK;
+    }
     // pick the schedule variant.  Up to 8192 waves (two rounds of the chip's 4096 wave slots) a variant with more
     // strands that carry work shortens the critical path of every instance group; a variant whose extra strands
     // only wait at barriers (Poseidon(2) has 3 independent lanes: S = 16 is S = 4 plus 12 idle waves) just takes
@@ -993,6 +1068,11 @@ extern "C" int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *
     *out = b;
     return CW_OK;
 }
+extern "C" int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *stream, cw_batch **out) {
+    const char *e = getenv("CW_BITS");                // CW_BITS=0 forces the 256-bit schedule (diagnostics, A/B timing)
+    return batch_create_impl(c, device, batch, stream, !(e && e[0] == '0'), out);
+}
+extern "C" int cw_batch_bitmode(const cw_batch *b) { return b && b->bitmode; }
 extern "C" uint32_t cw_batch_size(const cw_batch *b) { return b->batch; }
 extern "C" uint32_t cw_batch_strands(const cw_batch *b) { return b->var ? b->var->n_strands : 0; }
 extern "C" uint32_t cw_batch_lanes(const cw_batch *b) { return b->lanes; }
@@ -1268,6 +1348,105 @@ extern "C" int cw_set_inputs_json(cw_batch *b, uint32_t instance, const char *js
 // ---------------------------------------------------------------------------------------------------------
 // run / check / egress
 // ---------------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------------
+// bit-plane mode
+// ---------------------------------------------------------------------------------------------------------
+#define BTRY(x)                                                                \
+    do {                                                                       \
+        hipError_t e2 = (x);                                                   \
+        if (e2 != hipSuccess) return fail(CW_EDEVICE, std::string(#x ": ") + hipGetErrorString(e2)); \
+    } while (0)
+
+static int bits_batch_setup(cw_batch *b) {
+    cw_circuit *c = b->c;
+    const cwbits::Program &bp = c->bits;
+    b->n_groups = (b->batch + 63) / 64;
+    b->t_bytes = (uint64_t)b->n_groups * bp.n_slots * 8;
+    hipError_t e = hipMalloc((void **)&b->d_T, b->t_bytes);
+    if (e != hipSuccess)
+        return fail(CW_EDEVICE, "hipMalloc of the bit table failed (" + std::to_string(b->t_bytes) + " bytes): " + hipGetErrorString(e));
+    BTRY(hipMalloc((void **)&b->d_fbmask, (size_t)b->n_groups * 8));
+    BTRY(upload(&b->d_brecs, bp.recs, b->stream));
+    BTRY(upload(&b->d_w2s, c->w2s, b->stream));
+    BTRY(hipMalloc((void **)&b->d_status, (size_t)b->Bp * 4));
+    BTRY(hipMalloc((void **)&b->d_first_bad, (size_t)b->Bp * 4));
+    if (c->n_constraints) {
+        uint32_t tpc = 256;
+        if (const char *ev = getenv("CW_R1CS_TERMS")) tpc = (uint32_t)std::max(8, atoi(ev));
+        cwbits::R1Plan p = cwbits::build_r1cs(c->r_ptr, c->r_slot, c->r_cc, c->r_cctab, c->r_orig, c->q.w, tpc);
+        BTRY(upload(&b->d_erecs, p.erecs, b->stream));
+        BTRY(upload(&b->d_wchunk, p.chunk, b->stream));
+        BTRY(upload(&b->d_wterms, p.terms, b->stream));
+        BTRY(upload(&b->d_wctab, p.ctab, b->stream));
+        BTRY(upload(&b->d_wrow, p.row_orig, b->stream));
+        BTRY(hipStreamSynchronize(b->stream));                       // the plan goes out of scope
+        b->n_evrows = p.n_evrows;
+        b->n_wchunks = p.n_chunks;
+    }
+    BTRY(hipMalloc(&b->d_in, std::max<size_t>((size_t)b->batch * c->n_inputs * 32, 32)));
+    BTRY(hipMalloc(&b->d_gather, std::max<size_t>((size_t)c->n_witness * 32, 32)));
+    BTRY(cwk_bits_init(b->stream, b->d_T, bp.n_slots, b->n_groups, b->d_fbmask, b->d_status, b->d_first_bad, b->Bp));
+    BTRY(hipStreamSynchronize(b->stream));
+    b->fb_index.assign(b->batch, -1);
+    return CW_OK;
+}
+
+static int bits_run(cw_batch *b, const void *in) {
+    cw_circuit *c = b->c;
+    const cwbits::Program &bp = c->bits;
+    BTRY(cwk_bits_init(b->stream, b->d_T, bp.n_slots, b->n_groups, b->d_fbmask, b->d_status, b->d_first_bad, b->Bp));
+    BTRY(cwk_bits_ingest(b->stream, in, b->d_T, bp.n_slots, cwbits::SIG_BASE + c->input_start, c->n_inputs, b->batch, b->d_fbmask));
+    BTRY(cwk_bits_eval(b->stream, b->d_brecs, bp.n_vrows, bp.ring, b->d_T, bp.n_slots, b->n_groups, b->d_fbmask));
+    b->resolved = false;
+    b->checked = false;
+    return CW_OK;
+}
+
+// After the stream has drained: find the instances the bit-plane path could not serve (inputs other than 0/1, or an
+// assertion gate fired) and compute them with the 256-bit schedule in a side batch.  Their status words, witnesses
+// and public signals are then served from there, so every answer is the reference's for every input.
+static int bits_resolve(cw_batch *b) {
+    if (!b->bitmode || b->resolved || !b->ran) return CW_OK;
+    cw_circuit *c = b->c;
+    BTRY(hipStreamSynchronize(b->stream));
+    std::vector<uint64_t> m(b->n_groups);
+    BTRY(hipMemcpy(m.data(), b->d_fbmask, (size_t)b->n_groups * 8, hipMemcpyDeviceToHost));
+    b->fb_inst.clear();
+    std::fill(b->fb_index.begin(), b->fb_index.end(), -1);
+    for (uint32_t g = 0; g < b->n_groups; g++)
+        for (uint64_t x = m[g]; x; x &= x - 1) {
+            const uint32_t i = g * 64 + (uint32_t)__builtin_ctzll(x);
+            if (i < b->batch) {
+                b->fb_index[i] = (int32_t)b->fb_inst.size();
+                b->fb_inst.push_back(i);
+            }
+        }
+    if (b->fb && (b->fb_inst.empty() || b->fb->batch != b->fb_inst.size())) {
+        cw_batch_free(b->fb);
+        b->fb = nullptr;
+    }
+    if (!b->fb_inst.empty()) {
+        if (!b->fb) {
+            int rc = batch_create_impl(c, b->device, (uint32_t)b->fb_inst.size(), b->stream, false, &b->fb);
+            if (rc != CW_OK) return rc;
+        }
+        const size_t row = (size_t)c->n_inputs * 32;
+        const char *src = (const char *)(b->ext_in ? b->ext_in : b->d_in);
+        for (size_t k = 0; k < b->fb_inst.size(); k++)
+            BTRY(hipMemcpyAsync((char *)b->fb->d_in + k * row, src + (size_t)b->fb_inst[k] * row, row, hipMemcpyDeviceToDevice, b->stream));
+        b->fb->ext_in = nullptr;
+        b->fb->host_dirty = false;
+        b->fb->all_set = true;
+        std::fill(b->fb->remaining.begin(), b->fb->remaining.end(), 0);
+        int rc = cw_run(b->fb);
+        if (rc == CW_OK && b->checked && c->n_constraints) rc = cw_check_r1cs(b->fb);
+        if (rc != CW_OK) return rc;
+        BTRY(hipStreamSynchronize(b->stream));
+    }
+    b->resolved = true;
+    return CW_OK;
+}
+
 extern "C" int cw_run(cw_batch *b) {
     if (!b) return fail(CW_EINVAL, "null batch");
     NEED_DEVICE(b);
@@ -1286,6 +1465,11 @@ extern "C" int cw_run(cw_batch *b) {
         b->host_dirty = false;
     }
     const void *in = b->ext_in ? b->ext_in : b->d_in;
+    if (b->bitmode) {
+        int rc = bits_run(b, in);
+        if (rc == CW_OK) b->ran = true;
+        return rc;
+    }
     HIPCHK(cwk_init(b->stream, b->d_V, b->Bp, b->d_status, b->d_first_bad));
     HIPCHK(cwk_ingest(b->stream, in, b->d_V, c->input_start, c->n_inputs, b->batch, b->Bp));
     HIPCHK(cwk_eval(b->stream, c->need_full, b->var->wide_linsum, b->d_rows, b->d_stream_off, b->d_extras, b->d_extra_off, b->d_terms,
@@ -1302,6 +1486,13 @@ extern "C" int cw_check_r1cs(cw_batch *b) {
     if (!b->ran) return fail(CW_ESTATE, "cw_check_r1cs before cw_run");
     if (c->n_constraints == 0) return fail(CW_ESTATE, "no .r1cs was loaded for this circuit");
     HIPCHK(hipSetDevice(b->device));
+    if (b->bitmode) {
+        HIPCHK(cwk_bits_r1cs(b->stream, b->d_erecs, b->n_evrows, b->d_wchunk, b->n_wchunks, b->d_wterms, b->d_wctab, b->d_wrow,
+                             b->d_T, c->bits.n_slots, b->n_groups, b->batch, b->d_status, b->d_first_bad, c->P));
+        b->checked = true;
+        if (b->resolved && b->fb) return cw_check_r1cs(b->fb);       // the side batch was already computed: check it too
+        return CW_OK;
+    }
     if (b->r1_entries)
         HIPCHK(cwk_r1cs_staged(b->stream, b->d_pchunk, b->r1_chunks, b->d_prec, b->d_pterms, b->d_rctab, b->d_rctab29, b->d_prow,
                                b->r1_entries, b->d_V, b->Bp, b->batch, b->d_status, b->d_first_bad, c->P));
@@ -1316,6 +1507,16 @@ extern "C" int cw_sync(cw_batch *b) {
     NEED_DEVICE(b);
     HIPCHK(hipSetDevice(b->device));
     HIPCHK(hipStreamSynchronize(b->stream));
+    return bits_resolve(b);
+}
+
+// status words / first bad rows of the instances that were re-run by the 256-bit schedule come from the side batch
+static int bits_patch_words(cw_batch *b, uint32_t *dst, bool first_bad) {
+    if (!b->bitmode || b->fb_inst.empty()) return CW_OK;
+    std::vector<uint32_t> w(b->fb_inst.size());
+    int rc = first_bad ? cw_get_r1cs_first_bad(b->fb, w.data()) : cw_get_status(b->fb, w.data());
+    if (rc != CW_OK) return rc;
+    for (size_t k = 0; k < w.size(); k++) dst[b->fb_inst[k]] = w[k];
     return CW_OK;
 }
 
@@ -1323,17 +1524,19 @@ extern "C" int cw_get_status(cw_batch *b, uint32_t *status) {
     if (!b || !status) return fail(CW_EINVAL, "null argument");
     NEED_DEVICE(b);
     HIPCHK(hipSetDevice(b->device));
+    if (int rc = bits_resolve(b)) return rc;
     HIPCHK(hipMemcpyAsync(status, b->d_status, (size_t)b->batch * 4, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
-    return CW_OK;
+    return bits_patch_words(b, status, false);
 }
 extern "C" int cw_get_r1cs_first_bad(cw_batch *b, uint32_t *row) {
     if (!b || !row) return fail(CW_EINVAL, "null argument");
     NEED_DEVICE(b);
     HIPCHK(hipSetDevice(b->device));
+    if (int rc = bits_resolve(b)) return rc;
     HIPCHK(hipMemcpyAsync(row, b->d_first_bad, (size_t)b->batch * 4, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
-    return CW_OK;
+    return bits_patch_words(b, row, true);
 }
 
 extern "C" int cw_get_witness(cw_batch *b, uint32_t instance, uint8_t *out) {
@@ -1343,6 +1546,11 @@ extern "C" int cw_get_witness(cw_batch *b, uint32_t instance, uint8_t *out) {
     if (!b->ran) return fail(CW_ESTATE, "cw_get_witness before cw_run");
     cw_circuit *c = b->c;
     HIPCHK(hipSetDevice(b->device));
+    if (b->bitmode) {
+        if (int rc = bits_resolve(b)) return rc;
+        if (b->fb_index[instance] >= 0) return cw_get_witness(b->fb, (uint32_t)b->fb_index[instance], out);
+        HIPCHK(cwk_bits_gather(b->stream, b->d_T, c->bits.n_slots, b->d_w2s, c->n_witness, instance, 1, b->d_gather));
+    } else
     HIPCHK(cwk_gather(b->stream, b->d_V, b->d_w2s, c->n_witness, b->Bp, instance, b->d_gather));
     HIPCHK(hipMemcpyAsync(out, b->d_gather, (size_t)c->n_witness * 32, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -1358,6 +1566,7 @@ extern "C" int cw_get_witnesses(cw_batch *b, uint32_t first, uint32_t count, uin
     if (!b->ran) return fail(CW_ESTATE, "cw_get_witnesses before cw_run");
     cw_circuit *c = b->c;
     HIPCHK(hipSetDevice(b->device));
+    if (int rc = bits_resolve(b)) return rc;
     const size_t row = (size_t)c->n_witness * 32;
     uint32_t per = (uint32_t)std::max<size_t>(1, std::min<size_t>(count, ((size_t)256 << 20) / std::max<size_t>(row, 1)));
     per = std::max<uint32_t>(64, per / 64 * 64);
@@ -1370,10 +1579,17 @@ extern "C" int cw_get_witnesses(cw_batch *b, uint32_t first, uint32_t count, uin
     }
     for (uint32_t done = 0; done < count; done += per) {
         const uint32_t n = std::min(per, count - done);
-        HIPCHK(cwk_gather_many(b->stream, b->d_V, b->d_w2s, c->n_witness, b->Bp, first + done, n, b->d_bulk));
+        if (b->bitmode)
+            HIPCHK(cwk_bits_gather(b->stream, b->d_T, c->bits.n_slots, b->d_w2s, c->n_witness, first + done, n, b->d_bulk));
+        else
+            HIPCHK(cwk_gather_many(b->stream, b->d_V, b->d_w2s, c->n_witness, b->Bp, first + done, n, b->d_bulk));
         HIPCHK(hipMemcpyAsync(out + (size_t)done * row, b->d_bulk, (size_t)n * row, hipMemcpyDeviceToHost, b->stream));
         HIPCHK(hipStreamSynchronize(b->stream));
     }
+    if (b->bitmode)
+        for (size_t k = 0; k < b->fb_inst.size(); k++)
+            if (b->fb_inst[k] >= first && b->fb_inst[k] < first + count)
+                if (int rc = cw_get_witness(b->fb, (uint32_t)k, out + (size_t)(b->fb_inst[k] - first) * row)) return rc;
     return CW_OK;
 }
 
@@ -1388,6 +1604,24 @@ extern "C" int cw_get_public_device(cw_batch *b, void *d_out) {
     if (np == 0) return CW_OK;
     if (np >= c->n_witness) return fail(CW_ESTATE, "public signal count exceeds the witness");
     HIPCHK(hipSetDevice(b->device));
+    if (b->bitmode) {
+        if (int rc = bits_resolve(b)) return rc;
+        HIPCHK(cwk_bits_gather(b->stream, b->d_T, c->bits.n_slots, b->d_w2s + 1, np, 0, b->batch, d_out));
+        if (!b->fb_inst.empty()) {
+            void *tmp = nullptr;
+            const size_t prow = (size_t)np * 32;
+            HIPCHK(hipMalloc(&tmp, b->fb_inst.size() * prow));
+            int rc = cw_get_public_device(b->fb, tmp);
+            for (size_t k = 0; rc == CW_OK && k < b->fb_inst.size(); k++)
+                if (hipMemcpyAsync((char *)d_out + (size_t)b->fb_inst[k] * prow, (char *)tmp + k * prow, prow, hipMemcpyDeviceToDevice,
+                                   b->stream) != hipSuccess)
+                    rc = fail(CW_EDEVICE, "copy of re-run public signals failed");
+            hipStreamSynchronize(b->stream);
+            hipFree(tmp);
+            return rc;
+        }
+        return CW_OK;
+    }
     HIPCHK(cwk_gather_many(b->stream, b->d_V, b->d_w2s + 1, np, b->Bp, 0, b->batch, d_out));
     return CW_OK;
 }
@@ -1414,6 +1648,15 @@ extern "C" int cw_get_signal(cw_batch *b, uint32_t instance, uint32_t slot, uint
     if (instance >= b->batch || slot >= b->c->n_signals) return fail(CW_EINVAL, "instance or slot out of range");
     NEED_DEVICE(b);
     HIPCHK(hipSetDevice(b->device));
+    if (b->bitmode) {
+        if (int rc = bits_resolve(b)) return rc;
+        if (b->fb_index[instance] >= 0) return cw_get_signal(b->fb, (uint32_t)b->fb_index[instance], slot, out);
+        uint64_t m = 0;
+        HIPCHK(hipMemcpy(&m, b->d_T + (size_t)(instance >> 6) * b->c->bits.n_slots + cwbits::SIG_BASE + slot, 8, hipMemcpyDeviceToHost));
+        memset(out, 0, 32);
+        out[0] = (uint8_t)((m >> (instance & 63)) & 1);
+        return CW_OK;
+    }
     const uint8_t *V = (const uint8_t *)b->d_V;
     size_t base = ((size_t)slot * 2 * b->Bp + instance) * 16;
     HIPCHK(hipMemcpyAsync(out, V + base, 16, hipMemcpyDeviceToHost, b->stream));
@@ -1450,9 +1693,21 @@ extern "C" int cw_write_wtns(cw_batch *b, uint32_t instance, const char *path) {
 
 extern "C" void *cw_device_values(cw_batch *b, uint64_t *n_bytes, uint32_t *padded_batch) {
     if (!b) return nullptr;
+    if (b->bitmode) {                       // no 256-bit table exists: see cw_device_bits
+        if (n_bytes) *n_bytes = 0;
+        if (padded_batch) *padded_batch = b->Bp;
+        return nullptr;
+    }
     if (n_bytes) *n_bytes = b->v_bytes;
     if (padded_batch) *padded_batch = b->Bp;
     return b->d_V;
+}
+
+extern "C" void *cw_device_bits(cw_batch *b, uint64_t *n_bytes, uint64_t *slots_per_group) {
+    if (!b || !b->bitmode) return nullptr;
+    if (n_bytes) *n_bytes = b->t_bytes;
+    if (slots_per_group) *slots_per_group = b->c->bits.n_slots;
+    return b->d_T;
 }
 
 // ---------------------------------------------------------------------------------------------------------

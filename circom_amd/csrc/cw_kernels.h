@@ -25,3 +25,16 @@ hipError_t cwk_mulbench(hipStream_t s, const void *a, const void *b, void *out, 
                         const FpParams &P);
 hipError_t cwk_fpop(hipStream_t s, uint32_t op, const void *a, const void *b, const void *c, void *out, uint32_t *status,
                     uint32_t n, const FpParams &P);
+
+// ---- bit-plane path (cw_bits.hip) ----
+hipError_t cwk_bits_init(hipStream_t s, void *T, uint64_t slots, uint32_t n_groups, void *fbmask, uint32_t *status,
+                         uint32_t *first_bad, uint32_t Bp);
+hipError_t cwk_bits_ingest(hipStream_t s, const void *in, void *T, uint64_t slots, uint32_t input_slot0, uint32_t n_in,
+                           uint32_t batch, void *fbmask);
+hipError_t cwk_bits_eval(hipStream_t s, const void *recs, uint32_t n_vrows, uint32_t ring, void *T, uint64_t slots,
+                         uint32_t n_groups, void *fbmask);
+hipError_t cwk_bits_gather(hipStream_t s, const void *T, uint64_t slots, const uint32_t *w2s, uint32_t n_wit, uint32_t first,
+                           uint32_t count, void *out);
+hipError_t cwk_bits_r1cs(hipStream_t s, const void *erecs, uint32_t n_evrows, const uint32_t *chunk, uint32_t n_chunks,
+                         const uint32_t *terms, const uint32_t *ctab, const uint32_t *row_orig, const void *T, uint64_t slots,
+                         uint32_t n_groups, uint32_t batch, uint32_t *status, uint32_t *first_bad, const FpParams &P);

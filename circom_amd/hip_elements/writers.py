@@ -77,16 +77,17 @@ def write_dat(path, fc: FlatCircuit, witness2signal=None):
 
 
 TAPE_MAGIC = b"CWTP"
-TAPE_VERSION = 5
+TAPE_VERSION = 6
 
 
-def write_tape(path, tapes):
+def write_tape(path, tapes, bittape=None):
     """`.cwt` layout (little endian).  `tapes` = one Tape or a list of Tapes of the SAME circuit lowered with
     different strand counts (the runtime picks the variant that fills the chip for the batch at hand).
          0  "CWTP" | u32 version | u32 n64 | u32 n_variants
         16  prime, n64*8 bytes
             12 x u32: n_signals, n_witness, n_consts, main_input_start, n_main_inputs, n_input_names,
-                      hashmap_size, rbits (Montgomery radix exponent of MMUL rows), n_lconsts, n_public_inputs, 0, 0
+                      hashmap_size, rbits (Montgomery radix exponent of MMUL rows), n_lconsts, n_public_inputs,
+                      n_bit_programs (0 | 1), 0
             consts          n_consts x n64*8 bytes (raw residues as the schedule expects them)
             lconsts         n_lconsts x n64*8 bytes (coef*R' of D_DOTC terms; the runtime keeps them as 29-bit limbs)
             witness2signal  n_witness x u32
@@ -94,6 +95,8 @@ def write_tape(path, tapes):
             per variant     u32 n_strands | u32 n_tslots | u32 n_rows | u32 n_extras | u32 n_lds | u32 n_terms | 2 x u32 0
                             stream_off | extra_off | term_off      ((n_strands+1) x u32 each)
                             rows n_rows x 4 x u32 | extras n_extras x u32 | terms n_terms x 4 x u32
+            bit program     (if n_bit_programs, hip_elements/bitsched.py)  8 x u32: ring, n_vrows, n_slots lo, hi, 0, 0, 0, 0
+                            then n_vrows x 64 records of 8 x u32
     """
     if isinstance(tapes, Tape):
         tapes = [tapes]
@@ -106,7 +109,8 @@ def write_tape(path, tapes):
         f.write(TAPE_MAGIC + struct.pack("<III", TAPE_VERSION, n64, len(tapes)))
         f.write(t0.q.to_bytes(8 * n64, "little"))
         f.write(struct.pack("<12I", t0.n_signals, t0.n_witness, len(t0.consts), t0.main_input_start, t0.n_main_inputs,
-                            len(t0.inputs), hashmap_size(len(t0.inputs)), t0.rbits, len(t0.lconsts), t0.n_pub_in, 0, 0))
+                            len(t0.inputs), hashmap_size(len(t0.inputs)), t0.rbits, len(t0.lconsts), t0.n_pub_in,
+                            1 if bittape is not None else 0, 0))
         f.write(b"".join(c.to_bytes(8 * n64, "little") for c in t0.consts))
         f.write(b"".join(c.to_bytes(8 * n64, "little") for c in t0.lconsts))
         f.write(np.asarray(t0.witness2signal, dtype="<u4").tobytes())
@@ -121,6 +125,10 @@ def write_tape(path, tapes):
             f.write(np.ascontiguousarray(t.rows, dtype="<u4").tobytes())
             f.write(np.asarray(t.extras, dtype="<u4").tobytes())
             f.write(np.ascontiguousarray(t.terms, dtype="<u4").tobytes())
+        if bittape is not None:
+            assert bittape.n_signals == t0.n_signals
+            f.write(struct.pack("<8I", bittape.ring, bittape.n_vrows, bittape.n_slots & 0xFFFFFFFF, bittape.n_slots >> 32, 0, 0, 0, 0))
+            f.write(np.ascontiguousarray(bittape.recs, dtype="<u4").tobytes())
 
 
 def _le_key(k: int) -> bytes:

@@ -30,8 +30,8 @@ CLI_PATH = _HERE / "bin" / "cw_witness"     # process-level drop-in (csrc/cw_cli
 
 def build_library(force: bool = False) -> Path:
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [_HERE / "csrc" / n for n in ("cw_kernels.hip", "cw_host.cpp", "cw_cli.cpp", "cw_kernels.h", "cw_tape.h",
-                                         "cw_r1cs_plan.h", "fp256.hip.h")]
+    srcs = [_HERE / "csrc" / n for n in ("cw_kernels.hip", "cw_bits.hip", "cw_host.cpp", "cw_cli.cpp", "cw_kernels.h",
+                                         "cw_tape.h", "cw_r1cs_plan.h", "cw_bits_host.h", "fp256.hip.h")]
     outs = [LIB_PATH, CLI_PATH]
     if not force and all(o.exists() and all(o.stat().st_mtime >= s.stat().st_mtime for s in srcs) for o in outs):
         return LIB_PATH
@@ -61,6 +61,8 @@ _SIGS = {
     "cw_batch_size": (C.c_uint32, [C.c_void_p]),
     "cw_batch_strands": (C.c_uint32, [C.c_void_p]),
     "cw_batch_lanes": (C.c_uint32, [C.c_void_p]),
+    "cw_batch_bitmode": (C.c_int, [C.c_void_p]),
+    "cw_device_bits": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "cw_set_input_signal": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p]),
     "cw_set_inputs_json": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p]),
     "cw_set_inputs": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -164,6 +166,7 @@ class Batch:
         self.h = h
         self.strands = lib().cw_batch_strands(h)
         self.lanes = lib().cw_batch_lanes(h)
+        self.bitmode = bool(lib().cw_batch_bitmode(h))
 
     def close(self):
         if self.h:

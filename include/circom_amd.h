@@ -72,6 +72,10 @@ uint32_t cw_batch_size(const cw_batch *b);
 uint32_t cw_batch_strands(const cw_batch *b);
 /* instances per workgroup (64, 32 or 16) the evaluation kernel uses for this batch */
 uint32_t cw_batch_lanes(const cw_batch *b);
+/* 1 if this batch runs the bit-plane program (circuits whose signals are all boolean for 0/1 inputs: one bit per
+ * signal per instance, replaces the short-int paths of the tagged FrElement, generic/fr.cpp:416-439,900-917);
+ * instances whose inputs are not 0/1 are transparently re-run by the 256-bit schedule.  CW_BITS=0 disables it. */
+int cw_batch_bitmode(const cw_batch *b);
 
 /* setInputSignal(h, i, val) (calcwit.cpp:77-97) for one instance; `name` is hashed with FNV-1a
  * (calcwit.cpp:17-24).  val = canonical 32-byte little-endian value, reduced mod q by the caller. */
@@ -119,6 +123,9 @@ int cw_r1cs_plan_stats(const cw_circuit *c, uint32_t batch, uint32_t chunks, uin
 
 /* raw device pointers for zero-copy consumers (provers): value table, layout in DESIGN.md */
 void *cw_device_values(cw_batch *b, uint64_t *n_bytes, uint32_t *padded_batch);
+/* bit-plane batches: the bit table T[group][slot] (uint64, bit i = instance group*64+i; signal s at slot 3+s);
+ * NULL for 256-bit batches (and cw_device_values is NULL for bit-plane batches) */
+void *cw_device_bits(cw_batch *b, uint64_t *n_bytes, uint64_t *slots_per_group);
 
 /* ---- field micro-benchmark + unit-test hooks (Fr_* seam 2: bn128/fr.hpp:28-81) --------------------- */
 /* n lanes x iters dependent Montgomery multiplications on the device; out[i] = a[i]*b[i]^iters (raw

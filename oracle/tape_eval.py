@@ -315,3 +315,92 @@ def eval_tape(tape, inputs: dict):
     """Convenience wrapper over a circom_amd.hip_elements.lower.Tape (duck-typed)."""
     return eval_rows(tape.q, tape.n_signals, tape.n_tslots, tape.consts, tape.rows, inputs, tape.rbits,
                      tape.stream_off, tape.extras, tape.extra_off, tape.n_lds, tape.terms, tape.term_off, tape.lconsts)
+
+
+# ---- bit-plane program (circom_amd/hip_elements/bitsched.py), executed the way cw_bits_kernel does -------------------
+BK_GLOBAL, BK_RING, BK_PREV = 0, 1, 2
+BF_ASSERT = 1 << 8
+B_SIG_BASE = 3
+
+
+def eval_bits(recs, n_vrows: int, ring: int, n_slots: int, input_masks: dict, width: int = 1):
+    """Replays a bit-plane program on `width` instances at once (python ints as masks: bit i = instance i).
+    input_masks: bit-table slot -> mask of the main inputs.  Mirrors the kernel's timing: the ring / global operands
+    of vrow v+1 are fetched BEFORE vrow v writes its results; PREV operands are lanes of vrow v's result.
+    Raises ScheduleHazard when a read cannot be satisfied by the executor's rules.
+    Returns (bit table as list of masks, violation mask of the assertion gates)."""
+    full = (1 << width) - 1
+    T = [None] * n_slots
+    T[0], T[1], T[2] = 0, full, 0
+    for s, m in input_masks.items():
+        T[s] = m & full
+    ring_val = [0] * (ring * 64)
+    ring_tag = [-1] * (ring * 64)
+    recs = [[int(x) for x in r] for r in recs]
+    viol = 0
+
+    def early(v):
+        out = []
+        for lane in range(64):
+            r = recs[v * 64 + lane]
+            vals = []
+            for j in range(3):
+                w = r[j]
+                kind, off = w >> 30, w & 0x3FFFFFFF
+                if kind == BK_GLOBAL:
+                    if off % 8 or off // 8 >= n_slots:
+                        raise ScheduleHazard("vrow %d lane %d: global operand out of range" % (v, lane))
+                    x = T[off // 8]
+                    if x is None:
+                        raise ScheduleHazard("vrow %d lane %d reads bit slot %d before it is written" % (v, lane, off // 8))
+                    vals.append(x)
+                elif kind == BK_RING:
+                    if off % 8 or off // 8 >= ring * 64:
+                        raise ScheduleHazard("vrow %d lane %d: ring operand out of range" % (v, lane))
+                    tag = ring_tag[off // 8]
+                    if tag < 0 or tag > v - 2 or v - tag >= ring:
+                        raise ScheduleHazard("vrow %d lane %d reads a ring entry that is not a live older result" % (v, lane))
+                    vals.append(ring_val[off // 8])
+                elif kind == BK_PREV:
+                    if off % 4 or off // 4 >= 64 or v == 0:
+                        raise ScheduleHazard("vrow %d lane %d: bad PREV lane" % (v, lane))
+                    vals.append(None)
+                else:
+                    raise ScheduleHazard("vrow %d lane %d: unknown operand kind" % (v, lane))
+            out.append(vals)
+        return out
+
+    fetched = early(0) if n_vrows else []
+    prev = [0] * 64
+    for v in range(n_vrows):
+        nxt = early(v + 1) if v + 1 < n_vrows else None
+        res = [0] * 64
+        for lane in range(64):
+            r = recs[v * 64 + lane]
+            ops = fetched[lane]
+            for j in range(3):
+                if ops[j] is None:
+                    ops[j] = prev[(r[j] & 0x3FFFFFFF) // 4]
+            a, b, c = ops
+            t = r[3] & 0xFF
+            na, nb_ = full ^ a, full ^ b
+            lo = ((na & nb_) if t & 1 else 0) | ((a & nb_) if t & 2 else 0) | ((na & b) if t & 4 else 0) | ((a & b) if t & 8 else 0)
+            hi = ((na & nb_) if t & 16 else 0) | ((a & nb_) if t & 32 else 0) | ((na & b) if t & 64 else 0) | ((a & b) if t & 128 else 0)
+            x = (lo & (full ^ c)) | (hi & c)
+            res[lane] = x
+            if r[3] & BF_ASSERT:
+                viol |= x
+        base = (v % ring) * 64
+        for lane in range(64):
+            ring_val[base + lane] = res[lane]
+            ring_tag[base + lane] = v
+            r = recs[v * 64 + lane]
+            for j in range(4, 8):
+                d = r[j]
+                if d:
+                    if d % 8 or d // 8 >= n_slots or d // 8 < 3:
+                        raise ScheduleHazard("vrow %d lane %d: destination out of range" % (v, lane))
+                    T[d // 8] = res[lane]
+        prev = res
+        fetched = nxt
+    return T, viol

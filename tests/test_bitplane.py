@@ -1,0 +1,310 @@
+"""Bit-plane path (hip_elements/bitblast.py + bitsched.py + csrc/cw_bits.hip): circuits whose signals are all boolean
+for 0/1 inputs are evaluated one BIT per signal per instance.  CPU: the gate network and the scheduled program
+reproduce the flat witness code (oracle/tape_eval.eval_flat) on random 0/1 inputs; the executor's hazard rules are
+enforced by the replay.  GPU: witnesses, status words, R1CS verdicts and every egress path are bit-exact with the
+oracle — including instances whose inputs are NOT 0/1 (re-run by the 256-bit schedule)."""
+import hashlib
+import random
+
+import numpy as np
+import pytest
+
+from circom_amd.compiler import compile_program
+from circom_amd.frontend.dsl import Program, template
+from circom_amd.frontend.flatten import flatten
+from circom_amd.circuits.sha256 import Xor3, Maj_t, Ch_t, BinSum, RotR, Sha256
+from circom_amd.hip_elements import bitblast as BB, bitsched as BS
+from oracle.tape_eval import eval_flat, eval_bits, check_r1cs, ScheduleHazard
+
+
+@template
+def BitGadget(c, n):
+    """a few SHA-256 building blocks wired together: xor3 of rotations, maj, ch, a 4-operand adder"""
+    a = c.input("a", n)
+    b = c.input("b", n)
+    d = c.input("d", n)
+    out = c.output("out", n + 2)
+    rot = c.component("rot", RotR(n, 3))
+    x3 = c.component("x3", Xor3(n))
+    mj = c.component("mj", Maj_t(n))
+    ch = c.component("ch", Ch_t(n))
+    for k in range(n):
+        c.set(rot["in"][k], a[k])
+    for k in range(n):
+        c.set(x3["a"][k], rot["out"][k]); c.set(x3["b"][k], b[k]); c.set(x3["c"][k], d[k])
+        c.set(mj["a"][k], a[k]); c.set(mj["b"][k], b[k]); c.set(mj["c"][k], d[k])
+        c.set(ch["a"][k], d[k]); c.set(ch["b"][k], a[k]); c.set(ch["c"][k], b[k])
+    s = c.component("sum", BinSum(n, 4))
+    for k in range(n):
+        c.set(s["in"][0][k], x3["out"][k])
+        c.set(s["in"][1][k], mj["out"][k])
+        c.set(s["in"][2][k], ch["out"][k])
+        c.set(s["in"][3][k], (0xA5A5A5A5 >> k) & 1)
+    for k in range(n + 2):
+        c.set(out[k], s["out"][k])
+
+
+@template
+def BitAssert(c):
+    """`a === b` on two inputs cannot be discharged at compile time: it becomes an assertion gate"""
+    a = c.input("a")
+    b = c.input("b")
+    out = c.output("out")
+    c.enforce(a, b)
+    c.set(out, a * b)
+
+
+@template
+def BadBit(c, n):
+    """witness code (xor) disagrees with the constraint (and): only the R1CS check can notice"""
+    a = c.input("a", n)
+    b = c.input("b", n)
+    out = c.output("out", n)
+    for k in range(n):
+        c.hint(out[k], a[k] + b[k] - 2 * a[k] * b[k])
+        c.enforce(out[k], a[k] * b[k], runtime_check=False)
+
+
+def _rand_bits(fc, n, seed):
+    r = random.Random(seed)
+    return [[r.randrange(2) for _ in range(fc.n_main_inputs)] for _ in range(n)]
+
+
+def _flat(fc, row):
+    sig, failed = eval_flat(fc.fp.q, fc.n_signals, fc.n_temps, fc.constants, fc.code,
+                            {fc.main_input_start + k: v for k, v in enumerate(row)})
+    return sig, failed
+
+
+def _masks(fc, rows, base=0):
+    return {base + fc.main_input_start + k: sum((rows[i][k] & 1) << i for i in range(len(rows))) for k in range(fc.n_main_inputs)}
+
+
+def test_gate_network_reproduces_the_flat_code():
+    fc = flatten(Program(BitGadget(16)))
+    net = BB.bitblast(fc)
+    assert net is not None and net.stats["asserts_left"] == 0 and net.stats["asserts_proved"] > 0
+    rows = _rand_bits(fc, 64, 1)
+    val = BB.simulate(net, _masks(fc, rows), 64)
+    for i in (0, 1, 31, 63):
+        sig, failed = _flat(fc, rows[i])
+        assert failed is None
+        assert [(val[int(net.sig_node[s])] >> i) & 1 for s in range(fc.n_signals)] == sig
+
+
+@pytest.mark.parametrize("ring", [2, 8, 128])
+def test_scheduled_program_reproduces_the_flat_code(ring):
+    fc = flatten(Program(BitGadget(16)))
+    bt = BS.lower_bits(BB.bitblast(fc), fc, ring)
+    assert bt.n_slots >= BS.SIG_BASE + fc.n_signals
+    rows = _rand_bits(fc, 64, 2)
+    T, viol = eval_bits(bt.recs, bt.n_vrows, bt.ring, bt.n_slots, _masks(fc, rows, BS.SIG_BASE), 64)
+    assert viol == 0
+    for i in (0, 5, 63):
+        sig, _ = _flat(fc, rows[i])
+        assert [(T[BS.SIG_BASE + s] >> i) & 1 for s in range(fc.n_signals)] == sig
+    if ring == 2:
+        assert bt.stats["temp_slots"] > 0          # values older than the ring travel through the bit table
+
+
+def test_replay_rejects_programs_that_break_the_executor_rules():
+    fc = flatten(Program(BitGadget(8)))
+    bt = BS.lower_bits(BB.bitblast(fc), fc, 8)
+    rows = _rand_bits(fc, 4, 3)
+    m = _masks(fc, rows, BS.SIG_BASE)
+    recs = bt.recs.copy()
+    # a ring operand that points at the entry the CURRENT vrow is about to write (not yet a live older result)
+    v = bt.n_vrows - 1
+    recs[v * 64, 0] = (BS.K_RING << 30) | ((v % bt.ring) * 512)
+    with pytest.raises(ScheduleHazard):
+        eval_bits(recs, bt.n_vrows, bt.ring, bt.n_slots, m, 4)
+    recs = bt.recs.copy()
+    recs[0, 0] = (BS.K_GLOBAL << 30) | ((bt.n_slots - 1) * 8 if bt.n_slots > BS.SIG_BASE + fc.n_signals else (BS.SIG_BASE + 1) * 8)
+    with pytest.raises(ScheduleHazard):            # slot 1 of main (an output) is not written before vrow 0
+        eval_bits(recs, bt.n_vrows, bt.ring, bt.n_slots, m, 4)
+
+
+def test_unprovable_assert_becomes_an_assertion_gate():
+    fc = flatten(Program(BitAssert()))
+    net = BB.bitblast(fc)
+    assert net is not None and len(net.asserts) == 1
+    bt = BS.lower_bits(net, fc, 8)
+    rows = [[0, 0], [0, 1], [1, 0], [1, 1]]
+    T, viol = eval_bits(bt.recs, bt.n_vrows, bt.ring, bt.n_slots, _masks(fc, rows, BS.SIG_BASE), 4)
+    assert viol == 0b0110
+    for i, row in enumerate(rows):
+        sig, failed = _flat(fc, row)
+        assert (failed is not None) == bool((viol >> i) & 1)
+
+
+def test_arithmetic_circuits_are_left_to_the_wide_schedule():
+    from circom_amd.circuits.poseidon import Poseidon
+    from circom_amd.circuits.basic import Num2Bits, IsZero
+    assert BB.bitblast(flatten(Program(Poseidon(2)))) is None
+    assert BB.bitblast(flatten(Program(IsZero()))) is None            # division / select
+    # small circuits never get a bit program unless asked for
+    import tempfile
+    cp = compile_program(Program(BitGadget(8)), tempfile.mkdtemp(), "bg", sym=False, strands=(1,))
+    assert cp.bittape is None
+    cp = compile_program(Program(BitGadget(8)), tempfile.mkdtemp(), "bg", sym=False, strands=(1,), bits=True)
+    assert cp.bittape is not None
+
+
+def test_sha256_one_block_bitplane_digest():
+    fc = flatten(Program(Sha256(64)))
+    net = BB.bitblast(fc)
+    assert net is not None and net.stats["asserts_left"] == 0
+    bt = BS.lower_bits(net, fc)
+    msgs = [b"abcdefgh", b"\x00" * 8, b"\xff" * 8, b"MI355X!!"]
+    rows = [[(m[i // 8] >> (7 - i % 8)) & 1 for i in range(64)] for m in msgs]
+    T, viol = eval_bits(bt.recs, bt.n_vrows, bt.ring, bt.n_slots, _masks(fc, rows, BS.SIG_BASE), len(msgs))
+    assert viol == 0
+    for i, m in enumerate(msgs):
+        dg = hashlib.sha256(m).digest()
+        want = [(dg[k // 8] >> (7 - k % 8)) & 1 for k in range(256)]
+        assert [(T[BS.SIG_BASE + 1 + k] >> i) & 1 for k in range(256)] == want
+    sig, _ = _flat(fc, rows[3])
+    assert [(T[BS.SIG_BASE + s] >> 3) & 1 for s in range(fc.n_signals)] == sig
+
+
+def test_loader_validates_the_bit_program(tmp_path):
+    from circom_amd import runtime as rt
+    cp = compile_program(Program(BitGadget(8)), str(tmp_path), "bg", sym=False, strands=(1,), bits=True)
+    rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path).close()
+    tape = bytearray(open(cp.tape_path, "rb").read())
+    nrec = cp.bittape.n_vrows * 64 * 32
+    start = len(tape) - nrec
+    for word, val in ((0, (BS.K_GLOBAL << 30) | (cp.bittape.n_slots * 8)),      # operand beyond the table
+                      (1, (BS.K_RING << 30) | (cp.bittape.ring * 512)),          # beyond the ring
+                      (2, 3 << 30),                                              # unknown kind
+                      (4, 8),                                                    # destination on the constant-1 slot
+                      (5, cp.bittape.n_slots * 8)):                              # destination beyond the table
+        bad = bytearray(tape)
+        bad[start + 64 * 32 + word * 4: start + 64 * 32 + word * 4 + 4] = int(val).to_bytes(4, "little")
+        p = tmp_path / "bad.cwt"
+        p.write_bytes(bytes(bad))
+        with pytest.raises(rt.CwError):
+            rt.Circuit(p, cp.dat_path, cp.r1cs_path)
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------------------
+def _gpu(tmp_path, prog, name, **kw):
+    from circom_amd import runtime as rt
+    cp = compile_program(prog, str(tmp_path), name, sym=False, strands=(1,), bits=True, **kw)
+    assert cp.bittape is not None
+    return cp, rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
+
+
+@pytest.mark.gpu
+def test_gpu_bitplane_matches_oracle_on_every_instance(tmp_path):
+    cp, c = _gpu(tmp_path, Program(BitGadget(16)), "bg16")
+    fc = cp.flat
+    B = 300                                                    # ragged last group
+    rows = _rand_bits(fc, B, 7)
+    b = c.batch(B)
+    assert b.bitmode
+    b.set_inputs(rows)
+    b.run(); b.check_r1cs(); b.sync()
+    assert (b.status() == 0).all()
+    bulk = b.witnesses()
+    pub = b.public_signals()
+    for i in range(B):
+        sig, failed = _flat(fc, rows[i])
+        assert failed is None
+        got = [int.from_bytes(bulk[i, k].tobytes(), "little") for k in range(fc.n_signals)]
+        assert got == sig, i
+        assert [int.from_bytes(pub[i, k].tobytes(), "little") for k in range(c.n_public)] == sig[1:1 + c.n_public]
+    assert b.witness(299) == _flat(fc, rows[299])[0]
+    assert b.signal(17, 5) == _flat(fc, rows[17])[0][5]
+    b.close(); c.close()
+
+
+@pytest.mark.gpu
+def test_gpu_non_boolean_inputs_are_rerun_by_the_wide_schedule(tmp_path):
+    cp, c = _gpu(tmp_path, Program(BitGadget(8)), "bg8")
+    fc = cp.flat
+    q = c.q
+    B = 130
+    rows = _rand_bits(fc, B, 9)
+    odd = {3: (0, 2), 64: (5, q - 1), 65: (23, 12345678901234567890), 129: (7, 1 << 200)}
+    for i, (k, v) in odd.items():
+        rows[i][k] = v
+    b = c.batch(B)
+    b.set_inputs(rows)
+    b.run(); b.check_r1cs(); b.sync()
+    st = b.status()
+    bulk = b.witnesses()
+    pub = b.public_signals()
+    for i in range(B):
+        sig, failed = _flat(fc, rows[i])
+        if failed is not None:
+            assert st[i] & 1, i                                 # the reference would abort on this input (assert)
+            continue
+        assert not (st[i] & 1), i
+        assert [int.from_bytes(bulk[i, k].tobytes(), "little") for k in range(fc.n_signals)] == sig, i
+        assert b.witness(i) == sig
+        assert [int.from_bytes(pub[i, k].tobytes(), "little") for k in range(c.n_public)] == sig[1:1 + c.n_public]
+        assert bool(st[i] & 4) == (check_r1cs(q, fc.constraints, sig) is not None)
+    # a second run with clean inputs drops the side batch
+    rows2 = _rand_bits(fc, B, 10)
+    b.set_inputs(rows2)
+    b.run(); b.sync()
+    assert (b.status() == 0).all()
+    assert b.witness(64) == _flat(fc, rows2[64])[0]
+    b.close(); c.close()
+
+
+@pytest.mark.gpu
+def test_gpu_assertion_gate_flags_and_reruns(tmp_path):
+    cp, c = _gpu(tmp_path, Program(BitAssert()), "bassert")
+    rows = [[i & 1, (i >> 1) & 1] for i in range(200)]
+    b = c.batch(200)
+    b.set_inputs(rows)
+    b.run(); b.sync()
+    st = b.status()
+    for i, (x, y) in enumerate(rows):
+        assert bool(st[i] & 1) == (x != y), i
+    b.close(); c.close()
+
+
+@pytest.mark.gpu
+def test_gpu_bitplane_r1cs_check_reports_first_bad_row(tmp_path):
+    cp, c = _gpu(tmp_path, Program(BadBit(12)), "badbit")
+    fc = cp.flat
+    B = 200
+    rows = _rand_bits(fc, B, 11)
+    b = c.batch(B)
+    b.set_inputs(rows)
+    b.run(); b.check_r1cs(); b.sync()
+    st, fb = b.status(), b.r1cs_first_bad()
+    for i in range(B):
+        w = b.witness(i)
+        want = check_r1cs(c.q, fc.constraints, w)
+        assert bool(st[i] & 4) == (want is not None), i
+        if want is not None:
+            assert fb[i] == want, (i, fb[i], want)
+    b.close(); c.close()
+
+
+@pytest.mark.gpu
+def test_gpu_sha256_two_blocks_bitplane(tmp_path):
+    cp, c = _gpu(tmp_path, Program(Sha256(512)), "sha256_512")
+    fc = cp.flat
+    B = 200
+    rng = np.random.default_rng(3)
+    bits = rng.integers(0, 2, size=(B, 512), dtype=np.uint8)
+    arr = np.zeros((B, 512, 32), dtype=np.uint8)
+    arr[:, :, 0] = bits
+    b = c.batch(B)
+    assert b.bitmode
+    b.set_inputs(arr)
+    b.run(); b.check_r1cs(); b.sync()
+    assert (b.status() == 0).all()
+    pub = b.public_signals()
+    for i in range(B):
+        dg = np.unpackbits(np.frombuffer(hashlib.sha256(np.packbits(bits[i]).tobytes()).digest(), dtype=np.uint8))
+        assert (pub[i, :256, 0] == dg).all() and not pub[i, :256, 1:].any(), i
+    for i in (0, 199):
+        sig, failed = _flat(fc, bits[i].tolist())
+        assert failed is None and b.witness(i) == sig
+    b.close(); c.close()
