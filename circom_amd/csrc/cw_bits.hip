@@ -20,10 +20,6 @@
 #include "cw_kernels.h"
 #include "fp256.hip.h"
 
-#define BK_GLOBAL 0u
-#define BK_RING 1u
-#define BK_PREV 2u
-#define BF_ASSERT 0x100u
 
 // ---- init: constant slots, flags -------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) cw_bits_init_kernel(uint64_t *T, uint64_t slots, uint32_t n_groups, uint64_t *fbmask,
@@ -72,19 +68,25 @@ __global__ void __launch_bounds__(64) cw_bits_ingest_kernel(const uint4 *__restr
 }
 
 // ---- the gate program ------------------------------------------------------------------------------------------------------
-struct BRec {
-    uint32_t a, b, c, t;      // operands (kind << 30 | offset), truth table | flags
-    uint32_t d0, d1, d2, d3;  // destination byte offsets in the group's bit table (0 = none)
-};
-__device__ __forceinline__ BRec brec_load(const uint4 *__restrict__ recs, size_t idx) {
-    const uint4 x = recs[idx * 2], y = recs[idx * 2 + 1];
-    BRec r;
-    r.a = x.x; r.b = x.y; r.c = x.z; r.t = x.w;
-    r.d0 = y.x; r.d1 = y.y; r.d2 = y.z; r.d3 = y.w;
-    return r;
-}
+// Record (hip_elements/bitsched.py), 4 words per lane:
+//   w0 = a_off | b_off << 16      LDS byte offsets of ring entries (8-byte entries, < R * 512)
+//   w1 = c_off | tt << 16 | flags << 24
+//   w2 = g_off                    LOAD lanes: byte offset of a bit-table slot; gate lanes: NONE
+//   w3 = d_off                    byte offset of the slot this value is stored to, NONE = 0xFFFFFFFF
+// Signals that are copies of one another share a slot (sig_slot[] maps signal -> slot), so a value is stored once.
+// result = LUT(a, b, c) | loaded value: gate lanes load nothing (NONE is out of the buffer's range: the hardware
+// returns 0), load lanes carry table 0.  The destination goes through the same buffer descriptor, so a NONE store is
+// dropped: no branches, and hipcc counts every memory operation exactly (its waits for later loads then do not
+// drain the stores — vmcnt counts loads and stores alike on gfx9).
+// W = instances per wave: 64 (one wave per group), or 32 / 16 (2 / 4 independent waves per group, each on its slice
+// of every mask: small batches then spread over more CUs and the lookups run on 32-bit halves).
+#define BITS_NONE 0xFFFFFFFFu
+#define BITS_F_ASSERT 1u
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ uint32_t bfi32(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }   // v_bfi_b32
-// 3-input lookup on 32 instances: index bit 0 = a, bit 1 = b, bit 2 = c
+// 3-input lookup on 32 instances: index bit 0 = a, bit 1 = b, bit 2 = c; t[m] = 0 or ~0
 __device__ __forceinline__ uint32_t lut3_32(uint32_t a, uint32_t b, uint32_t c, const uint32_t t[8]) {
     const uint32_t x0 = bfi32(a, t[1], t[0]), x1 = bfi32(a, t[3], t[2]), x2 = bfi32(a, t[5], t[4]), x3 = bfi32(a, t[7], t[6]);
     const uint32_t y0 = bfi32(b, x1, x0), y1 = bfi32(b, x3, x2);
@@ -98,79 +100,141 @@ __device__ __forceinline__ uint64_t lut3(uint64_t a, uint64_t b, uint64_t c, uin
     const uint32_t hi = lut3_32((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32), t);
     return ((uint64_t)hi << 32) | lo;
 }
-// early operand fetch (ring / bit table), branch-free: lanes of the other kinds read entry / slot 0
-__device__ __forceinline__ uint64_t bits_early(uint32_t w, const char *Tg, const char *ring) {
-    const uint32_t kind = w >> 30, off = w & 0x3FFFFFFFu;
-    const uint64_t gv = *(const uint64_t *)(Tg + (kind == BK_GLOBAL ? off : 0u));
-    const uint64_t rv = *(const uint64_t *)(ring + (kind == BK_RING ? off : 0u));
-    return kind == BK_RING ? rv : gv;
-}
-__device__ __forceinline__ uint64_t bits_prev(uint32_t w, uint64_t early, uint64_t res) {
-    const uint32_t kind = w >> 30;
-    const int addr = (int)(kind == BK_PREV ? (w & 0xFCu) : 0u);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)res);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)(res >> 32));
-    const uint64_t p = ((uint64_t)hi << 32) | lo;
-    return kind == BK_PREV ? p : early;
+
+template <int W> struct BitsMask;
+template <> struct BitsMask<64> {
+    typedef uint64_t T;
+    static __device__ __forceinline__ T lds(const char *p) { return *(const uint64_t *)p; }
+    static __device__ __forceinline__ void lds_st(char *p, T v) { *(uint64_t *)p = v; }
+    static __device__ __forceinline__ T load(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
+        return ((uint64_t)v.y << 32) | v.x;
+    }
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, uint32_t off, T v) {
+        const u32x2 x = {(uint32_t)v, (uint32_t)(v >> 32)};
+        __builtin_amdgcn_raw_buffer_store_b64(x, r, (int)off, 0, 0);
+    }
+    static __device__ __forceinline__ T lut(T a, T b, T c, uint32_t w1) { return lut3(a, b, c, w1 >> 16); }
+};
+template <> struct BitsMask<32> {
+    typedef uint32_t T;
+    static __device__ __forceinline__ T lds(const char *p) { return *(const uint32_t *)p; }
+    static __device__ __forceinline__ void lds_st(char *p, T v) { *(uint32_t *)p = v; }
+    static __device__ __forceinline__ T load(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+        return __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0);
+    }
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, uint32_t off, T v) {
+        __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)off, 0, 0);
+    }
+    static __device__ __forceinline__ T lut(T a, T b, T c, uint32_t w1) {
+        uint32_t t[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) t[m] = (uint32_t)((int32_t)(w1 << (15 - m)) >> 31);
+        return lut3_32(a, b, c, t);
+    }
+};
+template <> struct BitsMask<16> {
+    typedef uint32_t T;
+    static __device__ __forceinline__ T lds(const char *p) { return *(const uint32_t *)p; }
+    static __device__ __forceinline__ void lds_st(char *p, T v) { *(uint32_t *)p = v; }
+    static __device__ __forceinline__ T load(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+        return (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(r, (int)off, 0, 0);
+    }
+    static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, uint32_t off, T v) {
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, r, (int)off, 0, 0);
+    }
+    static __device__ __forceinline__ T lut(T a, T b, T c, uint32_t w1) { return BitsMask<32>::lut(a, b, c, w1); }
+};
+
+struct BRec { uint32_t w0, w1, g, d; };
+__device__ __forceinline__ BRec brec_load(const uint4 *__restrict__ recs, size_t idx) {
+    const uint4 x = recs[idx];
+    BRec r;
+    r.w0 = x.x; r.w1 = x.y; r.g = x.z; r.d = x.w;
+    return r;
 }
 
-extern __shared__ uint64_t cw_bits_ring[];       // [R][64 lanes]
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+extern __shared__ uint64_t cw_bits_ring[];       // [R][64 lanes] x 8 B
 
+// One step of the software pipeline, device vrow v (the host shifts the stream: device record v carries the LOAD
+// address of program vrow v and the gate fields of program vrow v - 2, so a bit-table value is requested two steps
+// before its vrow without waiting for a younger record).  Entering: RC = record of this step, (a, b, c) = its ring
+// operands, GVC = its loaded value (requested two steps ago); RN = next record.  The step requests the bit-table
+// value for two steps ahead (RC.g) and the ring operands of the next step, evaluates, writes ring entry (v - 2) mod R
+// and the destinations, then refills RC's registers with the record four steps ahead.
+// timing experiments only (tools/bits_exp.sh; results are garbage): drop the stores / the bit-table loads
+#ifdef CW_EXP_NOSTORE
+#define BITS_EXP_STORE(x)
+#else
+#define BITS_EXP_STORE(x) x
+#endif
+#ifdef CW_EXP_NOLOAD
+#define BITS_EXP_LOAD(x) 0
+#else
+#define BITS_EXP_LOAD(x) x
+#endif
+#define BITS_STEP(RC, RN, GVC, GVN2)                                                                               \
+    {                                                                                                              \
+        GVN2 = BITS_EXP_LOAD(M::load(rsrc, RC.g));                                                                 \
+        const mask_t na = M::lds(ring + (RN.w0 & 0xFFFFu)), nb = M::lds(ring + (RN.w0 >> 16)),                     \
+                     nc = M::lds(ring + (RN.w1 & 0xFFFFu));                                                        \
+        const mask_t res = M::lut(a, b, c, RC.w1) | GVC;                                                           \
+        if ((RC.w1 >> 24) & BITS_F_ASSERT) viol |= res;                                                            \
+        M::lds_st(ring + (((v + ring_mask - 1u) & ring_mask) << 9) + lane * 8, res);                               \
+        BITS_EXP_STORE(M::store(rsrc, RC.d, res));                                                                 \
+        a = na; b = nb; c = nc;                                                                                    \
+        RC = brec_load(recs, (size_t)(v + 4) * 64 + lane);                                                         \
+        v++;                                                                                                       \
+    }
+
+template <int W>
 __global__ void __launch_bounds__(64)
-cw_bits_eval_kernel(const uint4 *__restrict__ recs, uint32_t n_vrows, uint32_t ring_mask, uint64_t *T, uint64_t slots,
+cw_bits_eval_kernel(const uint4 *__restrict__ recs, uint32_t n_steps, uint32_t ring_mask, uint64_t *T, uint64_t slots,
                     uint64_t *fbmask) {
-    const uint32_t lane = threadIdx.x, g = blockIdx.x;
-    char *Tg = (char *)(T + (size_t)g * slots);
+    typedef BitsMask<W> M;
+    typedef typename M::T mask_t;
+    const uint32_t lane = threadIdx.x, g = blockIdx.x, slice = blockIdx.y;
+    char *Tg = (char *)(T + (size_t)g * slots) + slice * (W / 8);
     char *ring = (char *)cw_bits_ring;
-    // buffer descriptor of this group's table (wave-uniform by construction: kernel arguments and blockIdx only)
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(Tg, 0, (int)(uint32_t)(slots * 8), 0x00020000);
-    // entry 0 of the ring is read by lanes that have no ring operand: keep it defined
-    cw_bits_ring[lane] = 0;
-    if (n_vrows == 0) return;
-    // records are streamed three vrows ahead (2 KiB per vrow, coalesced); the stream is padded with 3 empty vrows
-    BRec r0 = brec_load(recs, lane), r1 = brec_load(recs, 64 + lane), r2 = brec_load(recs, 128 + lane);
-    uint64_t a = bits_early(r0.a, Tg, ring), b = bits_early(r0.b, Tg, ring), c = bits_early(r0.c, Tg, ring);
-    uint64_t viol = 0;
-    for (uint32_t v = 0; v < n_vrows; v++) {
-        const BRec r3 = brec_load(recs, (size_t)(v + 3) * 64 + lane);
-        // ring / bit-table operands of the NEXT vrow, requested before this vrow's results are written
-        const uint64_t na = bits_early(r1.a, Tg, ring), nb = bits_early(r1.b, Tg, ring), nc = bits_early(r1.c, Tg, ring);
-        const uint64_t res = lut3(a, b, c, r0.t);
-        if (r0.t & BF_ASSERT) viol |= res;
-        *(uint64_t *)(ring + (size_t)(v & ring_mask) * 512 + lane * 8) = res;
-        // destinations: buffer stores through the group's descriptor; "none" (0) becomes an out-of-range offset, which
-        // the hardware drops.  No branches: hipcc then counts the stores exactly and its waits for later loads do not
-        // drain them (vmcnt counts loads and stores alike on gfx9).
-        const u32x2 rv = {(uint32_t)res, (uint32_t)(res >> 32)};
-        __builtin_amdgcn_raw_buffer_store_b64(rv, rsrc, (int)(r0.d0 ? r0.d0 : 0x80000000u), 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(rv, rsrc, (int)(r0.d1 ? r0.d1 : 0x80000000u), 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(rv, rsrc, (int)(r0.d2 ? r0.d2 : 0x80000000u), 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(rv, rsrc, (int)(r0.d3 ? r0.d3 : 0x80000000u), 0, 0);
-        // PREV operands of the next vrow: lanes of this vrow's result
-        a = bits_prev(r1.a, na, res);
-        b = bits_prev(r1.b, nb, res);
-        c = bits_prev(r1.c, nc, res);
-        r0 = r1; r1 = r2; r2 = r3;
+    // buffer descriptor of this group's table (wave-uniform by construction: kernel arguments and blockIdx only);
+    // a wave of a narrower slice addresses its bytes of every 8-byte mask through the shifted base
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(Tg, 0, (int)(uint32_t)(slots * 8 - slice * (W / 8)), 0x00020000);
+    if (n_steps == 0) return;
+    // n_steps = program vrows + 2; the stream is padded with 8 empty records per lane behind it (records are requested
+    // four steps ahead and the loop runs in trips of four)
+    BRec r0 = brec_load(recs, lane), r1 = brec_load(recs, 64 + lane), r2 = brec_load(recs, 128 + lane),
+         r3 = brec_load(recs, 192 + lane);
+    mask_t a = 0, b = 0, c = 0;                 // the first two steps carry no gate
+    mask_t gv0 = 0, gv1 = 0, gv2 = 0, gv3 = 0;
+    mask_t viol = 0;
+    uint32_t v = 0;
+    // four steps per trip: the record register sets and the loaded values rotate by name, not by moves
+    while (v < n_steps) {
+        BITS_STEP(r0, r1, gv0, gv2)
+        BITS_STEP(r1, r2, gv1, gv3)
+        BITS_STEP(r2, r3, gv2, gv0)
+        BITS_STEP(r3, r0, gv3, gv1)
     }
     // instances that tripped an assertion gate: OR over the lanes (gates), then into the group's fallback mask
+    uint64_t vz = (uint64_t)viol;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
-        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)viol, off), hi = (uint32_t)__shfl_xor((int)(uint32_t)(viol >> 32), off);
-        viol |= ((uint64_t)hi << 32) | lo;
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)vz, off), hi = (uint32_t)__shfl_xor((int)(uint32_t)(vz >> 32), off);
+        vz |= ((uint64_t)hi << 32) | lo;
     }
-    if (lane == 0 && viol) atomicOr((unsigned long long *)&fbmask[g], (unsigned long long)viol);
+    if (W < 64) vz = (vz & ((1ull << (W & 63)) - 1)) << (slice * W);
+    if (lane == 0 && vz) atomicOr((unsigned long long *)&fbmask[g], (unsigned long long)vz);
 }
 
 // ---- egress: canonical 32-byte values from the bit table (getWitness + Fr_toLongNormal, main.cpp:326-332) ----------------
 // element k of instance `first + blockIdx.y` -> out[(blockIdx.y * n_wit + k)]; w2s = witness -> signal map
 __global__ void __launch_bounds__(256)
-cw_bits_gather_kernel(const uint64_t *__restrict__ T, uint64_t slots, const uint32_t *__restrict__ w2s, uint32_t n_wit,
-                      uint32_t first, uint4 *__restrict__ out) {
+cw_bits_gather_kernel(const uint64_t *__restrict__ T, uint64_t slots, const uint32_t *__restrict__ w2s,
+                      const uint32_t *__restrict__ sig_slot, uint32_t n_wit, uint32_t first, uint4 *__restrict__ out) {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (k >= n_wit) return;
     const uint32_t i = first + blockIdx.y;
-    const uint64_t m = T[(size_t)(i >> 6) * slots + 3u + w2s[k]];
+    const uint64_t m = T[(size_t)(i >> 6) * slots + sig_slot[w2s[k]]];
     const uint32_t bit = (uint32_t)(m >> (i & 63u)) & 1u;
     const size_t o = ((size_t)blockIdx.y * n_wit + k) * 2;
     out[o] = make_uint4(bit, 0, 0, 0);
@@ -263,6 +327,51 @@ cw_bits_r1cs_wide_kernel(const uint4 *__restrict__ chunk, uint32_t n_chunks, con
     }
 }
 
+// Class I: the same stream, but every coefficient is a small signed integer (|c| < 2^40, < 2^20 terms per row): the
+// three parts are exact 64-bit integer sums (4 VALU per term), the row holds iff A * B - C == 0 over the integers
+// (|A*B - C| < 2^125 < q, so this IS the test modulo q).  SHA-256's `lin === lout` rows (up to 195 terms) live here.
+__global__ void __launch_bounds__(64)
+cw_bits_r1cs_int_kernel(const uint4 *__restrict__ chunk, uint32_t n_chunks, const uint2 *__restrict__ terms,
+                        const uint2 *__restrict__ itab, const uint32_t *__restrict__ row_orig,
+                        const uint64_t *__restrict__ T, uint64_t slots, uint32_t batch, uint32_t *status,
+                        uint32_t *first_bad) {
+    const uint32_t lane = threadIdx.x, g = blockIdx.x;
+    const uint32_t i = g * 64 + lane;
+    const char *Tg = (const char *)(T + (size_t)g * slots);
+    uint32_t bad = 0xFFFFFFFFu;
+    for (uint32_t cix = blockIdx.y; cix < n_chunks; cix += gridDim.y) {
+        const uint4 ch = chunk[cix];                                // first term, n terms, -, first row
+        const uint2 *tp = terms + ch.x;
+        int64_t A = 0, B = 0, cur = 0;
+        uint32_t row = ch.w;
+        for (uint32_t k = 0; k < ch.y; k++) {
+            const uint2 t = tp[k];
+            const uint32_t off = t.x & 0x0FFFFFFFu, part = (t.x >> 28) & 3u, last = t.x >> 31, endrow = (t.x >> 30) & 1u;
+            const uint64_t m = *(const uint64_t *)(Tg + off);      // wave-uniform address
+            const uint2 cw = itab[t.y];
+            const int64_t cf = (int64_t)(((uint64_t)cw.y << 32) | cw.x);
+            cur += ((m >> lane) & 1ull) ? cf : 0;
+            if (last) {
+                if (part == 0) { A = cur; cur = 0; }
+                else if (part == 1) { B = cur; cur = 0; }
+            }
+            if (endrow) {
+                const __int128 z = (__int128)A * (__int128)B - (__int128)cur;
+                if (z != 0) {
+                    const uint32_t oc = row_orig[row];
+                    if (oc < bad) bad = oc;
+                }
+                row++;
+                A = 0; B = 0; cur = 0;
+            }
+        }
+    }
+    if (bad != 0xFFFFFFFFu && i < batch) {
+        atomicMin(&first_bad[i], bad);
+        atomicOr(&status[i], CW_ST_R1CS_FAILED);
+    }
+}
+
 // ---- launch wrappers ---------------------------------------------------------------------------------------------------
 hipError_t cwk_bits_init(hipStream_t s, void *T, uint64_t slots, uint32_t n_groups, void *fbmask, uint32_t *status,
                          uint32_t *first_bad, uint32_t Bp) {
@@ -281,38 +390,47 @@ hipError_t cwk_bits_ingest(hipStream_t s, const void *in, void *T, uint64_t slot
     return hipGetLastError();
 }
 hipError_t cwk_bits_eval(hipStream_t s, const void *recs, uint32_t n_vrows, uint32_t ring, void *T, uint64_t slots,
-                         uint32_t n_groups, void *fbmask) {
+                         uint32_t n_groups, uint32_t width, void *fbmask) {
     const size_t lds = (size_t)ring * 512;
+    typedef void (*kern_t)(const uint4 *, uint32_t, uint32_t, uint64_t *, uint64_t, uint64_t *);
+    kern_t k = width == 16 ? (kern_t)cw_bits_eval_kernel<16> : width == 32 ? (kern_t)cw_bits_eval_kernel<32> : (kern_t)cw_bits_eval_kernel<64>;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)cw_bits_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(cw_bits_eval_kernel, dim3(n_groups), dim3(64), lds, s, (const uint4 *)recs, n_vrows, ring - 1,
-                       (uint64_t *)T, slots, (uint64_t *)fbmask);
+    hipLaunchKernelGGL(k, dim3(n_groups, 64 / width), dim3(64), lds, s, (const uint4 *)recs, n_vrows, ring - 1, (uint64_t *)T, slots,
+                       (uint64_t *)fbmask);
     return hipGetLastError();
 }
-hipError_t cwk_bits_gather(hipStream_t s, const void *T, uint64_t slots, const uint32_t *w2s, uint32_t n_wit, uint32_t first,
-                           uint32_t count, void *out) {
+hipError_t cwk_bits_gather(hipStream_t s, const void *T, uint64_t slots, const uint32_t *w2s, const uint32_t *sig_slot,
+                           uint32_t n_wit, uint32_t first, uint32_t count, void *out) {
     if (!count || !n_wit) return hipSuccess;
     for (uint32_t done = 0; done < count; done += 65535u) {       // grid.y limit
         const uint32_t n = count - done < 65535u ? count - done : 65535u;
         hipLaunchKernelGGL(cw_bits_gather_kernel, dim3((n_wit + 255) / 256, n), dim3(256), 0, s, (const uint64_t *)T, slots, w2s,
-                           n_wit, first + done, (uint4 *)out + (size_t)done * n_wit * 2);
+                           sig_slot, n_wit, first + done, (uint4 *)out + (size_t)done * n_wit * 2);
     }
     return hipGetLastError();
 }
 hipError_t cwk_bits_r1cs(hipStream_t s, const void *erecs, uint32_t n_evrows, const uint32_t *chunk, uint32_t n_chunks,
-                         const uint32_t *terms, const uint32_t *ctab, const uint32_t *row_orig, const void *T, uint64_t slots,
-                         uint32_t n_groups, uint32_t batch, uint32_t *status, uint32_t *first_bad, const FpParams &P) {
+                         const uint32_t *terms, const uint32_t *ctab, const uint32_t *row_orig, const uint32_t *ichunk,
+                         uint32_t n_ichunks, const uint32_t *iterms, const uint32_t *itab, const uint32_t *irow_orig, const void *T,
+                         uint64_t slots, uint32_t n_groups, uint32_t batch, uint32_t *status, uint32_t *first_bad, const FpParams &P) {
     if (n_evrows) {
-        // enough workgroups to fill the chip: groups x chunks >= ~2048 waves
-        uint32_t chunks = (2048 + n_groups - 1) / n_groups;
+        // the kernel is bound by the latency of its 5 mask loads per lane: ~8 waves per SIMD (8192 on the chip) hide it
+        uint32_t chunks = (8192 + n_groups - 1) / n_groups;
         if (chunks > n_evrows) chunks = n_evrows;
+        if (chunks > 65535u) chunks = 65535u;
         if (chunks < 1) chunks = 1;
         const uint32_t per = (n_evrows + chunks - 1) / chunks;
         chunks = (n_evrows + per - 1) / per;
         hipLaunchKernelGGL(cw_bits_r1cs_lut_kernel, dim3(n_groups, chunks), dim3(64), 0, s, (const uint4 *)erecs, n_evrows, per,
                            (const uint64_t *)T, slots, batch, status, first_bad);
+    }
+    if (n_ichunks) {
+        dim3 g(n_groups, n_ichunks < 65535u ? n_ichunks : 65535u);
+        hipLaunchKernelGGL(cw_bits_r1cs_int_kernel, g, dim3(64), 0, s, (const uint4 *)ichunk, n_ichunks, (const uint2 *)iterms,
+                           (const uint2 *)itab, irow_orig, (const uint64_t *)T, slots, batch, status, first_bad);
     }
     if (n_chunks) {
         dim3 g(n_groups, n_chunks < 65535u ? n_chunks : 65535u);

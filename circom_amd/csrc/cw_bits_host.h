@@ -9,45 +9,54 @@
 
 namespace cwbits {
 
-constexpr uint32_t SIG_BASE = 3;            // bit-table slot of signal 0 (slots 0,1,2 = constant 0, constant 1, reserved)
-constexpr uint32_t K_GLOBAL = 0, K_RING = 1, K_PREV = 2;
+constexpr uint32_t IN_BASE = 3;             // bit-table slot of main input 0 (slots 0,1,2 = constant 0, constant 1, reserved)
+constexpr uint32_t NONE = 0xFFFFFFFFu;      // "no destination" / "no load": out of the buffer's range, dropped by the hardware
 
 struct Program {                             // hip_elements/bitsched.py::BitTape
-    uint32_t ring = 0;                       // LDS ring entries (power of two)
+    uint32_t ring = 0;                       // LDS ring entries (power of two, <= 128: offsets travel in 16 bits)
     uint32_t n_vrows = 0;
     uint64_t n_slots = 0;                    // bit-table slots per group of 64 instances
-    std::vector<uint32_t> recs;              // (n_vrows + 3) * 64 * 8 words, the last 3 vrows empty (kernel prefetch)
+    std::vector<uint32_t> recs;              // n_vrows * 64 * 4 words (record layout: bitsched.py / cw_bits.hip)
+    std::vector<uint32_t> sig_slot;          // signal -> slot (signals that are copies of one another share a slot)
 };
 
-// Every offset a record carries is checked once at load time (files are untrusted input): operands and
-// destinations inside the group's bit table / the ring / the wave, destinations never on the constant slots.
-inline const char *validate(const Program &p, uint32_t n_signals) {
-    if (p.ring < 2 || p.ring > 256 || (p.ring & (p.ring - 1))) return "bit program: ring size";
-    if (p.n_slots < (uint64_t)SIG_BASE + n_signals || p.n_slots > (1ull << 27)) return "bit program: slot count";
-    if (p.recs.size() != ((size_t)p.n_vrows + 3) * 64 * 8) return "bit program: record count";
-    for (size_t v = 0; v < p.n_vrows; v++) {
-        for (uint32_t lane = 0; lane < 64; lane++) {
-            const uint32_t *r = &p.recs[(v * 64 + lane) * 8];
-            for (int j = 0; j < 3; j++) {
-                const uint32_t kind = r[j] >> 30, off = r[j] & 0x3FFFFFFFu;
-                if (kind == K_GLOBAL) {
-                    if ((off & 7) || off / 8 >= p.n_slots) return "bit program: operand slot out of range";
-                } else if (kind == K_RING) {
-                    if ((off & 7) || off >= p.ring * 512u) return "bit program: ring operand out of range";
-                } else if (kind == K_PREV) {
-                    if ((off & 3) || off >= 256 || v == 0) return "bit program: bad PREV operand";
-                } else {
-                    return "bit program: unknown operand kind";
-                }
-            }
-            if (r[3] & ~0x1FFu) return "bit program: bad gate word";
-            for (int j = 4; j < 8; j++) {
-                const uint32_t d = r[j];
-                if (d && ((d & 7) || d / 8 >= p.n_slots || d / 8 < SIG_BASE)) return "bit program: destination out of range";
-            }
-        }
+// Every offset a record carries is checked once at load time (files are untrusted input): ring operands inside the
+// ring, load addresses and destinations inside the group's bit table, destinations never on constant or input slots.
+inline const char *validate(const Program &p, uint32_t n_signals, uint32_t n_inputs) {
+    if (p.ring < 8 || p.ring > 128 || (p.ring & (p.ring - 1))) return "bit program: ring size";
+    if (p.n_slots < (uint64_t)IN_BASE + n_inputs || p.n_slots >= (1ull << 25)) return "bit program: slot count";
+    if (p.recs.size() != (size_t)p.n_vrows * 64 * 4) return "bit program: record count";
+    if (p.sig_slot.size() != n_signals) return "bit program: signal map size";
+    for (uint32_t s : p.sig_slot)
+        if (s >= p.n_slots || s == 2) return "bit program: signal slot out of range";
+    const uint32_t ring_bytes = p.ring * 512u;
+    const uint64_t tab_bytes = p.n_slots * 8;
+    for (size_t i = 0; i < (size_t)p.n_vrows * 64; i++) {
+        const uint32_t *r = &p.recs[i * 4];
+        const uint32_t a = r[0] & 0xFFFFu, b = r[0] >> 16, c = r[1] & 0xFFFFu;
+        if ((a & 7) || (b & 7) || (c & 7) || a >= ring_bytes || b >= ring_bytes || c >= ring_bytes) return "bit program: ring operand out of range";
+        if (r[1] >> 25) return "bit program: bad gate word";
+        if (r[2] != NONE && ((r[2] & 7) || r[2] >= tab_bytes)) return "bit program: load slot out of range";
+        if (r[3] != NONE && ((r[3] & 7) || r[3] >= tab_bytes || r[3] / 8 < IN_BASE + n_inputs)) return "bit program: destination out of range";
     }
     return nullptr;
+}
+
+// Device stream: the LOAD address of program vrow v travels in device record v, its gate fields in device record
+// v + 2 (the kernel requests a bit-table value two steps before the vrow that uses it); 8 empty records per lane pad
+// the end (records are requested four steps ahead, the loop runs in trips of four).  Returns the number of steps.
+inline uint32_t device_stream(const Program &p, std::vector<uint32_t> &dev) {
+    const size_t steps = (size_t)p.n_vrows + 2;
+    dev.assign((steps + 8) * 64 * 4, NONE);
+    for (size_t i = 0; i < (steps + 8) * 64; i++) dev[i * 4] = dev[i * 4 + 1] = 0;
+    for (size_t v = 0; v < p.n_vrows; v++)
+        for (size_t lane = 0; lane < 64; lane++) {
+            const uint32_t *src = &p.recs[(v * 64 + lane) * 4];
+            uint32_t *own = &dev[((v + 2) * 64 + lane) * 4];
+            own[0] = src[0]; own[1] = src[1]; own[3] = src[3];
+            dev[(v * 64 + lane) * 4 + 2] = src[2];
+        }
+    return (uint32_t)steps;
 }
 
 // ---- R1CS over the bit table --------------------------------------------------------------------------------------------
@@ -62,7 +71,11 @@ struct R1Plan {
     std::vector<uint32_t> row_orig;   // W-class rows -> constraint index of the .r1cs
     std::vector<uint32_t> ctab;       // canonical coefficients, 8 words each
     uint32_t n_chunks = 0;
-    uint64_t n_trivial = 0, n_lut = 0, n_wide = 0;
+    // class I: like W, but every coefficient is a small signed integer: exact 64-bit integer sums (cw_bits_r1cs_int_kernel)
+    std::vector<uint32_t> ichunk, iterms, irow_orig;
+    std::vector<uint32_t> itab;       // signed 64-bit value of every coefficient id (2 words each; 0 if not small)
+    uint32_t n_ichunks = 0;
+    uint64_t n_trivial = 0, n_lut = 0, n_wide = 0, n_int = 0;
 };
 
 // small signed value of a canonical coefficient, if |val| < 2^40
@@ -86,12 +99,17 @@ inline bool small_coef(const uint64_t c[4], const uint64_t q[4], int64_t *out) {
     return false;
 }
 
-// r_ptr: 3 * n_cons + 1 offsets (A, B, C parts of every row, processing order); r_slot: signal of each term;
-// r_cc: canonical coefficient id of each term into cc (8 words each); r_orig: processing order -> constraint index.
-inline R1Plan build_r1cs(const std::vector<uint32_t> &r_ptr, const std::vector<uint32_t> &r_slot, const std::vector<uint32_t> &r_cc,
-                         const std::vector<uint32_t> &cc, const std::vector<uint32_t> &r_orig, const uint64_t q[4],
-                         uint32_t terms_per_chunk) {
+// r_ptr: 3 * n_cons + 1 offsets (A, B, C parts of every row, processing order); r_sig: signal of each term;
+// r_cc: canonical coefficient id of each term into cc (8 words each); r_orig: processing order -> constraint index;
+// sig_slot: signal -> bit-table slot.  Wires are identified by their SLOT: signals that are copies of one another are
+// one wire (an `a.in === b.out` wiring row then has table 0: it holds by construction and is not checked at run time),
+// slot 1 is the constant 1 (like signal 0), slot 0 the constant 0 (its terms vanish).
+inline R1Plan build_r1cs(const std::vector<uint32_t> &r_ptr, const std::vector<uint32_t> &r_sig, const std::vector<uint32_t> &r_cc,
+                         const std::vector<uint32_t> &cc, const std::vector<uint32_t> &r_orig, const std::vector<uint32_t> &sig_slot,
+                         const uint64_t q[4], uint32_t terms_per_chunk) {
     R1Plan p;
+    std::vector<uint32_t> r_slot(r_sig.size());
+    for (size_t i = 0; i < r_sig.size(); i++) r_slot[i] = sig_slot[r_sig[i]];
     const size_t n_cons = r_orig.size();
     std::vector<int64_t> small(cc.size() / 8);
     std::vector<uint8_t> is_small(cc.size() / 8);
@@ -101,17 +119,27 @@ inline R1Plan build_r1cs(const std::vector<uint32_t> &r_ptr, const std::vector<u
         is_small[i] = small_coef(c, q, &small[i]);
     }
     p.ctab = cc;
+    p.itab.assign(small.size() * 2, 0);
+    for (size_t i = 0; i < small.size(); i++)
+        if (is_small[i]) {
+            p.itab[2 * i] = (uint32_t)(uint64_t)small[i];
+            p.itab[2 * i + 1] = (uint32_t)((uint64_t)small[i] >> 32);
+        }
     std::vector<uint32_t> erows;                  // flat 8-word records, packed into vrows afterwards
-    uint32_t cur_terms = 0, cur_first_term = 0, cur_first_row = 0;
-    auto close_chunk = [&]() {
-        if (cur_terms) {
-            p.chunk.push_back(cur_first_term);
-            p.chunk.push_back(cur_terms);
-            p.chunk.push_back(0);
-            p.chunk.push_back(cur_first_row);
-            cur_terms = 0;
+    struct Stream {
+        std::vector<uint32_t> *chunk, *terms, *rows;
+        uint32_t cur_terms = 0, cur_first_term = 0, cur_first_row = 0;
+        void close() {
+            if (cur_terms) {
+                chunk->push_back(cur_first_term);
+                chunk->push_back(cur_terms);
+                chunk->push_back(0);
+                chunk->push_back(cur_first_row);
+                cur_terms = 0;
+            }
         }
     };
+    Stream SW{&p.chunk, &p.terms, &p.row_orig}, SI{&p.ichunk, &p.iterms, &p.irow_orig};
     for (size_t j = 0; j < n_cons; j++) {
         const uint32_t orig = r_orig[j] & 0x7FFFFFFFu;
         const uint32_t t0 = r_ptr[3 * j], t3 = r_ptr[3 * j + 3];
@@ -123,7 +151,7 @@ inline R1Plan build_r1cs(const std::vector<uint32_t> &r_ptr, const std::vector<u
         for (uint32_t t = t0; t < t3 && ok; t++) {
             if (!is_small[r_cc[t]]) ok = false;
             const uint32_t s = r_slot[t];
-            if (s == 0) continue;
+            if (s <= 1) continue;
             int k = 0;
             while (k < nw && wires[k] != s) k++;
             if (k == nw) {
@@ -138,8 +166,8 @@ inline R1Plan build_r1cs(const std::vector<uint32_t> &r_ptr, const std::vector<u
                 for (int pi = 0; pi < 3; pi++)
                     for (uint32_t t = r_ptr[3 * j + pi]; t < r_ptr[3 * j + pi + 1]; t++) {
                         const uint32_t s = r_slot[t];
-                        int bit = 1;
-                        if (s != 0) {
+                        int bit = (int)s;                       // slot 0: constant 0, slot 1: constant 1
+                        if (s > 1) {
                             int k = 0;
                             while (wires[k] != s) k++;
                             bit = (m >> k) & 1;
@@ -151,34 +179,38 @@ inline R1Plan build_r1cs(const std::vector<uint32_t> &r_ptr, const std::vector<u
             // (wires beyond nw read the constant-0 slot: only the first 2^nw entries are ever selected)
             if (tt == 0) { p.n_trivial++; continue; }
             uint32_t rec[8] = {0, 0, 0, 0, 0, tt, orig, 0};
-            for (int k = 0; k < nw; k++) rec[k] = (SIG_BASE + wires[k]) * 8;
+            for (int k = 0; k < nw; k++) rec[k] = wires[k] * 8;
             erows.insert(erows.end(), rec, rec + 8);
             p.n_lut++;
             continue;
         }
-        // class W
-        p.n_wide++;
+        // class I (all coefficients small: 64-bit integer sums) or W (field arithmetic)
         const uint32_t nt = t3 - t0;
-        if (cur_terms && cur_terms + nt > terms_per_chunk) close_chunk();
-        if (cur_terms == 0) {
-            cur_first_term = (uint32_t)(p.terms.size() / 2);
-            cur_first_row = (uint32_t)p.row_orig.size();
+        bool all_small = nt < (1u << 20);
+        for (uint32_t t = t0; t < t3 && all_small; t++) all_small = is_small[r_cc[t]];
+        Stream &S = all_small ? SI : SW;
+        if (all_small) p.n_int++; else p.n_wide++;
+        if (S.cur_terms && S.cur_terms + nt > terms_per_chunk) S.close();
+        if (S.cur_terms == 0) {
+            S.cur_first_term = (uint32_t)(S.terms->size() / 2);
+            S.cur_first_row = (uint32_t)S.rows->size();
         }
         for (int pi = 0; pi < 3; pi++) {
             const uint32_t a = r_ptr[3 * j + pi], b = r_ptr[3 * j + pi + 1];
             for (uint32_t t = a; t < b; t++) {
-                uint32_t w = (SIG_BASE + r_slot[t]) * 8;           // < 2^28 (n_slots <= 2^25 checked by the caller)
+                uint32_t w = r_slot[t] * 8;                        // < 2^28 (n_slots < 2^25 checked by validate)
                 w |= (uint32_t)pi << 28;
                 if (t + 1 == b) w |= 1u << 31;                     // last term of its part
                 if (t + 1 == t3) w |= 1u << 30;                    // last term of the row
-                p.terms.push_back(w);
-                p.terms.push_back(r_cc[t]);
+                S.terms->push_back(w);
+                S.terms->push_back(r_cc[t]);
             }
         }
-        p.row_orig.push_back(orig);
-        cur_terms += nt;
+        S.rows->push_back(orig);
+        S.cur_terms += nt;
     }
-    close_chunk();
+    SW.close();
+    SI.close();
     p.n_chunks = (uint32_t)(p.chunk.size() / 4);
     p.n_evrows = (uint32_t)((erows.size() / 8 + 63) / 64);
     p.erecs.assign((size_t)p.n_evrows * 64 * 8, 0);
@@ -186,6 +218,11 @@ inline R1Plan build_r1cs(const std::vector<uint32_t> &r_ptr, const std::vector<u
     if (p.terms.empty()) p.terms.assign(2, 0);
     if (p.row_orig.empty()) p.row_orig.assign(1, 0);
     if (p.chunk.empty()) p.chunk.assign(4, 0);
+    p.n_ichunks = (uint32_t)(p.ichunk.size() / 4);
+    if (p.iterms.empty()) p.iterms.assign(2, 0);
+    if (p.irow_orig.empty()) p.irow_orig.assign(1, 0);
+    if (p.ichunk.empty()) p.ichunk.assign(4, 0);
+    if (p.itab.empty()) p.itab.assign(2, 0);
     return p;
 }
 

@@ -476,13 +476,15 @@ static int load_tape(cw_circuit *c, const char *path) {
         bp.ring = bh[0];
         bp.n_vrows = bh[1];
         bp.n_slots = (uint64_t)bh[2] | ((uint64_t)bh[3] << 32);
-        const uint64_t words = (uint64_t)bp.n_vrows * 64 * 8;
-        if (bp.n_vrows > (1u << 24) || words * 4 > b.size() - off) return fail(CW_EIO, "tape bit program truncated");
-        bp.recs.assign((size_t)words + 3 * 64 * 8, 0);           // + 3 empty vrows: the kernel streams records 3 ahead
+        const uint64_t words = (uint64_t)bp.n_vrows * 64 * 4;
+        if (bp.n_vrows > (1u << 24) || (words + c->n_signals) * 4 > b.size() - off) return fail(CW_EIO, "tape bit program truncated");
+        bp.recs.resize((size_t)words);
         memcpy(bp.recs.data(), b.data() + off, (size_t)words * 4);
         off += (size_t)words * 4;
-        if (const char *why = cwbits::validate(bp, c->n_signals)) return fail(CW_EIO, std::string("tape: ") + why);
-        if (bp.n_slots >= (1ull << 25)) return fail(CW_EIO, "tape: bit program too large");
+        bp.sig_slot.resize(c->n_signals);
+        memcpy(bp.sig_slot.data(), b.data() + off, (size_t)c->n_signals * 4);
+        off += (size_t)c->n_signals * 4;
+        if (const char *why = cwbits::validate(bp, c->n_signals, c->n_inputs)) return fail(CW_EIO, std::string("tape: ") + why);
         c->has_bits = true;
     }
     // hash map as generate_hash_map builds it (c_code_generator.rs:575-587); replaced by the .dat's if given
@@ -803,7 +805,9 @@ struct cw_batch {
     uint32_t n_groups = 0;
     uint32_t *d_brecs = nullptr;                      // the gate program
     uint32_t *d_erecs = nullptr, *d_wchunk = nullptr, *d_wterms = nullptr, *d_wctab = nullptr, *d_wrow = nullptr;
-    uint32_t n_evrows = 0, n_wchunks = 0;
+    uint32_t *d_ichunk = nullptr, *d_iterms = nullptr, *d_itab = nullptr, *d_irow = nullptr, *d_sigslot = nullptr;
+    uint32_t n_ichunks = 0;
+    uint32_t n_evrows = 0, n_wchunks = 0, bits_steps = 0, bits_width = 64;
     // instances whose inputs are not all 0/1 (or that tripped an assertion gate) are re-run by the 256-bit schedule
     cw_batch *fb = nullptr;                           // side batch (classic variant) holding them
     std::vector<uint32_t> fb_inst;                    // side-batch position -> instance
@@ -829,7 +833,8 @@ extern "C" void cw_batch_free(cw_batch *b) {
     hipSetDevice(b->device);
     hipStreamSynchronize(b->stream);
     if (b->fb) cw_batch_free(b->fb);
-    void *bptrs[] = {b->d_T, b->d_fbmask, b->d_brecs, b->d_erecs, b->d_wchunk, b->d_wterms, b->d_wctab, b->d_wrow};
+    void *bptrs[] = {b->d_T, b->d_fbmask, b->d_brecs, b->d_erecs, b->d_wchunk, b->d_wterms, b->d_wctab, b->d_wrow,
+                     b->d_ichunk, b->d_iterms, b->d_itab, b->d_irow, b->d_sigslot};
     for (void *p : bptrs)
         if (p) hipFree(p);
     void *ptrs[] = {b->d_V, b->d_rows, b->d_stream_off, b->d_extras, b->d_extra_off, b->d_terms, b->d_term_off, b->d_lconsts, b->d_consts, b->d_w2s, b->d_status, b->d_first_bad,
@@ -1075,7 +1080,7 @@ extern "C" int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *
 extern "C" int cw_batch_bitmode(const cw_batch *b) { return b && b->bitmode; }
 extern "C" uint32_t cw_batch_size(const cw_batch *b) { return b->batch; }
 extern "C" uint32_t cw_batch_strands(const cw_batch *b) { return b->var ? b->var->n_strands : 0; }
-extern "C" uint32_t cw_batch_lanes(const cw_batch *b) { return b->lanes; }
+extern "C" uint32_t cw_batch_lanes(const cw_batch *b) { return b->bitmode ? b->bits_width : b->lanes; }
 
 static int ensure_host_staging(cw_batch *b) {
     size_t n = (size_t)b->batch * b->c->n_inputs;
@@ -1366,19 +1371,37 @@ static int bits_batch_setup(cw_batch *b) {
     if (e != hipSuccess)
         return fail(CW_EDEVICE, "hipMalloc of the bit table failed (" + std::to_string(b->t_bytes) + " bytes): " + hipGetErrorString(e));
     BTRY(hipMalloc((void **)&b->d_fbmask, (size_t)b->n_groups * 8));
-    BTRY(upload(&b->d_brecs, bp.recs, b->stream));
+    {
+        std::vector<uint32_t> dev;
+        b->bits_steps = cwbits::device_stream(bp, dev);
+        BTRY(upload(&b->d_brecs, dev, b->stream));
+        BTRY(hipStreamSynchronize(b->stream));                       // `dev` goes out of scope
+    }
+    // instances per wave: small batches are spread over more CUs by giving every group of 64 instances to 2 or 4
+    // independent waves (each evaluates the whole program on its 32 / 16 bits of every mask)
+    b->bits_width = b->n_groups * 4 <= 512 ? 16 : b->n_groups * 2 <= 512 ? 32 : 64;
+    if (const char *ev = getenv("CW_BITS_WIDTH")) {
+        const int w = atoi(ev);
+        if (w == 16 || w == 32 || w == 64) b->bits_width = (uint32_t)w;
+    }
     BTRY(upload(&b->d_w2s, c->w2s, b->stream));
+    BTRY(upload(&b->d_sigslot, bp.sig_slot, b->stream));
     BTRY(hipMalloc((void **)&b->d_status, (size_t)b->Bp * 4));
     BTRY(hipMalloc((void **)&b->d_first_bad, (size_t)b->Bp * 4));
     if (c->n_constraints) {
         uint32_t tpc = 256;
         if (const char *ev = getenv("CW_R1CS_TERMS")) tpc = (uint32_t)std::max(8, atoi(ev));
-        cwbits::R1Plan p = cwbits::build_r1cs(c->r_ptr, c->r_slot, c->r_cc, c->r_cctab, c->r_orig, c->q.w, tpc);
+        cwbits::R1Plan p = cwbits::build_r1cs(c->r_ptr, c->r_slot, c->r_cc, c->r_cctab, c->r_orig, bp.sig_slot, c->q.w, tpc);
         BTRY(upload(&b->d_erecs, p.erecs, b->stream));
         BTRY(upload(&b->d_wchunk, p.chunk, b->stream));
         BTRY(upload(&b->d_wterms, p.terms, b->stream));
         BTRY(upload(&b->d_wctab, p.ctab, b->stream));
         BTRY(upload(&b->d_wrow, p.row_orig, b->stream));
+        BTRY(upload(&b->d_ichunk, p.ichunk, b->stream));
+        BTRY(upload(&b->d_iterms, p.iterms, b->stream));
+        BTRY(upload(&b->d_itab, p.itab, b->stream));
+        BTRY(upload(&b->d_irow, p.irow_orig, b->stream));
+        b->n_ichunks = p.n_ichunks;
         BTRY(hipStreamSynchronize(b->stream));                       // the plan goes out of scope
         b->n_evrows = p.n_evrows;
         b->n_wchunks = p.n_chunks;
@@ -1395,8 +1418,8 @@ static int bits_run(cw_batch *b, const void *in) {
     cw_circuit *c = b->c;
     const cwbits::Program &bp = c->bits;
     BTRY(cwk_bits_init(b->stream, b->d_T, bp.n_slots, b->n_groups, b->d_fbmask, b->d_status, b->d_first_bad, b->Bp));
-    BTRY(cwk_bits_ingest(b->stream, in, b->d_T, bp.n_slots, cwbits::SIG_BASE + c->input_start, c->n_inputs, b->batch, b->d_fbmask));
-    BTRY(cwk_bits_eval(b->stream, b->d_brecs, bp.n_vrows, bp.ring, b->d_T, bp.n_slots, b->n_groups, b->d_fbmask));
+    BTRY(cwk_bits_ingest(b->stream, in, b->d_T, bp.n_slots, cwbits::IN_BASE, c->n_inputs, b->batch, b->d_fbmask));
+    BTRY(cwk_bits_eval(b->stream, b->d_brecs, b->bits_steps, bp.ring, b->d_T, bp.n_slots, b->n_groups, b->bits_width, b->d_fbmask));
     b->resolved = false;
     b->checked = false;
     return CW_OK;
@@ -1488,7 +1511,8 @@ extern "C" int cw_check_r1cs(cw_batch *b) {
     HIPCHK(hipSetDevice(b->device));
     if (b->bitmode) {
         HIPCHK(cwk_bits_r1cs(b->stream, b->d_erecs, b->n_evrows, b->d_wchunk, b->n_wchunks, b->d_wterms, b->d_wctab, b->d_wrow,
-                             b->d_T, c->bits.n_slots, b->n_groups, b->batch, b->d_status, b->d_first_bad, c->P));
+                             b->d_ichunk, b->n_ichunks, b->d_iterms, b->d_itab, b->d_irow, b->d_T, c->bits.n_slots, b->n_groups,
+                             b->batch, b->d_status, b->d_first_bad, c->P));
         b->checked = true;
         if (b->resolved && b->fb) return cw_check_r1cs(b->fb);       // the side batch was already computed: check it too
         return CW_OK;
@@ -1549,7 +1573,7 @@ extern "C" int cw_get_witness(cw_batch *b, uint32_t instance, uint8_t *out) {
     if (b->bitmode) {
         if (int rc = bits_resolve(b)) return rc;
         if (b->fb_index[instance] >= 0) return cw_get_witness(b->fb, (uint32_t)b->fb_index[instance], out);
-        HIPCHK(cwk_bits_gather(b->stream, b->d_T, c->bits.n_slots, b->d_w2s, c->n_witness, instance, 1, b->d_gather));
+        HIPCHK(cwk_bits_gather(b->stream, b->d_T, c->bits.n_slots, b->d_w2s, b->d_sigslot, c->n_witness, instance, 1, b->d_gather));
     } else
     HIPCHK(cwk_gather(b->stream, b->d_V, b->d_w2s, c->n_witness, b->Bp, instance, b->d_gather));
     HIPCHK(hipMemcpyAsync(out, b->d_gather, (size_t)c->n_witness * 32, hipMemcpyDeviceToHost, b->stream));
@@ -1580,7 +1604,7 @@ extern "C" int cw_get_witnesses(cw_batch *b, uint32_t first, uint32_t count, uin
     for (uint32_t done = 0; done < count; done += per) {
         const uint32_t n = std::min(per, count - done);
         if (b->bitmode)
-            HIPCHK(cwk_bits_gather(b->stream, b->d_T, c->bits.n_slots, b->d_w2s, c->n_witness, first + done, n, b->d_bulk));
+            HIPCHK(cwk_bits_gather(b->stream, b->d_T, c->bits.n_slots, b->d_w2s, b->d_sigslot, c->n_witness, first + done, n, b->d_bulk));
         else
             HIPCHK(cwk_gather_many(b->stream, b->d_V, b->d_w2s, c->n_witness, b->Bp, first + done, n, b->d_bulk));
         HIPCHK(hipMemcpyAsync(out + (size_t)done * row, b->d_bulk, (size_t)n * row, hipMemcpyDeviceToHost, b->stream));
@@ -1606,7 +1630,7 @@ extern "C" int cw_get_public_device(cw_batch *b, void *d_out) {
     HIPCHK(hipSetDevice(b->device));
     if (b->bitmode) {
         if (int rc = bits_resolve(b)) return rc;
-        HIPCHK(cwk_bits_gather(b->stream, b->d_T, c->bits.n_slots, b->d_w2s + 1, np, 0, b->batch, d_out));
+        HIPCHK(cwk_bits_gather(b->stream, b->d_T, c->bits.n_slots, b->d_w2s + 1, b->d_sigslot, np, 0, b->batch, d_out));
         if (!b->fb_inst.empty()) {
             void *tmp = nullptr;
             const size_t prow = (size_t)np * 32;
@@ -1652,7 +1676,7 @@ extern "C" int cw_get_signal(cw_batch *b, uint32_t instance, uint32_t slot, uint
         if (int rc = bits_resolve(b)) return rc;
         if (b->fb_index[instance] >= 0) return cw_get_signal(b->fb, (uint32_t)b->fb_index[instance], slot, out);
         uint64_t m = 0;
-        HIPCHK(hipMemcpy(&m, b->d_T + (size_t)(instance >> 6) * b->c->bits.n_slots + cwbits::SIG_BASE + slot, 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&m, b->d_T + (size_t)(instance >> 6) * b->c->bits.n_slots + b->c->bits.sig_slot[slot], 8, hipMemcpyDeviceToHost));
         memset(out, 0, 32);
         out[0] = (uint8_t)((m >> (instance & 63)) & 1);
         return CW_OK;

@@ -43,6 +43,14 @@ class Unsupported(Exception):
     pass
 
 
+class _Wide:
+    """a temporary outside the domains (only an error if it reaches a signal or a run-time check)"""
+    __slots__ = ()
+
+
+_WIDE = _Wide()
+
+
 # ---- truth-table helpers ------------------------------------------------------------------------------------
 # A BoolFn is (leaves, tt): leaves = ascending tuple of node ids (len <= 3), tt = 2^len bits, bit m = value for the
 # assignment whose bit j gives leaves[j].
@@ -740,6 +748,47 @@ class _Blaster:
         else:
             self.net.asserts.append(n)
 
+    def step(self, o, x, y, steal):
+        """one flat operator on abstract values (temporaries)"""
+        if o == O.COPY:
+            return x
+        if o == O.NEG:
+            return self.mul(-1, x)
+        if y is None:
+            raise Unsupported("operator %s" % O.NAMES[o])
+        if o == O.ADD or o == O.SUB:
+            r = self.add(x, y, 1 if o == O.ADD else -1, steal)
+        elif o == O.MUL:
+            r = self.mul(x, y)
+        elif o == O.SHL:
+            r = self.mul(1 << self.shift_amount(y), x)
+        elif o == O.SHR:
+            k = self.shift_amount(y)
+            b = self.to_bv(x)
+            r = BV(b.bits[k:] if k < len(b.bits) else [((), 0)])
+        elif o == O.BAND:
+            if type(y) is int and y >= 0 and type(x) is not int:
+                b = self.to_bv(x)
+                bits = [f for k, f in enumerate(b.bits) if k < y.bit_length()]
+                r = BV([f if (y >> k) & 1 else ((), 0) for k, f in enumerate(bits)] or [((), 0)])
+            elif type(x) is int and x >= 0 and type(y) is not int:
+                b = self.to_bv(y)
+                bits = [f for k, f in enumerate(b.bits) if k < x.bit_length()]
+                r = BV([f if (x >> k) & 1 else ((), 0) for k, f in enumerate(bits)] or [((), 0)])
+            else:
+                r = self.bitwise(x, y, 8)
+        elif o == O.BOR:
+            r = self.bitwise(x, y, 14)
+        elif o == O.BXOR:
+            r = self.bitwise(x, y, 6)
+        else:
+            raise Unsupported("operator %s" % O.NAMES[o])
+        if type(r) is BV and len(r.bits) == 1:
+            r = r.bits[0]
+            if not r[0]:
+                r = r[1] & 1
+        return r
+
     # ---- main loop ------------------------------------------------------------------------------------------------
     def run(self):
         fc = self.fc
@@ -774,54 +823,36 @@ class _Blaster:
 
         ADD, SUB, MUL, NEG, COPY = O.ADD, O.SUB, O.MUL, O.NEG, O.COPY
         SHL, SHR, BAND, BOR, BXOR = O.SHL, O.SHR, O.BAND, O.BOR, O.BXOR
+        WIDE = _WIDE
         for i in range(n):
             o = op[i]
             if o == O.RUN:
                 continue
             x = rd(ak[i], av[i])
+            # a temporary the domains cannot express (field-sized weights, divisions, ...) only matters if it reaches a
+            # signal or a run-time check: dead helper computations (sums that exist for a constraint only) are common
+            if dk[i] == K_TMP and o != O.ASSERT_EQ:
+                y0 = rd(bk[i], bv_[i]) if bk[i] != K_NONE else None
+                if x is WIDE or y0 is WIDE:
+                    tmp[dv[i]] = WIDE
+                    continue
+                try:
+                    r = self.step(o, x, y0, ak[i] == K_TMP and uses[av[i]] == 1 and type(x) is Lin and x.own == av[i])
+                except Unsupported:
+                    r = WIDE
+                if type(r) is Lin and r.own is None:
+                    r.own = dv[i]
+                tmp[dv[i]] = r
+                continue
+            if x is WIDE or (bk[i] != K_NONE and rd(bk[i], bv_[i]) is WIDE):
+                raise Unsupported("a value outside the boolean/small-integer domains reaches a signal or a check")
             if o == COPY:
                 r = x
             elif o == O.ASSERT_EQ:
                 self.assert_eq(x, rd(bk[i], bv_[i]))
                 continue
-            elif o == NEG:
-                r = self.mul(-1, x)
             else:
-                if bk[i] == K_NONE:
-                    raise Unsupported("operator %s" % O.NAMES[o])
-                y = rd(bk[i], bv_[i])
-                if o == ADD or o == SUB:
-                    steal = ak[i] == K_TMP and uses[av[i]] == 1 and type(x) is Lin and x.own == av[i]
-                    r = self.add(x, y, 1 if o == ADD else -1, steal)
-                elif o == MUL:
-                    r = self.mul(x, y)
-                elif o == SHL:
-                    r = self.mul(1 << self.shift_amount(y), x)
-                elif o == SHR:
-                    k = self.shift_amount(y)
-                    b = self.to_bv(x)
-                    r = BV(b.bits[k:] if k < len(b.bits) else [((), 0)])
-                elif o == BAND:
-                    if type(y) is int and y >= 0 and type(x) is not int:
-                        b = self.to_bv(x)
-                        bits = [f for k, f in enumerate(b.bits) if k < y.bit_length()]
-                        r = BV([f if (y >> k) & 1 else ((), 0) for k, f in enumerate(bits)] or [((), 0)])
-                    elif type(x) is int and x >= 0 and type(y) is not int:
-                        b = self.to_bv(y)
-                        bits = [f for k, f in enumerate(b.bits) if k < x.bit_length()]
-                        r = BV([f if (x >> k) & 1 else ((), 0) for k, f in enumerate(bits)] or [((), 0)])
-                    else:
-                        r = self.bitwise(x, y, 8)
-                elif o == BOR:
-                    r = self.bitwise(x, y, 14)
-                elif o == BXOR:
-                    r = self.bitwise(x, y, 6)
-                else:
-                    raise Unsupported("operator %s" % O.NAMES[o])
-            if type(r) is BV and len(r.bits) == 1:
-                r = r.bits[0]
-                if not r[0]:
-                    r = r[1] & 1
+                r = self.step(o, x, rd(bk[i], bv_[i]) if bk[i] != K_NONE else None, False)
             if dk[i] == K_SIG:
                 # every signal must be a bit in bit mode
                 if type(r) is int:

@@ -1,21 +1,27 @@
-"""hip_elements bit-plane lowering, part 2: gate network (bitblast.BitNet) -> the program of `cw_bits_kernel`.
+"""hip_elements bit-plane lowering, part 2: gate network (bitblast.BitNet) -> the program of `cw_bits_eval_kernel`.
 
-Execution model (csrc/cw_bits.hip).  One wave evaluates the whole network for ONE group of 64 instances; a value is a
-64-bit mask (bit i = the value in instance i).  The program is a sequence of VROWS; in a vrow every lane evaluates one
-3-input gate (any truth table) on three operand masks and writes the result mask
-  * to the wave's LDS RING (entry `vrow mod R`, lane) — where the next R-1 vrows find it,
-  * to up to four slots of the group's BIT TABLE in HBM (`T[group][slot]`, 8 bytes each): the signals this value is
-    (a `x <== y` copy is one more destination, never a gate) and, if some consumer is R or more vrows away, a temp slot.
-Operand kinds: PREV (lane j of the previous vrow's result, read with ds_bpermute), RING (entry written 2..R-1 vrows
-ago), GLOBAL (bit-table slot: inputs, constants, values older than the ring).  Ring/global operands of vrow v+1 are
-requested while vrow v computes; PREV operands after it.  There are no barriers: one wave, in-order LDS and in-order
-vector memory make every read-after-write of the rules above safe by construction.
+Execution model (csrc/cw_bits.hip).  One wave evaluates the whole network for ONE group of instances; a value is a
+mask (bit i = the value in instance i of the group).  The program is a sequence of VROWS; in a vrow every LANE does
+one of
+  * GATE   any 3-input boolean function (8-bit truth table) of three masks read from the wave's LDS RING,
+  * LOAD   a mask read from the group's BIT TABLE in HBM (main inputs; values that left the ring),
+and writes the result mask to ring entry (vrow mod R, lane) and, if the value is a signal (or must be re-loaded later),
+to ITS slot of the bit table `T[group][slot]`.  Ring operands of vrow v+1 are requested while vrow v computes, so a
+consumer sits at least TWO vrows after its producer and at most R-1; the bit-table value of a LOAD lane is requested
+two vrows ahead.  No barriers, no data-dependent branches: one wave, in-order LDS, in-order vector memory.
 
-Bit-table slots: 0 = constant 0, 1 = constant 1 (all ones), 2 = reserved, signal s = SIG_BASE + s, then temps.
+Signals that are copies of one another (`a.in <== b.out`: ~85 % of the signals of a circomlib circuit at --O0) are
+the SAME value of the network: they share one slot.  `sig_slot[s]` maps every signal to its slot (egress and the
+R1CS check read through it); a copy costs nothing at run time.
+Bit-table slots: 0 = constant 0, 1 = constant 1 (all ones), 2 = reserved, main input k = IN_BASE + k, then one slot per
+distinct signal value in the order the program stores them, then temps.
 
-Scheduling: list scheduling of the gates into vrows of 64 (priority = longest path to a sink), so the vrow count
-approaches max(depth, gates / 64).  Lanes of a vrow are sorted by their first destination slot (consecutive
-signals of a component are written by neighbouring lanes: coalesced 8-byte stores).
+Record (4 x u32 per lane): a_off | b_off << 16,  c_off | tt << 16 | flags << 24,  g_off (LOAD lanes, else NONE),
+d_off (byte offset of the destination slot, NONE = 0xFFFFFFFF: dropped by the buffer bounds check).
+
+Scheduling: list scheduling into vrows of 64 lanes, priority = longest path to a sink; a value whose ring entry has
+expired (or a main input) is re-loaded by a LOAD lane that the scheduler inserts on demand.  The vrow count
+approaches max(2 * depth, operations / 64).
 """
 from __future__ import annotations
 
@@ -25,11 +31,11 @@ import numpy as np
 
 from .bitblast import BitNet
 
-SIG_BASE = 3
-SLOT_ZERO, SLOT_ONE, SLOT_RSV = 0, 1, 2
-K_GLOBAL, K_RING, K_PREV = 0, 1, 2
-F_ASSERT = 1 << 8
-DEFAULT_RING = 128
+IN_BASE = 3                   # slot of main input 0
+NONE = 0xFFFFFFFF
+F_ASSERT = 1
+DEFAULT_RING = 64
+LATENCY = 2                   # vrows between a producer and its first consumer
 
 
 class BitTape:
@@ -37,7 +43,8 @@ class BitTape:
         self.ring = DEFAULT_RING        # R: LDS ring entries (vrows); LDS bytes = R * 512
         self.n_slots = 0                # bit-table slots per group
         self.n_vrows = 0
-        self.recs = None                # uint32 [n_vrows * 64, 8]: a, b, c, tt|flags, d0, d1, d2, d3
+        self.recs = None                # uint32 [n_vrows * 64, 4]
+        self.sig_slot = None            # uint32 [n_signals]: slot holding each signal
         self.n_signals = 0
         self.n_inputs = 0
         self.input_start = 0
@@ -45,59 +52,32 @@ class BitTape:
 
 
 def lower_bits(net: BitNet, fc, ring: int = DEFAULT_RING) -> BitTape:
+    assert 8 <= ring <= 128 and ring & (ring - 1) == 0
     n_nodes = len(net.tt)
     tt, A, B, C = net.tt, net.a, net.b, net.c
     n_signals = fc.n_signals
     sig_node = net.sig_node
-    # ---- destinations of every node: the signals that alias it ---------------------------------------------------
-    dests = [None] * n_nodes
-    order = np.argsort(sig_node, kind="stable")
-    sn_sorted = sig_node[order]
-    starts = np.flatnonzero(np.r_[True, sn_sorted[1:] != sn_sorted[:-1]])
-    ends = np.r_[starts[1:], len(order)]
-    for s0, s1 in zip(starts.tolist(), ends.tolist()):
-        dests[int(sn_sorted[s0])] = order[s0:s1].tolist()
-    input_sig = {nid: s for s, nid in net.input_node.items()}
-
-    # ---- records: one per gate (+ more for values with > 4 destinations, + copies of inputs / constants) ---------------
-    # rec = [node (value computed), tt, a, b, c (operand NODES), dest slots list, flags, primary?]
-    recs = []
-    prim_of = {}                     # node -> index of its primary record
-
-    def add_recs(node, t8, a, b, c, dlist, flags=0):
-        first = True
-        i = 0
-        while first or i < len(dlist):
-            r = [node, t8, a, b, c, dlist[i:i + 4], flags, first]
-            if first:
-                prim_of[node] = len(recs)
-            recs.append(r)
-            first = False
-            i += 4
-
-    for nid in range(n_nodes):
-        d = dests[nid] or []
-        t8 = tt[nid]
-        if nid <= 1:
-            # constants: slots 0/1 are initialised by the runtime; signals equal to a constant are written by gates
-            if d:
-                for i in range(0, len(d), 4):
-                    recs.append([-1, 0xFF if nid else 0x00, 0, 0, 0, [SIG_BASE + s for s in d[i:i + 4]], 0, False])
-            continue
-        if t8 > 0xFF:
-            # main input: its own slot is written by the ingest kernel; further aliases are copies (identity gates)
-            own = input_sig[nid]
-            rest = [s for s in d if s != own]
-            for i in range(0, len(rest), 4):
-                recs.append([-1, 0xAA, nid, 0, 0, [SIG_BASE + s for s in rest[i:i + 4]], 0, False])
-            continue
-        add_recs(nid, t8, A[nid], B[nid], C[nid], [SIG_BASE + s for s in d])
-    for a in net.asserts:
-        recs.append([-1, 0xAA, a, 0, 0, [], F_ASSERT, False])
-    n_recs = len(recs)
-
-    # ---- list scheduling --------------------------------------------------------------------------------------------
+    input_k = {nid: s - fc.main_input_start for s, nid in net.input_node.items()}
     is_gate = [0 <= t <= 0xFF and i > 1 for i, t in enumerate(tt)]
+    is_signal = np.zeros(n_nodes, dtype=bool)
+    is_signal[sig_node] = True
+    # gates that no signal and no assertion depends on (helper computations of the witness code that only fed a
+    # constraint) are not evaluated
+    live = is_signal.tolist()
+    for a in net.asserts:
+        live[a] = True
+    for nid in range(n_nodes - 1, 1, -1):
+        if live[nid] and is_gate[nid]:
+            live[A[nid]] = live[B[nid]] = live[C[nid]] = True
+    is_gate = [g and live[i] for i, g in enumerate(is_gate)]
+
+    # ---- operations: 'G' gate, 'A' assertion gate, 'L' load (created on demand) ------------------------------------
+    o_kind, o_node, o_tt, o_src, o_pri = [], [], [], [], []
+
+    def new_op(kind, node, t8, src, pri):
+        o_kind.append(kind); o_node.append(node); o_tt.append(t8); o_src.append(src); o_pri.append(pri)
+        return len(o_kind) - 1
+
     height = [0] * n_nodes
     for nid in range(n_nodes - 1, 1, -1):
         if not is_gate[nid]:
@@ -106,112 +86,179 @@ def lower_bits(net: BitNet, fc, ring: int = DEFAULT_RING) -> BitTape:
         for o in (A[nid], B[nid], C[nid]):
             if is_gate[o] and height[o] < h:
                 height[o] = h
-    consumers = [[] for _ in range(n_nodes)]      # node -> records waiting for it
-    pending = [0] * n_recs
-    for ri, r in enumerate(recs):
-        ops = {o for o in (r[2], r[3], r[4]) if is_gate[o]}
-        pending[ri] = len(ops)
-        for o in ops:
-            consumers[o].append(ri)
-    ready = []                                      # heap of (-priority, rec index)
-    for ri, r in enumerate(recs):
-        if pending[ri] == 0:
-            heapq.heappush(ready, (-(height[r[0]] if r[0] >= 0 and r[7] else -1), ri))
-    vrow_of_node = [-1] * n_nodes                  # gates: vrow of the primary record
-    lane_of_node = [0] * n_nodes
+    prim = {}
+    for nid in range(2, n_nodes):
+        if is_gate[nid]:
+            prim[nid] = new_op('G', nid, tt[nid], [o for o in (A[nid], B[nid], C[nid]) if o > 1], height[nid] + 1.0)
+    for a in net.asserts:
+        new_op('A', -1, 0xAA, [a], 0.5)
+    n_static = len(o_kind)
+
+    # ---- list scheduling with on-demand loads ---------------------------------------------------------------------------
+    consumers = [[] for _ in range(n_nodes)]
+    pending = [0] * n_static
+    for oi in range(n_static):
+        ops = {x for x in o_src[oi] if is_gate[x]}
+        pending[oi] = len(ops)
+        for x in ops:
+            consumers[x].append(oi)
+    heap = []
+    seq = 0
+    for oi in range(n_static):
+        if pending[oi] == 0:
+            heap.append((-o_pri[oi], seq, oi))
+            seq += 1
+    heapq.heapify(heap)
+    buckets = {}
+    copy_slot = {}                      # node -> vrow of its freshest ring copy
+    copy_op = {}                        # node -> op that wrote that copy
+    src_ops = {}                        # op -> ops whose ring entries it reads
+    need_home = set()                   # gates that are no signal but must be stored (re-loaded later)
+    prod_slot = {}                      # gate node -> vrow of its record
     vrows = []
-    done = 0
-    while done < n_recs:
-        take = []
-        while ready and len(take) < 64:
-            take.append(heapq.heappop(ready)[1])
-        assert take, "scheduler stalled (cyclic network?)"
-        v = len(vrows)
-        # lanes sorted by first destination slot (coalesced stores); records without one keep their order at the end
-        take.sort(key=lambda ri: (recs[ri][5][0] if recs[ri][5] else 1 << 40))
-        vrows.append(take)
-        newly = []
-        for lane, ri in enumerate(take):
-            r = recs[ri]
-            if r[7]:
-                vrow_of_node[r[0]] = v
-                lane_of_node[r[0]] = lane
-                newly.append(r[0])
-        for nid in newly:
-            for ci in consumers[nid]:
+    placed = 0
+    total = n_static
+    n_loads = 0
+    carry_loads = []                    # loads that did not fit the vrow that asked for them
+    t = 0
+
+    def place_load(x, lanes, loading_now):
+        nonlocal total, n_loads
+        li = new_op('L', x, 0, [], 0.0)
+        total += 1
+        lanes.append(li)
+        copy_slot[x] = t
+        copy_op[x] = li
+        loading_now.add(x)
+        n_loads += 1
+        if is_gate[x] and not is_signal[x]:
+            need_home.add(x)
+
+    while placed < total:
+        for item in buckets.pop(t, ()):
+            heapq.heappush(heap, item)
+        lanes = []
+        loading_now = set()
+        for x in carry_loads[:64]:      # loads carried over from a full vrow go first
+            place_load(x, lanes, loading_now)
+        carry_loads = carry_loads[64:]
+        carry_set = set(carry_loads)
+        produced = []
+        while heap and len(lanes) < 64:
+            item = heapq.heappop(heap)
+            oi = item[2]
+            ok = True
+            retry = t + 1
+            for x in o_src[oi]:
+                c = copy_slot.get(x)
+                if c is None or t - c > ring - 1:
+                    ok = False
+                    if x in loading_now:
+                        pass
+                    elif len(lanes) < 63:
+                        place_load(x, lanes, loading_now)
+                    elif x not in carry_set:
+                        carry_loads.append(x)
+                        carry_set.add(x)
+                        if is_gate[x] and not is_signal[x]:
+                            need_home.add(x)
+                    if x in carry_set:
+                        retry = max(retry, t + 1 + LATENCY + len(carry_loads) // 64)
+                    retry = max(retry, t + LATENCY)
+                elif t - c < LATENCY:
+                    ok = False
+                    retry = max(retry, c + LATENCY)
+            if not ok:
+                # operands that would have left the ring by the time the op is retried are re-loaded now as well
+                # (otherwise two operands can keep expiring in turn); a LOAD lane reads the bit table two vrows ahead
+                # of its own vrow, so the value's store must be older than that
+                for x in o_src[oi]:
+                    c = copy_slot.get(x)
+                    if (c is not None and retry - c > ring - 1 and x not in loading_now and x not in carry_set
+                            and t - prod_slot.get(x, -1 << 30) >= LATENCY + 1):
+                        if len(lanes) < 63:
+                            place_load(x, lanes, loading_now)
+                        else:
+                            carry_loads.append(x)
+                            carry_set.add(x)
+                            if is_gate[x] and not is_signal[x]:
+                                need_home.add(x)
+                buckets.setdefault(retry, []).append(item)
+                continue
+            lanes.append(oi)
+            src_ops[oi] = [copy_op[x] for x in o_src[oi]]
+            if o_kind[oi] == 'G':
+                produced.append(oi)
+        for oi in produced:
+            x = o_node[oi]
+            prod_slot[x] = t
+            copy_slot[x] = t
+            copy_op[x] = oi
+            for ci in consumers[x]:
                 pending[ci] -= 1
                 if pending[ci] == 0:
-                    rr = recs[ci]
-                    heapq.heappush(ready, (-(height[rr[0]] if rr[0] >= 0 and rr[7] else -1), ci))
-        done += len(take)
+                    buckets.setdefault(t + LATENCY, []).append((-o_pri[ci], seq, ci))
+                    seq += 1
+        placed += len(lanes)
+        vrows.append(lanes)
+        t += 1
+        if not heap and not carry_loads and placed < total and not any(k >= t for k in buckets):
+            raise AssertionError("scheduler stalled")
     n_vrows = len(vrows)
 
-    # ---- operand kinds; which gates need a global temp slot --------------------------------------------------------------
-    far = set()
-    n_prev = n_ring = n_glob = 0
-    for v, take in enumerate(vrows):
-        for ri in take:
-            r = recs[ri]
-            for o in (r[2], r[3], r[4]):
-                if is_gate[o] and v - vrow_of_node[o] >= ring and not dests[o]:
-                    far.add(o)
-    home = {}
-    n_slots = SIG_BASE + n_signals
-    for nid in sorted(far, key=lambda x: (vrow_of_node[x], lane_of_node[x])):
-        home[nid] = n_slots
-        n_slots += 1
+    # ---- slots: constants, inputs, then stored values in program order (neighbouring lanes -> neighbouring slots) ----
+    n_in = fc.n_main_inputs
+    slot_of_node = {0: 0, 1: 1}
+    for nid, k in input_k.items():
+        slot_of_node[nid] = IN_BASE + k
+    n_slots = IN_BASE + n_in
+    slot_of_op = {}
+    lane_of_op = {}
+    for v, lanes in enumerate(vrows):
+        stored = [oi for oi in lanes if o_kind[oi] == 'G' and (is_signal[o_node[oi]] or o_node[oi] in need_home)]
+        rest = [oi for oi in lanes if not (o_kind[oi] == 'G' and (is_signal[o_node[oi]] or o_node[oi] in need_home))]
+        # stored values first, ordered by the first signal they are (signals of one component array then sit in
+        # neighbouring slots): one coalesced store per vrow
+        stored.sort(key=lambda oi: o_node[oi])
+        lanes[:] = stored + rest
+        for lane, oi in enumerate(lanes):
+            slot_of_op[oi] = v
+            lane_of_op[oi] = lane
+        for oi in stored:
+            slot_of_node[o_node[oi]] = n_slots
+            n_slots += 1
+    sig_slot = np.zeros(n_signals, dtype=np.uint32)
+    for s_ in range(n_signals):
+        sig_slot[s_] = slot_of_node[int(sig_node[s_])]
 
-    def node_slot(o):
-        if o <= 1:
-            return o
-        if not is_gate[o]:
-            return SIG_BASE + input_sig[o]
-        d = dests[o]
-        return SIG_BASE + d[0] if d else home[o]
-
-    out = np.zeros((n_vrows * 64, 8), dtype=np.uint32)
-    for v, take in enumerate(vrows):
-        for lane, ri in enumerate(take):
-            r = recs[ri]
+    out = np.zeros((n_vrows * 64, 4), dtype=np.uint32)
+    out[:, 2:] = NONE
+    for v, lanes in enumerate(vrows):
+        for lane, oi in enumerate(lanes):
             row = out[v * 64 + lane]
-            for j, o in enumerate((r[2], r[3], r[4])):
-                if is_gate[o]:
-                    dist = v - vrow_of_node[o]
-                    assert dist >= 1
-                    if dist == 1:
-                        row[j] = (K_PREV << 30) | (lane_of_node[o] * 4)
-                        n_prev += 1
-                    elif dist < ring:
-                        row[j] = (K_RING << 30) | ((vrow_of_node[o] % ring) * 512 + lane_of_node[o] * 8)
-                        n_ring += 1
-                    else:
-                        row[j] = (K_GLOBAL << 30) | (node_slot(o) * 8)
-                        n_glob += 1
-                else:
-                    row[j] = (K_GLOBAL << 30) | (node_slot(o) * 8)
-                    n_glob += 1 if o > 1 else 0
-            row[3] = r[1] | r[6]
-            dl = list(r[5])
-            if r[7] and r[0] in home:
-                dl.append(home[r[0]])
-            assert len(dl) <= 4 or not r[7]
-            if len(dl) > 4:                 # cannot happen: primary records carry <= 4 signal destinations + the temp
-                raise AssertionError
-            for j, s in enumerate(dl):
-                row[4 + j] = s * 8
-        # unused lanes: constant-0 gate without destination (all zero record)
-    # a primary record with 4 signal destinations AND a far temp slot would need 5 entries: handled by giving the temp
-    # slot to such nodes through an extra record is not needed — signal-aliased nodes use their signal slot as home.
+            kind = o_kind[oi]
+            offs = [0, 0, 0]
+            for j, po in enumerate(src_ops.get(oi, ())):
+                pv = slot_of_op[po]
+                assert LATENCY <= v - pv <= ring - 1
+                offs[j] = (pv % ring) * 512 + lane_of_op[po] * 8
+            row[0] = offs[0] | (offs[1] << 16)
+            row[1] = offs[2] | (o_tt[oi] << 16) | ((F_ASSERT if kind == 'A' else 0) << 24)
+            if kind == 'L':
+                row[2] = slot_of_node[o_node[oi]] * 8
+            elif kind == 'G' and o_node[oi] in slot_of_node:
+                row[3] = slot_of_node[o_node[oi]] * 8
     bt = BitTape()
     bt.ring = ring
     bt.n_slots = n_slots
     bt.n_vrows = n_vrows
     bt.recs = out
+    bt.sig_slot = sig_slot
     bt.n_signals = n_signals
-    bt.n_inputs = fc.n_main_inputs
+    bt.n_inputs = n_in
     bt.input_start = fc.main_input_start
-    bt.stats = {"vrows": n_vrows, "records": n_recs, "gates": int(sum(is_gate)), "fill": n_recs / (64.0 * n_vrows),
-                "prev_operands": n_prev, "ring_operands": n_ring, "global_operands": n_glob,
-                "temp_slots": n_slots - SIG_BASE - n_signals, "ring": ring, "depth": net.stats.get("depth"),
-                "asserts": len(net.asserts)}
+    kinds = {k: o_kind.count(k) for k in "GAL"}
+    bt.stats = {"vrows": n_vrows, "ops": total, "gates": kinds['G'], "loads": kinds['L'], "fill": total / (64.0 * n_vrows),
+                "slots": n_slots, "stored_values": n_slots - IN_BASE - n_in, "temp_values": len(need_home),
+                "ring": ring, "depth": net.stats.get("depth"), "asserts": len(net.asserts)}
     return bt

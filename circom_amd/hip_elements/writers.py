@@ -96,7 +96,7 @@ def write_tape(path, tapes, bittape=None):
                             stream_off | extra_off | term_off      ((n_strands+1) x u32 each)
                             rows n_rows x 4 x u32 | extras n_extras x u32 | terms n_terms x 4 x u32
             bit program     (if n_bit_programs, hip_elements/bitsched.py)  8 x u32: ring, n_vrows, n_slots lo, hi, 0, 0, 0, 0
-                            then n_vrows x 64 records of 8 x u32
+                            then n_vrows x 64 records of 4 x u32, then signal -> slot map n_signals x u32
     """
     if isinstance(tapes, Tape):
         tapes = [tapes]
@@ -129,6 +129,7 @@ def write_tape(path, tapes, bittape=None):
             assert bittape.n_signals == t0.n_signals
             f.write(struct.pack("<8I", bittape.ring, bittape.n_vrows, bittape.n_slots & 0xFFFFFFFF, bittape.n_slots >> 32, 0, 0, 0, 0))
             f.write(np.ascontiguousarray(bittape.recs, dtype="<u4").tobytes())
+            f.write(np.ascontiguousarray(bittape.sig_slot, dtype="<u4").tobytes())
 
 
 def _le_key(k: int) -> bytes:

@@ -14,7 +14,7 @@ from pathlib import Path
 import numpy as np
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "lib" / "libcircom_amd.so"
+LIB_PATH = Path(os.environ["CW_LIB"]).resolve() if os.environ.get("CW_LIB") else _HERE / "lib" / "libcircom_amd.so"   # CW_LIB: diagnostics builds
 
 ST_OK, ST_ASSERT_FAILED, ST_ARITH, ST_R1CS_FAILED = 0, 1, 2, 4
 

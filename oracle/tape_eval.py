@@ -317,18 +317,21 @@ def eval_tape(tape, inputs: dict):
                      tape.stream_off, tape.extras, tape.extra_off, tape.n_lds, tape.terms, tape.term_off, tape.lconsts)
 
 
-# ---- bit-plane program (circom_amd/hip_elements/bitsched.py), executed the way cw_bits_kernel does -------------------
-BK_GLOBAL, BK_RING, BK_PREV = 0, 1, 2
-BF_ASSERT = 1 << 8
-B_SIG_BASE = 3
+# ---- bit-plane program (circom_amd/hip_elements/bitsched.py), executed the way cw_bits_eval_kernel does ----------------
+B_NONE = 0xFFFFFFFF
+BF_ASSERT = 1
+B_IN_BASE = 3
 
 
-def eval_bits(recs, n_vrows: int, ring: int, n_slots: int, input_masks: dict, width: int = 1):
+def eval_bits(recs, n_vrows: int, ring: int, n_slots: int, input_masks: dict, width: int = 1, min_store_slot: int = 3):
     """Replays a bit-plane program on `width` instances at once (python ints as masks: bit i = instance i).
-    input_masks: bit-table slot -> mask of the main inputs.  Mirrors the kernel's timing: the ring / global operands
-    of vrow v+1 are fetched BEFORE vrow v writes its results; PREV operands are lanes of vrow v's result.
-    Raises ScheduleHazard when a read cannot be satisfied by the executor's rules.
-    Returns (bit table as list of masks, violation mask of the assertion gates)."""
+    input_masks: bit-table slot -> mask of the main inputs (slot B_IN_BASE + k for input k); records are 4 words
+    (bitsched.py).  Mirrors the kernel's timing:
+      * the ring operands of vrow v+1 are read BEFORE vrow v writes its ring entry,
+      * the bit-table value of a LOAD lane of vrow v+2 is read before vrow v stores its destinations,
+      * a record's result = LUT(a, b, c) | loaded value (gate lanes load nothing, load lanes carry table 0).
+    Raises ScheduleHazard when a read cannot be satisfied by these rules (entry not written yet / already reused,
+    slot never written).  Returns (bit table as list of masks, violation mask of the assertion gates)."""
     full = (1 << width) - 1
     T = [None] * n_slots
     T[0], T[1], T[2] = 0, full, 0
@@ -339,68 +342,67 @@ def eval_bits(recs, n_vrows: int, ring: int, n_slots: int, input_masks: dict, wi
     recs = [[int(x) for x in r] for r in recs]
     viol = 0
 
+    def ring_read(v, lane, off, used):
+        if off % 8 or off // 8 >= ring * 64:
+            raise ScheduleHazard("vrow %d lane %d: ring operand out of range" % (v, lane))
+        if used:
+            tag = ring_tag[off // 8]
+            if tag < 0 or tag > v - 2 or v - tag > ring - 1:
+                raise ScheduleHazard("vrow %d lane %d reads ring entry %d that is not a live older result (written by vrow %d)"
+                                     % (v, lane, off // 8, tag))
+        return ring_val[off // 8]
+
     def early(v):
         out = []
         for lane in range(64):
             r = recs[v * 64 + lane]
-            vals = []
-            for j in range(3):
-                w = r[j]
-                kind, off = w >> 30, w & 0x3FFFFFFF
-                if kind == BK_GLOBAL:
-                    if off % 8 or off // 8 >= n_slots:
-                        raise ScheduleHazard("vrow %d lane %d: global operand out of range" % (v, lane))
-                    x = T[off // 8]
-                    if x is None:
-                        raise ScheduleHazard("vrow %d lane %d reads bit slot %d before it is written" % (v, lane, off // 8))
-                    vals.append(x)
-                elif kind == BK_RING:
-                    if off % 8 or off // 8 >= ring * 64:
-                        raise ScheduleHazard("vrow %d lane %d: ring operand out of range" % (v, lane))
-                    tag = ring_tag[off // 8]
-                    if tag < 0 or tag > v - 2 or v - tag >= ring:
-                        raise ScheduleHazard("vrow %d lane %d reads a ring entry that is not a live older result" % (v, lane))
-                    vals.append(ring_val[off // 8])
-                elif kind == BK_PREV:
-                    if off % 4 or off // 4 >= 64 or v == 0:
-                        raise ScheduleHazard("vrow %d lane %d: bad PREV lane" % (v, lane))
-                    vals.append(None)
-                else:
-                    raise ScheduleHazard("vrow %d lane %d: unknown operand kind" % (v, lane))
-            out.append(vals)
+            t = (r[1] >> 16) & 0xFF
+            # which operands does the table depend on?  (unused fields may point anywhere)
+            dep = [any(((t >> m) & 1) != ((t >> (m ^ (1 << j))) & 1) for m in range(8)) for j in range(3)]
+            out.append([ring_read(v, lane, r[0] & 0xFFFF, dep[0]), ring_read(v, lane, r[0] >> 16, dep[1]),
+                        ring_read(v, lane, r[1] & 0xFFFF, dep[2])])
+        return out
+
+    def gload(v):
+        out = []
+        for lane in range(64):
+            g = recs[v * 64 + lane][2]
+            if g == B_NONE:
+                out.append(0)
+                continue
+            if g % 8 or g // 8 >= n_slots:
+                raise ScheduleHazard("vrow %d lane %d: load slot out of range" % (v, lane))
+            if T[g // 8] is None:
+                raise ScheduleHazard("vrow %d lane %d loads bit slot %d before it is written" % (v, lane, g // 8))
+            out.append(T[g // 8])
         return out
 
     fetched = early(0) if n_vrows else []
-    prev = [0] * 64
+    gv = [gload(0) if n_vrows else None, gload(1) if n_vrows > 1 else None]
     for v in range(n_vrows):
-        nxt = early(v + 1) if v + 1 < n_vrows else None
+        g2 = gload(v + 2) if v + 2 < n_vrows else None          # before this vrow's stores
+        nxt = early(v + 1) if v + 1 < n_vrows else None         # before this vrow's ring write
         res = [0] * 64
         for lane in range(64):
             r = recs[v * 64 + lane]
-            ops = fetched[lane]
-            for j in range(3):
-                if ops[j] is None:
-                    ops[j] = prev[(r[j] & 0x3FFFFFFF) // 4]
-            a, b, c = ops
-            t = r[3] & 0xFF
+            a, b, c = fetched[lane]
+            t = (r[1] >> 16) & 0xFF
             na, nb_ = full ^ a, full ^ b
             lo = ((na & nb_) if t & 1 else 0) | ((a & nb_) if t & 2 else 0) | ((na & b) if t & 4 else 0) | ((a & b) if t & 8 else 0)
             hi = ((na & nb_) if t & 16 else 0) | ((a & nb_) if t & 32 else 0) | ((na & b) if t & 64 else 0) | ((a & b) if t & 128 else 0)
-            x = (lo & (full ^ c)) | (hi & c)
+            x = ((lo & (full ^ c)) | (hi & c)) | gv[0][lane]
             res[lane] = x
-            if r[3] & BF_ASSERT:
+            if (r[1] >> 24) & BF_ASSERT:
                 viol |= x
         base = (v % ring) * 64
         for lane in range(64):
             ring_val[base + lane] = res[lane]
             ring_tag[base + lane] = v
-            r = recs[v * 64 + lane]
-            for j in range(4, 8):
-                d = r[j]
-                if d:
-                    if d % 8 or d // 8 >= n_slots or d // 8 < 3:
-                        raise ScheduleHazard("vrow %d lane %d: destination out of range" % (v, lane))
-                    T[d // 8] = res[lane]
-        prev = res
+            d = recs[v * 64 + lane][3]
+            if d != B_NONE:
+                if d % 8 or d // 8 >= n_slots or d // 8 < min_store_slot:
+                    raise ScheduleHazard("vrow %d lane %d: destination out of range" % (v, lane))
+                T[d // 8] = res[lane]
         fetched = nxt
+        gv = [gv[1], g2]
     return T, viol

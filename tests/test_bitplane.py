@@ -65,6 +65,27 @@ def BadBit(c, n):
         c.enforce(out[k], a[k] * b[k], runtime_check=False)
 
 
+@template
+def BadWeighted(c, n, big):
+    """out = a except that bit 2 is flipped when a0 & a1; the (long, linear) constraint sum w_k out_k === sum w_k a_k has
+    small weights (3^k: exact 64-bit path of the check) or field-sized ones (2^200 * 3^k: field path)"""
+    a = c.input("a", n)
+    out = c.output("out", n)
+    m = c.signal("m")
+    c.set(m, a[0] * a[1])
+    lhs = c.const(0)
+    rhs = c.const(0)
+    for k in range(n):
+        if k == 2:
+            c.hint(out[k], a[k] + m - 2 * a[k] * m)
+        else:
+            c.hint(out[k], a[k] + 0)
+        w = 3 ** k * ((1 << 200) if big else 1)
+        lhs = lhs + out[k] * w
+        rhs = rhs + a[k] * w
+    c.enforce(lhs, rhs, runtime_check=False)
+
+
 def _rand_bits(fc, n, seed):
     r = random.Random(seed)
     return [[r.randrange(2) for _ in range(fc.n_main_inputs)] for _ in range(n)]
@@ -80,6 +101,11 @@ def _masks(fc, rows, base=0):
     return {base + fc.main_input_start + k: sum((rows[i][k] & 1) << i for i in range(len(rows))) for k in range(fc.n_main_inputs)}
 
 
+def _in_masks(fc, rows):
+    """bit-table slot of main input k = IN_BASE + k"""
+    return {BS.IN_BASE + k: sum((rows[i][k] & 1) << i for i in range(len(rows))) for k in range(fc.n_main_inputs)}
+
+
 def test_gate_network_reproduces_the_flat_code():
     fc = flatten(Program(BitGadget(16)))
     net = BB.bitblast(fc)
@@ -92,35 +118,38 @@ def test_gate_network_reproduces_the_flat_code():
         assert [(val[int(net.sig_node[s])] >> i) & 1 for s in range(fc.n_signals)] == sig
 
 
-@pytest.mark.parametrize("ring", [2, 8, 128])
+@pytest.mark.parametrize("ring", [8, 16, 128])
 def test_scheduled_program_reproduces_the_flat_code(ring):
     fc = flatten(Program(BitGadget(16)))
     bt = BS.lower_bits(BB.bitblast(fc), fc, ring)
-    assert bt.n_slots >= BS.SIG_BASE + fc.n_signals
+    assert bt.n_slots < fc.n_signals           # copies share the slot of their source
     rows = _rand_bits(fc, 64, 2)
-    T, viol = eval_bits(bt.recs, bt.n_vrows, bt.ring, bt.n_slots, _masks(fc, rows, BS.SIG_BASE), 64)
+    T, viol = eval_bits(bt.recs, bt.n_vrows, bt.ring, bt.n_slots, _in_masks(fc, rows), 64, BS.IN_BASE + fc.n_main_inputs)
     assert viol == 0
     for i in (0, 5, 63):
         sig, _ = _flat(fc, rows[i])
-        assert [(T[BS.SIG_BASE + s] >> i) & 1 for s in range(fc.n_signals)] == sig
-    if ring == 2:
-        assert bt.stats["temp_slots"] > 0          # values older than the ring travel through the bit table
+        assert [(T[int(bt.sig_slot[s])] >> i) & 1 for s in range(fc.n_signals)] == sig
+    if ring == 8:
+        assert bt.stats["temp_values"] > 0          # values older than the ring travel through the bit table
 
 
 def test_replay_rejects_programs_that_break_the_executor_rules():
     fc = flatten(Program(BitGadget(8)))
     bt = BS.lower_bits(BB.bitblast(fc), fc, 8)
     rows = _rand_bits(fc, 4, 3)
-    m = _masks(fc, rows, BS.SIG_BASE)
+    m = _in_masks(fc, rows)
     recs = bt.recs.copy()
-    # a ring operand that points at the entry the CURRENT vrow is about to write (not yet a live older result)
+    # a ring operand that points at the entry the PREVIOUS vrow writes (one vrow is too close: the read is issued
+    # before that write)
     v = bt.n_vrows - 1
-    recs[v * 64, 0] = (BS.K_RING << 30) | ((v % bt.ring) * 512)
+    lane = next(l for l in range(64) if (int(recs[v * 64 + l, 1]) >> 16) & 0xFF)
+    recs[v * 64 + lane, 0] = ((v - 1) % bt.ring) * 512
+    recs[v * 64 + lane, 1] = (int(recs[v * 64 + lane, 1]) & 0xFFFF0000) | 0xAA0000
     with pytest.raises(ScheduleHazard):
         eval_bits(recs, bt.n_vrows, bt.ring, bt.n_slots, m, 4)
     recs = bt.recs.copy()
-    recs[0, 0] = (BS.K_GLOBAL << 30) | ((bt.n_slots - 1) * 8 if bt.n_slots > BS.SIG_BASE + fc.n_signals else (BS.SIG_BASE + 1) * 8)
-    with pytest.raises(ScheduleHazard):            # slot 1 of main (an output) is not written before vrow 0
+    recs[0, 2] = (bt.n_slots - 1) * 8              # the last stored value: not written before vrow 0
+    with pytest.raises(ScheduleHazard):
         eval_bits(recs, bt.n_vrows, bt.ring, bt.n_slots, m, 4)
 
 
@@ -130,7 +159,7 @@ def test_unprovable_assert_becomes_an_assertion_gate():
     assert net is not None and len(net.asserts) == 1
     bt = BS.lower_bits(net, fc, 8)
     rows = [[0, 0], [0, 1], [1, 0], [1, 1]]
-    T, viol = eval_bits(bt.recs, bt.n_vrows, bt.ring, bt.n_slots, _masks(fc, rows, BS.SIG_BASE), 4)
+    T, viol = eval_bits(bt.recs, bt.n_vrows, bt.ring, bt.n_slots, _in_masks(fc, rows), 4)
     assert viol == 0b0110
     for i, row in enumerate(rows):
         sig, failed = _flat(fc, row)
@@ -157,14 +186,14 @@ def test_sha256_one_block_bitplane_digest():
     bt = BS.lower_bits(net, fc)
     msgs = [b"abcdefgh", b"\x00" * 8, b"\xff" * 8, b"MI355X!!"]
     rows = [[(m[i // 8] >> (7 - i % 8)) & 1 for i in range(64)] for m in msgs]
-    T, viol = eval_bits(bt.recs, bt.n_vrows, bt.ring, bt.n_slots, _masks(fc, rows, BS.SIG_BASE), len(msgs))
+    T, viol = eval_bits(bt.recs, bt.n_vrows, bt.ring, bt.n_slots, _in_masks(fc, rows), len(msgs))
     assert viol == 0
     for i, m in enumerate(msgs):
         dg = hashlib.sha256(m).digest()
         want = [(dg[k // 8] >> (7 - k % 8)) & 1 for k in range(256)]
-        assert [(T[BS.SIG_BASE + 1 + k] >> i) & 1 for k in range(256)] == want
+        assert [(T[int(bt.sig_slot[1 + k])] >> i) & 1 for k in range(256)] == want
     sig, _ = _flat(fc, rows[3])
-    assert [(T[BS.SIG_BASE + s] >> 3) & 1 for s in range(fc.n_signals)] == sig
+    assert [(T[int(bt.sig_slot[s])] >> 3) & 1 for s in range(fc.n_signals)] == sig
 
 
 def test_loader_validates_the_bit_program(tmp_path):
@@ -172,19 +201,25 @@ def test_loader_validates_the_bit_program(tmp_path):
     cp = compile_program(Program(BitGadget(8)), str(tmp_path), "bg", sym=False, strands=(1,), bits=True)
     rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path).close()
     tape = bytearray(open(cp.tape_path, "rb").read())
-    nrec = cp.bittape.n_vrows * 64 * 32
-    start = len(tape) - nrec
-    for word, val in ((0, (BS.K_GLOBAL << 30) | (cp.bittape.n_slots * 8)),      # operand beyond the table
-                      (1, (BS.K_RING << 30) | (cp.bittape.ring * 512)),          # beyond the ring
-                      (2, 3 << 30),                                              # unknown kind
-                      (4, 8),                                                    # destination on the constant-1 slot
-                      (5, cp.bittape.n_slots * 8)):                              # destination beyond the table
+    nrec = cp.bittape.n_vrows * 64 * 16
+    start = len(tape) - nrec - 4 * cp.flat.n_signals
+    for word, val in ((0, cp.bittape.ring * 512),                                # ring operand beyond the ring
+                      (1, 1 << 25),                                              # unknown flag bits
+                      (2, cp.bittape.n_slots * 8),                               # load address beyond the table
+                      (3, 8),                                                    # destination on the constant-1 slot
+                      (3, BS.IN_BASE * 8),                                       # destination on an input slot
+                      (3, cp.bittape.n_slots * 8)):                              # destination beyond the table
         bad = bytearray(tape)
-        bad[start + 64 * 32 + word * 4: start + 64 * 32 + word * 4 + 4] = int(val).to_bytes(4, "little")
+        bad[start + 64 * 16 + word * 4: start + 64 * 16 + word * 4 + 4] = int(val).to_bytes(4, "little")
         p = tmp_path / "bad.cwt"
         p.write_bytes(bytes(bad))
         with pytest.raises(rt.CwError):
             rt.Circuit(p, cp.dat_path, cp.r1cs_path)
+    bad = bytearray(tape)                                                        # a signal mapped beyond the table
+    bad[len(tape) - 4:] = int(cp.bittape.n_slots).to_bytes(4, "little")
+    (tmp_path / "bad.cwt").write_bytes(bytes(bad))
+    with pytest.raises(rt.CwError):
+        rt.Circuit(tmp_path / "bad.cwt", cp.dat_path, cp.r1cs_path)
 
 
 # ---- GPU ---------------------------------------------------------------------------------------------------------------
@@ -283,6 +318,31 @@ def test_gpu_bitplane_r1cs_check_reports_first_bad_row(tmp_path):
         assert bool(st[i] & 4) == (want is not None), i
         if want is not None:
             assert fb[i] == want, (i, fb[i], want)
+    b.close(); c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("big", [False, True])
+def test_gpu_bitplane_r1cs_long_rows(tmp_path, big):
+    cp, c = _gpu(tmp_path, Program(BadWeighted(12, big)), "badw%d" % big)
+    fc = cp.flat
+    B = 200
+    rows = _rand_bits(fc, B, 12)
+    b = c.batch(B)
+    b.set_inputs(rows)
+    b.run(); b.check_r1cs(); b.sync()
+    st, fb = b.status(), b.r1cs_first_bad()
+    n_bad = 0
+    for i in range(B):
+        w = b.witness(i)
+        assert w == _flat(fc, rows[i])[0]
+        want = check_r1cs(c.q, fc.constraints, w)
+        assert (want is not None) == bool(rows[i][0] & rows[i][1])
+        assert bool(st[i] & 4) == (want is not None), i
+        if want is not None:
+            assert fb[i] == want, (i, fb[i], want)
+            n_bad += 1
+    assert 0 < n_bad < B
     b.close(); c.close()
 
 
