@@ -146,22 +146,8 @@ template <> struct BitsMask<16> {
     static __device__ __forceinline__ T lut(T a, T b, T c, uint32_t w1) { return BitsMask<32>::lut(a, b, c, w1); }
 };
 
-struct BRec { uint32_t w0, w1, g, d; };
-__device__ __forceinline__ BRec brec_load(const uint4 *__restrict__ recs, size_t idx) {
-    const uint4 x = recs[idx];
-    BRec r;
-    r.w0 = x.x; r.w1 = x.y; r.g = x.z; r.d = x.w;
-    return r;
-}
-
 extern __shared__ uint64_t cw_bits_ring[];       // [R][64 lanes] x 8 B
 
-// One step of the software pipeline, device vrow v (the host shifts the stream: device record v carries the LOAD
-// address of program vrow v and the gate fields of program vrow v - 2, so a bit-table value is requested two steps
-// before its vrow without waiting for a younger record).  Entering: RC = record of this step, (a, b, c) = its ring
-// operands, GVC = its loaded value (requested two steps ago); RN = next record.  The step requests the bit-table
-// value for two steps ahead (RC.g) and the ring operands of the next step, evaluates, writes ring entry (v - 2) mod R
-// and the destinations, then refills RC's registers with the record four steps ahead.
 // timing experiments only (tools/bits_exp.sh; results are garbage): drop the stores / the bit-table loads
 #ifdef CW_EXP_NOSTORE
 #define BITS_EXP_STORE(x)
@@ -173,48 +159,95 @@ extern __shared__ uint64_t cw_bits_ring[];       // [R][64 lanes] x 8 B
 #else
 #define BITS_EXP_LOAD(x) x
 #endif
-#define BITS_STEP(RC, RN, GVC, GVN2)                                                                               \
-    {                                                                                                              \
-        GVN2 = BITS_EXP_LOAD(M::load(rsrc, RC.g));                                                                 \
-        const mask_t na = M::lds(ring + (RN.w0 & 0xFFFFu)), nb = M::lds(ring + (RN.w0 >> 16)),                     \
-                     nc = M::lds(ring + (RN.w1 & 0xFFFFu));                                                        \
-        const mask_t res = M::lut(a, b, c, RC.w1) | GVC;                                                           \
-        if ((RC.w1 >> 24) & BITS_F_ASSERT) viol |= res;                                                            \
-        M::lds_st(ring + (((v + ring_mask - 1u) & ring_mask) << 9) + lane * 8, res);                               \
-        BITS_EXP_STORE(M::store(rsrc, RC.d, res));                                                                 \
-        a = na; b = nb; c = nc;                                                                                    \
-        RC = brec_load(recs, (size_t)(v + 4) * 64 + lane);                                                         \
-        v++;                                                                                                       \
+
+// The program runs in BATCHES of BITS_NB vrows so that vector-memory traffic never sits on the critical path:
+// at the start of batch b the wave requests, in one burst, the records of batch b + 2 and the bit-table values of the
+// LOAD lanes of batch b + 1 (their addresses are in the records of batch b + 1, resident since the previous burst);
+// then the BITS_NB steps run on registers and LDS only (ring operands of step k + 1 are read while step k computes);
+// at the end of the batch its BITS_NB results are stored in one burst.  Everything a batch consumes was requested a
+// whole batch (~1.5 K clocks) earlier, so the waits hipcc inserts (vmcnt counts loads and stores alike on gfx9 and
+// retires in order) find their operations long complete.  The three record sets and two loaded-value sets rotate
+// by NAME through six expansions of the batch body (no register moves).
+// Scheduler contract (bitsched.py): a LOAD lane of batch b reads a value stored by batch b - 2 or older.
+#define BITS_NB 8
+
+template <int W>
+struct BitsEval {
+    typedef BitsMask<W> M;
+    typedef typename M::T mask_t;
+    const uint4 *__restrict__ recs;
+    char *ring;
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t lane, ring_mask;
+    mask_t a, b, c, viol;
+
+    // cur: records of this batch, nxt: of the next one, fill: receives batch + 2; gcur: loaded values of this batch,
+    // gfill: receives those of the next one
+    __device__ __forceinline__ void batch(uint32_t v0, const uint4 (&cur)[BITS_NB], const uint4 (&nxt)[BITS_NB], uint4 (&fill)[BITS_NB],
+                                          const mask_t (&gcur)[BITS_NB], mask_t (&gfill)[BITS_NB]) {
+#pragma unroll
+        for (int k = 0; k < BITS_NB; k++) fill[k] = recs[(size_t)(v0 + 2 * BITS_NB + k) * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < BITS_NB; k++) gfill[k] = BITS_EXP_LOAD(M::load(rsrc, nxt[k].z));
+        mask_t res[BITS_NB];
+#pragma unroll
+        for (int k = 0; k < BITS_NB; k++) {
+            const uint4 rn = k + 1 < BITS_NB ? cur[k + 1 < BITS_NB ? k + 1 : 0] : nxt[0];
+            const mask_t na = M::lds(ring + (rn.x & 0xFFFFu)), nb = M::lds(ring + (rn.x >> 16)), nc = M::lds(ring + (rn.y & 0xFFFFu));
+            const mask_t r = M::lut(a, b, c, cur[k].y) | gcur[k];
+            if ((cur[k].y >> 24) & BITS_F_ASSERT) viol |= r;
+            M::lds_st(ring + (((v0 + k) & ring_mask) << 9) + lane * 8, r);
+            res[k] = r;
+            a = na; b = nb; c = nc;
+        }
+#pragma unroll
+        for (int k = 0; k < BITS_NB; k++) BITS_EXP_STORE(M::store(rsrc, cur[k].w, res[k]));
     }
+};
 
 template <int W>
 __global__ void __launch_bounds__(64)
-cw_bits_eval_kernel(const uint4 *__restrict__ recs, uint32_t n_steps, uint32_t ring_mask, uint64_t *T, uint64_t slots,
+cw_bits_eval_kernel(const uint4 *__restrict__ recs, uint32_t n_batches, uint32_t ring_mask, uint64_t *T, uint64_t slots,
                     uint64_t *fbmask) {
     typedef BitsMask<W> M;
     typedef typename M::T mask_t;
     const uint32_t lane = threadIdx.x, g = blockIdx.x, slice = blockIdx.y;
     char *Tg = (char *)(T + (size_t)g * slots) + slice * (W / 8);
-    char *ring = (char *)cw_bits_ring;
+    if (n_batches == 0) return;
+    BitsEval<W> E;
+    E.recs = recs;
+    E.ring = (char *)cw_bits_ring;
     // buffer descriptor of this group's table (wave-uniform by construction: kernel arguments and blockIdx only);
     // a wave of a narrower slice addresses its bytes of every 8-byte mask through the shifted base
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(Tg, 0, (int)(uint32_t)(slots * 8 - slice * (W / 8)), 0x00020000);
-    if (n_steps == 0) return;
-    // n_steps = program vrows + 2; the stream is padded with 8 empty records per lane behind it (records are requested
-    // four steps ahead and the loop runs in trips of four)
-    BRec r0 = brec_load(recs, lane), r1 = brec_load(recs, 64 + lane), r2 = brec_load(recs, 128 + lane),
-         r3 = brec_load(recs, 192 + lane);
-    mask_t a = 0, b = 0, c = 0;                 // the first two steps carry no gate
-    mask_t gv0 = 0, gv1 = 0, gv2 = 0, gv3 = 0;
-    mask_t viol = 0;
-    uint32_t v = 0;
-    // four steps per trip: the record register sets and the loaded values rotate by name, not by moves
-    while (v < n_steps) {
-        BITS_STEP(r0, r1, gv0, gv2)
-        BITS_STEP(r1, r2, gv1, gv3)
-        BITS_STEP(r2, r3, gv2, gv0)
-        BITS_STEP(r3, r0, gv3, gv1)
+    E.rsrc = __builtin_amdgcn_make_buffer_rsrc(Tg, 0, (int)(uint32_t)(slots * 8 - slice * (W / 8)), 0x00020000);
+    E.lane = lane;
+    E.ring_mask = ring_mask;
+    E.viol = 0;
+    // the host pads the program to whole batches and appends three empty ones (records are requested two batches ahead,
+    // the loop runs in trips of six batches)
+    uint4 R0[BITS_NB], R1[BITS_NB], R2[BITS_NB];
+    mask_t G0[BITS_NB], G1[BITS_NB];
+#pragma unroll
+    for (int k = 0; k < BITS_NB; k++) {
+        R0[k] = recs[(size_t)k * 64 + lane];
+        R1[k] = recs[(size_t)(BITS_NB + k) * 64 + lane];
     }
+#pragma unroll
+    for (int k = 0; k < BITS_NB; k++) G0[k] = BITS_EXP_LOAD(M::load(E.rsrc, R0[k].z));
+    E.a = M::lds(E.ring + (R0[0].x & 0xFFFFu));
+    E.b = M::lds(E.ring + (R0[0].x >> 16));
+    E.c = M::lds(E.ring + (R0[0].y & 0xFFFFu));
+    uint32_t v = 0;
+    const uint32_t n_steps = n_batches * BITS_NB;
+    while (v < n_steps) {
+        E.batch(v, R0, R1, R2, G0, G1); v += BITS_NB;
+        E.batch(v, R1, R2, R0, G1, G0); v += BITS_NB;
+        E.batch(v, R2, R0, R1, G0, G1); v += BITS_NB;
+        E.batch(v, R0, R1, R2, G1, G0); v += BITS_NB;
+        E.batch(v, R1, R2, R0, G0, G1); v += BITS_NB;
+        E.batch(v, R2, R0, R1, G1, G0); v += BITS_NB;
+    }
+    const mask_t viol = E.viol;
     // instances that tripped an assertion gate: OR over the lanes (gates), then into the group's fallback mask
     uint64_t vz = (uint64_t)viol;
 #pragma unroll

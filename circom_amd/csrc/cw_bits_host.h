@@ -23,7 +23,7 @@ struct Program {                             // hip_elements/bitsched.py::BitTap
 // Every offset a record carries is checked once at load time (files are untrusted input): ring operands inside the
 // ring, load addresses and destinations inside the group's bit table, destinations never on constant or input slots.
 inline const char *validate(const Program &p, uint32_t n_signals, uint32_t n_inputs) {
-    if (p.ring < 8 || p.ring > 128 || (p.ring & (p.ring - 1))) return "bit program: ring size";
+    if (p.ring < 32 || p.ring > 128 || (p.ring & (p.ring - 1))) return "bit program: ring size";
     if (p.n_slots < (uint64_t)IN_BASE + n_inputs || p.n_slots >= (1ull << 25)) return "bit program: slot count";
     if (p.recs.size() != (size_t)p.n_vrows * 64 * 4) return "bit program: record count";
     if (p.sig_slot.size() != n_signals) return "bit program: signal map size";
@@ -42,21 +42,15 @@ inline const char *validate(const Program &p, uint32_t n_signals, uint32_t n_inp
     return nullptr;
 }
 
-// Device stream: the LOAD address of program vrow v travels in device record v, its gate fields in device record
-// v + 2 (the kernel requests a bit-table value two steps before the vrow that uses it); 8 empty records per lane pad
-// the end (records are requested four steps ahead, the loop runs in trips of four).  Returns the number of steps.
+// Device stream: the program padded to whole batches of 8 vrows, plus 8 empty batches (the kernel requests records two
+// batches ahead and its loop runs in trips of six batches).  Returns the number of batches to execute.
 inline uint32_t device_stream(const Program &p, std::vector<uint32_t> &dev) {
-    const size_t steps = (size_t)p.n_vrows + 2;
-    dev.assign((steps + 8) * 64 * 4, NONE);
-    for (size_t i = 0; i < (steps + 8) * 64; i++) dev[i * 4] = dev[i * 4 + 1] = 0;
-    for (size_t v = 0; v < p.n_vrows; v++)
-        for (size_t lane = 0; lane < 64; lane++) {
-            const uint32_t *src = &p.recs[(v * 64 + lane) * 4];
-            uint32_t *own = &dev[((v + 2) * 64 + lane) * 4];
-            own[0] = src[0]; own[1] = src[1]; own[3] = src[3];
-            dev[(v * 64 + lane) * 4 + 2] = src[2];
-        }
-    return (uint32_t)steps;
+    const size_t batches = ((size_t)p.n_vrows + 7) / 8;
+    const size_t rows = (batches + 8) * 8 * 64;
+    dev.assign(rows * 4, NONE);
+    for (size_t i = 0; i < rows; i++) dev[i * 4] = dev[i * 4 + 1] = 0;
+    std::copy(p.recs.begin(), p.recs.end(), dev.begin());
+    return (uint32_t)batches;
 }
 
 // ---- R1CS over the bit table --------------------------------------------------------------------------------------------

