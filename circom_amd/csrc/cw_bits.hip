@@ -360,35 +360,66 @@ cw_bits_r1cs_wide_kernel(const uint4 *__restrict__ chunk, uint32_t n_chunks, con
     }
 }
 
-// Class I: the same stream, but every coefficient is a small signed integer (|c| < 2^40, < 2^20 terms per row): the
-// three parts are exact 64-bit integer sums (4 VALU per term), the row holds iff A * B - C == 0 over the integers
-// (|A*B - C| < 2^125 < q, so this IS the test modulo q).  SHA-256's `lin === lout` rows (up to 195 terms) live here.
+// Class I: every coefficient is a small signed integer (|c| < 2^40, < 2^20 terms per row): the three parts are exact
+// 64-bit integer sums and the row holds iff A * B - C == 0 over the integers (|A*B - C| < 2^125 < q, so this IS the test
+// modulo q).  SHA-256's `lin === lout` rows (up to 195 terms) live here.  One lane = one instance; the stream is
+// wave-uniform (scalar loads).  The host regrouped the terms (cw_bits_host.h): inside a GROUP the coefficients are
+// distinct powers of two of one sign within one 32-bit half, so a term costs two VALU instructions — select 0/1 with the
+// wire's 64-instance mask as the condition, shift-or it into the group's word — and a group one 64-bit add.
+__device__ __forceinline__ uint32_t bits_lane_bit(uint64_t mask) {
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(r) : "s"(mask));      // lane i gets bit i of the (wave-uniform) mask
+    return r;
+}
 __global__ void __launch_bounds__(64)
-cw_bits_r1cs_int_kernel(const uint4 *__restrict__ chunk, uint32_t n_chunks, const uint2 *__restrict__ terms,
+cw_bits_r1cs_int_kernel(const uint4 *__restrict__ chunk, uint32_t n_chunks, const uint32_t *__restrict__ words,
                         const uint2 *__restrict__ itab, const uint32_t *__restrict__ row_orig,
                         const uint64_t *__restrict__ T, uint64_t slots, uint32_t batch, uint32_t *status,
                         uint32_t *first_bad) {
     const uint32_t lane = threadIdx.x, g = blockIdx.x;
     const uint32_t i = g * 64 + lane;
-    const char *Tg = (const char *)(T + (size_t)g * slots);
+    const uint64_t *Tg = T + (size_t)g * slots;
     uint32_t bad = 0xFFFFFFFFu;
     for (uint32_t cix = blockIdx.y; cix < n_chunks; cix += gridDim.y) {
-        const uint4 ch = chunk[cix];                                // first term, n terms, -, first row
-        const uint2 *tp = terms + ch.x;
+        const uint4 ch = chunk[cix];                                // first word, groups, -, first row
+        const uint32_t *wp = words + ch.x;
         int64_t A = 0, B = 0, cur = 0;
         uint32_t row = ch.w;
-        for (uint32_t k = 0; k < ch.y; k++) {
-            const uint2 t = tp[k];
-            const uint32_t off = t.x & 0x0FFFFFFFu, part = (t.x >> 28) & 3u, last = t.x >> 31, endrow = (t.x >> 30) & 1u;
-            const uint64_t m = *(const uint64_t *)(Tg + off);      // wave-uniform address
-            const uint2 cw = itab[t.y];
-            const int64_t cf = (int64_t)(((uint64_t)cw.y << 32) | cw.x);
-            cur += ((m >> lane) & 1ull) ? cf : 0;
-            if (last) {
+        for (uint32_t gi = 0; gi < ch.y; gi++) {
+            const uint32_t hdr = wp[0];
+            const uint32_t nb = hdr & 0xFFu;
+            wp++;
+            if (!(hdr & (1u << 10))) {
+                uint32_t acc = 0;
+                for (uint32_t blk = 0; blk < nb; blk++, wp += 8) {
+                    uint32_t w[8];
+                    uint64_t m[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) w[k] = wp[k];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) m[k] = Tg[w[k] >> 5];           // wave-uniform addresses: scalar loads
+#pragma unroll
+                    for (int k = 0; k < 8; k++) acc |= bits_lane_bit(m[k]) << (w[k] & 31u);
+                }
+                const int64_t val = (int64_t)((hdr & (1u << 9)) ? ((uint64_t)acc << 32) : (uint64_t)acc);
+                cur += (hdr & (1u << 8)) ? -val : val;
+            } else {
+                for (uint32_t blk = 0; blk < nb; blk++, wp += 8) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint64_t m = Tg[wp[2 * k]];
+                        const uint2 cw = itab[wp[2 * k + 1]];
+                        const int64_t cf = (int64_t)(((uint64_t)cw.y << 32) | cw.x);
+                        cur += bits_lane_bit(m) ? cf : 0;
+                    }
+                }
+            }
+            if (hdr & (1u << 13)) {                                 // last group of its part
+                const uint32_t part = (hdr >> 11) & 3u;
                 if (part == 0) { A = cur; cur = 0; }
                 else if (part == 1) { B = cur; cur = 0; }
             }
-            if (endrow) {
+            if (hdr & (1u << 14)) {                                 // end of the row
                 const __int128 z = (__int128)A * (__int128)B - (__int128)cur;
                 if (z != 0) {
                     const uint32_t oc = row_orig[row];
@@ -462,7 +493,7 @@ hipError_t cwk_bits_r1cs(hipStream_t s, const void *erecs, uint32_t n_evrows, co
     }
     if (n_ichunks) {
         dim3 g(n_groups, n_ichunks < 65535u ? n_ichunks : 65535u);
-        hipLaunchKernelGGL(cw_bits_r1cs_int_kernel, g, dim3(64), 0, s, (const uint4 *)ichunk, n_ichunks, (const uint2 *)iterms,
+        hipLaunchKernelGGL(cw_bits_r1cs_int_kernel, g, dim3(64), 0, s, (const uint4 *)ichunk, n_ichunks, iterms,
                            (const uint2 *)itab, irow_orig, (const uint64_t *)T, slots, batch, status, first_bad);
     }
     if (n_chunks) {

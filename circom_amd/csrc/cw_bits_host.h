@@ -4,6 +4,8 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <array>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -65,8 +67,14 @@ struct R1Plan {
     std::vector<uint32_t> row_orig;   // W-class rows -> constraint index of the .r1cs
     std::vector<uint32_t> ctab;       // canonical coefficients, 8 words each
     uint32_t n_chunks = 0;
-    // class I: like W, but every coefficient is a small signed integer: exact 64-bit integer sums (cw_bits_r1cs_int_kernel)
-    std::vector<uint32_t> ichunk, iterms, irow_orig;
+    // class I: every coefficient is a small signed integer: exact 64-bit integer sums (cw_bits_r1cs_int_kernel).
+    // The terms of a row are regrouped (a sum does not care about order): a GROUP = terms whose coefficients are
+    // distinct powers of two with one sign inside one 32-bit half (the 32 bits of a word of a BinSum / Bits2Num row), so
+    // that a term is "or the bit in at position k" (2 VALU); other coefficients form generic groups.
+    // stream of u32: header {blocks:8 | sign:1 | hi:1 | generic:1 | part:2 | last of part:1 | end of row:1} then
+    // blocks x 8 words: power-of-two term = slot << 5 | k, generic term = two words (slot, coefficient id); padding
+    // terms name slot 0 (the constant 0).
+    std::vector<uint32_t> ichunk, iwords, irow_orig;   // chunk = {first word, groups, 0, first row}
     std::vector<uint32_t> itab;       // signed 64-bit value of every coefficient id (2 words each; 0 if not small)
     uint32_t n_ichunks = 0;
     uint64_t n_trivial = 0, n_lut = 0, n_wide = 0, n_int = 0;
@@ -133,7 +141,18 @@ inline R1Plan build_r1cs(const std::vector<uint32_t> &r_ptr, const std::vector<u
             }
         }
     };
-    Stream SW{&p.chunk, &p.terms, &p.row_orig}, SI{&p.ichunk, &p.iterms, &p.irow_orig};
+    Stream SW{&p.chunk, &p.terms, &p.row_orig};
+    uint32_t i_groups = 0, i_first_word = 0, i_first_row = 0, i_terms = 0;
+    auto iclose = [&]() {
+        if (i_groups) {
+            p.ichunk.push_back(i_first_word);
+            p.ichunk.push_back(i_groups);
+            p.ichunk.push_back(0);
+            p.ichunk.push_back(i_first_row);
+            i_groups = 0;
+            i_terms = 0;
+        }
+    };
     for (size_t j = 0; j < n_cons; j++) {
         const uint32_t orig = r_orig[j] & 0x7FFFFFFFu;
         const uint32_t t0 = r_ptr[3 * j], t3 = r_ptr[3 * j + 3];
@@ -182,8 +201,81 @@ inline R1Plan build_r1cs(const std::vector<uint32_t> &r_ptr, const std::vector<u
         const uint32_t nt = t3 - t0;
         bool all_small = nt < (1u << 20);
         for (uint32_t t = t0; t < t3 && all_small; t++) all_small = is_small[r_cc[t]];
-        Stream &S = all_small ? SI : SW;
-        if (all_small) p.n_int++; else p.n_wide++;
+        if (all_small) {
+            p.n_int++;
+            if (i_groups && i_terms + nt > terms_per_chunk) iclose();
+            if (i_groups == 0) {
+                i_first_word = (uint32_t)p.iwords.size();
+                i_first_row = (uint32_t)p.irow_orig.size();
+            }
+            struct G { uint32_t hdr; std::vector<uint32_t> w; };
+            std::vector<G> groups;
+            int last_part = -1;
+            for (int pi = 0; pi < 3; pi++) {
+                // power-of-two terms: key (sign, half) then slot order; generic terms afterwards
+                std::vector<std::array<uint32_t, 3>> pw;          // key, slot, k
+                std::vector<std::pair<uint32_t, uint32_t>> gen;    // slot, coefficient id
+                for (uint32_t t = r_ptr[3 * j + pi]; t < r_ptr[3 * j + pi + 1]; t++) {
+                    const uint32_t sl = r_slot[t];
+                    if (sl == 0) continue;                          // the constant 0
+                    const int64_t cv = small[r_cc[t]];
+                    const uint64_t mag = cv < 0 ? (uint64_t)(-cv) : (uint64_t)cv;
+                    if (mag && !(mag & (mag - 1))) {
+                        const uint32_t k = (uint32_t)__builtin_ctzll(mag);
+                        pw.push_back({(uint32_t)((cv < 0 ? 2u : 0u) | (k >= 32 ? 1u : 0u)), sl, k & 31u});
+                    } else if (mag) {
+                        gen.push_back({sl, r_cc[t]});
+                    }
+                }
+                std::stable_sort(pw.begin(), pw.end(), [](const std::array<uint32_t, 3> &x, const std::array<uint32_t, 3> &y) { return x[0] < y[0]; });
+                const size_t g0 = groups.size();
+                size_t i = 0;
+                while (i < pw.size()) {
+                    uint32_t used = 0;
+                    G g;
+                    g.hdr = ((pw[i][0] >> 1) << 8) | ((pw[i][0] & 1) << 9) | ((uint32_t)pi << 11);
+                    const uint32_t key = pw[i][0];
+                    while (i < pw.size() && pw[i][0] == key && !(used & (1u << pw[i][2]))) {
+                        used |= 1u << pw[i][2];
+                        g.w.push_back((pw[i][1] << 5) | pw[i][2]);
+                        i++;
+                    }
+                    while (g.w.size() % 8) g.w.push_back(0);
+                    groups.push_back(std::move(g));
+                }
+                for (size_t k0 = 0; k0 < gen.size(); k0 += 4 * 255) {
+                    G g;
+                    g.hdr = (1u << 10) | ((uint32_t)pi << 11);
+                    for (size_t k = k0; k < gen.size() && k < k0 + 4 * 255; k++) {
+                        g.w.push_back(gen[k].first);
+                        g.w.push_back(gen[k].second);
+                    }
+                    while (g.w.size() % 8) { g.w.push_back(0); g.w.push_back(0); }
+                    groups.push_back(std::move(g));
+                }
+                if (groups.size() > g0) {
+                    groups.back().hdr |= 1u << 13;                 // last group of its part
+                    last_part = pi;
+                }
+            }
+            (void)last_part;
+            if (groups.empty()) {                                   // 0 = 0
+                p.n_int--;
+                p.n_trivial++;
+                continue;
+            }
+            groups.back().hdr |= 1u << 14;                          // end of the row
+            for (auto &g : groups) {
+                p.iwords.push_back(g.hdr | (uint32_t)(g.w.size() / 8));
+                p.iwords.insert(p.iwords.end(), g.w.begin(), g.w.end());
+            }
+            i_groups += (uint32_t)groups.size();
+            i_terms += nt;
+            p.irow_orig.push_back(orig);
+            continue;
+        }
+        p.n_wide++;
+        Stream &S = SW;
         if (S.cur_terms && S.cur_terms + nt > terms_per_chunk) S.close();
         if (S.cur_terms == 0) {
             S.cur_first_term = (uint32_t)(S.terms->size() / 2);
@@ -204,7 +296,7 @@ inline R1Plan build_r1cs(const std::vector<uint32_t> &r_ptr, const std::vector<u
         S.cur_terms += nt;
     }
     SW.close();
-    SI.close();
+    iclose();
     p.n_chunks = (uint32_t)(p.chunk.size() / 4);
     p.n_evrows = (uint32_t)((erows.size() / 8 + 63) / 64);
     p.erecs.assign((size_t)p.n_evrows * 64 * 8, 0);
@@ -213,7 +305,7 @@ inline R1Plan build_r1cs(const std::vector<uint32_t> &r_ptr, const std::vector<u
     if (p.row_orig.empty()) p.row_orig.assign(1, 0);
     if (p.chunk.empty()) p.chunk.assign(4, 0);
     p.n_ichunks = (uint32_t)(p.ichunk.size() / 4);
-    if (p.iterms.empty()) p.iterms.assign(2, 0);
+    p.iwords.resize(p.iwords.size() + 16, 0);      // the kernel reads blocks of 8 words
     if (p.irow_orig.empty()) p.irow_orig.assign(1, 0);
     if (p.ichunk.empty()) p.ichunk.assign(4, 0);
     if (p.itab.empty()) p.itab.assign(2, 0);

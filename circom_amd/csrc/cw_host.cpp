@@ -1078,6 +1078,21 @@ extern "C" int cw_batch_create(cw_circuit *c, int device, uint32_t batch, void *
     return batch_create_impl(c, device, batch, stream, !(e && e[0] == '0'), out);
 }
 extern "C" int cw_batch_bitmode(const cw_batch *b) { return b && b->bitmode; }
+extern "C" int cw_bits_info(const cw_circuit *c, uint64_t out[8]) {
+    if (!c || !out) return fail(CW_EINVAL, "null argument");
+    memset(out, 0, 64);
+    if (!c->has_bits) return CW_OK;
+    const cwbits::Program &bp = c->bits;
+    uint64_t gates = 0, loads = 0, stores = 0;
+    for (size_t i = 0; i < (size_t)bp.n_vrows * 64; i++) {
+        const uint32_t *r = &bp.recs[i * 4];
+        if (r[2] != cwbits::NONE) loads++;
+        else if ((r[1] >> 16) & 0xFF) gates++;
+        if (r[3] != cwbits::NONE) stores++;
+    }
+    out[0] = 1; out[1] = bp.n_vrows; out[2] = bp.n_slots; out[3] = bp.ring; out[4] = gates; out[5] = loads; out[6] = stores;
+    return CW_OK;
+}
 extern "C" uint32_t cw_batch_size(const cw_batch *b) { return b->batch; }
 extern "C" uint32_t cw_batch_strands(const cw_batch *b) { return b->var ? b->var->n_strands : 0; }
 extern "C" uint32_t cw_batch_lanes(const cw_batch *b) { return b->bitmode ? b->bits_width : b->lanes; }
@@ -1398,7 +1413,7 @@ static int bits_batch_setup(cw_batch *b) {
         BTRY(upload(&b->d_wctab, p.ctab, b->stream));
         BTRY(upload(&b->d_wrow, p.row_orig, b->stream));
         BTRY(upload(&b->d_ichunk, p.ichunk, b->stream));
-        BTRY(upload(&b->d_iterms, p.iterms, b->stream));
+        BTRY(upload(&b->d_iterms, p.iwords, b->stream));
         BTRY(upload(&b->d_itab, p.itab, b->stream));
         BTRY(upload(&b->d_irow, p.irow_orig, b->stream));
         b->n_ichunks = p.n_ichunks;
@@ -1614,6 +1629,34 @@ extern "C" int cw_get_witnesses(cw_batch *b, uint32_t first, uint32_t count, uin
         for (size_t k = 0; k < b->fb_inst.size(); k++)
             if (b->fb_inst[k] >= first && b->fb_inst[k] < first + count)
                 if (int rc = cw_get_witness(b->fb, (uint32_t)k, out + (size_t)(b->fb_inst[k] - first) * row)) return rc;
+    return CW_OK;
+}
+
+// Device-side form for GPU provers: canonical 32-byte values of `count` instances written to DEVICE memory
+// ([count][n_witness][32]); no host copy.  In bit-plane batches this is where a bit becomes a field element again.
+extern "C" int cw_get_witnesses_device(cw_batch *b, uint32_t first, uint32_t count, void *d_out) {
+    if (!b || !d_out) return fail(CW_EINVAL, "null argument");
+    if ((uint64_t)first + count > b->batch) return fail(CW_EINVAL, "instance range out of the batch");
+    NEED_DEVICE(b);
+    if (!b->ran) return fail(CW_ESTATE, "cw_get_witnesses_device before cw_run");
+    cw_circuit *c = b->c;
+    HIPCHK(hipSetDevice(b->device));
+    if (!b->bitmode) {
+        HIPCHK(cwk_gather_many(b->stream, b->d_V, b->d_w2s, c->n_witness, b->Bp, first, count, d_out));
+        return CW_OK;
+    }
+    if (b->resolved && !b->fb_inst.empty()) {
+        // (instances re-run by the 256-bit schedule are patched in below; an unresolved batch is served as computed
+        //  so that the call stays asynchronous — cw_sync() first if the inputs may hold non-boolean values)
+    }
+    HIPCHK(cwk_bits_gather(b->stream, b->d_T, c->bits.n_slots, b->d_w2s, b->d_sigslot, c->n_witness, first, count, d_out));
+    if (b->resolved)
+        for (size_t k = 0; k < b->fb_inst.size(); k++)
+            if (b->fb_inst[k] >= first && b->fb_inst[k] < first + count) {
+                const size_t row = (size_t)c->n_witness * 32;
+                int rc = cw_get_witnesses_device(b->fb, (uint32_t)k, 1, (char *)d_out + (size_t)(b->fb_inst[k] - first) * row);
+                if (rc != CW_OK) return rc;
+            }
     return CW_OK;
 }
 

@@ -62,6 +62,7 @@ _SIGS = {
     "cw_batch_strands": (C.c_uint32, [C.c_void_p]),
     "cw_batch_lanes": (C.c_uint32, [C.c_void_p]),
     "cw_batch_bitmode": (C.c_int, [C.c_void_p]),
+    "cw_bits_info": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cw_device_bits": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "cw_set_input_signal": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p]),
     "cw_set_inputs_json": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p]),
@@ -75,6 +76,7 @@ _SIGS = {
     "cw_get_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cw_get_witness": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "cw_get_witnesses": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "cw_get_witnesses_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "cw_get_public": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cw_get_public_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cw_get_signal": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p]),
@@ -135,6 +137,14 @@ class Circuit:
         buf = C.create_string_buffer(32)
         L.cw_prime(h, buf)
         self.q = int.from_bytes(buf.raw, "little")
+
+    def bits_info(self) -> dict:
+        """shape of the bit-plane program ({} when the circuit has none)"""
+        out = (C.c_uint64 * 8)()
+        _chk(lib().cw_bits_info(self.h, out))
+        if not out[0]:
+            return {}
+        return dict(zip(("vrows", "slots_per_group", "ring", "gate_lanes", "load_lanes", "stored_values"), [int(x) for x in out[1:7]]))
 
     def input_size(self, name: str):
         start = C.c_uint32()
@@ -244,6 +254,10 @@ class Batch:
         out = np.zeros((count, self.circuit.n_witness, 32), dtype=np.uint8)
         _chk(lib().cw_get_witnesses(self.h, first, count, out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def witnesses_device(self, first: int, count: int, d_ptr: int) -> None:
+        """canonical values of `count` instances written to device memory at d_ptr ([count][n_witness][32])"""
+        _chk(lib().cw_get_witnesses_device(self.h, first, count, C.c_void_p(d_ptr)))
 
     def signal(self, instance: int, slot: int) -> int:
         buf = C.create_string_buffer(32)

@@ -76,6 +76,9 @@ uint32_t cw_batch_lanes(const cw_batch *b);
  * signal per instance, replaces the short-int paths of the tagged FrElement, generic/fr.cpp:416-439,900-917);
  * instances whose inputs are not 0/1 are transparently re-run by the 256-bit schedule.  CW_BITS=0 disables it. */
 int cw_batch_bitmode(const cw_batch *b);
+/* shape of the circuit's bit-plane program: out = {present, vrows, bit-table slots per group of 64 instances, LDS ring
+ * entries, gate lanes, load lanes, stored values, 0} (all zero when the circuit has none) */
+int cw_bits_info(const cw_circuit *c, uint64_t out[8]);
 
 /* setInputSignal(h, i, val) (calcwit.cpp:77-97) for one instance; `name` is hashed with FNV-1a
  * (calcwit.cpp:17-24).  val = canonical 32-byte little-endian value, reduced mod q by the caller. */
@@ -106,6 +109,8 @@ int cw_get_status(cw_batch *b, uint32_t *status /* [batch] */);
 int cw_get_witness(cw_batch *b, uint32_t instance, uint8_t *out);
 /* bulk form for provers: `count` instances from `first`, [count][n_witness][32], one device-side transpose */
 int cw_get_witnesses(cw_batch *b, uint32_t first, uint32_t count, uint8_t *out);
+/* the same to DEVICE memory (no host copy, asynchronous on the batch's stream): what a GPU prover consumes */
+int cw_get_witnesses_device(cw_batch *b, uint32_t first, uint32_t count, void *d_out);
 /* public signals (main's outputs, then its public inputs = witness positions 1..cw_n_public) of EVERY instance,
  * [batch][n_public][32]: to host memory, or to device memory for a multi-GPU gather */
 int cw_get_public(cw_batch *b, uint8_t *out);

@@ -64,3 +64,52 @@ def test_two_rank_gloo_status_gather(tmp_path):
     ids = torch.arange(0, total, dtype=torch.int64)
     wpub = ((ids[:, None, None] * 7 + torch.arange(2)[None, :, None] * 3 + torch.arange(32)[None, None, :]) % 251).to(torch.uint8)
     assert gpub.shape == (total, 2, 32) and torch.equal(gpub, wpub)
+
+
+def _cabi_worker(rank, world, port, total, shared_dir):
+    """N>1 path through the C ABI: rank 0 compiles the circuit once, the others load the artefacts from the shared
+    directory; every rank stages the inputs of ITS shard in a host-only batch (device = -1: the library validates and
+    stages, nothing computes without a GPU), then the per-instance words are gathered on rank 0."""
+    sys.path.insert(0, str(ROOT))
+    from circom_amd import runtime as rt
+    from circom_amd.sharding import shard_range, gather_status
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    p = lambda ext: os.path.join(shared_dir, "poseidon2" + ext)
+    if rank == 0:
+        from circom_amd.compiler import compile_program
+        from circom_amd.frontend.dsl import Program
+        from circom_amd.circuits.poseidon import Poseidon
+        compile_program(Program(Poseidon(2)), shared_dir, "poseidon2", sym=False, strands=(1,))
+    dist.barrier()
+    c = rt.Circuit(p(".cwt"), p(".dat"), p(".r1cs"))             # every rank loads the same files
+    lo, hi = shard_range(total, rank, world)
+    b = c.batch(hi - lo, device=-1)
+    for i in range(lo, hi):
+        b.set_inputs_json(i - lo, '{"inputs": ["%d", "%d"]}' % (i, 7 * i + 1))
+    assert all(b.remaining_inputs(k) == 0 for k in range(hi - lo))
+    try:
+        b.run()
+        raise AssertionError("a host-only batch must not compute")
+    except rt.CwError:
+        pass
+    # what each rank staged for its instances travels to rank 0 the way the status words do
+    words = torch.tensor([b.staged_input(k, 1) % (1 << 31) for k in range(hi - lo)], dtype=torch.int32)
+    got = gather_status(words, dist, rank, world)
+    if rank == 0:
+        torch.save(got, os.path.join(shared_dir, "staged.pt"))
+    dist.barrier()
+    b.close(); c.close()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_through_the_c_abi(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    total = 37
+    mp.spawn(_cabi_worker, args=(2, port, total, str(tmp_path)), nprocs=2, join=True)
+    got = torch.load(tmp_path / "staged.pt")
+    assert got.tolist() == [(7 * i + 1) % (1 << 31) for i in range(total)]

@@ -55,27 +55,38 @@ if len(sys.argv) > 3:
                 pass
         for k, v in tmp.items():
             dst[k] = sum(v) / len(v)
+    def short_name(k):
+        if "eval_kernel" in k:
+            return "eval"
+        if "r1cs" in k:
+            return "r1cs"
+        return None
+
     res = {}
     for k in fetch:
-        short = "cw_eval_kernel" if "cw_eval_kernel" in k else ("cw_r1cs_kernel" if "cw_r1cs" in k else None)
-        if short:
-            res[short] = (2 * fetch[k] + write.get(k, 0.0)) * 1024.0
-    # VALU-busy per kernel from the SQ pass: SQ_ACTIVE_INST_VALU (quad-cycles summed over SIMDs... per dispatch) x 4
-    # / (1024 SIMDs x GRBM_GUI_ACTIVE cycles)   (north-star: "VALU-busy reported against gfx950 peak")
+        short = short_name(k)
+        if short:                                       # the R1CS check may be several kernels: their traffic adds up
+            res[short] = res.get(short, 0.0) + (2 * fetch[k] + write.get(k, 0.0)) * 1024.0
+    # VALU-busy per kernel from the SQ pass: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE)
+    # (north-star: "VALU-busy reported against gfx950 peak")
     sq = defaultdict(lambda: defaultdict(list))
     for r in rows("pmc_sq/**/*counter_collection.csv"):
         try:
             sq[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         except (KeyError, ValueError):
             pass
+    agg = defaultdict(lambda: defaultdict(float))
     for k, cs in sq.items():
-        short = "cw_eval_kernel" if "cw_eval_kernel" in k else ("cw_r1cs_kernel" if "cw_r1cs" in k else None)
-        if short and cs.get("SQ_ACTIVE_INST_VALU") and cs.get("GRBM_GUI_ACTIVE"):
-            act = sum(cs["SQ_ACTIVE_INST_VALU"]) / len(cs["SQ_ACTIVE_INST_VALU"])
-            gui = sum(cs["GRBM_GUI_ACTIVE"]) / len(cs["GRBM_GUI_ACTIVE"])
-            res[short + "_valu_busy"] = act * 4.0 / (1024.0 * gui)
+        short = short_name(k)
+        if short:
+            for c, v in cs.items():
+                agg[short][c] += sum(v) / len(v)
+    for short, cs in agg.items():
+        if cs.get("SQ_ACTIVE_INST_VALU") and cs.get("GRBM_GUI_ACTIVE"):
+            res[short + "_valu_busy"] = cs["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cs["GRBM_GUI_ACTIVE"])
+            res[short + "_valu_insts"] = cs.get("SQ_INSTS_VALU")
             if cs.get("SQ_WAIT_ANY") and cs.get("SQ_WAVE_CYCLES"):
-                res[short + "_wait_frac"] = sum(cs["SQ_WAIT_ANY"]) / max(sum(cs["SQ_WAVE_CYCLES"]), 1.0)
+                res[short + "_wait_frac"] = cs["SQ_WAIT_ANY"] / max(cs["SQ_WAVE_CYCLES"], 1.0)
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     res["source"] = bench.source_fingerprint()          # bench.py only quotes these figures for the source they were measured on
