@@ -34,7 +34,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
-DEFAULT_BATCH = {"sha256_2048": 4096, "sha256_512": 4096, "poseidon2": 65536, "semaphore20": 8192}
+DEFAULT_BATCH = {"sha256_2048": 65536, "sha256_512": 4096, "poseidon2": 65536, "semaphore20": 8192}
 
 
 def make_program(name: str):
@@ -196,6 +196,7 @@ def main():
     ap.add_argument("--cache-dir", default=os.environ.get("CW_CACHE", ""))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-small", action="store_true", help="skip the batch-4096 side measurement (profiling runs)")
     ap.add_argument("--fp-bench-lanes", type=int, default=1 << 24)
     args = ap.parse_args()
 
@@ -325,6 +326,22 @@ def main():
             fp_mul[pname] = n * 1024 / (ms * 1e-3)
     fp_mul_per_s = fp_mul.get("bn128")
 
+    # the batch BASELINE.json's configs use for SHA-256 (4096), measured next to the throughput batch
+    small = None
+    if rank == 0 and world == 1 and args.workload == "sha256_2048" and B > 4096 and not args.batch and not args.no_small:
+        b2 = circ.batch(4096, device=local_rank, stream=stream.cuda_stream)
+        b2.set_inputs_device(d_in.data_ptr())
+        ev2 = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(4)]
+        for e in ev2:
+            e[0].record(stream); b2.run(); e[1].record(stream); b2.check_r1cs(); e[2].record(stream)
+        torch.cuda.synchronize()
+        g2 = sum(e[0].elapsed_time(e[1]) for e in ev2[1:]) / 3
+        c2 = sum(e[1].elapsed_time(e[2]) for e in ev2[1:]) / 3
+        assert (b2.status() == 0).all()
+        small = {"batch": 4096, "eval_ms": g2, "r1cs_check_ms": c2, "witnesses_per_s": 4096 / ((g2 + c2) * 1e-3),
+                 "lanes_per_wave": b2.lanes}
+        b2.close()
+
     if rank == 0:
         total_witnesses = n_total * args.steps
         value = total_witnesses / elapsed
@@ -401,6 +418,7 @@ def main():
             # against the measured Fp-multiply peak (micro-benchmark, 2^24 x 1024) for the 256-bit schedule
             "roofline_valu": roof_valu,
             "canonical_egress": egress,
+            "batch_4096": small,
             "fp_mul_per_s": fp_mul_per_s,
             "fp_mul_per_s_by_prime": fp_mul,
             "eval_ms": gen_ms,

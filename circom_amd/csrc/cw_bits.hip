@@ -39,32 +39,29 @@ __global__ void __launch_bounds__(256) cw_bits_init_kernel(uint64_t *T, uint64_t
 
 // ---- ingest: AoS canonical inputs [batch][n_in][32 B] -> one mask per (group, input) -----------------------------------
 // (setInputSignal's `signalValues[si] = val`, calcwit.cpp:93, for 64 instances at a time).  A wave handles 64 inputs
-// of one group: lane i reads instance i's value, the ballot over the wave is the mask; lane k keeps the mask of
-// input k, so the 64 masks leave as one coalesced 512-byte store.  Values other than 0/1 flag their instance.
+// of one group: lane k owns input k0 + k and walks the 64 instances of the group, so every load instruction reads
+// 2 KiB contiguous (64 consecutive inputs of one instance) and the lane shifts the value's low bit into its own mask;
+// the 64 masks leave as one coalesced 512-byte store.  Values other than 0/1 flag their instance.
 __global__ void __launch_bounds__(64) cw_bits_ingest_kernel(const uint4 *__restrict__ in, uint64_t *__restrict__ T,
                                                              uint64_t slots, uint32_t input_slot0, uint32_t n_in,
                                                              uint32_t batch, uint64_t *fbmask) {
-    const uint32_t lane = threadIdx.x, g = blockIdx.x, k0 = blockIdx.y * 64;
-    const uint32_t i = g * 64 + lane;
-    const bool valid = i < batch;
-    uint64_t mine = 0;
-    bool bad = false;
-    const uint32_t kn = min(64u, n_in - k0);
-    for (uint32_t kk = 0; kk < kn; kk++) {
+    const uint32_t lane = threadIdx.x, g = blockIdx.x, k = blockIdx.y * 64 + lane;
+    const bool have = k < n_in;
+    const uint32_t i0 = g * 64, ni = min(64u, batch - i0);
+    uint64_t mine = 0, badmask = 0;
+    for (uint32_t ii = 0; ii < ni; ii++) {
         uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
-        if (valid) {
-            const size_t src = ((size_t)i * n_in + k0 + kk) * 2;
+        if (have) {
+            const size_t src = ((size_t)(i0 + ii) * n_in + k) * 2;
             lo = in[src];
             hi = in[src + 1];
         }
         const bool isbit = (lo.x <= 1u) & ((lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) == 0u);
-        bad |= !isbit;
-        const uint64_t m = __ballot(valid && (lo.x & 1u));
-        if (lane == kk) mine = m;
+        mine |= (uint64_t)(lo.x & 1u) << ii;
+        if (__any(!isbit)) badmask |= 1ull << ii;                   // wave-uniform
     }
-    if (lane < kn) T[(size_t)g * slots + input_slot0 + k0 + lane] = mine;
-    const uint64_t bm = __ballot(valid && bad);
-    if (lane == 0 && bm) atomicOr((unsigned long long *)&fbmask[g], (unsigned long long)bm);
+    if (have) T[(size_t)g * slots + input_slot0 + k] = mine;
+    if (lane == 0 && badmask) atomicOr((unsigned long long *)&fbmask[g], (unsigned long long)badmask);
 }
 
 // ---- the gate program ------------------------------------------------------------------------------------------------------
@@ -396,8 +393,14 @@ cw_bits_r1cs_int_kernel(const uint4 *__restrict__ chunk, uint32_t n_chunks, cons
                     uint64_t m[8];
 #pragma unroll
                     for (int k = 0; k < 8; k++) w[k] = wp[k];
+                    if (w[0] >> 31) {                                          // 8 consecutive slots: one 64-byte scalar load
+                        const uint64_t *mp = Tg + ((w[0] & 0x7FFFFFFFu) >> 5);
 #pragma unroll
-                    for (int k = 0; k < 8; k++) m[k] = Tg[w[k] >> 5];           // wave-uniform addresses: scalar loads
+                        for (int k = 0; k < 8; k++) m[k] = mp[k];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) m[k] = Tg[w[k] >> 5];       // wave-uniform addresses: scalar loads
+                    }
 #pragma unroll
                     for (int k = 0; k < 8; k++) acc |= bits_lane_bit(m[k]) << (w[k] & 31u);
                 }

@@ -77,7 +77,7 @@ struct R1Plan {
     std::vector<uint32_t> ichunk, iwords, irow_orig;   // chunk = {first word, groups, 0, first row}
     std::vector<uint32_t> itab;       // signed 64-bit value of every coefficient id (2 words each; 0 if not small)
     uint32_t n_ichunks = 0;
-    uint64_t n_trivial = 0, n_lut = 0, n_wide = 0, n_int = 0;
+    uint64_t n_trivial = 0, n_lut = 0, n_wide = 0, n_int = 0, n_int_blocks = 0, n_contig_blocks = 0;
 };
 
 // small signed value of a canonical coefficient, if |val| < 2^40
@@ -240,7 +240,30 @@ inline R1Plan build_r1cs(const std::vector<uint32_t> &r_ptr, const std::vector<u
                         g.w.push_back((pw[i][1] << 5) | pw[i][2]);
                         i++;
                     }
-                    while (g.w.size() % 8) g.w.push_back(0);
+                    // blocks of 8 terms; a block whose slots are s, s+1, .., s+7 (the bits of a word usually are, see
+                    // bitsched.py) is marked in bit 31 of its first word: the kernel then fetches the 8 masks with ONE
+                    // 64-byte scalar load.  Runs of consecutive slots are aligned to block starts by padding.
+                    std::sort(g.w.begin(), g.w.end());              // by slot
+                    std::vector<uint32_t> out;
+                    size_t a = 0;
+                    while (a < g.w.size()) {
+                        size_t run = 1;
+                        while (a + run < g.w.size() && (g.w[a + run] >> 5) == (g.w[a] >> 5) + run) run++;
+                        while (run >= 8) {
+                            while (out.size() % 8) out.push_back(0);
+                            const size_t at = out.size();
+                            for (size_t k = 0; k < 8; k++) out.push_back(g.w[a + k]);
+                            out[at] |= 1u << 31;
+                            p.n_contig_blocks++;
+                            a += 8;
+                            run -= 8;
+                        }
+                        for (size_t k = 0; k < run; k++) out.push_back(g.w[a + k]);
+                        a += run;
+                    }
+                    while (out.size() % 8) out.push_back(0);
+                    p.n_int_blocks += out.size() / 8;
+                    g.w.swap(out);
                     groups.push_back(std::move(g));
                 }
                 for (size_t k0 = 0; k0 < gen.size(); k0 += 4 * 255) {

@@ -28,6 +28,7 @@ approaches max(2 * depth, operations / 64).
 from __future__ import annotations
 
 import heapq
+import os
 
 import numpy as np
 
@@ -219,19 +220,29 @@ def lower_bits(net: BitNet, fc, ring: int = DEFAULT_RING) -> BitTape:
     n_slots = IN_BASE + n_in
     slot_of_op = {}
     lane_of_op = {}
+    first_sig = {}
+    for s_ in range(n_signals - 1, -1, -1):
+        first_sig[int(sig_node[s_])] = s_
+    by_signal = os.environ.get("CW_BITS_SLOTS", "signal") == "signal"
+    stored_all = []
     for v, lanes in enumerate(vrows):
         stored = [oi for oi in lanes if o_kind[oi] == 'G' and (is_signal[o_node[oi]] or o_node[oi] in need_home)]
         rest = [oi for oi in lanes if not (o_kind[oi] == 'G' and (is_signal[o_node[oi]] or o_node[oi] in need_home))]
-        # stored values first, ordered by the first signal they are (signals of one component array then sit in
-        # neighbouring slots): one coalesced store per vrow
-        stored.sort(key=lambda oi: o_node[oi])
+        stored.sort(key=lambda oi: first_sig.get(o_node[oi], n_signals + o_node[oi]))
         lanes[:] = stored + rest
         for lane, oi in enumerate(lanes):
             slot_of_op[oi] = v
             lane_of_op[oi] = lane
-        for oi in stored:
-            slot_of_node[o_node[oi]] = n_slots
-            n_slots += 1
+        stored_all.extend(stored)
+    if by_signal:
+        # slots in the order of the FIRST SIGNAL each stored value is: the bits of a word (consecutive signals of a
+        # component array) sit in consecutive slots, which is what the R1CS check reads together (a 32-bit word of a
+        # BinSum row = one 64-byte scalar load per 8 bits); values that are no signal (re-load temps) follow
+        stored_all.sort(key=lambda oi: first_sig.get(o_node[oi], n_signals + o_node[oi]))
+    # (otherwise: in program order — neighbouring lanes of a vrow store to neighbouring slots)
+    for oi in stored_all:
+        slot_of_node[o_node[oi]] = n_slots
+        n_slots += 1
     sig_slot = np.zeros(n_signals, dtype=np.uint32)
     for s_ in range(n_signals):
         sig_slot[s_] = slot_of_node[int(sig_node[s_])]
