@@ -1762,6 +1762,128 @@ extern "C" int cw_write_wtns(cw_batch *b, uint32_t instance, const char *path) {
     return CW_OK;
 }
 
+// Many instances -> many .wtns files (one bulk device transpose per 256 MiB instead of one gather per instance):
+// `pattern` is a printf pattern with one %u / %d (the instance number).  What a prover farm consumes.
+extern "C" int cw_write_wtns_many(cw_batch *b, uint32_t first, uint32_t count, const char *pattern) {
+    if (!b || !pattern) return fail(CW_EINVAL, "null argument");
+    if ((uint64_t)first + count > b->batch) return fail(CW_EINVAL, "instance range out of the batch");
+    {   // exactly one integer conversion, nothing else
+        int convs = 0;
+        for (const char *p = pattern; *p; p++)
+            if (*p == '%') {
+                if (p[1] == '%') { p++; continue; }
+                const char *q = p + 1;
+                while (*q >= '0' && *q <= '9') q++;
+                if (*q != 'u' && *q != 'd') return fail(CW_EINVAL, "pattern may only hold one %u / %d conversion");
+                convs++;
+            }
+        if (convs != 1) return fail(CW_EINVAL, "pattern must hold exactly one %u / %d conversion");
+    }
+    cw_circuit *c = b->c;
+    const size_t row = (size_t)c->n_witness * 32;
+    const uint32_t per = (uint32_t)std::max<size_t>(1, std::min<size_t>(count, ((size_t)256 << 20) / std::max<size_t>(row, 1)));
+    std::vector<uint8_t> buf((size_t)per * row);
+    for (uint32_t done = 0; done < count; done += per) {
+        const uint32_t n = std::min(per, count - done);
+        int rc = cw_get_witnesses(b, first + done, n, buf.data());
+        if (rc) return rc;
+        for (uint32_t k = 0; k < n; k++) {
+            char path[4096];
+            snprintf(path, sizeof path, pattern, first + done + k);
+            FILE *f = fopen(path, "wb");
+            if (!f) return fail(CW_EIO, std::string("cannot open for writing: ") + path);
+            uint32_t version = 2, nsec = 2, id1 = 1, n8 = 32, id2 = 2, nw = c->n_witness;
+            uint64_t len1 = 8 + n8, len2 = (uint64_t)n8 * nw;
+            fwrite("wtns", 4, 1, f); fwrite(&version, 4, 1, f); fwrite(&nsec, 4, 1, f);
+            fwrite(&id1, 4, 1, f); fwrite(&len1, 8, 1, f); fwrite(&n8, 4, 1, f); fwrite(c->q.w, 32, 1, f); fwrite(&nw, 4, 1, f);
+            fwrite(&id2, 4, 1, f); fwrite(&len2, 8, 1, f);
+            fwrite(buf.data() + (size_t)k * row, 1, row, f);
+            fclose(f);
+        }
+    }
+    return CW_OK;
+}
+
+// Debug trace of one instance (the reference prints template, line and the component trace of a failed `===` and
+// aborts: c_code_generator.rs:461-468, calcwit.cpp:104-114).  Here: status word decoded, and for a violated
+// constraint its index, every wire with its .sym name (constraint_writers sym format: "s,w,c,name" per line) and value.
+static std::string u256_dec(const uint8_t le[32]) {
+    uint32_t limb[8];
+    memcpy(limb, le, 32);
+    std::string out;
+    bool nz = true;
+    while (nz) {
+        uint64_t rem = 0;
+        nz = false;
+        for (int i = 7; i >= 0; i--) {
+            uint64_t cur = (rem << 32) | limb[i];
+            limb[i] = (uint32_t)(cur / 1000000000u);
+            rem = cur % 1000000000u;
+            if (limb[i]) nz = true;
+        }
+        char tmp[16];
+        snprintf(tmp, sizeof tmp, nz ? "%09u" : "%u", (unsigned)rem);
+        out = std::string(tmp) + out;
+    }
+    return out;
+}
+extern "C" int cw_explain(cw_batch *b, uint32_t instance, const char *sym_path, char *out, size_t out_len) {
+    if (!b || !out || out_len == 0) return fail(CW_EINVAL, "null argument");
+    if (instance >= b->batch) return fail(CW_EINVAL, "instance out of range");
+    cw_circuit *c = b->c;
+    std::vector<uint32_t> st(b->batch), fb(b->batch);
+    int rc = cw_get_status(b, st.data());
+    if (rc == CW_OK) rc = cw_get_r1cs_first_bad(b, fb.data());
+    if (rc) return rc;
+    std::vector<std::string> names;
+    if (sym_path) {
+        std::vector<uint8_t> buf;
+        if (!read_file(sym_path, buf)) return fail(CW_EIO, std::string(".sym file not found: ") + sym_path);
+        names.assign(c->n_signals, std::string());
+        size_t i = 0;
+        while (i < buf.size()) {
+            size_t e = i;
+            while (e < buf.size() && buf[e] != '\n') e++;
+            std::string line((const char *)buf.data() + i, e - i);
+            i = e + 1;
+            size_t c1 = line.find(','), c2 = line.find(',', c1 + 1), c3 = line.find(',', c2 + 1);
+            if (c1 == std::string::npos || c2 == std::string::npos || c3 == std::string::npos) continue;
+            unsigned long sid = strtoul(line.c_str(), nullptr, 10);
+            if (sid < names.size()) names[sid] = line.substr(c3 + 1);
+        }
+    }
+    auto name_of = [&](uint32_t sgn) {
+        if (sgn == 0) return std::string("one");
+        if (sgn < names.size() && !names[sgn].empty()) return names[sgn];
+        return "signal " + std::to_string(sgn);
+    };
+    std::string t = "instance " + std::to_string(instance) + ": ";
+    const uint32_t s = st[instance];
+    if (s == 0) t += "ok\n";
+    if (s & CW_ST_ASSERT_FAILED) t += "a run-time check (=== / assert) failed at schedule row " + std::to_string(s >> 8) + "\n";
+    if (s & CW_ST_ARITH) t += "integer division or modulo by zero at schedule row " + std::to_string(s >> 8) + "\n";
+    if (s & CW_ST_R1CS_FAILED) {
+        const uint32_t k = fb[instance];
+        t += "constraint " + std::to_string(k) + " of the .r1cs is violated: A*B - C != 0 with\n";
+        for (size_t j = 0; j < c->r_orig.size(); j++) {
+            if ((c->r_orig[j] & 0x7FFFFFFFu) != k) continue;
+            for (int part = 0; part < 3; part++) {
+                t += std::string("  ") + "ABC"[part] + ":";
+                for (uint32_t q = c->r_ptr[3 * j + part]; q < c->r_ptr[3 * j + part + 1]; q++) {
+                    uint8_t v[32];
+                    rc = cw_get_signal(b, instance, c->r_slot[q], v);
+                    if (rc) return rc;
+                    t += " " + name_of(c->r_slot[q]) + " = " + u256_dec(v) + ";";
+                }
+                t += "\n";
+            }
+            break;
+        }
+    }
+    snprintf(out, out_len, "%s", t.c_str());
+    return CW_OK;
+}
+
 extern "C" void *cw_device_values(cw_batch *b, uint64_t *n_bytes, uint32_t *padded_batch) {
     if (!b) return nullptr;
     if (b->bitmode) {                       // no 256-bit table exists: see cw_device_bits

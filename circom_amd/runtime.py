@@ -82,6 +82,8 @@ _SIGS = {
     "cw_get_signal": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p]),
     "cw_write_wtns": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p]),
     "cw_get_r1cs_first_bad": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cw_write_wtns_many": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p]),
+    "cw_explain": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_size_t]),
     "cw_r1cs_plan_stats": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "cw_device_values": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "cw_fp_mul_bench": (C.c_int, [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -263,6 +265,14 @@ class Batch:
         buf = C.create_string_buffer(32)
         _chk(lib().cw_get_signal(self.h, instance, slot, buf))
         return int.from_bytes(buf.raw, "little")
+
+    def write_wtns_many(self, first: int, count: int, pattern: str):
+        _chk(lib().cw_write_wtns_many(self.h, first, count, os.fsencode(str(pattern))))
+
+    def explain(self, instance: int, sym_path=None) -> str:
+        buf = C.create_string_buffer(1 << 16)
+        _chk(lib().cw_explain(self.h, instance, None if sym_path is None else os.fsencode(str(sym_path)), buf, len(buf)))
+        return buf.value.decode()
 
     def write_wtns(self, instance: int, path):
         _chk(lib().cw_write_wtns(self.h, instance, os.fsencode(str(path))))

@@ -119,6 +119,12 @@ int cw_get_public_device(cw_batch *b, void *d_out);
 int cw_get_signal(cw_batch *b, uint32_t instance, uint32_t slot, uint8_t out[32]);
 /* writeBinWitness (main.cpp:288-334) */
 int cw_write_wtns(cw_batch *b, uint32_t instance, const char *path);
+/* `count` .wtns files from one bulk device transpose; `pattern` = printf pattern with one %u (instance number) */
+int cw_write_wtns_many(cw_batch *b, uint32_t first, uint32_t count, const char *pattern);
+/* human-readable trace of one instance into out[out_len]: decoded status word and, for a violated constraint, its index
+ * and every wire with its name from <name>.sym (may be NULL) and value — the batch counterpart of the trace the
+ * reference prints before aborting (c_code_generator.rs:461-468, calcwit.cpp:104-114) */
+int cw_explain(cw_batch *b, uint32_t instance, const char *sym_path, char *out, size_t out_len);
 /* first violated constraint per instance after cw_check_r1cs: [batch], 0xFFFFFFFF = none */
 int cw_get_r1cs_first_bad(cw_batch *b, uint32_t *row);
 /* host-only: build and hazard-check the LDS staging plan of the R1CS check kernel for `chunks` row chunks

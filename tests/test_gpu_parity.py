@@ -339,3 +339,33 @@ def test_process_level_cli_matches_reference_cli_contract(tmp_path):
     for k, v in ((0, vecs[0]), (1, vecs[2]), (3, vecs[3])):
         assert (tmp_path / ("w_%d.wtns" % k)).read_bytes().hex() == v["wtns_hex"]
     assert not (tmp_path / "w_2.wtns").exists()
+
+
+def test_bulk_wtns_files_and_failure_trace(tmp_path):
+    """many .wtns files from one bulk transpose (byte-equal to the per-instance writer), and a readable
+    trace of a failing instance with the .sym names of the violated constraint's wires."""
+    from circom_amd.compiler import compile_program
+    cp = compile_program(Program(FlakyChain(6)), str(tmp_path), "flaky6", sym=True)
+    c = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
+    B = 70
+    b = c.batch(B)
+    b.set_inputs([[i, 100 + i] for i in range(B)])
+    b.run(); b.check_r1cs(); b.sync()
+    b.write_wtns_many(3, 66, str(tmp_path / "w_%u.wtns"))
+    for i in (3, 40, 68):
+        b.write_wtns(i, tmp_path / "one.wtns")
+        assert (tmp_path / ("w_%d.wtns" % i)).read_bytes() == (tmp_path / "one.wtns").read_bytes()
+    assert not (tmp_path / "w_2.wtns").exists() and not (tmp_path / "w_69.wtns").exists()
+    with pytest.raises(rt.CwError):
+        b.write_wtns_many(0, 2, str(tmp_path / "no_conversion.wtns"))
+    fb = b.r1cs_first_bad()
+    text = b.explain(5, cp.sym_path)
+    assert "constraint %d" % fb[5] in text and "main.x[" in text and "violated" in text
+    w = b.witness(5)
+    k = int(fb[5])
+    a_, b_, c_ = cp.flat.constraints[k]
+    for sgn in list(a_) + list(b_) + list(c_):
+        if sgn > 0:
+            assert " = %d;" % w[sgn] in text
+    assert "instance 5" in b.explain(5)                 # without a .sym: signal numbers
+    b.close(); c.close()
