@@ -215,6 +215,8 @@ struct cw_circuit {
     // r1cs (CSR)
     uint32_t n_constraints = 0;
     std::vector<uint32_t> r_ptr, r_slot, r_coef, r_ctab, r_orig;
+    // circom functions with run-time control flow (D_CALL): concatenated bytecode + per function {first ins, n ins, n regs}
+    std::vector<uint32_t> fn_code, fn_tab;
     // bit-plane program (cw_bits.hip) when every signal of the circuit is provably boolean for 0/1 inputs
     bool has_bits = false;
     cwbits::Program bits;
@@ -244,7 +246,8 @@ static bool read_file(const char *path, std::vector<uint8_t> &buf) {
 
 // Every index a schedule variant carries is checked once at load time, so that a damaged or hostile file is rejected
 // instead of indexing out of bounds later (here, in the per-batch row resolution, or on the device).
-static const char *validate_variant(const Variant &v, uint32_t n_signals, uint32_t n_consts, uint32_t n_lconsts) {
+static const char *validate_variant(const Variant &v, uint32_t n_signals, uint32_t n_consts, uint32_t n_lconsts,
+                                    const std::vector<uint32_t> &fn_regs) {
     const size_t nrows = v.rows.size(), nextras = v.extras.size(), nterms = v.terms.size() / 4;
     auto mono = [&](const std::vector<uint32_t> &o, size_t limit) {
         if (o.size() != v.n_strands + 1 || o[0] != 0) return false;
@@ -287,6 +290,10 @@ static const char *validate_variant(const Variant &v, uint32_t n_signals, uint32
                 if (bk == K_CONST ? row.b >= n_consts : (bk != 0 || row.b != 0)) return "constant out of range";
             } else if (op == D_BIT) {
                 if (!operand_ok(ak, row.a)) return "operand out of range";
+            } else if (op == D_CALL) {
+                // a = function id; b = first register: the whole window must lie inside the temp slots
+                if (row.a >= fn_regs.size() || bk != K_TMP || (uint64_t)row.b + fn_regs[row.a] > v.n_tslots) return "function call out of range";
+                if (v.n_strands != 1) return "function calls need a single-strand schedule";
             } else {
                 if (!operand_ok(ak, row.a)) return "operand out of range";
                 const bool pair = (op == D_MULC || op == D_MADDC);
@@ -329,7 +336,8 @@ static int load_tape(cw_circuit *c, const char *path) {
     if (m[7] != CW_RBITS) return fail(CW_EIO, "tape was lowered for a different Montgomery radix");
     uint32_t n_lconsts = m[8];
     c->n_pub_in = m[9];
-    const uint32_t n_bit_programs = m[10];
+    const uint32_t n_bit_programs = m[10], n_functions = m[11];
+    if (n_functions > (1u << 16)) return fail(CW_EIO, "tape header: too many functions");
     if (n_bit_programs > 1) return fail(CW_EIO, "tape header: more than one bit-plane program");
     // shape of the main component: slot 0 is the constant 1, outputs from slot 1, inputs right after them
     if (c->input_start == 0 || (uint64_t)c->input_start + c->n_inputs > c->n_signals || c->n_pub_in > c->n_inputs ||
@@ -376,6 +384,49 @@ static int load_tape(cw_circuit *c, const char *path) {
         if (!c->input_names.emplace(name, std::make_pair(ss[0], ss[1])).second)
             return fail(CW_EIO, "tape input name appears twice");
     }
+    // circom functions (device bytecode): every register, constant, jump target and array window is checked here once
+    std::vector<uint32_t> fn_regs;
+    for (uint32_t fi = 0; fi < n_functions; fi++) {
+        if (off + 8 > b.size()) return fail(CW_EIO, "tape functions truncated");
+        uint32_t fh[2];
+        memcpy(fh, b.data() + off, 8);
+        off += 8;
+        const uint32_t n_regs = fh[0], n_ins = fh[1];
+        if (n_regs == 0 || n_regs >= (1u << 16) || n_ins == 0 || n_ins > (1u << 24) || (size_t)n_ins * 16 > b.size() - off)
+            return fail(CW_EIO, "tape function: bad size");
+        const uint32_t first = (uint32_t)(c->fn_code.size() / 4);
+        c->fn_code.resize(c->fn_code.size() + (size_t)n_ins * 4);
+        memcpy(&c->fn_code[(size_t)first * 4], b.data() + off, (size_t)n_ins * 16);
+        off += (size_t)n_ins * 16;
+        auto opnd_ok = [&](uint32_t x) { return (x & FN_CONST) ? (x & 0x7FFFFFFFu) < c->n_consts : x < n_regs; };
+        for (uint32_t i = 0; i < n_ins; i++) {
+            const uint32_t *ins = &c->fn_code[((size_t)first + i) * 4];
+            const uint32_t op = ins[0], d = ins[1], a = ins[2], bb = ins[3];
+            bool ok;
+            switch (op) {
+            case F_RET: ok = true; break;
+            case F_JMP: ok = d < n_ins; break;
+            case F_JZ: ok = d < n_ins && opnd_ok(a); break;
+            case F_LDX: ok = d < n_regs && (bb & 0xFFFFu) < n_regs && (uint64_t)a + (bb >> 16) <= n_regs && (bb >> 16) > 0; break;
+            case F_STX: ok = opnd_ok(a) && (bb & 0xFFFFu) < n_regs && (uint64_t)d + (bb >> 16) <= n_regs && (bb >> 16) > 0; break;
+            case F_DIV: case D_MUL2: case D_ADD: case D_SUB: case D_IDIV: case D_MOD: case D_POW: case D_SHL: case D_SHR:
+            case D_BAND: case D_BOR: case D_BXOR: case D_LT: case D_GT: case D_LEQ: case D_GEQ: case D_EQ: case D_NEQ:
+            case D_LAND: case D_LOR:
+                ok = d < n_regs && opnd_ok(a) && opnd_ok(bb); break;
+            case D_COPY: case D_NEG: case D_BNOT: case D_LNOT:
+                ok = d < n_regs && opnd_ok(a); break;
+            default: ok = false;
+            }
+            if (!ok) return fail(CW_EIO, "tape function: bad instruction");
+        }
+        if (c->fn_code[((size_t)first + n_ins - 1) * 4] != F_RET) return fail(CW_EIO, "tape function does not end with a return");
+        c->fn_tab.push_back(first);
+        c->fn_tab.push_back(n_ins);
+        c->fn_tab.push_back(n_regs);
+        c->fn_tab.push_back(0);
+        fn_regs.push_back(n_regs);
+        c->need_full = true;               // the interpreter lives in the full-operator kernel variant
+    }
     if (n_variants == 0) return fail(CW_EIO, "tape holds no schedule");
     for (uint32_t v = 0; v < n_variants; v++) {
         if (off + 32 > b.size()) return fail(CW_EIO, "tape variant truncated");
@@ -410,7 +461,7 @@ static int load_tape(cw_circuit *c, const char *path) {
         memcpy(var.terms.data(), b.data() + off, (size_t)nterms * 16);
         off += (size_t)nterms * 16;
         if (nterms < 4 || nextras < 4) return fail(CW_EIO, "tape variant: tables lack their padding");
-        if (const char *why = validate_variant(var, c->n_signals, c->n_consts, n_lconsts))
+        if (const char *why = validate_variant(var, c->n_signals, c->n_consts, n_lconsts, fn_regs))
             return fail(CW_EIO, std::string("tape variant: ") + why);
         if (var.term_off[var.n_strands] + 4 != nterms) return fail(CW_EIO, "tape variant: bad term offsets");
         {   // DOTC terms must index the limb-form constant table
@@ -784,6 +835,7 @@ struct cw_batch {
     uint64_t *d_extras = nullptr, *d_terms = nullptr;
     uint32_t *d_term_off = nullptr;
     uint32_t *d_lconsts = nullptr;
+    uint32_t *d_fncode = nullptr, *d_fntab = nullptr;   // circom functions (D_CALL)
     uint32_t *d_consts = nullptr, *d_w2s = nullptr, *d_status = nullptr, *d_first_bad = nullptr;
     // R1CS check plan (cw_r1cs_plan.h) on the device; r1_entries != 0 selects the LDS-staged kernel
     uint32_t *d_rctab = nullptr, *d_rctab29 = nullptr, *d_pchunk = nullptr, *d_prec = nullptr, *d_pterms = nullptr, *d_prow = nullptr;
@@ -837,6 +889,8 @@ extern "C" void cw_batch_free(cw_batch *b) {
                      b->d_ichunk, b->d_iterms, b->d_itab, b->d_irow, b->d_sigslot};
     for (void *p : bptrs)
         if (p) hipFree(p);
+    if (b->d_fncode) hipFree(b->d_fncode);
+    if (b->d_fntab) hipFree(b->d_fntab);
     void *ptrs[] = {b->d_V, b->d_rows, b->d_stream_off, b->d_extras, b->d_extra_off, b->d_terms, b->d_term_off, b->d_lconsts, b->d_consts, b->d_w2s, b->d_status, b->d_first_bad,
                     b->d_rctab, b->d_rctab29, b->d_pchunk, b->d_prec, b->d_pterms, b->d_prow,
                     b->d_in, b->d_gather, b->d_bulk};
@@ -969,6 +1023,10 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
                     d.dst_off = dk == KD_NONE ? 0 : resolve(dk, row.dst);
                     d.a_off = 0;
                     d.b_off = resolve(bk, row.b);                    // constant term c0 (kind CONST) or nothing
+                } else if (op == D_CALL) {
+                    d.aux = row.a;                                   // function id
+                    d.dst_off = d.a_off = 0;
+                    d.b_off = resolve(K_TMP, row.b);                 // first register of the call's window
                 } else if (op == D_BIT) {
                     d.aux = row.b;                                   // bit index k
                     d.dst_off = dk == KD_NONE ? 0 : resolve(dk, row.dst);
@@ -1026,6 +1084,8 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
         TRY(hipStreamSynchronize(b->stream));                        // host vectors go out of scope
     }
     TRY(upload(&b->d_consts, c->consts, b->stream));
+    TRY(upload(&b->d_fncode, c->fn_code, b->stream));
+    TRY(upload(&b->d_fntab, c->fn_tab, b->stream));
     TRY(upload(&b->d_lconsts, c->lconsts, b->stream));
     TRY(upload(&b->d_w2s, c->w2s, b->stream));
     TRY(hipMalloc((void **)&b->d_status, (size_t)b->Bp * 4));
@@ -1515,8 +1575,8 @@ extern "C" int cw_run(cw_batch *b) {
     HIPCHK(cwk_init(b->stream, b->d_V, b->Bp, b->d_status, b->d_first_bad));
     HIPCHK(cwk_ingest(b->stream, in, b->d_V, c->input_start, c->n_inputs, b->batch, b->Bp));
     HIPCHK(cwk_eval(b->stream, c->need_full, b->var->wide_linsum, b->d_rows, b->d_stream_off, b->d_extras, b->d_extra_off, b->d_terms,
-                    b->d_term_off, b->var->n_strands, b->var->n_lds, b->d_V, b->d_consts, b->d_lconsts, b->Bp, b->batch,
-                    b->lanes, b->prio_mask, b->d_status, c->P));
+                    b->d_term_off, b->var->n_strands, b->var->n_lds, b->d_V, b->d_consts, b->d_lconsts, b->d_fncode, b->d_fntab,
+                    (uint64_t)2 * b->Bp * 16, b->Bp, b->batch, b->lanes, b->prio_mask, b->d_status, c->P));
     b->ran = true;
     return CW_OK;
 }

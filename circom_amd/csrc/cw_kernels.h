@@ -10,6 +10,7 @@ hipError_t cwk_ingest(hipStream_t s, const void *in, void *V, uint32_t input_sta
 hipError_t cwk_eval(hipStream_t s, bool full, bool wide_linsum, const CwDRow *rows, const uint32_t *stream_off,
                     const uint64_t *extras, const uint32_t *extra_off, const uint64_t *terms, const uint32_t *term_off,
                     uint32_t n_strands, uint32_t n_lds, void *V, const uint32_t *consts, const uint32_t *lconsts,
+                    const uint32_t *fncode, const uint32_t *fntab, uint64_t slot_stride,
                     uint32_t Bp, uint32_t batch, uint32_t lanes, uint32_t prio_mask, uint32_t *status, const FpParams &P);
 hipError_t cwk_r1cs(hipStream_t s, const uint32_t *chunk, uint32_t n_chunks, const uint32_t *terms, const uint32_t *ctab,
                     const uint32_t *ctab29, const uint32_t *row_orig, const void *V, uint32_t Bp, uint32_t batch, uint32_t *status,

@@ -117,6 +117,9 @@ struct EvalCtx {                         // per-wave constants of the interprete
     uint32_t tp;                         // ... and the running position in it
     uint32_t vlo, vhi;                   // this lane's byte offsets of the lo/hi half inside a value slot
     uint32_t lane16;                     // lane * 16 (LDS)
+    const uint4 *fcode;                  // bytecode of circom functions (D_CALL), all functions concatenated
+    const uint4 *ftab;                   // per function {first instruction, n instructions, n registers, -}
+    uint64_t slot_stride;                // bytes between consecutive value slots (2 * Bp * 16)
 };
 
 __device__ __forceinline__ fe lds_load_off(uint32_t slot_off, const EvalCtx &c) {
@@ -262,6 +265,112 @@ __device__ __forceinline__ fe eval_dotc(uint32_t n, const fe &c0, const fe &prev
     return res;
 }
 
+// ---- D_CALL: a circom function with run-time control flow, interpreted per lane ---------------------------------------
+// Reference: the emitted C++ of a function is real control flow on Fr_isTrue / Fr_toInt (loop_bucket.rs:76-91,
+// branch_bucket.rs:100-122, compute_bucket.rs:361-363, call_bucket.rs:466-533); the trip counts differ per input, so the
+// trace cannot unroll it.  Every lane has its own program counter; per turn the wave executes the instruction of its
+// first unfinished lane for all lanes that sit on it (SIMT divergence, lanes elsewhere wait their turn).  Registers are
+// 256-bit values in the lane's column of consecutive temp slots (the call's window): operand loads and result stores
+// go to the value table like any spilled temporary — this is the slow path by design (tier 2).
+__device__ __forceinline__ fe fn_operand(uint32_t x, const char *regs, const EvalCtx &c) {
+    if (x & FN_CONST) return c_load((const uint32_t *)c.Cb, x & 0x7FFFFFFFu);
+    const char *p = regs + (uint64_t)x * c.slot_stride;
+    const uint4 lo = *(const uint4 *)(p + c.vlo), hi = *(const uint4 *)(p + c.vhi);
+    fe r;
+    r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
+    r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+    return r;
+}
+__device__ __forceinline__ void fn_store(uint32_t r, char *regs, const EvalCtx &c, const fe &x) {
+    char *p = regs + (uint64_t)r * c.slot_stride;
+    *(uint4 *)(p + c.vlo) = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    *(uint4 *)(p + c.vhi) = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+}
+// Fr_toInt (generic/fr.cpp:1146-1170) restricted to what an array address can be: [0, n) or "bad"
+__device__ __forceinline__ bool fn_index(const fe &v, uint32_t n, uint32_t *out) {
+    uint32_t hi = 0;
+    FE_UNROLL for (int k = 1; k < 8; k++) hi |= v.v[k];
+    *out = v.v[0];
+    return hi == 0 && v.v[0] < n;
+}
+__device__ __noinline__ void eval_call(uint32_t fn, uint64_t reg_off, uint32_t row_id, uint32_t &st, const EvalCtx &c, const FpParams &P) {
+    const uint4 ft = c.ftab[fn];
+    const uint4 *code = c.fcode + ft.x;
+    char *regs = (char *)c.Vb + reg_off;
+    uint32_t pc = 0, steps = 0;
+    bool done = false;
+    while (__any(!done)) {
+        if (!done) {
+            const uint32_t cur = __builtin_amdgcn_readfirstlane(pc);     // the first unfinished lane's instruction
+            if (pc == cur) {
+                const uint4 ins = code[cur];                              // wave-uniform
+                const uint32_t op = ins.x, d = ins.y;
+                pc = cur + 1;
+                if (++steps > CW_CALL_STEP_LIMIT) {
+                    if (st == 0) st = CW_ST_ARITH | (row_id << 8);
+                    done = true;
+                } else if (op == F_RET) {
+                    done = true;
+                } else if (op == F_JMP) {
+                    pc = d;
+                } else if (op == F_JZ) {
+                    if (fe_is_zero(fn_operand(ins.z, regs, c))) pc = d;
+                } else if (op == F_LDX || op == F_STX) {
+                    uint32_t idx;
+                    if (!fn_index(fn_operand(ins.w & 0xFFFFu, regs, c), ins.w >> 16, &idx)) {
+                        if (st == 0) st = CW_ST_ARITH | (row_id << 8);
+                        idx = 0;
+                    }
+                    if (op == F_LDX) fn_store(d, regs, c, fn_operand(ins.z + idx, regs, c));
+                    else fn_store(d + idx, regs, c, fn_operand(ins.z, regs, c));
+                } else {
+                    const fe a = fn_operand(ins.z, regs, c);
+                    fe b = fe_zero();
+                    if (op != D_COPY && op != D_NEG && op != D_BNOT && op != D_LNOT) b = fn_operand(ins.w, regs, c);
+                    fe r = fe_zero();
+                    switch (op) {
+                    case D_COPY: r = a; break;
+                    case D_ADD: r = fe_add(a, b, P); break;
+                    case D_SUB: r = fe_sub(a, b, P); break;
+                    case D_NEG: r = fe_neg(a, P); break;
+                    case D_MUL2: r = fe_mul2_auto(a, b, P); break;
+                    case F_DIV: r = fe_mul2_auto(a, fe_inv(b, P), P); break;
+                    case D_IDIV:
+                    case D_MOD: {
+                        fe qq, rr;
+                        if (fe_is_zero(b)) {
+                            if (st == 0) st = CW_ST_ARITH | (row_id << 8);
+                        } else {
+                            fe_divmod(a, b, &qq, &rr);
+                            r = (op == D_IDIV) ? qq : rr;
+                        }
+                        break;
+                    }
+                    case D_POW: r = fe_pow(a, b, P); break;
+                    case D_SHL: r = fe_shl(a, b, P); break;
+                    case D_SHR: r = fe_shr(a, b, P); break;
+                    case D_BAND: r = fe_band(a, b, P); break;
+                    case D_BOR: r = fe_bor(a, b, P); break;
+                    case D_BXOR: r = fe_bxor(a, b, P); break;
+                    case D_BNOT: r = fe_bnot(a, P); break;
+                    case D_LT: r = fe_small(fe_lt(a, b, P)); break;
+                    case D_GT: r = fe_small(fe_lt(b, a, P)); break;
+                    case D_LEQ: r = fe_small(!fe_lt(b, a, P)); break;
+                    case D_GEQ: r = fe_small(!fe_lt(a, b, P)); break;
+                    case D_EQ: r = fe_small(fe_eq(a, b)); break;
+                    case D_NEQ: r = fe_small(!fe_eq(a, b)); break;
+                    case D_LAND: r = fe_small(!fe_is_zero(a) & !fe_is_zero(b)); break;
+                    case D_LOR: r = fe_small(!fe_is_zero(a) | !fe_is_zero(b)); break;
+                    case D_LNOT: r = fe_small(fe_is_zero(a)); break;
+                    default: break;
+                    }
+                    fn_store(d, regs, c, r);
+                }
+            }
+        }
+    }
+}
+
 // One interpreter step: executes `row` with operands (xa, xb) while the operands of `nrow` are requested into
 // (ya, yb).  The loop calls it twice per iteration with the two register sets swapped (no rotation moves).
 template <bool FULL_OPS, int LW>
@@ -359,6 +468,10 @@ __device__ __forceinline__ void eval_step(const CwDRow &row, const fe &xa, const
         if (FULL_OPS) {
             switch (op) {
             case D_INV: d = fe_inv(a, P); break;
+            case D_CALL:
+                eval_call(row.aux, row.b_off, r, st, c, P);
+                has_d = false;
+                break;
             case D_POW: d = fe_pow(a, b, P); break;
             case D_IDIV:
             case D_MOD: {
@@ -418,7 +531,8 @@ __global__ void __launch_bounds__(1024)
 cw_eval_kernel(const CwDRow *__restrict__ rows, const uint32_t *__restrict__ stream_off,
                const uint64_t *__restrict__ extras, const uint32_t *__restrict__ extra_off,
                const uint64_t *__restrict__ terms, const uint32_t *__restrict__ term_off, uint4 *V,
-               const uint32_t *__restrict__ consts, const uint32_t *__restrict__ lconsts, uint32_t Bp, uint32_t batch,
+               const uint32_t *__restrict__ consts, const uint32_t *__restrict__ lconsts, const uint4 *__restrict__ fcode,
+               const uint4 *__restrict__ ftab, uint64_t slot_stride, uint32_t Bp, uint32_t batch,
                uint32_t lanes, uint32_t prio_mask, uint32_t *status, FpParams P) {
     // strand executed by this wave: rotated by the workgroup index, so that the strand carrying the critical chain
     // (the same one in every workgroup) does not land on the same SIMD of the CU in all co-resident workgroups
@@ -440,6 +554,9 @@ cw_eval_kernel(const CwDRow *__restrict__ rows, const uint32_t *__restrict__ str
     c.vhi = i * 16u + Bp * 16u;
     c.lane16 = lane * 16u;
     c.Lb = lconsts;
+    c.fcode = fcode;
+    c.ftab = ftab;
+    c.slot_stride = slot_stride;
     c.terms = terms;
     c.tp = term_off[wave];
     // every stream is padded with 3 NOP rows, so rows[r+1..r+3] are always readable
@@ -752,12 +869,13 @@ hipError_t cwk_ingest(hipStream_t s, const void *in, void *V, uint32_t input_sta
 hipError_t cwk_eval(hipStream_t s, bool full, bool wide_linsum, const CwDRow *rows, const uint32_t *stream_off,
                     const uint64_t *extras, const uint32_t *extra_off, const uint64_t *terms, const uint32_t *term_off,
                     uint32_t n_strands, uint32_t n_lds, void *V, const uint32_t *consts, const uint32_t *lconsts,
+                    const uint32_t *fncode, const uint32_t *fntab, uint64_t slot_stride,
                     uint32_t Bp, uint32_t batch, uint32_t lanes, uint32_t prio_mask, uint32_t *status, const FpParams &P) {
     dim3 grid((batch + lanes - 1) / lanes), block(64 * n_strands);
     const size_t lds_bytes = (size_t)n_lds * 2048;
     typedef void (*kern_t)(const CwDRow *, const uint32_t *, const uint64_t *, const uint32_t *, const uint64_t *,
-                           const uint32_t *, uint4 *, const uint32_t *, const uint32_t *, uint32_t, uint32_t, uint32_t,
-                           uint32_t, uint32_t *, FpParams);
+                           const uint32_t *, uint4 *, const uint32_t *, const uint32_t *, const uint4 *, const uint4 *, uint64_t,
+                           uint32_t, uint32_t, uint32_t, uint32_t, uint32_t *, FpParams);
     kern_t k = full ? (wide_linsum ? (kern_t)cw_eval_kernel<true, 4> : (kern_t)cw_eval_kernel<true, 2>)
                     : (wide_linsum ? (kern_t)cw_eval_kernel<false, 4> : (kern_t)cw_eval_kernel<false, 2>);
     if (lds_bytes > 64 * 1024) {
@@ -765,7 +883,8 @@ hipError_t cwk_eval(hipStream_t s, bool full, bool wide_linsum, const CwDRow *ro
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k, grid, block, lds_bytes, s, rows, stream_off, extras, extra_off, terms, term_off, (uint4 *)V,
-                       consts, lconsts, Bp, batch, lanes, prio_mask, status, P);
+                       consts, lconsts, (const uint4 *)fncode, (const uint4 *)fntab, slot_stride, Bp, batch, lanes, prio_mask,
+                       status, P);
     return hipGetLastError();
 }
 hipError_t cwk_r1cs(hipStream_t s, const uint32_t *chunk, uint32_t n_chunks, const uint32_t *terms, const uint32_t *ctab,

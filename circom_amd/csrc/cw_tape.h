@@ -6,7 +6,7 @@
 enum : uint32_t {
     D_COPY = 0, D_ADD, D_SUB, D_NEG, D_MMUL, D_INV, D_IDIV, D_MOD, D_POW, D_SHL, D_SHR, D_BAND, D_BOR, D_BXOR,
     D_BNOT, D_LT, D_GT, D_LEQ, D_GEQ, D_EQ, D_NEQ, D_LAND, D_LOR, D_LNOT, D_SELECT, D_EXT, D_ASSERT_EQ,
-    D_ASSERT_NZ, D_ALSO, D_BARRIER, D_MUL2, D_MADD, D_MULC, D_MADDC, D_LINSUM, D_BIT, D_DOTC, D_NOPS
+    D_ASSERT_NZ, D_ALSO, D_BARRIER, D_MUL2, D_MADD, D_MULC, D_MADDC, D_LINSUM, D_BIT, D_DOTC, D_CALL, D_NOPS
 };
 
 // row.w0 = op[0:8) | dk[8:11) | ak[11:14) | bk[14:17) | n_extra[17:29) | const flags[29:31)
@@ -41,6 +41,15 @@ struct CwDRow {      // 32 bytes, one scalar dwordx8 load
     uint64_t dst_off, a_off, b_off;
 };
 #define D_NOP 255u
+
+// D_CALL: a circom function with run-time control flow (frontend/rtcode.py; reference: call_bucket.rs:466-533,
+// loop_bucket.rs:76-91, branch_bucket.rs:100-122).  row.a = function id, operand b = first of its registers
+// (consecutive pinned temp slots).  Bytecode: 4 x u32 per instruction {opcode, dst, a, b}; opcode = D_* for arithmetic on
+// canonical values (D_MUL2 = product) or F_*; operands = register number, or FN_CONST | constant index;
+// F_LDX / F_STX: b = index register | array length << 16 (address through Fr_toInt, generic/fr.cpp:1146-1170).
+enum : uint32_t { F_JZ = 100, F_JMP = 101, F_LDX = 102, F_STX = 103, F_RET = 104, F_DIV = 105 };
+#define FN_CONST 0x80000000u
+#define CW_CALL_STEP_LIMIT (1u << 20)   // instructions per call and lane before the instance is flagged (runaway loop)
 
 // Field parameters, passed by value as a kernel argument (lands in SGPRs).
 // The device Montgomery radix is R' = 2^261 (9 limbs x 29 bits, see fp256.hip.h), NOT the reference's

@@ -568,6 +568,29 @@ class Ctx:
             return
         self._row(O.ASSERT_NZ, O.K_NONE, 0, cond)
 
+    # ---- circom functions with run-time control flow (tier 2, frontend/rtcode.py) ---------------------------------
+    def function(self, name: str, n_args: int, build):
+        """`function name(...) {...}`: built once per program (build(f, *args) -> results, see rtcode.RtFunction)"""
+        return self.prog.function(name, n_args, build)
+
+    def call(self, fn, args):
+        """`name(args)` inside `<--` code: CallBucket (call_bucket.rs:466-533).  The function's registers are a block of
+        consecutive temporaries of this instance: arguments are copied into the first ones, results are read back from
+        the registers the function reserves for them.  Returns the list of results."""
+        args = [self.lift(a) for a in args]
+        if len(args) != fn.n_args:
+            raise CircuitError("function %s takes %d arguments" % (fn.name, fn.n_args))
+        t0 = self.ntmp
+        self.ntmp += fn.n_regs
+        for k, a in enumerate(args):
+            self._row(O.COPY, K_TMP, t0 + k, a)
+        self.c_op.append(O.CALL)
+        self.c_dk.append(O.K_NONE); self.c_dv.append(0)
+        self.c_ak.append(O.K_NONE); self.c_av.append(fn.id)
+        self.c_bk.append(K_TMP); self.c_bv.append(t0)
+        self.c_ck.append(O.K_NONE); self.c_cv.append(0)
+        return [Expr(self, K_TMP, t0 + fn.ret_base + k, None) for k in range(fn.n_ret)]
+
     # ---- finalisation -----------------------------------------------------------------------------
     def finalize(self):
         inst = self.inst
@@ -660,6 +683,8 @@ class Program:
         self.constants = []
         self._const_ids = {}
         self.public = tuple(public)
+        self.functions = []            # rtcode.RtFunction, in order of first use
+        self.functions_by_name = {}
         self.main = self.instantiate(main)
         for name in self.public:
             if name not in self.main.iface or self.main.iface[name][2] != "i":
@@ -674,6 +699,21 @@ class Program:
             self._const_ids[v] = i
             self.constants.append(v)
         return i
+
+    def function(self, name: str, n_args: int, build):
+        fn = self.functions_by_name.get(name)
+        if fn is None:
+            from .rtcode import RtFunction
+            fn = RtFunction(name, n_args, build, self.fp)
+            # constants of the body live in the program-wide constant table like every other constant
+            fn.code = [tuple((x[0], self.const_id(x[1])) if isinstance(x, tuple) and len(x) == 2 and x[0] == 'c' else x
+                             for x in ins) for ins in fn.code]
+            fn.id = len(self.functions)
+            self.functions.append(fn)
+            self.functions_by_name[name] = fn
+        elif fn.n_args != n_args:
+            raise CircuitError("function %s redefined with another arity" % name)
+        return fn
 
     def instantiate(self, spec: TemplateSpec) -> TemplateInstance:
         inst = self.instances.get(spec.key)

@@ -30,6 +30,7 @@ class FlatCircuit:
         self.n_signals = 1 + m.n_total
         self.n_components = m.n_components
         self.constants = prog.constants
+        self.functions = [dict(f.as_data(), consts=prog.constants) for f in prog.functions]   # circom functions (rtcode.py)
         self.n_outputs = m.n_out
         self.n_pub_in = prog.n_public_inputs
         self.n_prv_in = m.n_in - self.n_pub_in

@@ -828,6 +828,8 @@ class _Blaster:
             o = op[i]
             if o == O.RUN:
                 continue
+            if o == O.CALL:
+                raise Unsupported("a function with run-time control flow")
             x = rd(ak[i], av[i])
             # a temporary the domains cannot express (field-sized weights, divisions, ...) only matters if it reaches a
             # signal or a run-time check: dead helper computations (sums that exist for a constraint only) are common

@@ -53,10 +53,19 @@ from ..frontend.flatten import FlatCircuit
 # device opcodes (csrc/cw_tape.h must match)
 (D_COPY, D_ADD, D_SUB, D_NEG, D_MMUL, D_INV, D_IDIV, D_MOD, D_POW, D_SHL, D_SHR, D_BAND, D_BOR, D_BXOR,
  D_BNOT, D_LT, D_GT, D_LEQ, D_GEQ, D_EQ, D_NEQ, D_LAND, D_LOR, D_LNOT, D_SELECT, D_EXT, D_ASSERT_EQ,
- D_ASSERT_NZ, D_ALSO, D_BARRIER, D_MUL2, D_MADD, D_MULC, D_MADDC, D_LINSUM, D_BIT, D_DOTC) = range(37)
+ D_ASSERT_NZ, D_ALSO, D_BARRIER, D_MUL2, D_MADD, D_MULC, D_MADDC, D_LINSUM, D_BIT, D_DOTC, D_CALL) = range(38)
 D_NAMES = ["copy", "add", "sub", "neg", "mmul", "inv", "idiv", "mod", "pow", "shl", "shr", "band", "bor",
            "bxor", "bnot", "lt", "gt", "leq", "geq", "eq", "neq", "land", "lor", "lnot", "select", "ext",
-           "assert_eq", "assert_nz", "also", "barrier", "mul2", "madd", "mulc", "maddc", "linsum", "bit", "dotc"]
+           "assert_eq", "assert_nz", "also", "barrier", "mul2", "madd", "mulc", "maddc", "linsum", "bit", "dotc", "call"]
+# D_CALL  : run the register bytecode of a circom function (frontend/rtcode.py) per lane: field a = function id, operand b
+#           = first of the function's registers, which are CONSECUTIVE pinned temp slots (arguments were stored there by
+#           ordinary rows, results are read from there by the rows after the BARRIER that follows every D_CALL: the
+#           interpreter's stores are not visible to an operand prefetched before the call).  Schedules with a D_CALL are
+#           lowered for one strand only.
+# function bytecode (device form): 4 x u32 per instruction: opcode (D_* for arithmetic, F_* below), dst, a, b; operands:
+#           register number, or FN_CONST | index into the constant table; F_LDX / F_STX: b = index register | length << 16
+F_JZ, F_JMP, F_LDX, F_STX, F_RET, F_DIV = 100, 101, 102, 103, 104, 105
+FN_CONST = 1 << 31
 # D_DOTC  : d = c0 + sum_i coef_i * x_i with ARBITRARY field coefficients: like D_LINSUM, but the second word of a
 #           term indexes the limb-form constant table (coef_i * R' as 9 x 29-bit limbs); the kernel accumulates the
 #           unreduced 29-bit-limb products of up to 4 terms and performs ONE Montgomery reduction for them
@@ -112,9 +121,10 @@ class Tape:
         self.n_pub_in = 0           # public inputs of main (`component main {public [...]}`); outputs are always public
         self.stats = {}
         self.rbits = 261            # Montgomery radix exponent of MMUL rows
+        self.functions = []         # device bytecode of circom functions: (n_regs, uint32[n,4])
 
 
-def _dce(code, n_temps):
+def _dce(code, n_temps, nregs=()):
     op = code["op"]
     n = len(op)
     keep = np.zeros(n, dtype=bool)
@@ -123,6 +133,10 @@ def _dce(code, n_temps):
     cols = ((code["ak"], code["av"]), (code["bk"], code["bv"]), (code["ck"], code["cv"]))
     for i in range(n - 1, -1, -1):
         o = op[i]
+        if o == O.CALL:             # the call and every register of its window (arguments are stored there)
+            keep[i] = True
+            live[code["bv"][i]:code["bv"][i] + nregs[code["av"][i]]] = True
+            continue
         need = (o == O.ASSERT_EQ or o == O.ASSERT_NZ or dk[i] == K_SIG or (dk[i] == K_TMP and live[dv[i]]))
         if need:
             keep[i] = True
@@ -201,7 +215,7 @@ def _expand(fc: FlatCircuit):
     if proved.any():
         code = dict(code)
         code["op"] = np.where(proved, np.uint8(O.RUN), code["op"])      # RUN rows are ignored by DCE and expansion
-    keep = _dce(code, fc.n_temps)
+    keep = _dce(code, fc.n_temps, [f["n_regs"] for f in getattr(fc, "functions", ())])
     keep &= ~proved
     idx = np.nonzero(keep)[0]
     op = code["op"][idx].tolist()
@@ -281,6 +295,11 @@ def _expand(fc: FlatCircuit):
                 rows.append(_Row(D_MMUL, dk[i], dv[i], K_TMP, t, K_CONST, cid((consts_in[av[i]] * R) % q)))
             else:
                 rows.append(_Row(D_MUL2, dk[i], dv[i], ak[i], av[i], K_TMP, t))
+        elif o == O.CALL:
+            r_ = _Row(D_CALL, KD_NONE, 0, K_NONE, av[i], K_TMP, bv[i])
+            # the arguments are operands of the call for every dependency analysis (they are read from memory)
+            r_.terms = [[K_TMP, bv[i] + k, 0] for k in range(fc.functions[av[i]]["n_args"])]
+            rows.append(r_)
         elif o == O.SELECT:
             ka, va = opnd(ak[i], av[i])
             kb, vb = opnd(bk[i], bv[i])
@@ -723,9 +742,15 @@ def _alias(rows, n_signals):
 def _schedule(rows, n_signals, n_strands):
     """Pass C.  Returns list of streams; each stream is a list whose items are _Row or the string 'B'."""
     if n_strands <= 1:
+        st = []
+        nb = 0
         for r in rows:
             r.strand = 0
-        return [list(rows)], 0
+            st.append(r)
+            if r.op == D_CALL:      # operands of the next row must not be prefetched before the call has run
+                st.append("B")
+                nb += 1
+        return [st], nb
 
     def vid(k, v):
         return v if k == K_SIG else n_signals + v
@@ -846,6 +871,40 @@ K_LDS = 4             # operand / destination kind: LDS slot of the workgroup (c
 X_TMP, X_LDS = 1 << 31, 1 << 30       # flags of an entry of the extra-destination table
 
 
+_FN_ALU = {O.COPY: D_COPY, O.ADD: D_ADD, O.SUB: D_SUB, O.NEG: D_NEG, O.MUL: D_MUL2, O.DIV: F_DIV, O.IDIV: D_IDIV, O.MOD: D_MOD,
+           O.POW: D_POW, O.SHL: D_SHL, O.SHR: D_SHR, O.BAND: D_BAND, O.BOR: D_BOR, O.BXOR: D_BXOR, O.BNOT: D_BNOT, O.LT: D_LT,
+           O.GT: D_GT, O.LEQ: D_LEQ, O.GEQ: D_GEQ, O.EQ: D_EQ, O.NEQ: D_NEQ, O.LAND: D_LAND, O.LOR: D_LOR, O.LNOT: D_LNOT}
+
+
+def _encode_function(fn, cid, q):
+    """rtcode bytecode -> device form (see the D_CALL comment at the top); constants go through the schedule's table"""
+    from ..frontend import rtcode as R
+    if fn["n_regs"] >= (1 << 16):
+        raise ValueError("function %s needs too many registers" % fn["name"])
+
+    def opnd(x, consts):
+        if x is None:
+            return 0
+        return x[1] if x[0] == 'r' else (FN_CONST | cid(consts[x[1]] % q))
+
+    out = np.zeros((len(fn["code"]), 4), dtype=np.uint32)
+    consts = fn["consts"]
+    for i, (op, d, a, b) in enumerate(fn["code"]):
+        if op == R.F_RET:
+            out[i] = (F_RET, 0, 0, 0)
+        elif op == R.F_JMP:
+            out[i] = (F_JMP, d, 0, 0)
+        elif op == R.F_JZ:
+            out[i] = (F_JZ, d, opnd(a, consts), 0)
+        elif op == R.F_LDX:
+            out[i] = (F_LDX, d, a, b[0] | (b[1] << 16))
+        elif op == R.F_STX:
+            out[i] = (F_STX, d, opnd(a, consts), b[0] | (b[1] << 16))
+        else:
+            out[i] = (_FN_ALU[op], d, opnd(a, consts), opnd(b, consts))
+    return fn["n_regs"], out
+
+
 def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
     q = fc.fp.q
     if not 225 <= q.bit_length() <= 256:
@@ -853,6 +912,9 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
                          "(the 64-bit Goldilocks runtime is a separate code path of the reference, out of scope)"
                          % (fc.prime, q.bit_length()))
     n_signals = fc.n_signals
+    functions = getattr(fc, "functions", ())
+    if functions and (fc.code["op"] == O.CALL).any():
+        n_strands = 1               # tier-2 code is the slow path: program order, one wave per 64 instances
     rows, dconsts, n_vtemps, cid, plain = _expand(fc)
     rows, n_vtemps, n_inv_batches = _batch_inversions(rows, n_vtemps, cid)
     rows, n_lin, n_bit = _fuse_linear(rows, plain, q, cid)
@@ -973,6 +1035,13 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
     # ---- pass D3: global temp slots (only temps that are actually read from global memory) ------------------------
     slot_of = {}
     n_tslots = 0
+    pinned = set()
+    for r in rows:                       # register windows of function calls: consecutive slots, never reused
+        if r.op == D_CALL:
+            for k in range(functions[r.av]["n_regs"]):
+                slot_of[r.bv + k] = n_tslots + k
+                pinned.add(r.bv + k)
+            n_tslots += functions[r.av]["n_regs"]
     tmp_last = {x - n_signals: t for x, t in mem_last.items() if x >= n_signals}
     if multi:
         by_time = sorted((def_time[n_signals + v], v) for v in tmp_last)
@@ -995,9 +1064,9 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
             release.setdefault(t, []).append(v)
         for (r, fl, t) in plan[0]:
             for v in release.get(t, ()):        # operands are read before the destination is written
-                if v in slot_of:
+                if v in slot_of and v not in pinned:
                     free.append(slot_of[v])
-            if r != "B" and r.dk == K_TMP and r.dv in tmp_last:
+            if r != "B" and r.dk == K_TMP and r.dv in tmp_last and r.dv not in pinned:
                 if free:
                     sl = free.pop()
                 else:
@@ -1046,6 +1115,9 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
                 ka, va = o_enc(r.ak, r.av, fl[0])
                 kb, vb = 0, r.bv
                 n_prev += fl[0]
+            elif r.op == D_CALL:
+                ka, va = 0, r.av                          # function id
+                kb, vb = K_TMP, slot_of[r.bv]             # first register slot
             else:
                 ka, va = o_enc(r.ak, r.av, fl[0])
                 kb, vb = o_enc(r.bk, r.bv, fl[1])
@@ -1095,6 +1167,7 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
     t.terms = tt
     t.term_off = np.asarray(term_off, dtype=np.uint32)
     t.lconsts = lconsts
+    t.functions = [_encode_function(f, cid, q) for f in functions]
     t.n_lds = n_lds_used
     t.n_strands = n_strands
     t.consts = dconsts

@@ -87,11 +87,12 @@ def write_tape(path, tapes, bittape=None):
         16  prime, n64*8 bytes
             12 x u32: n_signals, n_witness, n_consts, main_input_start, n_main_inputs, n_input_names,
                       hashmap_size, rbits (Montgomery radix exponent of MMUL rows), n_lconsts, n_public_inputs,
-                      n_bit_programs (0 | 1), 0
+                      n_bit_programs (0 | 1), n_functions
             consts          n_consts x n64*8 bytes (raw residues as the schedule expects them)
             lconsts         n_lconsts x n64*8 bytes (coef*R' of D_DOTC terms; the runtime keeps them as 29-bit limbs)
             witness2signal  n_witness x u32
             input names     per name  u32 len | bytes | u32 start | u32 size
+            functions       n_functions x { u32 n_regs | u32 n_ins | n_ins x 4 x u32 }   (device bytecode, lower.py D_CALL)
             per variant     u32 n_strands | u32 n_tslots | u32 n_rows | u32 n_extras | u32 n_lds | u32 n_terms | 2 x u32 0
                             stream_off | extra_off | term_off      ((n_strands+1) x u32 each)
                             rows n_rows x 4 x u32 | extras n_extras x u32 | terms n_terms x 4 x u32
@@ -110,13 +111,16 @@ def write_tape(path, tapes, bittape=None):
         f.write(t0.q.to_bytes(8 * n64, "little"))
         f.write(struct.pack("<12I", t0.n_signals, t0.n_witness, len(t0.consts), t0.main_input_start, t0.n_main_inputs,
                             len(t0.inputs), hashmap_size(len(t0.inputs)), t0.rbits, len(t0.lconsts), t0.n_pub_in,
-                            1 if bittape is not None else 0, 0))
+                            1 if bittape is not None else 0, len(t0.functions)))
         f.write(b"".join(c.to_bytes(8 * n64, "little") for c in t0.consts))
         f.write(b"".join(c.to_bytes(8 * n64, "little") for c in t0.lconsts))
         f.write(np.asarray(t0.witness2signal, dtype="<u4").tobytes())
         for name, start, size in t0.inputs:
             b = name.encode()
             f.write(struct.pack("<I", len(b)) + b + struct.pack("<II", start, size))
+        for n_regs, fcode in t0.functions:       # circom functions with run-time control flow (lower.py D_CALL)
+            f.write(struct.pack("<2I", n_regs, len(fcode)))
+            f.write(np.ascontiguousarray(fcode, dtype="<u4").tobytes())
         for t in tapes:
             f.write(struct.pack("<8I", t.n_strands, t.n_tslots, len(t.rows), len(t.extras), t.n_lds, len(t.terms), 0, 0))
             f.write(np.asarray(t.stream_off, dtype="<u4").tobytes())

@@ -22,7 +22,8 @@ from pathlib import Path
 COPY, ADD, SUB, MUL, DIV, IDIV, MOD, POW, NEG = range(9)
 SHL, SHR, BAND, BOR, BXOR, BNOT = range(9, 15)
 LT, GT, LEQ, GEQ, EQ, NEQ, LAND, LOR, LNOT = range(15, 24)
-SELECT, ASSERT_EQ, ASSERT_NZ, RUN = range(24, 28)
+SELECT, ASSERT_EQ, ASSERT_NZ, RUN, CALL = range(24, 29)
+F_JZ, F_JMP, F_LDX, F_STX, F_RET = 100, 101, 102, 103, 104      # circom_amd/frontend/rtcode.py
 K_SIG, K_TMP, K_CONST, K_NONE = 0, 1, 2, 3
 SYM = {ADD: "Fr_add", SUB: "Fr_sub", MUL: "Fr_mul", DIV: "Fr_div", IDIV: "Fr_idiv", MOD: "Fr_mod", POW: "Fr_pow",
        SHL: "Fr_shl", SHR: "Fr_shr", BAND: "Fr_band", BOR: "Fr_bor", BXOR: "Fr_bxor", LT: "Fr_lt", GT: "Fr_gt",
@@ -79,6 +80,9 @@ def _emit_instance(inst, out):
                 continue        # ran at creation (template.rs:274-278)
             stmts.append("assert(!(ctx->componentMemory[mySubcomponents[%d]].inputCounter)); %s_run(mySubcomponents[%d],ctx);"
                          % (ci, child.header, ci))
+            continue
+        if o == CALL:               # CallBucket (call_bucket.rs:466-533): the callee works on its own lvar arena
+            stmts.append("rtfn_%d(ctx,&expaux[%d]);" % (av[i], bv[i]))
             continue
         if o == ASSERT_EQ or o == ASSERT_NZ:
             if o == ASSERT_EQ:
@@ -147,6 +151,35 @@ def _emit_instance(inst, out):
     out.append("}")
 
 
+def _emit_function(fid, fn, out):
+    """A circom function with run-time control flow (function.rs:91-127 emits `while (Fr_isTrue(..))` / `if`; the same
+    control flow is printed here with labels and gotos): registers = the callee's lvar arena, array addresses through
+    Fr_toInt exactly as compute_bucket.rs:361-363 does (no bounds check there either)."""
+    def opnd(x):
+        return "&lvar[%d]" % x[1] if x[0] == 'r' else "&circuitConstants[%d]" % x[1]
+    out.append("static void rtfn_%d(Circom_CalcWit* ctx, FrElement* lvar){" % fid)
+    out.append("FrElement* circuitConstants = ctx->circuitConstants;")
+    for pc, (op, d, a, b) in enumerate(fn["code"]):
+        lab = "L%d: " % pc
+        if op == F_RET:
+            out.append(lab + "return;")
+        elif op == F_JMP:
+            out.append(lab + "goto L%d;" % d)
+        elif op == F_JZ:
+            out.append(lab + "if (!Fr_isTrue(%s)) goto L%d;" % (opnd(a), d))
+        elif op == F_LDX:
+            out.append(lab + "Fr_copy(&lvar[%d],&lvar[%d + Fr_toInt(&lvar[%d])]);" % (d, a, b[0]))
+        elif op == F_STX:
+            out.append(lab + "Fr_copy(&lvar[%d + Fr_toInt(&lvar[%d])],%s);" % (d, b[0], opnd(a)))
+        elif op in SYM:
+            out.append(lab + "%s(&lvar[%d],%s,%s);" % (SYM[op], d, opnd(a), opnd(b)))
+        elif op in SYM1:
+            out.append(lab + "%s(&lvar[%d],%s);" % (SYM1[op], d, opnd(a)))
+        else:
+            raise ValueError("function opcode %d" % op)
+    out.append("}")
+
+
 def emit(fc, path, hashmap_size: int):
     """fc: circom_amd FlatCircuit (duck-typed: .prog.inst_list, .prog.main, sizes)."""
     prog = fc.prog
@@ -172,6 +205,8 @@ def emit(fc, path, hashmap_size: int):
     out.append("void release_memory_component(Circom_CalcWit* ctx, uint pos) {{ if (pos != 0){{ if(ctx->componentMemory[pos].subcomponents) "
                "delete []ctx->componentMemory[pos].subcomponents; ctx->componentMemory[pos].subcomponents = NULL; }} }}")
     out.append("// function declarations")
+    for fid, fn in enumerate(getattr(fc, "functions", ())):
+        _emit_function(fid, fn, out)
     out.append("// template declarations")
     for t in insts:
         _emit_instance(t, out)

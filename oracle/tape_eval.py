@@ -14,8 +14,10 @@ from .field import Field, FieldError
 COPY, ADD, SUB, MUL, DIV, IDIV, MOD, POW, NEG = range(9)
 SHL, SHR, BAND, BOR, BXOR, BNOT = range(9, 15)
 LT, GT, LEQ, GEQ, EQ, NEQ, LAND, LOR, LNOT = range(15, 24)
-SELECT, ASSERT_EQ, ASSERT_NZ, RUN = range(24, 28)
+SELECT, ASSERT_EQ, ASSERT_NZ, RUN, CALL = range(24, 29)
 K_SIG, K_TMP, K_CONST, K_NONE = 0, 1, 2, 3
+F_JZ, F_JMP, F_LDX, F_STX, F_RET = 100, 101, 102, 103, 104      # circom_amd/frontend/rtcode.py
+CALL_STEP_LIMIT = 1 << 20
 
 _BIN = {ADD: "add", SUB: "sub", MUL: "mul", DIV: "div", IDIV: "idiv", MOD: "mod", POW: "pow",
         SHL: "shl", SHR: "shr", BAND: "band", BOR: "bor", BXOR: "bxor", LT: "lt", GT: "gt",
@@ -23,7 +25,66 @@ _BIN = {ADD: "add", SUB: "sub", MUL: "mul", DIV: "div", IDIV: "idiv", MOD: "mod"
 _UN = {NEG: "neg", BNOT: "bnot", LNOT: "lnot"}
 
 
-def eval_flat(q: int, n_signals: int, n_temps: int, constants, code, inputs: dict):
+def run_function(f: Field, fn: dict, regs: list, base: int, constants) -> bool:
+    """Interpret the register bytecode of a circom function (frontend/rtcode.py) the way the reference's emitted C++
+    would run it (while/if on Fr_isTrue, array addresses through Fr_toInt: loop_bucket.rs:76-91, branch_bucket.rs:100-122,
+    compute_bucket.rs:361-363).  regs[base + r] = register r.  Returns False on an arithmetic error (integer division by
+    zero, an array index outside its array, more than CALL_STEP_LIMIT instructions)."""
+    q = f.q
+    code = fn["code"]
+    bins = {k: getattr(f, v) for k, v in _BIN.items()}
+    uns = {k: getattr(f, v) for k, v in _UN.items()}
+
+    def val(x):
+        return regs[base + x[1]] if x[0] == 'r' else constants[x[1]]
+
+    def to_int(v):              # Fr_toInt, generic/fr.cpp:1146-1170: small non-negative, or q - small
+        if v < (1 << 31):
+            return v
+        if q - v <= (1 << 31):
+            return v - q
+        return None
+
+    pc = 0
+    steps = 0
+    ok = True
+    while True:
+        steps += 1
+        if steps > CALL_STEP_LIMIT:
+            return False
+        op, d, a, b = code[pc]
+        pc += 1
+        if op == F_RET:
+            return ok
+        if op == F_JMP:
+            pc = d
+        elif op == F_JZ:
+            if val(a) == 0:
+                pc = d
+        elif op == F_LDX or op == F_STX:
+            i = to_int(regs[base + b[0]])
+            if i is None or not 0 <= i < b[1]:
+                ok = False
+                i = 0
+            if op == F_LDX:
+                regs[base + d] = regs[base + a + i]
+            else:
+                regs[base + d + i] = val(a)
+        elif op == COPY:
+            regs[base + d] = val(a)
+        elif op in bins:
+            try:
+                regs[base + d] = bins[op](val(a), val(b))
+            except FieldError:
+                ok = False
+                regs[base + d] = 0
+        elif op in uns:
+            regs[base + d] = uns[op](val(a))
+        else:
+            raise ValueError("bad function opcode %d" % op)
+
+
+def eval_flat(q: int, n_signals: int, n_temps: int, constants, code, inputs: dict, functions=()):
     """inputs: {signal slot: canonical value}.  Returns (signals list, failed_row or None)."""
     f = Field(q)
     sig = [0] * n_signals
@@ -46,6 +107,10 @@ def eval_flat(q: int, n_signals: int, n_temps: int, constants, code, inputs: dic
     failed = None
     for i in range(len(op_)):
         op = int(op_[i])
+        if op == CALL:                      # a = function id, b = first register (a temporary)
+            if not run_function(f, functions[int(av[i])], tmp, int(bv[i]), constants) and failed is None:
+                failed = i
+            continue
         a = rd(int(ak[i]), int(av[i]))
         if op in bins:
             try:
@@ -92,7 +157,9 @@ def check_r1cs(q: int, constraints, w) -> int | None:
 # D_* numbering of circom_amd/csrc/cw_tape.h
 (D_COPY, D_ADD, D_SUB, D_NEG, D_MMUL, D_INV, D_IDIV, D_MOD, D_POW, D_SHL, D_SHR, D_BAND, D_BOR, D_BXOR,
  D_BNOT, D_LT, D_GT, D_LEQ, D_GEQ, D_EQ, D_NEQ, D_LAND, D_LOR, D_LNOT, D_SELECT, D_EXT, D_ASSERT_EQ,
- D_ASSERT_NZ, D_ALSO, D_BARRIER, D_MUL2, D_MADD, D_MULC, D_MADDC, D_LINSUM, D_BIT, D_DOTC) = range(37)   # D_ALSO unused
+ D_ASSERT_NZ, D_ALSO, D_BARRIER, D_MUL2, D_MADD, D_MULC, D_MADDC, D_LINSUM, D_BIT, D_DOTC, D_CALL) = range(38)   # D_ALSO unused
+DF_JZ, DF_JMP, DF_LDX, DF_STX, DF_RET, DF_DIV = 100, 101, 102, 103, 104, 105     # device bytecode of circom functions (lower.py)
+FN_CONST = 1 << 31
 _DBIN = {D_ADD: "add", D_SUB: "sub", D_IDIV: "idiv", D_MOD: "mod", D_POW: "pow", D_SHL: "shl", D_SHR: "shr",
          D_BAND: "band", D_BOR: "bor", D_BXOR: "bxor", D_LT: "lt", D_GT: "gt", D_LEQ: "leq", D_GEQ: "geq",
          D_EQ: "eq", D_NEQ: "neq", D_LAND: "land", D_LOR: "lor"}
@@ -108,8 +175,62 @@ K_PREV, K_LDS, KD_NONE = 3, 4, 2
 X_TMP, X_LDS = 1 << 31, 1 << 30
 
 
+def run_dev_function(f: Field, code, regs: list, base: int, consts) -> bool:
+    """the device form of a circom function (lower.py::_encode_function) executed the way the kernel's per-lane
+    interpreter does; regs[base + r] = register r.  False = arithmetic error / step limit"""
+    q = f.q
+    bins = {k: getattr(f, v) for k, v in _DBIN.items()}
+    uns = {k: (getattr(f, v) if v else (lambda x: x)) for k, v in _DUN.items()}
+
+    def val(x):
+        return consts[x & 0x7FFFFFFF] if x & FN_CONST else regs[base + x]
+
+    pc = 0
+    steps = 0
+    ok = True
+    while True:
+        steps += 1
+        if steps > CALL_STEP_LIMIT or pc >= len(code):
+            return False
+        op, d, a, b = (int(x) for x in code[pc])
+        pc += 1
+        if op == DF_RET:
+            return ok
+        if op == DF_JMP:
+            pc = d
+        elif op == DF_JZ:
+            if val(a) == 0:
+                pc = d
+        elif op in (DF_LDX, DF_STX):
+            v = regs[base + (b & 0xFFFF)]
+            n = b >> 16
+            i = v if v < (1 << 31) else (v - q if q - v <= (1 << 31) else None)
+            if i is None or not 0 <= i < n:
+                ok = False
+                i = 0
+            if op == DF_LDX:
+                regs[base + d] = regs[base + a + i]
+            else:
+                regs[base + d + i] = val(a)
+        elif op == D_MUL2:
+            regs[base + d] = val(a) * val(b) % q
+        elif op == DF_DIV:
+            regs[base + d] = f.div(val(a), val(b))
+        elif op in bins:
+            try:
+                regs[base + d] = bins[op](val(a), val(b))
+            except FieldError:
+                ok = False
+                regs[base + d] = 0
+        elif op in uns:
+            regs[base + d] = uns[op](val(a))
+        else:
+            raise ValueError("bad device function opcode %d" % op)
+
+
 def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict, rbits: int = 261,
-              stream_off=None, extras=None, extra_off=None, n_lds: int = 0, terms=None, term_off=None, lconsts=()):
+              stream_off=None, extras=None, extra_off=None, n_lds: int = 0, terms=None, term_off=None, lconsts=(),
+              functions=()):
     """Evaluate a lowered schedule exactly the way cw_eval_kernel does, for one instance:
       * every strand (stream) walks its own rows; strands meet at BARRIER rows,
       * operands of row r+1 are fetched BEFORE row r stores its result (one-row-ahead prefetch), except
@@ -188,8 +309,8 @@ def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict,
     def operands_of(s, r):
         w0, _, a_, b_ = rows[r]
         op = w0 & 0xFF
-        if op == D_BARRIER or op == D_LINSUM or op == D_DOTC:
-            return None, None                      # LINSUM / DOTC read their terms at execution time
+        if op == D_BARRIER or op == D_LINSUM or op == D_DOTC or op == D_CALL:
+            return None, None                      # LINSUM / DOTC / CALL read their operands at execution time
         if op == D_BIT:
             return fetch(s, (w0 >> SH_AK) & 7, a_), None
         ak, bk = (w0 >> SH_AK) & 7, (w0 >> SH_BK) & 7
@@ -263,6 +384,12 @@ def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict,
                 res = acc % q
             elif op == D_BIT:
                 res = (a >> b_) & 1 if b_ < 256 else 0
+            elif op == D_CALL:                # a = function id, b = first register slot (pinned temps)
+                n_regs, fcode = functions[a_]
+                for k in range(n_regs):       # the interpreter reads and writes its registers in the value table
+                    writer[(1, b_ + k)] = (state["epoch"], s)
+                if not run_dev_function(f, fcode, tmp, b_, consts) and status[0] == 0:
+                    status[0] = 2 | (r << 8)
             elif op == D_SELECT:
                 sel[s] = a != 0               # latched lane mask; no value
             elif op == D_EXT:
@@ -314,7 +441,8 @@ def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict,
 def eval_tape(tape, inputs: dict):
     """Convenience wrapper over a circom_amd.hip_elements.lower.Tape (duck-typed)."""
     return eval_rows(tape.q, tape.n_signals, tape.n_tslots, tape.consts, tape.rows, inputs, tape.rbits,
-                     tape.stream_off, tape.extras, tape.extra_off, tape.n_lds, tape.terms, tape.term_off, tape.lconsts)
+                     tape.stream_off, tape.extras, tape.extra_off, tape.n_lds, tape.terms, tape.term_off, tape.lconsts,
+                     getattr(tape, "functions", ()))
 
 
 # ---- bit-plane program (circom_amd/hip_elements/bitsched.py), executed the way cw_bits_eval_kernel does ----------------

@@ -1,0 +1,217 @@
+"""Tier 2: circom *functions* whose loops and branches depend on run-time values, and arrays indexed by a
+run-time value.  The reference emits them as real C++ control flow (loop_bucket.rs:76-91, branch_bucket.rs:100-122,
+call_bucket.rs:466-533) with addresses through Fr_toInt (compute_bucket.rs:361-363); here they are a register bytecode
+(frontend/rtcode.py) that the oracle interprets, that oracle/emit_ref_cpp.py prints over the reference's own Fr_* calls
+(so the reference RUNTIME executes it), and that the HIP kernel interprets per lane (D_CALL, divergent lanes take turns).
+"""
+import random
+
+import pytest
+
+from circom_amd.compiler import compile_program
+from circom_amd.frontend.dsl import Program, template
+from circom_amd.frontend.flatten import flatten
+from circom_amd.hip_elements.lower import lower
+from circom_amd.hip_elements.writers import wtns_bytes
+from oracle.tape_eval import eval_flat, eval_tape, check_r1cs
+
+
+def build_divmod(f, a, b):
+    """shift-subtract long division: both loops run a value-dependent number of times (bigint division of circom-ecdsa
+    has this shape)"""
+    q = f.var(0)
+    r = f.var(a)
+    sh = f.var(0)
+    d = f.var(b)
+    with f.loop() as L:                       # align the divisor under the dividend
+        L.break_unless((d << 1).leq(r))
+        d.set(d << 1)
+        sh.set(sh + 1)
+    with f.loop() as L:
+        with f.if_(r.geq(d)):
+            r.set(r - d)
+            q.set(q + (f.lift(1) << sh))
+        L.break_unless(sh.neq(0))
+        d.set(d >> 1)
+        sh.set(sh - 1)
+    return [q, r]
+
+
+@template
+def LongDiv(c):
+    a = c.input("a")
+    b = c.input("b")
+    qo = c.output("q")
+    ro = c.output("r")
+    fn = c.function("divmod", 2, build_divmod)
+    q, r = c.call(fn, [a, b])
+    c.hint(qo, q)
+    c.hint(ro, r)
+    c.enforce(qo * b + ro, a)
+
+
+def build_pick(f, *args):
+    arr = f.args_array(0, 8)
+    sel = args[8]
+    acc = f.var(arr.load(sel) * 3 + 1)
+    hist = f.array(4)                         # a local array written through a run-time index
+    hist.store(sel & 3, acc)
+    with f.if_(sel.gt(3)):
+        acc.set(acc + hist.load(sel - 4))
+    with f.else_():
+        acc.set(acc - hist[0])
+    return [acc]
+
+
+@template
+def Pick(c):
+    arr = c.input("arr", 8)
+    sel = c.input("sel")
+    out = c.output("out")
+    fn = c.function("pick", 9, build_pick)
+    (v,) = c.call(fn, [arr[k] for k in range(8)] + [sel])
+    c.hint(out, v)
+
+
+def _pick_model(q, arr, sel):
+    acc = (arr[sel] * 3 + 1) % q
+    hist = [0, 0, 0, 0]
+    hist[sel & 3] = acc
+    return (acc + hist[sel - 4]) % q if sel > 3 else (acc - hist[0]) % q
+
+
+def _flat(fc, inp):
+    return eval_flat(fc.fp.q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp, fc.functions)
+
+
+def test_oracle_interprets_loops_branches_and_indexed_arrays():
+    fc = flatten(Program(LongDiv()))
+    rnd = random.Random(1)
+    for _ in range(300):
+        a, b = rnd.randrange(1 << 20), rnd.randrange(1, 1 << 12)
+        sig, failed = _flat(fc, {3: a, 4: b})
+        assert failed is None and sig[1:3] == [a // b, a % b]
+        assert check_r1cs(fc.fp.q, fc.constraints, sig) is None
+    fc = flatten(Program(Pick()))
+    q = fc.fp.q
+    for sel in range(8):
+        arr = [rnd.randrange(q) for _ in range(8)]
+        inp = {2 + k: arr[k] for k in range(8)}
+        inp[10] = sel
+        sig, failed = _flat(fc, inp)
+        assert failed is None and sig[1] == _pick_model(q, arr, sel)
+    inp[10] = 8                                     # outside the array: the reference would read past it
+    assert _flat(fc, inp)[1] is not None
+
+
+@pytest.mark.parametrize("tmpl", [LongDiv, Pick])
+def test_lowered_schedule_runs_the_function(tmpl):
+    fc = flatten(Program(tmpl()))
+    t = lower(fc, n_strands=4)
+    assert t.n_strands == 1 and len(t.functions) == 1          # tier-2 code: one strand, program order
+    rnd = random.Random(2)
+    for _ in range(40):
+        if tmpl is LongDiv:
+            inp = {3: rnd.randrange(1 << 20), 4: rnd.randrange(1, 1 << 10)}
+        else:
+            inp = {2 + k: rnd.randrange(fc.fp.q) for k in range(8)}
+            inp[10] = rnd.randrange(8)
+        a, fa = _flat(fc, inp)
+        b, st = eval_tape(t, inp)
+        assert fa is None and st == 0 and a == b
+
+
+def test_reference_runtime_executes_the_same_function(tmp_path, ref_dir_bn128):
+    """the reference's own runtime + field library run the emitted C++ of the function: identical .wtns"""
+    from oracle import ref_build
+    cp = compile_program(Program(LongDiv()), str(tmp_path), "longdiv", sym=False, strands=(1,))
+    ref_build.build_circuit(cp)
+    rnd = random.Random(3)
+    rows = [[rnd.randrange(1 << 24), rnd.randrange(1, 1 << 12)] for _ in range(20)] + [[5, 7], [0, 3], [(1 << 30) - 1, 1]]
+    raw = b"".join(int(v).to_bytes(32, "little") for r in rows for v in r)
+    ref_build.run_loop(cp, raw, len(rows), 1, wtns_prefix=str(tmp_path / "r_"))
+    fc = cp.flat
+    for i, (a, b) in enumerate(rows):
+        sig, failed = _flat(fc, {3: a, 4: b})
+        assert failed is None
+        assert (tmp_path / ("r_%d.wtns" % i)).read_bytes() == wtns_bytes(fc.fp.q, sig)
+    cp2 = compile_program(Program(Pick()), str(tmp_path), "pickfn", sym=False, strands=(1,))
+    ref_build.build_circuit(cp2)
+    fc2 = cp2.flat
+    rows = [[rnd.randrange(fc2.fp.q) for _ in range(8)] + [sel] for sel in range(8)]
+    raw = b"".join(int(v).to_bytes(32, "little") for r in rows for v in r)
+    ref_build.run_loop(cp2, raw, len(rows), 1, wtns_prefix=str(tmp_path / "p_"))
+    for i, r in enumerate(rows):
+        sig, failed = _flat(fc2, {2 + k: v for k, v in enumerate(r)})
+        assert failed is None
+        assert (tmp_path / ("p_%d.wtns" % i)).read_bytes() == wtns_bytes(fc2.fp.q, sig)
+
+
+def test_loader_validates_function_bytecode(tmp_path):
+    from circom_amd import runtime as rt
+    cp = compile_program(Program(Pick()), str(tmp_path), "pickfn", sym=False, strands=(1,))
+    rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path).close()
+    n_regs, code = cp.tape.functions[0]
+    tape = bytearray(open(cp.tape_path, "rb").read())
+    blob = code.astype("<u4").tobytes()
+    at = bytes(tape).index(blob)
+    import numpy as np
+    for i, col, val in ((0, 1, n_regs),               # destination register beyond the window
+                        (1, 2, n_regs + 5),           # operand register beyond the window
+                        (0, 0, 77),                   # unknown opcode
+                        (len(code) - 1, 0, 0)):       # no return at the end
+        bad = code.copy()
+        bad[i, col] = val
+        t2 = bytearray(tape)
+        t2[at:at + len(blob)] = bad.astype("<u4").tobytes()
+        (tmp_path / "bad.cwt").write_bytes(bytes(t2))
+        with pytest.raises(rt.CwError):
+            rt.Circuit(tmp_path / "bad.cwt", cp.dat_path, cp.r1cs_path)
+
+
+@pytest.mark.gpu
+def test_gpu_interprets_divergent_function_calls(tmp_path):
+    from circom_amd import runtime as rt
+    cp = compile_program(Program(LongDiv()), str(tmp_path), "longdiv", sym=False)
+    c = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
+    fc = cp.flat
+    rnd = random.Random(5)
+    B = 200
+    rows = [[rnd.randrange(1 << rnd.randrange(1, 40)), rnd.randrange(1, 1 << rnd.randrange(1, 20))] for _ in range(B)]
+    rows[7] = [12345, 0]                                    # divisor 0: the alignment loop never ends -> step limit
+    b = c.batch(B)
+    b.set_inputs(rows)
+    b.run(); b.check_r1cs(); b.sync()
+    st = b.status()
+    for i, (x, y) in enumerate(rows):
+        if y == 0:
+            assert st[i] & rt.ST_ARITH, i
+            continue
+        assert st[i] == 0, (i, st[i])
+        assert b.witness(i) == _flat(fc, {3: x, 4: y})[0], i
+    b.close(); c.close()
+
+
+@pytest.mark.gpu
+def test_gpu_run_time_indexed_arrays(tmp_path):
+    from circom_amd import runtime as rt
+    cp = compile_program(Program(Pick()), str(tmp_path), "pickfn", sym=False)
+    c = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
+    fc = cp.flat
+    rnd = random.Random(6)
+    B = 130
+    rows = [[rnd.randrange(c.q) for _ in range(8)] + [rnd.randrange(8)] for _ in range(B)]
+    rows[3][8] = 8                                          # index outside the array
+    rows[64][8] = c.q - 1                                   # "-1"
+    b = c.batch(B)
+    b.set_inputs(rows)
+    b.run(); b.sync()
+    st = b.status()
+    for i, r in enumerate(rows):
+        if not 0 <= r[8] < 8:
+            assert st[i] & rt.ST_ARITH, i
+            continue
+        assert st[i] == 0
+        assert b.witness(i)[1] == _pick_model(c.q, r[:8], r[8]), i
+        assert b.witness(i) == _flat(fc, {2 + k: v for k, v in enumerate(r)})[0]
+    b.close(); c.close()
