@@ -81,9 +81,12 @@ if len(sys.argv) > 3:
         if short:
             for c, v in cs.items():
                 agg[short][c] += sum(v) / len(v)
+    # GRBM_GUI_ACTIVE is reported SUMMED over the 8 XCDs (MI355X_MICROARCH.md: "effective clock = GRBM_GUI_ACTIVE / kernel
+    # wall time" gives ~18 GHz = 8 x 2.3 GHz for these kernels), so the busy cycles of one SIMD's clock domain are 1/8 of it
+    N_XCD = 8.0
     for short, cs in agg.items():
         if cs.get("SQ_ACTIVE_INST_VALU") and cs.get("GRBM_GUI_ACTIVE"):
-            res[short + "_valu_busy"] = cs["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cs["GRBM_GUI_ACTIVE"])
+            res[short + "_valu_busy"] = cs["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cs["GRBM_GUI_ACTIVE"] / N_XCD)
             res[short + "_valu_insts"] = cs.get("SQ_INSTS_VALU")
             if cs.get("SQ_WAIT_ANY") and cs.get("SQ_WAVE_CYCLES"):
                 res[short + "_wait_frac"] = cs["SQ_WAIT_ANY"] / max(cs["SQ_WAVE_CYCLES"], 1.0)
