@@ -215,3 +215,67 @@ def test_gpu_run_time_indexed_arrays(tmp_path):
         assert b.witness(i)[1] == _pick_model(c.q, r[:8], r[8]), i
         assert b.witness(i) == _flat(fc, {2 + k: v for k, v in enumerate(r)})[0]
     b.close(); c.close()
+
+
+# ---- circom-ecdsa-shaped big-integer arithmetic on the BLS12-381 scalar field (BASELINE config 5's building block) ----
+def _limbs(x, n, m):
+    return [(x >> (n * i)) & ((1 << n) - 1) for i in range(m)]
+
+
+def _bigmult_rows(n, k, count, seed):
+    rnd = random.Random(seed)
+    rows = []
+    for it in range(count):
+        p = (1 << (n * k)) - 1 if it == 0 else rnd.randrange(1 << (n * k - 1), 1 << (n * k))
+        a, b = (p - 1, p - 1) if it == 1 else (rnd.randrange(p), rnd.randrange(p))
+        rows.append((a, b, p, _limbs(a, n, k) + _limbs(b, n, k) + _limbs(p, n, k)))
+    return rows
+
+
+def test_bigint_mult_mod_p_oracle_and_reference_runtime(tmp_path):
+    """a*b mod p on 3 x 32-bit limbs: the witness comes from the circom-ecdsa-style long_div / short_div functions
+    (data-dependent branches); the oracle, the lowered schedule and the REFERENCE runtime on bls12381 agree"""
+    from circom_amd.circuits.bigint import BigMultModP
+    from oracle import ref_build
+    import os
+    if not os.path.isdir(os.path.join(os.path.dirname(ref_build.__file__), "_ref", "bls12381")) and not ref_build.REF_ROOT.exists():
+        pytest.skip("no bls12381 reference build")
+    n, k = 32, 3
+    cp = compile_program(Program(BigMultModP(n, k), prime="bls12381"), str(tmp_path), "bigmultmodp_bls", sym=False, strands=(1,))
+    fc = cp.flat
+    rows = _bigmult_rows(n, k, 12, 1)
+    for a, b, p, vals in rows:
+        inp = {fc.main_input_start + i: v for i, v in enumerate(vals)}
+        sig, failed = _flat(fc, inp)
+        assert failed is None
+        assert sum(sig[1 + i] << (n * i) for i in range(k)) == a * b % p
+        assert check_r1cs(fc.fp.q, fc.constraints, sig) is None
+    s2, st = eval_tape(cp.tape, {fc.main_input_start + i: v for i, v in enumerate(rows[3][3])})
+    assert st == 0 and s2 == _flat(fc, {fc.main_input_start + i: v for i, v in enumerate(rows[3][3])})[0]
+    ref_build.build_circuit(cp)
+    raw = b"".join(int(v).to_bytes(32, "little") for r in rows for v in r[3])
+    ref_build.run_loop(cp, raw, len(rows), 1, wtns_prefix=str(tmp_path / "b_"))
+    for i, (a, b, p, vals) in enumerate(rows):
+        sig, _ = _flat(fc, {fc.main_input_start + j: v for j, v in enumerate(vals)})
+        assert (tmp_path / ("b_%d.wtns" % i)).read_bytes() == wtns_bytes(fc.fp.q, sig)
+
+
+@pytest.mark.gpu
+def test_gpu_bigint_mult_mod_p_bls12381(tmp_path):
+    from circom_amd import runtime as rt
+    from circom_amd.circuits.bigint import BigMultModP
+    n, k = 32, 3
+    cp = compile_program(Program(BigMultModP(n, k), prime="bls12381"), str(tmp_path), "bigmultmodp_bls", sym=False)
+    c = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
+    fc = cp.flat
+    rows = _bigmult_rows(n, k, 150, 2)
+    b = c.batch(len(rows))
+    b.set_inputs([r[3] for r in rows])
+    b.run(); b.check_r1cs(); b.sync()
+    assert (b.status() == 0).all()
+    for i, (x, y, p, vals) in enumerate(rows):
+        w = b.witness(i)
+        assert sum(w[1 + j] << (n * j) for j in range(k)) == x * y % p, i
+        if i % 10 == 0:
+            assert w == _flat(fc, {fc.main_input_start + j: v for j, v in enumerate(vals)})[0]
+    b.close(); c.close()
