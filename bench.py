@@ -34,7 +34,14 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
-DEFAULT_BATCH = {"sha256_2048": 65536, "sha256_512": 4096, "poseidon2": 65536, "semaphore20": 8192}
+DEFAULT_BATCH = {"sha256_2048": 65536, "sha256_512": 4096, "poseidon2": 65536, "semaphore20": 8192, "semaphore20p": 8192}
+
+
+def _semaphore_shape(name: str):
+    """semaphore<levels>[p]: p = the witness hints walk the scalar multiplications on a projective ladder"""
+    tail = name[len("semaphore"):]
+    proj = tail.endswith("p")
+    return int(tail.rstrip("p") or 20), proj
 
 
 def make_program(name: str):
@@ -47,7 +54,8 @@ def make_program(name: str):
         return Program(Sha256(int(name.split("_")[1])))
     if name.startswith("semaphore"):
         from circom_amd.circuits.eddsa import SemaphoreStyle
-        return Program(SemaphoreStyle(int(name[len("semaphore"):] or 20)))
+        levels, proj = _semaphore_shape(name)
+        return Program(SemaphoreStyle(levels, proj))
     raise SystemExit("unknown workload " + name)
 
 
@@ -108,7 +116,7 @@ def synth_inputs(name: str, q: int, batch: int, n_inputs: int, seed: int):
         import random
         from circom_amd.circuits import eddsa_host as H
         r = random.Random(seed)
-        levels = int(name[len("semaphore"):] or 20)
+        levels = _semaphore_shape(name)[0]
         pool = [H.semaphore_inputs(q, levels, r)[0] for _ in range(min(batch, 64))]
         one = np.frombuffer(b"".join(v.to_bytes(32, "little") for row in pool for v in row),
                             dtype=np.uint8).reshape(len(pool), n_inputs, 32)

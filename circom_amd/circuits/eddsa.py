@@ -10,7 +10,7 @@ Expected outputs are pinned against plain-integer arithmetic (eddsa_host.py) in 
 """
 from ..frontend.dsl import template
 from .basic import IsZero, Num2Bits
-from .babyjub import BabyAdd, BabyDbl, ScalarMulBits, BASE8
+from .babyjub import BabyAdd, BabyDbl, ScalarMulBits, ScalarMulBitsProj, BASE8
 from .merkle import MerkleTreeInclusionProof
 from .poseidon import Poseidon
 
@@ -81,7 +81,9 @@ def ForceEqualIfEnabled(c):
 
 
 @template
-def EdDSAPoseidonVerifier(c):
+def EdDSAPoseidonVerifier(c, proj=False):
+    """proj: compute the two scalar multiplications' witnesses on a projective ladder (babyjub.ScalarMulBitsProj)"""
+    Mul = ScalarMulBitsProj if proj else ScalarMulBits
     enabled = c.input("enabled")
     Ax = c.input("Ax"); Ay = c.input("Ay")
     S = c.input("S")
@@ -112,7 +114,7 @@ def EdDSAPoseidonVerifier(c):
     c.set(az["in"], d3["xout"])
     c.enforce(az["out"] * enabled, 0)                     # A is not in the small subgroup
 
-    mul_any = c.component("mulAny", ScalarMulBits(254))
+    mul_any = c.component("mulAny", Mul(254))
     for i in range(254):
         c.set(mul_any["e"][i], h2b["out"][i])
     c.set(mul_any["px"], d3["xout"]); c.set(mul_any["py"], d3["yout"])
@@ -123,7 +125,7 @@ def EdDSAPoseidonVerifier(c):
     c.set(add1["x2"], mul_any["outx"]); c.set(add1["y2"], mul_any["outy"])
 
     # left = S * B8
-    mul_fix = c.component("mulFix", ScalarMulBits(253))
+    mul_fix = c.component("mulFix", Mul(253))
     for i in range(253):
         c.set(mul_fix["e"][i], snum["out"][i])
     c.set(mul_fix["px"], BASE8[0]); c.set(mul_fix["py"], BASE8[1])
@@ -135,7 +137,7 @@ def EdDSAPoseidonVerifier(c):
 
 
 @template
-def SemaphoreStyle(c, nLevels):
+def SemaphoreStyle(c, nLevels, proj=False):
     """Membership + signed signal: the leaf Poseidon(Ax, Ay) is in the tree with the given root, the key signed
     the message (external nullifier), and nullifierHash = Poseidon(Ax, Ay, M) identifies the (key, message) pair."""
     Ax = c.input("Ax"); Ay = c.input("Ay")
@@ -156,7 +158,7 @@ def SemaphoreStyle(c, nLevels):
         c.set(tree["siblings"][i], siblings[i])
     c.set(root, tree["root"])
 
-    ver = c.component("verifier", EdDSAPoseidonVerifier())
+    ver = c.component("verifier", EdDSAPoseidonVerifier(proj))
     c.set(ver["enabled"], 1)
     for name, v in (("Ax", Ax), ("Ay", Ay), ("S", S), ("R8x", R8x), ("R8y", R8y), ("M", M)):
         c.set(ver[name], v)

@@ -5,6 +5,7 @@ from __future__ import annotations
 import os
 from dataclasses import dataclass
 
+from . import opcodes as O
 from .frontend.dsl import Program
 from .frontend.flatten import flatten, FlatCircuit
 from .hip_elements.lower import lower, Tape
@@ -55,14 +56,29 @@ def lower_bitplane(fc: FlatCircuit, bits="auto"):
     return lower_bits(net, fc)
 
 
-def compile_program(prog: Program, outdir: str, name: str, sym: bool = True, strands=DEFAULT_STRANDS, bits="auto") -> Compiled:
-    """strands: strand counts to lower the schedule for (one variant each; the runtime picks per batch)."""
+# The pipelined single-wave variant (hip_elements/pipe.py) is opt-in: measured on MI355X it matches the plain single-strand
+# schedule at high occupancy and loses to the multi-strand variants at small batches, where one wave per 64 instances
+# leaves most SIMDs idle (Poseidon(2) x 8 192: 1.2 ms against 0.67 ms with 4 strands; NOTES.md round 2).
+DEFAULT_PIPE = None
+
+
+def compile_program(prog: Program, outdir: str, name: str, sym: bool = True, strands=DEFAULT_STRANDS, bits="auto",
+                    pipe=DEFAULT_PIPE) -> Compiled:
+    """strands: strand counts to lower the schedule for (one variant each; the runtime picks per batch).
+    pipe: (rows, loads) per batch of the pipelined variant, e.g. (8, 8), which is added last; None = no pipelined variant."""
     os.makedirs(outdir, exist_ok=True)
     fc = flatten(prog)
     bittape = lower_bitplane(fc, bits)
     if bittape is not None and os.environ.get("CW_BITS", "1") != "0":
         strands = (1,)                      # the 256-bit schedule only serves the instances re-run with non-boolean inputs
+        pipe = None
+    if getattr(fc, "functions", None) and (fc.code["op"] == O.CALL).any():
+        pipe = None                         # run-time control flow: program order on the value table (tier 2)
+    if os.environ.get("CW_PIPE_SHAPE"):
+        pipe = tuple(int(x) for x in os.environ["CW_PIPE_SHAPE"].split(","))
     tapes = [lower(fc, n_strands=s) for s in strands]
+    if pipe is not None:
+        tapes.append(lower(fc, pipe=pipe))
     tape = tapes[0]
     p = lambda ext: os.path.join(outdir, name + ext)
     writers.write_tape(p(".cwt"), tapes, bittape)

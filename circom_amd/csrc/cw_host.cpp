@@ -196,6 +196,9 @@ struct Variant {               // one lowering of the schedule for a given stran
     uint32_t prio_mask = 0;        // strands whose share of the work is within 20 % of the heaviest one (s_setprio)
     uint32_t n_active = 1;         // strands that carry work (a 3-lane circuit leaves 13 of 16 strands with barriers only)
     bool wide_linsum = false;      // schedule dominated by long small-coefficient sums -> 4 operand loads in flight
+    // kind 1 = pipelined single-wave schedule (hip_elements/pipe.py): prows = 8 words per row, extras = the load lists
+    uint32_t kind = 0, nb = 0, nld = 0;
+    std::vector<uint32_t> prows;
     std::vector<CwRow> rows;
     std::vector<uint32_t> stream_off, extras, extra_off, term_off, terms;   // terms: 4 x u32 each
 };
@@ -309,6 +312,60 @@ static const char *validate_variant(const Variant &v, uint32_t n_signals, uint32
         }
         if (xp != v.extra_off[st + 1] || tp != v.term_off[st + 1]) return "strand tables do not add up";
     }
+    return nullptr;
+}
+
+// pipelined variant: every index the kernel dereferences (LDS entries, value-table slots, constants, term tables) and the
+// shape the kernel's fixed wait relies on (whole batches, NLD loads per batch, two store targets per row)
+static const char *validate_pipe_variant(const Variant &v, uint32_t n_signals, uint32_t n_consts, uint32_t n_lconsts) {
+    const uint32_t nb = v.nb, nld = v.nld, rr = 2 * nb, n_ent = rr + 2 * nld;
+    if (!((nb == 8 && (nld == 8 || nld == 4)) || (nb == 4 && nld == 4))) return "unsupported batch shape";
+    if (v.n_strands != 1 || v.n_lds != n_ent) return "pipelined variants are single-strand with 2*NB + 2*NLD LDS entries";
+    const size_t nrows = v.prows.size() / 8, nterms = v.terms.size() / 4;
+    if (nrows == 0 || nrows % nb || nrows > (1u << 30)) return "rows do not form whole batches";
+    if (v.extras.size() != (nrows / nb + 2) * (size_t)nld) return "load lists do not match the batches";
+    if (nterms < 4) return "term table lacks its padding";
+    auto target_ok = [&](uint32_t t) {
+        if (t == 0xFFFFFFFFu) return true;
+        if (t & 0x40000000u) return false;
+        return (t & X_TMP) ? (t & 0x3FFFFFFFu) < v.n_tslots : t < n_signals;
+    };
+    for (uint32_t lw : v.extras) {
+        if (lw == 0xFFFFFFFFu) continue;
+        if (lw & 0x40000000u) {
+            if ((lw & X_TMP) || (lw & 0x3FFFFFFFu) >= n_consts) return "load list: constant out of range";
+        } else if (!target_ok(lw)) return "load list: slot out of range";
+    }
+    size_t tp = 0;
+    for (size_t r = 0; r < nrows; r++) {
+        const uint32_t *w = &v.prows[r * 8];
+        const uint32_t op = w[0] & 0xFF, ak = (w[0] >> 8) & 7, bk = (w[0] >> 11) & 7;
+        const uint32_t ae = w[2] & 0xFF, be = (w[2] >> 8) & 0xFF, de = (w[2] >> 16) & 0xFF;
+        const uint32_t half = (uint32_t)(r / nb) & 1u;
+        auto entry_ok = [&](uint32_t e) { return e < rr || (e < n_ent && (e - rr) / nld == half); };
+        if (w[0] & 0x1FFFC000u) return "row word 0 has unknown bits";
+        if (!(op < D_NOPS || op == D_NOP) || op == D_BARRIER || op == D_CALL || op == D_ALSO) return "opcode not allowed in a pipelined schedule";
+        if ((ak != 0 && ak != K_PREV && ak != K_LDS) || (bk != 0 && bk != K_PREV && bk != K_LDS)) return "operand kind";
+        if ((ak == K_LDS && !entry_ok(ae)) || (bk == K_LDS && !entry_ok(be))) return "LDS entry out of range";
+        if ((ak != K_LDS && ae >= n_ent) || (bk != K_LDS && be >= n_ent)) return "LDS entry out of range";   // still prefetched
+        const bool value = !(op == D_NOP || op == D_ASSERT_EQ || op == D_ASSERT_NZ || op == D_SELECT);
+        if (value ? !(de == 0xFF || de == r % rr) : (de != 0xFF || w[3] != 0xFFFFFFFFu || w[4] != 0xFFFFFFFFu))
+            return "result entry / store targets";
+        if (!target_ok(w[3]) || !target_ok(w[4])) return "store target out of range";
+        if (op == D_LINSUM || op == D_DOTC) {
+            if (w[1] > nterms - 4 - tp) return "term list overruns the table";
+            for (uint32_t t = 0; t < w[1]; t++) {
+                const uint32_t *tm = &v.terms[(tp + t) * 4];
+                const uint32_t tk = tm[0] & 7;
+                if (tk != K_PREV && tk != K_LDS) return "term operand kind";
+                if (tm[0] & 0x7FFFFFF8u) return "term word has unknown bits";
+                if (tk == K_LDS ? !entry_ok(tm[1]) : tm[1] != 0) return "term entry out of range";
+                if (op == D_DOTC && tm[2] >= n_lconsts) return "term constant out of range";
+            }
+            tp += w[1];
+        }
+    }
+    if (tp + 4 != nterms) return "term table not consumed exactly";
     return nullptr;
 }
 
@@ -440,6 +497,48 @@ static int load_tape(cw_circuit *c, const char *path) {
         var.n_lds = vh[4];
         if (var.n_strands == 0 || var.n_strands > 16) return fail(CW_EIO, "tape variant: bad strand count");
         if (var.n_lds > 72) return fail(CW_EIO, "tape variant: too many LDS slots");
+        if (vh[6] > 1) return fail(CW_EIO, "tape variant: unknown kind");
+        if (vh[6] == 1) {       // pipelined single-wave schedule: rows of 8 words, `extras` = load lists
+            var.kind = 1;
+            var.nb = vh[7] & 0xFF;
+            var.nld = (vh[7] >> 8) & 0xFF;
+            if (var.n_strands != 1) return fail(CW_EIO, "tape variant: bad strand count");
+            size_t need = 24 + (size_t)nrows * 32 + (size_t)nextras * 4 + (size_t)nterms * 16;
+            if (off + need > b.size()) return fail(CW_EIO, "tape variant truncated");
+            uint32_t offs[6];
+            memcpy(offs, b.data() + off, 24);
+            off += 24;
+            if (offs[0] != 0 || offs[1] != nrows || offs[2] != 0 || offs[3] != nextras || offs[4] != 0 || nterms < 4 || offs[5] != nterms - 4)
+                return fail(CW_EIO, "tape variant: bad offsets");
+            var.stream_off = {0, nrows};
+            var.extra_off = {0, nextras};
+            var.term_off = {0, nterms - 4};
+            var.prows.resize((size_t)nrows * 8);
+            memcpy(var.prows.data(), b.data() + off, (size_t)nrows * 32);
+            off += (size_t)nrows * 32;
+            var.extras.resize(nextras);
+            memcpy(var.extras.data(), b.data() + off, (size_t)nextras * 4);
+            off += (size_t)nextras * 4;
+            var.terms.resize((size_t)nterms * 4);
+            memcpy(var.terms.data(), b.data() + off, (size_t)nterms * 16);
+            off += (size_t)nterms * 16;
+            if (const char *why = validate_pipe_variant(var, c->n_signals, c->n_consts, n_lconsts))
+                return fail(CW_EIO, std::string("tape variant (pipelined): ") + why);
+            uint64_t mm = 0;
+            for (size_t r = 0; r < nrows; r++) {
+                const uint32_t op = var.prows[r * 8] & 0xFF, n = var.prows[r * 8 + 1];
+                if (op == D_MMUL || op == D_MADD || op == D_MULC || op == D_MADDC) mm++;
+                if (op == D_MUL2) mm += 2;
+                if (op == D_DOTC || op == D_LINSUM) mm += n;
+                if (op == D_INV || op == D_IDIV || op == D_MOD || op == D_POW) c->need_full = true;
+            }
+            if (v == 0) {
+                c->n_rows = nrows;
+                c->n_mmul = mm;
+            }
+            c->variants.push_back(std::move(var));
+            continue;
+        }
         size_t need = (size_t)(var.n_strands + 1) * 12 + (size_t)nrows * 16 + (size_t)nextras * 4 + (size_t)nterms * 16;
         if (off + need > b.size()) return fail(CW_EIO, "tape variant truncated");
         var.stream_off.resize(var.n_strands + 1);
@@ -689,6 +788,11 @@ static int load_r1cs(cw_circuit *c, const char *path) {
     {
         const Variant &v0 = c->variants[0];
         size_t xp = 0;
+        for (size_t r = 0; r * 8 < v0.prows.size(); r++)            // a pipelined variant: the two store targets of each row
+            for (int k = 3; k <= 4; k++) {
+                const uint32_t t = v0.prows[r * 8 + k];
+                if (!(t & X_TMP) && t < c->n_signals) defpos[t] = (uint32_t)r + 1;
+            }
         for (size_t r = 0; r < v0.rows.size(); r++) {
             const CwRow &row = v0.rows[r];
             uint32_t op = row.w0 & 0xFF, dk = (row.w0 >> SH_DK) & 7, nx = (row.w0 >> SH_NX) & 0xFFF;
@@ -822,6 +926,8 @@ extern "C" int cw_r1cs_plan_stats(const cw_circuit *c, uint32_t batch, uint32_t 
 // ---------------------------------------------------------------------------------------------------------
 // batch
 // ---------------------------------------------------------------------------------------------------------
+static const uint64_t PIPE_MAX_GROUPS = 4096;
+
 struct cw_batch {
     cw_circuit *c = nullptr;
     int device = 0;
@@ -834,6 +940,7 @@ struct cw_batch {
     uint32_t *d_stream_off = nullptr, *d_extra_off = nullptr;
     uint64_t *d_extras = nullptr, *d_terms = nullptr;
     uint32_t *d_term_off = nullptr;
+    uint32_t *d_prows = nullptr, *d_ploads = nullptr;   // pipelined variant: device rows (CwPRow) and load lists
     uint32_t *d_lconsts = nullptr;
     uint32_t *d_fncode = nullptr, *d_fntab = nullptr;   // circom functions (D_CALL)
     uint32_t *d_consts = nullptr, *d_w2s = nullptr, *d_status = nullptr, *d_first_bad = nullptr;
@@ -891,7 +998,7 @@ extern "C" void cw_batch_free(cw_batch *b) {
         if (p) hipFree(p);
     if (b->d_fncode) hipFree(b->d_fncode);
     if (b->d_fntab) hipFree(b->d_fntab);
-    void *ptrs[] = {b->d_V, b->d_rows, b->d_stream_off, b->d_extras, b->d_extra_off, b->d_terms, b->d_term_off, b->d_lconsts, b->d_consts, b->d_w2s, b->d_status, b->d_first_bad,
+    void *ptrs[] = {b->d_V, b->d_prows, b->d_ploads, b->d_rows, b->d_stream_off, b->d_extras, b->d_extra_off, b->d_terms, b->d_term_off, b->d_lconsts, b->d_consts, b->d_w2s, b->d_status, b->d_first_bad,
                     b->d_rctab, b->d_rctab29, b->d_pchunk, b->d_prec, b->d_pterms, b->d_prow,
                     b->d_in, b->d_gather, b->d_bulk};
     for (void *p : ptrs)
@@ -948,19 +1055,38 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
         uint64_t groups = (batch + 63) / 64;
         const Variant *best = nullptr;
         for (auto &v : c->variants) {
+            if (v.kind) continue;
             if (groups * v.n_strands > 8192 && v.n_strands > 1) continue;
             if (!best || v.n_active > best->n_active || (v.n_active == best->n_active && v.n_strands < best->n_strands))
                 best = &v;
         }
-        if (!best) best = &c->variants[0];
-        if (const char *e = getenv("CW_STRANDS")) {
+        if (!best)
+            for (auto &v : c->variants)
+                if (!v.kind && (!best || v.n_strands < best->n_strands)) best = &v;
+        if (const char *e = best ? getenv("CW_STRANDS") : nullptr) {
             uint32_t want = (uint32_t)std::max(1, atoi(e));
-            best = &c->variants[0];
             for (auto &v : c->variants) {
+                if (v.kind) continue;
                 bool better = (v.n_strands <= want && v.n_strands > best->n_strands) ||
                               (best->n_strands > want && v.n_strands < best->n_strands);
                 if (better) best = &v;
             }
+        }
+        // The pipelined single-wave variant hides the value-table latency inside ONE wave (LDS ring + load lists a batch
+        // ahead), so it wins wherever the strand variants run at one or two waves per SIMD: up to PIPE_MAX_GROUPS groups
+        // of 64 instances.  Beyond that the plain single-strand schedule has enough waves per SIMD to hide the latency
+        // by itself and needs no LDS.  CW_PIPE = 0 / 1 overrides.
+        {
+            const Variant *pv = nullptr;
+            for (auto &v : c->variants)
+                if (v.kind == 1) pv = &v;
+            bool use = pv && (!best || (groups <= PIPE_MAX_GROUPS && !getenv("CW_STRANDS")));   // CW_STRANDS asks for a strand variant
+            if (const char *e = getenv("CW_PIPE")) use = pv && (atoi(e) != 0 || !best);
+            if (use) best = pv;
+        }
+        if (!best) {
+            delete b;
+            return fail(CW_EINVAL, "the tape holds no usable schedule variant");
         }
         b->var = best;
         // instances per workgroup: when there are fewer workgroups than CUs (256), a batch is spread over more of them
@@ -992,7 +1118,40 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
             return fail(CW_EDEVICE, std::string(#x ": ") + hipGetErrorString(e2)); \
         }                                                                   \
     } while (0)
-    {
+    if (b->var->kind == 1) {
+        // pipelined variant: value-table targets become unified slot numbers (signals, then temps), LDS entries of the terms
+        // byte offsets; the row table is padded with 3 NOPs (the kernel reads three rows ahead)
+        const Variant &v = *b->var;
+        std::vector<uint32_t> prow(v.prows.size() + 3 * 8);
+        const size_t nrows = v.prows.size() / 8;
+        auto unify = [&](uint32_t t) { return t == 0xFFFFFFFFu ? t : (t & X_TMP) ? c->n_signals + (t & 0x3FFFFFFFu) : t; };
+        for (size_t r = 0; r < nrows; r++) {
+            const uint32_t *w = &v.prows[r * 8];
+            uint32_t *o = &prow[r * 8];
+            o[0] = w[0]; o[1] = w[1]; o[2] = w[2];
+            o[3] = unify(w[3]); o[4] = unify(w[4]);
+            o[5] = w[5]; o[6] = w[6]; o[7] = 0;
+        }
+        for (int k = 0; k < 3; k++) {
+            uint32_t *o = &prow[(nrows + k) * 8];
+            o[0] = D_NOP; o[1] = 0; o[2] = 0xFFu << 16; o[3] = o[4] = 0xFFFFFFFFu; o[5] = o[6] = o[7] = 0;
+        }
+        std::vector<uint32_t> pl(v.extras.size());
+        for (size_t k = 0; k < v.extras.size(); k++) {
+            const uint32_t lw = v.extras[k];
+            pl[k] = lw == 0xFFFFFFFFu ? lw : (lw & 0x40000000u) ? (0x80000000u | (lw & 0x3FFFFFFFu)) : unify(lw);
+        }
+        std::vector<uint64_t> dterms(v.terms.size() / 2);
+        for (size_t k = 0; k + 3 < v.terms.size(); k += 4) {
+            const uint32_t kw = v.terms[k], kind = kw & 7;
+            dterms[k / 2] = ((uint64_t)kind << 61) | ((uint64_t)v.terms[k + 1] * 2048);
+            dterms[k / 2 + 1] = ((uint64_t)(kw >> 31) << 63) | ((uint64_t)v.terms[k + 3] << 32) | v.terms[k + 2];
+        }
+        TRY(upload(&b->d_prows, prow, b->stream));
+        TRY(upload(&b->d_ploads, pl, b->stream));
+        TRY(upload(&b->d_terms, dterms, b->stream));
+        TRY(hipStreamSynchronize(b->stream));
+    } else {
         // resolve the schedule for this batch: slot numbers -> byte offsets (CwDRow), streams padded with NOPs
         const Variant &v = *b->var;
         const uint64_t stride = (uint64_t)2 * b->Bp * 16;            // bytes per value slot
@@ -1155,6 +1314,7 @@ extern "C" int cw_bits_info(const cw_circuit *c, uint64_t out[8]) {
 }
 extern "C" uint32_t cw_batch_size(const cw_batch *b) { return b->batch; }
 extern "C" uint32_t cw_batch_strands(const cw_batch *b) { return b->var ? b->var->n_strands : 0; }
+extern "C" uint32_t cw_batch_pipelined(const cw_batch *b) { return b && b->var && b->var->kind == 1 ? b->var->nb | (b->var->nld << 8) : 0; }
 extern "C" uint32_t cw_batch_lanes(const cw_batch *b) { return b->bitmode ? b->bits_width : b->lanes; }
 
 static int ensure_host_staging(cw_batch *b) {
@@ -1574,6 +1734,13 @@ extern "C" int cw_run(cw_batch *b) {
     }
     HIPCHK(cwk_init(b->stream, b->d_V, b->Bp, b->d_status, b->d_first_bad));
     HIPCHK(cwk_ingest(b->stream, in, b->d_V, c->input_start, c->n_inputs, b->batch, b->Bp));
+    if (b->var->kind == 1) {
+        HIPCHK(cwk_eval_pipe(b->stream, c->need_full, false, b->var->nb, b->var->nld, b->d_prows, (uint32_t)(b->var->prows.size() / 8),
+                             b->d_ploads, b->d_terms, b->d_V, b->d_consts, b->d_lconsts, (uint64_t)2 * b->Bp * 16, b->Bp, b->batch,
+                             b->lanes, b->d_status, c->P));
+        b->ran = true;
+        return CW_OK;
+    }
     HIPCHK(cwk_eval(b->stream, c->need_full, b->var->wide_linsum, b->d_rows, b->d_stream_off, b->d_extras, b->d_extra_off, b->d_terms,
                     b->d_term_off, b->var->n_strands, b->var->n_lds, b->d_V, b->d_consts, b->d_lconsts, b->d_fncode, b->d_fntab,
                     (uint64_t)2 * b->Bp * 16, b->Bp, b->batch, b->lanes, b->prio_mask, b->d_status, c->P));

@@ -180,11 +180,14 @@ __device__ __forceinline__ fe acc192_to_fe(const Acc192 &a) {
     r.v[4] = (uint32_t)a.w2; r.v[5] = (uint32_t)(a.w2 >> 32);
     return r;
 }
+// LDS_ONLY: the pipelined kernel has no value-table operands (and must not contain a single vector-memory load: hipcc
+// would guard the merged registers with s_waitcnt vmcnt(small), which also drains the stores and LDS-DMA loads in flight)
+template <bool LDS_ONLY = false>
 __device__ __forceinline__ fe term_load(uint64_t t0, const fe &prev, const EvalCtx &c) {
     const uint32_t kind = (uint32_t)(t0 >> 61);
     const uint64_t off = t0 & 0x1FFFFFFFFFFFFFFFull;
     if (kind == K_PREV) return prev;
-    if (kind == K_LDS) return lds_load_off((uint32_t)off, c);
+    if (LDS_ONLY || kind == K_LDS) return lds_load_off((uint32_t)off, c);
     return fetch_off(K_SIG, off, c);
 }
 __device__ __forceinline__ void linsum_term(const fe &xc, uint64_t cf, fe &g, Acc192 &pos, Acc192 &neg, const FpParams &P) {
@@ -214,19 +217,19 @@ __device__ __forceinline__ void linsum_term(const fe &xc, uint64_t cf, fe &g, Ac
 // flight together (memory-level parallelism), then the products are accumulated.  Entries past the row's last
 // term (the table is padded by 4) are neutralised by a zero coefficient.  W = 4 costs 16 more live registers: it is
 // used for schedules dominated by long small-coefficient sums (bit-level circuits), W = 2 otherwise.
-template <int W>
+template <int W, bool LDS_ONLY = false>
 __device__ __forceinline__ fe eval_linsum(uint32_t n, const fe &c0, const fe &prev, EvalCtx &c, const FpParams &P) {
     fe g = c0;
     Acc192 pos = {0, 0, 0}, neg = {0, 0, 0};
     const uint64_t *tt = c.terms + (size_t)c.tp * 2;
     for (uint32_t k = 0; k < n; k += W) {
         const uint64_t a0 = tt[2 * k], c0_ = tt[2 * k + 1], a1 = tt[2 * k + 2], c1 = tt[2 * k + 3];
-        const fe x0 = term_load(a0, prev, c);
-        const fe x1 = term_load(a1, prev, c);
+        const fe x0 = term_load<LDS_ONLY>(a0, prev, c);
+        const fe x1 = term_load<LDS_ONLY>(a1, prev, c);
         if (W == 4) {
             const uint64_t a2 = tt[2 * k + 4], c2 = tt[2 * k + 5], a3 = tt[2 * k + 6], c3 = tt[2 * k + 7];
-            const fe x2 = term_load(a2, prev, c);
-            const fe x3 = term_load(a3, prev, c);
+            const fe x2 = term_load<LDS_ONLY>(a2, prev, c);
+            const fe x3 = term_load<LDS_ONLY>(a3, prev, c);
             linsum_term(x0, c0_, g, pos, neg, P);
             linsum_term(x1, k + 1 < n ? c1 : 0, g, pos, neg, P);
             linsum_term(x2, k + 2 < n ? c2 : 0, g, pos, neg, P);
@@ -245,16 +248,17 @@ __device__ __forceinline__ fe eval_linsum(uint32_t n, const fe &c0, const fe &pr
 // Up to four products x_i * (coef_i R') are accumulated as unreduced 29-bit-limb columns and reduced ONCE
 // (81 multiply-adds per term + 90 for the reduction, instead of a full Montgomery product and a modular
 // addition per term).  The constants come from the limb-form table through scalar loads.
+template <bool LDS_ONLY = false>
 __device__ __forceinline__ fe eval_dotc(uint32_t n, const fe &c0, const fe &prev, EvalCtx &c, const FpParams &P) {
     fe res = c0;
     const uint64_t *tt = c.terms + (size_t)c.tp * 2;
     uint64_t acc[18];
     for (int j = 0; j < 18; j++) acc[j] = 0;
-    fe x = term_load(tt[0], prev, c);
+    fe x = term_load<LDS_ONLY>(tt[0], prev, c);
     for (uint32_t k = 0; k < n; k++) {
         const fe29 xc = fe_to29(x);
         const uint32_t ci = (uint32_t)tt[2 * k + 1];
-        if (k + 1 < n) x = term_load(tt[2 * k + 2], prev, c);       // next operand in flight during the 81 MACs
+        if (k + 1 < n) x = term_load<LDS_ONLY>(tt[2 * k + 2], prev, c);       // next operand in flight during the 81 MACs
         fe29_mac(acc, xc, c.Lb + (size_t)ci * 12);
         if ((k & 3) == 3 || k + 1 == n) {                            // at most 4 products per reduction (column bound)
             res = fe_add(res, fe_from29(fe29_reduce(acc, P)), P);
@@ -588,6 +592,267 @@ cw_eval_kernel(const CwDRow *__restrict__ rows, const uint32_t *__restrict__ str
     }
 }
 
+// ---- pipelined single-wave schedule (hip_elements/pipe.py) -----------------------------------------------------------
+// One wave = 64 (or 32 / 16) instances, rows in batches of NB.  No row waits for the value table:
+//   * the far operands of batch k (value-table slots, constants) are listed in the batch's load list and copied
+//     global -> LDS by the LDS-DMA path (global_load_lds_dwordx4: no VGPRs, no VALU) a whole batch ahead: L(k+1) is issued
+//     when batch k starts, into the staging half (k+1) % 2;
+//   * every result goes to a ring of 2*NB LDS entries (entry = row position mod 2*NB) besides the forwarding register, so
+//     consumers up to 2*NB rows behind read LDS; the a/b operands of row r+1 are requested from LDS before row r executes;
+//   * every row issues exactly two value-table stores (4 buffer_store_dwordx4; a NONE target is a zero-sized buffer, dropped
+//     by the bounds check) and every batch exactly NLD loads, so 4*NB vector-memory instructions separate the issue of L(k)
+//     from the start of batch k: `s_waitcnt vmcnt(4*NB)` there means "L(k) is in LDS" (hipcc does not count asm memory
+//     operations, and the stores never need a wait).
+// LDS: [ring 2*NB][staging 2*NLD] entries of 2 KiB ([2 halves][64 lanes] x 16 B).
+struct CwPRow {      // 32 bytes, one scalar dwordx8 load
+    uint32_t w0;     // op[0:8) | kind of a [8:11) | kind of b [11:14) | const flags [29:31); kinds: 0 none, K_PREV, K_LDS
+    uint32_t aux;    // bit index / number of terms / row reported in the status word
+    uint32_t abd;    // LDS entry of a | of b << 8 | ring entry of the result << 16 (0xFF = no value)
+    uint32_t st0, st1;   // value-table slots the result is stored to (0xFFFFFFFF = none)
+    uint32_t cm_lo, cm_hi;   // D_MULC / D_MADDC: |val(c)| of a small constant
+    uint32_t pad;
+};
+static_assert(sizeof(CwPRow) == 32, "CwPRow is loaded with one s_load_dwordx8");
+
+template <int NLD>
+__device__ __forceinline__ void pipe_issue(const uint32_t *__restrict__ loads, uint32_t k, uint32_t ring_entries, uint64_t vbase,
+                                           uint64_t cbase, uint64_t slot_bytes, uint64_t half_bytes, uint32_t voff, uint32_t lds_base) {
+#ifdef CW_PEXP_NOLOAD          // timing experiment only (tools/pipe_exp.sh): results are garbage
+    return;
+#endif
+    // the whole list with one scalar load (NLD words, 16-byte aligned)
+    const uint4 *lp = (const uint4 *)(loads + (size_t)k * NLD);
+    uint32_t lws[NLD];
+    {
+        const uint4 q0 = lp[0];
+        lws[0] = q0.x; lws[1] = q0.y; lws[2] = q0.z; lws[3] = q0.w;
+        if (NLD == 8) {
+            const uint4 q1 = lp[1];
+            lws[NLD - 4] = q1.x; lws[NLD - 3] = q1.y; lws[NLD - 2] = q1.z; lws[NLD - 1] = q1.w;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NLD; j++) {
+        const uint32_t lw = lws[j];
+        const bool none = lw == 0xFFFFFFFFu, is_const = !none && (lw >> 31);
+        const uint32_t idx = none ? 0u : (lw & 0x7FFFFFFFu);
+        const uint64_t lo = is_const ? cbase + (uint64_t)idx * 32u : vbase + (uint64_t)idx * slot_bytes;
+        const uint64_t hi = lo + (is_const ? 16u : half_bytes);
+        const uint32_t vo = is_const ? 0u : voff;                   // constants: every lane copies the same 16 bytes
+        const uint32_t dlo = lds_base + (ring_entries + (k & 1u) * NLD + j) * 2048u, dhi = dlo + 1024u;
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
+                     "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(vo), "s"(dlo), "s"(dhi), "s"(lo), "s"(hi)
+                     : "memory");
+    }
+}
+
+typedef uint32_t pipe_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void pipe_store(uint32_t slot, const fe &x, const char *Vb, uint64_t slot_bytes, uint32_t vlo,
+                                           uint32_t vhi) {
+#ifdef CW_PEXP_NOSTORE
+    return;
+#endif
+    const bool none = slot == 0xFFFFFFFFu;
+    const char *base = Vb + (uint64_t)(none ? 0u : slot) * slot_bytes;
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, none ? 0 : (int)(uint32_t)slot_bytes, 0x00020000);
+    pipe_u32x4 lo = {x.v[0], x.v[1], x.v[2], x.v[3]}, hi = {x.v[4], x.v[5], x.v[6], x.v[7]};
+    __builtin_amdgcn_raw_buffer_store_b128(lo, rs, (int)vlo, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(hi, rs, (int)vhi, 0, 0);
+}
+
+template <bool FULL_OPS, int LW>
+__device__ __forceinline__ void pipe_step(const CwPRow &row, const fe &xa, const fe &xb, const CwPRow &nrow, fe &ya, fe &yb,
+                                          fe &prev, uint64_t &selmask, uint32_t &st, EvalCtx &c, uint64_t slot_bytes,
+                                          const FpParams &P) {
+    const uint32_t op = row.w0 & 0xFF, ak = (row.w0 >> 8) & 7, bk = (row.w0 >> 11) & 7;
+    // the next row's LDS operands first (its producer is never THIS row: that would be kind PREV)
+    ya = lds_load_off((nrow.abd & 0xFFu) << 11, c);
+    yb = lds_load_off(((nrow.abd >> 8) & 0xFFu) << 11, c);
+    fe a = xa, b = xb;
+    if (ak == K_PREV) a = prev;
+    if (bk == K_PREV) b = prev;
+    fe d = prev;
+    bool has_d = true;
+    switch (op) {
+    case D_COPY: d = a; break;
+    case D_ADD: d = fe_add(a, b, P); break;
+    case D_SUB: d = fe_sub(a, b, P); break;
+    case D_NEG: d = fe_neg(a, P); break;
+    case D_MMUL: d = fe_mmul(a, b, P); break;
+    case D_MUL2: d = fe_mul2_auto(a, b, P); break;
+    case D_MADD: d = fe_add(fe_mmul(a, b, P), prev, P); break;
+    case D_MULC:
+    case D_MADDC: {
+        const uint32_t cs = (row.w0 >> SH_FLAG) & 3;
+        d = fe_mulc_auto(a, b, cs != 0, ((uint64_t)row.cm_hi << 32) | row.cm_lo, cs == 2, P);
+        if (op == D_MADDC) d = fe_add(d, prev, P);
+        break;
+    }
+    case D_LINSUM: d = eval_linsum<LW, true>(row.aux, bk ? b : fe_zero(), prev, c, P); break;
+    case D_DOTC: d = eval_dotc<true>(row.aux, bk ? b : fe_zero(), prev, c, P); break;
+    case D_BIT: {
+        const uint32_t k = row.aux, w = k >> 5;
+        const uint32_t limb = w == 0 ? a.v[0] : w == 1 ? a.v[1] : w == 2 ? a.v[2] : w == 3 ? a.v[3] : w == 4 ? a.v[4]
+                              : w == 5 ? a.v[5] : w == 6 ? a.v[6] : a.v[7];
+        d = fe_small(k < 256 ? (limb >> (k & 31)) & 1u : 0u);
+        break;
+    }
+    case D_SHL: d = fe_shl(a, b, P); break;
+    case D_SHR: d = fe_shr(a, b, P); break;
+    case D_BAND: d = fe_band(a, b, P); break;
+    case D_BOR: d = fe_bor(a, b, P); break;
+    case D_BXOR: d = fe_bxor(a, b, P); break;
+    case D_BNOT: d = fe_bnot(a, P); break;
+    case D_LT: d = fe_small(fe_lt(a, b, P)); break;
+    case D_GT: d = fe_small(fe_lt(b, a, P)); break;
+    case D_LEQ: d = fe_small(!fe_lt(b, a, P)); break;
+    case D_GEQ: d = fe_small(!fe_lt(a, b, P)); break;
+    case D_EQ: d = fe_small(fe_eq(a, b)); break;
+    case D_NEQ: d = fe_small(!fe_eq(a, b)); break;
+    case D_LAND: d = fe_small(!fe_is_zero(a) & !fe_is_zero(b)); break;
+    case D_LOR: d = fe_small(!fe_is_zero(a) | !fe_is_zero(b)); break;
+    case D_LNOT: d = fe_small(fe_is_zero(a)); break;
+    case D_SELECT:
+        selmask = __ballot(!fe_is_zero(a));
+        has_d = false;
+        break;
+    case D_EXT: {
+        const bool t = (selmask >> (c.lane16 >> 4)) & 1;
+        for (int k = 0; k < 8; k++) d.v[k] = t ? a.v[k] : b.v[k];
+        break;
+    }
+    case D_ASSERT_EQ:
+        if (!fe_eq(a, b) && st == 0) st = CW_ST_ASSERT_FAILED | (row.aux << 8);
+        has_d = false;
+        break;
+    case D_ASSERT_NZ:
+        if (fe_is_zero(a) && st == 0) st = CW_ST_ASSERT_FAILED | (row.aux << 8);
+        has_d = false;
+        break;
+    default:
+        has_d = false;
+        if (FULL_OPS) {
+            has_d = true;
+            switch (op) {
+            case D_INV: d = fe_inv(a, P); break;
+            case D_POW: d = fe_pow(a, b, P); break;
+            case D_IDIV:
+            case D_MOD: {
+                fe qq, rr;
+                if (fe_is_zero(b)) {
+                    if (st == 0) st = CW_ST_ARITH | (row.aux << 8);
+                    d = fe_zero();
+                } else {
+                    fe_divmod(a, b, &qq, &rr);
+                    d = (op == D_IDIV) ? qq : rr;
+                }
+                break;
+            }
+            default: has_d = false; break;
+            }
+        }
+        break;
+    }
+    if (has_d) {
+        prev = d;
+        const uint32_t de = (row.abd >> 16) & 0xFFu;
+        if (de != 0xFFu) lds_store_off(de << 11, c, d);
+    }
+    // always two stores = four vector-memory instructions (rows without a value carry no targets)
+    pipe_store(row.st0, d, c.Vb, slot_bytes, c.vlo, c.vhi);
+    pipe_store(row.st1, d, c.Vb, slot_bytes, c.vlo, c.vhi);
+}
+
+template <bool FULL_OPS, int LW, int NB, int NLD>
+__global__ void __launch_bounds__(64)
+cw_pipe_kernel(const CwPRow *__restrict__ rows, uint32_t n_rows, const uint32_t *__restrict__ loads,
+               const uint64_t *__restrict__ terms, uint4 *V, const uint32_t *__restrict__ consts,
+               const uint32_t *__restrict__ lconsts, uint64_t slot_stride, uint32_t Bp, uint32_t batch, uint32_t lanes,
+               uint32_t *status, FpParams P) {
+    static_assert(NB == 4 || NB == 8, "the wait below is written for these");
+    const uint32_t lane = threadIdx.x;
+    if (lane < lanes) {
+        const uint32_t i = blockIdx.x * lanes + lane;              // < Bp
+        EvalCtx c;
+        c.Vb = (const char *)V;
+        c.Cb = (const char *)consts;
+        c.vlo = i * 16u;
+        c.vhi = i * 16u + Bp * 16u;
+        c.lane16 = lane * 16u;
+        c.Lb = lconsts;
+        c.fcode = nullptr;
+        c.ftab = nullptr;
+        c.slot_stride = slot_stride;
+        c.terms = terms;
+        c.tp = 0;
+        const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)cw_lds;
+        const uint64_t vbase = (uint64_t)V, cbase = (uint64_t)consts, half_bytes = (uint64_t)Bp * 16u;
+        pipe_issue<NLD>(loads, 0, 2 * NB, vbase, cbase, slot_stride, half_bytes, c.vlo, lds_base);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pipe_issue<NLD>(loads, 1, 2 * NB, vbase, cbase, slot_stride, half_bytes, c.vlo, lds_base);
+        uint32_t st = 0;
+        uint64_t selmask = 0;
+        fe prev = fe_zero();
+#ifdef CW_PROFILE                  // per-opcode clocks of workgroup 0 in LDS behind the value entries (tools/profile_ops.sh)
+        unsigned long long *prof_tab = (unsigned long long *)((char *)cw_lds + (2 * NB + 2 * NLD) * 2048);
+        unsigned long long prof_t0 = 0;
+        if (lane == 0)
+            for (int k = 0; k < 128; k++) prof_tab[k] = 0;
+#define PIPE_PROF_BEGIN() prof_t0 = __builtin_readcyclecounter()
+#define PIPE_PROF_END(row)                                                                   \
+    do {                                                                                     \
+        if (blockIdx.x == 0 && lane == 0) {                                                  \
+            prof_tab[((row).w0 & 63u) * 2] += __builtin_readcyclecounter() - prof_t0;       \
+            prof_tab[((row).w0 & 63u) * 2 + 1] += 1;                                         \
+        }                                                                                    \
+    } while (0)
+#else
+#define PIPE_PROF_BEGIN()
+#define PIPE_PROF_END(row)
+#endif
+        // the row table is padded by 3 NOP rows
+        CwPRow r0 = rows[0], r1 = rows[1];
+        fe a0 = fe_zero(), b0 = fe_zero(), a1, b1;
+        for (uint32_t r = 0; r < n_rows; r += 2) {
+            const CwPRow r2 = rows[r + 2];
+            if ((r & (NB - 1)) == 0) {
+                if (r) {
+                    // 4*NB stores were issued since L(r / NB): everything older has completed
+#ifndef CW_PEXP_NOLOAD
+                    if (NB == 8) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+#endif
+                    pipe_issue<NLD>(loads, r / NB + 1, 2 * NB, vbase, cbase, slot_stride, half_bytes, c.vlo, lds_base);
+                }
+                // first row of a batch: its staged operands have only just landed
+                a0 = lds_load_off((r0.abd & 0xFFu) << 11, c);
+                b0 = lds_load_off(((r0.abd >> 8) & 0xFFu) << 11, c);
+            }
+            PIPE_PROF_BEGIN();
+            pipe_step<FULL_OPS, LW>(r0, a0, b0, r1, a1, b1, prev, selmask, st, c, slot_stride, P);
+            PIPE_PROF_END(r0);
+            r0 = rows[r + 3];
+            PIPE_PROF_BEGIN();
+            pipe_step<FULL_OPS, LW>(r1, a1, b1, r2, a0, b0, prev, selmask, st, c, slot_stride, P);
+            PIPE_PROF_END(r1);
+            r1 = r0;
+            r0 = r2;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the last load list must not outlive the wave's LDS
+#ifdef CW_PROFILE
+        if (blockIdx.x == 0 && lane == 0)
+            for (int k = 0; k < 128; k++) atomicAdd(&cw_prof[k], prof_tab[k]);
+#endif
+        if (st && i < batch) atomicCAS(&status[i], 0u, st);
+    }
+}
+
 // ---- R1CS check:  (A.w) * (B.w) == C.w  for every constraint row and instance ---------------------------
 // One single-wave workgroup = 64 instances x one chunk of constraint rows (uniform control flow).  The host
 // flattens the rows into a term stream (cw_r1cs_plan.h): word 0 = value slot | accumulator (A/B/C) | row-end
@@ -885,6 +1150,34 @@ hipError_t cwk_eval(hipStream_t s, bool full, bool wide_linsum, const CwDRow *ro
     hipLaunchKernelGGL(k, grid, block, lds_bytes, s, rows, stream_off, extras, extra_off, terms, term_off, (uint4 *)V,
                        consts, lconsts, (const uint4 *)fncode, (const uint4 *)fntab, slot_stride, Bp, batch, lanes, prio_mask,
                        status, P);
+    return hipGetLastError();
+}
+hipError_t cwk_eval_pipe(hipStream_t s, bool full, bool wide_linsum, uint32_t nb, uint32_t nld, const void *rows, uint32_t n_rows,
+                         const uint32_t *loads, const uint64_t *terms, void *V, const uint32_t *consts, const uint32_t *lconsts,
+                         uint64_t slot_stride, uint32_t Bp, uint32_t batch, uint32_t lanes, uint32_t *status, const FpParams &P) {
+    typedef void (*kern_t)(const CwPRow *, uint32_t, const uint32_t *, const uint64_t *, uint4 *, const uint32_t *, const uint32_t *,
+                           uint64_t, uint32_t, uint32_t, uint32_t, uint32_t *, FpParams);
+    kern_t k = nullptr;
+#define PIPE_PICK(F, W)                                                                   \
+    (nb == 8 && nld == 8   ? (kern_t)cw_pipe_kernel<F, W, 8, 8>                            \
+     : nb == 8 && nld == 4 ? (kern_t)cw_pipe_kernel<F, W, 8, 4>                            \
+     : nb == 4 && nld == 4 ? (kern_t)cw_pipe_kernel<F, W, 4, 4>                            \
+                           : (kern_t) nullptr)
+    (void)wide_linsum;          // long small-coefficient sums belong to bit-level circuits, which have their own engine
+    k = full ? PIPE_PICK(true, 2) : PIPE_PICK(false, 2);
+#undef PIPE_PICK
+    if (!k) return hipErrorInvalidValue;
+    size_t lds_bytes = (size_t)(2 * nb + 2 * nld) * 2048;
+#ifdef CW_PROFILE
+    lds_bytes += 1024;
+#endif
+    if (lds_bytes >= 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    dim3 grid((batch + lanes - 1) / lanes), block(64);
+    hipLaunchKernelGGL(k, grid, block, lds_bytes, s, (const CwPRow *)rows, n_rows, loads, terms, (uint4 *)V, consts, lconsts,
+                       slot_stride, Bp, batch, lanes, status, P);
     return hipGetLastError();
 }
 hipError_t cwk_r1cs(hipStream_t s, const uint32_t *chunk, uint32_t n_chunks, const uint32_t *terms, const uint32_t *ctab,

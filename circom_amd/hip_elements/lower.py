@@ -121,6 +121,8 @@ class Tape:
         self.n_pub_in = 0           # public inputs of main (`component main {public [...]}`); outputs are always public
         self.stats = {}
         self.rbits = 261            # Montgomery radix exponent of MMUL rows
+        self.kind = 0               # 0 = strand schedule (passes C/D), 1 = pipelined single-wave schedule (pipe.py)
+        self.pipe = (0, 0, 0)       # kind 1: rows per batch, loads per batch, ring entries
         self.functions = []         # device bytecode of circom functions: (n_regs, uint32[n,4])
 
 
@@ -485,35 +487,47 @@ def _reassociate(rows, n_vtemps):
     return out, nxt
 
 
-INV_WINDOW = 96      # same-level inversions at most this many rows apart are batched
-INV_GROUP = 8        # members per batch
+INV_WINDOW = 2048    # independent inversions at most this many rows behind the previous member join its batch
+INV_GROUP = 64       # members per batch
 
 
 def _batch_inversions(rows, n_vtemps, cid):
-    """Pass A4: Montgomery's trick.  k independent inversions (same dependency level, close together in program
-    order: the two denominators of a BabyAdd, the lambdas of parallel ladder segments, ...) become ONE inversion
-    of their running product plus 3(k-1) multiplications:
-        p_i = e_1 ... e_i,   t = 1/p_k,   1/e_i = t_i * p_(i-1),   t_(i-1) = t_i * e_i.
+    """Pass A4: Montgomery's trick.  k mutually independent inversions, close together in program order (the two
+    denominators of a BabyAdd, the Z's of a projective ladder, the lambdas of parallel ladder segments, ...) become ONE
+    inversion of their product plus 3(k-1) multiplications, arranged as a product tree (depth 2 log2 k, so that the strands
+    can share the work):  up: p = p_left * p_right;  t_root = 1 / p_root;  down: t_left = t * p_right, t_right = t * p_left.
+    Independence: inversions whose ARGUMENTS have the same inversion depth (number of INV rows on the longest path from
+    the inputs) cannot feed one another.
     The reference's inverse maps 0 to 0 (mpz_invert fails, generic/fr.cpp:2895-2906), and a zero member would
     poison the product, so each member enters as e = d + [d == 0] and leaves as 1/e - [d == 0].
     Consumers of an early member that sit before the last member in program order are moved behind the batch
     (the rows are in SSA form, so any order that respects the data flow computes the same values)."""
-    level = {}
+    depth = {}
     inv_idx = []
+    sel_depth = 0
     for idx, r in enumerate(rows):
         lv = 0
         for k, v in _value_operands(r):
             if k == K_SIG or k == K_TMP:
-                lv = max(lv, level.get((k, v), -1) + 1)
-        if r.dk in (K_SIG, K_TMP):
-            level[(r.dk, r.dv)] = lv
-        if r.op == D_INV and r.extra is None:
+                lv = max(lv, depth.get((k, v), 0))
+        if r.op == D_SELECT:             # the EXT row that follows also depends on the latched condition
+            sel_depth = lv
+        elif r.op == D_EXT:
+            lv = max(lv, sel_depth)
+        is_inv = r.op == D_INV and r.extra is None
+        if is_inv:
             inv_idx.append((idx, lv))
-    open_group = {}                      # level -> current group (list of row indices)
+        out_lv = lv + 1 if r.op == D_INV else lv
+        if r.dk in (K_SIG, K_TMP):
+            depth[(r.dk, r.dv)] = out_lv
+        if r.extra:
+            for x in r.extra:
+                depth[x] = out_lv
+    open_group = {}                      # inversion depth -> current group (list of row indices)
     groups = []
     for idx, lv in inv_idx:
         g = open_group.get(lv)
-        if g is None or idx - g[0] > INV_WINDOW or len(g) >= INV_GROUP:
+        if g is None or idx - g[-1] > INV_WINDOW or len(g) >= INV_GROUP:
             g = []
             groups.append(g)
             open_group[lv] = g
@@ -547,27 +561,31 @@ def _batch_inversions(rows, n_vtemps, cid):
             out.append(_Row(D_ADD, ei[0], ei[1], r.ak, r.av, zi[0], zi[1]))
             z.append(zi)
             e.append(ei)
-        pref = [e[0]]
-        for i in range(1, len(mem)):
-            pi = tmp()
-            out.append(_Row(D_MUL2, pi[0], pi[1], pref[-1][0], pref[-1][1], e[i][0], e[i][1]))
-            pref.append(pi)
+        # product tree, bottom up (an odd node is carried to the next level unchanged)
+        levels = [e]
+        while len(levels[-1]) > 1:
+            cur, up = levels[-1], []
+            for i in range(0, len(cur) - 1, 2):
+                pi = tmp()
+                out.append(_Row(D_MUL2, pi[0], pi[1], cur[i][0], cur[i][1], cur[i + 1][0], cur[i + 1][1]))
+                up.append(pi)
+            if len(cur) & 1:
+                up.append(cur[-1])
+            levels.append(up)
         t = tmp()
-        out.append(_Row(D_INV, t[0], t[1], pref[-1][0], pref[-1][1]))
-        inv = [None] * len(mem)
-        for i in range(len(mem) - 1, 0, -1):
-            ri = tmp()
-            out.append(_Row(D_MUL2, ri[0], ri[1], t[0], t[1], pref[i - 1][0], pref[i - 1][1]))
-            inv[i] = ri
-            if i > 1:
-                t2 = tmp()
-                out.append(_Row(D_MUL2, t2[0], t2[1], t[0], t[1], e[i][0], e[i][1]))
-                t = t2
-            else:
-                t2 = tmp()
-                out.append(_Row(D_MUL2, t2[0], t2[1], t[0], t[1], e[1][0], e[1][1]))
-                t = t2
-        inv[0] = t
+        out.append(_Row(D_INV, t[0], t[1], levels[-1][0][0], levels[-1][0][1]))
+        inv = [t]
+        for lv in range(len(levels) - 2, -1, -1):      # top down: the inverse of a node times its sibling's product
+            cur, down = levels[lv], []
+            for i in range(0, len(cur) - 1, 2):
+                ti = inv[i // 2]
+                tl, tr = tmp(), tmp()
+                out.append(_Row(D_MUL2, tl[0], tl[1], ti[0], ti[1], cur[i + 1][0], cur[i + 1][1]))
+                out.append(_Row(D_MUL2, tr[0], tr[1], ti[0], ti[1], cur[i][0], cur[i][1]))
+                down.extend((tl, tr))
+            if len(cur) & 1:
+                down.append(inv[len(cur) // 2])
+            inv = down
         for r, ri, zi in zip(mem, inv, z):
             out.append(_Row(D_SUB, r.dk, r.dv, ri[0], ri[1], zi[0], zi[1]))
 
@@ -905,7 +923,61 @@ def _encode_function(fn, cid, q):
     return fn["n_regs"], out
 
 
-def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
+def _finish_pipe(fc, stream, dconsts, lconsts, lcid, witness_map, pipe, stats):
+    import sys
+    from . import pipe as PP
+    n_signals = fc.n_signals
+    n_before = len(lconsts)
+    pl = PP.plan_pipe(stream, n_signals, dconsts, sys.modules[__name__], pipe[0], pipe[1])
+    t = Tape()
+    t.kind = 1
+    t.pipe = (pipe[0], pipe[1], pl["ring"])
+    t.prime = fc.prime
+    t.q = fc.fp.q
+    t.n_signals = n_signals
+    t.n_tslots = pl["n_tslots"]
+    t.rows = pl["rows"]
+    t.stream_off = np.asarray([0, len(pl["rows"])], dtype=np.uint32)
+    t.extras = pl["loads"].reshape(-1)
+    t.extra_off = np.asarray([0, len(t.extras)], dtype=np.uint32)
+    tt = np.zeros((len(pl["terms"]) + 4, 4), dtype=np.uint32)
+    for j, (tk, te, cf, is_dotc) in enumerate(pl["terms"]):
+        if is_dotc:
+            tt[j] = (tk, te, lcid(cf), 0)
+        else:
+            m = abs(cf)
+            tt[j] = (tk | (0x80000000 if cf < 0 else 0), te, m & 0xFFFFFFFF, m >> 32)
+    assert len(lconsts) == n_before, "the limb-form constant table is shared by all variants"
+    t.terms = tt
+    t.term_off = np.asarray([0, len(pl["terms"])], dtype=np.uint32)
+    t.lconsts = lconsts
+    t.functions = []
+    t.n_lds = pl["ring"] + 2 * pipe[1]
+    t.n_strands = 1
+    t.consts = dconsts
+    if witness_map is None:
+        witness_map = np.arange(n_signals, dtype=np.uint32)
+    t.witness2signal = np.asarray(witness_map, dtype=np.uint32)
+    t.n_witness = len(t.witness2signal)
+    t.inputs = list(fc.inputs)
+    t.main_input_start = fc.main_input_start
+    t.n_main_inputs = fc.n_main_inputs
+    t.n_pub_in = fc.n_pub_in
+    dops = t.rows[:, 0] & 0xFF
+    t.stats = dict(stats)
+    t.stats.update(pl["stats"])
+    t.stats.update({
+        "rows": int(len(t.rows)), "strands": 1, "temp_slots": t.n_tslots, "consts": len(dconsts), "barriers": 0,
+        "mmul": int((dops == D_MMUL).sum()), "mul2": int((dops == D_MUL2).sum()),
+        "mulc": int(((dops == D_MULC) | (dops == D_MADDC)).sum()), "dotc": int((dops == D_DOTC).sum()),
+        "addsub": int(((dops == D_ADD) | (dops == D_SUB) | (dops == D_NEG)).sum()), "inv": int((dops == D_INV).sum()),
+        "linsum_terms": len(pl["terms"]),
+    })
+    return t
+
+
+def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None) -> Tape:
+    """pipe = (rows per batch, loads per batch): lower to the pipelined single-wave variant (pipe.py) instead of strands"""
     q = fc.fp.q
     if not 225 <= q.bit_length() <= 256:
         raise ValueError("hip_elements targets circom's 253..256-bit primes (4 x 64-bit limbs); prime %s has %d bits "
@@ -913,8 +985,12 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
                          % (fc.prime, q.bit_length()))
     n_signals = fc.n_signals
     functions = getattr(fc, "functions", ())
+    if pipe is not None:
+        n_strands = 1
     if functions and (fc.code["op"] == O.CALL).any():
         n_strands = 1               # tier-2 code is the slow path: program order, one wave per 64 instances
+        if pipe is not None:
+            raise ValueError("circuits that call run-time functions have no pipelined variant")
     rows, dconsts, n_vtemps, cid, plain = _expand(fc)
     rows, n_vtemps, n_inv_batches = _batch_inversions(rows, n_vtemps, cid)
     rows, n_lin, n_bit = _fuse_linear(rows, plain, q, cid)
@@ -944,6 +1020,10 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1) -> Tape:
         rows, n_madd = _fuse_madd(rows)
     streams, n_levels = _schedule(rows, n_signals, n_strands)
     multi = n_strands > 1
+    if pipe is not None:
+        return _finish_pipe(fc, streams[0], dconsts, lconsts, lcid, witness_map, pipe,
+                            {"copies_elided": n_elided, "fused_madd": n_madd, "inv_batches": n_inv_batches, "linsum": n_lin,
+                             "bit": n_bit, "asserts_proved": getattr(_expand, "n_proved", 0)})
 
     def vid(k, v):
         return v if k == K_SIG else n_signals + v

@@ -93,9 +93,11 @@ def write_tape(path, tapes, bittape=None):
             witness2signal  n_witness x u32
             input names     per name  u32 len | bytes | u32 start | u32 size
             functions       n_functions x { u32 n_regs | u32 n_ins | n_ins x 4 x u32 }   (device bytecode, lower.py D_CALL)
-            per variant     u32 n_strands | u32 n_tslots | u32 n_rows | u32 n_extras | u32 n_lds | u32 n_terms | 2 x u32 0
+            per variant     u32 n_strands | u32 n_tslots | u32 n_rows | u32 n_extras | u32 n_lds | u32 n_terms | u32 kind | u32 shape
                             stream_off | extra_off | term_off      ((n_strands+1) x u32 each)
                             rows n_rows x 4 x u32 | extras n_extras x u32 | terms n_terms x 4 x u32
+                            kind 1 (pipelined, pipe.py): rows are 8 x u32, `extras` = the load lists ((n_rows/NB + 2) x NLD
+                            words), shape = NB | NLD << 8, n_lds = 2*NB + 2*NLD
             bit program     (if n_bit_programs, hip_elements/bitsched.py)  8 x u32: ring, n_vrows, n_slots lo, hi, 0, 0, 0, 0
                             then n_vrows x 64 records of 4 x u32, then signal -> slot map n_signals x u32
     """
@@ -122,7 +124,9 @@ def write_tape(path, tapes, bittape=None):
             f.write(struct.pack("<2I", n_regs, len(fcode)))
             f.write(np.ascontiguousarray(fcode, dtype="<u4").tobytes())
         for t in tapes:
-            f.write(struct.pack("<8I", t.n_strands, t.n_tslots, len(t.rows), len(t.extras), t.n_lds, len(t.terms), 0, 0))
+            kind = getattr(t, "kind", 0)
+            shape = (t.pipe[0] | (t.pipe[1] << 8)) if kind == 1 else 0
+            f.write(struct.pack("<8I", t.n_strands, t.n_tslots, len(t.rows), len(t.extras), t.n_lds, len(t.terms), kind, shape))
             f.write(np.asarray(t.stream_off, dtype="<u4").tobytes())
             f.write(np.asarray(t.extra_off, dtype="<u4").tobytes())
             f.write(np.asarray(t.term_off, dtype="<u4").tobytes())

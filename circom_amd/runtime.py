@@ -60,6 +60,7 @@ _SIGS = {
     "cw_batch_free": (None, [C.c_void_p]),
     "cw_batch_size": (C.c_uint32, [C.c_void_p]),
     "cw_batch_strands": (C.c_uint32, [C.c_void_p]),
+    "cw_batch_pipelined": (C.c_uint32, [C.c_void_p]),
     "cw_batch_lanes": (C.c_uint32, [C.c_void_p]),
     "cw_batch_bitmode": (C.c_int, [C.c_void_p]),
     "cw_bits_info": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -177,6 +178,8 @@ class Batch:
         _chk(lib().cw_batch_create(circuit.h, device, batch, C.c_void_p(stream or 0), C.byref(h)))
         self.h = h
         self.strands = lib().cw_batch_strands(h)
+        pp = lib().cw_batch_pipelined(h)
+        self.pipelined = (pp & 0xFF, pp >> 8) if pp else None     # (rows per batch, loads per batch) of the pipelined variant
         self.lanes = lib().cw_batch_lanes(h)
         self.bitmode = bool(lib().cw_batch_bitmode(h))
 

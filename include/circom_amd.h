@@ -70,6 +70,9 @@ void cw_batch_free(cw_batch *b);
 uint32_t cw_batch_size(const cw_batch *b);
 /* strands (waves cooperating on the same 64 instances) of the schedule variant picked for this batch */
 uint32_t cw_batch_strands(const cw_batch *b);
+/* 0, or (rows per batch | loads per batch << 8) when the batch runs the pipelined single-wave variant of the schedule
+   (LDS result ring + load lists issued one batch ahead: hip_elements/pipe.py; CW_PIPE=0/1 overrides the choice) */
+uint32_t cw_batch_pipelined(const cw_batch *b);
 /* instances per workgroup (64, 32 or 16) the evaluation kernel uses for this batch */
 uint32_t cw_batch_lanes(const cw_batch *b);
 /* 1 if this batch runs the bit-plane program (circuits whose signals are all boolean for 0/1 inputs: one bit per

@@ -155,7 +155,7 @@ def time_reference(cp, workload: str, seconds_budget: float = 15.0):
             import random
             from circom_amd.circuits import eddsa_host as H
             r = random.Random(1)
-            pool = [b"".join(v.to_bytes(32, "little") for v in H.semaphore_inputs(q, int(workload[9:] or 20), r)[0])
+            pool = [b"".join(v.to_bytes(32, "little") for v in H.semaphore_inputs(q, int(workload[9:].rstrip("p") or 20), r)[0])
                     for _ in range(min(n, 16))]
             return b"".join(pool[i % len(pool)] for i in range(n))
         vals = [int.from_bytes(rng.bytes(32), "little") % q for _ in range(n * n_in)]
@@ -235,6 +235,7 @@ def build_default_circuits():
     from circom_amd.circuits.sha256 import Sha256
     from circom_amd.circuits.eddsa import SemaphoreStyle
     for name, prog in (("multiplier2", Program(Multiplier2())), ("poseidon2", Program(Poseidon(2))),
-                       ("sha256_512", Program(Sha256(512))), ("semaphore20", Program(SemaphoreStyle(20)))):
+                       ("sha256_512", Program(Sha256(512))), ("semaphore20", Program(SemaphoreStyle(20))),
+                       ("semaphore20p", Program(SemaphoreStyle(20, True))), ("sha256_2048", Program(Sha256(2048)))):
         cp = compile_program(prog, d, name, sym=False)
         build_circuit(cp)

@@ -440,9 +440,189 @@ def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict,
 
 def eval_tape(tape, inputs: dict):
     """Convenience wrapper over a circom_amd.hip_elements.lower.Tape (duck-typed)."""
+    if getattr(tape, "kind", 0) == 1:
+        return eval_pipe(tape.q, tape.n_signals, tape.n_tslots, tape.consts, tape.rows, tape.extras, tape.terms, tape.lconsts,
+                         tape.pipe, inputs, tape.rbits)
     return eval_rows(tape.q, tape.n_signals, tape.n_tslots, tape.consts, tape.rows, inputs, tape.rbits,
                      tape.stream_off, tape.extras, tape.extra_off, tape.n_lds, tape.terms, tape.term_off, tape.lconsts,
                      getattr(tape, "functions", ()))
+
+
+# ---- pipelined single-wave schedule (circom_amd/hip_elements/pipe.py), executed the way cw_pipe_kernel does ------------
+P_NONE = 0xFFFFFFFF
+PX_TMP, PX_CONST = 1 << 31, 1 << 30
+P_ENTRY_NONE = 0xFF
+D_NOP = 255
+
+
+def eval_pipe(q: int, n_signals: int, n_tslots: int, consts, rows, loads, terms, lconsts, pipe, inputs: dict, rbits: int = 261):
+    """Replays a pipelined schedule for one instance with the kernel's timing:
+      * L(k), the load list of batch k, reads the value table / constant table when batch k-1 starts (after batch k-2's
+        loads have landed) and lands in the staging half k % 2 when batch k starts; L(0) and L(1) are issued up front;
+      * the a/b operands of row r+1 are read from LDS BEFORE row r writes its ring entry, except for the first row of a
+        batch, which reads them after its batch's loads have landed; LINSUM / DOTC terms are read when the row executes;
+      * a value-producing row writes ring entry `d`, then its two store targets.
+    Raises ScheduleHazard for: an LDS entry read before anything wrote it, a staging entry of the half that is being
+    filled, a load of a temp slot nobody wrote, a store on a row without a value.
+    Returns (signal values, status) like eval_rows."""
+    f = Field(q)
+    nb, nld, rr = pipe
+    rinv = pow(1 << rbits, -1, q)
+    sig = [0] * n_signals
+    sig[0] = 1
+    for k, v in inputs.items():
+        sig[k] = v % q
+    tmp = [None] * max(n_tslots, 1)
+    n_ent = rr + 2 * nld
+    lds = [None] * n_ent
+    rows = [tuple(int(x) for x in r) for r in rows]
+    loads = [int(x) for x in loads]
+    terms = [tuple(int(x) for x in t) for t in terms]
+    n_rows = len(rows)
+    if n_rows % nb or len(loads) != (n_rows // nb + 2) * nld:
+        raise ScheduleHazard("row / load counts do not form whole batches")
+    bins = {k: getattr(f, v) for k, v in _DBIN.items()}
+    uns = {k: (getattr(f, v) if v else (lambda x: x)) for k, v in _DUN.items()}
+    status = 0
+    pending = {}
+
+    def issue(k):
+        vals = []
+        for j in range(nld):
+            lw = loads[k * nld + j]
+            if lw == P_NONE:
+                vals.append(None)
+            elif lw & PX_TMP:
+                v = tmp[lw & 0x3FFFFFFF]
+                if v is None:
+                    raise ScheduleHazard("batch %d loads temp slot %d before any row stored it" % (k, lw & 0x3FFFFFFF))
+                vals.append(v)
+            elif lw & PX_CONST:
+                vals.append(consts[lw & 0x3FFFFFFF])
+            else:
+                vals.append(sig[lw])
+        pending[k] = vals
+
+    def land(k):
+        base = rr + (k & 1) * nld
+        for j, v in enumerate(pending.pop(k)):
+            lds[base + j] = v
+
+    def lds_read(pos, e):
+        k = pos // nb
+        if e >= n_ent:
+            raise ScheduleHazard("row %d: LDS entry %d out of range" % (pos, e))
+        if e >= rr and (e - rr) // nld != (k & 1):
+            raise ScheduleHazard("row %d reads the staging half that is being filled" % pos)
+        v = lds[e]
+        if v is None:
+            raise ScheduleHazard("row %d reads LDS entry %d, which holds nothing" % (pos, e))
+        return v
+
+    def operands(pos):
+        w0, _, abd = rows[pos][:3]
+        op = w0 & 0xFF
+        ak, bk = (w0 >> 8) & 7, (w0 >> 11) & 7
+        a = lds_read(pos, abd & 0xFF) if ak == K_LDS else None
+        b = lds_read(pos, (abd >> 8) & 0xFF) if bk == K_LDS else None
+        return a, b
+
+    issue(0)
+    land(0)
+    issue(1)
+    prev = 0
+    sel = False
+    tp = 0
+    pre = (None, None)
+    for pos in range(n_rows):
+        if pos % nb == 0:
+            if pos:
+                land(pos // nb)
+                issue(pos // nb + 1)
+            pre = operands(pos)
+        w0, aux, abd, st0, st1, cml, cmh, _ = rows[pos]
+        op, ak, bk, flag = w0 & 0xFF, (w0 >> 8) & 7, (w0 >> 11) & 7, (w0 >> 29) & 3
+        a, b = pre
+        if pos + 1 < n_rows and (pos + 1) % nb:
+            pre = operands(pos + 1)
+        if ak == K_PREV:
+            a = prev
+        if bk == K_PREV:
+            b = prev
+        res = None
+        if op == D_NOP:
+            pass
+        elif op == D_MMUL:
+            res = a * b * rinv % q
+        elif op == D_MUL2:
+            res = a * b % q
+        elif op == D_MADD:
+            res = (a * b * rinv + prev) % q
+        elif op in (D_MULC, D_MADDC):
+            res = a * b * rinv % q
+            if flag:
+                mag = cml | (cmh << 32)
+                c_plain = mag if flag == 1 else (q - mag) % q
+                if mag >= (1 << 63) or (a * c_plain) % q != res:
+                    raise ScheduleHazard("constant pair of row %d is inconsistent" % pos)
+            if op == D_MADDC:
+                res = (res + prev) % q
+        elif op in bins:
+            try:
+                res = bins[op](a, b)
+            except FieldError:
+                if status == 0:
+                    status = 2 | (aux << 8)
+                res = 0
+        elif op in uns:
+            res = uns[op](a)
+        elif op in (D_LINSUM, D_DOTC):
+            acc = b if bk else 0
+            for (tk, te, lo, hi) in terms[tp:tp + aux]:
+                kind = tk & 7
+                x = prev if kind == K_PREV else lds_read(pos, te)
+                if kind not in (K_PREV, K_LDS):
+                    raise ScheduleHazard("row %d: term kind %d" % (pos, kind))
+                if op == D_DOTC:
+                    acc += x * lconsts[lo] * rinv
+                else:
+                    cf = lo | (hi << 32)
+                    acc += -cf * x if tk >> 31 else cf * x
+            tp += aux
+            res = acc % q
+        elif op == D_BIT:
+            res = (a >> aux) & 1 if aux < 256 else 0
+        elif op == D_SELECT:
+            sel = a != 0
+        elif op == D_EXT:
+            res = a if sel else b
+        elif op == D_ASSERT_EQ:
+            if a != b and status == 0:
+                status = 1 | (aux << 8)
+        elif op == D_ASSERT_NZ:
+            if a == 0 and status == 0:
+                status = 1 | (aux << 8)
+        else:
+            raise ValueError("bad device op %d in a pipelined schedule" % op)
+        d = (abd >> 16) & 0xFF
+        if res is not None:
+            prev = res
+            if d != P_ENTRY_NONE:
+                if d >= rr:
+                    raise ScheduleHazard("row %d writes outside the ring" % pos)
+                lds[d] = res
+            for st in (st0, st1):
+                if st == P_NONE:
+                    continue
+                if st & PX_TMP:
+                    tmp[st & 0x3FFFFFFF] = res
+                else:
+                    sig[st] = res
+        elif d != P_ENTRY_NONE or st0 != P_NONE or st1 != P_NONE:
+            raise ScheduleHazard("row %d has destinations but no value" % pos)
+    if tp != len(terms) - 4 and tp != len(terms):
+        raise ScheduleHazard("term table not consumed exactly")
+    return sig, status
 
 
 # ---- bit-plane program (circom_amd/hip_elements/bitsched.py), executed the way cw_bits_eval_kernel does ----------------

@@ -126,3 +126,77 @@ def test_gpu_semaphore_matches_oracle_and_reference(sem, tmp_path):
             b.write_wtns(i, g)
             assert g.read_bytes() == open(pre + "%d.wtns" % j, "rb").read(), i
     b.close(); c.close()
+
+
+# ---- the same relation with the scalar multiplications' witnesses computed on a projective ladder ---------------------
+@pytest.fixture(scope="module")
+def semp(tmp_path_factory):
+    d = tmp_path_factory.mktemp("semp")
+    return compile_program(Program(SemaphoreStyle(LEVELS, True)), str(d), "semaphore20p", sym=False)
+
+
+def test_projective_ladder_same_outputs_fewer_chained_inversions(semp):
+    fc = semp.flat
+    rng = random.Random(7)
+    row, (root, nullifier) = H.semaphore_inputs(Q, LEVELS, rng)
+    sig, failed = eval_flat(Q, fc.n_signals, fc.n_temps, fc.constants, fc.code, _inp(fc, row))
+    assert failed is None and (sig[1], sig[2]) == (root, nullifier)
+    assert check_r1cs(Q, fc.constraints, sig) is None
+    for S in (1, 16):
+        tp = lower(fc, n_strands=S)
+        got, st = eval_tape(tp, _inp(fc, row))
+        assert st == 0 and got == sig
+        assert tp.stats["inv"] > 1000 and tp.stats["inv_batches"] <= 8      # the inversions do not depend on each other
+    for k, v in ((2, (row[2] + 1) % SUBGROUP_ORDER), (5, row[5] ^ 1), (0, row[0] ^ 1)):
+        bad = list(row)
+        bad[k] = v % Q
+        assert eval_flat(Q, fc.n_signals, fc.n_temps, fc.constants, fc.code, _inp(fc, bad))[1] is not None
+
+
+def test_projective_ladder_reference_runtime_wtns_equal_oracle(semp, tmp_path, ref_dir_bn128):
+    try:
+        ref_build.build_circuit(semp)
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    fc = semp.flat
+    rng = random.Random(12)
+    rows = [H.semaphore_inputs(Q, LEVELS, rng)[0] for _ in range(2)]
+    raw = b"".join(v.to_bytes(32, "little") for r in rows for v in r)
+    pre = str(tmp_path / "r_")
+    ref_build.run_loop(semp, raw, len(rows), 1, wtns_prefix=pre)
+    for i, r in enumerate(rows):
+        want, failed = eval_flat(Q, fc.n_signals, fc.n_temps, fc.constants, fc.code, _inp(fc, r))
+        assert failed is None
+        assert open(pre + "%d.wtns" % i, "rb").read() == wtns_bytes(Q, want), i
+
+
+@pytest.mark.gpu
+def test_gpu_projective_ladder_matches_oracle_and_reference(semp, tmp_path):
+    from circom_amd import runtime as rt
+    fc = semp.flat
+    rng = random.Random(14)
+    B = 70
+    rows, outs = zip(*(H.semaphore_inputs(Q, LEVELS, rng) for _ in range(B)))
+    rows = [list(r) for r in rows]
+    rows[9][2] = (rows[9][2] + 1) % SUBGROUP_ORDER          # forged signature
+    c = rt.Circuit(semp.tape_path, semp.dat_path, semp.r1cs_path)
+    b = c.batch(B)
+    b.set_inputs(rows)
+    b.run(); b.check_r1cs(); b.sync()
+    st = b.status()
+    assert st[9] & rt.ST_ASSERT_FAILED and (np.delete(st, [9]) == 0).all()
+    for i in (0, 1, 33, 69):
+        assert (b.signal(i, 1), b.signal(i, 2)) == outs[i], i
+    want, failed = eval_flat(Q, fc.n_signals, fc.n_temps, fc.constants, fc.code, _inp(fc, rows[40]))
+    assert failed is None and b.witness(40) == want
+    _, loop = ref_build.binaries("bn128", "semaphore20p")
+    if loop.exists():
+        idx = [0, 1, 2, 3]
+        raw = b"".join(v.to_bytes(32, "little") for i in idx for v in rows[i])
+        pre = str(tmp_path / "ref_")
+        ref_build.run_loop(semp, raw, len(idx), 1, wtns_prefix=pre)
+        for j, i in enumerate(idx):
+            g = tmp_path / ("gpu_%d.wtns" % i)
+            b.write_wtns(i, g)
+            assert g.read_bytes() == open(pre + "%d.wtns" % j, "rb").read(), i
+    b.close(); c.close()

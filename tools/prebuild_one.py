@@ -9,7 +9,8 @@ if name == "poseidon2":
 elif name == "sha256_512":
     from circom_amd.circuits.sha256 import Sha256 as T; prog = T(512)
 else:
-    from circom_amd.circuits.eddsa import SemaphoreStyle as T; prog = T(20)
+    from circom_amd.circuits.eddsa import SemaphoreStyle as T; prog = T(20, name.endswith("p"))
 os.makedirs(out, exist_ok=True)
-cp = compile_program(Program(prog), out, name, sym=False, strands=strands)
+pipe = tuple(int(x) for x in os.environ["CW_PIPE_SHAPE"].split(",")) if os.environ.get("CW_PIPE_SHAPE") else None
+cp = compile_program(Program(prog), out, name, sym=False, strands=strands, pipe=pipe)
 print(out, name, strands, cp.tape.stats.get("barriers"))

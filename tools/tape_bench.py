@@ -23,7 +23,7 @@ ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(st
 for e in ev:
     e[0].record(stream); b.run(); e[1].record(stream); b.check_r1cs(); e[2].record(stream)
 torch.cuda.synchronize()
-print("TB %s %s B=%d S=%d L=%d eval %.3f ms r1cs %.3f ms" % (d, name, B, b.strands, b.lanes, sum(e[0].elapsed_time(e[1]) for e in ev) / steps, sum(e[1].elapsed_time(e[2]) for e in ev) / steps))
+print("TB %s %s B=%d S=%d pipe=%s L=%d eval %.3f ms r1cs %.3f ms" % (d, name, B, b.strands, b.pipelined, b.lanes, sum(e[0].elapsed_time(e[1]) for e in ev) / steps, sum(e[1].elapsed_time(e[2]) for e in ev) / steps))
 
 if os.environ.get("CW_LIB"):
     import ctypes
