@@ -81,7 +81,8 @@ def get_compiled(name: str, batch: int, cache_root: str, rank: int, dist):
     from circom_amd.hip_elements.lower import lower
     fp = source_fingerprint()
     strands = compiler.strands_for(batch)
-    d = os.path.join(cache_root, "%s_s%s_b%s_%s" % (name, "-".join(map(str, strands)), os.environ.get("CW_BITS", "1"), fp))
+    d = os.path.join(cache_root, "%s_s%s_b%s_m%s_%s" % (name, "-".join(map(str, strands)), os.environ.get("CW_BITS", "1"),
+                                                       os.environ.get("CW_MONT", "a"), fp))
     p = lambda ext: os.path.join(d, name + ext)
     t0 = time.perf_counter()
     fc = flatten(make_program(name))
@@ -89,9 +90,13 @@ def get_compiled(name: str, batch: int, cache_root: str, rank: int, dist):
     if rank == 0 and not os.path.exists(done):
         os.makedirs(d, exist_ok=True)
         bittape = None if os.environ.get("CW_BITS", "1") == "0" else compiler.lower_bitplane(fc)
+        mont = compiler.choose_mont(fc)     # arithmetic circuits keep their signals in Montgomery form on the device
+        if os.environ.get("CW_MONT"):
+            mont = os.environ["CW_MONT"] != "0"
         if bittape is not None:
             strands = (1,)                  # the 256-bit schedule only serves instances re-run with non-boolean inputs
-        tapes = [lower(fc, n_strands=s) for s in strands]
+            mont = False
+        tapes = [lower(fc, n_strands=s, mont=mont) for s in strands]
         writers.write_tape(p(".cwt"), tapes, bittape)
         writers.write_dat(p(".dat"), fc)
         writers.write_r1cs(p(".r1cs"), fc)
@@ -414,7 +419,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s bn128 --O0 (%d constraints), batch=%d per GPU" % (args.workload, circ.n_constraints, B),
                        "n_signals": circ.n_signals, "n_witness": n_wit, "n_constraints": circ.n_constraints,
-                       "engine": "bit-plane (1 bit per signal value per instance)" if batch.bitmode else "256-bit schedule",
+                       "engine": "bit-plane (1 bit per signal value per instance)" if batch.bitmode else
+                       ("256-bit schedule, signals in Montgomery form" if circ.montgomery else "256-bit schedule"),
                        "bit_program": bits, "schedule_rows": circ.n_rows, "fp_mul_per_witness": circ.n_mmul,
                        "parallelism": "instances sharded x%d, status + public-signal gather only" % world,
                        "compile_s": compile_s},

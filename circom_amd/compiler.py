@@ -39,6 +39,21 @@ def strands_for(batch: int):
     return (1,)
 
 
+def choose_mont(fc: FlatCircuit) -> bool:
+    """Montgomery-form signals (lower.py pass A6) pay off for arithmetic circuits: every product of two run-time values
+    saves one of its two Montgomery products, every value that an integer operator touches (bit extraction, shifts, bitwise,
+    ordering comparisons, integer division) costs one conversion, and the short paths for small values (bit-level circuits:
+    products and sums of 0/1 signals) are lost.  Chosen when the run-time products outnumber the integer operators 4 : 1."""
+    code = fc.code
+    op = code["op"]
+    if (op == O.CALL).any():
+        return False
+    n_mul = int(((op == O.MUL) & (code["ak"] != O.K_CONST) & (code["bk"] != O.K_CONST)).sum()) + int((op == O.DIV).sum())
+    int_ops = (O.IDIV, O.MOD, O.POW, O.SHL, O.SHR, O.BAND, O.BOR, O.BXOR, O.BNOT, O.LT, O.GT, O.LEQ, O.GEQ)
+    n_int = sum(int((op == o).sum()) for o in int_ops)
+    return n_mul > 0 and n_mul >= 4 * n_int
+
+
 BITS_AUTO_MIN_SIGNALS = 4096
 
 
@@ -63,9 +78,10 @@ DEFAULT_PIPE = None
 
 
 def compile_program(prog: Program, outdir: str, name: str, sym: bool = True, strands=DEFAULT_STRANDS, bits="auto",
-                    pipe=DEFAULT_PIPE) -> Compiled:
+                    pipe=DEFAULT_PIPE, mont="auto") -> Compiled:
     """strands: strand counts to lower the schedule for (one variant each; the runtime picks per batch).
-    pipe: (rows, loads) per batch of the pipelined variant, e.g. (8, 8), which is added last; None = no pipelined variant."""
+    pipe: (rows, loads) per batch of the pipelined variant, e.g. (8, 8), which is added last; None = no pipelined variant.
+    mont: signals in Montgomery form on the device (True / False / "auto" = choose_mont); CW_MONT=0/1 overrides."""
     os.makedirs(outdir, exist_ok=True)
     fc = flatten(prog)
     bittape = lower_bitplane(fc, bits)
@@ -76,9 +92,15 @@ def compile_program(prog: Program, outdir: str, name: str, sym: bool = True, str
         pipe = None                         # run-time control flow: program order on the value table (tier 2)
     if os.environ.get("CW_PIPE_SHAPE"):
         pipe = tuple(int(x) for x in os.environ["CW_PIPE_SHAPE"].split(","))
-    tapes = [lower(fc, n_strands=s) for s in strands]
+    if bittape is not None and os.environ.get("CW_BITS", "1") != "0":
+        mont = False                        # bit-level circuit: the short paths for small values need canonical values
+    elif os.environ.get("CW_MONT"):
+        mont = os.environ["CW_MONT"] != "0" and not (fc.code["op"] == O.CALL).any()
+    elif mont == "auto":
+        mont = choose_mont(fc)
+    tapes = [lower(fc, n_strands=s, mont=mont) for s in strands]
     if pipe is not None:
-        tapes.append(lower(fc, pipe=pipe))
+        tapes.append(lower(fc, pipe=pipe, mont=mont))
     tape = tapes[0]
     p = lambda ext: os.path.join(outdir, name + ext)
     writers.write_tape(p(".cwt"), tapes, bittape)

@@ -110,6 +110,23 @@ static U256 mulsmall_add_mod(const U256 &a, uint32_t m, uint32_t d, const U256 &
     return U256{{t[0], t[1], t[2], t[3]}};
 }
 // a * 2^k mod q by repeated doubling
+static U256 shrmod(U256 a, unsigned k, const U256 &q) {      // a / 2^k mod q (q odd)
+    for (unsigned i = 0; i < k; i++) {
+        uint64_t carry = 0;
+        if (a.w[0] & 1) {                                        // a + q is even; the sum may need a 257th bit
+            unsigned __int128 t = 0;
+            for (int j = 0; j < 4; j++) {
+                t += (unsigned __int128)a.w[j] + q.w[j];
+                a.w[j] = (uint64_t)t;
+                t >>= 64;
+            }
+            carry = (uint64_t)t;
+        }
+        for (int j = 0; j < 3; j++) a.w[j] = (a.w[j] >> 1) | (a.w[j + 1] << 63);
+        a.w[3] = (a.w[3] >> 1) | (carry << 63);
+    }
+    return a;
+}
 static U256 shlmod(U256 a, unsigned k, const U256 &q) {
     for (unsigned i = 0; i < k; i++) a = addmod(a, a, q);
     return a;
@@ -209,6 +226,7 @@ struct cw_circuit {
     uint32_t n_signals = 0, n_witness = 0, n_consts = 0, input_start = 0, n_inputs = 0, n_pub_in = 0;
     uint64_t n_rows = 0, n_mmul = 0;
     bool need_full = false;
+    bool mont = false;                     // the value table holds Montgomery forms x R' (lower.py pass A6)
     std::vector<Variant> variants;
     std::vector<uint32_t> consts;          // n_consts * 8
     std::vector<uint32_t> lconsts;         // n_lconsts * 12 (29-bit limbs)
@@ -374,7 +392,7 @@ static int load_tape(cw_circuit *c, const char *path) {
     if (!read_file(path, b)) return fail(CW_EIO, std::string("tape file not found: ") + path);
     if (b.size() < 16 + 32 + 48 || memcmp(b.data(), "CWTP", 4)) return fail(CW_EIO, "bad tape magic");
     const uint32_t *h = (const uint32_t *)(b.data() + 4);
-    if (h[0] != 6) return fail(CW_EIO, "unsupported tape version");
+    if (h[0] != 7) return fail(CW_EIO, "unsupported tape version");
     if (h[1] != 4) return fail(CW_EIO, "only 4x64-bit primes are supported (bn128, bls12381, ...)");
     uint32_t n_variants = h[2];
     size_t off = 16;
@@ -390,12 +408,15 @@ static int load_tape(cw_circuit *c, const char *path) {
     c->input_start = m[3];
     c->n_inputs = m[4];
     uint32_t n_names = m[5], hsize = m[6];
-    if (m[7] != CW_RBITS) return fail(CW_EIO, "tape was lowered for a different Montgomery radix");
+    if ((m[7] & 0xFFFFu) != CW_RBITS || (m[7] >> 17)) return fail(CW_EIO, "tape was lowered for a different Montgomery radix");
+    c->mont = (m[7] >> 16) & 1;
     uint32_t n_lconsts = m[8];
     c->n_pub_in = m[9];
     const uint32_t n_bit_programs = m[10], n_functions = m[11];
     if (n_functions > (1u << 16)) return fail(CW_EIO, "tape header: too many functions");
     if (n_bit_programs > 1) return fail(CW_EIO, "tape header: more than one bit-plane program");
+    if (c->mont && (n_bit_programs || n_functions))
+        return fail(CW_EIO, "tape header: Montgomery-form signals cannot be combined with a bit-plane program or run-time functions");
     // shape of the main component: slot 0 is the constant 1, outputs from slot 1, inputs right after them
     if (c->input_start == 0 || (uint64_t)c->input_start + c->n_inputs > c->n_signals || c->n_pub_in > c->n_inputs ||
         c->n_witness == 0 || c->n_witness > c->n_signals || hsize < 256 || (hsize & (hsize - 1)) ||
@@ -753,7 +774,8 @@ static int load_r1cs(cw_circuit *c, const char *path) {
                     auto it = cid.find(key);
                     if (it == cid.end()) {
                         id = (uint32_t)(c->r_ctab.size() / 8);
-                        U256 cm = on_one ? co : shlmod(co, CW_RBITS, c->q);
+                        // the constant-1 wire holds 1 (R' when the table holds Montgomery forms): its term is the coefficient itself
+                        U256 cm = (on_one && !c->mont) ? co : shlmod(co, CW_RBITS, c->q);
                         uint32_t limbs[8];
                         memcpy(limbs, cm.w, 32);
                         c->r_ctab.insert(c->r_ctab.end(), limbs, limbs + 8);
@@ -1286,7 +1308,7 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
     }
     TRY(hipMalloc(&b->d_in, std::max<size_t>((size_t)batch * c->n_inputs * 32, 32)));
     TRY(hipMalloc(&b->d_gather, std::max<size_t>((size_t)c->n_witness * 32, 32)));
-    TRY(cwk_init(b->stream, b->d_V, b->Bp, b->d_status, b->d_first_bad));
+    TRY(cwk_init(b->stream, b->d_V, b->Bp, b->d_status, b->d_first_bad, c->mont, c->P));
 #undef TRY
     b->remaining.assign(batch, c->n_inputs);
     *out = b;
@@ -1313,6 +1335,7 @@ extern "C" int cw_bits_info(const cw_circuit *c, uint64_t out[8]) {
     return CW_OK;
 }
 extern "C" uint32_t cw_batch_size(const cw_batch *b) { return b->batch; }
+extern "C" int cw_circuit_montgomery(const cw_circuit *c) { return c && c->mont ? 1 : 0; }
 extern "C" uint32_t cw_batch_strands(const cw_batch *b) { return b->var ? b->var->n_strands : 0; }
 extern "C" uint32_t cw_batch_pipelined(const cw_batch *b) { return b && b->var && b->var->kind == 1 ? b->var->nb | (b->var->nld << 8) : 0; }
 extern "C" uint32_t cw_batch_lanes(const cw_batch *b) { return b->bitmode ? b->bits_width : b->lanes; }
@@ -1732,8 +1755,8 @@ extern "C" int cw_run(cw_batch *b) {
         if (rc == CW_OK) b->ran = true;
         return rc;
     }
-    HIPCHK(cwk_init(b->stream, b->d_V, b->Bp, b->d_status, b->d_first_bad));
-    HIPCHK(cwk_ingest(b->stream, in, b->d_V, c->input_start, c->n_inputs, b->batch, b->Bp));
+    HIPCHK(cwk_init(b->stream, b->d_V, b->Bp, b->d_status, b->d_first_bad, c->mont, c->P));
+    HIPCHK(cwk_ingest(b->stream, in, b->d_V, c->input_start, c->n_inputs, b->batch, b->Bp, c->mont, c->P));
     if (b->var->kind == 1) {
         HIPCHK(cwk_eval_pipe(b->stream, c->need_full, false, b->var->nb, b->var->nld, b->d_prows, (uint32_t)(b->var->prows.size() / 8),
                              b->d_ploads, b->d_terms, b->d_V, b->d_consts, b->d_lconsts, (uint64_t)2 * b->Bp * 16, b->Bp, b->batch,
@@ -1765,10 +1788,10 @@ extern "C" int cw_check_r1cs(cw_batch *b) {
     }
     if (b->r1_entries)
         HIPCHK(cwk_r1cs_staged(b->stream, b->d_pchunk, b->r1_chunks, b->d_prec, b->d_pterms, b->d_rctab, b->d_rctab29, b->d_prow,
-                               b->r1_entries, b->d_V, b->Bp, b->batch, b->d_status, b->d_first_bad, c->P));
+                               b->r1_entries, b->d_V, b->Bp, b->batch, b->d_status, b->d_first_bad, c->mont, c->P));
     else
         HIPCHK(cwk_r1cs(b->stream, b->d_pchunk, b->r1_chunks, b->d_pterms, b->d_rctab, b->d_rctab29, b->d_prow, b->d_V, b->Bp, b->batch,
-                        b->d_status, b->d_first_bad, c->P));
+                        b->d_status, b->d_first_bad, c->mont, c->P));
     return CW_OK;
 }
 
@@ -1821,7 +1844,7 @@ extern "C" int cw_get_witness(cw_batch *b, uint32_t instance, uint8_t *out) {
         if (b->fb_index[instance] >= 0) return cw_get_witness(b->fb, (uint32_t)b->fb_index[instance], out);
         HIPCHK(cwk_bits_gather(b->stream, b->d_T, c->bits.n_slots, b->d_w2s, b->d_sigslot, c->n_witness, instance, 1, b->d_gather));
     } else
-    HIPCHK(cwk_gather(b->stream, b->d_V, b->d_w2s, c->n_witness, b->Bp, instance, b->d_gather));
+    HIPCHK(cwk_gather(b->stream, b->d_V, b->d_w2s, c->n_witness, b->Bp, instance, b->d_gather, c->mont, c->P));
     HIPCHK(hipMemcpyAsync(out, b->d_gather, (size_t)c->n_witness * 32, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     return CW_OK;
@@ -1852,7 +1875,7 @@ extern "C" int cw_get_witnesses(cw_batch *b, uint32_t first, uint32_t count, uin
         if (b->bitmode)
             HIPCHK(cwk_bits_gather(b->stream, b->d_T, c->bits.n_slots, b->d_w2s, b->d_sigslot, c->n_witness, first + done, n, b->d_bulk));
         else
-            HIPCHK(cwk_gather_many(b->stream, b->d_V, b->d_w2s, c->n_witness, b->Bp, first + done, n, b->d_bulk));
+            HIPCHK(cwk_gather_many(b->stream, b->d_V, b->d_w2s, c->n_witness, b->Bp, first + done, n, b->d_bulk, c->mont, c->P));
         HIPCHK(hipMemcpyAsync(out + (size_t)done * row, b->d_bulk, (size_t)n * row, hipMemcpyDeviceToHost, b->stream));
         HIPCHK(hipStreamSynchronize(b->stream));
     }
@@ -1873,7 +1896,7 @@ extern "C" int cw_get_witnesses_device(cw_batch *b, uint32_t first, uint32_t cou
     cw_circuit *c = b->c;
     HIPCHK(hipSetDevice(b->device));
     if (!b->bitmode) {
-        HIPCHK(cwk_gather_many(b->stream, b->d_V, b->d_w2s, c->n_witness, b->Bp, first, count, d_out));
+        HIPCHK(cwk_gather_many(b->stream, b->d_V, b->d_w2s, c->n_witness, b->Bp, first, count, d_out, c->mont, c->P));
         return CW_OK;
     }
     if (b->resolved && !b->fb_inst.empty()) {
@@ -1920,7 +1943,7 @@ extern "C" int cw_get_public_device(cw_batch *b, void *d_out) {
         }
         return CW_OK;
     }
-    HIPCHK(cwk_gather_many(b->stream, b->d_V, b->d_w2s + 1, np, b->Bp, 0, b->batch, d_out));
+    HIPCHK(cwk_gather_many(b->stream, b->d_V, b->d_w2s + 1, np, b->Bp, 0, b->batch, d_out, c->mont, c->P));
     return CW_OK;
 }
 extern "C" int cw_get_public(cw_batch *b, uint8_t *out) {
@@ -1960,6 +1983,12 @@ extern "C" int cw_get_signal(cw_batch *b, uint32_t instance, uint32_t slot, uint
     HIPCHK(hipMemcpyAsync(out, V + base, 16, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipMemcpyAsync(out + 16, V + base + (size_t)b->Bp * 16, 16, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
+    if (b->c->mont) {                       // x R' -> x: halve CW_RBITS times modulo q
+        U256 x;
+        memcpy(x.w, out, 32);
+        x = shrmod(x, CW_RBITS, b->c->q);
+        memcpy(out, x.w, 32);
+    }
     return CW_OK;
 }
 

@@ -4,9 +4,11 @@
 #include <stdint.h>
 #include "cw_tape.h"
 
-hipError_t cwk_init(hipStream_t s, void *V, uint32_t Bp, uint32_t *status, uint32_t *first_bad);
+// `mont`: the value table holds Montgomery forms x R' (lower.py pass A6): init writes R' into the constant-one slot, ingest
+// multiplies by R'^2, the gathers by 1, the R1CS check compares mmul(A~, B~) with C~
+hipError_t cwk_init(hipStream_t s, void *V, uint32_t Bp, uint32_t *status, uint32_t *first_bad, bool mont, const FpParams &P);
 hipError_t cwk_ingest(hipStream_t s, const void *in, void *V, uint32_t input_start, uint32_t n_in, uint32_t batch,
-                      uint32_t Bp);
+                      uint32_t Bp, bool mont, const FpParams &P);
 hipError_t cwk_eval(hipStream_t s, bool full, bool wide_linsum, const CwDRow *rows, const uint32_t *stream_off,
                     const uint64_t *extras, const uint32_t *extra_off, const uint64_t *terms, const uint32_t *term_off,
                     uint32_t n_strands, uint32_t n_lds, void *V, const uint32_t *consts, const uint32_t *lconsts,
@@ -18,14 +20,14 @@ hipError_t cwk_eval_pipe(hipStream_t s, bool full, bool wide_linsum, uint32_t nb
                          uint64_t slot_stride, uint32_t Bp, uint32_t batch, uint32_t lanes, uint32_t *status, const FpParams &P);
 hipError_t cwk_r1cs(hipStream_t s, const uint32_t *chunk, uint32_t n_chunks, const uint32_t *terms, const uint32_t *ctab,
                     const uint32_t *ctab29, const uint32_t *row_orig, const void *V, uint32_t Bp, uint32_t batch, uint32_t *status,
-                    uint32_t *first_bad, const FpParams &P);
+                    uint32_t *first_bad, bool mont, const FpParams &P);
 hipError_t cwk_r1cs_staged(hipStream_t s, const uint32_t *chunk, uint32_t n_chunks, const uint32_t *rec, const uint32_t *terms,
                            const uint32_t *ctab, const uint32_t *ctab29, const uint32_t *row_orig, uint32_t entries, const void *V, uint32_t Bp,
-                           uint32_t batch, uint32_t *status, uint32_t *first_bad, const FpParams &P);
+                           uint32_t batch, uint32_t *status, uint32_t *first_bad, bool mont, const FpParams &P);
 hipError_t cwk_gather(hipStream_t s, const void *V, const uint32_t *w2s, uint32_t n_wit, uint32_t Bp, uint32_t instance,
-                      void *out);
+                      void *out, bool mont, const FpParams &P);
 hipError_t cwk_gather_many(hipStream_t s, const void *V, const uint32_t *w2s, uint32_t n_wit, uint32_t Bp, uint32_t first,
-                           uint32_t count, void *out);
+                           uint32_t count, void *out, bool mont, const FpParams &P);
 hipError_t cwk_mulbench(hipStream_t s, const void *a, const void *b, void *out, uint32_t n, uint32_t iters,
                         const FpParams &P);
 hipError_t cwk_fpop(hipStream_t s, uint32_t op, const void *a, const void *b, const void *c, void *out, uint32_t *status,

@@ -39,26 +39,35 @@ __device__ __forceinline__ fe c_load(const uint32_t *__restrict__ consts, uint32
 }
 
 // ---- init: slot 0 = 1 (calcwit.cpp:34), status = 0 -----------------------------------------------
-__global__ void __launch_bounds__(CW_BLOCK) cw_init_kernel(uint4 *V, uint32_t Bp, uint32_t *status, uint32_t *first_bad) {
+// `one` = 1, or R' mod q when the table holds Montgomery forms (lower.py pass A6)
+__global__ void __launch_bounds__(CW_BLOCK) cw_init_kernel(uint4 *V, uint32_t Bp, uint32_t *status, uint32_t *first_bad, fe one) {
     uint32_t i = blockIdx.x * CW_BLOCK + threadIdx.x;
     if (i >= Bp) return;
-    v_store(V, 0, Bp, i, fe_small(1));
+    v_store(V, 0, Bp, i, one);
     status[i] = 0;
     first_bad[i] = 0xFFFFFFFFu;
 }
 
 // ---- ingest: AoS canonical inputs [batch][n_in][32 B] -> SoA input slots ----------------------------
 // (setInputSignal's `signalValues[si] = val`, calcwit.cpp:93, for the whole batch)
+// MONT: the table holds Montgomery forms: x -> x R' = mmul(x, R'^2)
+template <bool MONT>
 __global__ void __launch_bounds__(CW_BLOCK) cw_ingest_kernel(const uint4 *__restrict__ in, uint4 *__restrict__ V,
                                                               uint32_t input_start, uint32_t n_in, uint32_t batch,
-                                                              uint32_t Bp) {
+                                                              uint32_t Bp, FpParams P) {
     uint32_t i = blockIdx.x * CW_BLOCK + threadIdx.x;
     if (i >= batch) return;
     for (uint32_t k = blockIdx.y; k < n_in; k += gridDim.y) {      // grid.y is capped at 65535 input signals per pass
         size_t src = ((size_t)i * n_in + k) * 2;
         size_t dst = (size_t)(input_start + k) * 2 * Bp + i;
-        V[dst] = in[src];
-        V[dst + Bp] = in[src + 1];
+        if (MONT) {
+            const fe x = fe_mmul(aos_load(in, (uint32_t)((size_t)i * n_in + k)), fe_from(P.r2), P);
+            V[dst] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+            V[dst + Bp] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+        } else {
+            V[dst] = in[src];
+            V[dst + Bp] = in[src + 1];
+        }
     }
 }
 
@@ -876,6 +885,7 @@ __device__ __forceinline__ fe fe_pick(bool c, const fe &a, const fe &b) {
     for (int k = 0; k < 8; k++) r.v[k] = c ? a.v[k] : b.v[k];
     return r;
 }
+template <bool MONT>
 __device__ __forceinline__ void r1_term(const fe &wv, uint32_t w0, uint32_t ci, R1State &s,
                                         const uint32_t *__restrict__ ctab, const uint32_t *__restrict__ ctab29,
                                         const uint32_t *__restrict__ row_orig, const FpParams &P) {
@@ -898,11 +908,15 @@ __device__ __forceinline__ void r1_term(const fe &wv, uint32_t w0, uint32_t ci, 
             s.cur = fe_zero();
         }
         if (endk == 2) ok = fe_is_zero(s.cur);                      // A or B empty: linear row, C must vanish
-        else if (endk == 1) {                                       // A*B == C  <=>  (A*B + (q - C)) / R' == 0 (mod q)
-            const fe29 z = fe29_mmul_add(fe_to29(s.A), fe_to29(s.B), fe_to29(fe_neg(s.cur, P)), P);
-            uint32_t o = 0;
-            FE_UNROLL for (int k = 0; k < 9; k++) o |= z.l[k];
-            ok = (o == 0);
+        else if (endk == 1) {
+            if (MONT) {                                             // wires in Montgomery form: mmul(A~, B~) = (AB)~ == C~
+                ok = fe_eq(fe_from29(fe29_mmul(fe_to29(s.A), fe_to29(s.B), P)), s.cur);
+            } else {                                                // A*B == C  <=>  (A*B + (q - C)) / R' == 0 (mod q)
+                const fe29 z = fe29_mmul_add(fe_to29(s.A), fe_to29(s.B), fe_to29(fe_neg(s.cur, P)), P);
+                uint32_t o = 0;
+                FE_UNROLL for (int k = 0; k < 9; k++) o |= z.l[k];
+                ok = (o == 0);
+            }
         }
     }
     if (endk) {
@@ -921,6 +935,7 @@ __device__ __forceinline__ void r1_finish(const R1State &s, uint32_t i, uint32_t
     }
 }
 
+template <bool MONT>
 __global__ void __launch_bounds__(64)
 cw_r1cs_stream_kernel(const uint4 *__restrict__ chunk, uint32_t n_chunks, const uint2 *__restrict__ terms, const uint32_t *__restrict__ ctab,
                       const uint32_t *__restrict__ ctab29, const uint32_t *__restrict__ row_orig, const uint4 *__restrict__ V, uint32_t Bp, uint32_t batch,
@@ -940,7 +955,7 @@ cw_r1cs_stream_kernel(const uint4 *__restrict__ chunk, uint32_t n_chunks, const 
         for (uint32_t k = 0; k < ch.y; k++) {
             const uint2 t1 = tp[k + 1];
             const fe w1 = v_load(V, t1.x & 0x3FFFFFFu, Bp, i);
-            r1_term(w0, t0.x, t0.y, s, ctab, ctab29, row_orig, P);
+            r1_term<MONT>(w0, t0.x, t0.y, s, ctab, ctab29, row_orig, P);
             t0 = t1; w0 = w1;
         }
     }
@@ -971,6 +986,7 @@ __device__ __forceinline__ void r1_issue(uint32_t lw, uint64_t vbase, uint64_t s
                  : "memory");
 }
 
+template <bool MONT>
 __global__ void __launch_bounds__(64)
 cw_r1cs_staged_kernel(const uint4 *__restrict__ chunk, const uint2 *__restrict__ rec, const uint2 *__restrict__ terms,
                       const uint32_t *__restrict__ ctab, const uint32_t *__restrict__ ctab29,
@@ -1004,7 +1020,7 @@ cw_r1cs_staged_kernel(const uint4 *__restrict__ chunk, const uint2 *__restrict__
             fe w;
             w.v[0] = lo.x; w.v[1] = lo.y; w.v[2] = lo.z; w.v[3] = lo.w;
             w.v[4] = hi.x; w.v[5] = hi.y; w.v[6] = hi.z; w.v[7] = hi.w;
-            r1_term(w, tw.x, tw.y, s, ctab, ctab29, row_orig, P);
+            r1_term<MONT>(w, tw.x, tw.y, s, ctab, ctab29, row_orig, P);
             tw = nx;
         }
     }
@@ -1013,22 +1029,33 @@ cw_r1cs_staged_kernel(const uint4 *__restrict__ chunk, const uint2 *__restrict__
 }
 
 // ---- egress: one instance's witness as [n_witness][32 B] (getWitness + Fr_toLongNormal, main.cpp:326-332) ----
+// MONT: the table holds Montgomery forms: x~ -> x = mmul(x~, 1)   (the role of Fr_toLongNormal, generic/fr.cpp)
+template <bool MONT>
 __global__ void __launch_bounds__(CW_BLOCK)
 cw_gather_kernel(const uint4 *__restrict__ V, const uint32_t *__restrict__ w2s, uint32_t n_wit, uint32_t Bp,
-                 uint32_t instance, uint4 *__restrict__ out) {
+                 uint32_t instance, uint4 *__restrict__ out, FpParams P) {
     uint32_t k = blockIdx.x * CW_BLOCK + threadIdx.x;
     if (k >= n_wit) return;
     size_t base = (size_t)w2s[k] * 2 * Bp + instance;
-    out[2 * (size_t)k] = V[base];
-    out[2 * (size_t)k + 1] = V[base + Bp];
+    uint4 lo = V[base], hi = V[base + Bp];
+    if (MONT) {
+        fe x;
+        x.v[0] = lo.x; x.v[1] = lo.y; x.v[2] = lo.z; x.v[3] = lo.w; x.v[4] = hi.x; x.v[5] = hi.y; x.v[6] = hi.z; x.v[7] = hi.w;
+        x = fe_mmul(x, fe_small(1), P);
+        lo = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+        hi = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+    }
+    out[2 * (size_t)k] = lo;
+    out[2 * (size_t)k + 1] = hi;
 }
 
 // ---- bulk egress: witnesses of `count` consecutive instances as [count][n_witness][32 B] ----------------------
 // SoA -> AoS transpose through LDS: a 256-thread block moves a tile of 64 instances x 32 witness elements.
 // Reads are coalesced along instances (the table's layout), writes along the witness index (the output's).
+template <bool MONT>
 __global__ void __launch_bounds__(256)
 cw_gather_many_kernel(const uint4 *__restrict__ V, const uint32_t *__restrict__ w2s, uint32_t n_wit, uint32_t Bp,
-                      uint32_t first, uint32_t count, uint4 *__restrict__ out) {
+                      uint32_t first, uint32_t count, uint4 *__restrict__ out, FpParams P) {
     __shared__ uint4 tile[32][2][65];                               // [element][half][instance] (+1: bank spread)
     const uint32_t k0 = blockIdx.x * 32, i0 = blockIdx.y * 64;
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;  // 4 waves
@@ -1036,8 +1063,16 @@ cw_gather_many_kernel(const uint4 *__restrict__ V, const uint32_t *__restrict__ 
         const uint32_t k = k0 + e;
         if (k < n_wit && i0 + lane < count) {
             const size_t base = (size_t)w2s[k] * 2 * Bp + first + i0 + lane;
-            tile[e][0][lane] = V[base];
-            tile[e][1][lane] = V[base + Bp];
+            uint4 lo = V[base], hi = V[base + Bp];
+            if (MONT) {
+                fe x;
+                x.v[0] = lo.x; x.v[1] = lo.y; x.v[2] = lo.z; x.v[3] = lo.w; x.v[4] = hi.x; x.v[5] = hi.y; x.v[6] = hi.z; x.v[7] = hi.w;
+                x = fe_mmul(x, fe_small(1), P);
+                lo = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+                hi = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+            }
+            tile[e][0][lane] = lo;
+            tile[e][1][lane] = hi;
         }
     }
     __syncthreads();
@@ -1119,16 +1154,20 @@ cw_fpop_kernel(uint32_t op, const uint4 *a_, const uint4 *b_, const uint4 *c_, u
 // ---- launch wrappers -----------------------------------------------------------------------------------------
 static inline dim3 blocks_for(uint32_t n) { return dim3((n + CW_BLOCK - 1) / CW_BLOCK); }
 
-hipError_t cwk_init(hipStream_t s, void *V, uint32_t Bp, uint32_t *status, uint32_t *first_bad) {
-    hipLaunchKernelGGL(cw_init_kernel, blocks_for(Bp), dim3(CW_BLOCK), 0, s, (uint4 *)V, Bp, status, first_bad);
+hipError_t cwk_init(hipStream_t s, void *V, uint32_t Bp, uint32_t *status, uint32_t *first_bad, bool mont, const FpParams &P) {
+    fe one;
+    for (int k = 0; k < 8; k++) one.v[k] = mont ? P.one_m[k] : (k == 0 ? 1u : 0u);
+    hipLaunchKernelGGL(cw_init_kernel, blocks_for(Bp), dim3(CW_BLOCK), 0, s, (uint4 *)V, Bp, status, first_bad, one);
     return hipGetLastError();
 }
 hipError_t cwk_ingest(hipStream_t s, const void *in, void *V, uint32_t input_start, uint32_t n_in, uint32_t batch,
-                      uint32_t Bp) {
+                      uint32_t Bp, bool mont, const FpParams &P) {
     if (n_in == 0) return hipSuccess;
     dim3 g((batch + CW_BLOCK - 1) / CW_BLOCK, n_in < 65535u ? n_in : 65535u);
-    hipLaunchKernelGGL(cw_ingest_kernel, g, dim3(CW_BLOCK), 0, s, (const uint4 *)in, (uint4 *)V, input_start, n_in, batch,
-                       Bp);
+    if (mont)
+        hipLaunchKernelGGL(cw_ingest_kernel<true>, g, dim3(CW_BLOCK), 0, s, (const uint4 *)in, (uint4 *)V, input_start, n_in, batch, Bp, P);
+    else
+        hipLaunchKernelGGL(cw_ingest_kernel<false>, g, dim3(CW_BLOCK), 0, s, (const uint4 *)in, (uint4 *)V, input_start, n_in, batch, Bp, P);
     return hipGetLastError();
 }
 hipError_t cwk_eval(hipStream_t s, bool full, bool wide_linsum, const CwDRow *rows, const uint32_t *stream_off,
@@ -1182,40 +1221,52 @@ hipError_t cwk_eval_pipe(hipStream_t s, bool full, bool wide_linsum, uint32_t nb
 }
 hipError_t cwk_r1cs(hipStream_t s, const uint32_t *chunk, uint32_t n_chunks, const uint32_t *terms, const uint32_t *ctab,
                     const uint32_t *ctab29, const uint32_t *row_orig, const void *V, uint32_t Bp, uint32_t batch, uint32_t *status,
-                    uint32_t *first_bad, const FpParams &P) {
+                    uint32_t *first_bad, bool mont, const FpParams &P) {
     if (n_chunks == 0) return hipSuccess;
     dim3 g((batch + 63) / 64, n_chunks < 65535u ? n_chunks : 65535u);
-    hipLaunchKernelGGL(cw_r1cs_stream_kernel, g, dim3(64), 0, s, (const uint4 *)chunk, n_chunks, (const uint2 *)terms, ctab, ctab29, row_orig,
-                       (const uint4 *)V, Bp, batch, status, first_bad, P);
+    if (mont)
+        hipLaunchKernelGGL(cw_r1cs_stream_kernel<true>, g, dim3(64), 0, s, (const uint4 *)chunk, n_chunks, (const uint2 *)terms, ctab, ctab29,
+                           row_orig, (const uint4 *)V, Bp, batch, status, first_bad, P);
+    else
+        hipLaunchKernelGGL(cw_r1cs_stream_kernel<false>, g, dim3(64), 0, s, (const uint4 *)chunk, n_chunks, (const uint2 *)terms, ctab, ctab29,
+                           row_orig, (const uint4 *)V, Bp, batch, status, first_bad, P);
     return hipGetLastError();
 }
 hipError_t cwk_r1cs_staged(hipStream_t s, const uint32_t *chunk, uint32_t n_chunks, const uint32_t *rec, const uint32_t *terms,
                            const uint32_t *ctab, const uint32_t *ctab29, const uint32_t *row_orig, uint32_t entries, const void *V, uint32_t Bp,
-                           uint32_t batch, uint32_t *status, uint32_t *first_bad, const FpParams &P) {
+                           uint32_t batch, uint32_t *status, uint32_t *first_bad, bool mont, const FpParams &P) {
     if (n_chunks == 0) return hipSuccess;
     const uint32_t lds_bytes = entries * 2048u;
+    typedef void (*kern_t)(const uint4 *, const uint2 *, const uint2 *, const uint32_t *, const uint32_t *, const uint32_t *, const uint4 *,
+                           uint32_t, uint32_t, uint32_t *, uint32_t *, FpParams);
+    kern_t k = mont ? (kern_t)cw_r1cs_staged_kernel<true> : (kern_t)cw_r1cs_staged_kernel<false>;
     if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)cw_r1cs_staged_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
     dim3 g((batch + 63) / 64, n_chunks);
-    hipLaunchKernelGGL(cw_r1cs_staged_kernel, g, dim3(64), lds_bytes, s, (const uint4 *)chunk, (const uint2 *)rec,
-                       (const uint2 *)terms, ctab, ctab29, row_orig, (const uint4 *)V, Bp, batch, status, first_bad, P);
+    hipLaunchKernelGGL(k, g, dim3(64), lds_bytes, s, (const uint4 *)chunk, (const uint2 *)rec, (const uint2 *)terms, ctab, ctab29, row_orig,
+                       (const uint4 *)V, Bp, batch, status, first_bad, P);
     return hipGetLastError();
 }
 hipError_t cwk_gather(hipStream_t s, const void *V, const uint32_t *w2s, uint32_t n_wit, uint32_t Bp, uint32_t instance,
-                      void *out) {
-    hipLaunchKernelGGL(cw_gather_kernel, blocks_for(n_wit), dim3(CW_BLOCK), 0, s, (const uint4 *)V, w2s, n_wit, Bp,
-                       instance, (uint4 *)out);
+                      void *out, bool mont, const FpParams &P) {
+    if (mont)
+        hipLaunchKernelGGL(cw_gather_kernel<true>, blocks_for(n_wit), dim3(CW_BLOCK), 0, s, (const uint4 *)V, w2s, n_wit, Bp, instance,
+                           (uint4 *)out, P);
+    else
+        hipLaunchKernelGGL(cw_gather_kernel<false>, blocks_for(n_wit), dim3(CW_BLOCK), 0, s, (const uint4 *)V, w2s, n_wit, Bp, instance,
+                           (uint4 *)out, P);
     return hipGetLastError();
 }
 hipError_t cwk_gather_many(hipStream_t s, const void *V, const uint32_t *w2s, uint32_t n_wit, uint32_t Bp, uint32_t first,
-                           uint32_t count, void *out) {
+                           uint32_t count, void *out, bool mont, const FpParams &P) {
     if (!count || !n_wit) return hipSuccess;
     dim3 g((n_wit + 31) / 32, (count + 63) / 64);
-    hipLaunchKernelGGL(cw_gather_many_kernel, g, dim3(256), 0, s, (const uint4 *)V, w2s, n_wit, Bp, first, count,
-                       (uint4 *)out);
+    if (mont)
+        hipLaunchKernelGGL(cw_gather_many_kernel<true>, g, dim3(256), 0, s, (const uint4 *)V, w2s, n_wit, Bp, first, count, (uint4 *)out, P);
+    else
+        hipLaunchKernelGGL(cw_gather_many_kernel<false>, g, dim3(256), 0, s, (const uint4 *)V, w2s, n_wit, Bp, first, count, (uint4 *)out, P);
     return hipGetLastError();
 }
 hipError_t cwk_mulbench(hipStream_t s, const void *a, const void *b, void *out, uint32_t n, uint32_t iters,

@@ -121,6 +121,7 @@ class Tape:
         self.n_pub_in = 0           # public inputs of main (`component main {public [...]}`); outputs are always public
         self.stats = {}
         self.rbits = 261            # Montgomery radix exponent of MMUL rows
+        self.mont = False           # signals (value table) in Montgomery form x R' mod q (pass A6)
         self.kind = 0               # 0 = strand schedule (passes C/D), 1 = pipelined single-wave schedule (pipe.py)
         self.pipe = (0, 0, 0)       # kind 1: rows per batch, loads per batch, ring entries
         self.functions = []         # device bytecode of circom functions: (n_regs, uint32[n,4])
@@ -634,6 +635,140 @@ def _batch_inversions(rows, n_vtemps, cid):
     return out, nxt[0], sum(1 for g in groups if len(g) >= 2)
 
 
+_INT_OPS = (D_IDIV, D_MOD, D_POW, D_SHL, D_SHR, D_BAND, D_BOR, D_BXOR, D_BNOT, D_LT, D_GT, D_LEQ, D_GEQ)
+
+
+def _to_montgomery(rows, plain, cid, q, R, n_vtemps):
+    """Pass A6 (arithmetic circuits: compiler.choose_mont): keep every SIGNAL and most temporaries in Montgomery form
+    x~ = x R' mod q, so that a product of two run-time values is ONE Montgomery product (mmul(a~, b~) = ab R') instead of
+    the two a canonical product needs (mmul(mmul(a, b), R'^2)).  Linear operators, comparisons with zero, equality and
+    selection are the same on both forms; constants are re-scaled here; D_MMUL / D_MULC / D_DOTC already multiply by
+    c R', which maps a~ to (ac)~.  Operators defined on canonical integers (bit extraction, shifts, bitwise, ordering, integer
+    division, powers) get their operands converted (mmul(x~, 1) = x, cached per value) and produce integers; an integer
+    that becomes a signal, or meets a Montgomery-form value in an addition or product, is converted back (mmul(x, R'^2)).
+    The inverse of a~ is a^-1 R'^-1: one more product by R'^3.
+    The runtime converts at its boundary: ingest multiplies the inputs by R'^2, egress by 1, the R1CS check compares
+    mmul(A~, B~) with C~ (csrc/cw_kernels.hip).  Returns (rows, n_vtemps, number of conversion rows)."""
+    M, I = 'M', 'I'
+    R2, R3 = R * R % q, R * R * R % q
+    dom = {}
+    as_i, as_m = {}, {}
+    out = []
+    nxt = [n_vtemps]
+    n_conv = [0]
+    one, r2c, r3c = cid(1), cid(R2), cid(R3)
+
+    def fresh():
+        t = nxt[0]
+        nxt[0] += 1
+        return (K_TMP, t)
+
+    def dom_of(k, v):
+        return dom.get((k, v), M)           # main inputs and the constant-one signal: converted by the ingest kernel
+
+    def conv(k, v, want):
+        """operand (k, v) in the wanted domain"""
+        if k == K_NONE:
+            return k, v
+        if k == K_CONST:
+            return (K_CONST, cid(plain[v] * R % q)) if want == M else (k, v)
+        if dom_of(k, v) == want:
+            return k, v
+        cache = as_i if want == I else as_m
+        got = cache.get((k, v))
+        if got is None:
+            got = fresh()
+            out.append(_Row(D_MMUL, got[0], got[1], k, v, K_CONST, one if want == I else r2c))
+            dom[got] = want
+            cache[(k, v)] = got
+            n_conv[0] += 1
+        return got
+
+    def finish(r, d):
+        """r computes a value of domain d into (r.dk, r.dv); signals hold the Montgomery form"""
+        if r.dk == K_SIG and d == I:
+            t = fresh()
+            sig = (r.dk, r.dv)
+            r.dk, r.dv = t
+            out.append(r)
+            dom[t] = I
+            out.append(_Row(D_MMUL, sig[0], sig[1], t[0], t[1], K_CONST, r2c))
+            dom[sig] = M
+            as_i[sig] = t
+            n_conv[0] += 1
+            return
+        out.append(r)
+        if r.dk in (K_SIG, K_TMP):
+            dom[(r.dk, r.dv)] = d
+
+    def common(ops):
+        ds = {dom_of(k, v) for k, v in ops if k in (K_SIG, K_TMP)}
+        return I if ds == {I} else M
+
+    for r in rows:
+        op = r.op
+        if op in (D_LINSUM, D_DOTC):
+            d = common([(t[0], t[1]) for t in r.terms])
+            if op == D_DOTC or d == M:
+                d = M
+                if op == D_LINSUM:
+                    r.op = D_DOTC
+                    for t in r.terms:
+                        t[2] = t[2] % q if t[2] >= 0 else -((-t[2]) % q)
+            for t in r.terms:
+                t[0], t[1] = conv(t[0], t[1], d)
+            if r.bk == K_CONST:
+                r.bk, r.bv = conv(r.bk, r.bv, d)
+            finish(r, d)
+        elif op == D_BIT:
+            r.ak, r.av = conv(r.ak, r.av, I)
+            finish(r, I)
+        elif op in _INT_OPS:
+            r.ak, r.av = conv(r.ak, r.av, I)
+            r.bk, r.bv = conv(r.bk, r.bv, I)
+            finish(r, I)
+        elif op in (D_EQ, D_NEQ, D_ASSERT_EQ):
+            d = common([(r.ak, r.av), (r.bk, r.bv)])
+            r.ak, r.av = conv(r.ak, r.av, d)
+            r.bk, r.bv = conv(r.bk, r.bv, d)
+            finish(r, I)
+        elif op in (D_LAND, D_LOR, D_LNOT, D_SELECT, D_ASSERT_NZ):
+            finish(r, I)                          # tests against zero: the same on both forms
+        elif op in (D_ADD, D_SUB, D_NEG, D_COPY, D_EXT):
+            d = common([(r.ak, r.av), (r.bk, r.bv)])
+            r.ak, r.av = conv(r.ak, r.av, d)
+            r.bk, r.bv = conv(r.bk, r.bv, d)
+            finish(r, d)
+        elif op == D_MUL2:
+            d = common([(r.ak, r.av), (r.bk, r.bv)])
+            if d == M:
+                r.op = D_MMUL
+                r.ak, r.av = conv(r.ak, r.av, M)
+                r.bk, r.bv = conv(r.bk, r.bv, M)
+            finish(r, d)
+        elif op == D_MMUL or op == D_MULC:        # second operand = c R' (pre-scaled): a~ -> (ac)~, a -> ac
+            d = dom_of(r.ak, r.av)
+            if d == M:
+                r.flag = 0                        # the small-constant shortcut multiplies canonical values
+            finish(r, d)
+        elif op == D_INV:
+            if dom_of(r.ak, r.av) == I:
+                finish(r, I)
+            else:
+                t = fresh()
+                dst = (r.dk, r.dv)
+                r.dk, r.dv = t
+                out.append(r)
+                dom[t] = M
+                nr = _Row(D_MMUL, dst[0], dst[1], t[0], t[1], K_CONST, r3c)
+                out.append(nr)
+                dom[dst] = M
+                n_conv[0] += 1
+        else:
+            raise ValueError("operator %d has no Montgomery-domain rule" % op)
+    return out, nxt[0], n_conv[0]
+
+
 LINSUM_SPLIT_MIN = 24     # D_LINSUM rows with at least this many terms are split across strands (S > 1)
 
 
@@ -976,8 +1111,9 @@ def _finish_pipe(fc, stream, dconsts, lconsts, lcid, witness_map, pipe, stats):
     return t
 
 
-def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None) -> Tape:
-    """pipe = (rows per batch, loads per batch): lower to the pipelined single-wave variant (pipe.py) instead of strands"""
+def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None, mont: bool = False) -> Tape:
+    """pipe = (rows per batch, loads per batch): lower to the pipelined single-wave variant (pipe.py) instead of strands.
+    mont: signals in Montgomery form (pass A6; every variant of a circuit must use the same setting)"""
     q = fc.fp.q
     if not 225 <= q.bit_length() <= 256:
         raise ValueError("hip_elements targets circom's 253..256-bit primes (4 x 64-bit limbs); prime %s has %d bits "
@@ -994,6 +1130,11 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None) -> T
     rows, dconsts, n_vtemps, cid, plain = _expand(fc)
     rows, n_vtemps, n_inv_batches = _batch_inversions(rows, n_vtemps, cid)
     rows, n_lin, n_bit = _fuse_linear(rows, plain, q, cid)
+    n_conv = 0
+    if mont:
+        if functions and (fc.code["op"] == O.CALL).any():
+            raise ValueError("circuits that call run-time functions compute on canonical values")
+        rows, n_vtemps, n_conv = _to_montgomery(rows, plain, cid, q, fc.fp.Rdev, n_vtemps)
     # limb-form constant table of the D_DOTC terms, interned in program order (identical for every strand count)
     lconsts, lconst_id = [], {}
 
@@ -1021,9 +1162,11 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None) -> T
     streams, n_levels = _schedule(rows, n_signals, n_strands)
     multi = n_strands > 1
     if pipe is not None:
-        return _finish_pipe(fc, streams[0], dconsts, lconsts, lcid, witness_map, pipe,
-                            {"copies_elided": n_elided, "fused_madd": n_madd, "inv_batches": n_inv_batches, "linsum": n_lin,
-                             "bit": n_bit, "asserts_proved": getattr(_expand, "n_proved", 0)})
+        t = _finish_pipe(fc, streams[0], dconsts, lconsts, lcid, witness_map, pipe,
+                         {"copies_elided": n_elided, "fused_madd": n_madd, "inv_batches": n_inv_batches, "linsum": n_lin,
+                          "bit": n_bit, "asserts_proved": getattr(_expand, "n_proved", 0), "mont": int(mont), "mont_conversions": n_conv})
+        t.mont = bool(mont)
+        return t
 
     def vid(k, v):
         return v if k == K_SIG else n_signals + v
@@ -1250,6 +1393,7 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None) -> T
     t.functions = [_encode_function(f, cid, q) for f in functions]
     t.n_lds = n_lds_used
     t.n_strands = n_strands
+    t.mont = bool(mont)
     t.consts = dconsts
     if witness_map is None:
         witness_map = np.arange(n_signals, dtype=np.uint32)     # --O0: identity
@@ -1281,6 +1425,7 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None) -> T
         "linsum_splits": n_split,
         "barriers": n_levels,
         "full_barriers": len(full_after),
+        "mont": int(mont), "mont_conversions": n_conv,
         "strands": n_strands,
         "temp_slots": n_tslots,
         "consts": len(dconsts),

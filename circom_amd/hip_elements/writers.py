@@ -77,7 +77,7 @@ def write_dat(path, fc: FlatCircuit, witness2signal=None):
 
 
 TAPE_MAGIC = b"CWTP"
-TAPE_VERSION = 6
+TAPE_VERSION = 7
 
 
 def write_tape(path, tapes, bittape=None):
@@ -86,7 +86,8 @@ def write_tape(path, tapes, bittape=None):
          0  "CWTP" | u32 version | u32 n64 | u32 n_variants
         16  prime, n64*8 bytes
             12 x u32: n_signals, n_witness, n_consts, main_input_start, n_main_inputs, n_input_names,
-                      hashmap_size, rbits (Montgomery radix exponent of MMUL rows), n_lconsts, n_public_inputs,
+                      hashmap_size, rbits (Montgomery radix exponent of MMUL rows; bit 16 set = the value table holds
+                      Montgomery forms, lower.py pass A6), n_lconsts, n_public_inputs,
                       n_bit_programs (0 | 1), n_functions
             consts          n_consts x n64*8 bytes (raw residues as the schedule expects them)
             lconsts         n_lconsts x n64*8 bytes (coef*R' of D_DOTC terms; the runtime keeps them as 29-bit limbs)
@@ -108,11 +109,13 @@ def write_tape(path, tapes, bittape=None):
     for t in tapes[1:]:
         assert t.consts == t0.consts and t.n_signals == t0.n_signals, "variants must come from the same circuit"
         assert t.lconsts == t0.lconsts, "variants must share the limb-form constant table"
+        assert bool(getattr(t, "mont", False)) == bool(getattr(t0, "mont", False)), "variants must share the value form"
     with open(path, "wb") as f:
         f.write(TAPE_MAGIC + struct.pack("<III", TAPE_VERSION, n64, len(tapes)))
         f.write(t0.q.to_bytes(8 * n64, "little"))
         f.write(struct.pack("<12I", t0.n_signals, t0.n_witness, len(t0.consts), t0.main_input_start, t0.n_main_inputs,
-                            len(t0.inputs), hashmap_size(len(t0.inputs)), t0.rbits, len(t0.lconsts), t0.n_pub_in,
+                            len(t0.inputs), hashmap_size(len(t0.inputs)), t0.rbits | (0x10000 if getattr(t0, "mont", False) else 0),
+                            len(t0.lconsts), t0.n_pub_in,
                             1 if bittape is not None else 0, len(t0.functions)))
         f.write(b"".join(c.to_bytes(8 * n64, "little") for c in t0.consts))
         f.write(b"".join(c.to_bytes(8 * n64, "little") for c in t0.lconsts))
@@ -134,7 +137,7 @@ def write_tape(path, tapes, bittape=None):
             f.write(np.asarray(t.extras, dtype="<u4").tobytes())
             f.write(np.ascontiguousarray(t.terms, dtype="<u4").tobytes())
         if bittape is not None:
-            assert bittape.n_signals == t0.n_signals
+            assert bittape.n_signals == t0.n_signals and not getattr(t0, "mont", False)
             f.write(struct.pack("<8I", bittape.ring, bittape.n_vrows, bittape.n_slots & 0xFFFFFFFF, bittape.n_slots >> 32, 0, 0, 0, 0))
             f.write(np.ascontiguousarray(bittape.recs, dtype="<u4").tobytes())
             f.write(np.ascontiguousarray(bittape.sig_slot, dtype="<u4").tobytes())

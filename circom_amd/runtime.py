@@ -60,6 +60,7 @@ _SIGS = {
     "cw_batch_free": (None, [C.c_void_p]),
     "cw_batch_size": (C.c_uint32, [C.c_void_p]),
     "cw_batch_strands": (C.c_uint32, [C.c_void_p]),
+    "cw_circuit_montgomery": (C.c_int, [C.c_void_p]),
     "cw_batch_pipelined": (C.c_uint32, [C.c_void_p]),
     "cw_batch_lanes": (C.c_uint32, [C.c_void_p]),
     "cw_batch_bitmode": (C.c_int, [C.c_void_p]),
@@ -137,6 +138,7 @@ class Circuit:
         self.n_public = L.cw_n_public(h)
         self.n_rows = L.cw_n_rows(h)
         self.n_mmul = L.cw_n_mmul(h)
+        self.montgomery = bool(L.cw_circuit_montgomery(h))     # the device value table holds x * 2^261 mod q
         buf = C.create_string_buffer(32)
         L.cw_prime(h, buf)
         self.q = int.from_bytes(buf.raw, "little")

@@ -135,8 +135,12 @@ int cw_get_r1cs_first_bad(cw_batch *b, uint32_t *row);
    out[8] = {chunks, loads, terms, filler loads, distinct wires, entries, prefetch depth, 0}. */
 int cw_r1cs_plan_stats(const cw_circuit *c, uint32_t batch, uint32_t chunks, uint32_t entries, uint64_t out[8]);
 
-/* raw device pointers for zero-copy consumers (provers): value table, layout in DESIGN.md */
+/* raw device pointers for zero-copy consumers (provers): value table, layout in DESIGN.md.  When cw_circuit_montgomery()
+   is 1 the table holds x * 2^261 mod q (the schedule of an arithmetic circuit keeps its signals in Montgomery form, so that
+   a product of two signals is one Montgomery product); every other egress (cw_get_witness*, cw_get_signal, cw_write_wtns*,
+   cw_get_witnesses_device) returns canonical values, as the reference's Fr_toLongNormal does (main.cpp:326-332). */
 void *cw_device_values(cw_batch *b, uint64_t *n_bytes, uint32_t *padded_batch);
+int cw_circuit_montgomery(const cw_circuit *c);
 /* bit-plane batches: the bit table T[group][slot] (uint64, bit i = instance group*64+i; signal s at slot 3+s);
  * NULL for 256-bit batches (and cw_device_values is NULL for bit-plane batches) */
 void *cw_device_bits(cw_batch *b, uint64_t *n_bytes, uint64_t *slots_per_group);

@@ -230,7 +230,7 @@ def run_dev_function(f: Field, code, regs: list, base: int, consts) -> bool:
 
 def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict, rbits: int = 261,
               stream_off=None, extras=None, extra_off=None, n_lds: int = 0, terms=None, term_off=None, lconsts=(),
-              functions=()):
+              functions=(), one: int = 1):
     """Evaluate a lowered schedule exactly the way cw_eval_kernel does, for one instance:
       * every strand (stream) walks its own rows; strands meet at BARRIER rows,
       * operands of row r+1 are fetched BEFORE row r stores its result (one-row-ahead prefetch), except
@@ -245,7 +245,7 @@ def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict,
     f = Field(q)
     rinv = pow(1 << rbits, -1, q)        # MMUL = a*b*R'^-1 with the schedule's radix (device: R' = 2^261)
     sig = [0] * n_signals
-    sig[0] = 1
+    sig[0] = one                         # the constant-one signal (R' when the table holds Montgomery forms)
     for k, v in inputs.items():
         sig[k] = v % q
     tmp = [0] * max(n_tslots, 1)
@@ -439,13 +439,24 @@ def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict,
 
 
 def eval_tape(tape, inputs: dict):
-    """Convenience wrapper over a circom_amd.hip_elements.lower.Tape (duck-typed)."""
+    """Convenience wrapper over a circom_amd.hip_elements.lower.Tape (duck-typed).  A tape lowered with signals in
+    Montgomery form (tape.mont) is fed x R' and its signals are multiplied by R'^-1, as the runtime's ingest / egress do."""
+    mont = bool(getattr(tape, "mont", False))
+    R = pow(2, tape.rbits, tape.q)
+    if mont:
+        inputs = {k: v % tape.q * R % tape.q for k, v in inputs.items()}
+    one = R if mont else 1
     if getattr(tape, "kind", 0) == 1:
-        return eval_pipe(tape.q, tape.n_signals, tape.n_tslots, tape.consts, tape.rows, tape.extras, tape.terms, tape.lconsts,
-                         tape.pipe, inputs, tape.rbits)
-    return eval_rows(tape.q, tape.n_signals, tape.n_tslots, tape.consts, tape.rows, inputs, tape.rbits,
-                     tape.stream_off, tape.extras, tape.extra_off, tape.n_lds, tape.terms, tape.term_off, tape.lconsts,
-                     getattr(tape, "functions", ()))
+        sig, st = eval_pipe(tape.q, tape.n_signals, tape.n_tslots, tape.consts, tape.rows, tape.extras, tape.terms, tape.lconsts,
+                            tape.pipe, inputs, tape.rbits, one)
+    else:
+        sig, st = eval_rows(tape.q, tape.n_signals, tape.n_tslots, tape.consts, tape.rows, inputs, tape.rbits,
+                            tape.stream_off, tape.extras, tape.extra_off, tape.n_lds, tape.terms, tape.term_off, tape.lconsts,
+                            getattr(tape, "functions", ()), one)
+    if mont:
+        rinv = pow(R, -1, tape.q)
+        sig = [v * rinv % tape.q for v in sig]
+    return sig, st
 
 
 # ---- pipelined single-wave schedule (circom_amd/hip_elements/pipe.py), executed the way cw_pipe_kernel does ------------
@@ -455,7 +466,8 @@ P_ENTRY_NONE = 0xFF
 D_NOP = 255
 
 
-def eval_pipe(q: int, n_signals: int, n_tslots: int, consts, rows, loads, terms, lconsts, pipe, inputs: dict, rbits: int = 261):
+def eval_pipe(q: int, n_signals: int, n_tslots: int, consts, rows, loads, terms, lconsts, pipe, inputs: dict, rbits: int = 261,
+              one: int = 1):
     """Replays a pipelined schedule for one instance with the kernel's timing:
       * L(k), the load list of batch k, reads the value table / constant table when batch k-1 starts (after batch k-2's
         loads have landed) and lands in the staging half k % 2 when batch k starts; L(0) and L(1) are issued up front;
@@ -469,7 +481,7 @@ def eval_pipe(q: int, n_signals: int, n_tslots: int, consts, rows, loads, terms,
     nb, nld, rr = pipe
     rinv = pow(1 << rbits, -1, q)
     sig = [0] * n_signals
-    sig[0] = 1
+    sig[0] = one
     for k, v in inputs.items():
         sig[k] = v % q
     tmp = [None] * max(n_tslots, 1)

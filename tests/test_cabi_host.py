@@ -37,7 +37,8 @@ def test_load_reports_circuit_shape(tmp_path):
     assert c.q == Q and c.input_size("inputs") == (2, 2) and c.input_size("nope") == (None, None)
     st = cp.tape.stats
     # field multiplications per witness: 81 S-boxes x 3 products (2 Montgomery products each) + 65 x 9 MDS products
-    assert c.n_mmul == st["mmul"] + st["madd"] + st["mulc"] + 2 * st["mul2"] + st["linsum_terms"] == 1071
+    # signals in Montgomery form (compiler.choose_mont): 243 products + 585 matrix terms, one Montgomery product each
+    assert c.montgomery and c.n_mmul == st["mmul"] + st["madd"] + st["mulc"] + 2 * st["mul2"] + st["linsum_terms"] == 828
     c.close()
     with pytest.raises(rt.CwError):
         rt.Circuit(str(tmp_path / "missing.cwt"))

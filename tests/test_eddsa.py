@@ -146,7 +146,8 @@ def test_projective_ladder_same_outputs_fewer_chained_inversions(semp):
         tp = lower(fc, n_strands=S)
         got, st = eval_tape(tp, _inp(fc, row))
         assert st == 0 and got == sig
-        assert tp.stats["inv"] > 1000 and tp.stats["inv_batches"] <= 8      # the inversions do not depend on each other
+        # the ~1 000 inversions of the ladder do not depend on each other: Montgomery's trick leaves one per 64
+        assert tp.stats["inv"] == tp.stats["inv_batches"] <= 24
     for k, v in ((2, (row[2] + 1) % SUBGROUP_ORDER), (5, row[5] ^ 1), (0, row[0] ^ 1)):
         bad = list(row)
         bad[k] = v % Q
