@@ -1007,7 +1007,7 @@ def _schedule(rows, n_signals, n_strands):
 ROW_OVERHEAD = float(os.environ.get("CW_ROW_OVERHEAD", "4"))   # scheduler cost units charged to every row
 EXTRA_COST = float(os.environ.get("CW_EXTRA_COST", "2"))     # ... and to every extra destination (two 1-KiB stores)
 FULL_PERIOD = 8        # every FULL_PERIOD-th barrier also drains global stores
-AFFINITY_SLACK = 1.25  # a strand may take this much more than the average load of a level to keep data local
+AFFINITY_SLACK = float(os.environ.get("CW_AFFINITY_SLACK", "1.25"))  # a strand may take this much more than the average load of a level to keep data local
 
 
 def lds_slots_for(n_strands: int) -> int:
