@@ -218,6 +218,7 @@ struct Variant {               // one lowering of the schedule for a given stran
     std::vector<uint32_t> prows;
     std::vector<CwRow> rows;
     std::vector<uint32_t> stream_off, extras, extra_off, term_off, terms;   // terms: 4 x u32 each
+    std::vector<uint32_t> seq_off, seqs;    // per strand: flat-operation index of every row that can fail a check, in row order
 };
 
 struct cw_circuit {
@@ -329,6 +330,14 @@ static const char *validate_variant(const Variant &v, uint32_t n_signals, uint32
             xp += nx;
         }
         if (xp != v.extra_off[st + 1] || tp != v.term_off[st + 1]) return "strand tables do not add up";
+        size_t can_fail = 0;
+        for (size_t r = v.stream_off[st]; r < v.stream_off[st + 1]; r++) {
+            const uint32_t op = v.rows[r].w0 & 0xFF;
+            can_fail += (op == D_ASSERT_EQ || op == D_ASSERT_NZ || op == D_IDIV || op == D_MOD || op == D_CALL);
+        }
+        if (v.seq_off.size() != v.n_strands + 1 || v.seq_off[st] > v.seq_off[st + 1] ||
+            v.seq_off[st + 1] - v.seq_off[st] != can_fail)
+            return "check-index table does not match the rows that can fail";
     }
     return nullptr;
 }
@@ -392,7 +401,7 @@ static int load_tape(cw_circuit *c, const char *path) {
     if (!read_file(path, b)) return fail(CW_EIO, std::string("tape file not found: ") + path);
     if (b.size() < 16 + 32 + 48 || memcmp(b.data(), "CWTP", 4)) return fail(CW_EIO, "bad tape magic");
     const uint32_t *h = (const uint32_t *)(b.data() + 4);
-    if (h[0] != 7) return fail(CW_EIO, "unsupported tape version");
+    if (h[0] != 8) return fail(CW_EIO, "unsupported tape version");
     if (h[1] != 4) return fail(CW_EIO, "only 4x64-bit primes are supported (bn128, bls12381, ...)");
     uint32_t n_variants = h[2];
     size_t off = 16;
@@ -580,6 +589,19 @@ static int load_tape(cw_circuit *c, const char *path) {
         var.terms.resize((size_t)nterms * 4);
         memcpy(var.terms.data(), b.data() + off, (size_t)nterms * 16);
         off += (size_t)nterms * 16;
+        {   // which flat operation every row that can fail comes from (reported in the status word)
+            const uint32_t nseq = vh[7];
+            if (nseq > nrows || off + ((size_t)var.n_strands + 1 + nseq) * 4 > b.size()) return fail(CW_EIO, "tape variant truncated");
+            var.seq_off.resize(var.n_strands + 1);
+            memcpy(var.seq_off.data(), b.data() + off, (size_t)(var.n_strands + 1) * 4);
+            off += (size_t)(var.n_strands + 1) * 4;
+            var.seqs.resize(nseq);
+            memcpy(var.seqs.data(), b.data() + off, (size_t)nseq * 4);
+            off += (size_t)nseq * 4;
+            if (var.seq_off[0] != 0 || var.seq_off[var.n_strands] != nseq) return fail(CW_EIO, "tape variant: bad check-index offsets");
+            for (uint32_t sq : var.seqs)
+                if (sq > 0xFFFFFFu) return fail(CW_EIO, "tape variant: check index exceeds 24 bits");
+        }
         if (nterms < 4 || nextras < 4) return fail(CW_EIO, "tape variant: tables lack their padding");
         if (const char *why = validate_variant(var, c->n_signals, c->n_consts, n_lconsts, fn_regs))
             return fail(CW_EIO, std::string("tape variant: ") + why);
@@ -1190,12 +1212,15 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
         std::vector<uint32_t> doff(1, 0);
         drows.reserve(v.rows.size() + 3 * v.n_strands);
         for (uint32_t st = 0; st < v.n_strands; st++) {
+            size_t sq = v.seq_off[st];
             for (uint32_t r = v.stream_off[st]; r < v.stream_off[st + 1]; r++) {
                 const CwRow &row = v.rows[r];
                 uint32_t op = row.w0 & 0xFF, dk = (row.w0 >> SH_DK) & 7, ak = (row.w0 >> SH_AK) & 7,
                          bk = (row.w0 >> SH_BK) & 7;
                 CwDRow d;
                 d.w0 = row.w0;
+                const bool can_fail = op == D_ASSERT_EQ || op == D_ASSERT_NZ || op == D_IDIV || op == D_MOD || op == D_CALL;
+                const uint32_t seq = can_fail ? v.seqs[sq++] : 0;
                 if (op == D_BARRIER) {
                     d.aux = row.dst;
                     d.dst_off = d.a_off = d.b_off = 0;
@@ -1206,7 +1231,8 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
                     d.b_off = resolve(bk, row.b);                    // constant term c0 (kind CONST) or nothing
                 } else if (op == D_CALL) {
                     d.aux = row.a;                                   // function id
-                    d.dst_off = d.a_off = 0;
+                    d.dst_off = seq;                                 // reported if the function fails (no destination)
+                    d.a_off = 0;
                     d.b_off = resolve(K_TMP, row.b);                 // first register of the call's window
                 } else if (op == D_BIT) {
                     d.aux = row.b;                                   // bit index k
@@ -1214,7 +1240,7 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
                     d.a_off = resolve(ak, row.a);
                     d.b_off = 0;
                 } else {
-                    d.aux = r;                                       // schedule row, reported in the status word
+                    d.aux = seq;                                     // flat operation, reported in the status word
                     d.dst_off = dk == KD_NONE ? 0 : resolve(dk, row.dst);
                     d.a_off = resolve(ak, row.a);
                     d.b_off = resolve(bk, row.b);
@@ -2116,8 +2142,8 @@ extern "C" int cw_explain(cw_batch *b, uint32_t instance, const char *sym_path, 
     std::string t = "instance " + std::to_string(instance) + ": ";
     const uint32_t s = st[instance];
     if (s == 0) t += "ok\n";
-    if (s & CW_ST_ASSERT_FAILED) t += "a run-time check (=== / assert) failed at schedule row " + std::to_string(s >> 8) + "\n";
-    if (s & CW_ST_ARITH) t += "integer division or modulo by zero at schedule row " + std::to_string(s >> 8) + "\n";
+    if (s & CW_ST_ASSERT_FAILED) t += "a run-time check (=== / assert) failed: operation " + std::to_string(s >> 8) + " of the witness program (the first failing one in program order)\n";
+    if (s & CW_ST_ARITH) t += "integer division or modulo by zero (or a run-away function): operation " + std::to_string(s >> 8) + " of the witness program\n";
     if (s & CW_ST_R1CS_FAILED) {
         const uint32_t k = fb[instance];
         t += "constraint " + std::to_string(k) + " of the .r1cs is violated: A*B - C != 0 with\n";

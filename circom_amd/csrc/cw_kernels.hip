@@ -118,6 +118,21 @@ extern "C" int cw_debug_profile(unsigned long long *out, int reset) {
 #endif
 extern __shared__ uint4 cw_lds[];       // [slot][2 halves][64 lanes] x 16 B
 
+// Status word of an instance = bits | index << 8, index = the flat operation of the failing check (cw_tape.h).  When several
+// checks fail - in any row order, on any strand - the smallest index wins: the check the reference's sequential program
+// stops at (assert_bucket.rs:75-77, calcwit.cpp:104-114).
+__device__ __forceinline__ void cw_fail(uint32_t &st, uint32_t bits, uint32_t idx) {
+    if (st == 0 || idx < (st >> 8)) st = bits | (idx << 8);
+}
+__device__ __forceinline__ void cw_publish_status(uint32_t *status, uint32_t i, uint32_t st) {
+    uint32_t old = status[i];
+    while (old == 0 || (st >> 8) < (old >> 8)) {
+        const uint32_t prev = atomicCAS(&status[i], old, st);
+        if (prev == old) break;
+        old = prev;
+    }
+}
+
 struct EvalCtx {                         // per-wave constants of the interpreter
     const char *Vb;                      // value table, bytes
     const char *Cb;                      // constant table, bytes
@@ -320,7 +335,7 @@ __device__ __noinline__ void eval_call(uint32_t fn, uint64_t reg_off, uint32_t r
                 const uint32_t op = ins.x, d = ins.y;
                 pc = cur + 1;
                 if (++steps > CW_CALL_STEP_LIMIT) {
-                    if (st == 0) st = CW_ST_ARITH | (row_id << 8);
+                    cw_fail(st, CW_ST_ARITH, row_id);
                     done = true;
                 } else if (op == F_RET) {
                     done = true;
@@ -331,7 +346,7 @@ __device__ __noinline__ void eval_call(uint32_t fn, uint64_t reg_off, uint32_t r
                 } else if (op == F_LDX || op == F_STX) {
                     uint32_t idx;
                     if (!fn_index(fn_operand(ins.w & 0xFFFFu, regs, c), ins.w >> 16, &idx)) {
-                        if (st == 0) st = CW_ST_ARITH | (row_id << 8);
+                        cw_fail(st, CW_ST_ARITH, row_id);
                         idx = 0;
                     }
                     if (op == F_LDX) fn_store(d, regs, c, fn_operand(ins.z + idx, regs, c));
@@ -352,7 +367,7 @@ __device__ __noinline__ void eval_call(uint32_t fn, uint64_t reg_off, uint32_t r
                     case D_MOD: {
                         fe qq, rr;
                         if (fe_is_zero(b)) {
-                            if (st == 0) st = CW_ST_ARITH | (row_id << 8);
+                            cw_fail(st, CW_ST_ARITH, row_id);
                         } else {
                             fe_divmod(a, b, &qq, &rr);
                             r = (op == D_IDIV) ? qq : rr;
@@ -470,11 +485,11 @@ __device__ __forceinline__ void eval_step(const CwDRow &row, const fe &xa, const
         break;
     }
     case D_ASSERT_EQ:
-        if (!fe_eq(a, b) && st == 0) st = CW_ST_ASSERT_FAILED | (row.aux << 8);
+        if (!fe_eq(a, b)) cw_fail(st, CW_ST_ASSERT_FAILED, row.aux);
         has_d = false;
         break;
     case D_ASSERT_NZ:
-        if (fe_is_zero(a) && st == 0) st = CW_ST_ASSERT_FAILED | (row.aux << 8);
+        if (fe_is_zero(a)) cw_fail(st, CW_ST_ASSERT_FAILED, row.aux);
         has_d = false;
         break;
     default:
@@ -482,7 +497,7 @@ __device__ __forceinline__ void eval_step(const CwDRow &row, const fe &xa, const
             switch (op) {
             case D_INV: d = fe_inv(a, P); break;
             case D_CALL:
-                eval_call(row.aux, row.b_off, r, st, c, P);
+                eval_call(row.aux, row.b_off, (uint32_t)row.dst_off, st, c, P);
                 has_d = false;
                 break;
             case D_POW: d = fe_pow(a, b, P); break;
@@ -490,7 +505,7 @@ __device__ __forceinline__ void eval_step(const CwDRow &row, const fe &xa, const
             case D_MOD: {
                 fe qq, rr;
                 if (fe_is_zero(b)) {
-                    if (st == 0) st = CW_ST_ARITH | (row.aux << 8);
+                    cw_fail(st, CW_ST_ARITH, row.aux);
                     d = fe_zero();
                 } else {
                     fe_divmod(a, b, &qq, &rr);
@@ -597,7 +612,7 @@ cw_eval_kernel(const CwDRow *__restrict__ rows, const uint32_t *__restrict__ str
         r0 = r2;
         r += 2;
     }
-    if (st && i < batch) atomicCAS(&status[i], 0u, st);
+    if (st && i < batch) cw_publish_status(status, i, st);
     }
 }
 
@@ -737,11 +752,11 @@ __device__ __forceinline__ void pipe_step(const CwPRow &row, const fe &xa, const
         break;
     }
     case D_ASSERT_EQ:
-        if (!fe_eq(a, b) && st == 0) st = CW_ST_ASSERT_FAILED | (row.aux << 8);
+        if (!fe_eq(a, b)) cw_fail(st, CW_ST_ASSERT_FAILED, row.aux);
         has_d = false;
         break;
     case D_ASSERT_NZ:
-        if (fe_is_zero(a) && st == 0) st = CW_ST_ASSERT_FAILED | (row.aux << 8);
+        if (fe_is_zero(a)) cw_fail(st, CW_ST_ASSERT_FAILED, row.aux);
         has_d = false;
         break;
     default:
@@ -755,7 +770,7 @@ __device__ __forceinline__ void pipe_step(const CwPRow &row, const fe &xa, const
             case D_MOD: {
                 fe qq, rr;
                 if (fe_is_zero(b)) {
-                    if (st == 0) st = CW_ST_ARITH | (row.aux << 8);
+                    cw_fail(st, CW_ST_ARITH, row.aux);
                     d = fe_zero();
                 } else {
                     fe_divmod(a, b, &qq, &rr);
@@ -858,7 +873,7 @@ cw_pipe_kernel(const CwPRow *__restrict__ rows, uint32_t n_rows, const uint32_t 
         if (blockIdx.x == 0 && lane == 0)
             for (int k = 0; k < 128; k++) atomicAdd(&cw_prof[k], prof_tab[k]);
 #endif
-        if (st && i < batch) atomicCAS(&status[i], 0u, st);
+        if (st && i < batch) cw_publish_status(status, i, st);
     }
 }
 

@@ -93,6 +93,11 @@ _DIRECT = {O.COPY: D_COPY, O.ADD: D_ADD, O.SUB: D_SUB, O.NEG: D_NEG, O.IDIV: D_I
            O.LAND: D_LAND, O.LOR: D_LOR, O.LNOT: D_LNOT, O.ASSERT_EQ: D_ASSERT_EQ, O.ASSERT_NZ: D_ASSERT_NZ}
 _COST = {D_MMUL: 10.0, D_MUL2: 20.0, D_MADD: 11.0, D_MULC: 10.0, D_MADDC: 11.0, D_INV: 1000.0, D_POW: 6000.0, D_IDIV: 8000.0, D_MOD: 8000.0}
 _NO_VALUE = (D_ASSERT_EQ, D_ASSERT_NZ, D_SELECT)
+# rows that can set the status word of an instance; the word carries the index of the flat operation (24 bits), and when
+# several checks of one instance fail - on any strand, in any schedule order - the smallest index is reported: the check
+# the reference's sequential program would have stopped at (assert_bucket.rs:75-77)
+_FAIL_OPS = (D_ASSERT_EQ, D_ASSERT_NZ, D_IDIV, D_MOD, D_CALL)
+SEQ_MAX = 0xFFFFFF
 
 
 class Tape:
@@ -111,6 +116,8 @@ class Tape:
         self.n_lds = 0              # LDS value slots the workgroup needs
         self.terms = None           # uint32[n,4]: D_LINSUM terms (kind|sign, index, |coef| lo, hi), stream/row order
         self.term_off = None        # uint32[n_strands+1]
+        self.seqs = np.zeros(0, dtype=np.uint32)      # flat-operation index of every row that can fail, stream/row order
+        self.seq_off = np.zeros(2, dtype=np.uint32)   # uint32[n_strands+1]
         self.lconsts = []           # constants of D_DOTC terms (coef * R' mod q), stored by the runtime as 29-bit limbs
         self.n_strands = 1
         self.consts = []            # raw residues (python ints)
@@ -150,7 +157,7 @@ def _dce(code, n_temps, nregs=()):
 
 
 class _Row:
-    __slots__ = ("op", "dk", "dv", "ak", "av", "bk", "bv", "ck", "cv", "extra", "level", "strand", "flag", "coef", "terms")
+    __slots__ = ("op", "dk", "dv", "ak", "av", "bk", "bv", "ck", "cv", "extra", "level", "strand", "flag", "coef", "terms", "seq")
 
     def __init__(self, op, dk, dv, ak, av, bk=K_NONE, bv=0, ck=K_NONE, cv=0):
         self.op, self.dk, self.dv = op, dk, dv
@@ -161,6 +168,7 @@ class _Row:
         self.terms = None        # D_LINSUM: list of [kind, id, signed coefficient]
         self.level = 0
         self.strand = 0
+        self.seq = 0             # index of the flat operation this row comes from (reported when the row fails a check)
 
 
 def _proved_asserts(code, constants):
@@ -273,8 +281,13 @@ def _expand(fc: FlatCircuit):
         return k, v
 
     rows = []
+    row_seq, cur_seq = [], 0        # rows[k] comes from flat operation row_seq[k] (eval_flat's index of a failing check)
+    flat_index = idx.tolist()
     for i in range(len(op)):
         o = op[i]
+        while len(row_seq) < len(rows):
+            row_seq.append(cur_seq)
+        cur_seq = flat_index[i]
         if o == O.MUL:
             a_c, b_c = ak[i] == K_CONST, bk[i] == K_CONST
             if a_c or b_c:
@@ -313,6 +326,10 @@ def _expand(fc: FlatCircuit):
             ka, va = opnd(ak[i], av[i])
             kb, vb = opnd(bk[i], bv[i]) if bk[i] != K_NONE else (K_NONE, 0)
             rows.append(_Row(_DIRECT[o], dk[i] if dk[i] != K_NONE else KD_NONE, dv[i], ka, va, kb, vb))
+    while len(row_seq) < len(rows):
+        row_seq.append(cur_seq)
+    for r_, sq in zip(rows, row_seq):
+        r_.seq = min(sq, SEQ_MAX)
     _expand.n_proved = int(proved.sum())
     return rows, dconsts, nxt[0], cid, plain
 
@@ -1305,6 +1322,7 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None, mont
     stream_off = [0]
     extra_off = [0]
     term_off = [0]
+    seqs, seq_off = [], [0]   # flat-operation index of every row that can fail (in stream order), per strand
     n_prev = n_ldsops = 0
     for si, items in enumerate(plan):
         for (r, fl, t) in items:
@@ -1365,12 +1383,15 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None, mont
                     elif v in slot_of:
                         ex.append(X_TMP | slot_of[v])
             assert len(ex) <= MAX_EXTRA, "fan-out of one value exceeds the extra-destination field"
+            if r.op in _FAIL_OPS:
+                seqs.append(r.seq)
             enc.append((r.op | (kd << SH_DK) | (ka << SH_AK) | (kb << SH_BK) | (len(ex) << SH_NX) | (r.flag << SH_FLAG),
                         vd, va, vb))
             extras.extend(ex)
         stream_off.append(len(enc))
         extra_off.append(len(extras))
         term_off.append(len(terms))
+        seq_off.append(len(seqs))
     out = np.asarray(enc, dtype=np.uint32).reshape(-1, 4)
 
     t = Tape()
@@ -1389,6 +1410,8 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None, mont
         tt[j] = (tk | (0x80000000 if cf < 0 else 0), tv, m & 0xFFFFFFFF, m >> 32)
     t.terms = tt
     t.term_off = np.asarray(term_off, dtype=np.uint32)
+    t.seqs = np.asarray(seqs, dtype=np.uint32)
+    t.seq_off = np.asarray(seq_off, dtype=np.uint32)
     t.lconsts = lconsts
     t.functions = [_encode_function(f, cid, q) for f in functions]
     t.n_lds = n_lds_used

@@ -117,7 +117,7 @@ def plan_pipe(stream, n_signals, dconsts, D, nb=DEFAULT_NB, nld=DEFAULT_NLD):
             res.append((K_LDS, RR + (k & 1) * nld + j))
         return res
 
-    def place(op, ops, terms, names, stores, flag=0, aux=0, cmag=0):
+    def place(op, ops, terms, names, stores, flag=0, aux=0, cmag=0, seq=0):
         """terms: list of (kind, id, coef) or None.  names: value ids this row's result is known by."""
         nonlocal last_names
         while True:
@@ -138,7 +138,7 @@ def plan_pipe(stream, n_signals, dconsts, D, nb=DEFAULT_NB, nld=DEFAULT_NLD):
             if s[0] == 'v':
                 far_names.add(s[1])
         batch_loads[k].extend(newloads)
-        row = dict(op=op, a=cl[0] if len(cl) > 0 else (0, 0), b=cl[1] if len(cl) > 1 else (0, 0), flag=flag, aux=aux,
+        row = dict(op=op, a=cl[0] if len(cl) > 0 else (0, 0), b=cl[1] if len(cl) > 1 else (0, 0), flag=flag, aux=aux, seq=seq,
                    names=tuple(names), stores=list(stores[:2]), cmag=cmag,
                    terms=[(c_[0], c_[1], t[2]) for c_, t in zip(tl, terms)] if terms is not None else None)
         out.append(row)
@@ -190,7 +190,7 @@ def plan_pipe(stream, n_signals, dconsts, D, nb=DEFAULT_NB, nld=DEFAULT_NLD):
             cmag = dconsts[r.bv + 1] if r.flag else 0
             place(op, [(r.ak, r.av), (r.bk, r.bv)], None, names, stores, flag=r.flag, cmag=cmag)
             continue
-        place(op, [(r.ak, r.av), (r.bk, r.bv)], None, names, stores)
+        place(op, [(r.ak, r.av), (r.bk, r.bv)], None, names, stores, seq=r.seq)
     close_batch()
     n_rows = len(out)
     n_batches = n_rows // nb
@@ -243,7 +243,7 @@ def plan_pipe(stream, n_signals, dconsts, D, nb=DEFAULT_NB, nld=DEFAULT_NLD):
         n_stores += sum(1 for s in st if s != P_NONE)
         aux = row["aux"]
         if op in (D.D_ASSERT_EQ, D.D_ASSERT_NZ, D.D_IDIV, D.D_MOD):
-            aux = pos
+            aux = row.get("seq", 0)         # index of the flat operation: what the status word reports
         for kk, ee in ((ak, ae), (bk, be)):
             n_prev += kk == KO_PREV
             n_ring += kk == K_LDS and ee < RR

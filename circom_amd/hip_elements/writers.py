@@ -77,7 +77,7 @@ def write_dat(path, fc: FlatCircuit, witness2signal=None):
 
 
 TAPE_MAGIC = b"CWTP"
-TAPE_VERSION = 7
+TAPE_VERSION = 8
 
 
 def write_tape(path, tapes, bittape=None):
@@ -97,6 +97,8 @@ def write_tape(path, tapes, bittape=None):
             per variant     u32 n_strands | u32 n_tslots | u32 n_rows | u32 n_extras | u32 n_lds | u32 n_terms | u32 kind | u32 shape
                             stream_off | extra_off | term_off      ((n_strands+1) x u32 each)
                             rows n_rows x 4 x u32 | extras n_extras x u32 | terms n_terms x 4 x u32
+                            kind 0: shape = n_seq, then seq_off (n_strands+1) x u32 | seqs n_seq x u32: for every row that can
+                            fail a check (ASSERT_EQ/NZ, IDIV, MOD, CALL), in stream order, the index of its flat operation
                             kind 1 (pipelined, pipe.py): rows are 8 x u32, `extras` = the load lists ((n_rows/NB + 2) x NLD
                             words), shape = NB | NLD << 8, n_lds = 2*NB + 2*NLD
             bit program     (if n_bit_programs, hip_elements/bitsched.py)  8 x u32: ring, n_vrows, n_slots lo, hi, 0, 0, 0, 0
@@ -128,7 +130,7 @@ def write_tape(path, tapes, bittape=None):
             f.write(np.ascontiguousarray(fcode, dtype="<u4").tobytes())
         for t in tapes:
             kind = getattr(t, "kind", 0)
-            shape = (t.pipe[0] | (t.pipe[1] << 8)) if kind == 1 else 0
+            shape = (t.pipe[0] | (t.pipe[1] << 8)) if kind == 1 else len(t.seqs)
             f.write(struct.pack("<8I", t.n_strands, t.n_tslots, len(t.rows), len(t.extras), t.n_lds, len(t.terms), kind, shape))
             f.write(np.asarray(t.stream_off, dtype="<u4").tobytes())
             f.write(np.asarray(t.extra_off, dtype="<u4").tobytes())
@@ -136,6 +138,9 @@ def write_tape(path, tapes, bittape=None):
             f.write(np.ascontiguousarray(t.rows, dtype="<u4").tobytes())
             f.write(np.asarray(t.extras, dtype="<u4").tobytes())
             f.write(np.ascontiguousarray(t.terms, dtype="<u4").tobytes())
+            if kind == 0:
+                f.write(np.asarray(t.seq_off, dtype="<u4").tobytes())
+                f.write(np.asarray(t.seqs, dtype="<u4").tobytes())
         if bittape is not None:
             assert bittape.n_signals == t0.n_signals and not getattr(t0, "mont", False)
             f.write(struct.pack("<8I", bittape.ring, bittape.n_vrows, bittape.n_slots & 0xFFFFFFFF, bittape.n_slots >> 32, 0, 0, 0, 0))

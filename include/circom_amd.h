@@ -37,8 +37,11 @@ typedef struct cw_batch cw_batch;     /* replaces Circom_CalcWit (calcwit.hpp:17
 
 /* instance status word (cw_get_status) */
 #define CW_ST_OK 0u
-#define CW_ST_ASSERT_FAILED 1u /* a `===` / assert() did not hold; bits 8.. = schedule row */
-#define CW_ST_ARITH 2u         /* `\` or `%` by zero (reference: GMP abort, generic/fr.cpp:2835-2875) */
+#define CW_ST_ASSERT_FAILED 1u /* a `===` / assert() did not hold */
+#define CW_ST_ARITH 2u         /* `\` or `%` by zero (reference: GMP abort, generic/fr.cpp:2835-2875), run-away function */
+/* bits 8..31 of a word with bit 0 or 1 set: index of the failing operation in the circuit's flat witness program.  When
+   several checks of an instance fail, the one with the smallest index is reported whatever the schedule's row order and
+   strand count - the check the reference's sequential program stops at (assert_bucket.rs:75-77, calcwit.cpp:104-114). */
 #define CW_ST_R1CS_FAILED 4u   /* set by cw_check_r1cs */
 
 const char *cw_last_error(void);

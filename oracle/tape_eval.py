@@ -230,7 +230,7 @@ def run_dev_function(f: Field, code, regs: list, base: int, consts) -> bool:
 
 def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict, rbits: int = 261,
               stream_off=None, extras=None, extra_off=None, n_lds: int = 0, terms=None, term_off=None, lconsts=(),
-              functions=(), one: int = 1):
+              functions=(), one: int = 1, seqs=None, seq_off=None):
     """Evaluate a lowered schedule exactly the way cw_eval_kernel does, for one instance:
       * every strand (stream) walks its own rows; strands meet at BARRIER rows,
       * operands of row r+1 are fetched BEFORE row r stores its result (one-row-ahead prefetch), except
@@ -241,7 +241,10 @@ def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict,
     Strands of one epoch are simulated one after the other; any cross-strand read-after-write or
     write-after-read inside an epoch, and any cross-strand global read not separated from its write by a
     FULL barrier, is reported as a ScheduleHazard (on the GPU it would be a race).
-    Returns (signal values, status) with status = 0 | bits + (row << 8) like the kernel."""
+    Returns (signal values, status) with status = 0 | bits + (index << 8) like the kernel: `seqs` names, for every row
+    that can fail (in stream order), the flat operation it comes from, and the failing check with the SMALLEST index wins
+    whatever strand hits it and in whatever order - the check the reference's sequential program stops at; without
+    `seqs` the schedule row of the first failure met is reported."""
     f = Field(q)
     rinv = pow(1 << rbits, -1, q)        # MMUL = a*b*R'^-1 with the schedule's radix (device: R' = 2^261)
     sig = [0] * n_signals
@@ -269,6 +272,17 @@ def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict,
     prev = [0] * ns
     sel = [False] * ns
     status = [0]
+    sp = [int(seq_off[s]) for s in range(ns)] if seqs is not None else None
+
+    def fail(s, bits, r):
+        if seqs is None:
+            if status[0] == 0:
+                status[0] = bits | (r << 8)
+            return
+        word = bits | (int(seqs[sp[s]]) << 8)
+        if status[0] == 0 or (word >> 8) < (status[0] >> 8):
+            status[0] = word
+
     writer = {}      # (kind, slot) -> (epoch, strand) of the last write
     reader = {}      # (kind, slot) -> set of strands that read it in the current epoch
     state = {"epoch": 0, "last_full": -1}
@@ -360,8 +374,7 @@ def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict,
                 try:
                     res = bins[op](a, b)
                 except FieldError:
-                    if status[0] == 0:
-                        status[0] = 2 | (r << 8)
+                    fail(s, 2, r)
                     res = 0
             elif op in uns:
                 res = uns[op](a)
@@ -388,20 +401,22 @@ def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict,
                 n_regs, fcode = functions[a_]
                 for k in range(n_regs):       # the interpreter reads and writes its registers in the value table
                     writer[(1, b_ + k)] = (state["epoch"], s)
-                if not run_dev_function(f, fcode, tmp, b_, consts) and status[0] == 0:
-                    status[0] = 2 | (r << 8)
+                if not run_dev_function(f, fcode, tmp, b_, consts):
+                    fail(s, 2, r)
             elif op == D_SELECT:
                 sel[s] = a != 0               # latched lane mask; no value
             elif op == D_EXT:
                 res = a if sel[s] else b
             elif op == D_ASSERT_EQ:
-                if a != b and status[0] == 0:
-                    status[0] = 1 | (r << 8)
+                if a != b:
+                    fail(s, 1, r)
             elif op == D_ASSERT_NZ:
-                if a == 0 and status[0] == 0:
-                    status[0] = 1 | (r << 8)
+                if a == 0:
+                    fail(s, 1, r)
             else:
                 raise ValueError("bad device op %d" % op)
+            if sp is not None and op in (D_ASSERT_EQ, D_ASSERT_NZ, D_IDIV, D_MOD, D_CALL):
+                sp[s] += 1
             if res is not None:
                 prev[s] = res
                 if dk != KD_NONE:
@@ -452,7 +467,7 @@ def eval_tape(tape, inputs: dict):
     else:
         sig, st = eval_rows(tape.q, tape.n_signals, tape.n_tslots, tape.consts, tape.rows, inputs, tape.rbits,
                             tape.stream_off, tape.extras, tape.extra_off, tape.n_lds, tape.terms, tape.term_off, tape.lconsts,
-                            getattr(tape, "functions", ()), one)
+                            getattr(tape, "functions", ()), one, getattr(tape, "seqs", None), getattr(tape, "seq_off", None))
     if mont:
         rinv = pow(R, -1, tape.q)
         sig = [v * rinv % tape.q for v in sig]
@@ -583,7 +598,7 @@ def eval_pipe(q: int, n_signals: int, n_tslots: int, consts, rows, loads, terms,
             try:
                 res = bins[op](a, b)
             except FieldError:
-                if status == 0:
+                if status == 0 or aux < (status >> 8):
                     status = 2 | (aux << 8)
                 res = 0
         elif op in uns:
@@ -609,10 +624,10 @@ def eval_pipe(q: int, n_signals: int, n_tslots: int, consts, rows, loads, terms,
         elif op == D_EXT:
             res = a if sel else b
         elif op == D_ASSERT_EQ:
-            if a != b and status == 0:
+            if a != b and (status == 0 or aux < (status >> 8)):
                 status = 1 | (aux << 8)
         elif op == D_ASSERT_NZ:
-            if a == 0 and status == 0:
+            if a == 0 and (status == 0 or aux < (status >> 8)):
                 status = 1 | (aux << 8)
         else:
             raise ValueError("bad device op %d in a pipelined schedule" % op)
