@@ -866,6 +866,13 @@ class _Blaster:
                     r = self.poly_result(p) if p is not None else r
                     if type(r) is int and r in (0, 1):
                         r = ((), r)
+                    if type(r) is Poly and all(v == 0 or v == 1 for v in r.vals):
+                        # a boolean function of 4..KMAX leaves (constants folded into one side of an xor3 / maj of a short
+                        # message): mux tree over 3-input gates
+                        tt = 0
+                        for m, v in enumerate(r.vals):
+                            tt |= v << m
+                        r = self.shannon(r.leaves, tt)
                     if type(r) is not tuple:
                         raise Unsupported("signal %d is not provably a bit" % dv[i])
                 nid = self.node_of(r)
