@@ -211,6 +211,9 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-small", action="store_true", help="skip the batch-4096 side measurement (profiling runs)")
     ap.add_argument("--fp-bench-lanes", type=int, default=1 << 24)
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("CW_IN_FLIGHT", "2")),
+                    help="batches in flight on separate HIP streams (consecutive steps alternate between them, so the R1CS "
+                         "check of one step overlaps the evaluation of the next); 1 = strictly sequential steps")
     args = ap.parse_args()
 
     import numpy as np
@@ -252,19 +255,43 @@ def main():
     h_in = synth_inputs(args.workload, circ.q, B, circ.n_inputs, seed=1 + rank)
     d_in = torch.from_numpy(h_in).to(dev)
     batch.set_inputs_device(d_in.data_ptr())
+    # Steps are independent batches, so consecutive steps may overlap: `in_flight` batch objects (own tables, own HIP
+    # stream each) take the steps in turn; the evaluation of step k+1 (vector-memory / issue bound) runs while the R1CS check
+    # of step k (scalar-load / latency bound) is still going.  Every step is a complete pass: ingest + evaluation + check of
+    # all B instances.  The first warm-up step runs alone on the first batch: the `isolated` timings of the JSON line.
+    n_fl = max(1, args.in_flight)
+    streams, batches = [stream], [batch]
+    for _ in range(n_fl - 1):
+        try:
+            st_ = torch.cuda.Stream(device=dev)
+            b_ = circ.batch(B, device=local_rank, stream=st_.cuda_stream)
+        except rt.CwError:
+            break                                            # no room for another table: fewer batches in flight
+        b_.set_inputs_device(d_in.data_ptr())
+        streams.append(st_)
+        batches.append(b_)
+    n_fl = len(batches)
 
-    def step(ev=None):
+    def step(i, ev=None):
+        b, s_ = batches[i % n_fl], streams[i % n_fl]
         if ev:
-            ev[0].record(stream)
-        batch.run()
+            ev[0].record(s_)
+        b.run()
         if ev:
-            ev[1].record(stream)
-        batch.check_r1cs()
+            ev[1].record(s_)
+        b.check_r1cs()
         if ev:
-            ev[2].record(stream)
+            ev[2].record(s_)
 
-    for _ in range(args.warmup):
-        step()
+    iso = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    step(0, None)
+    torch.cuda.synchronize()
+    step(0, iso)
+    torch.cuda.synchronize()
+    isolated = {"eval_ms": iso[0].elapsed_time(iso[1]), "r1cs_check_ms": iso[1].elapsed_time(iso[2]),
+                "ms_per_step": iso[0].elapsed_time(iso[2])}
+    for i in range(max(args.warmup, n_fl)):
+        step(i)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -272,7 +299,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        step(evs[s])
+        step(s, evs[s])
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -281,6 +308,8 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    for b_ in batches[1:]:                                   # every batch in flight computed the same instances
+        assert (b_.status() == batch.status()).all()
 
     # correctness gate + the one data-path collective: gather per-instance status words on rank 0
     # (status words + public signals of every instance; full witnesses stay on the GPU that computed them)
@@ -321,7 +350,7 @@ def main():
         e_gbs = n_e * circ.n_witness * 32 / (e_ms * 1e-3) / 1e9
         egress = {"instances": n_e, "ms": e_ms, "GB/s": e_gbs, "frac_of_hbm_peak": e_gbs / HBM_PEAK_GBS,
                   "whole_batch_ms": e_ms * B / n_e,
-                  "witnesses_per_s_with_egress": B / ((gen_ms + chk_ms + e_ms * B / n_e) * 1e-3)}
+                  "witnesses_per_s_with_egress": B / (elapsed / args.steps + e_ms * B / n_e * 1e-3)}
         del buf
 
     # Fp mul/s half of the metric: 2^24 lanes x 1024 dependent Montgomery products, bn128 and bls12381
@@ -423,7 +452,7 @@ def main():
                        ("256-bit schedule, signals in Montgomery form" if circ.montgomery else "256-bit schedule"),
                        "bit_program": bits, "schedule_rows": circ.n_rows, "fp_mul_per_witness": circ.n_mmul,
                        "parallelism": "instances sharded x%d, status + public-signal gather only" % world,
-                       "compile_s": compile_s},
+                       "in_flight": n_fl, "compile_s": compile_s},
             # the dominant kernel of THIS run (longest measured duration)
             "roofline": roof_eval if gen_ms >= chk_ms else roof_r1cs,
             "roofline_eval": roof_eval,
@@ -435,8 +464,11 @@ def main():
             "batch_4096": small,
             "fp_mul_per_s": fp_mul_per_s,
             "fp_mul_per_s_by_prime": fp_mul,
+            # eval_ms / r1cs_check_ms / roofline*: averages over the timed region (with in_flight > 1 the two regions of
+            # consecutive steps overlap, so they add up to more than ms_per_step); `isolated`: one step running alone
             "eval_ms": gen_ms,
             "r1cs_check_ms": chk_ms,
+            "isolated": isolated,
             "failed_instances": n_bad,
             "parity": parity,
             "parity_checked": parity["parity_checked"] if parity else 0,
@@ -447,7 +479,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cp, args.workload)
         print(json.dumps(out))
-    batch.close()
+    for b_ in batches:
+        b_.close()
     circ.close()
     if dist:
         dist.destroy_process_group()
