@@ -368,6 +368,24 @@ __device__ __forceinline__ uint32_t bits_lane_bit(uint64_t mask) {
     asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(r) : "s"(mask));      // lane i gets bit i of the (wave-uniform) mask
     return r;
 }
+// 32 x 32 bit-matrix transpose across the 32 lanes of a half-wave: lane k enters with row k (bit j = element (k, j)) and
+// leaves with column k.  Five butterfly stages; stage d exchanges the off-diagonal d x d blocks between lanes k and k ^ d.
+__device__ __forceinline__ uint32_t bits_transpose32(uint32_t x, uint32_t lane) {
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+        const uint32_t d = 16u >> s;
+        const uint32_t m = s == 0 ? 0x0000FFFFu : s == 1 ? 0x00FF00FFu : s == 2 ? 0x0F0F0F0Fu : s == 3 ? 0x33333333u : 0x55555555u;
+        const uint32_t p = (uint32_t)__shfl_xor((int)x, (int)d);
+        x = (lane & d) ? (((p >> d) & m) | (x & ~m)) : ((x & m) | ((p & m) << d));
+    }
+    return x;
+}
+// the word of every instance from the 32 masks of a whole word (slots s .. s + 31 = bits 0 .. 31): lane l loads the
+// (l >> 5)-th dword of mask l & 31 - one coalesced 256-byte load, lanes 0..31 then hold the rows of the instances 0..31
+// and lanes 32..63 those of the instances 32..63 - and the transpose hands lane i the word of instance i
+__device__ __forceinline__ uint32_t bits_word_load(const uint64_t *__restrict__ Tg, uint32_t slot, uint32_t lane) {
+    return ((const uint32_t *)(Tg + slot))[(lane & 31u) * 2u + (lane >> 5)];
+}
 __global__ void __launch_bounds__(64)
 cw_bits_r1cs_int_kernel(const uint4 *__restrict__ chunk, uint32_t n_chunks, const uint32_t *__restrict__ words,
                         const uint2 *__restrict__ itab, const uint32_t *__restrict__ row_orig,
@@ -386,7 +404,23 @@ cw_bits_r1cs_int_kernel(const uint4 *__restrict__ chunk, uint32_t n_chunks, cons
             const uint32_t hdr = wp[0];
             const uint32_t nb = hdr & 0xFFu;
             wp++;
-            if (!(hdr & (1u << 10))) {
+            if (hdr & (1u << 15)) {                                 // whole words: nb first slots, four loads in flight
+                const uint32_t padded = (nb + 7u) & ~7u;
+                for (uint32_t j = 0; j < nb; j += 4) {
+                    uint32_t sl[4], x[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) sl[k] = wp[j + k];                 // the list is padded to 8 entries (zeros)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) x[k] = bits_word_load(Tg, j + k < nb ? sl[k] : 0u, lane);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t y = j + k < nb ? bits_transpose32(x[k], lane) : 0u;
+                        const int64_t val = (int64_t)((hdr & (1u << 9)) ? ((uint64_t)y << 32) : (uint64_t)y);
+                        cur += (hdr & (1u << 8)) ? -val : val;
+                    }
+                }
+                wp += padded;
+            } else if (!(hdr & (1u << 10))) {
                 uint32_t acc = 0;
                 for (uint32_t blk = 0; blk < nb; blk++, wp += 8) {
                     uint32_t w[8];

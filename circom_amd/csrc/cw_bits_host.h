@@ -7,6 +7,7 @@
 #include <array>
 #include <cstring>
 #include <string>
+#include <map>
 #include <vector>
 
 namespace cwbits {
@@ -71,13 +72,14 @@ struct R1Plan {
     // The terms of a row are regrouped (a sum does not care about order): a GROUP = terms whose coefficients are
     // distinct powers of two with one sign inside one 32-bit half (the 32 bits of a word of a BinSum / Bits2Num row), so
     // that a term is "or the bit in at position k" (2 VALU); other coefficients form generic groups.
-    // stream of u32: header {blocks:8 | sign:1 | hi:1 | generic:1 | part:2 | last of part:1 | end of row:1} then
+    // stream of u32: header {blocks:8 | sign:1 | hi:1 | generic:1 | part:2 | last of part:1 | end of row:1 | words:1} then
     // blocks x 8 words: power-of-two term = slot << 5 | k, generic term = two words (slot, coefficient id); padding
-    // terms name slot 0 (the constant 0).
+    // terms name slot 0 (the constant 0).  A WORD group (bit 15) carries `blocks` = n whole 32-bit words: n first slots,
+    // padded to a multiple of 8 words.
     std::vector<uint32_t> ichunk, iwords, irow_orig;   // chunk = {first word, groups, 0, first row}
     std::vector<uint32_t> itab;       // signed 64-bit value of every coefficient id (2 words each; 0 if not small)
     uint32_t n_ichunks = 0;
-    uint64_t n_trivial = 0, n_lut = 0, n_wide = 0, n_int = 0, n_int_blocks = 0, n_contig_blocks = 0;
+    uint64_t n_trivial = 0, n_lut = 0, n_wide = 0, n_int = 0, n_int_blocks = 0, n_contig_blocks = 0, n_word_terms = 0;
 };
 
 // small signed value of a canonical coefficient, if |val| < 2^40
@@ -208,7 +210,7 @@ inline R1Plan build_r1cs(const std::vector<uint32_t> &r_ptr, const std::vector<u
                 i_first_word = (uint32_t)p.iwords.size();
                 i_first_row = (uint32_t)p.irow_orig.size();
             }
-            struct G { uint32_t hdr; std::vector<uint32_t> w; };
+            struct G { uint32_t hdr; std::vector<uint32_t> w; uint32_t n_words = 0; };   // n_words != 0: a word group
             std::vector<G> groups;
             int last_part = -1;
             for (int pi = 0; pi < 3; pi++) {
@@ -227,8 +229,29 @@ inline R1Plan build_r1cs(const std::vector<uint32_t> &r_ptr, const std::vector<u
                         gen.push_back({sl, r_cc[t]});
                     }
                 }
-                std::stable_sort(pw.begin(), pw.end(), [](const std::array<uint32_t, 3> &x, const std::array<uint32_t, 3> &y) { return x[0] < y[0]; });
                 const size_t g0 = groups.size();
+                std::map<uint32_t, std::vector<uint32_t>> word_slots;     // key (sign, half) -> first slots of whole words
+                {   // whole words first, wherever their 32 terms sit in the part: per key, by slot, runs (s + t, 2^t), t = 0..31
+                    std::vector<std::array<uint32_t, 3>> srt(pw);
+                    std::sort(srt.begin(), srt.end());
+                    std::vector<std::array<uint32_t, 3>> rest;
+                    size_t a = 0;
+                    while (a < srt.size()) {
+                        bool word = a + 32 <= srt.size() && srt[a][2] == 0;
+                        for (uint32_t t = 1; t < 32 && word; t++)
+                            word = srt[a + t][0] == srt[a][0] && srt[a + t][1] == srt[a][1] + t && srt[a + t][2] == t;
+                        if (word) {
+                            word_slots[srt[a][0]].push_back(srt[a][1]);
+                            p.n_word_terms += 32;
+                            a += 32;
+                        } else {
+                            rest.push_back(srt[a]);
+                            a++;
+                        }
+                    }
+                    if (!word_slots.empty()) pw.swap(rest);
+                }
+                std::stable_sort(pw.begin(), pw.end(), [](const std::array<uint32_t, 3> &x, const std::array<uint32_t, 3> &y) { return x[0] < y[0]; });
                 size_t i = 0;
                 while (i < pw.size()) {
                     uint32_t used = 0;
@@ -244,6 +267,9 @@ inline R1Plan build_r1cs(const std::vector<uint32_t> &r_ptr, const std::vector<u
                     // bitsched.py) is marked in bit 31 of its first word: the kernel then fetches the 8 masks with ONE
                     // 64-byte scalar load.  Runs of consecutive slots are aligned to block starts by padding.
                     std::sort(g.w.begin(), g.w.end());              // by slot
+                    // (whole 32-bit words - 32 consecutive slots carrying 2^0 .. 2^31, the bits of a BinSum / Bits2Num operand,
+                    // 87 % of the terms of SHA-256's adder rows - were taken out above: the kernel fetches their 32 masks with
+                    // one coalesced vector load and transposes the 32 x 64 bit matrix across the lanes)
                     std::vector<uint32_t> out;
                     size_t a = 0;
                     while (a < g.w.size()) {
@@ -266,6 +292,15 @@ inline R1Plan build_r1cs(const std::vector<uint32_t> &r_ptr, const std::vector<u
                     g.w.swap(out);
                     groups.push_back(std::move(g));
                 }
+                for (auto &kv : word_slots)
+                    for (size_t k0 = 0; k0 < kv.second.size(); k0 += 255) {
+                        G g;
+                        g.hdr = ((kv.first >> 1) << 8) | ((kv.first & 1) << 9) | ((uint32_t)pi << 11) | (1u << 15);
+                        g.n_words = (uint32_t)std::min<size_t>(255, kv.second.size() - k0);
+                        g.w.assign(kv.second.begin() + k0, kv.second.begin() + k0 + g.n_words);
+                        while (g.w.size() % 8) g.w.push_back(0);     // the stream stays 32-byte aligned; entries past n are not read as words
+                        groups.push_back(std::move(g));
+                    }
                 for (size_t k0 = 0; k0 < gen.size(); k0 += 4 * 255) {
                     G g;
                     g.hdr = (1u << 10) | ((uint32_t)pi << 11);
@@ -289,7 +324,7 @@ inline R1Plan build_r1cs(const std::vector<uint32_t> &r_ptr, const std::vector<u
             }
             groups.back().hdr |= 1u << 14;                          // end of the row
             for (auto &g : groups) {
-                p.iwords.push_back(g.hdr | (uint32_t)(g.w.size() / 8));
+                p.iwords.push_back(g.hdr | (g.n_words ? g.n_words : (uint32_t)(g.w.size() / 8)));
                 p.iwords.insert(p.iwords.end(), g.w.begin(), g.w.end());
             }
             i_groups += (uint32_t)groups.size();

@@ -1689,9 +1689,11 @@ static int bits_batch_setup(cw_batch *b) {
         BTRY(hipStreamSynchronize(b->stream));                       // the plan goes out of scope
         b->n_evrows = p.n_evrows;
         if (getenv("CW_VERBOSE"))
-            fprintf(stderr, "[cw] bit-plane R1CS plan: %llu trivial, %llu lut, %llu int (%llu blocks, %llu contiguous), %llu field rows\n",
+            fprintf(stderr, "[cw] bit-plane R1CS plan: %llu trivial, %llu lut, %llu int (%llu terms in whole 32-bit words, %llu blocks of 8, "
+                            "%llu contiguous), %llu field rows\n",
                     (unsigned long long)p.n_trivial, (unsigned long long)p.n_lut, (unsigned long long)p.n_int,
-                    (unsigned long long)p.n_int_blocks, (unsigned long long)p.n_contig_blocks, (unsigned long long)p.n_wide);
+                    (unsigned long long)p.n_word_terms, (unsigned long long)p.n_int_blocks, (unsigned long long)p.n_contig_blocks,
+                    (unsigned long long)p.n_wide);
         b->n_wchunks = p.n_chunks;
     }
     BTRY(hipMalloc(&b->d_in, std::max<size_t>((size_t)b->batch * c->n_inputs * 32, 32)));

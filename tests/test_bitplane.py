@@ -86,6 +86,26 @@ def BadWeighted(c, n, big):
     c.enforce(lhs, rhs, runtime_check=False)
 
 
+@template
+def BadWords(c, flip, second_only=False):
+    """Three 32-bit words x, y, z (bits of consecutive signals) and a copy of each, except that bit `flip` of the copy of y is
+    inverted when x0 & x1.  The check rows are the shapes of a BinSum: `sum 2^k x'_k + 2^32 sum 2^k y'_k === sum 2^k x_k +
+    2^32 sum 2^k y_k` (whole words in the low and the high half) and `sum 2^k z'_k - sum 2^k y'_k === sum 2^k z_k - sum 2^k y_k`
+    (a negative whole word): the word path of the R1CS check (one vector load + bit-matrix transpose per word) must
+    notice exactly the instances with the flipped bit, in both halves of the wave."""
+    x = c.input("x", 32); y = c.input("y", 32); z = c.input("z", 32)
+    xo = c.output("xo", 32); yo = c.output("yo", 32); zo = c.output("zo", 32)
+    m = c.signal("m")
+    c.set(m, x[0] * x[1])
+    for k in range(32):
+        c.hint(xo[k], x[k] + 0)
+        c.hint(zo[k], z[k] + 0)
+        c.hint(yo[k], y[k] + m - 2 * y[k] * m if k == flip else y[k] + 0)
+    w = lambda v, sh=0: sum((v[k] * (1 << (k + sh)) for k in range(1, 32)), v[0] * (1 << sh))
+    c.enforce(w(xo) + w(y if second_only else yo, 32), w(x) + w(y, 32), runtime_check=False)
+    c.enforce(w(zo) - w(yo), w(z) - w(y), runtime_check=False)
+
+
 def _rand_bits(fc, n, seed):
     r = random.Random(seed)
     return [[r.randrange(2) for _ in range(fc.n_main_inputs)] for _ in range(n)]
@@ -339,6 +359,32 @@ def test_gpu_bitplane_r1cs_long_rows(tmp_path, big):
         assert bool(st[i] & 4) == (want is not None), i
         if want is not None:
             assert fb[i] == want, (i, fb[i], want)
+            n_bad += 1
+    assert 0 < n_bad < B
+    b.close(); c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flip,second_only", [(0, False), (13, True), (31, False), (31, True)])
+def test_gpu_bitplane_r1cs_whole_words(tmp_path, flip, second_only):
+    cp, c = _gpu(tmp_path, Program(BadWords(flip, second_only)), "badwords%d" % flip)
+    fc = cp.flat
+    B = 200
+    rows = _rand_bits(fc, B, 40 + flip)
+    b = c.batch(B)
+    assert b.bitmode
+    b.set_inputs(rows)
+    b.run(); b.check_r1cs(); b.sync()
+    st, fb = b.status(), b.r1cs_first_bad()
+    n_bad = 0
+    for i in range(B):
+        w = b.witness(i)
+        assert w == _flat(fc, rows[i])[0]
+        want = check_r1cs(c.q, fc.constraints, w)
+        assert (want is not None) == bool(rows[i][0] & rows[i][1])
+        assert bool(st[i] & 4) == (want is not None), i
+        if want is not None:
+            assert fb[i] == want == (2 if second_only else 1), (i, fb[i], want)
             n_bad += 1
     assert 0 < n_bad < B
     b.close(); c.close()
