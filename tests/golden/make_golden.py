@@ -61,6 +61,10 @@ def cases():
     r2 = random.Random(77)
     out["semaphore20"] = (lambda: Program(SemaphoreStyle(20)), "bn128",
                           [H.semaphore_inputs(q, 20, r2)[0] for _ in range(2)])
+    # the same relation with the scalar multiplications' hints computed on a projective ladder (circuits/babyjub.py)
+    r4 = random.Random(78)
+    out["semaphore20p"] = (lambda: Program(SemaphoreStyle(20, True)), "bn128",
+                           [H.semaphore_inputs(q, 20, r4)[0] for _ in range(2)])
     return out
 
 
