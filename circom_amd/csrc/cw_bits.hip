@@ -411,7 +411,7 @@ cw_bits_r1cs_int_kernel(const uint4 *__restrict__ chunk, uint32_t n_chunks, cons
 #pragma unroll
                     for (int k = 0; k < 4; k++) sl[k] = wp[j + k];                 // the list is padded to 8 entries (zeros)
 #pragma unroll
-                    for (int k = 0; k < 4; k++) x[k] = bits_word_load(Tg, j + k < nb ? sl[k] : 0u, lane);
+                    for (int k = 0; k < 4; k++) x[k] = bits_word_load(Tg, j + k < nb ? sl[k] : sl[0], lane);   // padding: a valid word, unused
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const uint32_t y = j + k < nb ? bits_transpose32(x[k], lane) : 0u;
