@@ -11,9 +11,18 @@ rng = np.random.default_rng(1)
 if name.startswith("sha"):
     arr = np.zeros((B, c.n_inputs, 32), dtype=np.uint8); arr[:, :, 0] = rng.integers(0, 2, size=(B, c.n_inputs), dtype=np.uint8)
 else:
-    arr = rng.integers(0, 256, size=(B, c.n_inputs, 32), dtype=np.uint8); arr[:, :, 31] &= 0x0F
+    if name.startswith("semaphore"):
+        import random
+        from circom_amd.circuits import eddsa_host as H
+        r = random.Random(1)
+        pool = [H.semaphore_inputs(c.q, 20, r)[0] for _ in range(32)]
+        one = np.frombuffer(b"".join(v.to_bytes(32, "little") for row in pool for v in row), dtype=np.uint8).reshape(len(pool), c.n_inputs, 32)
+        arr = np.ascontiguousarray(np.tile(one, ((B + 31) // 32, 1, 1))[:B])
+    else:
+        arr = rng.integers(0, 256, size=(B, c.n_inputs, 32), dtype=np.uint8); arr[:, :, 31] &= 0x0F
 din = torch.from_numpy(arr).cuda()
-streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+nfl = int(os.environ.get("OV_N", "2"))
+streams = [torch.cuda.Stream() for _ in range(nfl)]
 batches = [c.batch(B, device=0, stream=s.cuda_stream) for s in streams]
 for b in batches:
     b.set_inputs_device(din.data_ptr()); b.run(); b.check_r1cs()
@@ -25,6 +34,6 @@ def run(n_batches):
         b.set_inputs_device(din.data_ptr()); b.run(); b.check_r1cs()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps * 1e3
-for n in (1, 2, 1, 2):
+for n in (1, nfl, 1, nfl):
     print("OV %s B=%d batches in flight %d: %.3f ms/step" % (name, B, n, run(n)))
-assert all((b.status() == 0).all() for b in batches) or not name.startswith("sha")
+assert all((b.status() == 0).all() for b in batches) or not (name.startswith("sha") or name.startswith("semaphore"))
