@@ -165,7 +165,9 @@ extern __shared__ uint64_t cw_bits_ring[];       // [R][64 lanes] x 8 B
 // whole batch (~1.5 K clocks) earlier, so the waits hipcc inserts (vmcnt counts loads and stores alike on gfx9 and
 // retires in order) find their operations long complete.  The three record sets and two loaded-value sets rotate
 // by NAME through six expansions of the batch body (no register moves).
-// Scheduler contract (bitsched.py): a LOAD lane of batch b reads a value stored by batch b - 2 or older.
+// Scheduler contract (bitsched.py): a LOAD lane of batch b reads a value stored by batch b - 2 or older; LOAD lanes only
+// sit in even vrows (the kernel issues no bit-table request for odd ones: the vector-memory path - ~23 TA cycles per
+// instruction whatever its width - is the busiest unit of this kernel, 79 % at 1 024 waves).
 #define BITS_NB 8
 
 template <int W>
@@ -184,14 +186,15 @@ struct BitsEval {
                                           const mask_t (&gcur)[BITS_NB], mask_t (&gfill)[BITS_NB]) {
 #pragma unroll
         for (int k = 0; k < BITS_NB; k++) fill[k] = recs[(size_t)(v0 + 2 * BITS_NB + k) * 64 + lane];
+        // LOAD lanes sit in even vrows only (bitsched.py LOAD_EVERY = 2): half the bit-table requests
 #pragma unroll
-        for (int k = 0; k < BITS_NB; k++) gfill[k] = BITS_EXP_LOAD(M::load(rsrc, nxt[k].z));
+        for (int k = 0; k < BITS_NB; k += 2) gfill[k] = BITS_EXP_LOAD(M::load(rsrc, nxt[k].z));
         mask_t res[BITS_NB];
 #pragma unroll
         for (int k = 0; k < BITS_NB; k++) {
             const uint4 rn = k + 1 < BITS_NB ? cur[k + 1 < BITS_NB ? k + 1 : 0] : nxt[0];
             const mask_t na = M::lds(ring + (rn.x & 0xFFFFu)), nb = M::lds(ring + (rn.x >> 16)), nc = M::lds(ring + (rn.y & 0xFFFFu));
-            const mask_t r = M::lut(a, b, c, cur[k].y) | gcur[k];
+            const mask_t r = (k & 1) ? M::lut(a, b, c, cur[k].y) : (M::lut(a, b, c, cur[k].y) | gcur[k]);
             if ((cur[k].y >> 24) & BITS_F_ASSERT) viol |= r;
             M::lds_st(ring + (((v0 + k) & ring_mask) << 9) + lane * 8, r);
             res[k] = r;
@@ -230,7 +233,7 @@ cw_bits_eval_kernel(const uint4 *__restrict__ recs, uint32_t n_batches, uint32_t
         R1[k] = recs[(size_t)(BITS_NB + k) * 64 + lane];
     }
 #pragma unroll
-    for (int k = 0; k < BITS_NB; k++) G0[k] = BITS_EXP_LOAD(M::load(E.rsrc, R0[k].z));
+    for (int k = 0; k < BITS_NB; k += 2) G0[k] = BITS_EXP_LOAD(M::load(E.rsrc, R0[k].z));
     E.a = M::lds(E.ring + (R0[0].x & 0xFFFFu));
     E.b = M::lds(E.ring + (R0[0].x >> 16));
     E.c = M::lds(E.ring + (R0[0].y & 0xFFFFu));

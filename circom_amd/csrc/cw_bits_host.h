@@ -40,6 +40,7 @@ inline const char *validate(const Program &p, uint32_t n_signals, uint32_t n_inp
         if ((a & 7) || (b & 7) || (c & 7) || a >= ring_bytes || b >= ring_bytes || c >= ring_bytes) return "bit program: ring operand out of range";
         if (r[1] >> 25) return "bit program: bad gate word";
         if (r[2] != NONE && ((r[2] & 7) || r[2] >= tab_bytes)) return "bit program: load slot out of range";
+        if (r[2] != NONE && ((i / 64) & 1)) return "bit program: LOAD lane in an odd vrow (the kernel loads for even vrows only)";
         if (r[3] != NONE && ((r[3] & 7) || r[3] >= tab_bytes || r[3] / 8 < IN_BASE + n_inputs)) return "bit program: destination out of range";
     }
     return nullptr;

@@ -38,7 +38,9 @@ IN_BASE = 3                   # slot of main input 0
 NONE = 0xFFFFFFFF
 F_ASSERT = 1
 DEFAULT_RING = 64
-LATENCY = 2                   # vrows between a producer and its first consumer
+LATENCY = 2
+LOAD_EVERY = 2                # LOAD lanes only sit in vrows t % LOAD_EVERY == 0: the kernel requests bit-table values for even
+                              # vrows only (cw_bits.hip); measured on Sha256(2048): 16 932 -> 15 931 vrows, 210 K -> 105 K loads
 BATCH = 8                     # vrows per batch of the kernel (memory traffic is issued per batch, cw_bits.hip)
 
 
@@ -143,9 +145,12 @@ def lower_bits(net: BitNet, fc, ring: int = DEFAULT_RING) -> BitTape:
             heapq.heappush(heap, item)
         lanes = []
         loading_now = set()
-        for x in carry_loads[:64]:      # loads carried over from a full vrow go first
-            place_load(x, lanes, loading_now)
-        carry_loads = carry_loads[64:]
+        load_row = t % LOAD_EVERY == 0          # LOAD lanes only sit in every LOAD_EVERY-th vrow (the kernel requests bit-table
+                                                # values for those vrows only: fewer, denser vector-memory instructions)
+        if load_row:
+            for x in carry_loads[:64]:  # loads waiting for a load vrow go first
+                place_load(x, lanes, loading_now)
+            carry_loads = carry_loads[64:]
         carry_set = set(carry_loads)
         produced = []
         while heap and len(lanes) < 64:
@@ -161,7 +166,7 @@ def lower_bits(net: BitNet, fc, ring: int = DEFAULT_RING) -> BitTape:
                         pass
                     elif is_gate[x] and t // BATCH - prod_slot[x] // BATCH < 2:
                         retry = max(retry, (prod_slot[x] // BATCH + 2) * BATCH)     # its store is not old enough yet
-                    elif len(lanes) < 63:
+                    elif load_row and len(lanes) < 63:
                         place_load(x, lanes, loading_now)
                     elif x not in carry_set:
                         carry_loads.append(x)
@@ -169,7 +174,8 @@ def lower_bits(net: BitNet, fc, ring: int = DEFAULT_RING) -> BitTape:
                         if is_gate[x] and not is_signal[x]:
                             need_home.add(x)
                     if x in carry_set:
-                        retry = max(retry, t + 1 + LATENCY + len(carry_loads) // 64)
+                        nxt_row = (t // LOAD_EVERY + 1) * LOAD_EVERY
+                        retry = max(retry, nxt_row + LATENCY + (len(carry_loads) // 64) * LOAD_EVERY)
                     retry = max(retry, t + LATENCY)
                 elif t - c < LATENCY:
                     ok = False
@@ -182,7 +188,7 @@ def lower_bits(net: BitNet, fc, ring: int = DEFAULT_RING) -> BitTape:
                     c = copy_slot.get(x)
                     if (c is not None and retry - c > ring - 1 and x not in loading_now and x not in carry_set
                             and t // BATCH - prod_slot.get(x, -1 << 30) // BATCH >= 2):
-                        if len(lanes) < 63:
+                        if load_row and len(lanes) < 63:
                             place_load(x, lanes, loading_now)
                         else:
                             carry_loads.append(x)

@@ -665,7 +665,8 @@ def eval_bits(recs, n_vrows: int, ring: int, n_slots: int, input_masks: dict, wi
       * the ring operands of vrow v+1 are read BEFORE vrow v writes its ring entry,
       * vector memory is touched per batch of 8 vrows: the LOAD lanes of batch b+1 read the bit table when batch b
         starts, the results of batch b are stored when it ends,
-      * a record's result = LUT(a, b, c) | loaded value (gate lanes load nothing, load lanes carry table 0).
+      * a record's result = LUT(a, b, c) | loaded value (gate lanes load nothing, load lanes carry table 0); LOAD lanes
+        may only sit in even vrows (the kernel issues no bit-table request for odd ones),
     Raises ScheduleHazard when a read cannot be satisfied by these rules (entry not written yet / already reused,
     slot never written).  Returns (bit table as list of masks, violation mask of the assertion gates)."""
     full = (1 << width) - 1
@@ -706,6 +707,8 @@ def eval_bits(recs, n_vrows: int, ring: int, n_slots: int, input_masks: dict, wi
             if g == B_NONE:
                 out.append(0)
                 continue
+            if v & 1:                 # the kernel requests bit-table values for even vrows only
+                raise ScheduleHazard("vrow %d lane %d: LOAD lane in an odd vrow" % (v, lane))
             if g % 8 or g // 8 >= n_slots:
                 raise ScheduleHazard("vrow %d lane %d: load slot out of range" % (v, lane))
             if T[g // 8] is None:
