@@ -102,6 +102,9 @@ def test_random_circuits_lower_race_free_and_equivalent(seed):
     rng = random.Random(1000 + seed)
     fc = flatten(Program(_random_template(seed, 40 + 26 * (seed % 11))))
     tapes = [lower(fc, n_strands=S) for S in (1, 4, 16)]
+    # the same circuits with signals in Montgomery form (integer operators get conversions) and as pipelined schedules
+    tapes += [lower(fc, n_strands=S, mont=True) for S in (1, 16)]
+    tapes += [lower(fc, pipe=(8, 8)), lower(fc, pipe=(4, 4), mont=True)]
     for trial in range(3):
         if trial == 0:
             row = [rng.randrange(Q) for _ in range(4)]
@@ -115,17 +118,19 @@ def test_random_circuits_lower_race_free_and_equivalent(seed):
         assert check_r1cs(Q, fc.constraints, sig) is None
         for t in tapes:
             got, st = eval_tape(t, inp)                          # raises ScheduleHazard on a race
-            assert st == 0 and got == sig, (seed, trial, t.stats["strands"])
+            assert st == 0 and got == sig, (seed, trial, t.stats["strands"], t.kind, t.mont)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mont", [False, True])
 @pytest.mark.parametrize("seed", [3, 7, 18, 29])
-def test_gpu_random_circuits_match_oracle(seed, tmp_path):
+def test_gpu_random_circuits_match_oracle(seed, mont, tmp_path):
     import numpy as np
     from circom_amd import runtime as rt
     from circom_amd.compiler import compile_program
     rng = random.Random(2000 + seed)
-    cp = compile_program(Program(_random_template(seed, 40 + 26 * (seed % 11))), str(tmp_path), "fuzz%d" % seed, sym=False)
+    cp = compile_program(Program(_random_template(seed, 40 + 26 * (seed % 11))), str(tmp_path), "fuzz%d" % seed, sym=False, mont=mont)
+    assert cp.tape.mont == mont
     fc = cp.flat
     B = 130
     rows = [[rng.randrange(Q) for _ in range(4)] for _ in range(B - 10)] + [[rng.randrange(4) for _ in range(4)] for _ in range(10)]
