@@ -72,6 +72,21 @@ def source_fingerprint() -> str:
     return h.hexdigest()[:16]
 
 
+def artefact_fingerprint() -> str:
+    """Hash of what shapes the compiled artefacts (.cwt/.dat/.r1cs): the Python front-end and lowering, the circuit
+    library and the tape format - NOT the kernels, so that a kernel change does not invalidate a cached schedule."""
+    h = hashlib.sha256()
+    files = sorted((ROOT / "circom_amd" / "hip_elements").glob("*.py")) + sorted((ROOT / "circom_amd" / "frontend").glob("*.py")) \
+        + sorted((ROOT / "circom_amd" / "circuits").glob("*.py")) + [ROOT / "circom_amd" / "csrc" / "cw_tape.h",
+                                                                    ROOT / "circom_amd" / "compiler.py", ROOT / "circom_amd" / "opcodes.py",
+                                                                    ROOT / "circom_amd" / "field.py"]
+    for f in files:
+        if f.is_file():
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 def get_compiled(name: str, batch: int, cache_root: str, rank: int, dist):
     """Rank 0 traces + lowers the circuit once (or finds the artefacts of this exact source in the cache); the other
     ranks wait and load the files.  Every rank traces + flattens (seconds) to have the flat code for the oracle."""
@@ -79,7 +94,7 @@ def get_compiled(name: str, batch: int, cache_root: str, rank: int, dist):
     from circom_amd.frontend.flatten import flatten
     from circom_amd.hip_elements import writers
     from circom_amd.hip_elements.lower import lower
-    fp = source_fingerprint()
+    fp = artefact_fingerprint()
     strands = compiler.strands_for(batch)
     d = os.path.join(cache_root, "%s_s%s_b%s_m%s_%s" % (name, "-".join(map(str, strands)), os.environ.get("CW_BITS", "1"),
                                                        os.environ.get("CW_MONT", "a"), fp))
@@ -87,7 +102,8 @@ def get_compiled(name: str, batch: int, cache_root: str, rank: int, dist):
     t0 = time.perf_counter()
     fc = flatten(make_program(name))
     done = os.path.join(d, "done")
-    if rank == 0 and not os.path.exists(done):
+    cached = os.path.exists(done)
+    if rank == 0 and not cached:
         os.makedirs(d, exist_ok=True)
         bittape = None if os.environ.get("CW_BITS", "1") == "0" else compiler.lower_bitplane(fc)
         mont = compiler.choose_mont(fc)     # arithmetic circuits keep their signals in Montgomery form on the device
@@ -104,7 +120,7 @@ def get_compiled(name: str, batch: int, cache_root: str, rank: int, dist):
     if dist:
         dist.barrier()
     cp = compiler.Compiled(name, d, p(".cwt"), p(".dat"), p(".r1cs"), p(".sym"), fc, None)
-    return cp, time.perf_counter() - t0
+    return cp, time.perf_counter() - t0, cached
 
 
 def synth_inputs(name: str, q: int, batch: int, n_inputs: int, seed: int):
@@ -198,6 +214,56 @@ def cpu_baseline(cp, name, seconds_budget=15.0):
         return {"value": None, "unit": "witnesses/s", "cores": 0, "kind": "reference", "sample": "failed: %s" % e}
 
 
+def host_only_rehearsal(args, world, rank):
+    """The N-rank launch without GPUs (gloo): rank 0 compiles once, every rank loads the artefacts, stages the inputs of
+    ITS shard in a host-only batch through the C ABI (validated, nothing computes), and the one exchange of the job -
+    the gather of per-instance words and public-signal rows on rank 0 - runs over gloo.  Prints the JSON line with
+    `value: null`."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from circom_amd import runtime as rt
+    from circom_amd.sharding import shard_range, gather_status, gather_rows
+    if world > 1:
+        dist.init_process_group("gloo")
+    else:
+        dist = None
+    B = args.batch or 64
+    scaling = "weak"
+    if args.total_batch:
+        scaling = "strong"
+        lo, hi = shard_range(args.total_batch, rank, world)
+        B = hi - lo
+    cache_root = args.cache_dir or os.path.join(tempfile.gettempdir(), "cw_bench_cache_%d" % os.getuid())
+    cp, compile_s, cached = get_compiled(args.workload, B, cache_root, rank, dist)
+    circ = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
+    batch = circ.batch(B, device=-1)
+    h_in = synth_inputs(args.workload, circ.q, B, circ.n_inputs, seed=1 + rank)
+    batch.set_inputs(h_in)
+    assert all(batch.remaining_inputs(k) == 0 for k in (0, B - 1))
+    try:
+        batch.run()
+        raise AssertionError("a host-only batch must not compute")
+    except rt.CwError:
+        pass
+    # stand-ins for the status words / public signals of this shard: derived from the staged inputs
+    words = torch.tensor([batch.staged_input(k, 0) % (1 << 20) for k in range(B)], dtype=torch.int32)
+    got = gather_status(words, dist, rank, world)
+    rows = gather_rows(torch.from_numpy(np.ascontiguousarray(h_in[:, :1, :])), dist, rank, world)
+    if rank == 0:
+        print(json.dumps({"metric": "witnesses/sec (batched inputs)", "value": None, "unit": "witnesses/s", "n_gpus": world,
+                          "steps": 0, "warmup": 0, "ms_per_step": None, "higher_is_better": True, "scaling": scaling,
+                          "vs_baseline": None, "dtype": "none (host-only rehearsal)", "data": "synthetic", "host_only": True,
+                          "config": {"workload": "%s, batch=%d per rank (host-only rehearsal of the launch path)" % (args.workload, B),
+                                     "compile_s": compile_s, "compile_cached": cached},
+                          "gathered": {"status_words": int(got.numel()), "public_signal_rows": int(rows.shape[0])}}))
+    batch.close()
+    circ.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,6 +272,12 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("CW_WORKLOAD", "sha256_2048"))
     ap.add_argument("--batch", type=int, default=int(os.environ.get("CW_BATCH", "0")), help="instances per GPU")
     ap.add_argument("--total-batch", type=int, default=0, help="instances of the whole job (strong scaling)")
+    ap.add_argument("--shard-of", type=int, default=0,
+                    help="with --total-batch on ONE GPU: run the shard rank 0 of a job of this many GPUs would own "
+                         "(BASELINE config 4 = --workload semaphore20p --total-batch 8192 --shard-of 8 -> 1024 instances)")
+    ap.add_argument("--host-only", action="store_true",
+                    help="CPU rehearsal of the N-rank launch (gloo, host-only batches: inputs are staged and validated through "
+                         "the C ABI, nothing computes - there is no CPU fallback); used by tests/test_bench_spawn.py")
     ap.add_argument("--cache-dir", default=os.environ.get("CW_CACHE", ""))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -216,6 +288,19 @@ def main():
                          "check of one step overlaps the evaluation of the next); 1 = strictly sequential steps")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` started by hand (no launcher environment): start the N ranks ourselves, exactly the way
+    # the driver does (one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1), and pass their output on
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     import numpy as np
     import torch
     from circom_amd import runtime as rt
@@ -223,6 +308,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and not os.environ.get("CW_FORCE_DIST"):
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); refusing to report a line whose "
+                         "n_gpus would not be what was asked for" % (args.gpus, world))
+    if args.host_only:
+        return host_only_rehearsal(args, world, rank)
     dist = None
     if world > 1 or os.environ.get("CW_FORCE_DIST"):      # CW_FORCE_DIST: exercise the RCCL path on a single GPU
         import torch.distributed as dist
@@ -235,11 +325,15 @@ def main():
     if args.total_batch:
         scaling = "strong"
         from circom_amd.sharding import shard_range
-        lo, hi = shard_range(args.total_batch, rank, world)
+        if args.shard_of:
+            assert world == 1, "--shard-of describes a single-GPU run of one shard of a larger job"
+            lo, hi = shard_range(args.total_batch, 0, args.shard_of)
+        else:
+            lo, hi = shard_range(args.total_batch, rank, world)
         B = hi - lo
     cache_root = args.cache_dir or (str(ROOT / "gpurun_in" / "cache") if (ROOT / "gpurun_in" / "cache").is_dir()
                                     else os.path.join(tempfile.gettempdir(), "cw_bench_cache_%d" % os.getuid()))
-    cp, compile_s = get_compiled(args.workload, B, cache_root, rank, dist)
+    cp, compile_s, compile_cached = get_compiled(args.workload, B, cache_root, rank, dist)
     circ = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
     if args.workload == "sha256_2048":
         assert circ.n_constraints >= 1_000_000, "the metric's workload must have >= 1M constraints"
@@ -452,7 +546,7 @@ def main():
                        ("256-bit schedule, signals in Montgomery form" if circ.montgomery else "256-bit schedule"),
                        "bit_program": bits, "schedule_rows": circ.n_rows, "fp_mul_per_witness": circ.n_mmul,
                        "parallelism": "instances sharded x%d, status + public-signal gather only" % world,
-                       "in_flight": n_fl, "compile_s": compile_s},
+                       "in_flight": n_fl, "compile_s": compile_s, "compile_cached": compile_cached},
             # the dominant kernel of THIS run (longest measured duration)
             "roofline": roof_eval if gen_ms >= chk_ms else roof_r1cs,
             "roofline_eval": roof_eval,

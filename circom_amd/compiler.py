@@ -68,7 +68,8 @@ def lower_bitplane(fc: FlatCircuit, bits="auto"):
     net = bitblast(fc)
     if net is None:
         return None
-    return lower_bits(net, fc)
+    from .hip_elements.bitmap import map_network
+    return lower_bits(map_network(net), fc)
 
 
 # The pipelined single-wave variant (hip_elements/pipe.py) is opt-in: measured on MI355X it matches the plain single-strand

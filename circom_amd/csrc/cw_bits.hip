@@ -10,8 +10,8 @@
 // and the witness program is a sequence of VROWS (hip_elements/bitsched.py): one wave = one group of 64 instances,
 // in a vrow every LANE evaluates one 3-input gate of the network on 64-bit masks (64 gates x 64 instances per ~60
 // VALU instructions).  Results go to the wave's LDS ring (entry vrow mod R) and to up to four bit-table slots;
-// operands come from the previous vrow (ds_bpermute), the ring, or the bit table.  No barriers: a single wave,
-// in-order LDS and in-order vector memory.
+// operands and results are entries of the wave's LDS (result ring + cached rows of the bit table); vector memory moves
+// whole rows at batch boundaries.  No barriers: a single wave, in-order LDS and in-order vector memory.
 //
 // The assumption "main inputs are 0/1" is checked by the ingest kernel; instances that violate it, or trip an
 // assertion gate, are flagged in fbmask[group] and re-evaluated by the 256-bit schedule (cw_host.cpp), so every
@@ -65,25 +65,54 @@ __global__ void __launch_bounds__(64) cw_bits_ingest_kernel(const uint4 *__restr
 }
 
 // ---- the gate program ------------------------------------------------------------------------------------------------------
-// Record (hip_elements/bitsched.py), 4 words per lane:
-//   w0 = a_off | b_off << 16      LDS byte offsets of ring entries (8-byte entries, < R * 512)
-//   w1 = c_off | tt << 16 | flags << 24
-//   w2 = g_off                    LOAD lanes: byte offset of a bit-table slot; gate lanes: NONE
-//   w3 = d_off                    byte offset of the slot this value is stored to, NONE = 0xFFFFFFFF
-// Signals that are copies of one another share a slot (sig_slot[] maps signal -> slot), so a value is stored once.
-// result = LUT(a, b, c) | loaded value: gate lanes load nothing (NONE is out of the buffer's range: the hardware
-// returns 0), load lanes carry table 0.  The destination goes through the same buffer descriptor, so a NONE store is
-// dropped: no branches, and hipcc counts every memory operation exactly (its waits for later loads then do not
-// drain the stores — vmcnt counts loads and stores alike on gfx9).
-// W = instances per wave: 64 (one wave per group), or 32 / 16 (2 / 4 independent waves per group, each on its slice
-// of every mask: small batches then spread over more CUs and the lookups run on 32-bit halves).
-#define BITS_NONE 0xFFFFFFFFu
-#define BITS_F_ASSERT 1u
+// Program model: hip_elements/bitsched.py (round 3).  The wave's LDS holds a RING of R result rows, a CACHE of C rows of
+// the group's bit table and the constants 0 / ~0; every operand and every result of a lane is ONE LDS
+// entry named in its 8-byte record:
+//   w0 = a_off | K1 | K2 << 1 | b_off << 16        LDS byte offsets (multiples of 8); K1: stage 1 is AND (else XOR),
+//   w1 = c_off | dst_off << 16                                                         K2: stage 2 is OR (else XOR)
+//   result = K2 ? (u | c) : (u ^ c),  u = K1 ? (a & b) : (a ^ b)          two v_bitop3_b32 per 32 instances
+// (bitmap.py maps every 3-input gate of the network onto this primitive; round 2 evaluated a lane-specific 8-bit truth
+// table with 8 v_bfe + 14 v_bfi per vrow).  Vector memory moves whole 512-byte ROWS only, at batch boundaries, named in a
+// per-batch command block that the wave reads through the scalar cache: row LOADS (bit table -> cache slot: main
+// inputs, values that left the cache) and row FLUSHES (cache slot -> bit table: every row exactly once, when complete).
+// Round 2's per-lane scattered stores and loads cost 23..48 clocks of the CU's memory pipeline per instruction with
+// four waves per CU (tools/ubench_isa) - 2.5 of them per vrow: that was the bound of the kernel.
+// W = instances per wave: 64 (one wave per group), or 32 / 16 (2 / 4 independent waves per group, each on its slice of
+// every mask: small batches then spread over more CUs).
+#define BITS_NB 8
+#define BITS_MAX_LOADS 4
+#define BITS_MAX_FLUSH 6
+#define BITS_CMD_WORDS 24
+#define BITS_AHEAD 4          // records are requested this many batches ahead (BITS_AHEAD + 1 register sets of 16 dwords): two
+                              // batches (~0.7 us) proved shorter than the latency of the stream, +25 ns per vrow of waiting
+#define BITS_OOR 0xFFFFFFF0u
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// v_bitop3_b32 table of a function of (s0, s1, s2): bit (s0 << 2 | s1 << 1 | s2)
+constexpr uint32_t bitop3_stage1() {           // (a, b, K) -> K ? a & b : a ^ b
+    uint32_t t = 0;
+    for (int i = 0; i < 8; i++) {
+        const int a = (i >> 2) & 1, b = (i >> 1) & 1, k = i & 1;
+        t |= (uint32_t)(k ? (a & b) : (a ^ b)) << i;
+    }
+    return t;
+}
+constexpr uint32_t bitop3_stage2() {           // (u, c, K) -> K ? u | c : u ^ c
+    uint32_t t = 0;
+    for (int i = 0; i < 8; i++) {
+        const int u = (i >> 2) & 1, c = (i >> 1) & 1, k = i & 1;
+        t |= (uint32_t)(k ? (u | c) : (u ^ c)) << i;
+    }
+    return t;
+}
+static_assert(bitop3_stage1() == 0x94u && bitop3_stage2() == 0xBCu, "v_bitop3_b32 tables of the two primitive stages");
+__device__ __forceinline__ uint32_t prim32(uint32_t a, uint32_t b, uint32_t c, uint32_t k1, uint32_t k2) {
+    const uint32_t u = __builtin_amdgcn_bitop3_b32(a, b, k1, 0x94);
+    return __builtin_amdgcn_bitop3_b32(u, c, k2, 0xBC);
+}
+// 3-input lookup on 64 instances with a wave-uniform or per-lane table (R1CS LUT class): index bit 0 = a, 1 = b, 2 = c
 __device__ __forceinline__ uint32_t bfi32(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }   // v_bfi_b32
-// 3-input lookup on 32 instances: index bit 0 = a, bit 1 = b, bit 2 = c; t[m] = 0 or ~0
 __device__ __forceinline__ uint32_t lut3_32(uint32_t a, uint32_t b, uint32_t c, const uint32_t t[8]) {
     const uint32_t x0 = bfi32(a, t[1], t[0]), x1 = bfi32(a, t[3], t[2]), x2 = bfi32(a, t[5], t[4]), x3 = bfi32(a, t[7], t[6]);
     const uint32_t y0 = bfi32(b, x1, x0), y1 = bfi32(b, x3, x2);
@@ -101,8 +130,8 @@ __device__ __forceinline__ uint64_t lut3(uint64_t a, uint64_t b, uint64_t c, uin
 template <int W> struct BitsMask;
 template <> struct BitsMask<64> {
     typedef uint64_t T;
-    static __device__ __forceinline__ T lds(const char *p) { return *(const uint64_t *)p; }
-    static __device__ __forceinline__ void lds_st(char *p, T v) { *(uint64_t *)p = v; }
+    static __device__ __forceinline__ T lds(uint32_t off) { return *(const __attribute__((address_space(3))) uint64_t *)(uintptr_t)off; }
+    static __device__ __forceinline__ void lds_st(uint32_t off, T v) { *(__attribute__((address_space(3))) uint64_t *)(uintptr_t)off = v; }
     static __device__ __forceinline__ T load(__amdgpu_buffer_rsrc_t r, uint32_t off) {
         const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
         return ((uint64_t)v.y << 32) | v.x;
@@ -111,104 +140,125 @@ template <> struct BitsMask<64> {
         const u32x2 x = {(uint32_t)v, (uint32_t)(v >> 32)};
         __builtin_amdgcn_raw_buffer_store_b64(x, r, (int)off, 0, 0);
     }
-    static __device__ __forceinline__ T lut(T a, T b, T c, uint32_t w1) { return lut3(a, b, c, w1 >> 16); }
+    static __device__ __forceinline__ T prim(T a, T b, T c, uint32_t k1, uint32_t k2) {
+        // one block: the compiler then waits ONCE for the three LDS operands instead of once per stage (a wave alone on
+        // its SIMD issues one instruction of any kind per ~4 clocks: s_waitcnt instructions count)
+        uint32_t lo, hi;
+        asm("v_bitop3_b32 %0, %2, %4, %8 bitop3:0x94\n\t"
+            "v_bitop3_b32 %1, %3, %5, %8 bitop3:0x94\n\t"
+            "v_bitop3_b32 %0, %0, %6, %9 bitop3:0xbc\n\t"
+            "v_bitop3_b32 %1, %1, %7, %9 bitop3:0xbc"
+            : "=&v"(lo), "=&v"(hi)
+            : "v"((uint32_t)a), "v"((uint32_t)(a >> 32)), "v"((uint32_t)b), "v"((uint32_t)(b >> 32)), "v"((uint32_t)c),
+              "v"((uint32_t)(c >> 32)), "v"(k1), "v"(k2));
+        return ((uint64_t)hi << 32) | lo;
+    }
 };
 template <> struct BitsMask<32> {
     typedef uint32_t T;
-    static __device__ __forceinline__ T lds(const char *p) { return *(const uint32_t *)p; }
-    static __device__ __forceinline__ void lds_st(char *p, T v) { *(uint32_t *)p = v; }
+    static __device__ __forceinline__ T lds(uint32_t off) { return *(const __attribute__((address_space(3))) uint32_t *)(uintptr_t)off; }
+    static __device__ __forceinline__ void lds_st(uint32_t off, T v) { *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)off = v; }
     static __device__ __forceinline__ T load(__amdgpu_buffer_rsrc_t r, uint32_t off) {
         return __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0);
     }
     static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, uint32_t off, T v) {
         __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)off, 0, 0);
     }
-    static __device__ __forceinline__ T lut(T a, T b, T c, uint32_t w1) {
-        uint32_t t[8];
-#pragma unroll
-        for (int m = 0; m < 8; m++) t[m] = (uint32_t)((int32_t)(w1 << (15 - m)) >> 31);
-        return lut3_32(a, b, c, t);
-    }
+    static __device__ __forceinline__ T prim(T a, T b, T c, uint32_t k1, uint32_t k2) { return prim32(a, b, c, k1, k2); }
 };
 template <> struct BitsMask<16> {
     typedef uint32_t T;
-    static __device__ __forceinline__ T lds(const char *p) { return *(const uint32_t *)p; }
-    static __device__ __forceinline__ void lds_st(char *p, T v) { *(uint32_t *)p = v; }
+    static __device__ __forceinline__ T lds(uint32_t off) { return *(const __attribute__((address_space(3))) uint32_t *)(uintptr_t)off; }
+    static __device__ __forceinline__ void lds_st(uint32_t off, T v) { *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)off = v; }
     static __device__ __forceinline__ T load(__amdgpu_buffer_rsrc_t r, uint32_t off) {
         return (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(r, (int)off, 0, 0);
     }
     static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, uint32_t off, T v) {
         __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, r, (int)off, 0, 0);
     }
-    static __device__ __forceinline__ T lut(T a, T b, T c, uint32_t w1) { return BitsMask<32>::lut(a, b, c, w1); }
+    static __device__ __forceinline__ T prim(T a, T b, T c, uint32_t k1, uint32_t k2) { return prim32(a, b, c, k1, k2); }
 };
 
-extern __shared__ uint64_t cw_bits_ring[];       // [R][64 lanes] x 8 B
+extern __shared__ uint64_t cw_bits_lds[];        // ring rows | cache rows | constants 0, ~0
 
-// timing experiments only (tools/bits_exp.sh; results are garbage): drop the stores / the bit-table loads
-#ifdef CW_EXP_NOSTORE
-#define BITS_EXP_STORE(x)
-#else
-#define BITS_EXP_STORE(x) x
-#endif
-#ifdef CW_EXP_NOLOAD
-#define BITS_EXP_LOAD(x) 0
-#else
-#define BITS_EXP_LOAD(x) x
-#endif
-
-// The program runs in BATCHES of BITS_NB vrows so that vector-memory traffic never sits on the critical path:
-// at the start of batch b the wave requests, in one burst, the records of batch b + 2 and the bit-table values of the
-// LOAD lanes of batch b + 1 (their addresses are in the records of batch b + 1, resident since the previous burst);
-// then the BITS_NB steps run on registers and LDS only (ring operands of step k + 1 are read while step k computes);
-// at the end of the batch its BITS_NB results are stored in one burst.  Everything a batch consumes was requested a
-// whole batch (~1.5 K clocks) earlier, so the waits hipcc inserts (vmcnt counts loads and stores alike on gfx9 and
-// retires in order) find their operations long complete.  The three record sets and two loaded-value sets rotate
-// by NAME through six expansions of the batch body (no register moves).
-// Scheduler contract (bitsched.py): a LOAD lane of batch b reads a value stored by batch b - 2 or older; LOAD lanes only
-// sit in even vrows (the kernel issues no bit-table request for odd ones: the vector-memory path - ~23 TA cycles per
-// instruction whatever its width - is the busiest unit of this kernel, 79 % at 1 024 waves).
-#define BITS_NB 8
-
+// One batch = BITS_NB vrows.  When batch b starts the wave requests the records of batch b + BITS_AHEAD (device stream: 4 x 16
+// bytes per lane and batch) and the row loads of its command block; the BITS_NB steps then run on registers and LDS
+// only (the operands of step k + 1 are read while step k computes: a consumer sits two vrows behind its producer); the
+// rows requested by batch b - 1 are written to their cache slots before the last step reads the operands of the next
+// batch's first vrow; the flushes of the command block copy cache slots to the bit table when the batch ends.
 template <int W>
 struct BitsEval {
     typedef BitsMask<W> M;
     typedef typename M::T mask_t;
     const uint4 *__restrict__ recs;
-    char *ring;
+    const uint32_t *__restrict__ cmds;
     __amdgpu_buffer_rsrc_t rsrc;
-    uint32_t lane, ring_mask;
-    mask_t a, b, c, viol;
+    uint32_t lane8;
+    mask_t a, b, c;
+    uint32_t pn, poff[BITS_MAX_LOADS];           // row loads of the previous batch still to be written to the LDS (wave-uniform)
 
-    // cur: records of this batch, nxt: of the next one, fill: receives batch + 2; gcur: loaded values of this batch,
-    // gfill: receives those of the next one
-    __device__ __forceinline__ void batch(uint32_t v0, const uint4 (&cur)[BITS_NB], const uint4 (&nxt)[BITS_NB], uint4 (&fill)[BITS_NB],
-                                          const mask_t (&gcur)[BITS_NB], mask_t (&gfill)[BITS_NB]) {
+    static __device__ __forceinline__ uint32_t word(const uint4 (&r)[4], int k, int i) {
+        const int d = 2 * k + i;
+        const uint4 &q = r[d >> 2];
+        return (d & 3) == 0 ? q.x : (d & 3) == 1 ? q.y : (d & 3) == 2 ? q.z : q.w;
+    }
+
+    // ccur: command block of this batch (requested a batch ago, resident in SGPRs), cfill: receives the next one
+    __device__ __forceinline__ void batch(uint32_t bi, const uint4 (&cur)[4], const uint4 (&nxt)[4], uint4 (&fill)[4],
+                                          const mask_t (&lprev)[BITS_MAX_LOADS], mask_t (&lfill)[BITS_MAX_LOADS],
+                                          const uint32_t (&ccur)[BITS_CMD_WORDS], uint32_t (&cfill)[BITS_CMD_WORDS]) {
+        const uint32_t nl = ccur[0] & 0xFFu, nf = (ccur[0] >> 8) & 0xFFu;
+        // row loads first: when they are awaited (a batch later) at least the eight unconditional record loads issued
+        // behind them stand between, so the compiler's vmcnt never waits for a request younger than a batch
+        if (nl) {                                   // rare (a few row loads per hundred batches): one branch in the common case
 #pragma unroll
-        for (int k = 0; k < BITS_NB; k++) fill[k] = recs[(size_t)(v0 + 2 * BITS_NB + k) * 64 + lane];
-        // LOAD lanes sit in even vrows only (bitsched.py LOAD_EVERY = 2): half the bit-table requests
+            for (int j = 0; j < BITS_MAX_LOADS; j++)
+                if (j < (int)nl) lfill[j] = M::load(rsrc, ccur[2 + 2 * j] + lane8);
+        }
+#ifdef CW_EXP_NORECS      /* timing experiment only (tools/bits_exp.sh): no record fetch, every batch replays the first */
 #pragma unroll
-        for (int k = 0; k < BITS_NB; k += 2) gfill[k] = BITS_EXP_LOAD(M::load(rsrc, nxt[k].z));
-        mask_t res[BITS_NB];
+        for (int j = 0; j < 4; j++) fill[j] = cur[j];
+#else
+#pragma unroll
+        for (int j = 0; j < 4; j++) fill[j] = recs[((size_t)(bi + BITS_AHEAD) * 4 + j) * 64 + (lane8 >> 3)];
+#endif
+        const uint32_t *ncmd = cmds + (size_t)(bi + 1) * BITS_CMD_WORDS;
+#pragma unroll
+        for (int j = 0; j < BITS_CMD_WORDS; j++) cfill[j] = ncmd[j];
 #pragma unroll
         for (int k = 0; k < BITS_NB; k++) {
-            const uint4 rn = k + 1 < BITS_NB ? cur[k + 1 < BITS_NB ? k + 1 : 0] : nxt[0];
-            const mask_t na = M::lds(ring + (rn.x & 0xFFFFu)), nb = M::lds(ring + (rn.x >> 16)), nc = M::lds(ring + (rn.y & 0xFFFFu));
-            const mask_t r = (k & 1) ? M::lut(a, b, c, cur[k].y) : (M::lut(a, b, c, cur[k].y) | gcur[k]);
-            if ((cur[k].y >> 24) & BITS_F_ASSERT) viol |= r;
-            M::lds_st(ring + (((v0 + k) & ring_mask) << 9) + lane * 8, r);
-            res[k] = r;
+            if (k == BITS_NB - 1 && pn) {
+#pragma unroll
+                for (int j = 0; j < BITS_MAX_LOADS; j++)
+                    if (j < (int)pn) M::lds_st(poff[j] + lane8, lprev[j]);
+            }
+            const uint32_t n0 = k + 1 < BITS_NB ? word(cur, k + 1 < BITS_NB ? k + 1 : 0, 0) : word(nxt, 0, 0);
+            const uint32_t n1 = k + 1 < BITS_NB ? word(cur, k + 1 < BITS_NB ? k + 1 : 0, 1) : word(nxt, 0, 1);
+            const mask_t na = M::lds(n0 & 0xFFF8u), nb = M::lds(n0 >> 16), nc = M::lds(n1 & 0xFFFFu);
+            const uint32_t w0 = word(cur, k, 0), w1 = word(cur, k, 1);
+            const uint32_t k1 = (uint32_t)((int32_t)(w0 << 31) >> 31), k2 = (uint32_t)((int32_t)(w0 << 30) >> 31);
+            M::lds_st(w1 >> 16, M::prim(a, b, c, k1, k2));
             a = na; b = nb; c = nc;
         }
+        if (nf) {
+            mask_t fv[BITS_MAX_FLUSH];
 #pragma unroll
-        for (int k = 0; k < BITS_NB; k++) BITS_EXP_STORE(M::store(rsrc, cur[k].w, res[k]));
+            for (int j = 0; j < BITS_MAX_FLUSH; j++)       // unconditional reads (slots beyond the count read ring row 0)
+                fv[j] = M::lds((j < (int)nf ? ccur[3 + 2 * BITS_MAX_LOADS + 2 * j] : 0u) + lane8);
+#pragma unroll
+            for (int j = 0; j < BITS_MAX_FLUSH; j++)
+                if (j < (int)nf) M::store(rsrc, ccur[2 + 2 * BITS_MAX_LOADS + 2 * j] + lane8, fv[j]);
+        }
+        pn = nl;
+#pragma unroll
+        for (int j = 0; j < BITS_MAX_LOADS; j++) poff[j] = ccur[3 + 2 * j];
     }
 };
 
 template <int W>
 __global__ void __launch_bounds__(64)
-cw_bits_eval_kernel(const uint4 *__restrict__ recs, uint32_t n_batches, uint32_t ring_mask, uint64_t *T, uint64_t slots,
-                    uint64_t *fbmask) {
+cw_bits_eval_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict__ cmds, uint32_t n_batches, uint32_t const_off,
+                    uint64_t *T, uint64_t slots) {
     typedef BitsMask<W> M;
     typedef typename M::T mask_t;
     const uint32_t lane = threadIdx.x, g = blockIdx.x, slice = blockIdx.y;
@@ -216,62 +266,133 @@ cw_bits_eval_kernel(const uint4 *__restrict__ recs, uint32_t n_batches, uint32_t
     if (n_batches == 0) return;
     BitsEval<W> E;
     E.recs = recs;
-    E.ring = (char *)cw_bits_ring;
+    E.cmds = cmds;
+    // the dynamic LDS of this kernel starts at LDS address 0 (it declares no static LDS): records carry raw LDS offsets
     // buffer descriptor of this group's table (wave-uniform by construction: kernel arguments and blockIdx only);
     // a wave of a narrower slice addresses its bytes of every 8-byte mask through the shifted base
     E.rsrc = __builtin_amdgcn_make_buffer_rsrc(Tg, 0, (int)(uint32_t)(slots * 8 - slice * (W / 8)), 0x00020000);
-    E.lane = lane;
-    E.ring_mask = ring_mask;
-    E.viol = 0;
-    // the host pads the program to whole batches and appends three empty ones (records are requested two batches ahead,
-    // the loop runs in trips of six batches)
-    uint4 R0[BITS_NB], R1[BITS_NB], R2[BITS_NB];
-    mask_t G0[BITS_NB], G1[BITS_NB];
+    E.lane8 = lane * 8;
+    E.pn = 0;
 #pragma unroll
-    for (int k = 0; k < BITS_NB; k++) {
-        R0[k] = recs[(size_t)k * 64 + lane];
-        R1[k] = recs[(size_t)(BITS_NB + k) * 64 + lane];
+    for (int j = 0; j < BITS_MAX_LOADS; j++) E.poff[j] = 0;
+    if (lane == 0) {
+        M::lds_st(const_off, (mask_t)0);
+        M::lds_st(const_off + 8, (mask_t)~(mask_t)0);
     }
+    // every lane's ring entries start as 0 (idle lanes of the first vrows read constants only; a defined value keeps
+    // the kernel deterministic when a damaged program names an entry that was never written)
+    for (uint32_t o = E.lane8; o < const_off; o += 512) M::lds_st(o, (mask_t)0);
+    // the host pads the stream to whole trips of ten batches and appends BITS_AHEAD empty ones (records are requested
+    // BITS_AHEAD batches ahead); five record sets, two loaded-row sets and two command-block sets rotate by NAME through
+    // the ten expansions of the batch body
+    uint4 R0[4], R1[4], R2[4], R3[4], R4[4];
+    mask_t L0[BITS_MAX_LOADS], L1[BITS_MAX_LOADS];
 #pragma unroll
-    for (int k = 0; k < BITS_NB; k += 2) G0[k] = BITS_EXP_LOAD(M::load(E.rsrc, R0[k].z));
-    E.a = M::lds(E.ring + (R0[0].x & 0xFFFFu));
-    E.b = M::lds(E.ring + (R0[0].x >> 16));
-    E.c = M::lds(E.ring + (R0[0].y & 0xFFFFu));
-    uint32_t v = 0;
-    const uint32_t n_steps = n_batches * BITS_NB;
-    while (v < n_steps) {
-        E.batch(v, R0, R1, R2, G0, G1); v += BITS_NB;
-        E.batch(v, R1, R2, R0, G1, G0); v += BITS_NB;
-        E.batch(v, R2, R0, R1, G0, G1); v += BITS_NB;
-        E.batch(v, R0, R1, R2, G1, G0); v += BITS_NB;
-        E.batch(v, R1, R2, R0, G0, G1); v += BITS_NB;
-        E.batch(v, R2, R0, R1, G1, G0); v += BITS_NB;
-    }
-    const mask_t viol = E.viol;
-    // instances that tripped an assertion gate: OR over the lanes (gates), then into the group's fallback mask
-    uint64_t vz = (uint64_t)viol;
+    for (int j = 0; j < BITS_MAX_LOADS; j++) L0[j] = L1[j] = 0;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)vz, off), hi = (uint32_t)__shfl_xor((int)(uint32_t)(vz >> 32), off);
-        vz |= ((uint64_t)hi << 32) | lo;
+    for (int j = 0; j < 4; j++) {
+        R0[j] = recs[(size_t)j * 64 + lane];
+        R1[j] = recs[((size_t)4 + j) * 64 + lane];
+        R2[j] = recs[((size_t)8 + j) * 64 + lane];
+        R3[j] = recs[((size_t)12 + j) * 64 + lane];
     }
-    if (W < 64) vz = (vz & ((1ull << (W & 63)) - 1)) << (slice * W);
-    if (lane == 0 && vz) atomicOr((unsigned long long *)&fbmask[g], (unsigned long long)vz);
+    uint32_t C0[BITS_CMD_WORDS], C1[BITS_CMD_WORDS];
+#pragma unroll
+    for (int j = 0; j < BITS_CMD_WORDS; j++) { C0[j] = cmds[j]; C1[j] = 0; }
+    E.a = M::lds(R0[0].x & 0xFFF8u);
+    E.b = M::lds(R0[0].x >> 16);
+    E.c = M::lds(R0[0].y & 0xFFFFu);
+    static_assert(BITS_AHEAD == 4, "the rotation below is written for five record sets");
+    for (uint32_t bi = 0; bi < n_batches; bi += 10) {
+        E.batch(bi + 0, R0, R1, R4, L0, L1, C0, C1);
+        E.batch(bi + 1, R1, R2, R0, L1, L0, C1, C0);
+        E.batch(bi + 2, R2, R3, R1, L0, L1, C0, C1);
+        E.batch(bi + 3, R3, R4, R2, L1, L0, C1, C0);
+        E.batch(bi + 4, R4, R0, R3, L0, L1, C0, C1);
+        E.batch(bi + 5, R0, R1, R4, L1, L0, C1, C0);
+        E.batch(bi + 6, R1, R2, R0, L0, L1, C0, C1);
+        E.batch(bi + 7, R2, R3, R1, L1, L0, C1, C0);
+        E.batch(bi + 8, R3, R4, R2, L0, L1, C0, C1);
+        E.batch(bi + 9, R4, R0, R3, L1, L0, C1, C0);
+    }
+}
+
+// instances that tripped an assertion gate: the program gives every assertion value a bit-table slot; a mask that is not
+// zero names the instances to be re-run by the 256-bit schedule
+__global__ void __launch_bounds__(256)
+cw_bits_assert_kernel(const uint64_t *__restrict__ T, uint64_t slots, const uint32_t *__restrict__ aslots, uint32_t n_asserts,
+                      uint32_t n_groups, uint64_t *fbmask) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= n_groups) return;
+    uint64_t v = 0;
+    for (uint32_t i = 0; i < n_asserts; i++) v |= T[(size_t)g * slots + aslots[i]];
+    if (v) fbmask[g] |= v;
 }
 
 // ---- egress: canonical 32-byte values from the bit table (getWitness + Fr_toLongNormal, main.cpp:326-332) ----------------
-// element k of instance `first + blockIdx.y` -> out[(blockIdx.y * n_wit + k)]; w2s = witness -> signal map
+// out[j][k] (32 bytes) = value of witness element k in instance first + j.  The kernel is a pure HBM writer: a wave owns 32
+// consecutive elements and walks 64 instances; lane l holds the mask of element k0 + l / 2 (ONE 8-byte read per 2 KiB
+// written, through wslot = sig_slot o w2s composed on the host) and every store instruction writes the 1 KiB that 32
+// elements of one instance occupy (global_store_dwordx4, consecutive lanes -> consecutive 16-byte halves).  Round 2's
+// kernel ran one thread per element with two dependent index loads per 32 bytes: 0.53 of the HBM peak.
 __global__ void __launch_bounds__(256)
-cw_bits_gather_kernel(const uint64_t *__restrict__ T, uint64_t slots, const uint32_t *__restrict__ w2s,
-                      const uint32_t *__restrict__ sig_slot, uint32_t n_wit, uint32_t first, uint4 *__restrict__ out) {
-    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= n_wit) return;
-    const uint32_t i = first + blockIdx.y;
-    const uint64_t m = T[(size_t)(i >> 6) * slots + sig_slot[w2s[k]]];
-    const uint32_t bit = (uint32_t)(m >> (i & 63u)) & 1u;
-    const size_t o = ((size_t)blockIdx.y * n_wit + k) * 2;
-    out[o] = make_uint4(bit, 0, 0, 0);
-    out[o + 1] = make_uint4(0, 0, 0, 0);
+cw_bits_gather_kernel(const uint64_t *__restrict__ T, uint64_t slots, const uint32_t *__restrict__ wslot, uint32_t n_wit,
+                      uint32_t first, uint32_t count, uint4 *__restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t k0 = (blockIdx.x * 4 + wv) * 32;                  // this wave's 32 elements
+    const uint32_t j0 = blockIdx.y * 64;                             // its 64 output instances
+    if (k0 >= n_wit) return;
+    const uint32_t k = k0 + (lane >> 1);
+    const bool have = k < n_wit;
+    const uint32_t i0 = first + j0, g = i0 >> 6, sh = i0 & 63u;
+    uint64_t win = 0;                                                // bit jj = the value in instance i0 + jj
+    if (have) {
+        const uint32_t sl = wslot[k];
+        const uint64_t lo = T[(size_t)g * slots + sl];
+        win = lo >> sh;
+        if (sh && (uint64_t)(i0 + 64 - sh) < (uint64_t)first + count) win |= T[(size_t)(g + 1) * slots + sl] << (64 - sh);
+    }
+    const uint32_t nj = min(64u, count - j0);
+    const bool low_half = !(lane & 1);
+    uint4 *o = out + ((size_t)j0 * n_wit + k0) * 2 + lane;
+    for (uint32_t jj = 0; jj < nj; jj++) {
+        const uint32_t bit = low_half ? (uint32_t)(win >> jj) & 1u : 0u;
+        if (have) {
+            const u32x4 v = {bit, 0u, 0u, 0u};
+            __builtin_nontemporal_store(v, (u32x4 *)o);
+        }
+        o += (size_t)n_wit * 2;
+    }
+}
+
+// packed main inputs (cw_set_inputs_bits*): masks[group][k] -> bit-table slot input_slot0 + k
+__global__ void __launch_bounds__(256)
+cw_bits_ingest_packed_kernel(const uint64_t *__restrict__ masks, uint64_t *__restrict__ T, uint64_t slots, uint32_t input_slot0,
+                             uint32_t n_in, uint32_t batch) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    if (k >= n_in) return;
+    uint64_t m = masks[(size_t)g * n_in + k];
+    const uint32_t live = batch - g * 64;                            // instances of the last group beyond the batch read as 0
+    if (live < 64) m &= (1ull << live) - 1;
+    T[(size_t)g * slots + input_slot0 + k] = m;
+}
+// canonical inputs of the listed instances from packed masks / from the AoS input image (rows of the side batch that
+// re-runs them on the 256-bit schedule): out[j][k] = input k of instance inst[j]
+__global__ void __launch_bounds__(256)
+cw_bits_collect_inputs_kernel(const uint64_t *__restrict__ masks, const uint4 *__restrict__ aos, const uint32_t *__restrict__ inst,
+                              uint32_t n_inst, uint32_t n_in, uint4 *__restrict__ out) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (k >= n_in || j >= n_inst) return;
+    const uint32_t i = inst[j];
+    uint4 lo, hi = make_uint4(0, 0, 0, 0);
+    if (masks) {
+        lo = make_uint4((uint32_t)(masks[(size_t)(i >> 6) * n_in + k] >> (i & 63u)) & 1u, 0, 0, 0);
+    } else {
+        lo = aos[((size_t)i * n_in + k) * 2];
+        hi = aos[((size_t)i * n_in + k) * 2 + 1];
+    }
+    out[((size_t)j * n_in + k) * 2] = lo;
+    out[((size_t)j * n_in + k) * 2 + 1] = hi;
 }
 
 // ---- R1CS check on the bit table ---------------------------------------------------------------------------------------------
@@ -493,26 +614,46 @@ hipError_t cwk_bits_ingest(hipStream_t s, const void *in, void *T, uint64_t slot
                        batch, (uint64_t *)fbmask);
     return hipGetLastError();
 }
-hipError_t cwk_bits_eval(hipStream_t s, const void *recs, uint32_t n_vrows, uint32_t ring, void *T, uint64_t slots,
-                         uint32_t n_groups, uint32_t width, void *fbmask) {
-    const size_t lds = (size_t)ring * 512;
-    typedef void (*kern_t)(const uint4 *, uint32_t, uint32_t, uint64_t *, uint64_t, uint64_t *);
+hipError_t cwk_bits_eval(hipStream_t s, const void *recs, const uint32_t *cmds, uint32_t n_batches, uint32_t ring, uint32_t cache,
+                         void *T, uint64_t slots, uint32_t n_groups, uint32_t width, const uint32_t *aslots, uint32_t n_asserts,
+                         void *fbmask) {
+    const uint32_t const_off = (ring + cache) * 512u;
+    const size_t lds = (size_t)const_off + 16;
+    typedef void (*kern_t)(const uint4 *, const uint32_t *, uint32_t, uint32_t, uint64_t *, uint64_t);
     kern_t k = width == 16 ? (kern_t)cw_bits_eval_kernel<16> : width == 32 ? (kern_t)cw_bits_eval_kernel<32> : (kern_t)cw_bits_eval_kernel<64>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(k, dim3(n_groups, 64 / width), dim3(64), lds, s, (const uint4 *)recs, n_vrows, ring - 1, (uint64_t *)T, slots,
-                       (uint64_t *)fbmask);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k, dim3(n_groups, 64 / width), dim3(64), lds, s, (const uint4 *)recs, cmds, n_batches, const_off, (uint64_t *)T, slots);
+    if (n_asserts)
+        hipLaunchKernelGGL(cw_bits_assert_kernel, dim3((n_groups + 255) / 256), dim3(256), 0, s, (const uint64_t *)T, slots, aslots, n_asserts,
+                           n_groups, (uint64_t *)fbmask);
     return hipGetLastError();
 }
-hipError_t cwk_bits_gather(hipStream_t s, const void *T, uint64_t slots, const uint32_t *w2s, const uint32_t *sig_slot,
-                           uint32_t n_wit, uint32_t first, uint32_t count, void *out) {
+hipError_t cwk_bits_gather(hipStream_t s, const void *T, uint64_t slots, const uint32_t *wslot, uint32_t n_wit, uint32_t first,
+                           uint32_t count, void *out) {
     if (!count || !n_wit) return hipSuccess;
-    for (uint32_t done = 0; done < count; done += 65535u) {       // grid.y limit
-        const uint32_t n = count - done < 65535u ? count - done : 65535u;
-        hipLaunchKernelGGL(cw_bits_gather_kernel, dim3((n_wit + 255) / 256, n), dim3(256), 0, s, (const uint64_t *)T, slots, w2s,
-                           sig_slot, n_wit, first + done, (uint4 *)out + (size_t)done * n_wit * 2);
+    for (uint32_t done = 0; done < count; done += 65535u * 64u) {       // grid.y limit
+        const uint32_t n = count - done < 65535u * 64u ? count - done : 65535u * 64u;
+        hipLaunchKernelGGL(cw_bits_gather_kernel, dim3((n_wit + 127) / 128, (n + 63) / 64), dim3(256), 0, s, (const uint64_t *)T, slots,
+                           wslot, n_wit, first + done, n, (uint4 *)out + (size_t)done * n_wit * 2);
+    }
+    return hipGetLastError();
+}
+hipError_t cwk_bits_ingest_packed(hipStream_t s, const void *masks, void *T, uint64_t slots, uint32_t input_slot0, uint32_t n_in,
+                                  uint32_t batch) {
+    if (n_in == 0) return hipSuccess;
+    dim3 g((n_in + 255) / 256, (batch + 63) / 64);
+    if (g.y > 65535u) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(cw_bits_ingest_packed_kernel, g, dim3(256), 0, s, (const uint64_t *)masks, (uint64_t *)T, slots, input_slot0, n_in,
+                       batch);
+    return hipGetLastError();
+}
+hipError_t cwk_bits_collect_inputs(hipStream_t s, const void *masks, const void *aos, const uint32_t *inst, uint32_t n_inst,
+                                   uint32_t n_in, void *out) {
+    if (!n_inst || !n_in) return hipSuccess;
+    for (uint32_t done = 0; done < n_inst; done += 65535u) {
+        const uint32_t n = n_inst - done < 65535u ? n_inst - done : 65535u;
+        hipLaunchKernelGGL(cw_bits_collect_inputs_kernel, dim3((n_in + 255) / 256, n), dim3(256), 0, s, (const uint64_t *)masks,
+                           (const uint4 *)aos, inst + done, n, n_in, (uint4 *)out + (size_t)done * n_in * 2);
     }
     return hipGetLastError();
 }

@@ -13,48 +13,93 @@
 namespace cwbits {
 
 constexpr uint32_t IN_BASE = 3;             // bit-table slot of main input 0 (slots 0,1,2 = constant 0, constant 1, reserved)
-constexpr uint32_t NONE = 0xFFFFFFFFu;      // "no destination" / "no load": out of the buffer's range, dropped by the hardware
+
+constexpr uint32_t BATCH = 8;               // vrows per batch (cw_bits.hip BITS_NB)
+constexpr uint32_t MAX_LOADS = 4, MAX_FLUSH = 6, CMD_WORDS = 24;
 
 struct Program {                             // hip_elements/bitsched.py::BitTape
-    uint32_t ring = 0;                       // LDS ring entries (power of two, <= 128: offsets travel in 16 bits)
-    uint32_t n_vrows = 0;
-    uint64_t n_slots = 0;                    // bit-table slots per group of 64 instances
-    std::vector<uint32_t> recs;              // n_vrows * 64 * 4 words (record layout: bitsched.py / cw_bits.hip)
+    uint32_t ring = 0;                       // LDS ring rows (results that are no signal)
+    uint32_t cache = 0;                      // LDS cache slots (rows of the bit table)
+    uint32_t n_vrows = 0;                    // multiple of BATCH
+    uint64_t n_slots = 0;                    // bit-table slots per group of 64 instances (multiple of 64)
+    std::vector<uint32_t> recs;              // n_vrows * 64 * 2 words (record layout: bitsched.py / cw_bits.hip)
+    std::vector<uint32_t> cmds;              // n_vrows / BATCH * CMD_WORDS words: row loads and flushes per batch
     std::vector<uint32_t> sig_slot;          // signal -> slot (signals that are copies of one another share a slot)
+    std::vector<uint32_t> assert_slots;      // slots that must be zero in every instance (unproved `===`)
 };
 
-// Every offset a record carries is checked once at load time (files are untrusted input): ring operands inside the
-// ring, load addresses and destinations inside the group's bit table, destinations never on constant or input slots.
+// Every offset a record or a command carries is checked once at load time (files are untrusted input): LDS operands
+// inside ring / cache / constants, results inside ring / cache, rows inside the group's bit table, flushes never onto
+// the rows of the constants and main inputs.  (Races are the lowering's business: oracle/tape_eval.py replays the
+// program with poisoned memory; a damaged program can only compute wrong bits inside its own group's table.)
 inline const char *validate(const Program &p, uint32_t n_signals, uint32_t n_inputs) {
-    if (p.ring < 32 || p.ring > 128 || (p.ring & (p.ring - 1))) return "bit program: ring size";
-    if (p.n_slots < (uint64_t)IN_BASE + n_inputs || p.n_slots >= (1ull << 25)) return "bit program: slot count";
-    if (p.recs.size() != (size_t)p.n_vrows * 64 * 4) return "bit program: record count";
+    if (p.ring < 8 || p.ring > 96 || p.ring % BATCH || p.cache < 8) return "bit program: ring / cache size";
+    const uint32_t const_off = (p.ring + p.cache) * 512u;
+    if (const_off + 16 > 0xFFF8u) return "bit program: LDS areas exceed the 16-bit offsets of a record";
+    const uint64_t in_rows = ((uint64_t)IN_BASE + n_inputs + 63) / 64;
+    if (p.n_slots % 64 || p.n_slots < in_rows * 64 || p.n_slots >= (1ull << 25)) return "bit program: slot count";
+    if (p.n_vrows % BATCH) return "bit program: not a whole number of batches";
+    if (p.recs.size() != (size_t)p.n_vrows * 64 * 2) return "bit program: record count";
+    if (p.cmds.size() != (size_t)(p.n_vrows / BATCH) * CMD_WORDS) return "bit program: command block count";
     if (p.sig_slot.size() != n_signals) return "bit program: signal map size";
     for (uint32_t s : p.sig_slot)
         if (s >= p.n_slots || s == 2) return "bit program: signal slot out of range";
-    const uint32_t ring_bytes = p.ring * 512u;
-    const uint64_t tab_bytes = p.n_slots * 8;
+    for (uint32_t s : p.assert_slots)
+        if (s >= p.n_slots) return "bit program: assertion slot out of range";
     for (size_t i = 0; i < (size_t)p.n_vrows * 64; i++) {
-        const uint32_t *r = &p.recs[i * 4];
-        const uint32_t a = r[0] & 0xFFFFu, b = r[0] >> 16, c = r[1] & 0xFFFFu;
-        if ((a & 7) || (b & 7) || (c & 7) || a >= ring_bytes || b >= ring_bytes || c >= ring_bytes) return "bit program: ring operand out of range";
-        if (r[1] >> 25) return "bit program: bad gate word";
-        if (r[2] != NONE && ((r[2] & 7) || r[2] >= tab_bytes)) return "bit program: load slot out of range";
-        if (r[2] != NONE && ((i / 64) & 1)) return "bit program: LOAD lane in an odd vrow (the kernel loads for even vrows only)";
-        if (r[3] != NONE && ((r[3] & 7) || r[3] >= tab_bytes || r[3] / 8 < IN_BASE + n_inputs)) return "bit program: destination out of range";
+        const uint32_t w0 = p.recs[i * 2], w1 = p.recs[i * 2 + 1];
+        const uint32_t a = w0 & 0xFFF8u, b = w0 >> 16, c = w1 & 0xFFFFu, d = w1 >> 16;
+        if ((w0 & 4u) || (b & 7) || (c & 7) || (d & 7)) return "bit program: bad record word";
+        if (a >= const_off + 16 || b >= const_off + 16 || c >= const_off + 16) return "bit program: operand outside the LDS areas";
+        if (d >= const_off) return "bit program: result outside ring and cache";
+    }
+    const uint64_t tab_bytes = p.n_slots * 8;
+    for (size_t b = 0; b < p.n_vrows / BATCH; b++) {
+        const uint32_t *c = &p.cmds[b * CMD_WORDS];
+        const uint32_t nl = c[0] & 0xFFu, nf = (c[0] >> 8) & 0xFFu;
+        if (nl > MAX_LOADS || nf > MAX_FLUSH || (c[0] >> 16)) return "bit program: command counts";
+        for (uint32_t j = 0; j < nl + nf; j++) {
+            const uint32_t k = j < nl ? j : MAX_LOADS + (j - nl);
+            const uint32_t goff = c[2 + 2 * k], loff = c[3 + 2 * k];
+            if ((goff % 512) || (uint64_t)goff + 512 > tab_bytes) return "bit program: row outside the bit table";
+            if ((loff % 512) || loff < p.ring * 512u || loff + 512 > const_off) return "bit program: cache slot outside the cache area";
+            if (j >= nl && goff / 512 < in_rows) return "bit program: flush onto a constant / input row";
+        }
     }
     return nullptr;
 }
 
-// Device stream: the program padded to whole batches of 8 vrows, plus 8 empty batches (the kernel requests records two
-// batches ahead and its loop runs in trips of six batches).  Returns the number of batches to execute.
-inline uint32_t device_stream(const Program &p, std::vector<uint32_t> &dev) {
-    const size_t batches = ((size_t)p.n_vrows + 7) / 8;
-    const size_t rows = (batches + 8) * 8 * 64;
-    dev.assign(rows * 4, NONE);
-    for (size_t i = 0; i < rows; i++) dev[i * 4] = dev[i * 4 + 1] = 0;
-    std::copy(p.recs.begin(), p.recs.end(), dev.begin());
-    return (uint32_t)batches;
+// Device stream: per batch 4 x 64 lanes x 16 bytes (load j of a lane carries the records of vrows 2j, 2j + 1 of the
+// batch), padded to whole trips of ten batches plus AHEAD empty ones (the kernel requests records AHEAD batches ahead:
+// cw_bits.hip BITS_AHEAD); idle lanes compute 0 ^ 0 ^ 0 into their own ring entry.  `cmds` gets zero blocks for the
+// padding.  Returns the number of batches to execute (multiple of 10).
+constexpr size_t AHEAD = 4, TRIP = 10;
+inline uint32_t device_stream(const Program &p, std::vector<uint32_t> &dev, std::vector<uint32_t> &cmds) {
+    const size_t batches = p.n_vrows / BATCH;
+    const size_t run = (batches + TRIP - 1) / TRIP * TRIP;
+    const uint32_t const_off = (p.ring + p.cache) * 512u;
+    dev.assign((run + AHEAD) * 4 * 64 * 4, 0);
+    for (size_t b = 0; b < run + AHEAD; b++)
+        for (uint32_t k = 0; k < BATCH; k++) {
+            const size_t v = b * BATCH + k;
+            for (uint32_t lane = 0; lane < 64; lane++) {
+                uint32_t w0, w1;
+                if (v < p.n_vrows) {
+                    w0 = p.recs[(v * 64 + lane) * 2];
+                    w1 = p.recs[(v * 64 + lane) * 2 + 1];
+                } else {
+                    w0 = const_off | (const_off << 16);
+                    w1 = const_off | ((uint32_t)((v % p.ring) * 512 + lane * 8) << 16);
+                }
+                const uint32_t d = 2 * k;                         // dword index of w0 among the lane's 16 of this batch
+                uint32_t *q = &dev[((b * 4 + d / 4) * 64 + lane) * 4 + d % 4];
+                q[0] = w0;
+                q[1] = w1;
+            }
+        }
+    cmds.assign((run + AHEAD) * CMD_WORDS, 0);
+    std::copy(p.cmds.begin(), p.cmds.end(), cmds.begin());
+    return (uint32_t)run;
 }
 
 // ---- R1CS over the bit table --------------------------------------------------------------------------------------------

@@ -660,23 +660,34 @@ static int load_tape(cw_circuit *c, const char *path) {
         c->variants.push_back(std::move(var));
     }
     if (n_bit_programs) {
-        // bit-plane program: 8 x u32 {ring, n_vrows, n_slots lo, hi, 0...} then n_vrows * 64 records of 8 x u32
+        // bit-plane program: 8 x u32 {ring, n_vrows, n_slots lo, hi, cache, n_asserts, format version, 0}, records
+        // (n_vrows * 64 x 2 u32), command blocks (n_vrows / 8 x 24 u32), signal -> slot map, assertion slots
         if (off + 32 > b.size()) return fail(CW_EIO, "tape bit program truncated");
         uint32_t bh[8];
         memcpy(bh, b.data() + off, 32);
         off += 32;
+        if (bh[6] != 2 || bh[7]) return fail(CW_EIO, "tape bit program: unknown format version (lowered by another release)");
         cwbits::Program &bp = c->bits;
         bp.ring = bh[0];
         bp.n_vrows = bh[1];
         bp.n_slots = (uint64_t)bh[2] | ((uint64_t)bh[3] << 32);
-        const uint64_t words = (uint64_t)bp.n_vrows * 64 * 4;
-        if (bp.n_vrows > (1u << 24) || (words + c->n_signals) * 4 > b.size() - off) return fail(CW_EIO, "tape bit program truncated");
-        bp.recs.resize((size_t)words);
-        memcpy(bp.recs.data(), b.data() + off, (size_t)words * 4);
-        off += (size_t)words * 4;
+        bp.cache = bh[4];
+        const uint32_t n_asserts = bh[5];
+        if (bp.n_vrows > (1u << 24) || bp.n_vrows % cwbits::BATCH || n_asserts > (1u << 24)) return fail(CW_EIO, "tape bit program truncated");
+        const uint64_t rwords = (uint64_t)bp.n_vrows * 64 * 2, cwords = (uint64_t)(bp.n_vrows / cwbits::BATCH) * cwbits::CMD_WORDS;
+        if ((rwords + cwords + c->n_signals + n_asserts) * 4 > b.size() - off) return fail(CW_EIO, "tape bit program truncated");
+        bp.recs.resize((size_t)rwords);
+        memcpy(bp.recs.data(), b.data() + off, (size_t)rwords * 4);
+        off += (size_t)rwords * 4;
+        bp.cmds.resize((size_t)cwords);
+        memcpy(bp.cmds.data(), b.data() + off, (size_t)cwords * 4);
+        off += (size_t)cwords * 4;
         bp.sig_slot.resize(c->n_signals);
         memcpy(bp.sig_slot.data(), b.data() + off, (size_t)c->n_signals * 4);
         off += (size_t)c->n_signals * 4;
+        bp.assert_slots.resize(n_asserts);
+        memcpy(bp.assert_slots.data(), b.data() + off, (size_t)n_asserts * 4);
+        off += (size_t)n_asserts * 4;
         if (const char *why = cwbits::validate(bp, c->n_signals, c->n_inputs)) return fail(CW_EIO, std::string("tape: ") + why);
         c->has_bits = true;
     }
@@ -1006,7 +1017,11 @@ struct cw_batch {
     uint64_t *d_T = nullptr, *d_fbmask = nullptr;   // bit table [groups][slots]; per-group mask of instances to re-run wide
     uint64_t t_bytes = 0;
     uint32_t n_groups = 0;
-    uint32_t *d_brecs = nullptr;                      // the gate program
+    uint32_t *d_brecs = nullptr, *d_bcmds = nullptr, *d_aslots = nullptr;   // the gate program: records, command blocks, assertion slots
+    uint32_t *d_wslot = nullptr;                      // witness position -> bit-table slot (sig_slot o w2s)
+    uint32_t *d_fbinst = nullptr;                     // instances of the side batch (device copy of fb_inst)
+    uint32_t fbinst_cap = 0;
+    const void *packed_in = nullptr;                  // cw_set_inputs_bits_device: uint64 masks [groups][n_inputs] instead of ext_in
     uint32_t *d_erecs = nullptr, *d_wchunk = nullptr, *d_wterms = nullptr, *d_wctab = nullptr, *d_wrow = nullptr;
     uint32_t *d_ichunk = nullptr, *d_iterms = nullptr, *d_itab = nullptr, *d_irow = nullptr, *d_sigslot = nullptr;
     uint32_t n_ichunks = 0;
@@ -1036,7 +1051,7 @@ extern "C" void cw_batch_free(cw_batch *b) {
     hipSetDevice(b->device);
     hipStreamSynchronize(b->stream);
     if (b->fb) cw_batch_free(b->fb);
-    void *bptrs[] = {b->d_T, b->d_fbmask, b->d_brecs, b->d_erecs, b->d_wchunk, b->d_wterms, b->d_wctab, b->d_wrow,
+    void *bptrs[] = {b->d_T, b->d_fbmask, b->d_brecs, b->d_bcmds, b->d_aslots, b->d_wslot, b->d_fbinst, b->d_erecs, b->d_wchunk, b->d_wterms, b->d_wctab, b->d_wrow,
                      b->d_ichunk, b->d_iterms, b->d_itab, b->d_irow, b->d_sigslot};
     for (void *p : bptrs)
         if (p) hipFree(p);
@@ -1350,14 +1365,17 @@ extern "C" int cw_bits_info(const cw_circuit *c, uint64_t out[8]) {
     memset(out, 0, 64);
     if (!c->has_bits) return CW_OK;
     const cwbits::Program &bp = c->bits;
-    uint64_t gates = 0, loads = 0, stores = 0;
-    for (size_t i = 0; i < (size_t)bp.n_vrows * 64; i++) {
-        const uint32_t *r = &bp.recs[i * 4];
-        if (r[2] != cwbits::NONE) loads++;
-        else if ((r[1] >> 16) & 0xFF) gates++;
-        if (r[3] != cwbits::NONE) stores++;
+    // gate lanes = records that are not the idle pattern (all three operands the constant 0, result into the ring)
+    const uint32_t const_off = (bp.ring + bp.cache) * 512u;
+    uint64_t gates = 0, loads = 0, flushes = 0;
+    for (size_t i = 0; i < (size_t)bp.n_vrows * 64; i++)
+        if (bp.recs[i * 2] != (const_off | (const_off << 16)) || (bp.recs[i * 2 + 1] & 0xFFFFu) != const_off) gates++;
+    for (size_t b = 0; b < bp.n_vrows / cwbits::BATCH; b++) {
+        loads += bp.cmds[b * cwbits::CMD_WORDS] & 0xFFu;
+        flushes += (bp.cmds[b * cwbits::CMD_WORDS] >> 8) & 0xFFu;
     }
-    out[0] = 1; out[1] = bp.n_vrows; out[2] = bp.n_slots; out[3] = bp.ring; out[4] = gates; out[5] = loads; out[6] = stores;
+    out[0] = 1; out[1] = bp.n_vrows; out[2] = bp.n_slots; out[3] = bp.ring; out[4] = gates; out[5] = loads; out[6] = flushes;
+    out[7] = bp.cache;
     return CW_OK;
 }
 extern "C" uint32_t cw_batch_size(const cw_batch *b) { return b->batch; }
@@ -1393,6 +1411,7 @@ static int set_input_hashed(cw_batch *b, uint32_t inst, uint64_t h, uint32_t idx
     b->remaining[inst]--;
     b->host_dirty = true;
     b->ext_in = nullptr;
+    b->packed_in = nullptr;
     return CW_OK;
 }
 
@@ -1421,11 +1440,21 @@ extern "C" int64_t cw_remaining_inputs(const cw_batch *b, uint32_t instance) {
 
 extern "C" int cw_set_inputs(cw_batch *b, const uint8_t *le32) {
     if (!b || !le32) return fail(CW_EINVAL, "null argument");
-    NEED_DEVICE(b);
     size_t n = (size_t)b->batch * b->c->n_inputs * 32;
+    if (b->device < 0) {                                     // host-only batch: stage (every cell counts as assigned)
+        ensure_host_staging(b);
+        memcpy(b->h_in.data(), le32, n);
+        std::fill(b->assigned.begin(), b->assigned.end(), 1);
+        std::fill(b->remaining.begin(), b->remaining.end(), 0);
+        b->all_set = true;
+        b->host_dirty = true;
+        b->ext_in = nullptr;
+        return CW_OK;
+    }
     HIPCHK(hipSetDevice(b->device));
     HIPCHK(hipMemcpyAsync(b->d_in, le32, n, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));   // caller may free le32 on return
+    b->packed_in = nullptr;
     b->ext_in = nullptr;
     b->host_dirty = false;
     b->all_set = true;
@@ -1433,8 +1462,31 @@ extern "C" int cw_set_inputs(cw_batch *b, const uint8_t *le32) {
     return CW_OK;
 }
 
+extern "C" int cw_set_inputs_bits_device(cw_batch *b, const void *d_masks) {
+    if (!b || !d_masks) return fail(CW_EINVAL, "null argument");
+    NEED_DEVICE(b);
+    if (!b->bitmode) return fail(CW_ESTATE, "packed boolean inputs need a bit-plane batch (cw_batch_bitmode)");
+    b->packed_in = d_masks;
+    b->ext_in = nullptr;
+    b->host_dirty = false;
+    b->all_set = true;
+    std::fill(b->remaining.begin(), b->remaining.end(), 0);
+    return CW_OK;
+}
+extern "C" int cw_set_inputs_bits(cw_batch *b, const uint64_t *masks) {
+    if (!b || !masks) return fail(CW_EINVAL, "null argument");
+    NEED_DEVICE(b);
+    if (!b->bitmode) return fail(CW_ESTATE, "packed boolean inputs need a bit-plane batch (cw_batch_bitmode)");
+    HIPCHK(hipSetDevice(b->device));
+    // d_in holds 32 bytes per input and instance: the masks (1 bit each) always fit
+    HIPCHK(hipMemcpyAsync(b->d_in, masks, (size_t)b->n_groups * b->c->n_inputs * 8, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return cw_set_inputs_bits_device(b, b->d_in);
+}
+
 extern "C" int cw_set_inputs_device(cw_batch *b, const void *d_le32) {
     if (!b || !d_le32) return fail(CW_EINVAL, "null argument");
+    b->packed_in = nullptr;
     b->ext_in = d_le32;
     b->host_dirty = false;
     b->all_set = true;
@@ -1656,10 +1708,12 @@ static int bits_batch_setup(cw_batch *b) {
         return fail(CW_EDEVICE, "hipMalloc of the bit table failed (" + std::to_string(b->t_bytes) + " bytes): " + hipGetErrorString(e));
     BTRY(hipMalloc((void **)&b->d_fbmask, (size_t)b->n_groups * 8));
     {
-        std::vector<uint32_t> dev;
-        b->bits_steps = cwbits::device_stream(bp, dev);
+        std::vector<uint32_t> dev, cmds;
+        b->bits_steps = cwbits::device_stream(bp, dev, cmds);
         BTRY(upload(&b->d_brecs, dev, b->stream));
-        BTRY(hipStreamSynchronize(b->stream));                       // `dev` goes out of scope
+        BTRY(upload(&b->d_bcmds, cmds, b->stream));
+        BTRY(upload(&b->d_aslots, bp.assert_slots, b->stream));
+        BTRY(hipStreamSynchronize(b->stream));                       // the vectors go out of scope
     }
     // instances per wave: small batches are spread over more CUs by giving every group of 64 instances to 2 or 4
     // independent waves (each evaluates the whole program on its 32 / 16 bits of every mask)
@@ -1670,6 +1724,12 @@ static int bits_batch_setup(cw_batch *b) {
     }
     BTRY(upload(&b->d_w2s, c->w2s, b->stream));
     BTRY(upload(&b->d_sigslot, bp.sig_slot, b->stream));
+    {
+        std::vector<uint32_t> wslot(c->w2s.size());
+        for (size_t k = 0; k < wslot.size(); k++) wslot[k] = bp.sig_slot[c->w2s[k]];
+        BTRY(upload(&b->d_wslot, wslot, b->stream));
+        BTRY(hipStreamSynchronize(b->stream));
+    }
     BTRY(hipMalloc((void **)&b->d_status, (size_t)b->Bp * 4));
     BTRY(hipMalloc((void **)&b->d_first_bad, (size_t)b->Bp * 4));
     if (c->n_constraints) {
@@ -1708,8 +1768,12 @@ static int bits_run(cw_batch *b, const void *in) {
     cw_circuit *c = b->c;
     const cwbits::Program &bp = c->bits;
     BTRY(cwk_bits_init(b->stream, b->d_T, bp.n_slots, b->n_groups, b->d_fbmask, b->d_status, b->d_first_bad, b->Bp));
-    BTRY(cwk_bits_ingest(b->stream, in, b->d_T, bp.n_slots, cwbits::IN_BASE, c->n_inputs, b->batch, b->d_fbmask));
-    BTRY(cwk_bits_eval(b->stream, b->d_brecs, b->bits_steps, bp.ring, b->d_T, bp.n_slots, b->n_groups, b->bits_width, b->d_fbmask));
+    if (b->packed_in)
+        BTRY(cwk_bits_ingest_packed(b->stream, b->packed_in, b->d_T, bp.n_slots, cwbits::IN_BASE, c->n_inputs, b->batch));
+    else
+        BTRY(cwk_bits_ingest(b->stream, in, b->d_T, bp.n_slots, cwbits::IN_BASE, c->n_inputs, b->batch, b->d_fbmask));
+    BTRY(cwk_bits_eval(b->stream, b->d_brecs, b->d_bcmds, b->bits_steps, bp.ring, bp.cache, b->d_T, bp.n_slots, b->n_groups, b->bits_width,
+                       b->d_aslots, (uint32_t)bp.assert_slots.size(), b->d_fbmask));
     b->resolved = false;
     b->checked = false;
     return CW_OK;
@@ -1729,24 +1793,42 @@ static int bits_resolve(cw_batch *b) {
     for (uint32_t g = 0; g < b->n_groups; g++)
         for (uint64_t x = m[g]; x; x &= x - 1) {
             const uint32_t i = g * 64 + (uint32_t)__builtin_ctzll(x);
-            if (i < b->batch) {
-                b->fb_index[i] = (int32_t)b->fb_inst.size();
-                b->fb_inst.push_back(i);
-            }
+            if (i < b->batch) b->fb_inst.push_back(i);
         }
-    if (b->fb && (b->fb_inst.empty() || b->fb->batch != b->fb_inst.size())) {
+    // when a large share of the batch is not boolean (a circuit class the bit program does not suit, or a caller feeding
+    // field-valued inputs) the whole batch goes through the 256-bit schedule: one dense side batch instead of a sparse one
+    if (b->fb_inst.size() > b->batch / 4) {
+        b->fb_inst.resize(b->batch);
+        for (uint32_t i = 0; i < b->batch; i++) b->fb_inst[i] = i;
+    }
+    const size_t n_fb = b->fb_inst.size();
+    for (size_t k = 0; k < n_fb; k++) b->fb_index[b->fb_inst[k]] = (int32_t)k;
+    // the side batch is kept while it is large enough and not more than 4x too large (its tail then repeats the first
+    // instance): a caller whose batches have a few odd instances each does not pay a table allocation per run
+    if (b->fb && (n_fb == 0 || b->fb->batch < n_fb || b->fb->batch > 4 * n_fb)) {
         cw_batch_free(b->fb);
         b->fb = nullptr;
     }
-    if (!b->fb_inst.empty()) {
+    if (n_fb) {
         if (!b->fb) {
-            int rc = batch_create_impl(c, b->device, (uint32_t)b->fb_inst.size(), b->stream, false, &b->fb);
+            int rc = batch_create_impl(c, b->device, (uint32_t)n_fb, b->stream, false, &b->fb);
             if (rc != CW_OK) return rc;
         }
-        const size_t row = (size_t)c->n_inputs * 32;
-        const char *src = (const char *)(b->ext_in ? b->ext_in : b->d_in);
-        for (size_t k = 0; k < b->fb_inst.size(); k++)
-            BTRY(hipMemcpyAsync((char *)b->fb->d_in + k * row, src + (size_t)b->fb_inst[k] * row, row, hipMemcpyDeviceToDevice, b->stream));
+        std::vector<uint32_t> inst(b->fb_inst);
+        inst.resize(b->fb->batch, b->fb_inst[0]);
+        if (b->fbinst_cap < inst.size()) {
+            if (b->d_fbinst) hipFree(b->d_fbinst);
+            b->d_fbinst = nullptr;
+            b->fbinst_cap = 0;
+            BTRY(hipMalloc((void **)&b->d_fbinst, inst.size() * 4));
+            b->fbinst_cap = (uint32_t)inst.size();
+        }
+        BTRY(hipMemcpyAsync(b->d_fbinst, inst.data(), inst.size() * 4, hipMemcpyHostToDevice, b->stream));
+        // one kernel gathers the inputs of the listed instances (from the packed masks or the 32-byte image the caller
+        // handed over: that buffer must stay unmodified until the first cw_sync / getter after cw_run, see circom_amd.h)
+        BTRY(cwk_bits_collect_inputs(b->stream, b->packed_in, b->packed_in ? nullptr : (b->ext_in ? b->ext_in : b->d_in), b->d_fbinst,
+                                     (uint32_t)inst.size(), c->n_inputs, b->fb->d_in));
+        BTRY(hipStreamSynchronize(b->stream));                       // `inst` goes out of scope
         b->fb->ext_in = nullptr;
         b->fb->host_dirty = false;
         b->fb->all_set = true;
@@ -1834,10 +1916,10 @@ extern "C" int cw_sync(cw_batch *b) {
 // status words / first bad rows of the instances that were re-run by the 256-bit schedule come from the side batch
 static int bits_patch_words(cw_batch *b, uint32_t *dst, bool first_bad) {
     if (!b->bitmode || b->fb_inst.empty()) return CW_OK;
-    std::vector<uint32_t> w(b->fb_inst.size());
+    std::vector<uint32_t> w(b->fb->batch);
     int rc = first_bad ? cw_get_r1cs_first_bad(b->fb, w.data()) : cw_get_status(b->fb, w.data());
     if (rc != CW_OK) return rc;
-    for (size_t k = 0; k < w.size(); k++) dst[b->fb_inst[k]] = w[k];
+    for (size_t k = 0; k < b->fb_inst.size(); k++) dst[b->fb_inst[k]] = w[k];
     return CW_OK;
 }
 
@@ -1870,7 +1952,7 @@ extern "C" int cw_get_witness(cw_batch *b, uint32_t instance, uint8_t *out) {
     if (b->bitmode) {
         if (int rc = bits_resolve(b)) return rc;
         if (b->fb_index[instance] >= 0) return cw_get_witness(b->fb, (uint32_t)b->fb_index[instance], out);
-        HIPCHK(cwk_bits_gather(b->stream, b->d_T, c->bits.n_slots, b->d_w2s, b->d_sigslot, c->n_witness, instance, 1, b->d_gather));
+        HIPCHK(cwk_bits_gather(b->stream, b->d_T, c->bits.n_slots, b->d_wslot, c->n_witness, instance, 1, b->d_gather));
     } else
     HIPCHK(cwk_gather(b->stream, b->d_V, b->d_w2s, c->n_witness, b->Bp, instance, b->d_gather, c->mont, c->P));
     HIPCHK(hipMemcpyAsync(out, b->d_gather, (size_t)c->n_witness * 32, hipMemcpyDeviceToHost, b->stream));
@@ -1901,7 +1983,7 @@ extern "C" int cw_get_witnesses(cw_batch *b, uint32_t first, uint32_t count, uin
     for (uint32_t done = 0; done < count; done += per) {
         const uint32_t n = std::min(per, count - done);
         if (b->bitmode)
-            HIPCHK(cwk_bits_gather(b->stream, b->d_T, c->bits.n_slots, b->d_w2s, b->d_sigslot, c->n_witness, first + done, n, b->d_bulk));
+            HIPCHK(cwk_bits_gather(b->stream, b->d_T, c->bits.n_slots, b->d_wslot, c->n_witness, first + done, n, b->d_bulk));
         else
             HIPCHK(cwk_gather_many(b->stream, b->d_V, b->d_w2s, c->n_witness, b->Bp, first + done, n, b->d_bulk, c->mont, c->P));
         HIPCHK(hipMemcpyAsync(out + (size_t)done * row, b->d_bulk, (size_t)n * row, hipMemcpyDeviceToHost, b->stream));
@@ -1927,11 +2009,11 @@ extern "C" int cw_get_witnesses_device(cw_batch *b, uint32_t first, uint32_t cou
         HIPCHK(cwk_gather_many(b->stream, b->d_V, b->d_w2s, c->n_witness, b->Bp, first, count, d_out, c->mont, c->P));
         return CW_OK;
     }
-    if (b->resolved && !b->fb_inst.empty()) {
-        // (instances re-run by the 256-bit schedule are patched in below; an unresolved batch is served as computed
-        //  so that the call stays asynchronous — cw_sync() first if the inputs may hold non-boolean values)
-    }
-    HIPCHK(cwk_bits_gather(b->stream, b->d_T, c->bits.n_slots, b->d_w2s, b->d_sigslot, c->n_witness, first, count, d_out));
+    // instances the bit-plane program could not serve (inputs that are not 0/1, assertion gates) are known only after
+    // the evaluation: the first egress of a run waits for it (one stream synchronisation + an 8-byte-per-group copy),
+    // then everything below is asynchronous on the batch's stream
+    if (int rc = bits_resolve(b)) return rc;
+    HIPCHK(cwk_bits_gather(b->stream, b->d_T, c->bits.n_slots, b->d_wslot, c->n_witness, first, count, d_out));
     if (b->resolved)
         for (size_t k = 0; k < b->fb_inst.size(); k++)
             if (b->fb_inst[k] >= first && b->fb_inst[k] < first + count) {
@@ -1939,6 +2021,28 @@ extern "C" int cw_get_witnesses_device(cw_batch *b, uint32_t first, uint32_t cou
                 int rc = cw_get_witnesses_device(b->fb, (uint32_t)k, 1, (char *)d_out + (size_t)(b->fb_inst[k] - first) * row);
                 if (rc != CW_OK) return rc;
             }
+    return CW_OK;
+}
+
+// Chunked device-side egress for provers: the canonical image of `count` instances does not fit anywhere for a
+// million-signal circuit (32 MB per instance), so it is produced `chunk` instances at a time into two caller-owned
+// device buffers in turn; after each chunk's transpose has been ENQUEUED on the batch's stream, `consume` is called with
+// that stream: work the consumer enqueues on it (or on its own stream behind an event recorded on it) sees the chunk
+// complete, and the library's next write to the same buffer - two chunks later - is ordered behind that work.
+// Another batch object of the same circuit, on another stream, can be evaluating the next inputs meanwhile (bench.py).
+extern "C" int cw_stream_witnesses_device(cw_batch *b, uint32_t first, uint32_t count, uint32_t chunk, void *d_buf0, void *d_buf1,
+                                          cw_chunk_fn consume, void *user) {
+    if (!b || !d_buf0 || !d_buf1 || !consume || chunk == 0) return fail(CW_EINVAL, "null argument / zero chunk");
+    if ((uint64_t)first + count > b->batch) return fail(CW_EINVAL, "instance range out of the batch");
+    uint32_t n_chunk = 0;
+    for (uint32_t done = 0; done < count; done += chunk, n_chunk++) {
+        const uint32_t n = std::min(chunk, count - done);
+        void *buf = (n_chunk & 1) ? d_buf1 : d_buf0;
+        int rc = cw_get_witnesses_device(b, first + done, n, buf);
+        if (rc != CW_OK) return rc;
+        rc = consume(user, first + done, n, buf, (void *)b->stream);
+        if (rc != 0) return fail(CW_ESTATE, "the chunk consumer returned " + std::to_string(rc));
+    }
     return CW_OK;
 }
 
@@ -1955,11 +2059,11 @@ extern "C" int cw_get_public_device(cw_batch *b, void *d_out) {
     HIPCHK(hipSetDevice(b->device));
     if (b->bitmode) {
         if (int rc = bits_resolve(b)) return rc;
-        HIPCHK(cwk_bits_gather(b->stream, b->d_T, c->bits.n_slots, b->d_w2s + 1, b->d_sigslot, np, 0, b->batch, d_out));
+        HIPCHK(cwk_bits_gather(b->stream, b->d_T, c->bits.n_slots, b->d_wslot + 1, np, 0, b->batch, d_out));
         if (!b->fb_inst.empty()) {
             void *tmp = nullptr;
             const size_t prow = (size_t)np * 32;
-            HIPCHK(hipMalloc(&tmp, b->fb_inst.size() * prow));
+            HIPCHK(hipMalloc(&tmp, (size_t)b->fb->batch * prow));
             int rc = cw_get_public_device(b->fb, tmp);
             for (size_t k = 0; rc == CW_OK && k < b->fb_inst.size(); k++)
                 if (hipMemcpyAsync((char *)d_out + (size_t)b->fb_inst[k] * prow, (char *)tmp + k * prow, prow, hipMemcpyDeviceToDevice,
@@ -2001,7 +2105,8 @@ extern "C" int cw_get_signal(cw_batch *b, uint32_t instance, uint32_t slot, uint
         if (int rc = bits_resolve(b)) return rc;
         if (b->fb_index[instance] >= 0) return cw_get_signal(b->fb, (uint32_t)b->fb_index[instance], slot, out);
         uint64_t m = 0;
-        HIPCHK(hipMemcpy(&m, b->d_T + (size_t)(instance >> 6) * b->c->bits.n_slots + b->c->bits.sig_slot[slot], 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpyAsync(&m, b->d_T + (size_t)(instance >> 6) * b->c->bits.n_slots + b->c->bits.sig_slot[slot], 8, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
         memset(out, 0, 32);
         out[0] = (uint8_t)((m >> (instance & 63)) & 1);
         return CW_OK;
@@ -2180,6 +2285,7 @@ extern "C" void *cw_device_values(cw_batch *b, uint64_t *n_bytes, uint32_t *padd
     return b->d_V;
 }
 
+extern "C" const uint32_t *cw_signal_slots(const cw_circuit *c) { return c && c->has_bits ? c->bits.sig_slot.data() : nullptr; }
 extern "C" void *cw_device_bits(cw_batch *b, uint64_t *n_bytes, uint64_t *slots_per_group) {
     if (!b || !b->bitmode) return nullptr;
     if (n_bytes) *n_bytes = b->t_bytes;
@@ -2190,6 +2296,52 @@ extern "C" void *cw_device_bits(cw_batch *b, uint64_t *n_bytes, uint64_t *slots_
 // ---------------------------------------------------------------------------------------------------------
 // field micro-benchmark and unit-test hook
 // ---------------------------------------------------------------------------------------------------------
+// Measurement hook (tools/bits_shape_bench.py): time the bit-plane evaluation kernel on an arbitrary (validated) program
+// - synthetic programs separate what a vrow costs from what THIS circuit's operand pattern adds (LDS bank conflicts,
+// row traffic).  The table is zero-filled; results are not read back.
+extern "C" int cw_bits_eval_bench(int device, uint32_t ring, uint32_t cache, uint32_t n_vrows, uint64_t n_slots, const uint32_t *recs,
+                                  const uint32_t *cmds, uint32_t n_groups, uint32_t width, uint32_t iters, float *ms) {
+    if (!recs || !cmds || !ms || n_groups == 0 || iters == 0 || (width != 16 && width != 32 && width != 64)) return fail(CW_EINVAL, "bad argument");
+    cwbits::Program p;
+    p.ring = ring;
+    p.cache = cache;
+    p.n_vrows = n_vrows;
+    p.n_slots = n_slots;
+    p.recs.assign(recs, recs + (size_t)n_vrows * 64 * 2);
+    p.cmds.assign(cmds, cmds + (size_t)(n_vrows / cwbits::BATCH) * cwbits::CMD_WORDS);
+    if (n_vrows % cwbits::BATCH) return fail(CW_EINVAL, "not a whole number of batches");
+    if (const char *why = cwbits::validate(p, 0, 0)) return fail(CW_EINVAL, why);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(CW_EDEVICE, "no HIP device available");
+    HIPCHK(hipSetDevice(device));
+    std::vector<uint32_t> dev, dcmds;
+    const uint32_t steps = cwbits::device_stream(p, dev, dcmds);
+    uint32_t *d_recs = nullptr, *d_cmds = nullptr;
+    void *d_T = nullptr;
+    HIPCHK(upload(&d_recs, dev, nullptr));
+    HIPCHK(upload(&d_cmds, dcmds, nullptr));
+    HIPCHK(hipMalloc(&d_T, (size_t)n_groups * n_slots * 8));
+    HIPCHK(hipMemset(d_T, 0, (size_t)n_groups * n_slots * 8));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(cwk_bits_eval(nullptr, d_recs, d_cmds, steps, ring, cache, d_T, n_slots, n_groups, width, nullptr, 0, nullptr));
+    HIPCHK(hipEventRecord(e0, nullptr));
+    for (uint32_t i = 0; i < iters; i++)
+        HIPCHK(cwk_bits_eval(nullptr, d_recs, d_cmds, steps, ring, cache, d_T, n_slots, n_groups, width, nullptr, 0, nullptr));
+    HIPCHK(hipEventRecord(e1, nullptr));
+    HIPCHK(hipEventSynchronize(e1));
+    float t = 0;
+    HIPCHK(hipEventElapsedTime(&t, e0, e1));
+    *ms = t / iters;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(d_recs);
+    hipFree(d_cmds);
+    hipFree(d_T);
+    return CW_OK;
+}
+
 extern "C" int cw_fp_mul_bench(const uint8_t prime_le32[32], int device, uint32_t n, uint32_t iters, const uint8_t *a,
                                const uint8_t *b, uint8_t *out, float *ms) {
     if (!prime_le32 || !a || !b || !out || n == 0) return fail(CW_EINVAL, "bad argument");

@@ -101,8 +101,8 @@ def write_tape(path, tapes, bittape=None):
                             fail a check (ASSERT_EQ/NZ, IDIV, MOD, CALL), in stream order, the index of its flat operation
                             kind 1 (pipelined, pipe.py): rows are 8 x u32, `extras` = the load lists ((n_rows/NB + 2) x NLD
                             words), shape = NB | NLD << 8, n_lds = 2*NB + 2*NLD
-            bit program     (if n_bit_programs, hip_elements/bitsched.py)  8 x u32: ring, n_vrows, n_slots lo, hi, 0, 0, 0, 0
-                            then n_vrows x 64 records of 4 x u32, then signal -> slot map n_signals x u32
+            bit program     (if n_bit_programs, hip_elements/bitsched.py)  8 x u32: ring, n_vrows, n_slots lo, hi, cache, n_asserts, 2, 0;
+                            records n_vrows*64 x 2 u32; command blocks n_vrows/8 x 24 u32; signal -> slot; assertion slots
     """
     if isinstance(tapes, Tape):
         tapes = [tapes]
@@ -143,9 +143,12 @@ def write_tape(path, tapes, bittape=None):
                 f.write(np.asarray(t.seqs, dtype="<u4").tobytes())
         if bittape is not None:
             assert bittape.n_signals == t0.n_signals and not getattr(t0, "mont", False)
-            f.write(struct.pack("<8I", bittape.ring, bittape.n_vrows, bittape.n_slots & 0xFFFFFFFF, bittape.n_slots >> 32, 0, 0, 0, 0))
+            f.write(struct.pack("<8I", bittape.ring, bittape.n_vrows, bittape.n_slots & 0xFFFFFFFF, bittape.n_slots >> 32,
+                                bittape.cache, len(bittape.assert_slots), 2, 0))
             f.write(np.ascontiguousarray(bittape.recs, dtype="<u4").tobytes())
+            f.write(np.ascontiguousarray(bittape.cmds, dtype="<u4").tobytes())
             f.write(np.ascontiguousarray(bittape.sig_slot, dtype="<u4").tobytes())
+            f.write(np.ascontiguousarray(bittape.assert_slots, dtype="<u4").tobytes())
 
 
 def _le_key(k: int) -> bytes:

@@ -35,7 +35,7 @@ def build_library(force: bool = False) -> Path:
     outs = [LIB_PATH, CLI_PATH]
     if not force and all(o.exists() and all(o.stat().st_mtime >= s.stat().st_mtime for s in srcs) for o in outs):
         return LIB_PATH
-    subprocess.run(["make", "-C", str(_HERE / "csrc")], check=True, capture_output=True)
+    subprocess.run(["make", "-j4", "-C", str(_HERE / "csrc")], check=True, capture_output=True)
     return LIB_PATH
 
 
@@ -70,6 +70,10 @@ _SIGS = {
     "cw_set_inputs_json": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p]),
     "cw_set_inputs": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cw_set_inputs_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cw_set_inputs_bits": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cw_set_inputs_bits_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cw_stream_witnesses_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cw_signal_slots": (C.POINTER(C.c_uint32), [C.c_void_p]),
     "cw_get_staged_input": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p]),
     "cw_remaining_inputs": (C.c_int64, [C.c_void_p, C.c_uint32]),
     "cw_run": (C.c_int, [C.c_void_p]),
@@ -90,6 +94,8 @@ _SIGS = {
     "cw_device_values": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "cw_fp_mul_bench": (C.c_int, [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.POINTER(C.c_float)]),
+    "cw_bits_eval_bench": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32,
+                                     C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]),
     "cw_fp_op": (C.c_int, [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                            C.c_void_p, C.c_void_p]),
 }
@@ -149,7 +155,7 @@ class Circuit:
         _chk(lib().cw_bits_info(self.h, out))
         if not out[0]:
             return {}
-        return dict(zip(("vrows", "slots_per_group", "ring", "gate_lanes", "load_lanes", "stored_values"), [int(x) for x in out[1:7]]))
+        return dict(zip(("vrows", "slots_per_group", "ring", "gate_lanes", "row_loads", "row_flushes", "cache"), [int(x) for x in out[1:8]]))
 
     def input_size(self, name: str):
         start = C.c_uint32()
@@ -204,6 +210,21 @@ class Batch:
         arr = np.ascontiguousarray(arr, dtype=np.uint8)
         assert arr.size == self.n * self.circuit.n_inputs * 32, "input array has the wrong size"
         _chk(lib().cw_set_inputs(self.h, arr.ctypes.data_as(C.c_void_p)))
+
+    def set_inputs_bits(self, masks):
+        """packed boolean inputs: uint64 [groups][n_inputs], bit i of masks[g][k] = input k of instance 64 g + i"""
+        arr = np.ascontiguousarray(masks, dtype=np.uint64)
+        assert arr.shape == ((self.n + 63) // 64, self.circuit.n_inputs), arr.shape
+        _chk(lib().cw_set_inputs_bits(self.h, arr.ctypes.data_as(C.c_void_p)))
+
+    def set_inputs_bits_device(self, dptr: int):
+        _chk(lib().cw_set_inputs_bits_device(self.h, C.c_void_p(dptr)))
+
+    def stream_witnesses_device(self, first: int, count: int, chunk: int, d_buf0: int, d_buf1: int, consume):
+        """consume(first, count, d_chunk, stream) -> int, called once per chunk (cw_stream_witnesses_device)"""
+        CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p)
+        cb = CB(lambda user, f, n, ptr, st: int(consume(f, n, ptr, st) or 0))
+        _chk(lib().cw_stream_witnesses_device(self.h, first, count, chunk, C.c_void_p(d_buf0), C.c_void_p(d_buf1), cb, None))
 
     def set_inputs_device(self, dptr: int):
         _chk(lib().cw_set_inputs_device(self.h, C.c_void_p(dptr)))

@@ -83,7 +83,7 @@ uint32_t cw_batch_lanes(const cw_batch *b);
  * instances whose inputs are not 0/1 are transparently re-run by the 256-bit schedule.  CW_BITS=0 disables it. */
 int cw_batch_bitmode(const cw_batch *b);
 /* shape of the circuit's bit-plane program: out = {present, vrows, bit-table slots per group of 64 instances, LDS ring
- * entries, gate lanes, load lanes, stored values, 0} (all zero when the circuit has none) */
+ * rows, gate lanes, row loads, row flushes, LDS cache rows} (all zero when the circuit has none) */
 int cw_bits_info(const cw_circuit *c, uint64_t out[8]);
 
 /* setInputSignal(h, i, val) (calcwit.cpp:77-97) for one instance; `name` is hashed with FNV-1a
@@ -95,8 +95,17 @@ int cw_set_inputs_json(cw_batch *b, uint32_t instance, const char *json_text);
 /* Bulk: all instances at once, [batch][n_inputs][32] canonical LE values in main-input slot order
  * (slot = cw_input_start() + k).  Marks every input of every instance as set. */
 int cw_set_inputs(cw_batch *b, const uint8_t *le32);
-/* Same, but `d_le32` is a DEVICE pointer (HBM-resident inputs; no host copy). */
+/* Same, but `d_le32` is a DEVICE pointer (HBM-resident inputs; no host copy).  The buffer is read by cw_run (stream
+ * order) and, in bit-plane batches, once more by the first cw_sync / getter after it - instances whose inputs are not 0/1
+ * are re-run by the 256-bit schedule from these bytes - so it must stay unmodified until then. */
 int cw_set_inputs_device(cw_batch *b, const void *d_le32);
+/* Bit-plane batches (cw_batch_bitmode) only: PACKED boolean inputs, uint64 masks[groups][n_inputs], groups =
+ * ceil(batch / 64), bit i of masks[g][k] = main input k of instance 64 g + i.  The reference reads one JSON number per
+ * bit (main.cpp:243-286); the 32-byte-per-value bulk form moves 256 bytes per input BIT of a SHA-256 circuit, this form
+ * one bit.  cw_set_inputs_bits copies from host memory; the _device form keeps reading the caller's device buffer
+ * (same lifetime rule as cw_set_inputs_device).  CW_ESTATE for batches on the 256-bit schedule. */
+int cw_set_inputs_bits(cw_batch *b, const uint64_t *masks);
+int cw_set_inputs_bits_device(cw_batch *b, const void *d_masks);
 /* read back input k (slot cw_input_start()+k) of one instance as staged by the two per-signal setters */
 int cw_get_staged_input(cw_batch *b, uint32_t instance, uint32_t k, uint8_t out[32]);
 /* getRemaingInputsToBeSet() (calcwit.hpp:50-52) of one instance */
@@ -115,8 +124,18 @@ int cw_get_status(cw_batch *b, uint32_t *status /* [batch] */);
 int cw_get_witness(cw_batch *b, uint32_t instance, uint8_t *out);
 /* bulk form for provers: `count` instances from `first`, [count][n_witness][32], one device-side transpose */
 int cw_get_witnesses(cw_batch *b, uint32_t first, uint32_t count, uint8_t *out);
-/* the same to DEVICE memory (no host copy, asynchronous on the batch's stream): what a GPU prover consumes */
+/* the same to DEVICE memory (no host copy): what a GPU prover consumes.  Asynchronous on the batch's stream, except that
+ * the first egress after a cw_run of a bit-plane batch waits for the evaluation (it has to know which instances were
+ * re-run by the 256-bit schedule; every egress serves those from there). */
 int cw_get_witnesses_device(cw_batch *b, uint32_t first, uint32_t count, void *d_out);
+/* chunked form: `chunk` instances at a time into d_buf0 / d_buf1 in turn ([chunk][n_witness][32] each); `consume` is called
+ * after each chunk's transpose has been enqueued on the batch's stream (passed as `stream`, a hipStream_t): work enqueued
+ * there sees the chunk complete and orders the library's next write to that buffer behind itself.  Non-zero return of
+ * `consume` aborts with CW_ESTATE.  (writeBinWitness's loop over getWitness(i), main.cpp:326-332, for a consumer that
+ * cannot hold B x 32 MB.) */
+typedef int (*cw_chunk_fn)(void *user, uint32_t first, uint32_t count, void *d_chunk, void *stream);
+int cw_stream_witnesses_device(cw_batch *b, uint32_t first, uint32_t count, uint32_t chunk, void *d_buf0, void *d_buf1,
+                               cw_chunk_fn consume, void *user);
 /* public signals (main's outputs, then its public inputs = witness positions 1..cw_n_public) of EVERY instance,
  * [batch][n_public][32]: to host memory, or to device memory for a multi-GPU gather */
 int cw_get_public(cw_batch *b, uint8_t *out);
@@ -144,15 +163,24 @@ int cw_r1cs_plan_stats(const cw_circuit *c, uint32_t batch, uint32_t chunks, uin
    cw_get_witnesses_device) returns canonical values, as the reference's Fr_toLongNormal does (main.cpp:326-332). */
 void *cw_device_values(cw_batch *b, uint64_t *n_bytes, uint32_t *padded_batch);
 int cw_circuit_montgomery(const cw_circuit *c);
-/* bit-plane batches: the bit table T[group][slot] (uint64, bit i = instance group*64+i; signal s at slot 3+s);
- * NULL for 256-bit batches (and cw_device_values is NULL for bit-plane batches) */
+/* bit-plane batches: the bit table T[group][slot] (uint64, bit i = instance group*64+i).  Slot 0 / 1 = the constants
+ * 0 / 1, main input k = slot 3 + k; every other signal sits in the slot cw_signal_slots() names (signals that are copies
+ * of one another share a slot; slots follow the order in which the program produces the values, 32-bit words of
+ * consecutive signals keep 32 consecutive slots).  NULL for 256-bit batches (cw_device_values is NULL for bit-plane ones). */
 void *cw_device_bits(cw_batch *b, uint64_t *n_bytes, uint64_t *slots_per_group);
+/* signal -> bit-table slot, n_signals entries (host memory owned by the circuit), NULL when there is no bit program */
+const uint32_t *cw_signal_slots(const cw_circuit *c);
 
 /* ---- field micro-benchmark + unit-test hooks (Fr_* seam 2: bn128/fr.hpp:28-81) --------------------- */
 /* n lanes x iters dependent Montgomery multiplications on the device; out[i] = a[i]*b[i]^iters (raw
  * Montgomery domain).  a,b,out: host [n][32].  ms: kernel time from HIP events. */
 int cw_fp_mul_bench(const uint8_t prime_le32[32], int device, uint32_t n, uint32_t iters, const uint8_t *a,
                     const uint8_t *b, uint8_t *out, float *ms);
+/* Time the bit-plane evaluation kernel on an arbitrary program (records / command blocks as in the .cwt, validated like
+ * a loaded one) for n_groups groups of 64 instances on a zero-filled table: average ms over `iters` launches.  A
+ * measurement hook (tools/bits_shape_bench.py), not part of the witness path. */
+int cw_bits_eval_bench(int device, uint32_t ring, uint32_t cache, uint32_t n_vrows, uint64_t n_slots, const uint32_t *recs,
+                       const uint32_t *cmds, uint32_t n_groups, uint32_t width, uint32_t iters, float *ms);
 /* Element-wise device evaluation of one schedule opcode (D_* numbering of cw_tape.h) on n operand
  * pairs — the unit-test hook for the device field functions.  status[n] receives CW_ST_* bits. */
 int cw_fp_op(const uint8_t prime_le32[32], int device, uint32_t dop, uint32_t n, const uint8_t *a, const uint8_t *b,

@@ -653,105 +653,115 @@ def eval_pipe(q: int, n_signals: int, n_tslots: int, consts, rows, loads, terms,
 
 
 # ---- bit-plane program (circom_amd/hip_elements/bitsched.py), executed the way cw_bits_eval_kernel does ----------------
-B_NONE = 0xFFFFFFFF
-BF_ASSERT = 1
 B_IN_BASE = 3
+B_BATCH = 8
+B_MAX_LOADS = 4
+B_MAX_FLUSH = 6
+B_CMD_WORDS = 24
+B_K_AND = 1
+B_K_OR = 2
 
 
-def eval_bits(recs, n_vrows: int, ring: int, n_slots: int, input_masks: dict, width: int = 1, min_store_slot: int = 3):
+def eval_bits(recs, cmds, ring: int, cache: int, n_slots: int, input_masks: dict, width: int = 1):
     """Replays a bit-plane program on `width` instances at once (python ints as masks: bit i = instance i).
-    input_masks: bit-table slot -> mask of the main inputs (slot B_IN_BASE + k for input k); records are 4 words
-    (bitsched.py).  Mirrors the kernel's timing:
-      * the ring operands of vrow v+1 are read BEFORE vrow v writes its ring entry,
-      * vector memory is touched per batch of 8 vrows: the LOAD lanes of batch b+1 read the bit table when batch b
-        starts, the results of batch b are stored when it ends,
-      * a record's result = LUT(a, b, c) | loaded value (gate lanes load nothing, load lanes carry table 0); LOAD lanes
-        may only sit in even vrows (the kernel issues no bit-table request for odd ones),
-    Raises ScheduleHazard when a read cannot be satisfied by these rules (entry not written yet / already reused,
-    slot never written).  Returns (bit table as list of masks, violation mask of the assertion gates)."""
+    recs: [n_vrows * 64][2] record words, cmds: [n_batches][B_CMD_WORDS] command blocks (bitsched.py); input_masks:
+    bit-table slot -> mask of the main inputs (slot B_IN_BASE + k for input k).  Mirrors the kernel's timing:
+      * the three LDS operands of vrow v+1 are read BEFORE vrow v writes its result entry,
+      * row loads of batch b read the bit table when the batch starts (they see flushes of batches <= b-1) and land in
+        their cache slot between steps 6 and 7 of batch b+1,
+      * flushes of batch b copy a cache slot to the bit table after the last vrow of batch b.
+    LDS entries and table slots start POISONED (None): using a poisoned operand, reading a table row that was never
+    written, or any offset outside the areas raises ScheduleHazard.  Returns the bit table (list of masks / None)."""
     full = (1 << width) - 1
+    n_vrows = len(recs) // 64
+    n_batches = n_vrows // B_BATCH
+    if n_vrows % B_BATCH or len(cmds) != n_batches:
+        raise ScheduleHazard("program is not a whole number of batches with one command block each")
+    if n_slots % 64:
+        raise ScheduleHazard("bit table is not a whole number of rows")
     T = [None] * n_slots
     T[0], T[1], T[2] = 0, full, 0
+    n_in_rows = 0
     for s, m in input_masks.items():
         T[s] = m & full
-    ring_val = [0] * (ring * 64)
-    ring_tag = [-1] * (ring * 64)
-    recs = [[int(x) for x in r] for r in recs]
-    viol = 0
+        n_in_rows = max(n_in_rows, s // 64 + 1)
+    for s in range(n_in_rows * 64):          # padding of the input rows: the init kernel zeroes what ingest does not write
+        if T[s] is None:
+            T[s] = 0
+    ring_bytes = ring * 512
+    const_off = (ring + cache) * 512
+    lds_entries = (ring + cache) * 64 + 2
+    lds = [None] * lds_entries
+    lds[const_off // 8] = 0
+    lds[const_off // 8 + 1] = full
+    recs = [(int(r[0]), int(r[1])) for r in recs]
+    cmds = [[int(x) for x in c] for c in cmds]
 
-    def ring_read(v, lane, off, used):
-        if off % 8 or off // 8 >= ring * 64:
-            raise ScheduleHazard("vrow %d lane %d: ring operand out of range" % (v, lane))
-        if used:
-            tag = ring_tag[off // 8]
-            if tag < 0 or tag > v - 2 or v - tag > ring - 1:
-                raise ScheduleHazard("vrow %d lane %d reads ring entry %d that is not a live older result (written by vrow %d)"
-                                     % (v, lane, off // 8, tag))
-        return ring_val[off // 8]
+    def entry(v, lane, off, what):
+        if off % 8 or off // 8 >= lds_entries:
+            raise ScheduleHazard("vrow %d lane %d: %s offset outside the LDS areas" % (v, lane, what))
+        return off // 8
 
     def early(v):
         out = []
         for lane in range(64):
-            r = recs[v * 64 + lane]
-            t = (r[1] >> 16) & 0xFF
-            # which operands does the table depend on?  (unused fields may point anywhere)
-            dep = [any(((t >> m) & 1) != ((t >> (m ^ (1 << j))) & 1) for m in range(8)) for j in range(3)]
-            out.append([ring_read(v, lane, r[0] & 0xFFFF, dep[0]), ring_read(v, lane, r[0] >> 16, dep[1]),
-                        ring_read(v, lane, r[1] & 0xFFFF, dep[2])])
+            w0, w1 = recs[v * 64 + lane]
+            vals = []
+            for what, off in (("a", w0 & 0xFFF8), ("b", w0 >> 16), ("c", w1 & 0xFFFF)):
+                x = lds[entry(v, lane, off, what)]
+                if x is None:
+                    raise ScheduleHazard("vrow %d lane %d reads LDS entry %d (operand %s) that holds no value" % (v, lane, off // 8, what))
+                vals.append(x)
+            out.append(vals)
         return out
 
-    def gload(v):
+    def parse_cmd(b):
+        c = cmds[b]
+        nl, nf = c[0] & 0xFF, (c[0] >> 8) & 0xFF
+        if nl > B_MAX_LOADS or nf > B_MAX_FLUSH or c[0] >> 16:
+            raise ScheduleHazard("batch %d: command counts" % b)
         out = []
-        for lane in range(64):
-            g = recs[v * 64 + lane][2]
-            if g == B_NONE:
-                out.append(0)
-                continue
-            if v & 1:                 # the kernel requests bit-table values for even vrows only
-                raise ScheduleHazard("vrow %d lane %d: LOAD lane in an odd vrow" % (v, lane))
-            if g % 8 or g // 8 >= n_slots:
-                raise ScheduleHazard("vrow %d lane %d: load slot out of range" % (v, lane))
-            if T[g // 8] is None:
-                raise ScheduleHazard("vrow %d lane %d loads bit slot %d before it is written" % (v, lane, g // 8))
-            out.append(T[g // 8])
-        return out
-
-    NB = 8                                   # vrows per batch (cw_bits.hip BITS_NB)
-    n_batches = (n_vrows + NB - 1) // NB
-
-    def gload_batch(bi):
-        return {v: gload(v) for v in range(bi * NB, min(n_vrows, (bi + 1) * NB))}
+        for j in range(nl + nf):
+            k = j if j < nl else B_MAX_LOADS + (j - nl)
+            goff, loff = c[2 + 2 * k], c[3 + 2 * k]
+            if goff % 512 or goff // 8 + 64 > n_slots:
+                raise ScheduleHazard("batch %d: row outside the bit table" % b)
+            if loff % 512 or loff < ring_bytes or loff + 512 > const_off:
+                raise ScheduleHazard("batch %d: cache slot outside the cache area" % b)
+            out.append((goff // 8, loff // 8))
+        return out[:nl], out[nl:]
 
     fetched = early(0) if n_vrows else []
-    gv = gload_batch(0)                      # prologue
-    for bi in range(n_batches):
-        gnext = gload_batch(bi + 1) if bi + 1 < n_batches else {}     # at the start of the batch, before its steps
-        pending = []
-        for v in range(bi * NB, min(n_vrows, (bi + 1) * NB)):
-            nxt = early(v + 1) if v + 1 < n_vrows else None           # before this vrow's ring write
-            res = [0] * 64
+    in_flight = []                           # rows requested by the previous batch: (values, LDS entry)
+    for b in range(n_batches):
+        loads, flushes = parse_cmd(b)
+        requested = []
+        for g, l in loads:                   # requested when the batch starts
+            row = T[g:g + 64]
+            if any(x is None for x in row) and all(x is None for x in row):
+                raise ScheduleHazard("batch %d loads bit-table row %d before it was written" % (b, g // 64))
+            requested.append((row, l))
+        for k in range(B_BATCH):
+            v = b * B_BATCH + k
+            if k == B_BATCH - 1:             # the rows requested a batch ago land before the last step's operand reads
+                for row, l in in_flight:
+                    lds[l:l + 64] = row
+                in_flight = []
+            nxt = early(v + 1) if v + 1 < n_vrows else None
             for lane in range(64):
-                r = recs[v * 64 + lane]
-                a, b, c = fetched[lane]
-                t = (r[1] >> 16) & 0xFF
-                na, nb_ = full ^ a, full ^ b
-                lo = ((na & nb_) if t & 1 else 0) | ((a & nb_) if t & 2 else 0) | ((na & b) if t & 4 else 0) | ((a & b) if t & 8 else 0)
-                hi = ((na & nb_) if t & 16 else 0) | ((a & nb_) if t & 32 else 0) | ((na & b) if t & 64 else 0) | ((a & b) if t & 128 else 0)
-                x = ((lo & (full ^ c)) | (hi & c)) | gv[v][lane]
-                res[lane] = x
-                if (r[1] >> 24) & BF_ASSERT:
-                    viol |= x
-            base = (v % ring) * 64
-            for lane in range(64):
-                ring_val[base + lane] = res[lane]
-                ring_tag[base + lane] = v
-                d = recs[v * 64 + lane][3]
-                if d != B_NONE:
-                    if d % 8 or d // 8 >= n_slots or d // 8 < min_store_slot:
-                        raise ScheduleHazard("vrow %d lane %d: destination out of range" % (v, lane))
-                    pending.append((d // 8, res[lane]))
+                w0, w1 = recs[v * 64 + lane]
+                a_, b_, c_ = fetched[lane]
+                u = (a_ & b_) if (w0 & B_K_AND) else (a_ ^ b_)
+                r = (u | c_) if (w0 & B_K_OR) else (u ^ c_)
+                if (w0 >> 2) & 1:
+                    raise ScheduleHazard("vrow %d lane %d: reserved record bit" % (v, lane))
+                lds[entry(v, lane, w1 >> 16, "destination")] = r
+                if (w1 >> 16) >= const_off:
+                    raise ScheduleHazard("vrow %d lane %d writes a constant entry" % (v, lane))
             fetched = nxt
-        for sl, val in pending:              # the batch's results are stored when it ends
-            T[sl] = val
-        gv = gnext
-    return T, viol
+        in_flight = requested
+        for g, l in flushes:                 # after the last vrow of the batch
+            if g // 64 < n_in_rows:
+                raise ScheduleHazard("batch %d flushes onto a constant / input row" % b)
+            T[g:g + 64] = lds[l:l + 64]
+    return T

@@ -1,0 +1,38 @@
+"""`python bench.py --gpus 2` started by hand must start TWO ranks itself (the flag used to be parsed
+and ignored).  Rehearsed on CPU: --host-only swaps RCCL for gloo and device batches for host-only ones; everything else
+- the re-exec under torch.distributed.run, rank 0 compiling once, the shards, the one gather - is the code the GPU run
+uses."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _run(args, tmp_path, env_extra=None):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, str(ROOT / "bench.py")] + args + ["--cache-dir", str(tmp_path / "cache")],
+                          capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+
+
+def test_bench_gpus_2_starts_two_ranks(tmp_path):
+    r = _run(["--gpus", "2", "--host-only", "--workload", "poseidon2", "--total-batch", "101"], tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                       # rank 0 prints the one JSON line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["host_only"] is True
+    assert out["gathered"] == {"status_words": 101, "public_signal_rows": 101}
+    assert out["config"]["compile_cached"] is False
+
+
+def test_bench_refuses_a_world_that_is_not_what_was_asked_for(tmp_path):
+    # a launcher environment of ONE rank with --gpus 2 must not print an `n_gpus: 1` line
+    r = _run(["--gpus", "2", "--host-only", "--workload", "poseidon2"], tmp_path,
+             {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)

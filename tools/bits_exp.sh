@@ -1,11 +1,11 @@
 # Build timing-experiment variants of the library (never the product build): tools/bits_exp.sh  -> gpurun_in/exp/lib_<name>.so
+# NORECS: the bit-plane evaluation kernel fetches no records (every batch replays the first): what the record stream costs.
 set -e
 cd "$(dirname "$0")/../circom_amd/csrc"
-mkdir -p ../../gpurun_in/exp
+mkdir -p ../../gpurun_in/exp build
 FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-bitwise-instead-of-logical -Wno-unused-value -w"
-for v in NOSTORE NOLOAD "NOSTORE -DCW_EXP_NOLOAD"; do
-  name=$(echo $v | tr -d ' ' | tr -d '-' | sed 's/DCW_EXP_//g')
-  /opt/rocm/bin/hipcc $FL -DCW_EXP_$v -shared -x hip cw_kernels.hip cw_bits.hip cw_host.cpp -o ../../gpurun_in/exp/lib_$name.so &
+for v in NORECS; do
+  /opt/rocm/bin/hipcc $FL -DCW_EXP_$v -x hip -c cw_bits.hip -o build/cw_bits_$v.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/cw_kernels.hip.o build/cw_bits_$v.o build/cw_host.cpp.o -o ../../gpurun_in/exp/lib_$v.so
 done
-wait
 ls -la ../../gpurun_in/exp/

@@ -9,5 +9,5 @@ name = sys.argv[1] if len(sys.argv) > 1 else "sha256_2048"
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else bench.DEFAULT_BATCH.get(name, 4096)
 root = os.path.join(str(bench.ROOT), "gpurun_in", "cache")
 os.makedirs(root, exist_ok=True)
-cp, s = bench.get_compiled(name, batch, root, 0, None)
+cp, s, _ = bench.get_compiled(name, batch, root, 0, None)
 print("cached", cp.dir, "%.1f s" % s)
