@@ -34,6 +34,12 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
+N_SIMD = 1024             # 256 CUs x 4 SIMD-32
+NOMINAL_CLOCK_HZ = 2.4e9  # max shader clock; profiles carry the clock the kernel actually ran at (GRBM_GUI_ACTIVE / 8 / duration)
+VALU_CLK_PER_WAVE_INST = 2.0       # a SIMD-32 issues a wave64 VALU instruction over 2 clocks (guide; tools/ubench_isa: 2.05 from 2 waves/SIMD)
+LONE_WAVE_CLK_PER_INST = 4.1       # ONE wave issues at most one instruction of any kind per ~4.1 clocks (tools/ubench_isa)
+BITS_VALU_PER_VROW = 10            # cw_bits_eval_kernel<64>, from the disassembly: 3 operand offsets, 2 mask expansions, 1 result
+BITS_INSTS_PER_VROW = 15           # offset, 4 v_bitop3  + 3 ds_read_b64, 1 ds_write_b64, 1 s_waitcnt
 DEFAULT_BATCH = {"sha256_2048": 65536, "sha256_512": 4096, "poseidon2": 65536, "semaphore20": 8192, "semaphore20p": 8192}
 
 
@@ -415,6 +421,7 @@ def main():
     if circ.n_public:
         batch.public_signals_device(pub.data_ptr())
         torch.cuda.synchronize()
+    pub_local = pub
     pub = gather_rows(pub, dist, rank, world)
     n_pub_gathered = int(pub.shape[0]) if rank == 0 else 0
 
@@ -426,26 +433,82 @@ def main():
         parity = parity_check(cp, circ, batch, h_in, args.workload)       # every rank checks its own shard
         parity["parity_checked"] = len(parity["instances"])
 
-    # canonical egress: the 32-byte-per-element image a prover would read (cw_get_witnesses_device), HBM-write bound;
-    # timed on a slice of the batch (the whole image of a 1M-signal circuit x 4096 instances is 134 GB)
+    # canonical egress: the 32-byte-per-element image a prover reads (SURVEY 8d's B_gen: what the reference's
+    # writeBinWitness produces), through the chunked device-side API into two rotating buffers; a pure HBM writer.
+    # Timed on a slice of the batch (the image of a 1M-signal circuit is 32 MB per instance: 2.1 TB for 65 536) alone,
+    # and while the OTHER batch in flight keeps evaluating + checking on its own stream (the overlapped pipeline)
     egress = None
     if rank == 0:
-        n_e = max(1, min(B, (2 << 30) // (circ.n_witness * 32)))
-        buf = torch.empty((n_e, circ.n_witness, 32), dtype=torch.uint8, device=dev)
-        batch.witnesses_device(0, n_e, buf.data_ptr())
+        row_bytes = circ.n_witness * 32
+        chunk = max(1, min(B, (1 << 30) // row_bytes))
+        n_e = min(B, chunk * 8)
+        bufs = [torch.empty((chunk, circ.n_witness, 32), dtype=torch.uint8, device=dev) for _ in range(2)]
+        noop = lambda f, n, ptr, st: 0
+        batch.stream_witnesses_device(0, min(n_e, chunk), chunk, bufs[0].data_ptr(), bufs[1].data_ptr(), noop)   # warm-up (+ resolve)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for _ in range(3):
-            batch.witnesses_device(0, n_e, buf.data_ptr())
-        e1.record(stream)
+        e0.record(streams[0])
+        batch.stream_witnesses_device(0, n_e, chunk, bufs[0].data_ptr(), bufs[1].data_ptr(), noop)
+        e1.record(streams[0])
         torch.cuda.synchronize()
-        e_ms = e0.elapsed_time(e1) / 3
-        e_gbs = n_e * circ.n_witness * 32 / (e_ms * 1e-3) / 1e9
-        egress = {"instances": n_e, "ms": e_ms, "GB/s": e_gbs, "frac_of_hbm_peak": e_gbs / HBM_PEAK_GBS,
-                  "whole_batch_ms": e_ms * B / n_e,
-                  "witnesses_per_s_with_egress": B / (elapsed / args.steps + e_ms * B / n_e * 1e-3)}
-        del buf
+        e_ms = e0.elapsed_time(e1)
+        e_gbs = n_e * row_bytes / (e_ms * 1e-3) / 1e9
+        step_ms = elapsed / args.steps * 1e3
+        whole_ms = e_ms * B / n_e
+        egress = {"instances": n_e, "chunk_instances": chunk, "ms": e_ms, "GB/s": e_gbs, "frac_of_hbm_peak": e_gbs / HBM_PEAK_GBS,
+                  "whole_batch_ms": whole_ms, "witnesses_per_s_with_egress": B / ((step_ms + whole_ms) * 1e-3)}
+        if n_fl > 1:
+            # egress of this batch's slice on stream 0 while the other batch runs whole steps on stream 1
+            k_steps = max(1, int(round(e_ms / max(step_ms, 1e-3))))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            batch.stream_witnesses_device(0, n_e, chunk, bufs[0].data_ptr(), bufs[1].data_ptr(), noop)
+            for _ in range(k_steps):
+                batches[1].run()
+                batches[1].check_r1cs()
+            torch.cuda.synchronize()
+            both_ms = (time.perf_counter() - t1) * 1e3
+            egress["overlapped"] = {"egress_instances": n_e, "steps_alongside": k_steps, "wall_ms": both_ms,
+                                    "sum_of_parts_ms": e_ms + k_steps * step_ms,
+                                    "egress_GB/s_while_evaluating": n_e * row_bytes / (both_ms * 1e-3) / 1e9}
+        del bufs
+
+    # packed boolean inputs (cw_set_inputs_bits_device): one bit per input and instance instead of 32 bytes
+    packed = None
+    if rank == 0 and batch.bitmode and args.workload.startswith("sha256_"):
+        ng = (B + 63) // 64
+        bits01 = np.zeros((ng * 64, circ.n_inputs), dtype=np.uint8)
+        bits01[:B] = h_in[:, :, 0]
+        masks = np.packbits(bits01.reshape(ng, 64, circ.n_inputs), axis=1, bitorder="little")      # [ng][8][n_in] bytes
+        masks = np.ascontiguousarray(masks.transpose(0, 2, 1)).view(np.uint64).reshape(ng, circ.n_inputs)
+        d_masks = torch.from_numpy(masks.view(np.int64)).to(dev)
+        for b_ in batches:
+            b_.set_inputs_bits_device(d_masks.data_ptr())
+        for i in range(n_fl + 1):
+            step(i)
+        torch.cuda.synchronize()
+        iso2 = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        step(0, iso2)                                       # one step alone: evaluation without the 32-byte ingest
+        torch.cuda.synchronize()
+        isolated["eval_only_ms"] = iso2[0].elapsed_time(iso2[1])
+        isolated["ingest_ms"] = max(isolated["eval_ms"] - isolated["eval_only_ms"], 1e-3)
+        pe = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+        t1 = time.perf_counter()
+        for s_ in range(args.steps):
+            step(s_, pe[s_])
+        torch.cuda.synchronize()
+        p_el = time.perf_counter() - t1
+        assert (batch.status() == 0).all()
+        pub2 = torch.empty((B, circ.n_public, 32), dtype=torch.uint8, device=dev)
+        batch.public_signals_device(pub2.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(pub2, pub_local), "packed inputs gave other public signals than the 32-byte inputs"
+        packed = {"ms_per_step": p_el / args.steps * 1e3, "witnesses_per_s": B * args.steps / p_el,
+                  "eval_ms": sum(e[0].elapsed_time(e[1]) for e in pe) / args.steps,
+                  "input_bytes_per_step": int(masks.nbytes), "canonical_input_bytes_per_step": int(h_in.nbytes)}
+        for b_ in batches:
+            b_.set_inputs_device(d_in.data_ptr())
+        del pub2
 
     # Fp mul/s half of the metric: 2^24 lanes x 1024 dependent Montgomery products, bn128 and bls12381
     fp_mul = {}
@@ -482,10 +545,10 @@ def main():
         total_witnesses = n_total * args.steps
         value = total_witnesses / elapsed
         n_in, n_wit = circ.n_inputs, circ.n_witness
-        alg_gen = 32.0 * (n_in + n_wit) * B            # B_gen of SURVEY §8d, per launch
+        alg_gen = 32.0 * (n_in + n_wit) * B            # B_gen of SURVEY §8d, per launch: the canonical 32-byte image
         alg_chk = 32.0 * n_wit * B                     # B_chk
-        # HBM bytes per launch + VALU-busy from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
-        # tools/summarize_prof.py) — only if those passes ran on this exact source (fingerprint), else null
+        # rocprofv3 figures of this exact source (profiles/traffic.json, written by tools/summarize_prof.py: kernel
+        # durations from the kernel trace, HBM bytes / instruction counts / clock from the PMC passes), else null
         prof = {}
         try:
             tj = json.load(open(ROOT / "profiles" / "traffic.json"))
@@ -494,39 +557,69 @@ def main():
                 prof = ent
         except Exception:
             pass
-        gen_gbs = alg_gen / (gen_ms * 1e-3) / 1e9
-        chk_gbs = alg_chk / (chk_ms * 1e-3) / 1e9
         bits = circ.bits_info() if batch.bitmode else {}
         ek = "cw_bits_eval_kernel" if batch.bitmode else "cw_eval_kernel"
         rk = "cw_bits_r1cs_{lut,int,wide}_kernel" if batch.bitmode else "cw_r1cs_stream_kernel"
-        # `achieved` is the ALGORITHMIC byte rate of SURVEY section 8d (32 bytes per witness element written, per input
-        # read).  In bit-plane mode the table holds ONE BIT per distinct signal value, so the HBM bytes really moved
-        # (`traffic`, rocprofv3 counters) are a small fraction of that and `frac` may exceed 1: the representation beats
-        # the byte roof; the kernel's own bound is VALU issue (roofline_valu), the 32-byte image is materialised by the
-        # egress kernel (`canonical_egress`, a true HBM-write-bound kernel).
-        roof_eval = {"bound": "hbm", "kernel": ek, "achieved": gen_gbs, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": gen_gbs / HBM_PEAK_GBS, "traffic": prof.get("eval"),
-                     "valu_busy": prof.get("eval_valu_busy"),
-                     "algorithmic_bytes_per_launch": alg_gen, "kernel_ms": gen_ms,
-                     "strands": batch.strands, "lanes_per_workgroup": batch.lanes}
-        roof_r1cs = {"bound": "hbm", "kernel": rk, "achieved": chk_gbs, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": chk_gbs / HBM_PEAK_GBS, "traffic": prof.get("r1cs"),
-                     "valu_busy": prof.get("r1cs_valu_busy"),
-                     "algorithmic_bytes_per_launch": alg_chk, "kernel_ms": chk_ms}
+        clk = prof.get("eval_clock_hz") or NOMINAL_CLOCK_HZ
+        valu_peak = N_SIMD * clk / VALU_CLK_PER_WAVE_INST     # wave64 VALU instructions per second the chip can issue
         if batch.bitmode:
-            # VALU roof of the bit-plane evaluation: wave-instructions issued per second against the chip's issue rate
-            # (1024 SIMDs x one VALU instruction per 4 clocks at 2.4 GHz); instruction count from the profile when it
-            # was taken on this source, else the kernel's static count per vrow
+            # The bit-plane engine holds ONE BIT per distinct signal value and instance: its kernels neither read nor write
+            # the 32-byte image, so SURVEY 8d's byte roof does not bind them (round 2 divided the image's bytes by their
+            # time and reported "fractions" of 53 and 96).  Their roofs: instruction issue for the evaluation, the scalar /
+            # vector issue mix for the check; the image is priced where it is produced (`value_canonical`, `canonical_egress`).
             waves = ((B + 63) // 64) * (64 // batch.lanes)
-            insts = prof.get("eval_valu_insts") or 44.0 * bits["vrows"] * waves
-            valu_peak = 1024 * 2.4e9 / 4
-            roof_valu = {"bound": "valu", "kernel": ek, "unit": "wave-instructions/s", "achieved": insts / (gen_ms * 1e-3),
-                         "peak": valu_peak, "frac": insts / (gen_ms * 1e-3) / valu_peak, "waves": waves,
-                         "gate_evaluations_per_s": bits["gate_lanes"] * B / (gen_ms * 1e-3)}
+            valu_insts = prof.get("eval_valu_insts") or float(BITS_VALU_PER_VROW) * bits["vrows"] * waves
+            kern_ms = prof.get("eval_avg_us", 0.0) / 1e3 or isolated.get("eval_only_ms") or isolated["eval_ms"]
+            roof_eval = {"bound": "valu", "kernel": ek, "unit": "wave-instructions/s", "achieved": valu_insts / (kern_ms * 1e-3),
+                         "peak": valu_peak, "frac": valu_insts / (kern_ms * 1e-3) / valu_peak,
+                         "traffic": prof.get("eval"), "kernel_ms": kern_ms,
+                         "kernel_ms_source": "rocprofv3 kernel trace (profiles/)" if prof.get("eval_avg_us") else "HIP events, one step alone",
+                         "valu_insts_source": "SQ_INSTS_VALU (profiles/)" if prof.get("eval_valu_insts") else
+                         "%d VALU per vrow and wave (disassembly) x vrows x waves" % BITS_VALU_PER_VROW,
+                         "clock_hz": clk, "waves": waves,
+                         "all_instructions_per_vrow": BITS_INSTS_PER_VROW,
+                         "lone_wave_issue_frac": BITS_INSTS_PER_VROW * bits["vrows"] / (kern_ms * 1e-3) / (clk / LONE_WAVE_CLK_PER_INST),
+                         "gate_evaluations_per_s": bits["gate_lanes"] * B / (kern_ms * 1e-3)}
+            # HBM view of the same launch: bytes the program must move (records once per XCD at best, the table's rows once)
+            tab_bytes = 8.0 * bits["slots_per_group"] * ((B + 63) // 64)
+            roof_eval["hbm"] = {"bit_table_bytes": tab_bytes, "algorithmic_bytes": tab_bytes,
+                                "achieved_GB/s": tab_bytes / (kern_ms * 1e-3) / 1e9, "frac": tab_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "counter_bytes": prof.get("eval"),
+                                "counter_frac": (prof["eval"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if prof.get("eval") else None}
+            chk_kern_ms = prof.get("r1cs_avg_us", 0.0) / 1e3 or isolated["r1cs_check_ms"]
+            chk_insts = prof.get("r1cs_valu_insts")
+            roof_r1cs = {"bound": "valu", "kernel": rk, "unit": "wave-instructions/s",
+                         "achieved": chk_insts / (chk_kern_ms * 1e-3) if chk_insts else None, "peak": valu_peak,
+                         "frac": chk_insts / (chk_kern_ms * 1e-3) / valu_peak if chk_insts else None,
+                         "traffic": prof.get("r1cs"), "kernel_ms": chk_kern_ms,
+                         "hbm": {"algorithmic_bytes": tab_bytes, "achieved_GB/s": tab_bytes / (chk_kern_ms * 1e-3) / 1e9,
+                                 "frac": tab_bytes / (chk_kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "counter_bytes": prof.get("r1cs")}}
+            roof_valu = roof_eval
+            ing_ms = prof.get("ingest_avg_us", 0.0) / 1e3 or isolated.get("ingest_ms")
+            roof_ingest = None if not ing_ms else {"bound": "hbm", "kernel": "cw_bits_ingest_kernel", "unit": "GB/s", "achieved": 32.0 * n_in * B / (ing_ms * 1e-3) / 1e9,
+                           "peak": HBM_PEAK_GBS, "frac": 32.0 * n_in * B / (ing_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": ing_ms,
+                           "algorithmic_bytes_per_launch": 32.0 * n_in * B}
         else:
-            fpk = circ.n_mmul * B / (gen_ms * 1e-3)
+            gen_k = prof.get("eval_avg_us", 0.0) / 1e3 or isolated["eval_ms"]
+            chk_k = prof.get("r1cs_avg_us", 0.0) / 1e3 or isolated["r1cs_check_ms"]
+            gen_gbs = alg_gen / (gen_k * 1e-3) / 1e9
+            chk_gbs = alg_chk / (chk_k * 1e-3) / 1e9
+            roof_eval = {"bound": "hbm", "kernel": ek, "achieved": gen_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gen_gbs / HBM_PEAK_GBS, "traffic": prof.get("eval"), "algorithmic_bytes_per_launch": alg_gen,
+                         "kernel_ms": gen_k, "strands": batch.strands, "lanes_per_workgroup": batch.lanes}
+            roof_r1cs = {"bound": "hbm", "kernel": rk, "achieved": chk_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": chk_gbs / HBM_PEAK_GBS, "traffic": prof.get("r1cs"), "algorithmic_bytes_per_launch": alg_chk,
+                         "kernel_ms": chk_k}
+            fpk = circ.n_mmul * B / (gen_k * 1e-3)
             roof_valu = {"bound": "valu", "kernel": ek, "unit": "Fp-mul/s", "achieved": fpk, "peak": fp_mul_per_s,
-                         "frac": fpk / fp_mul_per_s if fp_mul_per_s else None}
+                         "frac": fpk / fp_mul_per_s if fp_mul_per_s else None,
+                         "valu_wave_insts_per_s": (prof["eval_valu_insts"] / (gen_k * 1e-3)) if prof.get("eval_valu_insts") else None,
+                         "valu_issue_frac": (prof["eval_valu_insts"] / (gen_k * 1e-3) / valu_peak) if prof.get("eval_valu_insts") else None}
+            roof_ingest = None
+        # witnesses per second INCLUDING the 32-byte image (SURVEY 8d's definition of a witness's bytes): the step plus the
+        # egress of the whole batch, sequentially; with the egress overlapped (another batch evaluating meanwhile) the step
+        # hides behind it
+        value_canonical = egress["witnesses_per_s_with_egress"] if egress else None
         out = {
             "metric": "witnesses/sec (batched inputs)",
             "value": value,
@@ -538,28 +631,41 @@ def main():
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
-            "dtype": "u256 (8xu32 limbs, Montgomery multiply)",
+            "dtype": "bit-plane boolean gates on u64 instance masks (u256 Montgomery fallback for non-boolean instances)" if batch.bitmode
+            else "u256 (9x29-bit limbs, Montgomery multiply)",
             "data": "synthetic",
             "config": {"workload": "%s bn128 --O0 (%d constraints), batch=%d per GPU" % (args.workload, circ.n_constraints, B),
+                       "value_is": ("witness generated + R1CS-verified per second, resident as bit planes (1 bit per signal value and "
+                                    "instance); value_canonical includes writing the 32-byte-per-element image") if batch.bitmode else
+                       "witness generated + R1CS-verified per second, resident as 32-byte field elements (the table IS the image)",
                        "n_signals": circ.n_signals, "n_witness": n_wit, "n_constraints": circ.n_constraints,
                        "engine": "bit-plane (1 bit per signal value per instance)" if batch.bitmode else
                        ("256-bit schedule, signals in Montgomery form" if circ.montgomery else "256-bit schedule"),
                        "bit_program": bits, "schedule_rows": circ.n_rows, "fp_mul_per_witness": circ.n_mmul,
                        "parallelism": "instances sharded x%d, status + public-signal gather only" % world,
-                       "in_flight": n_fl, "compile_s": compile_s, "compile_cached": compile_cached},
+                       "in_flight": n_fl, "compile_s": compile_s, "compile_cached": compile_cached,
+                       "shard_of": args.shard_of or None, "total_batch": args.total_batch or None},
+            "value_canonical": value_canonical if batch.bitmode else value,
+            "value_canonical_hbm_frac": (egress["frac_of_hbm_peak"] if egress else None),
             # the dominant kernel of THIS run (longest measured duration)
             "roofline": roof_eval if gen_ms >= chk_ms else roof_r1cs,
             "roofline_eval": roof_eval,
             "roofline_r1cs": roof_r1cs,
+            "roofline_ingest": roof_ingest,
             # second bound of SURVEY §8d (integer work, no MFMA): VALU issue in bit-plane mode, Fp products per second
             # against the measured Fp-multiply peak (micro-benchmark, 2^24 x 1024) for the 256-bit schedule
             "roofline_valu": roof_valu,
+            "valu_peak": {"wave_insts_per_s": valu_peak, "clk_per_wave_inst_per_simd": VALU_CLK_PER_WAVE_INST, "clock_hz": clk,
+                          "calibration": "tools/ubench_isa (profiles/r03_ubench_isa.json): v_bitop3/v_bfi/v_and chains reach 1 "
+                                         "instruction per 2.05 clocks per SIMD from 2 waves per SIMD; ONE wave issues one per 4.1-4.6"},
             "canonical_egress": egress,
+            "packed_inputs": packed,
             "batch_4096": small,
             "fp_mul_per_s": fp_mul_per_s,
             "fp_mul_per_s_by_prime": fp_mul,
-            # eval_ms / r1cs_check_ms / roofline*: averages over the timed region (with in_flight > 1 the two regions of
-            # consecutive steps overlap, so they add up to more than ms_per_step); `isolated`: one step running alone
+            # eval_ms / r1cs_check_ms: HIP-event intervals inside the timed region (with in_flight > 1 the regions of
+            # consecutive steps overlap on the GPU, so each is stretched by the other batch's kernels and they add up to
+            # more than ms_per_step); `isolated`: one step running alone; roofline*.kernel_ms: the kernel's own duration
             "eval_ms": gen_ms,
             "r1cs_check_ms": chk_ms,
             "isolated": isolated,

@@ -85,6 +85,11 @@ __global__ void __launch_bounds__(64) cw_bits_ingest_kernel(const uint4 *__restr
 #define BITS_CMD_WORDS 24
 #define BITS_AHEAD 4          // records are requested this many batches ahead (BITS_AHEAD + 1 register sets of 16 dwords): two
                               // batches (~0.7 us) proved shorter than the latency of the stream, +25 ns per vrow of waiting
+#ifndef BITS_STORE_AUX
+#define BITS_STORE_AUX 2      // cache policy of the row flushes: nt (streaming).  A flushed row is dead for this kernel; with the default
+                              // policy the 1.2 GB of rows a launch writes thrashed the 4 MB L2s and the in-order vmcnt made the record
+                              // loads wait behind slow stores: 1.24 -> 0.91 ms for Sha256(2048) x 65 536 (tools/bits_shape_bench.py)
+#endif
 #define BITS_OOR 0xFFFFFFF0u
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -138,7 +143,7 @@ template <> struct BitsMask<64> {
     }
     static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t r, uint32_t off, T v) {
         const u32x2 x = {(uint32_t)v, (uint32_t)(v >> 32)};
-        __builtin_amdgcn_raw_buffer_store_b64(x, r, (int)off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(x, r, (int)off, 0, BITS_STORE_AUX);
     }
     static __device__ __forceinline__ T prim(T a, T b, T c, uint32_t k1, uint32_t k2) {
         // one block: the compiler then waits ONCE for the three LDS operands instead of once per stage (a wave alone on
@@ -190,47 +195,73 @@ template <int W>
 struct BitsEval {
     typedef BitsMask<W> M;
     typedef typename M::T mask_t;
-    const uint4 *__restrict__ recs;
-    const uint32_t *__restrict__ cmds;
-    __amdgpu_buffer_rsrc_t rsrc;
+    __amdgpu_buffer_rsrc_t rsrc, rrecs, rcmds;   // the group's bit table; the record stream; the command blocks
     uint32_t lane8;
     mask_t a, b, c;
-    uint32_t pn, poff[BITS_MAX_LOADS];           // row loads of the previous batch still to be written to the LDS (wave-uniform)
+    // command blocks travel in ONE VGPR each (lane j = word j, a 96-byte vector load a batch ahead) and are read with
+    // v_readlane where a wave-uniform value is needed.  Scalar loads would be the natural fit, but they share the
+    // LGKM counter with the LDS and return out of order: with one in flight hipcc turns every LDS wait into
+    // lgkmcnt(0) - the pipelined operand reads of the next steps then serialise behind a ~200-clock scalar load.
+    uint32_t cprev, ccur, cnext;
 
     static __device__ __forceinline__ uint32_t word(const uint4 (&r)[4], int k, int i) {
         const int d = 2 * k + i;
         const uint4 &q = r[d >> 2];
         return (d & 3) == 0 ? q.x : (d & 3) == 1 ? q.y : (d & 3) == 2 ? q.z : q.w;
     }
+    static __device__ __forceinline__ uint32_t cw(uint32_t blk, int j) { return (uint32_t)__builtin_amdgcn_readlane((int)blk, j); }
 
-    // ccur: command block of this batch (requested a batch ago, resident in SGPRs), cfill: receives the next one
+    // records of batch b, load j: 1 KiB at (b * 4 + j) * 1024, lane l takes 16 bytes at l * 16 (32-bit lane offset +
+    // scalar batch offset)
+    __device__ __forceinline__ uint4 rec_load(uint32_t b, int j) const {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rrecs, (int)(lane8 * 2), (int)((b * 4 + j) * 1024u), 0);
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+    __device__ __forceinline__ uint32_t cmd_load(uint32_t b) const {
+        return __builtin_amdgcn_raw_buffer_load_b32(rcmds, (int)(lane8 >> 1), (int)(b * (BITS_CMD_WORDS * 4u)), 0);
+    }
+
     __device__ __forceinline__ void batch(uint32_t bi, const uint4 (&cur)[4], const uint4 (&nxt)[4], uint4 (&fill)[4],
-                                          const mask_t (&lprev)[BITS_MAX_LOADS], mask_t (&lfill)[BITS_MAX_LOADS],
-                                          const uint32_t (&ccur)[BITS_CMD_WORDS], uint32_t (&cfill)[BITS_CMD_WORDS]) {
-        const uint32_t nl = ccur[0] & 0xFFu, nf = (ccur[0] >> 8) & 0xFFu;
-        // row loads first: when they are awaited (a batch later) at least the eight unconditional record loads issued
-        // behind them stand between, so the compiler's vmcnt never waits for a request younger than a batch
+                                          const mask_t (&lprev)[BITS_MAX_LOADS], mask_t (&lfill)[BITS_MAX_LOADS]) {
+        // the rows the PREVIOUS batch completed leave now: the first two (a batch completes 1.4 rows on average) are read
+        // from the LDS before anything of this batch is written and stored a step later, without a wait on the spot
+        const uint32_t pcounts = cw(cprev, 0), pn = pcounts & 0xFFu, fn = (pcounts >> 8) & 0xFFu;
+        const mask_t fv0 = M::lds(cw(cprev, 3 + 2 * BITS_MAX_LOADS) + lane8);          // unused entries are 0: ring row 0
+        const mask_t fv1 = M::lds(cw(cprev, 5 + 2 * BITS_MAX_LOADS) + lane8);
+        const uint32_t nl = cw(ccur, 0) & 0xFFu;
+        // row loads first: when they are awaited (a batch later) the unconditional record loads issued behind them stand
+        // between, so the compiler's vmcnt never waits for a request younger than a batch
         if (nl) {                                   // rare (a few row loads per hundred batches): one branch in the common case
 #pragma unroll
             for (int j = 0; j < BITS_MAX_LOADS; j++)
-                if (j < (int)nl) lfill[j] = M::load(rsrc, ccur[2 + 2 * j] + lane8);
+                if (j < (int)nl) lfill[j] = M::load(rsrc, cw(ccur, 2 + 2 * j) + lane8);
         }
 #ifdef CW_EXP_NORECS      /* timing experiment only (tools/bits_exp.sh): no record fetch, every batch replays the first */
 #pragma unroll
         for (int j = 0; j < 4; j++) fill[j] = cur[j];
 #else
 #pragma unroll
-        for (int j = 0; j < 4; j++) fill[j] = recs[((size_t)(bi + BITS_AHEAD) * 4 + j) * 64 + (lane8 >> 3)];
+        for (int j = 0; j < 4; j++) fill[j] = rec_load(bi + BITS_AHEAD, j);
 #endif
-        const uint32_t *ncmd = cmds + (size_t)(bi + 1) * BITS_CMD_WORDS;
-#pragma unroll
-        for (int j = 0; j < BITS_CMD_WORDS; j++) cfill[j] = ncmd[j];
+        cnext = cmd_load(bi + 1);
 #pragma unroll
         for (int k = 0; k < BITS_NB; k++) {
+            if (k == 1) {
+                asm volatile("" ::"v"(fv0), "v"(fv1));          // the two reads are complete HERE on every path
+                if (fn) {
+                    M::store(rsrc, cw(cprev, 2 + 2 * BITS_MAX_LOADS) + lane8, fv0);
+                    if (fn > 1) M::store(rsrc, cw(cprev, 4 + 2 * BITS_MAX_LOADS) + lane8, fv1);
+                    if (fn > 2) {
+#pragma unroll
+                        for (int j = 2; j < BITS_MAX_FLUSH; j++)
+                            if (j < (int)fn) M::store(rsrc, cw(cprev, 2 + 2 * BITS_MAX_LOADS + 2 * j) + lane8, M::lds(cw(cprev, 3 + 2 * BITS_MAX_LOADS + 2 * j) + lane8));
+                    }
+                }
+            }
             if (k == BITS_NB - 1 && pn) {
 #pragma unroll
                 for (int j = 0; j < BITS_MAX_LOADS; j++)
-                    if (j < (int)pn) M::lds_st(poff[j] + lane8, lprev[j]);
+                    if (j < (int)pn) M::lds_st(cw(cprev, 3 + 2 * j) + lane8, lprev[j]);
             }
             const uint32_t n0 = k + 1 < BITS_NB ? word(cur, k + 1 < BITS_NB ? k + 1 : 0, 0) : word(nxt, 0, 0);
             const uint32_t n1 = k + 1 < BITS_NB ? word(cur, k + 1 < BITS_NB ? k + 1 : 0, 1) : word(nxt, 0, 1);
@@ -240,18 +271,16 @@ struct BitsEval {
             M::lds_st(w1 >> 16, M::prim(a, b, c, k1, k2));
             a = na; b = nb; c = nc;
         }
-        if (nf) {
-            mask_t fv[BITS_MAX_FLUSH];
+        cprev = ccur;
+        ccur = cnext;
+    }
+
+    // after the last batch: what it completed, and the row loads it may still hold are dropped (nothing reads them)
+    __device__ __forceinline__ void drain() {
+        const uint32_t fn = (cw(cprev, 0) >> 8) & 0xFFu;
 #pragma unroll
-            for (int j = 0; j < BITS_MAX_FLUSH; j++)       // unconditional reads (slots beyond the count read ring row 0)
-                fv[j] = M::lds((j < (int)nf ? ccur[3 + 2 * BITS_MAX_LOADS + 2 * j] : 0u) + lane8);
-#pragma unroll
-            for (int j = 0; j < BITS_MAX_FLUSH; j++)
-                if (j < (int)nf) M::store(rsrc, ccur[2 + 2 * BITS_MAX_LOADS + 2 * j] + lane8, fv[j]);
-        }
-        pn = nl;
-#pragma unroll
-        for (int j = 0; j < BITS_MAX_LOADS; j++) poff[j] = ccur[3 + 2 * j];
+        for (int j = 0; j < BITS_MAX_FLUSH; j++)
+            if (j < (int)fn) M::store(rsrc, cw(cprev, 2 + 2 * BITS_MAX_LOADS + 2 * j) + lane8, M::lds(cw(cprev, 3 + 2 * BITS_MAX_LOADS + 2 * j) + lane8));
     }
 };
 
@@ -265,16 +294,13 @@ cw_bits_eval_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict__
     char *Tg = (char *)(T + (size_t)g * slots) + slice * (W / 8);
     if (n_batches == 0) return;
     BitsEval<W> E;
-    E.recs = recs;
-    E.cmds = cmds;
-    // the dynamic LDS of this kernel starts at LDS address 0 (it declares no static LDS): records carry raw LDS offsets
-    // buffer descriptor of this group's table (wave-uniform by construction: kernel arguments and blockIdx only);
-    // a wave of a narrower slice addresses its bytes of every 8-byte mask through the shifted base
+    // buffer descriptors (wave-uniform by construction: kernel arguments and blockIdx only); a wave of a narrower slice
+    // addresses its bytes of every 8-byte mask through the shifted base
     E.rsrc = __builtin_amdgcn_make_buffer_rsrc(Tg, 0, (int)(uint32_t)(slots * 8 - slice * (W / 8)), 0x00020000);
+    E.rrecs = __builtin_amdgcn_make_buffer_rsrc((void *)recs, 0, (int)((n_batches + BITS_AHEAD) * 4096u), 0x00020000);
+    E.rcmds = __builtin_amdgcn_make_buffer_rsrc((void *)cmds, 0, (int)((n_batches + BITS_AHEAD) * (BITS_CMD_WORDS * 4u)), 0x00020000);
     E.lane8 = lane * 8;
-    E.pn = 0;
-#pragma unroll
-    for (int j = 0; j < BITS_MAX_LOADS; j++) E.poff[j] = 0;
+    // the dynamic LDS of this kernel starts at LDS address 0 (it declares no static LDS): records carry raw LDS offsets
     if (lane == 0) {
         M::lds_st(const_off, (mask_t)0);
         M::lds_st(const_off + 8, (mask_t)~(mask_t)0);
@@ -283,38 +309,39 @@ cw_bits_eval_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict__
     // the kernel deterministic when a damaged program names an entry that was never written)
     for (uint32_t o = E.lane8; o < const_off; o += 512) M::lds_st(o, (mask_t)0);
     // the host pads the stream to whole trips of ten batches and appends BITS_AHEAD empty ones (records are requested
-    // BITS_AHEAD batches ahead); five record sets, two loaded-row sets and two command-block sets rotate by NAME through
-    // the ten expansions of the batch body
+    // BITS_AHEAD batches ahead); five record sets and two loaded-row sets rotate by NAME through the ten expansions of
+    // the batch body (no register moves)
     uint4 R0[4], R1[4], R2[4], R3[4], R4[4];
     mask_t L0[BITS_MAX_LOADS], L1[BITS_MAX_LOADS];
 #pragma unroll
     for (int j = 0; j < BITS_MAX_LOADS; j++) L0[j] = L1[j] = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        R0[j] = recs[(size_t)j * 64 + lane];
-        R1[j] = recs[((size_t)4 + j) * 64 + lane];
-        R2[j] = recs[((size_t)8 + j) * 64 + lane];
-        R3[j] = recs[((size_t)12 + j) * 64 + lane];
+        R0[j] = E.rec_load(0, j);
+        R1[j] = E.rec_load(1, j);
+        R2[j] = E.rec_load(2, j);
+        R3[j] = E.rec_load(3, j);
     }
-    uint32_t C0[BITS_CMD_WORDS], C1[BITS_CMD_WORDS];
-#pragma unroll
-    for (int j = 0; j < BITS_CMD_WORDS; j++) { C0[j] = cmds[j]; C1[j] = 0; }
+    E.cprev = 0;
+    E.ccur = E.cmd_load(0);
+    E.cnext = 0;
     E.a = M::lds(R0[0].x & 0xFFF8u);
     E.b = M::lds(R0[0].x >> 16);
     E.c = M::lds(R0[0].y & 0xFFFFu);
     static_assert(BITS_AHEAD == 4, "the rotation below is written for five record sets");
     for (uint32_t bi = 0; bi < n_batches; bi += 10) {
-        E.batch(bi + 0, R0, R1, R4, L0, L1, C0, C1);
-        E.batch(bi + 1, R1, R2, R0, L1, L0, C1, C0);
-        E.batch(bi + 2, R2, R3, R1, L0, L1, C0, C1);
-        E.batch(bi + 3, R3, R4, R2, L1, L0, C1, C0);
-        E.batch(bi + 4, R4, R0, R3, L0, L1, C0, C1);
-        E.batch(bi + 5, R0, R1, R4, L1, L0, C1, C0);
-        E.batch(bi + 6, R1, R2, R0, L0, L1, C0, C1);
-        E.batch(bi + 7, R2, R3, R1, L1, L0, C1, C0);
-        E.batch(bi + 8, R3, R4, R2, L0, L1, C0, C1);
-        E.batch(bi + 9, R4, R0, R3, L1, L0, C1, C0);
+        E.batch(bi + 0, R0, R1, R4, L0, L1);
+        E.batch(bi + 1, R1, R2, R0, L1, L0);
+        E.batch(bi + 2, R2, R3, R1, L0, L1);
+        E.batch(bi + 3, R3, R4, R2, L1, L0);
+        E.batch(bi + 4, R4, R0, R3, L0, L1);
+        E.batch(bi + 5, R0, R1, R4, L1, L0);
+        E.batch(bi + 6, R1, R2, R0, L0, L1);
+        E.batch(bi + 7, R2, R3, R1, L1, L0);
+        E.batch(bi + 8, R3, R4, R2, L0, L1);
+        E.batch(bi + 9, R4, R0, R3, L1, L0);
     }
+    E.drain();
 }
 
 // instances that tripped an assertion gate: the program gives every assertion value a bit-table slot; a mask that is not

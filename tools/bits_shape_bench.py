@@ -48,6 +48,14 @@ def run(label, r, cm):
 zero_cmds = np.zeros_like(cmds)
 run("real", recs, cmds)
 run("norows", recs, zero_cmds)
+nf_only = cmds.copy(); nf_only[:, 0] &= 0xFF00        # flushes only
+nl_only = cmds.copy(); nl_only[:, 0] &= 0x00FF        # loads only
+run("flushes", recs, nf_only)
+run("loads", recs, nl_only)
+same = nf_only.copy()                                  # every flush onto ONE row of the table (no HBM write-back volume)
+for j in range(6):
+    same[:, 2 + 8 + 2 * j] = (n_slots // 64 - 1) * 512
+run("flush1row", recs, same)
 al = recs.copy()
 w0, w1 = al[:, 0], al[:, 1]
 def realign(off):
