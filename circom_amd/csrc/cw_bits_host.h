@@ -404,7 +404,21 @@ inline R1Plan build_r1cs(const std::vector<uint32_t> &r_ptr, const std::vector<u
     p.n_chunks = (uint32_t)(p.chunk.size() / 4);
     p.n_evrows = (uint32_t)((erows.size() / 8 + 63) / 64);
     p.erecs.assign((size_t)p.n_evrows * 64 * 8, 0);
-    std::copy(erows.begin(), erows.end(), p.erecs.begin());
+    {   // neighbouring lanes read neighbouring slots: records ordered by the youngest (highest) slot they read, so that the 64
+        // lanes of a vrow - five scattered 8-byte loads each - fall into a few rows of the table instead of all over it
+        const size_t n = erows.size() / 8;
+        std::vector<std::pair<uint64_t, uint32_t>> key(n);
+        for (size_t i = 0; i < n; i++) {
+            uint32_t hi = 0, lo = 0xFFFFFFFFu;
+            for (int k = 0; k < 5; k++) {
+                hi = std::max(hi, erows[i * 8 + k]);
+                if (erows[i * 8 + k]) lo = std::min(lo, erows[i * 8 + k]);
+            }
+            key[i] = {((uint64_t)hi << 32) | lo, (uint32_t)i};
+        }
+        std::sort(key.begin(), key.end());
+        for (size_t i = 0; i < n; i++) std::copy(erows.begin() + (size_t)key[i].second * 8, erows.begin() + (size_t)key[i].second * 8 + 8, p.erecs.begin() + i * 8);
+    }
     if (p.terms.empty()) p.terms.assign(2, 0);
     if (p.row_orig.empty()) p.row_orig.assign(1, 0);
     if (p.chunk.empty()) p.chunk.assign(4, 0);

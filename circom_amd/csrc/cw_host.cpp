@@ -1378,6 +1378,17 @@ extern "C" int cw_bits_info(const cw_circuit *c, uint64_t out[8]) {
     out[7] = bp.cache;
     return CW_OK;
 }
+// host-only: shape of the R1CS check plan over the bit table (cw_bits_host.h::build_r1cs): how the slot assignment of
+// the bit program serves the check (whole-word terms need 32 consecutive slots)
+extern "C" int cw_bits_r1cs_plan_stats(const cw_circuit *c, uint64_t out[8]) {
+    if (!c || !out) return fail(CW_EINVAL, "null argument");
+    memset(out, 0, 64);
+    if (!c->has_bits || !c->n_constraints) return CW_OK;
+    cwbits::R1Plan p = cwbits::build_r1cs(c->r_ptr, c->r_slot, c->r_cc, c->r_cctab, c->r_orig, c->bits.sig_slot, c->q.w, 256);
+    out[0] = p.n_trivial; out[1] = p.n_lut; out[2] = p.n_int; out[3] = p.n_word_terms; out[4] = p.n_int_blocks;
+    out[5] = p.n_contig_blocks; out[6] = p.n_wide; out[7] = p.iwords.size();
+    return CW_OK;
+}
 extern "C" uint32_t cw_batch_size(const cw_batch *b) { return b->batch; }
 extern "C" int cw_circuit_montgomery(const cw_circuit *c) { return c && c->mont ? 1 : 0; }
 extern "C" uint32_t cw_batch_strands(const cw_batch *b) { return b->var ? b->var->n_strands : 0; }

@@ -21,8 +21,9 @@ Timing contract (mirrored by oracle/tape_eval.py::eval_bits and checked there):
   * operands of vrow v+1 are read BEFORE vrow v writes its result: a consumer sits >= LATENCY = 2 vrows behind its producer;
   * a ring entry lives R - 1 vrows;
   * batch b: row loads of cmd[b] are requested when the batch starts and written to their cache slots between steps 6
-    and 7 of batch b + 1 (readable by every vrow of batch b + 2); flushes of cmd[b] copy a cache slot to the table after
-    the last vrow of batch b; a load of batch b sees flushes of batches <= b - 1.
+    and 7 of batch b + 1 (readable by every vrow of batch b + 2); flushes of cmd[b] copy a cache slot to the table DURING
+    batch b + 1 (the kernel reads the first two slots before that batch's first vrow and the others after it: nothing may
+    overwrite a flushed slot before batch b + 2); a load of batch b sees flushes of batches <= b - 2.
 A row is flushed exactly once, when all its positions are produced (never read-modify-write).  Signals that the R1CS
 check reads as whole 32-bit words (32 consecutive signals) keep 32 consecutive slots: the first of them to be produced
 reserves half a row for all of them (ATOMS); the row stays pinned until they all arrived.
@@ -53,7 +54,7 @@ MAX_FLUSH = 6                 # row flushes per batch
 CMD_WORDS = 24
 LOAD_DELAY = 2                # a row requested in batch b is readable from batch b + LOAD_DELAY
 ATOM = 32                     # signals the R1CS check reads as one word
-ATOM_SPREAD = 40              # levels: an atom whose members are further apart than this is not kept together
+ATOM_SPREAD = 64              # levels: an atom whose members are further apart than this is not kept together
 PREFETCH_PENDING = -1         # rows of an operation's operands are requested when this many of its producers are still missing (-1: on demand only)
 WINDOW = 8                    # levels an operation may run ahead of the frontier
 CLOSE_AGE = 64                # vrows after which a half-filled atom row with nothing pending is closed
@@ -129,9 +130,40 @@ def _schedule(net: PrimNet, fc, ring: int, cache: int, extra_homes: set, WINDOW:
     for s_ in range(n_signals - 1, -1, -1):
         first_sig[int(sig_node[s_])] = s_
     level = net.level
-    sg = sorted((first_sig[i], i) for i in range(2, n_nodes) if stored[i] and i in first_sig)
     atom_of = {}                              # node -> (atom id, index)
     atoms = []                                # [base slot or None, members]
+    # (1) words the R1CS check reads whole (cw_bits_host.h: 32 consecutive slots carrying 2^0 .. 2^31 of one sign inside one
+    #     32-bit half of a long linear row - BinSum's `lin === lout`, Bits2Num): taken from the constraints themselves
+    q = fc.fp.q
+    pow2 = {}
+    for k in range(64):
+        pow2[1 << k] = (0, k)
+        pow2[q - (1 << k)] = (1, k)
+    for cons in getattr(fc, "constraints", ()):
+        if len(cons[0]) + len(cons[1]) + len(cons[2]) < 33:
+            continue
+        for part in cons:
+            if len(part) < 32:
+                continue
+            words = {}
+            for sgn, cf in part.items():
+                pk = pow2.get(cf)
+                if pk is not None:
+                    words.setdefault((pk[0], pk[1] // 32), {})[pk[1] % 32] = sgn
+            for w in words.values():
+                if len(w) != 32:
+                    continue
+                mem = [int(sig_node[w[k]]) for k in range(32)]
+                if len(set(mem)) != 32 or any((not stored[n]) or n in atom_of for n in mem):
+                    continue
+                lv = [level[n] for n in mem]
+                if max(lv) - min(lv) > ATOM_SPREAD:
+                    continue
+                for j, n in enumerate(mem):
+                    atom_of[n] = (len(atoms), j)
+                atoms.append([None, mem])
+    # (2) runs of 32 consecutive signals among the rest (the check's blocks of 8 single-bit terms want consecutive slots too)
+    sg = sorted((first_sig[i], i) for i in range(2, n_nodes) if stored[i] and i in first_sig and i not in atom_of)
     run = []
 
     def close_run():
@@ -220,6 +252,7 @@ def _schedule(net: PrimNet, fc, ring: int, cache: int, extra_homes: set, WINDOW:
     slot_used = [0] * cache                   # positions handed out
     slot_open_at = [0] * cache
     slot_dirty = [False] * cache
+    slot_free_at = [0] * cache                # first vrow that may overwrite the slot (a flushed row is read by the batch AFTER its flush)
     resident = {}                             # row -> cache slot
     row_flushed = {}                          # row -> batch of its flush (input rows: -10)
     for r_ in range(n_in_rows):
@@ -258,7 +291,7 @@ def _schedule(net: PrimNet, fc, ring: int, cache: int, extra_homes: set, WINDOW:
             st = slot_state[s_]
             if st == FREE:
                 return s_
-            if st == CLEAN and slot_last[s_] <= now and slot_ready[s_] <= now:
+            if st == CLEAN and slot_last[s_] <= now and slot_ready[s_] <= now and slot_free_at[s_] <= now:
                 key = (1 if row_refs.get(slot_row[s_], 0) > 0 else 0, slot_last[s_])
                 if best_key is None or key < best_key:
                     best, best_key = s_, key
@@ -289,7 +322,7 @@ def _schedule(net: PrimNet, fc, ring: int, cache: int, extra_homes: set, WINDOW:
         """returns the vrow from which the row is readable, or -1 if the request cannot be issued in this batch"""
         b = batch_of(now)
         ensure_batch(b)
-        if len(cmd_loads[b]) >= MAX_LOADS or row_flushed.get(row, 1 << 60) > b - 1:
+        if len(cmd_loads[b]) >= MAX_LOADS or row_flushed.get(row, 1 << 60) > b - 2:
             return -1
         s_ = take_slot(now)
         if s_ < 0:
@@ -366,6 +399,7 @@ def _schedule(net: PrimNet, fc, ring: int, cache: int, extra_homes: set, WINDOW:
                 cmd_flush[b].append((slot_row[s_], s_))
                 stat["flushes"] += 1
                 row_flushed[slot_row[s_]] = b
+                slot_free_at[s_] = (b + 2) * BATCH
                 slot_state[s_] = CLEAN
                 slot_dirty[s_] = False
                 slot_ready[s_] = 0

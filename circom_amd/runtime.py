@@ -65,6 +65,7 @@ _SIGS = {
     "cw_batch_lanes": (C.c_uint32, [C.c_void_p]),
     "cw_batch_bitmode": (C.c_int, [C.c_void_p]),
     "cw_bits_info": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cw_bits_r1cs_plan_stats": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cw_device_bits": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "cw_set_input_signal": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p]),
     "cw_set_inputs_json": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p]),
@@ -156,6 +157,12 @@ class Circuit:
         if not out[0]:
             return {}
         return dict(zip(("vrows", "slots_per_group", "ring", "gate_lanes", "row_loads", "row_flushes", "cache"), [int(x) for x in out[1:8]]))
+
+    def bits_r1cs_plan_stats(self) -> dict:
+        out = (C.c_uint64 * 8)()
+        _chk(lib().cw_bits_r1cs_plan_stats(self.h, out))
+        return dict(zip(("trivial_rows", "lut_rows", "int_rows", "word_terms", "bit_blocks", "contiguous_blocks", "field_rows", "int_stream_words"),
+                        [int(x) for x in out]))
 
     def input_size(self, name: str):
         start = C.c_uint32()

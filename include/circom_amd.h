@@ -85,6 +85,10 @@ int cw_batch_bitmode(const cw_batch *b);
 /* shape of the circuit's bit-plane program: out = {present, vrows, bit-table slots per group of 64 instances, LDS ring
  * rows, gate lanes, row loads, row flushes, LDS cache rows} (all zero when the circuit has none) */
 int cw_bits_info(const cw_circuit *c, uint64_t out[8]);
+/* host-only: shape of the R1CS check plan over the bit table: out = {rows that hold by construction, LUT-class rows,
+ * integer-class rows, terms read as whole 32-bit words, blocks of 8 single-bit terms, of which on 8 consecutive slots,
+ * field-class rows, words of the integer-class stream} */
+int cw_bits_r1cs_plan_stats(const cw_circuit *c, uint64_t out[8]);
 
 /* setInputSignal(h, i, val) (calcwit.cpp:77-97) for one instance; `name` is hashed with FNV-1a
  * (calcwit.cpp:17-24).  val = canonical 32-byte little-endian value, reduced mod q by the caller. */

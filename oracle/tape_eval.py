@@ -669,7 +669,9 @@ def eval_bits(recs, cmds, ring: int, cache: int, n_slots: int, input_masks: dict
       * the three LDS operands of vrow v+1 are read BEFORE vrow v writes its result entry,
       * row loads of batch b read the bit table when the batch starts (they see flushes of batches <= b-1) and land in
         their cache slot between steps 6 and 7 of batch b+1,
-      * flushes of batch b copy a cache slot to the bit table after the last vrow of batch b.
+      * flushes of batch b copy a cache slot to the bit table DURING batch b+1: the first two entries of the command block
+        are read before that batch's first vrow writes, the others after it (cw_bits.hip); their stores are issued in
+        batch b+1, so a load sees flushes of batches <= its own - 2,
     LDS entries and table slots start POISONED (None): using a poisoned operand, reading a table row that was never
     written, or any offset outside the areas raises ScheduleHazard.  Returns the bit table (list of masks / None)."""
     full = (1 << width) - 1
@@ -733,8 +735,15 @@ def eval_bits(recs, cmds, ring: int, cache: int, n_slots: int, input_masks: dict
 
     fetched = early(0) if n_vrows else []
     in_flight = []                           # rows requested by the previous batch: (values, LDS entry)
-    for b in range(n_batches):
+    pending_flush = []                       # flushes of the previous batch: (table slot, LDS entry)
+    for b in range(n_batches + 1):
+        if b == n_batches:                   # the kernel's drain after the last batch
+            for g, l in pending_flush:
+                T[g:g + 64] = lds[l:l + 64]
+            break
         loads, flushes = parse_cmd(b)
+        early_flush = [(g, lds[l:l + 64]) for g, l in pending_flush[:2]]      # read before this batch's first vrow writes
+        late_flush = pending_flush[2:]
         requested = []
         for g, l in loads:                   # requested when the batch starts
             row = T[g:g + 64]
@@ -759,9 +768,14 @@ def eval_bits(recs, cmds, ring: int, cache: int, n_slots: int, input_masks: dict
                 if (w1 >> 16) >= const_off:
                     raise ScheduleHazard("vrow %d lane %d writes a constant entry" % (v, lane))
             fetched = nxt
+            if k == 0:                       # the stores of the previous batch's flushes leave after this batch's first vrow
+                for g, row in early_flush:
+                    T[g:g + 64] = row
+                for g, l in late_flush:
+                    T[g:g + 64] = lds[l:l + 64]
         in_flight = requested
-        for g, l in flushes:                 # after the last vrow of the batch
+        for g, l in flushes:
             if g // 64 < n_in_rows:
                 raise ScheduleHazard("batch %d flushes onto a constant / input row" % b)
-            T[g:g + 64] = lds[l:l + 64]
+        pending_flush = flushes
     return T
