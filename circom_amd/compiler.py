@@ -55,6 +55,8 @@ def choose_mont(fc: FlatCircuit) -> bool:
 
 
 BITS_AUTO_MIN_SIGNALS = 4096
+BITS_AUTO_MIN_SIGNALS_PER_GATE = 16     # "auto" wants at least one gate per 16 signals (see lower_bitplane)
+BITS_KEEP_STRANDS_BELOW = 200_000       # signals: smaller circuits keep every strand variant next to the bit program
 
 
 def lower_bitplane(fc: FlatCircuit, bits="auto"):
@@ -69,7 +71,14 @@ def lower_bitplane(fc: FlatCircuit, bits="auto"):
     if net is None:
         return None
     from .hip_elements.bitmap import map_network
-    return lower_bits(map_network(net), fc)
+    bt = lower_bits(map_network(net), fc)
+    # Evidence that the circuit really is bit-level: the analysis only proves "boolean IF the inputs are 0/1" - a Num2Bits or
+    # range check on field-valued inputs passes it with a handful of gates (everything else is discharged symbolically) and
+    # would then send every instance through the non-boolean fallback.  A bit-level circuit has gates in proportion to its
+    # signals (SHA-256: 0.7 per signal).
+    if bt is not None and bits == "auto" and bt.stats["gates"] * BITS_AUTO_MIN_SIGNALS_PER_GATE < fc.n_signals:
+        return None
+    return bt
 
 
 # The pipelined single-wave variant (hip_elements/pipe.py) is opt-in: measured on MI355X it matches the plain single-strand
@@ -85,15 +94,19 @@ def compile_program(prog: Program, outdir: str, name: str, sym: bool = True, str
     mont: signals in Montgomery form on the device (True / False / "auto" = choose_mont); CW_MONT=0/1 overrides."""
     os.makedirs(outdir, exist_ok=True)
     fc = flatten(prog)
-    bittape = lower_bitplane(fc, bits)
-    if bittape is not None and os.environ.get("CW_BITS", "1") != "0":
-        strands = (1,)                      # the 256-bit schedule only serves the instances re-run with non-boolean inputs
+    bittape = None if os.environ.get("CW_BITS", "1") == "0" else lower_bitplane(fc, bits)      # CW_BITS=0: no bit program in the tape
+    if bittape is not None:
+        # the 256-bit schedule serves the instances re-run with non-boolean inputs - possibly the whole batch (a caller that
+        # feeds field-valued inputs): small circuits keep their multi-strand variants, for a 1M-signal circuit one
+        # variant is a minute of lowering
+        if fc.n_signals >= BITS_KEEP_STRANDS_BELOW:
+            strands = (1,)
         pipe = None
     if getattr(fc, "functions", None) and (fc.code["op"] == O.CALL).any():
         pipe = None                         # run-time control flow: program order on the value table (tier 2)
     if os.environ.get("CW_PIPE_SHAPE"):
         pipe = tuple(int(x) for x in os.environ["CW_PIPE_SHAPE"].split(","))
-    if bittape is not None and os.environ.get("CW_BITS", "1") != "0":
+    if bittape is not None:
         mont = False                        # bit-level circuit: the short paths for small values need canonical values
     elif os.environ.get("CW_MONT"):
         mont = os.environ["CW_MONT"] != "0" and not (fc.code["op"] == O.CALL).any()

@@ -362,31 +362,40 @@ cw_bits_assert_kernel(const uint64_t *__restrict__ T, uint64_t slots, const uint
 // written, through wslot = sig_slot o w2s composed on the host) and every store instruction writes the 1 KiB that 32
 // elements of one instance occupy (global_store_dwordx4, consecutive lanes -> consecutive 16-byte halves).  Round 2's
 // kernel ran one thread per element with two dependent index loads per 32 bytes: 0.53 of the HBM peak.
+#define BITS_GATHER_RUN 4      // consecutive 1 KiB pieces (32 elements each) a wave writes per instance: 4 KiB runs, 16 KiB per block
 __global__ void __launch_bounds__(256)
 cw_bits_gather_kernel(const uint64_t *__restrict__ T, uint64_t slots, const uint32_t *__restrict__ wslot, uint32_t n_wit,
                       uint32_t first, uint32_t count, uint4 *__restrict__ out) {
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t k0 = (blockIdx.x * 4 + wv) * 32;                  // this wave's 32 elements
-    const uint32_t j0 = blockIdx.y * 64;                             // its 64 output instances
+    const uint32_t k0 = (blockIdx.x * 4 + wv) * 32 * BITS_GATHER_RUN;        // this wave's elements
+    const uint32_t j0 = blockIdx.y * 64;                                     // its 64 output instances
     if (k0 >= n_wit) return;
-    const uint32_t k = k0 + (lane >> 1);
-    const bool have = k < n_wit;
     const uint32_t i0 = first + j0, g = i0 >> 6, sh = i0 & 63u;
-    uint64_t win = 0;                                                // bit jj = the value in instance i0 + jj
-    if (have) {
-        const uint32_t sl = wslot[k];
-        const uint64_t lo = T[(size_t)g * slots + sl];
-        win = lo >> sh;
-        if (sh && (uint64_t)(i0 + 64 - sh) < (uint64_t)first + count) win |= T[(size_t)(g + 1) * slots + sl] << (64 - sh);
+    const bool two = sh && (uint64_t)(i0 + 64 - sh) < (uint64_t)first + count;
+    uint64_t win[BITS_GATHER_RUN];                                           // bit jj = the value in instance i0 + jj
+    bool have[BITS_GATHER_RUN];
+#pragma unroll
+    for (int r = 0; r < BITS_GATHER_RUN; r++) {
+        const uint32_t k = k0 + r * 32 + (lane >> 1);
+        have[r] = k < n_wit;
+        win[r] = 0;
+        if (have[r]) {
+            const uint32_t sl = wslot[k];
+            win[r] = T[(size_t)g * slots + sl] >> sh;
+            if (two) win[r] |= T[(size_t)(g + 1) * slots + sl] << (64 - sh);
+        }
     }
     const uint32_t nj = min(64u, count - j0);
     const bool low_half = !(lane & 1);
     uint4 *o = out + ((size_t)j0 * n_wit + k0) * 2 + lane;
     for (uint32_t jj = 0; jj < nj; jj++) {
-        const uint32_t bit = low_half ? (uint32_t)(win >> jj) & 1u : 0u;
-        if (have) {
-            const u32x4 v = {bit, 0u, 0u, 0u};
-            __builtin_nontemporal_store(v, (u32x4 *)o);
+#pragma unroll
+        for (int r = 0; r < BITS_GATHER_RUN; r++) {
+            const uint32_t bit = low_half ? (uint32_t)(win[r] >> jj) & 1u : 0u;
+            if (have[r]) {
+                const u32x4 v = {bit, 0u, 0u, 0u};
+                __builtin_nontemporal_store(v, (u32x4 *)(o + r * 64));
+            }
         }
         o += (size_t)n_wit * 2;
     }
@@ -660,7 +669,7 @@ hipError_t cwk_bits_gather(hipStream_t s, const void *T, uint64_t slots, const u
     if (!count || !n_wit) return hipSuccess;
     for (uint32_t done = 0; done < count; done += 65535u * 64u) {       // grid.y limit
         const uint32_t n = count - done < 65535u * 64u ? count - done : 65535u * 64u;
-        hipLaunchKernelGGL(cw_bits_gather_kernel, dim3((n_wit + 127) / 128, (n + 63) / 64), dim3(256), 0, s, (const uint64_t *)T, slots,
+        hipLaunchKernelGGL(cw_bits_gather_kernel, dim3((n_wit + 128 * BITS_GATHER_RUN - 1) / (128 * BITS_GATHER_RUN), (n + 63) / 64), dim3(256), 0, s, (const uint64_t *)T, slots,
                            wslot, n_wit, first + done, n, (uint4 *)out + (size_t)done * n_wit * 2);
     }
     return hipGetLastError();

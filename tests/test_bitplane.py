@@ -269,6 +269,38 @@ def test_gate_free_boolean_circuit_gets_no_bit_program():
     assert cp.bittape is None
 
 
+def test_auto_mode_wants_evidence_of_a_bit_level_circuit(tmp_path):
+    # Num2Bits on FIELD-valued inputs "is boolean for 0/1 inputs" with almost no gates: auto mode keeps such a
+    # circuit on the 256-bit schedule with all its strand variants; SHA-256 (0.7 gates per signal) gets its bit program
+    from circom_amd.circuits.basic import Num2Bits
+
+    @template
+    def ManyNum2Bits(c, n, w):
+        x = c.input("x", n)
+        out = c.output("out")
+        cs = [c.component("n2b%d" % i, Num2Bits(w)) for i in range(n)]
+        for i in range(n):
+            c.set(cs[i]["in"], x[i])
+        c.set(out, cs[0]["out"][0] * cs[1]["out"][0])
+
+    prog = Program(ManyNum2Bits(80, 64))
+    fc = flatten(prog)
+    assert fc.n_signals > 4096
+    cp = compile_program(prog, str(tmp_path / "a"), "n2b", sym=False, strands=(1, 4))
+    assert cp.bittape is None
+    from circom_amd import runtime as rt
+    c = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
+    assert c.bits_info() == {}
+    c.close()
+    import os
+    os.environ["CW_BITS"] = "0"                      # compile-time switch: no bit program in the tape at all
+    try:
+        cp2 = compile_program(Program(BitGadget(8)), str(tmp_path / "b"), "bg", sym=False, strands=(1,), bits=True)
+    finally:
+        del os.environ["CW_BITS"]
+    assert cp2.bittape is None
+
+
 def test_unprovable_assert_becomes_an_assertion_slot():
     fc = flatten(Program(BitAssert()))
     net = BB.bitblast(fc)

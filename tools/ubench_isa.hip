@@ -260,6 +260,44 @@ static void run_lds(const char *name, int per_trip, FILE *js, bool &first) {
     }
 }
 
+// ---- HBM write roof: what a pure writer can reach (calibrates canonical_egress in bench.py) -----------------------------
+// MODE 0: plain 16-byte stores   1: nontemporal 16-byte stores   2: copy (16-byte load + store)
+template <int MODE>
+__global__ void __launch_bounds__(256) k_fill(u32x4 *__restrict__ dst, const u32x4 *__restrict__ src, size_t n16, uint32_t seed) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n16; i += stride) {
+        u32x4 v = {seed, 0u, 0u, 0u};
+        if (MODE == 2) v = src[i];
+        if (MODE == 1) __builtin_nontemporal_store(v, dst + i);
+        else dst[i] = v;
+    }
+}
+template <int MODE>
+static void run_fill(const char *name, FILE *js, bool &first) {
+    const size_t bytes = (size_t)8 << 30;
+    u32x4 *d, *s2 = nullptr;
+    CHECK(hipMalloc(&d, bytes));
+    if (MODE == 2) { CHECK(hipMalloc(&s2, bytes)); CHECK(hipMemset(s2, 1, bytes)); }
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_fill<MODE>, dim3(256 * 32), dim3(256), 0, 0, d, s2, bytes / 16, 1u);
+    CHECK(hipEventRecord(e0));
+    for (int r = 0; r < 3; r++) hipLaunchKernelGGL(k_fill<MODE>, dim3(256 * 32), dim3(256), 0, 0, d, s2, bytes / 16, 2u + r);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double gbs = 3.0 * bytes / (ms * 1e-3) / 1e9;
+    printf("HBM  %-22s 8 GiB x 3  %8.3f ms  %7.1f GB/s written%s\n", name, ms, gbs, MODE == 2 ? " (+ as much read)" : "");
+    if (js) {
+        fprintf(js, "%s{\"kind\":\"hbm\",\"op\":\"%s\",\"ms\":%.4f,\"written_GBps\":%.1f}", first ? "" : ",\n", name, ms, gbs);
+        first = false;
+    }
+    CHECK(hipFree(d));
+    if (s2) CHECK(hipFree(s2));
+}
+
 int main(int argc, char **argv) {
     FILE *js = argc > 1 ? fopen(argv[1], "w") : nullptr;
     bool first = true;
@@ -283,6 +321,9 @@ int main(int argc, char **argv) {
     run_lds<1>("ds_write_b64 x8", 0, js, first);
     run_lds<2>("eval step, reads 1 ahead", 1, js, first);
     run_lds<3>("eval step, reads 2 ahead", 1, js, first);
+    run_fill<0>("fill, plain stores", js, first);
+    run_fill<1>("fill, nt stores", js, first);
+    run_fill<2>("copy", js, first);
     if (argc > 2) { if (js) { fprintf(js, "\n]\n"); fclose(js); } return 0; }
     run_vmem<0>("store_b64 coalesced", js, first);
     run_vmem<1>("store_b64 all-OOR", js, first);
