@@ -529,16 +529,41 @@ __device__ __forceinline__ uint32_t bits_lane_bit(uint64_t mask) {
     return r;
 }
 // 32 x 32 bit-matrix transpose across the 32 lanes of a half-wave: lane k enters with row k (bit j = element (k, j)) and
-// leaves with column k.  Five butterfly stages; stage d exchanges the off-diagonal d x d blocks between lanes k and k ^ d.
-__device__ __forceinline__ uint32_t bits_transpose32(uint32_t x, uint32_t lane) {
+// leaves with column k.  Five butterfly stages; stage d exchanges the off-diagonal d x d blocks between lanes k and k ^ d:
+// the partner's word arrives through ds_swizzle (xor mask inside groups of 32 lanes: no index register), is ROTATED so
+// that the wanted blocks land on the positions this lane gives up (left by d in the lower lane of a pair, right by d in the
+// upper one; what the rotation drags into the kept positions is masked out) and merged with one v_bfi: 3 instructions
+// per stage (round 2: ~12 - index arithmetic for ds_bpermute, two masked shifts, compare + select).
+struct BitsTr {
+    uint32_t rot[5], keep[5];                 // per stage: v_alignbit shift (32 - rotate-left amount), mask of the bits this lane keeps
+};
+__device__ __forceinline__ BitsTr bits_tr_setup(uint32_t lane) {
+    BitsTr t;
 #pragma unroll
     for (int s = 0; s < 5; s++) {
         const uint32_t d = 16u >> s;
         const uint32_t m = s == 0 ? 0x0000FFFFu : s == 1 ? 0x00FF00FFu : s == 2 ? 0x0F0F0F0Fu : s == 3 ? 0x33333333u : 0x55555555u;
-        const uint32_t p = (uint32_t)__shfl_xor((int)x, (int)d);
-        x = (lane & d) ? (((p >> d) & m) | (x & ~m)) : ((x & m) | ((p & m) << d));
+        const bool upper = lane & d;
+        t.keep[s] = upper ? ~m : m;
+        t.rot[s] = upper ? d : 32u - d;       // v_alignbit_b32(p, p, n) = rotate right by n
     }
-    return x;
+    return t;
+}
+template <int S>
+__device__ __forceinline__ uint32_t bits_tr_stage(uint32_t x, const BitsTr &t) {
+    constexpr int d = 16 >> S;
+    // partner lane ^ d: hipcc turns the small distances into DPP moves (VALU speed), the large ones into LDS-crossbar
+    // permutes; five ds_swizzle per word were measured slower (1.73 vs 1.51 ms for the check of Sha256(2048) x 65 536)
+    const uint32_t p = (uint32_t)__shfl_xor((int)x, d);
+    const uint32_t r = __builtin_amdgcn_alignbit(p, p, t.rot[S]);
+    return (x & t.keep[S]) | (r & ~t.keep[S]);                                                // v_bfi_b32
+}
+__device__ __forceinline__ uint32_t bits_transpose32(uint32_t x, const BitsTr &t) {
+    x = bits_tr_stage<0>(x, t);
+    x = bits_tr_stage<1>(x, t);
+    x = bits_tr_stage<2>(x, t);
+    x = bits_tr_stage<3>(x, t);
+    return bits_tr_stage<4>(x, t);
 }
 // the word of every instance from the 32 masks of a whole word (slots s .. s + 31 = bits 0 .. 31): lane l loads the
 // (l >> 5)-th dword of mask l & 31 - one coalesced 256-byte load, lanes 0..31 then hold the rows of the instances 0..31
@@ -554,6 +579,7 @@ cw_bits_r1cs_int_kernel(const uint4 *__restrict__ chunk, uint32_t n_chunks, cons
     const uint32_t lane = threadIdx.x, g = blockIdx.x;
     const uint32_t i = g * 64 + lane;
     const uint64_t *Tg = T + (size_t)g * slots;
+    const BitsTr TR = bits_tr_setup(lane);
     uint32_t bad = 0xFFFFFFFFu;
     for (uint32_t cix = blockIdx.y; cix < n_chunks; cix += gridDim.y) {
         const uint4 ch = chunk[cix];                                // first word, groups, -, first row
@@ -564,21 +590,24 @@ cw_bits_r1cs_int_kernel(const uint4 *__restrict__ chunk, uint32_t n_chunks, cons
             const uint32_t hdr = wp[0];
             const uint32_t nb = hdr & 0xFFu;
             wp++;
-            if (hdr & (1u << 15)) {                                 // whole words: nb first slots, four loads in flight
+            if (hdr & (1u << 15)) {                                 // whole words: nb entries slot | half << 30 | sign << 31 (list padded to 8)
                 const uint32_t padded = (nb + 7u) & ~7u;
+                uint64_t pos = 0, neg = 0;                          // sums of the words with + / - sign, as 64-bit integers
                 for (uint32_t j = 0; j < nb; j += 4) {
-                    uint32_t sl[4], x[4];
+                    uint32_t e[4], x[4];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) sl[k] = wp[j + k];                 // the list is padded to 8 entries (zeros)
+                    for (int k = 0; k < 4; k++) e[k] = wp[j + k];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) x[k] = bits_word_load(Tg, j + k < nb ? sl[k] : sl[0], lane);   // padding: a valid word, unused
+                    for (int k = 0; k < 4; k++) x[k] = bits_word_load(Tg, e[k] & 0x3FFFFFFFu, lane);   // padding entries name slot 0: valid memory, unused
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        const uint32_t y = j + k < nb ? bits_transpose32(x[k], lane) : 0u;
-                        const int64_t val = (int64_t)((hdr & (1u << 9)) ? ((uint64_t)y << 32) : (uint64_t)y);
-                        cur += (hdr & (1u << 8)) ? -val : val;
+                        const uint32_t y = j + k < nb ? bits_transpose32(x[k], TR) : 0u;
+                        const uint64_t v = (e[k] & (1u << 30)) ? ((uint64_t)y << 32) : (uint64_t)y;       // wave-uniform choices
+                        if (e[k] >> 31) neg += v;
+                        else pos += v;
                     }
                 }
+                cur += (int64_t)(pos - neg);
                 wp += padded;
             } else if (!(hdr & (1u << 10))) {
                 uint32_t acc = 0;

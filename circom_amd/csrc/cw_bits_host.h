@@ -120,8 +120,8 @@ struct R1Plan {
     // that a term is "or the bit in at position k" (2 VALU); other coefficients form generic groups.
     // stream of u32: header {blocks:8 | sign:1 | hi:1 | generic:1 | part:2 | last of part:1 | end of row:1 | words:1} then
     // blocks x 8 words: power-of-two term = slot << 5 | k, generic term = two words (slot, coefficient id); padding
-    // terms name slot 0 (the constant 0).  A WORD group (bit 15) carries `blocks` = n whole 32-bit words: n first slots,
-    // padded to a multiple of 8 words.
+    // terms name slot 0 (the constant 0).  A WORD group (bit 15) carries `blocks` = n whole 32-bit words: n entries
+    // first slot | half << 30 | sign << 31, padded to a multiple of 8 words.
     std::vector<uint32_t> ichunk, iwords, irow_orig;   // chunk = {first word, groups, 0, first row}
     std::vector<uint32_t> itab;       // signed 64-bit value of every coefficient id (2 words each; 0 if not small)
     uint32_t n_ichunks = 0;
@@ -338,15 +338,21 @@ inline R1Plan build_r1cs(const std::vector<uint32_t> &r_ptr, const std::vector<u
                     g.w.swap(out);
                     groups.push_back(std::move(g));
                 }
-                for (auto &kv : word_slots)
-                    for (size_t k0 = 0; k0 < kv.second.size(); k0 += 255) {
+                {   // ONE group for all whole words of the part: every entry carries its own sign (bit 31) and half (bit 30)
+                    // next to the first slot (< 2^25), so that the kernel's four-at-a-time loop runs over ~6 words
+                    // (a 195-term BinSum row) instead of over 1-3 per (sign, half) key
+                    std::vector<uint32_t> all;
+                    for (auto &kv : word_slots)
+                        for (uint32_t sl : kv.second) all.push_back(sl | ((kv.first >> 1) << 31) | ((kv.first & 1u) << 30));
+                    for (size_t k0 = 0; k0 < all.size(); k0 += 255) {
                         G g;
-                        g.hdr = ((kv.first >> 1) << 8) | ((kv.first & 1) << 9) | ((uint32_t)pi << 11) | (1u << 15);
-                        g.n_words = (uint32_t)std::min<size_t>(255, kv.second.size() - k0);
-                        g.w.assign(kv.second.begin() + k0, kv.second.begin() + k0 + g.n_words);
+                        g.hdr = ((uint32_t)pi << 11) | (1u << 15);
+                        g.n_words = (uint32_t)std::min<size_t>(255, all.size() - k0);
+                        g.w.assign(all.begin() + k0, all.begin() + k0 + g.n_words);
                         while (g.w.size() % 8) g.w.push_back(0);     // the stream stays 32-byte aligned; entries past n are not read as words
                         groups.push_back(std::move(g));
                     }
+                }
                 for (size_t k0 = 0; k0 < gen.size(); k0 += 4 * 255) {
                     G g;
                     g.hdr = (1u << 10) | ((uint32_t)pi << 11);
