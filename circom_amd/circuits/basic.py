@@ -54,3 +54,38 @@ def Num2Bits(c, n):
         lc1 = lc1 + out[i] * e2
         e2 = e2 + e2
     c.enforce(lc1, inp)
+
+
+@template
+def PowerSums(c, n, m):
+    """out[j][k] = in[j]^(k+1) for j < n, k < m: a template with a 2-dimensional output (its size depends on BOTH
+    parameters), used as the element of a Mixed component array below"""
+    x = c.input("in", n)
+    out = c.output("out", n, m)
+    for j in range(n):
+        c.set(out[j][0], x[j] + 0)
+        for k in range(1, m):
+            c.set(out[j][k], out[j][k - 1] * x[j])
+
+
+@template
+def MixedArray(c, widths):
+    """`component ps[len(widths)]; ps[i] = PowerSums(widths[i][0], widths[i][1]);` - one template NAME, different
+    parameters per element: a `Mixed` cluster (compiler/src/intermediate_representation/translate.rs:1017-1045).  The
+    reference addresses the signals of such components through the io-map it reads from the `.dat`
+    (store_bucket.rs:498-566, load_bucket.rs:264-330) and runs them through `_functionTable`
+    (store_bucket.rs:706-710): the parity case of SURVEY row a13's Mapped locations."""
+    n_in = sum(w[0] for w in widths)
+    x = c.input("x", n_in)
+    s = c.output("s")
+    ps = [c.component("ps", PowerSums(w[0], w[1]), index=i) for i, w in enumerate(widths)]
+    k0 = 0
+    acc = c.const(0)
+    for i, (n, m) in enumerate(widths):
+        for j in range(n):
+            c.set(ps[i]["in"][j], x[k0 + j])
+        k0 += n
+    for i, (n, m) in enumerate(widths):
+        for j in range(n):
+            acc = acc + ps[i]["out"][j][m - 1] * (i + 2)
+    c.set(s, acc)

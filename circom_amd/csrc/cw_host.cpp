@@ -229,6 +229,10 @@ struct cw_circuit {
     bool need_full = false;
     bool mont = false;                     // the value table holds Montgomery forms x R' (lower.py pass A6)
     std::vector<Variant> variants;
+    uint32_t n_dat_consts = 0xFFFFFFFFu, n_io_templates = 0;   // sections of the .dat (0xFFFFFFFF: constants count unknown)
+    struct IoDef { uint32_t offset = 0, size = 0, bus_id = 0; std::vector<uint32_t> lengths; };
+    struct IoTemplate { uint32_t id = 0; std::vector<IoDef> defs; };
+    std::vector<IoTemplate> io_map;        // TemplateInstanceIOMap read from the .dat (Mixed component clusters)
     std::vector<uint32_t> consts;          // n_consts * 8
     std::vector<uint32_t> lconsts;         // n_lconsts * 12 (29-bit limbs)
     std::vector<uint32_t> w2s;
@@ -401,14 +405,15 @@ static int load_tape(cw_circuit *c, const char *path) {
     if (!read_file(path, b)) return fail(CW_EIO, std::string("tape file not found: ") + path);
     if (b.size() < 16 + 32 + 48 || memcmp(b.data(), "CWTP", 4)) return fail(CW_EIO, "bad tape magic");
     const uint32_t *h = (const uint32_t *)(b.data() + 4);
-    if (h[0] != 8) return fail(CW_EIO, "unsupported tape version");
+    if (h[0] != 9) return fail(CW_EIO, "unsupported tape version");
     if (h[1] != 4) return fail(CW_EIO, "only 4x64-bit primes are supported (bn128, bls12381, ...)");
     uint32_t n_variants = h[2];
     size_t off = 16;
     memcpy(c->q.w, b.data() + off, 32);
     off += 32;
+    if (b.size() < off + 64) return fail(CW_EIO, "tape file truncated");
     const uint32_t *m = (const uint32_t *)(b.data() + off);
-    off += 48;
+    off += 64;
     c->n_signals = m[0];
     if (c->n_signals == 0 || c->n_signals >= (1u << cwplan::SLOT_BITS))      // slot ids travel in 26-bit fields
         return fail(CW_EIO, "tape: signal count out of range (1 .. 2^26 - 1)");
@@ -422,6 +427,10 @@ static int load_tape(cw_circuit *c, const char *path) {
     uint32_t n_lconsts = m[8];
     c->n_pub_in = m[9];
     const uint32_t n_bit_programs = m[10], n_functions = m[11];
+    c->n_dat_consts = m[12];                 // constants / io-map templates of the matching .dat (load_dat checks its sections)
+    c->n_io_templates = m[13];
+    if (m[14] || m[15] || c->n_io_templates > (1u << 20) || (c->n_dat_consts != 0xFFFFFFFFu && c->n_dat_consts > (1u << 26)))
+        return fail(CW_EIO, "tape header: reserved words / section counts");
     if (n_functions > (1u << 16)) return fail(CW_EIO, "tape header: too many functions");
     if (n_bit_programs > 1) return fail(CW_EIO, "tape header: more than one bit-plane program");
     if (c->mont && (n_bit_programs || n_functions))
@@ -735,6 +744,49 @@ static int load_dat(cw_circuit *c, const char *path) {
         if (s >= c->n_signals) return fail(CW_EIO, ".dat witness list refers to a signal out of range");
         c->w2s[i] = (uint32_t)s;
     }
+    // constants (40 bytes each, c_code_generator.rs:616-679), then the io-map of the Mixed component clusters
+    // (c_code_generator.rs:681-738, main.cpp:60-92): u32 template ids, then per template the number of io signals and per
+    // signal {offset, number of lengths - 1, lengths[1..], element size, bus id}.  The reference binary knows both counts
+    // from compiled-in constants (get_size_of_constants(), get_size_of_io_map()); here the tape header carries them.  The
+    // evaluator never needs the table (every access was resolved when the circuit was traced); it is validated, kept
+    // for cw_io_map_size / cw_io_map_offset, and a damaged one is rejected.
+    c->io_map.clear();
+    if (c->n_dat_consts == 0xFFFFFFFFu) return CW_OK;          // tape without section counts
+    const size_t tail0 = need + (size_t)c->n_dat_consts * 40;
+    if (b.size() < tail0) return fail(CW_EIO, ".dat file too small for the constants of this circuit");
+    if ((b.size() - tail0) % 4) return fail(CW_EIO, ".dat io-map section is not a whole number of words");
+    const size_t nw = (b.size() - tail0) / 4, n = c->n_io_templates;
+    std::vector<uint32_t> w32(nw);
+    if (nw) memcpy(w32.data(), b.data() + tail0, nw * 4);
+    if (nw < n) return fail(CW_EIO, ".dat io-map section truncated");
+    size_t at = n;
+    for (size_t i = 0; i < n; i++) {
+        if (i && w32[i] <= w32[i - 1]) return fail(CW_EIO, ".dat io-map: template ids are not increasing");
+        if (at >= nw) return fail(CW_EIO, ".dat io-map section truncated");
+        const uint32_t nd = w32[at++];
+        cw_circuit::IoTemplate t;
+        t.id = w32[i];
+        for (uint32_t d = 0; d < nd; d++) {
+            if (at + 2 > nw) return fail(CW_EIO, ".dat io-map section truncated");
+            cw_circuit::IoDef def;
+            def.offset = w32[at];
+            const uint32_t nl = w32[at + 1];
+            at += 2;
+            if (nl > 16 || at + nl + 2 > nw) return fail(CW_EIO, ".dat io-map section truncated");
+            def.lengths.assign(w32.begin() + at, w32.begin() + at + nl);
+            at += nl;
+            def.size = w32[at];
+            def.bus_id = w32[at + 1];
+            at += 2;
+            uint64_t span = def.size;
+            for (uint32_t l : def.lengths) span *= std::max<uint32_t>(l, 1);
+            if (def.size == 0 || def.offset >= c->n_signals || span > c->n_signals)
+                return fail(CW_EIO, ".dat io-map: signal definition out of range");
+            t.defs.push_back(std::move(def));
+        }
+        c->io_map.push_back(std::move(t));
+    }
+    if (at != nw) return fail(CW_EIO, ".dat: bytes behind the io-map (bus-field maps are not supported)");
     return CW_OK;
 }
 
@@ -915,6 +967,13 @@ extern "C" int cw_load(const char *tape_path, const char *dat_path, const char *
     return CW_OK;
 }
 extern "C" void cw_free(cw_circuit *c) { delete c; }
+extern "C" uint32_t cw_io_map_size(const cw_circuit *c) { return c ? (uint32_t)c->io_map.size() : 0; }
+extern "C" int64_t cw_io_map_offset(const cw_circuit *c, uint32_t template_id, uint32_t signal_code) {
+    if (!c) return -1;
+    for (const auto &t : c->io_map)
+        if (t.id == template_id) return signal_code < t.defs.size() ? (int64_t)t.defs[signal_code].offset : -1;
+    return -1;
+}
 extern "C" uint32_t cw_n_signals(const cw_circuit *c) { return c->n_signals; }
 extern "C" uint32_t cw_n_witness(const cw_circuit *c) { return c->n_witness; }
 extern "C" uint32_t cw_n_inputs(const cw_circuit *c) { return c->n_inputs; }

@@ -120,6 +120,39 @@ class FlatCircuit:
         emit(0)
         self.code = {k: (np.concatenate(v) if v else np.zeros(0, dtype=np.int64)) for k, v in chunks.items()}
         self.constraints = cons
+        self.io_map = self._build_io_map()
+
+    def _build_io_map(self):
+        """TemplateInstanceIOMap of compiler/src/circuit_design/build.rs:488-520: the component arrays of a template whose
+        elements are instances of ONE template name with DIFFERENT parameters are `Mixed` clusters (translate.rs:1017-1045):
+        the reference addresses their signals through a run-time table - per template instance, per input/output signal
+        (code = position among the template's wires: outputs, then inputs): local offset, array lengths, element size, bus
+        id - which it reads from the tail of the `.dat` (c_code_generator.rs:681-738, main.cpp:60-92), and runs them
+        through `_functionTable[templateId]` (store_bucket.rs:706-710).  Here every access is resolved at trace time, so the
+        table only matters for the files: `write_dat` emits it, `cw_load` validates it, and the reference runtime executes
+        the oracle's emitted C++ THROUGH it (oracle/emit_ref_cpp.py).
+        Sets `inst.mixed_children` (child table positions) on every instance; returns [(template id, [(offset, dims, size,
+        bus id)])] sorted by template id."""
+        mixed_templates = {}
+        for inst in self.prog.inst_list:
+            groups = {}
+            for k, (cname, cidx, cinst, soff, coff) in enumerate(inst.children):
+                groups.setdefault(cname, []).append((k, cinst))
+            inst.mixed_children = set()
+            for cname, members in groups.items():
+                if len({id(ci) for _, ci in members}) > 1:
+                    for k, ci in members:
+                        inst.mixed_children.add(k)
+                        mixed_templates[ci.id] = ci
+        out = []
+        for tid in sorted(mixed_templates):
+            ci = mixed_templates[tid]
+            defs = []
+            for cat in ("o", "i"):
+                for name, dims, pid0 in ci.decls[cat]:
+                    defs.append((int(pid0), tuple(int(d) for d in dims), 1, 0))
+            out.append((tid, defs))
+        return out
 
     @staticmethod
     def _reloc(d, base):

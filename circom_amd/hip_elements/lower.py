@@ -1418,6 +1418,8 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None, mont
     t.n_strands = n_strands
     t.mont = bool(mont)
     t.consts = dconsts
+    t.n_dat_consts = len(fc.constants)           # what the .dat holds (the reference's constant list), not the schedule's table
+    t.n_io_templates = len(getattr(fc, "io_map", ()))
     if witness_map is None:
         witness_map = np.arange(n_signals, dtype=np.uint32)     # --O0: identity
     t.witness2signal = np.asarray(witness_map, dtype=np.uint32)

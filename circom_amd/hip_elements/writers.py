@@ -73,11 +73,27 @@ def write_dat(path, fc: FlatCircuit, witness2signal=None):
         f.write(b"".join(struct.pack("<QQQ", *e) for e in tab))
         f.write(np.asarray(witness2signal, dtype="<u8").tobytes())
         f.write(b"".join(dat_constant(v, fc.fp) for v in fc.constants))
+        f.write(dat_io_map(getattr(fc, "io_map", ())))
     return size
 
 
+def dat_io_map(io_map) -> bytes:
+    """io-map section of the `.dat` (c_code_generator.rs:681-738 `generate_dat_io_signals_info`; reader main.cpp:60-92):
+    the template ids, then per template: number of io signals and, per signal, offset | number of lengths - 1 (0 for a
+    scalar) | lengths[1..] | element size | bus id - all u32 little endian.  (The bus-field map that follows it in the
+    reference is empty here: the front-end has no buses.)"""
+    out = [struct.pack("<I", tid) for tid, _ in io_map]
+    for _, defs in io_map:
+        out.append(struct.pack("<I", len(defs)))
+        for offset, dims, size, bus in defs:
+            out.append(struct.pack("<II", offset, max(len(dims) - 1, 0)))
+            out.extend(struct.pack("<I", d) for d in dims[1:])
+            out.append(struct.pack("<II", size, bus))
+    return b"".join(out)
+
+
 TAPE_MAGIC = b"CWTP"
-TAPE_VERSION = 8
+TAPE_VERSION = 9
 
 
 def write_tape(path, tapes, bittape=None):
@@ -85,10 +101,10 @@ def write_tape(path, tapes, bittape=None):
     different strand counts (the runtime picks the variant that fills the chip for the batch at hand).
          0  "CWTP" | u32 version | u32 n64 | u32 n_variants
         16  prime, n64*8 bytes
-            12 x u32: n_signals, n_witness, n_consts, main_input_start, n_main_inputs, n_input_names,
+            16 x u32: n_signals, n_witness, n_consts, main_input_start, n_main_inputs, n_input_names,
                       hashmap_size, rbits (Montgomery radix exponent of MMUL rows; bit 16 set = the value table holds
                       Montgomery forms, lower.py pass A6), n_lconsts, n_public_inputs,
-                      n_bit_programs (0 | 1), n_functions
+                      n_bit_programs (0 | 1), n_functions, constants in the .dat, io-map templates in the .dat, 0, 0
             consts          n_consts x n64*8 bytes (raw residues as the schedule expects them)
             lconsts         n_lconsts x n64*8 bytes (coef*R' of D_DOTC terms; the runtime keeps them as 29-bit limbs)
             witness2signal  n_witness x u32
@@ -115,10 +131,11 @@ def write_tape(path, tapes, bittape=None):
     with open(path, "wb") as f:
         f.write(TAPE_MAGIC + struct.pack("<III", TAPE_VERSION, n64, len(tapes)))
         f.write(t0.q.to_bytes(8 * n64, "little"))
-        f.write(struct.pack("<12I", t0.n_signals, t0.n_witness, len(t0.consts), t0.main_input_start, t0.n_main_inputs,
+        f.write(struct.pack("<16I", t0.n_signals, t0.n_witness, len(t0.consts), t0.main_input_start, t0.n_main_inputs,
                             len(t0.inputs), hashmap_size(len(t0.inputs)), t0.rbits | (0x10000 if getattr(t0, "mont", False) else 0),
                             len(t0.lconsts), t0.n_pub_in,
-                            1 if bittape is not None else 0, len(t0.functions)))
+                            1 if bittape is not None else 0, len(t0.functions),
+                            getattr(t0, "n_dat_consts", 0xFFFFFFFF), getattr(t0, "n_io_templates", 0), 0, 0))
         f.write(b"".join(c.to_bytes(8 * n64, "little") for c in t0.consts))
         f.write(b"".join(c.to_bytes(8 * n64, "little") for c in t0.lconsts))
         f.write(np.asarray(t0.witness2signal, dtype="<u4").tobytes())

@@ -47,6 +47,8 @@ _SIGS = {
     "cw_load": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]),
     "cw_free": (None, [C.c_void_p]),
     "cw_n_signals": (C.c_uint32, [C.c_void_p]),
+    "cw_io_map_size": (C.c_uint32, [C.c_void_p]),
+    "cw_io_map_offset": (C.c_int64, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "cw_n_witness": (C.c_uint32, [C.c_void_p]),
     "cw_n_inputs": (C.c_uint32, [C.c_void_p]),
     "cw_input_start": (C.c_uint32, [C.c_void_p]),

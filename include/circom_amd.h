@@ -53,6 +53,12 @@ const char *cw_version(void);
 int cw_load(const char *tape_path, const char *dat_path, const char *r1cs_path, cw_circuit **out);
 void cw_free(cw_circuit *c);
 uint32_t cw_n_signals(const cw_circuit *c);          /* get_total_signal_no() */
+/* get_size_of_io_map(): template instances of Mixed component clusters described in the .dat's io-map section
+ * (c_code_generator.rs:681-738; Circom_Circuit::templateInsId2IOSignalInfo, circom.hpp:41), and the local offset of io
+ * signal `signal_code` of one of them (-1: unknown).  The evaluator resolves every access at trace time; the table is
+ * read, validated and exposed because the file format carries it. */
+uint32_t cw_io_map_size(const cw_circuit *c);
+int64_t cw_io_map_offset(const cw_circuit *c, uint32_t template_id, uint32_t signal_code);
 uint32_t cw_n_witness(const cw_circuit *c);          /* get_size_of_witness() */
 uint32_t cw_n_inputs(const cw_circuit *c);           /* get_main_input_signal_no() */
 uint32_t cw_input_start(const cw_circuit *c);        /* get_main_input_signal_start() */

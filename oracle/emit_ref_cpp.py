@@ -48,11 +48,47 @@ def _child_of(inst, off):
     return lo, off - ch[lo][3]
 
 
+def _mapped(child, o):
+    """(signal code, index expression) of offset `o` inside a child of a Mixed cluster: LocationRule::Mapped
+    (store_bucket.rs:498-566, load_bucket.rs:264-330): code = position among the template's wires (outputs, inputs),
+    multi-dimensional indices are folded with the lengths the RUNTIME holds (`cur_def->lengths[i-1]`)."""
+    code = 0
+    for cat in ("o", "i"):
+        for name, dims, pid0 in child.decls[cat]:
+            size = 1
+            for d in dims:
+                size *= d
+            if pid0 <= o < pid0 + size:
+                rem = o - pid0
+                idx = []
+                for d in reversed(dims):
+                    idx.append(rem % d)
+                    rem //= d
+                idx.reverse()
+                if not idx:
+                    return code, None
+                e = "%d" % idx[0]
+                for i in range(1, len(idx)):
+                    e = "(%s)*cur_def->lengths[%d]+%d" % (e, i - 1, idx[i])
+                return code, e
+            code += 1
+    raise ValueError("offset %d is no input/output of %s" % (o, child.header))
+
+
 def _ref(inst, k, v):
     if k == K_SIG:
         if v < inst.n_local:
             return "&signalValues[mySignalStart + %d]" % v
         ci, o = _child_of(inst, v)
+        if ci in getattr(inst, "mixed_children", ()):
+            code, idx = _mapped(inst.children[ci][2], o)
+            cm = "ctx->componentMemory[mySubcomponents[%d]]" % ci
+            base = "%s.signalStart + ctx->templateInsId2IOSignalInfo[%s.templateId].defs[%d].offset" % (cm, cm, code)
+            if idx is None:
+                return "&ctx->signalValues[%s]" % base
+            # a GNU statement expression keeps the reference's shape (cur_def, then the folded index times the element size)
+            return ("({ IOFieldDef *cur_def = &(ctx->templateInsId2IOSignalInfo[%s.templateId].defs[%d]); "
+                    "&ctx->signalValues[%s + (%s)*cur_def->size]; })" % (cm, code, base, idx))
         return "&ctx->signalValues[ctx->componentMemory[mySubcomponents[%d]].signalStart + %d]" % (ci, o)
     if k == K_TMP:
         return "&expaux[%d]" % v
@@ -78,6 +114,10 @@ def _emit_instance(inst, out):
             child = inst.children[ci][2]
             if child.n_in == 0:
                 continue        # ran at creation (template.rs:274-278)
+            if ci in getattr(inst, "mixed_children", ()):       # store_bucket.rs:706-710: through the function table
+                stmts.append("assert(!(ctx->componentMemory[mySubcomponents[%d]].inputCounter)); "
+                             "(*_functionTable[ctx->componentMemory[mySubcomponents[%d]].templateId])(mySubcomponents[%d],ctx);" % (ci, ci, ci))
+                continue
             stmts.append("assert(!(ctx->componentMemory[mySubcomponents[%d]].inputCounter)); %s_run(mySubcomponents[%d],ctx);"
                          % (ci, child.header, ci))
             continue
@@ -199,7 +239,7 @@ def emit(fc, path, hashmap_size: int):
     out.append("uint get_size_of_input_hashmap() {return %d;}" % hashmap_size)
     out.append("uint get_size_of_witness() {return %d;}" % fc.n_signals)
     out.append("uint get_size_of_constants() {return %d;}" % len(fc.constants))
-    out.append("uint get_size_of_io_map() {return 0;}")
+    out.append("uint get_size_of_io_map() {return %d;}" % len(getattr(fc, "io_map", ())))
     out.append("uint get_size_of_bus_field_map() {return 0;}")
     # generate_function_release_memory_component, c_code_generator.rs:914-933
     out.append("void release_memory_component(Circom_CalcWit* ctx, uint pos) {{ if (pos != 0){{ if(ctx->componentMemory[pos].subcomponents) "

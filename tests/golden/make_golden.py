@@ -65,6 +65,12 @@ def cases():
     r4 = random.Random(78)
     out["semaphore20p"] = (lambda: Program(SemaphoreStyle(20, True)), "bn128",
                            [H.semaphore_inputs(q, 20, r4)[0] for _ in range(2)])
+    # a Mixed component cluster (one template, different parameters per array element): the reference runtime executes it
+    # through the io-map section of the .dat and _functionTable (store_bucket.rs:498-566)
+    from circom_amd.circuits.basic import MixedArray
+    r5 = random.Random(13)
+    out["mixed_array"] = (lambda: Program(MixedArray(((2, 3), (1, 5), (3, 2), (2, 3)))), "bn128",
+                          [list(range(1, 9)), [0] * 8, [q - 1] * 8, [r5.randrange(q) for _ in range(8)]])
     return out
 
 
