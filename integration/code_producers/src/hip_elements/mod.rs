@@ -1,0 +1,253 @@
+// code_producers/src/hip_elements/mod.rs  --  NEW FILE of the `--hip` target.
+//
+// STATUS: written against circom v2.2.x's crates, NOT COMPILED in the environment this repository was built in (no
+// cargo / rustc there).  The executable specification of everything below is the Python package `circom_amd`
+// (`frontend/flatten.py` = the trace, `cwf.py` = this file's byte layout, `hip_backend.py` = the process `finish` runs);
+// tests/test_cwf_backend.py pins the byte layout on the Python side, tests/test_integration_sources.py checks that the
+// field lists and opcode tables of this file and of `circom_amd/cwf.py` / `opcodes.py` name the same things in the same
+// order.
+//
+// Role, next to the existing producers (c_elements/mod.rs:6-39 `CProducer`, wasm_elements `WASMProducer`): a `HipProducer`
+// does not print code.  The compiler's `WriteHip` implementation (integration/compiler/src/hip_backend.rs) EXECUTES the IR
+// once at compile time and records, through the methods below, the flat witness program over GLOBAL signal ids;
+// `finish` writes it as `<name>.cwf` and runs the lowering (`python -m circom_amd.hip_backend`), which emits
+// `<name>.cwt` (batched evaluation schedule + bit-plane program), `<name>.dat` (the reference's layout, byte for byte:
+// c_code_generator.rs:818-865) and `<name>.r1cs` for the R1CS check kernel.
+
+use num_bigint_dig::BigInt;
+use std::fs::File;
+use std::io::{BufWriter, Write};
+use std::path::Path;
+use std::process::Command;
+
+/// Opcodes of the flat program = `circom_amd/opcodes.py` (same numbers).  The first 24 mirror `OperatorType`
+/// (compiler/src/intermediate_representation/compute_bucket.rs:7-34); address arithmetic never reaches the flat program
+/// (indices are compile-time values of the trace).
+#[repr(i64)]
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub enum FlatOpcode {
+    Copy = 0,
+    Add = 1,
+    Sub = 2,
+    Mul = 3,
+    Div = 4,
+    IntDiv = 5,
+    Mod = 6,
+    Pow = 7,
+    Neg = 8,
+    ShiftL = 9,
+    ShiftR = 10,
+    BitAnd = 11,
+    BitOr = 12,
+    BitXor = 13,
+    Complement = 14,
+    Lesser = 15,
+    Greater = 16,
+    LesserEq = 17,
+    GreaterEq = 18,
+    Eq = 19,
+    NotEq = 20,
+    BoolAnd = 21,
+    BoolOr = 22,
+    BoolNot = 23,
+    Select = 24,
+    AssertEq = 25,
+    AssertNz = 26,
+    Run = 27,
+    Call = 28,
+}
+
+/// Operand kinds of the flat program (`opcodes.py` K_*).
+pub const K_SIG: i64 = 0;
+pub const K_TMP: i64 = 1;
+pub const K_CONST: i64 = 2;
+pub const K_NONE: i64 = 3;
+
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub struct Operand {
+    pub kind: i64,
+    pub value: i64,
+}
+impl Operand {
+    pub fn signal(id: usize) -> Operand { Operand { kind: K_SIG, value: id as i64 } }
+    pub fn temp(id: usize) -> Operand { Operand { kind: K_TMP, value: id as i64 } }
+    pub fn constant(id: usize) -> Operand { Operand { kind: K_CONST, value: id as i64 } }
+    pub fn none() -> Operand { Operand { kind: K_NONE, value: 0 } }
+}
+
+#[derive(Clone, Debug)]
+pub struct FlatOp {
+    pub op: FlatOpcode,
+    pub dst: Operand,
+    pub a: Operand,
+    pub b: Operand,
+    pub c: Operand,
+}
+
+/// One constraint A * B - C = 0 over global signal ids (signal 0 = the constant 1), coefficients canonical in [0, p):
+/// what `constraint_list` already holds for the r1cs writer (constraint_writers/src/r1cs_writer.rs:49-91).
+#[derive(Clone, Debug, Default)]
+pub struct FlatConstraint {
+    pub a: Vec<(u32, BigInt)>,
+    pub b: Vec<(u32, BigInt)>,
+    pub c: Vec<(u32, BigInt)>,
+}
+
+/// `IODef` of the Mixed component clusters (compiler/src/circuit_design/build.rs:488-520), as the `.cwf` carries it.
+#[derive(Clone, Debug)]
+pub struct FlatIoDef {
+    pub offset: u32,
+    pub dims: Vec<u32>,
+    pub size: u32,
+    pub bus_id: u32,
+}
+
+/// The ten u32 of the `.cwf` header, in file order (cwf.py: `struct.pack("<10I", ...)`).
+pub const CWF_HEADER_FIELDS: [&str; 10] = [
+    "n_signals",
+    "n_temps",
+    "n_constants",
+    "main_input_start",
+    "n_main_inputs",
+    "n_public_inputs",
+    "n_outputs",
+    "n_input_names",
+    "n_ops",
+    "n_constraints",
+];
+pub const CWF_MAGIC: &[u8; 4] = b"CWFL";
+pub const CWF_VERSION: u32 = 1;
+/// Columns of the flat code section, in file order (cwf.py `COLS`), each n_ops x i64.
+pub const CWF_CODE_COLUMNS: [&str; 9] = ["op", "dk", "dv", "ak", "av", "bk", "bv", "ck", "cv"];
+
+#[derive(Default)]
+pub struct HipProducer {
+    pub prime: BigInt,
+    pub prime_str: String,
+    pub n64: usize,
+    // numbering, exactly as CProducer holds it (c_elements/mod.rs:6-39): filled by compiler/src/circuit_design/build.rs
+    pub total_number_of_signals: usize,
+    pub main_signal_offset: usize,       // get_main_input_signal_start(): 1 + #outputs of main (c_elements/mod.rs:156-158)
+    pub number_of_main_inputs: usize,
+    pub number_of_main_outputs: usize,
+    pub number_of_public_inputs: usize,
+    pub main_input_list: Vec<(String, usize, usize)>,    // (name, first signal, size), InputList of c_elements/mod.rs:12
+    pub field_tracking: Vec<String>,     // constant list (decimal strings), index = ValueBucket.value for BigInt values
+    pub io_map: Vec<(u32, Vec<FlatIoDef>)>,
+    // the trace
+    pub ops: Vec<FlatOp>,
+    pub n_temps: usize,
+    pub constraints: Vec<FlatConstraint>,
+}
+
+impl HipProducer {
+    pub fn new_temp(&mut self) -> Operand {
+        self.n_temps += 1;
+        Operand::temp(self.n_temps - 1)
+    }
+    pub fn emit(&mut self, op: FlatOpcode, dst: Operand, a: Operand, b: Operand) {
+        self.ops.push(FlatOp { op, dst, a, b, c: Operand::none() });
+    }
+    pub fn emit3(&mut self, op: FlatOpcode, dst: Operand, a: Operand, b: Operand, c: Operand) {
+        self.ops.push(FlatOp { op, dst, a, b, c });
+    }
+
+    fn le_bytes(&self, v: &BigInt) -> Vec<u8> {
+        let (_, mut bytes) = v.to_bytes_le();
+        bytes.resize(8 * self.n64, 0);
+        bytes
+    }
+
+    /// `<name>.cwf`, byte for byte what `circom_amd/cwf.py::write_cwf` writes.
+    pub fn write_cwf(&self, path: &Path) -> std::io::Result<()> {
+        let mut w = BufWriter::new(File::create(path)?);
+        w.write_all(CWF_MAGIC)?;
+        for v in [CWF_VERSION, self.n64 as u32, 0u32] {
+            w.write_all(&v.to_le_bytes())?;
+        }
+        w.write_all(&self.le_bytes(&self.prime))?;
+        let header: [u32; 10] = [
+            self.total_number_of_signals as u32,
+            self.n_temps as u32,
+            self.field_tracking.len() as u32,
+            self.main_signal_offset as u32,
+            self.number_of_main_inputs as u32,
+            self.number_of_public_inputs as u32,
+            self.number_of_main_outputs as u32,
+            self.main_input_list.len() as u32,
+            self.ops.len() as u32,
+            self.constraints.len() as u32,
+        ];
+        for v in header {
+            w.write_all(&v.to_le_bytes())?;
+        }
+        for c in &self.field_tracking {
+            let v = BigInt::parse_bytes(c.as_bytes(), 10).expect("constant list holds decimal strings");
+            w.write_all(&self.le_bytes(&v))?;
+        }
+        for (name, start, size) in &self.main_input_list {
+            w.write_all(&(name.len() as u32).to_le_bytes())?;
+            w.write_all(name.as_bytes())?;
+            w.write_all(&(*start as u32).to_le_bytes())?;
+            w.write_all(&(*size as u32).to_le_bytes())?;
+        }
+        // nine columns, each n_ops x i64: op, dk, dv, ak, av, bk, bv, ck, cv
+        let col = |f: &dyn Fn(&FlatOp) -> i64, w: &mut BufWriter<File>| -> std::io::Result<()> {
+            for o in &self.ops {
+                w.write_all(&f(o).to_le_bytes())?;
+            }
+            Ok(())
+        };
+        col(&|o| o.op as i64, &mut w)?;
+        col(&|o| o.dst.kind, &mut w)?;
+        col(&|o| o.dst.value, &mut w)?;
+        col(&|o| o.a.kind, &mut w)?;
+        col(&|o| o.a.value, &mut w)?;
+        col(&|o| o.b.kind, &mut w)?;
+        col(&|o| o.b.value, &mut w)?;
+        col(&|o| o.c.kind, &mut w)?;
+        col(&|o| o.c.value, &mut w)?;
+        for cons in &self.constraints {
+            for part in [&cons.a, &cons.b, &cons.c] {
+                let mut terms = part.clone();
+                terms.sort_by_key(|t| t.0);                    // cwf.py writes the terms of a part by signal id
+                w.write_all(&(terms.len() as u32).to_le_bytes())?;
+                for (sig, coef) in terms {
+                    w.write_all(&sig.to_le_bytes())?;
+                    w.write_all(&self.le_bytes(&coef))?;
+                }
+            }
+        }
+        w.write_all(&0u32.to_le_bytes())?;                     // functions: CallBuckets are inlined by the trace or refused (hip_backend.rs)
+        w.write_all(&(self.io_map.len() as u32).to_le_bytes())?;
+        for (tid, defs) in &self.io_map {
+            w.write_all(&tid.to_le_bytes())?;
+            w.write_all(&(defs.len() as u32).to_le_bytes())?;
+            for d in defs {
+                w.write_all(&d.offset.to_le_bytes())?;
+                w.write_all(&(d.dims.len() as u32).to_le_bytes())?;
+                for l in &d.dims {
+                    w.write_all(&l.to_le_bytes())?;
+                }
+                w.write_all(&d.size.to_le_bytes())?;
+                w.write_all(&d.bus_id.to_le_bytes())?;
+            }
+        }
+        w.flush()
+    }
+
+    /// Writes `<dir>/<name>.cwf` and runs the lowering, the way the `--c` target leaves `make` to the user but in one
+    /// step: the artefacts the runtime loads (`cw_load`) are `<name>.cwt`, `<name>.dat`, `<name>.r1cs` in `dir`.
+    pub fn finish(&self, dir: &Path, name: &str) -> Result<(), ()> {
+        let cwf = dir.join(format!("{}.cwf", name));
+        self.write_cwf(&cwf).map_err(|_| {})?;
+        let status = Command::new(std::env::var("CIRCOM_HIP_PYTHON").unwrap_or_else(|_| "python3".to_string()))
+            .args(["-m", "circom_amd.hip_backend"])
+            .arg(&cwf)
+            .arg("-o")
+            .arg(dir)
+            .status()
+            .map_err(|_| {})?;
+        if status.success() { Ok(()) } else { Err(()) }
+    }
+}
