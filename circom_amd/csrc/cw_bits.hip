@@ -83,8 +83,10 @@ __global__ void __launch_bounds__(64) cw_bits_ingest_kernel(const uint4 *__restr
 #define BITS_MAX_LOADS 4
 #define BITS_MAX_FLUSH 6
 #define BITS_CMD_WORDS 24
-#define BITS_AHEAD 4          // records are requested this many batches ahead (BITS_AHEAD + 1 register sets of 16 dwords): two
-                              // batches (~0.7 us) proved shorter than the latency of the stream, +25 ns per vrow of waiting
+#define BITS_AHEAD 8          // records are requested this many batches ahead (BITS_AHEAD + 1 register sets of 16 dwords).  vmcnt
+                              // retires loads AND stores in order, so a record wait also waits for every row flush issued before the
+                              // newest 4 * BITS_AHEAD operations: behind cold caches / TLBs (tools/bits_shape_bench.py with
+                              // CW_BENCH_COLD=1) four batches of slack cost 1.31 ms, eight 1.18 (0.90 warm either way)
 #ifndef BITS_STORE_AUX
 #define BITS_STORE_AUX 2      // cache policy of the row flushes: nt (streaming).  A flushed row is dead for this kernel; with the default
                               // policy the 1.2 GB of rows a launch writes thrashed the 4 MB L2s and the in-order vmcnt made the record
@@ -308,10 +310,10 @@ cw_bits_eval_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict__
     // every lane's ring entries start as 0 (idle lanes of the first vrows read constants only; a defined value keeps
     // the kernel deterministic when a damaged program names an entry that was never written)
     for (uint32_t o = E.lane8; o < const_off; o += 512) M::lds_st(o, (mask_t)0);
-    // the host pads the stream to whole trips of ten batches and appends BITS_AHEAD empty ones (records are requested
-    // BITS_AHEAD batches ahead); five record sets and two loaded-row sets rotate by NAME through the ten expansions of
+    // the host pads the stream to whole trips of 18 batches and appends BITS_AHEAD empty ones (records are requested
+    // BITS_AHEAD batches ahead); nine record sets and two loaded-row sets rotate by NAME through the 18 expansions of
     // the batch body (no register moves)
-    uint4 R0[4], R1[4], R2[4], R3[4], R4[4];
+    uint4 R0[4], R1[4], R2[4], R3[4], R4[4], R5[4], R6[4], R7[4], R8[4];
     mask_t L0[BITS_MAX_LOADS], L1[BITS_MAX_LOADS];
 #pragma unroll
     for (int j = 0; j < BITS_MAX_LOADS; j++) L0[j] = L1[j] = 0;
@@ -321,6 +323,10 @@ cw_bits_eval_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict__
         R1[j] = E.rec_load(1, j);
         R2[j] = E.rec_load(2, j);
         R3[j] = E.rec_load(3, j);
+        R4[j] = E.rec_load(4, j);
+        R5[j] = E.rec_load(5, j);
+        R6[j] = E.rec_load(6, j);
+        R7[j] = E.rec_load(7, j);
     }
     E.cprev = 0;
     E.ccur = E.cmd_load(0);
@@ -328,18 +334,26 @@ cw_bits_eval_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict__
     E.a = M::lds(R0[0].x & 0xFFF8u);
     E.b = M::lds(R0[0].x >> 16);
     E.c = M::lds(R0[0].y & 0xFFFFu);
-    static_assert(BITS_AHEAD == 4, "the rotation below is written for five record sets");
-    for (uint32_t bi = 0; bi < n_batches; bi += 10) {
-        E.batch(bi + 0, R0, R1, R4, L0, L1);
+    static_assert(BITS_AHEAD == 8, "the rotation below is written for 9 record sets");
+    for (uint32_t bi = 0; bi < n_batches; bi += 18) {
+        E.batch(bi + 0, R0, R1, R8, L0, L1);
         E.batch(bi + 1, R1, R2, R0, L1, L0);
         E.batch(bi + 2, R2, R3, R1, L0, L1);
         E.batch(bi + 3, R3, R4, R2, L1, L0);
-        E.batch(bi + 4, R4, R0, R3, L0, L1);
-        E.batch(bi + 5, R0, R1, R4, L1, L0);
-        E.batch(bi + 6, R1, R2, R0, L0, L1);
-        E.batch(bi + 7, R2, R3, R1, L1, L0);
-        E.batch(bi + 8, R3, R4, R2, L0, L1);
-        E.batch(bi + 9, R4, R0, R3, L1, L0);
+        E.batch(bi + 4, R4, R5, R3, L0, L1);
+        E.batch(bi + 5, R5, R6, R4, L1, L0);
+        E.batch(bi + 6, R6, R7, R5, L0, L1);
+        E.batch(bi + 7, R7, R8, R6, L1, L0);
+        E.batch(bi + 8, R8, R0, R7, L0, L1);
+        E.batch(bi + 9, R0, R1, R8, L1, L0);
+        E.batch(bi + 10, R1, R2, R0, L0, L1);
+        E.batch(bi + 11, R2, R3, R1, L1, L0);
+        E.batch(bi + 12, R3, R4, R2, L0, L1);
+        E.batch(bi + 13, R4, R5, R3, L1, L0);
+        E.batch(bi + 14, R5, R6, R4, L0, L1);
+        E.batch(bi + 15, R6, R7, R5, L1, L0);
+        E.batch(bi + 16, R7, R8, R6, L0, L1);
+        E.batch(bi + 17, R8, R0, R7, L1, L0);
     }
     E.drain();
 }

@@ -70,10 +70,10 @@ inline const char *validate(const Program &p, uint32_t n_signals, uint32_t n_inp
 }
 
 // Device stream: per batch 4 x 64 lanes x 16 bytes (load j of a lane carries the records of vrows 2j, 2j + 1 of the
-// batch), padded to whole trips of ten batches plus AHEAD empty ones (the kernel requests records AHEAD batches ahead:
+// batch), padded to whole trips of TRIP batches plus AHEAD empty ones (the kernel requests records AHEAD batches ahead:
 // cw_bits.hip BITS_AHEAD); idle lanes compute 0 ^ 0 ^ 0 into their own ring entry.  `cmds` gets zero blocks for the
-// padding.  Returns the number of batches to execute (multiple of 10).
-constexpr size_t AHEAD = 4, TRIP = 10;
+// padding.  Returns the number of batches to execute (multiple of TRIP).
+constexpr size_t AHEAD = 8, TRIP = 18;
 inline uint32_t device_stream(const Program &p, std::vector<uint32_t> &dev, std::vector<uint32_t> &cmds) {
     const size_t batches = p.n_vrows / BATCH;
     const size_t run = (batches + TRIP - 1) / TRIP * TRIP;
