@@ -154,6 +154,39 @@ def synth_inputs(name: str, q: int, batch: int, n_inputs: int, seed: int):
     return np.frombuffer(b"".join(v.to_bytes(32, "little") for v in vals), dtype=np.uint8).reshape(batch, n_inputs, 32).copy()
 
 
+class BoolInputs:
+    """Boolean inputs held as one byte each ([B][n_inputs] of 0/1) that index like the canonical [B][n_inputs][32] image
+    (`--packed-inputs`: a 53-block SHA-256 batch of 65 536 is 57 GB in canonical form, 221 MB as packed masks)."""
+
+    def __init__(self, bits):
+        self.bits = bits
+        self.nbytes = int(bits.shape[0]) * int(bits.shape[1]) * 32
+
+    def __getitem__(self, key):
+        import numpy as np
+        if isinstance(key, tuple) and len(key) == 3 and key[2] == 0:
+            return self.bits[key[0], key[1]]
+        if isinstance(key, tuple):
+            return self[key[0]][key[1]]
+        row = np.zeros((self.bits.shape[1], 32), dtype=np.uint8)
+        row[:, 0] = self.bits[key]
+        return row
+
+    def masks(self):
+        import numpy as np
+        B, n = self.bits.shape
+        ng = (B + 63) // 64
+        out = np.empty((ng, n), dtype=np.uint64)
+        for g0 in range(0, ng, 64):                          # 64 groups at a time: the padded copy stays small
+            g1 = min(ng, g0 + 64)
+            blk = np.zeros(((g1 - g0) * 64, n), dtype=np.uint8)
+            part = self.bits[g0 * 64:min(B, g1 * 64)]
+            blk[:part.shape[0]] = part
+            m = np.packbits(blk.reshape(g1 - g0, 64, n), axis=1, bitorder="little")
+            out[g0:g1] = np.ascontiguousarray(m.transpose(0, 2, 1)).view(np.uint64).reshape(g1 - g0, n)
+        return out
+
+
 def parity_check(cp, circ, batch, h_in, workload: str, n_sample: int = 4):
     """Oracle comparison at the benchmark batch (after the timed region).  Returns a dict for the JSON line; raises
     AssertionError on any mismatch (a fast wrong answer is not a result)."""
@@ -285,6 +318,10 @@ def main():
                     help="CPU rehearsal of the N-rank launch (gloo, host-only batches: inputs are staged and validated through "
                          "the C ABI, nothing computes - there is no CPU fallback); used by tests/test_bench_spawn.py")
     ap.add_argument("--cache-dir", default=os.environ.get("CW_CACHE", ""))
+    ap.add_argument("--packed-inputs", action="store_true",
+                    help="boolean circuits: the batch's inputs enter as packed masks (cw_set_inputs_bits_device, one bit per "
+                         "input and instance) in the timed steps too; the canonical 32-byte image is never materialised")
+    ap.add_argument("--parity-instances", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-small", action="store_true", help="skip the batch-4096 side measurement (profiling runs)")
@@ -352,9 +389,17 @@ def main():
         B //= 2                                              # the value table did not fit: halve the batch once
         batch = circ.batch(B, device=local_rank, stream=stream.cuda_stream)
     # synthetic inputs, resident in HBM before the timed region (different seed per rank = different shard)
-    h_in = synth_inputs(args.workload, circ.q, B, circ.n_inputs, seed=1 + rank)
-    d_in = torch.from_numpy(h_in).to(dev)
-    batch.set_inputs_device(d_in.data_ptr())
+    if args.packed_inputs:
+        assert batch.bitmode and args.workload.startswith("sha256_"), "--packed-inputs needs a bit-plane circuit"
+        h_in = BoolInputs(np.random.default_rng(1 + rank).integers(0, 2, size=(B, circ.n_inputs), dtype=np.uint8))
+        main_masks = h_in.masks()
+        d_in = torch.from_numpy(main_masks.view(np.int64)).to(dev)
+        set_in = lambda b_: b_.set_inputs_bits_device(d_in.data_ptr())
+    else:
+        h_in = synth_inputs(args.workload, circ.q, B, circ.n_inputs, seed=1 + rank)
+        d_in = torch.from_numpy(h_in).to(dev)
+        set_in = lambda b_: b_.set_inputs_device(d_in.data_ptr())
+    set_in(batch)
     # Steps are independent batches, so consecutive steps may overlap: `in_flight` batch objects (own tables, own HIP
     # stream each) take the steps in turn; the evaluation of step k+1 (vector-memory / issue bound) runs while the R1CS check
     # of step k (scalar-load / latency bound) is still going.  Every step is a complete pass: ingest + evaluation + check of
@@ -367,7 +412,7 @@ def main():
             b_ = circ.batch(B, device=local_rank, stream=st_.cuda_stream)
         except rt.CwError:
             break                                            # no room for another table: fewer batches in flight
-        b_.set_inputs_device(d_in.data_ptr())
+        set_in(b_)
         streams.append(st_)
         batches.append(b_)
     n_fl = len(batches)
@@ -430,7 +475,7 @@ def main():
 
     parity = None
     if not args.no_parity:
-        parity = parity_check(cp, circ, batch, h_in, args.workload)       # every rank checks its own shard
+        parity = parity_check(cp, circ, batch, h_in, args.workload, args.parity_instances)   # every rank checks its own shard
         parity["parity_checked"] = len(parity["instances"])
 
     # canonical egress: the 32-byte-per-element image a prover reads (SURVEY 8d's B_gen: what the reference's
@@ -475,7 +520,7 @@ def main():
 
     # packed boolean inputs (cw_set_inputs_bits_device): one bit per input and instance instead of 32 bytes
     packed = None
-    if rank == 0 and batch.bitmode and args.workload.startswith("sha256_"):
+    if rank == 0 and batch.bitmode and args.workload.startswith("sha256_") and not args.packed_inputs:
         ng = (B + 63) // 64
         bits01 = np.zeros((ng * 64, circ.n_inputs), dtype=np.uint8)
         bits01[:B] = h_in[:, :, 0]
@@ -507,7 +552,7 @@ def main():
                   "eval_ms": sum(e[0].elapsed_time(e[1]) for e in pe) / args.steps,
                   "input_bytes_per_step": int(masks.nbytes), "canonical_input_bytes_per_step": int(h_in.nbytes)}
         for b_ in batches:
-            b_.set_inputs_device(d_in.data_ptr())
+            set_in(b_)
         del pub2
 
     # Fp mul/s half of the metric: 2^24 lanes x 1024 dependent Montgomery products, bn128 and bls12381
@@ -529,7 +574,7 @@ def main():
     small = None
     if rank == 0 and world == 1 and args.workload == "sha256_2048" and B > 4096 and not args.batch and not args.no_small:
         b2 = circ.batch(4096, device=local_rank, stream=stream.cuda_stream)
-        b2.set_inputs_device(d_in.data_ptr())
+        set_in(b2)
         ev2 = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(4)]
         for e in ev2:
             e[0].record(stream); b2.run(); e[1].record(stream); b2.check_r1cs(); e[2].record(stream)
@@ -641,8 +686,11 @@ def main():
                        "n_signals": circ.n_signals, "n_witness": n_wit, "n_constraints": circ.n_constraints,
                        "engine": "bit-plane (1 bit per signal value per instance)" if batch.bitmode else
                        ("256-bit schedule, signals in Montgomery form" if circ.montgomery else "256-bit schedule"),
-                       "bit_program": bits, "schedule_rows": circ.n_rows, "fp_mul_per_witness": circ.n_mmul,
+                       "bit_program": bits, "r1cs_check_classes": (circ.bits_r1cs_plan_stats() if batch.bitmode else None),
+                       "schedule_rows": circ.n_rows, "fp_mul_per_witness": circ.n_mmul,
                        "parallelism": "instances sharded x%d, status + public-signal gather only" % world,
+                       "inputs": "packed boolean masks (8 bytes per input and 64 instances)" if args.packed_inputs else
+                       "canonical 32-byte field elements",
                        "in_flight": n_fl, "compile_s": compile_s, "compile_cached": compile_cached,
                        "shard_of": args.shard_of or None, "total_batch": args.total_batch or None},
             "value_canonical": value_canonical if batch.bitmode else value,

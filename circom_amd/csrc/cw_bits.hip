@@ -204,14 +204,18 @@ struct BitsEval {
     // v_readlane where a wave-uniform value is needed.  Scalar loads would be the natural fit, but they share the
     // LGKM counter with the LDS and return out of order: with one in flight hipcc turns every LDS wait into
     // lgkmcnt(0) - the pipelined operand reads of the next steps then serialise behind a ~200-clock scalar load.
-    uint32_t cprev, ccur, cnext;
+    uint32_t cprev;
 
     static __device__ __forceinline__ uint32_t word(const uint4 (&r)[4], int k, int i) {
         const int d = 2 * k + i;
         const uint4 &q = r[d >> 2];
         return (d & 3) == 0 ? q.x : (d & 3) == 1 ? q.y : (d & 3) == 2 ? q.z : q.w;
     }
+#ifdef CW_EXP_NOCMD       /* timing experiment only (tools/bits_exp.sh): every command block reads as empty */
+    static __device__ __forceinline__ uint32_t cw(uint32_t, int) { return 0; }
+#else
     static __device__ __forceinline__ uint32_t cw(uint32_t blk, int j) { return (uint32_t)__builtin_amdgcn_readlane((int)blk, j); }
+#endif
 
     // records of batch b, load j: 1 KiB at (b * 4 + j) * 1024, lane l takes 16 bytes at l * 16 (32-bit lane offset +
     // scalar batch offset)
@@ -224,6 +228,7 @@ struct BitsEval {
     }
 
     __device__ __forceinline__ void batch(uint32_t bi, const uint4 (&cur)[4], const uint4 (&nxt)[4], uint4 (&fill)[4],
+                                          const uint32_t ccur, uint32_t &cfill,
                                           const mask_t (&lprev)[BITS_MAX_LOADS], mask_t (&lfill)[BITS_MAX_LOADS]) {
         // the rows the PREVIOUS batch completed leave now: the first two (a batch completes 1.4 rows on average) are read
         // from the LDS before anything of this batch is written and stored a step later, without a wait on the spot
@@ -245,7 +250,10 @@ struct BitsEval {
 #pragma unroll
         for (int j = 0; j < 4; j++) fill[j] = rec_load(bi + BITS_AHEAD, j);
 #endif
-        cnext = cmd_load(bi + 1);
+        // the command block travels with the records of its batch (same age in the in-order request queue: the wait for it
+        // leaves the newer BITS_AHEAD - 1 batches of requests in flight.  Requested one batch ahead, as the first version of
+        // this kernel did, its wait was a vmcnt(0) at the top of every batch: the queue drained 280 times a launch.)
+        cfill = cmd_load(bi + BITS_AHEAD);
 #pragma unroll
         for (int k = 0; k < BITS_NB; k++) {
             if (k == 1) {
@@ -268,13 +276,16 @@ struct BitsEval {
             const uint32_t n0 = k + 1 < BITS_NB ? word(cur, k + 1 < BITS_NB ? k + 1 : 0, 0) : word(nxt, 0, 0);
             const uint32_t n1 = k + 1 < BITS_NB ? word(cur, k + 1 < BITS_NB ? k + 1 : 0, 1) : word(nxt, 0, 1);
             const mask_t na = M::lds(n0 & 0xFFF8u), nb = M::lds(n0 >> 16), nc = M::lds(n1 & 0xFFFFu);
+            // the three reads of step k + 1 are ISSUED before step k computes (left to itself the scheduler put them behind
+            // the four v_bitop3: 8 instructions between a read and its wait, ~35 clocks of a lone wave against an LDS latency
+            // of ~100; in front there are 17)
+            __builtin_amdgcn_sched_barrier(0);
             const uint32_t w0 = word(cur, k, 0), w1 = word(cur, k, 1);
             const uint32_t k1 = (uint32_t)((int32_t)(w0 << 31) >> 31), k2 = (uint32_t)((int32_t)(w0 << 30) >> 31);
             M::lds_st(w1 >> 16, M::prim(a, b, c, k1, k2));
             a = na; b = nb; c = nc;
         }
         cprev = ccur;
-        ccur = cnext;
     }
 
     // after the last batch: what it completed, and the row loads it may still hold are dropped (nothing reads them)
@@ -329,31 +340,31 @@ cw_bits_eval_kernel(const uint4 *__restrict__ recs, const uint32_t *__restrict__
         R7[j] = E.rec_load(7, j);
     }
     E.cprev = 0;
-    E.ccur = E.cmd_load(0);
-    E.cnext = 0;
+    uint32_t C0 = E.cmd_load(0), C1 = E.cmd_load(1), C2 = E.cmd_load(2), C3 = E.cmd_load(3), C4 = E.cmd_load(4),
+             C5 = E.cmd_load(5), C6 = E.cmd_load(6), C7 = E.cmd_load(7), C8 = 0;
     E.a = M::lds(R0[0].x & 0xFFF8u);
     E.b = M::lds(R0[0].x >> 16);
     E.c = M::lds(R0[0].y & 0xFFFFu);
     static_assert(BITS_AHEAD == 8, "the rotation below is written for 9 record sets");
     for (uint32_t bi = 0; bi < n_batches; bi += 18) {
-        E.batch(bi + 0, R0, R1, R8, L0, L1);
-        E.batch(bi + 1, R1, R2, R0, L1, L0);
-        E.batch(bi + 2, R2, R3, R1, L0, L1);
-        E.batch(bi + 3, R3, R4, R2, L1, L0);
-        E.batch(bi + 4, R4, R5, R3, L0, L1);
-        E.batch(bi + 5, R5, R6, R4, L1, L0);
-        E.batch(bi + 6, R6, R7, R5, L0, L1);
-        E.batch(bi + 7, R7, R8, R6, L1, L0);
-        E.batch(bi + 8, R8, R0, R7, L0, L1);
-        E.batch(bi + 9, R0, R1, R8, L1, L0);
-        E.batch(bi + 10, R1, R2, R0, L0, L1);
-        E.batch(bi + 11, R2, R3, R1, L1, L0);
-        E.batch(bi + 12, R3, R4, R2, L0, L1);
-        E.batch(bi + 13, R4, R5, R3, L1, L0);
-        E.batch(bi + 14, R5, R6, R4, L0, L1);
-        E.batch(bi + 15, R6, R7, R5, L1, L0);
-        E.batch(bi + 16, R7, R8, R6, L0, L1);
-        E.batch(bi + 17, R8, R0, R7, L1, L0);
+        E.batch(bi + 0, R0, R1, R8, C0, C8, L0, L1);
+        E.batch(bi + 1, R1, R2, R0, C1, C0, L1, L0);
+        E.batch(bi + 2, R2, R3, R1, C2, C1, L0, L1);
+        E.batch(bi + 3, R3, R4, R2, C3, C2, L1, L0);
+        E.batch(bi + 4, R4, R5, R3, C4, C3, L0, L1);
+        E.batch(bi + 5, R5, R6, R4, C5, C4, L1, L0);
+        E.batch(bi + 6, R6, R7, R5, C6, C5, L0, L1);
+        E.batch(bi + 7, R7, R8, R6, C7, C6, L1, L0);
+        E.batch(bi + 8, R8, R0, R7, C8, C7, L0, L1);
+        E.batch(bi + 9, R0, R1, R8, C0, C8, L1, L0);
+        E.batch(bi + 10, R1, R2, R0, C1, C0, L0, L1);
+        E.batch(bi + 11, R2, R3, R1, C2, C1, L1, L0);
+        E.batch(bi + 12, R3, R4, R2, C3, C2, L0, L1);
+        E.batch(bi + 13, R4, R5, R3, C4, C3, L1, L0);
+        E.batch(bi + 14, R5, R6, R4, C5, C4, L0, L1);
+        E.batch(bi + 15, R6, R7, R5, C6, C5, L1, L0);
+        E.batch(bi + 16, R7, R8, R6, C7, C6, L0, L1);
+        E.batch(bi + 17, R8, R0, R7, C8, C7, L1, L0);
     }
     E.drain();
 }

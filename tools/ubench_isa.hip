@@ -195,7 +195,11 @@ __global__ void __launch_bounds__(256) k_lds(uint64_t *out, uint32_t seed) {
     uint64_t acc = seed, a = 1, b = 2, c = 3, a2 = 4, b2 = 5, c2 = 6;
     const uint32_t km = (lane & 1) ? ~0u : 0u;
     uint64_t t0 = __builtin_readcyclecounter();
-    for (int it = 0; it < LTRIPS; it++) {
+    constexpr int UNR = MODE == 4 ? 16 : MODE == 5 ? 32 : 1;          // 4, 5: mode 2 as 15 / 30 KB of straight-line code
+    for (int it0 = 0; it0 < LTRIPS; it0 += UNR) {
+#pragma unroll
+      for (int u = 0; u < UNR; u++) {
+        const int it = it0 + u;
         if (MODE == 0) {
             uint64_t v[8];
 #pragma unroll
@@ -208,7 +212,7 @@ __global__ void __launch_bounds__(256) k_lds(uint64_t *out, uint32_t seed) {
             for (int k = 0; k < 8; k++) *(lds_u64 *)(uintptr_t)(addr[k] + 8192 - 8192) = acc + k;
             acc += it;
         }
-        if (MODE == 2 || MODE == 3) {
+        if (MODE >= 2) {
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const uint32_t w0 = addr[k] + (uint32_t)it * 0, w1 = addr[(k + 3) & 7];
@@ -221,10 +225,11 @@ __global__ void __launch_bounds__(256) k_lds(uint64_t *out, uint32_t seed) {
                              : "v"((uint32_t)a), "v"((uint32_t)(a >> 32)), "v"((uint32_t)b), "v"((uint32_t)(b >> 32)), "v"((uint32_t)c),
                                "v"((uint32_t)(c >> 32)), "v"(k1), "v"(k2));
                 *(lds_u64 *)(uintptr_t)(addr[(k + 1) & 7]) = ((uint64_t)hi << 32) | lo;
-                if (MODE == 2) { a = na; b = nb; c = nc; }
+                if (MODE != 3) { a = na; b = nb; c = nc; }
                 else { a = a2; b = b2; c = c2; a2 = na; b2 = nb; c2 = nc; }
             }
         }
+      }
     }
     uint64_t t1 = __builtin_readcyclecounter();
     out[blockIdx.x * 256 + threadIdx.x] = (uint64_t)(uint32_t)(acc ^ a ^ b ^ c) | ((t1 - t0) << 32);
@@ -321,6 +326,8 @@ int main(int argc, char **argv) {
     run_lds<1>("ds_write_b64 x8", 0, js, first);
     run_lds<2>("eval step, reads 1 ahead", 1, js, first);
     run_lds<3>("eval step, reads 2 ahead", 1, js, first);
+    run_lds<4>("eval step, 15 KB of code", 1, js, first);
+    run_lds<5>("eval step, 30 KB of code", 1, js, first);
     run_fill<0>("fill, plain stores", js, first);
     run_fill<1>("fill, nt stores", js, first);
     run_fill<2>("copy", js, first);
