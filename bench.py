@@ -40,7 +40,7 @@ VALU_CLK_PER_WAVE_INST = 2.0       # a SIMD-32 issues a wave64 VALU instruction 
 LONE_WAVE_CLK_PER_INST = 4.1       # ONE wave issues at most one instruction of any kind per ~4.1 clocks (tools/ubench_isa)
 BITS_VALU_PER_VROW = 10            # cw_bits_eval_kernel<64>, from the disassembly: 3 operand offsets, 2 mask expansions, 1 result
 BITS_INSTS_PER_VROW = 15           # offset, 4 v_bitop3  + 3 ds_read_b64, 1 ds_write_b64, 1 s_waitcnt
-DEFAULT_BATCH = {"sha256_2048": 65536, "sha256_512": 4096, "poseidon2": 65536, "semaphore20": 8192, "semaphore20p": 8192}
+DEFAULT_BATCH = {"bigmultmodp": 8192, "sha256_2048": 65536, "sha256_512": 4096, "poseidon2": 65536, "semaphore20": 8192, "semaphore20p": 8192}
 
 
 def _semaphore_shape(name: str):
@@ -62,6 +62,13 @@ def make_program(name: str):
         from circom_amd.circuits.eddsa import SemaphoreStyle
         levels, proj = _semaphore_shape(name)
         return Program(SemaphoreStyle(levels, proj))
+    if name.startswith("bigmultmodp"):
+        # circom-ecdsa's field multiplication (a * b mod p on k limbs of n bits; the witness comes from the run-time
+        # functions long_div / short_div with value-dependent branches = tier 2) on the BLS12-381 scalar field:
+        # BASELINE config 5's building block.  bigmultmodp = 3 limbs of 32 bits; bigmultmodp_<n>_<k> picks the shape
+        from circom_amd.circuits.bigint import BigMultModP
+        n, k = ([int(x) for x in name.split("_")[1:3]] if "_" in name else (32, 3))
+        return Program(BigMultModP(n, k), prime="bls12381")
     raise SystemExit("unknown workload " + name)
 
 
@@ -137,6 +144,21 @@ def synth_inputs(name: str, q: int, batch: int, n_inputs: int, seed: int):
         arr = np.zeros((batch, n_inputs, 32), dtype=np.uint8)
         arr[:, :, 0] = bits
         return arr
+    if name.startswith("bigmultmodp"):
+        n, k = ([int(x) for x in name.split("_")[1:3]] if "_" in name else (32, 3))
+        import random
+        rnd = random.Random(seed)
+        out = np.zeros((batch, n_inputs, 32), dtype=np.uint8)
+        pool = []
+        for it in range(min(batch, 512)):                  # 512 distinct (a, b, p): every instance takes its own branches
+            p = rnd.randrange(1 << (n * k - 1), 1 << (n * k))
+            a, b = rnd.randrange(p), rnd.randrange(p)
+            vals = [(x >> (n * i)) & ((1 << n) - 1) for x in (a, b, p) for i in range(k)]
+            pool.append(np.frombuffer(b"".join(v.to_bytes(32, "little") for v in vals), dtype=np.uint8).reshape(n_inputs, 32))
+        perm = rng.integers(0, len(pool), size=batch)
+        for i in range(batch):
+            out[i] = pool[perm[i]]
+        return out
     if name.startswith("semaphore"):
         # valid EdDSA signatures + Merkle paths must be synthesised on the host: 64 distinct
         # (key, message, signature, path) vectors, tiled over the batch (the schedule is data-independent)
@@ -219,7 +241,7 @@ def parity_check(cp, circ, batch, h_in, workload: str, n_sample: int = 4):
         want = {}
         for i in picks:
             inp = {fc.main_input_start + k: int.from_bytes(h_in[i, k].tobytes(), "little") for k in range(n_in)}
-            sig, failed = eval_flat(circ.q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp)
+            sig, failed = eval_flat(circ.q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp, getattr(fc, "functions", ()))
             assert failed is None, "oracle reports a failed assert for instance %d" % i
             want[i] = wtns_bytes(circ.q, sig)
         out["oracle"] = "oracle/tape_eval.eval_flat (Python restatement of the emitted calculator), full .wtns bytes"
@@ -679,7 +701,7 @@ def main():
             "dtype": "bit-plane boolean gates on u64 instance masks (u256 Montgomery fallback for non-boolean instances)" if batch.bitmode
             else "u256 (9x29-bit limbs, Montgomery multiply)",
             "data": "synthetic",
-            "config": {"workload": "%s bn128 --O0 (%d constraints), batch=%d per GPU" % (args.workload, circ.n_constraints, B),
+            "config": {"workload": "%s %s --O0 (%d constraints), batch=%d per GPU" % (args.workload, cp.flat.prime, circ.n_constraints, B),
                        "value_is": ("witness generated + R1CS-verified per second, resident as bit planes (1 bit per signal value and "
                                     "instance); value_canonical includes writing the 32-byte-per-element image") if batch.bitmode else
                        "witness generated + R1CS-verified per second, resident as 32-byte field elements (the table IS the image)",

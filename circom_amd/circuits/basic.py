@@ -89,3 +89,30 @@ def MixedArray(c, widths):
         for j in range(n):
             acc = acc + ps[i]["out"][j][m - 1] * (i + 2)
     c.set(s, acc)
+
+
+@template
+def LogSquare(c):
+    """a sub-component that logs while it runs: its line appears where the component FIRES (after its last input)"""
+    x = c.input("in")
+    y = c.output("out")
+    c.set(y, x * x)
+    c.log("square of", x, "is", y)
+
+
+@template
+def LogDemo(c):
+    """`log(...)` in the shapes LogBucket knows (log_bucket.rs:105-162): strings, signals, expressions, several arguments,
+    no argument, inside a sub-component, before and after a run-time check that an instance may fail"""
+    a = c.input("a")
+    b = c.input("b")
+    out = c.output("out")
+    c.log("inputs:", a, b)
+    sq = c.component("sq", LogSquare())
+    c.set(sq["in"], a + b)
+    c.log(a * b + 7)
+    c.log()
+    c.log("constant", 42)
+    c.assert_(a.neq(13))
+    c.set(out, sq["out"] + a)
+    c.log("out =", out, "(after the check)")

@@ -65,6 +65,8 @@ def lower_bitplane(fc: FlatCircuit, bits="auto"):
     instance whose inputs are not 0/1 is re-run by the 256-bit schedule, so tiny arithmetic circuits gain nothing)."""
     if bits is False or (bits == "auto" and fc.n_signals < BITS_AUTO_MIN_SIGNALS) or fc.n_main_inputs == 0:
         return None
+    if (fc.code["op"] == O.LOG).any():
+        return None         # logged values live in the 256-bit table (hidden signals); the bit table has no place for them
     from .hip_elements.bitblast import bitblast
     from .hip_elements.bitsched import lower_bits
     net = bitblast(fc)

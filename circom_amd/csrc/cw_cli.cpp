@@ -85,7 +85,15 @@ int main(int argc, char **argv) {
     int failed = 0;
     const bool many = strstr(argv[3], "%d") != nullptr;
     if (!many && ins.size() > 1) { fprintf(stderr, "%zu inputs need an output pattern with %%d\n", ins.size()); return 2; }
+    const bool logs = cw_n_log_statements(c) != 0;
     for (size_t i = 0; i < ins.size(); i++) {
+        if (logs) {                 // what the reference binary prints for this input (log(...) statements), instance by instance
+            const int64_t n = cw_get_log(b, (uint32_t)i, nullptr, 0);
+            if (n < 0) { fprintf(stderr, "cw_get_log: %s\n", cw_last_error()); return 2; }
+            std::vector<char> text((size_t)n + 1);
+            if (cw_get_log(b, (uint32_t)i, text.data(), text.size()) < 0) { fprintf(stderr, "cw_get_log: %s\n", cw_last_error()); return 2; }
+            fwrite(text.data(), 1, (size_t)n, stdout);
+        }
         if (st[i]) {
             fprintf(stderr, "instance %zu: %s%s%s\n", i, (st[i] & 1) ? "Failed assert " : "", (st[i] & 2) ? "division by zero " : "",
                     (st[i] & 4) ? "R1CS row violated" : "");

@@ -247,6 +247,11 @@ struct cw_circuit {
     bool has_bits = false;
     cwbits::Program bits;
     std::vector<uint32_t> r_cc, r_cctab;   // per term: id of its canonical coefficient in r_cctab (8 words each)
+    // log(...) statements (LogBucket): the LAST n_logv of n_signals are hidden signals holding their arguments
+    uint32_t n_logv = 0;
+    struct LogItem { bool is_value = false; uint32_t value = 0; std::string text; };
+    struct LogStmt { uint32_t at = 0; std::vector<LogItem> items; };      // at = flat operation that ends the statement
+    std::vector<LogStmt> logs;
 };
 
 static uint64_t fnv1a(const char *s, size_t n) {   // calcwit.cpp:17-24
@@ -405,7 +410,7 @@ static int load_tape(cw_circuit *c, const char *path) {
     if (!read_file(path, b)) return fail(CW_EIO, std::string("tape file not found: ") + path);
     if (b.size() < 16 + 32 + 48 || memcmp(b.data(), "CWTP", 4)) return fail(CW_EIO, "bad tape magic");
     const uint32_t *h = (const uint32_t *)(b.data() + 4);
-    if (h[0] != 9) return fail(CW_EIO, "unsupported tape version");
+    if (h[0] != 10) return fail(CW_EIO, "unsupported tape version");
     if (h[1] != 4) return fail(CW_EIO, "only 4x64-bit primes are supported (bn128, bls12381, ...)");
     uint32_t n_variants = h[2];
     size_t off = 16;
@@ -429,15 +434,19 @@ static int load_tape(cw_circuit *c, const char *path) {
     const uint32_t n_bit_programs = m[10], n_functions = m[11];
     c->n_dat_consts = m[12];                 // constants / io-map templates of the matching .dat (load_dat checks its sections)
     c->n_io_templates = m[13];
-    if (m[14] || m[15] || c->n_io_templates > (1u << 20) || (c->n_dat_consts != 0xFFFFFFFFu && c->n_dat_consts > (1u << 26)))
-        return fail(CW_EIO, "tape header: reserved words / section counts");
+    const uint32_t n_log_statements = m[14];
+    c->n_logv = m[15];
+    if (n_log_statements > (1u << 20) || c->n_logv >= c->n_signals || c->n_io_templates > (1u << 20) ||
+        (c->n_dat_consts != 0xFFFFFFFFu && c->n_dat_consts > (1u << 26)))
+        return fail(CW_EIO, "tape header: section counts");
+    if (c->n_logv && n_bit_programs) return fail(CW_EIO, "tape header: log values cannot be combined with a bit-plane program");
     if (n_functions > (1u << 16)) return fail(CW_EIO, "tape header: too many functions");
     if (n_bit_programs > 1) return fail(CW_EIO, "tape header: more than one bit-plane program");
     if (c->mont && (n_bit_programs || n_functions))
         return fail(CW_EIO, "tape header: Montgomery-form signals cannot be combined with a bit-plane program or run-time functions");
     // shape of the main component: slot 0 is the constant 1, outputs from slot 1, inputs right after them
     if (c->input_start == 0 || (uint64_t)c->input_start + c->n_inputs > c->n_signals || c->n_pub_in > c->n_inputs ||
-        c->n_witness == 0 || c->n_witness > c->n_signals || hsize < 256 || (hsize & (hsize - 1)) ||
+        c->n_witness == 0 || c->n_witness > c->n_signals - c->n_logv || hsize < 256 || (hsize & (hsize - 1)) ||
         n_names > hsize || hsize > std::max<uint64_t>(256, 2 * (uint64_t)n_names) ||            // max(2^ceil(log2 n), 256), mod.rs:167
         (hsize > 256 && hsize / 2 >= n_names) || n_names > c->n_inputs + 1u)
         return fail(CW_EIO, "tape header: inconsistent circuit shape");
@@ -463,7 +472,7 @@ static int load_tape(cw_circuit *c, const char *path) {
     memcpy(c->w2s.data(), b.data() + off, (size_t)c->n_witness * 4);
     off += (size_t)c->n_witness * 4;
     for (uint32_t s : c->w2s)
-        if (s >= c->n_signals) return fail(CW_EIO, "tape witness list refers to a signal out of range");
+        if (s >= c->n_signals - c->n_logv) return fail(CW_EIO, "tape witness list refers to a signal out of range");
     for (uint32_t i = 0; i < n_names; i++) {
         if (off + 4 > b.size()) return fail(CW_EIO, "tape names truncated");
         uint32_t len;
@@ -522,6 +531,38 @@ static int load_tape(cw_circuit *c, const char *path) {
         c->fn_tab.push_back(0);
         fn_regs.push_back(n_regs);
         c->need_full = true;               // the interpreter lives in the full-operator kernel variant
+    }
+    // log statements: strings and references to the hidden signals
+    {
+        uint32_t seen = 0;
+        for (uint32_t li = 0; li < n_log_statements; li++) {
+            if (off + 8 > b.size()) return fail(CW_EIO, "tape log program truncated");
+            uint32_t lh[2];
+            memcpy(lh, b.data() + off, 8);
+            off += 8;
+            cw_circuit::LogStmt st;
+            st.at = lh[0];
+            if (lh[1] > (1u << 16) || (!c->logs.empty() && st.at <= c->logs.back().at)) return fail(CW_EIO, "tape log program: bad statement");
+            for (uint32_t k = 0; k < lh[1]; k++) {
+                if (off + 8 > b.size()) return fail(CW_EIO, "tape log program truncated");
+                uint32_t ih[2];
+                memcpy(ih, b.data() + off, 8);
+                off += 8;
+                cw_circuit::LogItem it;
+                if (ih[0] == 0) {
+                    if (ih[1] > b.size() - off) return fail(CW_EIO, "tape log program truncated");
+                    it.text.assign((const char *)b.data() + off, ih[1]);
+                    off += ih[1];
+                } else if (ih[0] == 1 && ih[1] == seen) {       // values are numbered in statement order
+                    it.is_value = true;
+                    it.value = ih[1];
+                    seen++;
+                } else return fail(CW_EIO, "tape log program: bad item");
+                st.items.push_back(std::move(it));
+            }
+            c->logs.push_back(std::move(st));
+        }
+        if (seen != c->n_logv) return fail(CW_EIO, "tape log program: value count differs from the header");
     }
     if (n_variants == 0) return fail(CW_EIO, "tape holds no schedule");
     for (uint32_t v = 0; v < n_variants; v++) {
@@ -974,7 +1015,8 @@ extern "C" int64_t cw_io_map_offset(const cw_circuit *c, uint32_t template_id, u
         if (t.id == template_id) return signal_code < t.defs.size() ? (int64_t)t.defs[signal_code].offset : -1;
     return -1;
 }
-extern "C" uint32_t cw_n_signals(const cw_circuit *c) { return c->n_signals; }
+extern "C" uint32_t cw_n_signals(const cw_circuit *c) { return c->n_signals - c->n_logv; }     // the circuit's signals (hidden log values excluded)
+extern "C" uint32_t cw_n_log_statements(const cw_circuit *c) { return c ? (uint32_t)c->logs.size() : 0; }
 extern "C" uint32_t cw_n_witness(const cw_circuit *c) { return c->n_witness; }
 extern "C" uint32_t cw_n_inputs(const cw_circuit *c) { return c->n_inputs; }
 extern "C" uint32_t cw_input_start(const cw_circuit *c) { return c->input_start; }
@@ -2341,6 +2383,39 @@ extern "C" int cw_explain(cw_batch *b, uint32_t instance, const char *sym_path, 
     }
     snprintf(out, out_len, "%s", t.c_str());
     return CW_OK;
+}
+
+// What the reference binary prints on stdout for this instance (LogBucket code, log_bucket.rs:105-162: arguments through
+// printf, values as Fr_element2str = canonical residue in decimal, one blank between arguments, newline at the end), up
+// to the first failed run-time check (the reference process exits there: statements that end behind that operation of the
+// witness program are not printed).  Returns the length of the text (without the terminator) or a negative error code;
+// at most out_len - 1 characters are stored.
+extern "C" int64_t cw_get_log(cw_batch *b, uint32_t instance, char *out, size_t out_len) {
+    if (!b || (!out && out_len)) return fail(CW_EINVAL, "null argument");
+    if (instance >= b->batch) return fail(CW_EINVAL, "instance out of range");
+    cw_circuit *c = b->c;
+    std::string t;
+    if (!c->logs.empty()) {
+        std::vector<uint32_t> st(b->batch);
+        if (int rc = cw_get_status(b, st.data())) return rc;
+        const uint32_t s = st[instance];
+        const uint32_t stop = (s & (CW_ST_ASSERT_FAILED | CW_ST_ARITH)) ? (s >> 8) : 0xFFFFFFFFu;
+        for (const auto &stmt : c->logs) {
+            if (stmt.at >= stop) break;
+            for (size_t k = 0; k < stmt.items.size(); k++) {
+                const auto &it = stmt.items[k];
+                if (it.is_value) {
+                    uint8_t v[32];
+                    if (int rc = cw_get_signal(b, instance, c->n_signals - c->n_logv + it.value, v)) return rc;
+                    t += u256_dec(v);
+                } else t += it.text;
+                if (k + 1 < stmt.items.size()) t += " ";
+            }
+            t += "\n";
+        }
+    }
+    if (out_len) snprintf(out, out_len, "%s", t.c_str());
+    return (int64_t)t.size();
 }
 
 extern "C" void *cw_device_values(cw_batch *b, uint64_t *n_bytes, uint32_t *padded_batch) {

@@ -297,7 +297,7 @@ __device__ __forceinline__ fe eval_dotc(uint32_t n, const fe &c0, const fe &prev
 // Reference: the emitted C++ of a function is real control flow on Fr_isTrue / Fr_toInt (loop_bucket.rs:76-91,
 // branch_bucket.rs:100-122, compute_bucket.rs:361-363, call_bucket.rs:466-533); the trip counts differ per input, so the
 // trace cannot unroll it.  Every lane has its own program counter; per turn the wave executes the instruction of its
-// first unfinished lane for all lanes that sit on it (SIMT divergence, lanes elsewhere wait their turn).  Registers are
+// unfinished lane with the LOWEST program counter for all lanes that sit on it (SIMT divergence, lanes elsewhere wait).  Registers are
 // 256-bit values in the lane's column of consecutive temp slots (the call's window): operand loads and result stores
 // go to the value table like any spilled temporary — this is the slow path by design (tier 2).
 __device__ __forceinline__ fe fn_operand(uint32_t x, const char *regs, const EvalCtx &c) {
@@ -327,9 +327,22 @@ __device__ __noinline__ void eval_call(uint32_t fn, uint64_t reg_off, uint32_t r
     char *regs = (char *)c.Vb + reg_off;
     uint32_t pc = 0, steps = 0;
     bool done = false;
+    const uint32_t lane = __lane_id();
+    const int pc_bits = 32 - __builtin_clz(ft.y | 1u);                   // instruction indices are < ft.y (wave-uniform)
     while (__any(!done)) {
+        // The instruction to issue = the LOWEST program counter among the unfinished lanes (found bit by bit with ballots:
+        // no cross-lane data movement, lanes outside EXEC never matter).  The bytecode of rtcode.py is structured - an
+        // `if` jumps forward over its body, a loop jumps back to its head - so lanes that took different sides of a branch
+        // meet again at its join instead of running one after the other to the end of the function (the first version
+        // followed the first unfinished lane: 32 lanes with 32 different paths through long_div cost 32 passes).
+        uint64_t cand = __ballot(!done);
+        uint32_t cur = 0;
+        for (int bit = pc_bits - 1; bit >= 0; bit--) {
+            const uint64_t z = __ballot(!done && ((cand >> lane) & 1ull) && !((pc >> bit) & 1u));
+            if (z) cand = z;
+            else cur |= 1u << bit;
+        }
         if (!done) {
-            const uint32_t cur = __builtin_amdgcn_readfirstlane(pc);     // the first unfinished lane's instruction
             if (pc == cur) {
                 const uint4 ins = code[cur];                              // wave-uniform
                 const uint32_t op = ins.x, d = ins.y;

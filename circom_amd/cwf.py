@@ -8,7 +8,7 @@ fixes that hand-over as a file, so that the Rust side (integration/code_producer
 cargo) and the Python stand-in emit the same bytes, and `python -m circom_amd.hip_backend x.cwf` lowers either.
 
 Layout (little endian):
-     0  "CWFL" | u32 version = 1 | u32 n64 (limbs of the prime) | u32 flags (0)
+     0  "CWFL" | u32 version = 2 | u32 n64 (limbs of the prime) | u32 flags (0)
     16  prime, n64 * 8 bytes
         10 x u32: n_signals, n_temps, n_constants, main_input_start, n_main_inputs, n_public_inputs, n_outputs,
                   n_input_names, n_ops, n_constraints
@@ -24,6 +24,7 @@ Layout (little endian):
                          into the function's constants) | n_fconsts x n64*8 bytes
                          (register bytecode of circom functions with run-time control flow, frontend/rtcode.py)
         io map           u32 n | per template: u32 id | u32 n_defs | per def: u32 offset | u32 n_dims | dims | u32 size | u32 bus
+        log strings      u32 n | per string: u32 len | bytes      (string table of the LOG rows: opcodes.py LOG)
 """
 from __future__ import annotations
 
@@ -35,7 +36,7 @@ import numpy as np
 from .field import Fp, PRIMES
 
 MAGIC = b"CWFL"
-VERSION = 1
+VERSION = 2
 COLS = ("op", "dk", "dv", "ak", "av", "bk", "bv", "ck", "cv")
 
 
@@ -88,6 +89,11 @@ def write_cwf(path, fc):
             f.write(struct.pack("<II", tid, len(defs)))
             for offset, dims, size, bus in defs:
                 f.write(struct.pack("<II", offset, len(dims)) + b"".join(struct.pack("<I", d) for d in dims) + struct.pack("<II", size, bus))
+        strings = list(getattr(fc, "log_strings", ()))
+        f.write(struct.pack("<I", len(strings)))
+        for t in strings:
+            b = t.encode()
+            f.write(struct.pack("<I", len(b)) + b)
 
 
 def read_cwf(path):
@@ -165,9 +171,17 @@ def read_cwf(path):
             off += 16 + 4 * ndim
             defs.append((offset, tuple(dims), size, bus))
         io_map.append((tid, defs))
+    (n_str,) = struct.unpack_from("<I", b, off)
+    off += 4
+    log_strings = []
+    for _ in range(n_str):
+        (ln,) = struct.unpack_from("<I", b, off)
+        log_strings.append(b[off + 4: off + 4 + ln].decode())
+        off += 4 + ln
     if off != len(b):
         raise ValueError(".cwf: trailing bytes")
     prime = next((n for n, p in PRIMES.items() if p == q), "")
     return SimpleNamespace(fp=Fp(q, prime), prime=prime, n_signals=n_signals, n_temps=n_temps, constants=consts,
                            main_input_start=main_in0, n_main_inputs=n_in, n_pub_in=n_pub, n_prv_in=n_in - n_pub, n_outputs=n_out,
-                           inputs=inputs, code=code, constraints=constraints, functions=functions, io_map=io_map)
+                           inputs=inputs, code=code, constraints=constraints, functions=functions, io_map=io_map,
+                           log_strings=log_strings)

@@ -555,9 +555,19 @@ class Ctx:
         self._row(O.ASSERT_EQ, O.K_NONE, 0, lhs, rhs)
 
     def log(self, *args):
-        """`log(...)`: the reference prints through printf per process (log_bucket.rs:105-162); a batched kernel has
-        no per-instance console, so logs are dropped at trace time."""
-        return None
+        """`log(arg, ...)`: strings and expressions (LogBucket, log_bucket.rs:105-162: the reference prints every argument
+        with printf - values through Fr_element2str, i.e. the canonical residue in decimal - separated by blanks, then a
+        newline).  One LOG row per argument; the row that ends the statement carries dv = 1.  A batched run has no console
+        per instance: the lowering keeps every logged value in the table and `cw_get_log` formats the text the reference
+        binary prints for one instance."""
+        items = list(args) or [None]
+        for k, a in enumerate(items):
+            last = 1 if k == len(items) - 1 else 0
+            if a is None or isinstance(a, str):
+                sid = -1 if a is None else self.prog.log_string_id(a)
+                self._row(O.LOG, O.K_NONE, last, Expr(self, O.K_NONE, sid, None))
+            else:
+                self._row(O.LOG, O.K_NONE, last, self.lift(a))
 
     def assert_(self, cond):
         """`assert(cond)`."""
@@ -691,6 +701,17 @@ class Program:
                 raise CircuitError("public signal %r is not an input of main" % name)
         if self.public:
             self._reorder_main_public()
+
+    def log_string_id(self, text: str) -> int:
+        """string table of the log statements (the producer's string table, c_elements/mod.rs get_string_table)"""
+        if not hasattr(self, "log_strings"):
+            self.log_strings, self._log_string_ids = [], {}
+        i = self._log_string_ids.get(text)
+        if i is None:
+            i = len(self.log_strings)
+            self._log_string_ids[text] = i
+            self.log_strings.append(text)
+        return i
 
     def const_id(self, v: int) -> int:
         i = self._const_ids.get(v)

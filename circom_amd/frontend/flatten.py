@@ -121,6 +121,14 @@ class FlatCircuit:
         self.code = {k: (np.concatenate(v) if v else np.zeros(0, dtype=np.int64)) for k, v in chunks.items()}
         self.constraints = cons
         self.io_map = self._build_io_map()
+        self.log_strings = list(getattr(self.prog, "log_strings", ()))
+        self.n_log_values = int(((self.code["op"] == O.LOG) & (self.code["ak"] != O.K_NONE)).sum())
+
+    def log_program(self):
+        return log_program(self)
+
+    def code_with_log_copies(self):
+        return code_with_log_copies(self)
 
     def _build_io_map(self):
         """TemplateInstanceIOMap of compiler/src/circuit_design/build.rs:488-520: the component arrays of a template whose
@@ -192,6 +200,41 @@ class FlatCircuit:
                     for j, nm in enumerate(arr_names(pre, name, dims)):
                         names[base + off + j] = nm
         return names
+
+
+def log_program(fc):
+    """The `log(...)` statements in execution order: [(index of the flat operation that ends the statement, [item])],
+    item = ("s", string id) | ("v", j): the j-th logged value of the program (LOG rows with an operand, in order)."""
+    op, ak, av, dv = fc.code["op"], fc.code["ak"], fc.code["av"], fc.code["dv"]
+    out, items, j = [], [], 0
+    for i in np.nonzero(op == O.LOG)[0]:
+        if ak[i] != O.K_NONE:
+            items.append(("v", j))
+            j += 1
+        elif av[i] >= 0:
+            items.append(("s", int(av[i])))
+        if dv[i]:
+            out.append((int(i), items))
+            items = []
+    assert not items
+    return out
+
+
+def code_with_log_copies(fc):
+    """The flat code as the lowering sees it: a LOG row with an operand is a COPY of that operand into a HIDDEN signal
+    (ids n_signals .. n_signals + n_log_values - 1: table slots that are no witness elements), the other LOG rows
+    are RUN markers (ignored).  Row indices are unchanged (failure reports name flat operations by index)."""
+    code = {k: v.copy() for k, v in fc.code.items()}
+    j = 0
+    for i in np.nonzero(code["op"] == O.LOG)[0]:
+        if code["ak"][i] != O.K_NONE:
+            code["op"][i] = O.COPY
+            code["dk"][i], code["dv"][i] = K_SIG, fc.n_signals + j
+            j += 1
+        else:
+            code["op"][i] = O.RUN
+            code["dk"][i], code["dv"][i] = O.K_NONE, 0
+    return code, j
 
 
 def flatten(prog: Program) -> FlatCircuit:

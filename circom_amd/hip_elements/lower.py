@@ -132,6 +132,8 @@ class Tape:
         self.kind = 0               # 0 = strand schedule (passes C/D), 1 = pipelined single-wave schedule (pipe.py)
         self.pipe = (0, 0, 0)       # kind 1: rows per batch, loads per batch, ring entries
         self.functions = []         # device bytecode of circom functions: (n_regs, uint32[n,4])
+        self.log_strings = []       # string table of the log statements
+        self.log_prog = []          # [(flat operation that ends the statement, [("s", string id) | ("v", j-th hidden signal)])]
 
 
 def _dce(code, n_temps, nregs=()):
@@ -1136,6 +1138,20 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None, mont
         raise ValueError("hip_elements targets circom's 253..256-bit primes (4 x 64-bit limbs); prime %s has %d bits "
                          "(the 64-bit Goldilocks runtime is a separate code path of the reference, out of scope)"
                          % (fc.prime, q.bit_length()))
+    circuit_signals = fc.n_signals
+    if (fc.code["op"] == O.LOG).any():
+        # log(...) arguments stay in the table as HIDDEN signals behind the circuit's own (flatten.code_with_log_copies):
+        # the schedule computes and keeps them like signals, the witness list does not name them, cw_get_log reads them
+        import copy
+        from ..frontend.flatten import log_program, code_with_log_copies
+        log_prog, log_strings = log_program(fc), list(fc.log_strings)
+        fc = copy.copy(fc)
+        fc.code, n_logv = code_with_log_copies(fc)
+        fc.n_signals = circuit_signals + n_logv
+        if witness_map is None:
+            witness_map = np.arange(circuit_signals, dtype=np.uint32)
+    else:
+        log_prog, log_strings = [], []
     n_signals = fc.n_signals
     functions = getattr(fc, "functions", ())
     if pipe is not None:
@@ -1183,6 +1199,7 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None, mont
                          {"copies_elided": n_elided, "fused_madd": n_madd, "inv_batches": n_inv_batches, "linsum": n_lin,
                           "bit": n_bit, "asserts_proved": getattr(_expand, "n_proved", 0), "mont": int(mont), "mont_conversions": n_conv})
         t.mont = bool(mont)
+        t.log_strings, t.log_prog = log_strings, log_prog
         return t
 
     def vid(k, v):
@@ -1455,4 +1472,5 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None, mont
         "temp_slots": n_tslots,
         "consts": len(dconsts),
     }
+    t.log_strings, t.log_prog = log_strings, log_prog
     return t

@@ -93,7 +93,7 @@ def dat_io_map(io_map) -> bytes:
 
 
 TAPE_MAGIC = b"CWTP"
-TAPE_VERSION = 9
+TAPE_VERSION = 10
 
 
 def write_tape(path, tapes, bittape=None):
@@ -104,12 +104,16 @@ def write_tape(path, tapes, bittape=None):
             16 x u32: n_signals, n_witness, n_consts, main_input_start, n_main_inputs, n_input_names,
                       hashmap_size, rbits (Montgomery radix exponent of MMUL rows; bit 16 set = the value table holds
                       Montgomery forms, lower.py pass A6), n_lconsts, n_public_inputs,
-                      n_bit_programs (0 | 1), n_functions, constants in the .dat, io-map templates in the .dat, 0, 0
+                      n_bit_programs (0 | 1), n_functions, constants in the .dat, io-map templates in the .dat,
+                      n_log_statements, n_log_values (hidden signals: the LAST n_log_values of n_signals hold the arguments
+                      of the log statements, lower.py)
             consts          n_consts x n64*8 bytes (raw residues as the schedule expects them)
             lconsts         n_lconsts x n64*8 bytes (coef*R' of D_DOTC terms; the runtime keeps them as 29-bit limbs)
             witness2signal  n_witness x u32
             input names     per name  u32 len | bytes | u32 start | u32 size
             functions       n_functions x { u32 n_regs | u32 n_ins | n_ins x 4 x u32 }   (device bytecode, lower.py D_CALL)
+            log program     n_log_statements x { u32 flat operation that ends the statement | u32 n_items |
+                            n_items x { u32 0 | u32 len | bytes   (a string)   or   u32 1 | u32 j   (the j-th logged value) } }
             per variant     u32 n_strands | u32 n_tslots | u32 n_rows | u32 n_extras | u32 n_lds | u32 n_terms | u32 kind | u32 shape
                             stream_off | extra_off | term_off      ((n_strands+1) x u32 each)
                             rows n_rows x 4 x u32 | extras n_extras x u32 | terms n_terms x 4 x u32
@@ -135,7 +139,8 @@ def write_tape(path, tapes, bittape=None):
                             len(t0.inputs), hashmap_size(len(t0.inputs)), t0.rbits | (0x10000 if getattr(t0, "mont", False) else 0),
                             len(t0.lconsts), t0.n_pub_in,
                             1 if bittape is not None else 0, len(t0.functions),
-                            getattr(t0, "n_dat_consts", 0xFFFFFFFF), getattr(t0, "n_io_templates", 0), 0, 0))
+                            getattr(t0, "n_dat_consts", 0xFFFFFFFF), getattr(t0, "n_io_templates", 0),
+                            len(getattr(t0, "log_prog", ())), sum(1 for _, items in getattr(t0, "log_prog", ()) for it in items if it[0] == "v")))
         f.write(b"".join(c.to_bytes(8 * n64, "little") for c in t0.consts))
         f.write(b"".join(c.to_bytes(8 * n64, "little") for c in t0.lconsts))
         f.write(np.asarray(t0.witness2signal, dtype="<u4").tobytes())
@@ -145,6 +150,14 @@ def write_tape(path, tapes, bittape=None):
         for n_regs, fcode in t0.functions:       # circom functions with run-time control flow (lower.py D_CALL)
             f.write(struct.pack("<2I", n_regs, len(fcode)))
             f.write(np.ascontiguousarray(fcode, dtype="<u4").tobytes())
+        for at, items in getattr(t0, "log_prog", ()):
+            f.write(struct.pack("<2I", at, len(items)))
+            for kind, v in items:
+                if kind == "s":
+                    b = t0.log_strings[v].encode()
+                    f.write(struct.pack("<2I", 0, len(b)) + b)
+                else:
+                    f.write(struct.pack("<2I", 1, v))
         for t in tapes:
             kind = getattr(t, "kind", 0)
             shape = (t.pipe[0] | (t.pipe[1] << 8)) if kind == 1 else len(t.seqs)

@@ -93,6 +93,8 @@ _SIGS = {
     "cw_get_r1cs_first_bad": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cw_write_wtns_many": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p]),
     "cw_explain": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_size_t]),
+    "cw_n_log_statements": (C.c_uint32, [C.c_void_p]),
+    "cw_get_log": (C.c_int64, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_size_t]),
     "cw_r1cs_plan_stats": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "cw_device_values": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "cw_fp_mul_bench": (C.c_int, [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -311,6 +313,17 @@ class Batch:
 
     def write_wtns(self, instance: int, path):
         _chk(lib().cw_write_wtns(self.h, instance, os.fsencode(str(path))))
+
+    def log(self, instance: int) -> str:
+        """what the reference binary prints on stdout for this instance (its log(...) statements)"""
+        n = lib().cw_get_log(self.h, instance, None, 0)
+        if n < 0:
+            _chk(int(n))
+        buf = C.create_string_buffer(int(n) + 1)
+        n = lib().cw_get_log(self.h, instance, buf, len(buf))
+        if n < 0:
+            _chk(int(n))
+        return buf.value.decode()
 
 
 def fp_mul_bench(q: int, a: np.ndarray, b: np.ndarray, iters: int, device: int = 0):

@@ -160,6 +160,14 @@ int cw_write_wtns_many(cw_batch *b, uint32_t first, uint32_t count, const char *
  * and every wire with its name from <name>.sym (may be NULL) and value — the batch counterpart of the trace the
  * reference prints before aborting (c_code_generator.rs:461-468, calcwit.cpp:104-114) */
 int cw_explain(cw_batch *b, uint32_t instance, const char *sym_path, char *out, size_t out_len);
+/* log(...) statements of the circuit (LogBucket, compiler/src/intermediate_representation/log_bucket.rs:105-162: the
+ * emitted calculator prints every argument with printf - values through Fr_element2str - one blank between arguments
+ * and a newline per statement).  A batched run has no console per instance: the schedule keeps every logged value in
+ * the table (hidden signals behind the circuit's own; cw_n_signals does not count them) and cw_get_log formats what the
+ * reference binary prints on stdout for ONE instance, up to its first failed run-time check (where the reference process
+ * exits).  Returns the length of the text or a negative CW_E* code; stores at most out_len - 1 characters + NUL. */
+uint32_t cw_n_log_statements(const cw_circuit *c);
+int64_t cw_get_log(cw_batch *b, uint32_t instance, char *out, size_t out_len);
 /* first violated constraint per instance after cw_check_r1cs: [batch], 0xFFFFFFFF = none */
 int cw_get_r1cs_first_bad(cw_batch *b, uint32_t *row);
 /* host-only: build and hazard-check the LDS staging plan of the R1CS check kernel for `chunks` row chunks

@@ -55,6 +55,7 @@ pub enum FlatOpcode {
     AssertNz = 26,
     Run = 27,
     Call = 28,
+    Log = 29,
 }
 
 /// Operand kinds of the flat program (`opcodes.py` K_*).
@@ -116,7 +117,7 @@ pub const CWF_HEADER_FIELDS: [&str; 10] = [
     "n_constraints",
 ];
 pub const CWF_MAGIC: &[u8; 4] = b"CWFL";
-pub const CWF_VERSION: u32 = 1;
+pub const CWF_VERSION: u32 = 2;
 /// Columns of the flat code section, in file order (cwf.py `COLS`), each n_ops x i64.
 pub const CWF_CODE_COLUMNS: [&str; 9] = ["op", "dk", "dv", "ak", "av", "bk", "bv", "ck", "cv"];
 
@@ -134,6 +135,8 @@ pub struct HipProducer {
     pub main_input_list: Vec<(String, usize, usize)>,    // (name, first signal, size), InputList of c_elements/mod.rs:12
     pub field_tracking: Vec<String>,     // constant list (decimal strings), index = ValueBucket.value for BigInt values
     pub io_map: Vec<(u32, Vec<FlatIoDef>)>,
+    pub string_table: Vec<String>,       // the producer's string table (c_elements/mod.rs get_string_table), set by build.rs
+    pub log_strings: Vec<String>,        // the strings the trace's LOG rows name, in first-use order
     // the trace
     pub ops: Vec<FlatOp>,
     pub n_temps: usize,
@@ -144,6 +147,17 @@ impl HipProducer {
     pub fn new_temp(&mut self) -> Operand {
         self.n_temps += 1;
         Operand::temp(self.n_temps - 1)
+    }
+    /// index in `log_strings` of string `id` of the producer's string table (LogBucketArg::LogStr)
+    pub fn log_string(&mut self, id: usize) -> usize {
+        let text = self.string_table[id].clone();
+        match self.log_strings.iter().position(|t| *t == text) {
+            Some(i) => i,
+            None => {
+                self.log_strings.push(text);
+                self.log_strings.len() - 1
+            }
+        }
     }
     pub fn emit(&mut self, op: FlatOpcode, dst: Operand, a: Operand, b: Operand) {
         self.ops.push(FlatOp { op, dst, a, b, c: Operand::none() });
@@ -232,6 +246,11 @@ impl HipProducer {
                 w.write_all(&d.size.to_le_bytes())?;
                 w.write_all(&d.bus_id.to_le_bytes())?;
             }
+        }
+        w.write_all(&(self.log_strings.len() as u32).to_le_bytes())?;
+        for t in &self.log_strings {
+            w.write_all(&(t.len() as u32).to_le_bytes())?;
+            w.write_all(t.as_bytes())?;
         }
         w.flush()
     }

@@ -28,7 +28,7 @@
 use crate::circuit_design::circuit::Circuit;
 use crate::circuit_design::template::TemplateCode;
 use crate::intermediate_representation::ir_interface::*;
-use code_producers::hip_elements::{FlatOpcode, HipProducer, Operand};
+use code_producers::hip_elements::{FlatOpcode, HipProducer, Operand, K_NONE};
 use num_bigint_dig::BigInt;
 use circom_algebra::modular_arithmetic as ma;
 
@@ -169,7 +169,24 @@ impl<'a> Tracer<'a> {
                 }
                 Ok(())
             }
-            Instruction::Log(_) => Ok(()),                      // log() is dropped (a batch has no single stdout)
+            Instruction::Log(b) => {
+                // LogBucket (log_bucket.rs:105-162): one LOG row per argument - the value as operand a, or kind NONE with the
+                // string-table index (-1: `log()` without arguments) - and dst.value = 1 on the row that ends the statement.
+                // The lowering keeps every logged value in the table; cw_get_log formats the reference's stdout per instance.
+                let n = b.argsprint.len();
+                if n == 0 {
+                    self.p.emit(FlatOpcode::Log, Operand { kind: K_NONE, value: 1 }, Operand { kind: K_NONE, value: -1 }, Operand::none());
+                }
+                for (k, arg) in b.argsprint.iter().enumerate() {
+                    let last = if k + 1 == n { 1 } else { 0 };
+                    let a = match arg {
+                        LogBucketArg::LogExp(e) => { let v = self.eval(e, f)?; self.materialise(v) }
+                        LogBucketArg::LogStr(id) => Operand { kind: K_NONE, value: self.p.log_string(*id) as i64 },
+                    };
+                    self.p.emit(FlatOpcode::Log, Operand { kind: K_NONE, value: last }, a, Operand::none());
+                }
+                Ok(())
+            }
             Instruction::Call(b) => Err(HipError::RunTimeControl { line: b.line, what: "function call as a statement" }),   // TODO(tier2)
             Instruction::Return(b) => Err(HipError::Unsupported { line: b.line, what: "return outside a traced function" }),
             Instruction::Value(_) | Instruction::Load(_) | Instruction::Compute(_) => {

@@ -22,7 +22,7 @@ from pathlib import Path
 COPY, ADD, SUB, MUL, DIV, IDIV, MOD, POW, NEG = range(9)
 SHL, SHR, BAND, BOR, BXOR, BNOT = range(9, 15)
 LT, GT, LEQ, GEQ, EQ, NEQ, LAND, LOR, LNOT = range(15, 24)
-SELECT, ASSERT_EQ, ASSERT_NZ, RUN, CALL = range(24, 29)
+SELECT, ASSERT_EQ, ASSERT_NZ, RUN, CALL, LOG = range(24, 30)
 F_JZ, F_JMP, F_LDX, F_STX, F_RET = 100, 101, 102, 103, 104      # circom_amd/frontend/rtcode.py
 K_SIG, K_TMP, K_CONST, K_NONE = 0, 1, 2, 3
 SYM = {ADD: "Fr_add", SUB: "Fr_sub", MUL: "Fr_mul", DIV: "Fr_div", IDIV: "Fr_idiv", MOD: "Fr_mod", POW: "Fr_pow",
@@ -120,6 +120,14 @@ def _emit_instance(inst, out):
                 continue
             stmts.append("assert(!(ctx->componentMemory[mySubcomponents[%d]].inputCounter)); %s_run(mySubcomponents[%d],ctx);"
                          % (ci, child.header, ci))
+            continue
+        if o == LOG:                # LogBucket, statement by statement as log_bucket.rs:105-162 prints it
+            if ak[i] != 3:
+                stmts.append("{ char* temp = Fr_element2str(%s); printf(\"%%s\",temp); delete [] temp; }" % _ref(inst, ak[i], av[i]))
+            elif av[i] >= 0:
+                text = inst.prog.log_strings[av[i]].replace("\\", "\\\\").replace("\"", "\\\"").replace("\n", "\\n")
+                stmts.append("{ printf(\"%s\"); }" % text)
+            stmts.append("{ printf(\"\\n\"); }" if dv[i] else "{ printf(\" \"); }")
             continue
         if o == CALL:               # CallBucket (call_bucket.rs:466-533): the callee works on its own lvar arena
             stmts.append("rtfn_%d(ctx,&expaux[%d]);" % (av[i], bv[i]))

@@ -14,7 +14,7 @@ from .field import Field, FieldError
 COPY, ADD, SUB, MUL, DIV, IDIV, MOD, POW, NEG = range(9)
 SHL, SHR, BAND, BOR, BXOR, BNOT = range(9, 15)
 LT, GT, LEQ, GEQ, EQ, NEQ, LAND, LOR, LNOT = range(15, 24)
-SELECT, ASSERT_EQ, ASSERT_NZ, RUN, CALL = range(24, 29)
+SELECT, ASSERT_EQ, ASSERT_NZ, RUN, CALL, LOG = range(24, 30)
 K_SIG, K_TMP, K_CONST, K_NONE = 0, 1, 2, 3
 F_JZ, F_JMP, F_LDX, F_STX, F_RET = 100, 101, 102, 103, 104      # circom_amd/frontend/rtcode.py
 CALL_STEP_LIMIT = 1 << 20
@@ -84,8 +84,11 @@ def run_function(f: Field, fn: dict, regs: list, base: int, constants) -> bool:
             raise ValueError("bad function opcode %d" % op)
 
 
-def eval_flat(q: int, n_signals: int, n_temps: int, constants, code, inputs: dict, functions=()):
-    """inputs: {signal slot: canonical value}.  Returns (signals list, failed_row or None)."""
+def eval_flat(q: int, n_signals: int, n_temps: int, constants, code, inputs: dict, functions=(), log=None, log_strings=()):
+    """inputs: {signal slot: canonical value}.  Returns (signals list, failed_row or None).
+    log: a list that receives the text of the log(...) statements, one entry per statement with its newline, as the
+    emitted calculator prints them (log_bucket.rs:105-162: values through Fr_element2str = the canonical residue in
+    decimal, arguments separated by one blank) up to the first failed check (where the reference process exits)."""
     f = Field(q)
     sig = [0] * n_signals
     sig[0] = 1
@@ -105,8 +108,19 @@ def eval_flat(q: int, n_signals: int, n_temps: int, constants, code, inputs: dic
         return constants[v]
 
     failed = None
+    line = []
     for i in range(len(op_)):
         op = int(op_[i])
+        if op == LOG:                       # one argument of a log statement; dv = 1 on the row that ends it
+            if int(ak[i]) != 3:             # K_NONE: a string (av = its id, -1 = no argument)
+                line.append(str(rd(int(ak[i]), int(av[i])) % q))
+            elif int(av[i]) >= 0:
+                line.append(log_strings[int(av[i])])
+            if int(dv[i]):
+                if log is not None and failed is None:
+                    log.append(" ".join(line) + "\n")
+                line = []
+            continue
         if op == CALL:                      # a = function id, b = first register (a temporary)
             if not run_function(f, functions[int(av[i])], tmp, int(bv[i]), constants) and failed is None:
                 failed = i

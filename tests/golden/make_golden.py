@@ -74,9 +74,47 @@ def cases():
     return out
 
 
+def log_cases():
+    """name -> (builder, prime, input rows as {name: value}): circuits whose log(...) output is pinned (stdout of the
+    reference binary, main.cpp + the LogBucket code of log_bucket.rs:105-162)"""
+    from circom_amd.circuits.basic import LogDemo
+    q = PRIMES["bn128"]
+    r = random.Random(5)
+    return {"logdemo": (lambda: Program(LogDemo()), "bn128",
+                        [{"a": 3, "b": 4}, {"a": 0, "b": 0}, {"a": q - 1, "b": 2}, {"a": 13, "b": 1},
+                         {"a": r.randrange(q), "b": r.randrange(q)}])}
+
+
+def make_logs():
+    """tests/golden/reference_logs.json: stdout, exit status and .wtns digest of the reference CLI per input row.  For an
+    instance that fails a run-time check only the lines BEFORE the reference's own failure trace are kept (`log`)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_logs.json")
+    result = {"generator": "tests/golden/make_golden.py logs", "cases": {}}
+    for name, (mk, prime, rows) in log_cases().items():
+        d = tempfile.mkdtemp(prefix="goldenlog_")
+        cp = compile_program(mk(), d, name, sym=False, strands=(1,))
+        ref_build.build_circuit(cp)
+        entries = []
+        for row in rows:
+            out = os.path.join(d, "o.wtns")
+            if os.path.exists(out):
+                os.unlink(out)
+            r = ref_build.run_cli(cp, json.dumps({k: str(v) for k, v in row.items()}), out)
+            ok = r.returncode == 0
+            text = r.stdout if ok else r.stdout[:r.stdout.index("Failed assert")]
+            entries.append({"inputs": {k: str(v) for k, v in row.items()}, "ok": ok, "log": text,
+                            "wtns_sha256": hashlib.sha256(open(out, "rb").read()).hexdigest() if ok else None})
+        result["cases"][name] = {"prime": prime, "vectors": entries}
+        print(name, len(rows), "vectors")
+    with open(path, "w") as f:
+        json.dump(result, f, indent=1)
+
+
 def main():
     """`make_golden.py` regenerates everything; `make_golden.py NAME...` only (re)generates the named cases and keeps
     the other entries of the JSON as they are."""
+    if sys.argv[1:] == ["logs"]:
+        return make_logs()
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_wtns.json")
     only = set(sys.argv[1:])
     result = {"generator": "tests/golden/make_golden.py", "runtime": "reference common/{main,calcwit}.cpp + generic/fr.cpp (GMP, no asm)",

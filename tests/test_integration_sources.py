@@ -55,7 +55,7 @@ def test_opcode_numbering_agrees():
             "Neg": O.NEG, "ShiftL": O.SHL, "ShiftR": O.SHR, "BitAnd": O.BAND, "BitOr": O.BOR, "BitXor": O.BXOR, "Complement": O.BNOT,
             "Lesser": O.LT, "Greater": O.GT, "LesserEq": O.LEQ, "GreaterEq": O.GEQ, "Eq": O.EQ, "NotEq": O.NEQ, "BoolAnd": O.LAND,
             "BoolOr": O.LOR, "BoolNot": O.LNOT, "Select": O.SELECT, "AssertEq": O.ASSERT_EQ, "AssertNz": O.ASSERT_NZ, "Run": O.RUN,
-            "Call": O.CALL}
+            "Call": O.CALL, "Log": O.LOG}
     assert nums == want
     kinds = {k: int(v) for k, v in re.findall(r"pub const (K_\w+): i64 = (\d+);", MOD)}
     assert kinds == {"K_SIG": O.K_SIG, "K_TMP": O.K_TMP, "K_CONST": O.K_CONST, "K_NONE": O.K_NONE}
