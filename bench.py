@@ -704,7 +704,9 @@ def main():
             "config": {"workload": "%s %s --O0 (%d constraints), batch=%d per GPU" % (args.workload, cp.flat.prime, circ.n_constraints, B),
                        "value_is": ("witness generated + R1CS-verified per second, resident as bit planes (1 bit per signal value and "
                                     "instance); value_canonical includes writing the 32-byte-per-element image") if batch.bitmode else
-                       "witness generated + R1CS-verified per second, resident as 32-byte field elements (the table IS the image)",
+                       ("witness generated + R1CS-verified per second, resident as 32-byte field elements in the value table "
+                        "([signal][instance] order" + (", Montgomery form" if circ.montgomery else "") + "); value_canonical includes "
+                        "writing the reference's image ([instance][witness element], canonical residues)"),
                        "n_signals": circ.n_signals, "n_witness": n_wit, "n_constraints": circ.n_constraints,
                        "engine": "bit-plane (1 bit per signal value per instance)" if batch.bitmode else
                        ("256-bit schedule, signals in Montgomery form" if circ.montgomery else "256-bit schedule"),
@@ -715,7 +717,7 @@ def main():
                        "canonical 32-byte field elements",
                        "in_flight": n_fl, "compile_s": compile_s, "compile_cached": compile_cached,
                        "shard_of": args.shard_of or None, "total_batch": args.total_batch or None},
-            "value_canonical": value_canonical if batch.bitmode else value,
+            "value_canonical": value_canonical,
             "value_canonical_hbm_frac": (egress["frac_of_hbm_peak"] if egress else None),
             # the dominant kernel of THIS run (longest measured duration)
             "roofline": roof_eval if gen_ms >= chk_ms else roof_r1cs,

@@ -1078,16 +1078,22 @@ cw_gather_kernel(const uint4 *__restrict__ V, const uint32_t *__restrict__ w2s, 
 }
 
 // ---- bulk egress: witnesses of `count` consecutive instances as [count][n_witness][32 B] ----------------------
-// SoA -> AoS transpose through LDS: a 256-thread block moves a tile of 64 instances x 32 witness elements.
+// SoA -> AoS transpose through LDS: a 256-thread block moves a tile of 64 instances x GM_TILE witness elements.
 // Reads are coalesced along instances (the table's layout), writes along the witness index (the output's).
+#ifndef GM_TILE
+#define GM_TILE 16        // witness elements per block: 33 KB of LDS, four blocks per CU.  Poseidon(2) x 65 536 (2.3 GB image, Montgomery
+                          // -> canonical on the way): 16 -> 0.86 ms = 2.69 TB/s written + as much read (the copy roof of
+                          // tools/ubench_isa is 2.4 + 2.4); 8 -> 1.05 ms; 32 (66 KB, two blocks per CU) -> 1.19 ms; round 2's
+                          // kernel (32, default-policy stores) 1.28 ms
+#endif
 template <bool MONT>
 __global__ void __launch_bounds__(256)
 cw_gather_many_kernel(const uint4 *__restrict__ V, const uint32_t *__restrict__ w2s, uint32_t n_wit, uint32_t Bp,
                       uint32_t first, uint32_t count, uint4 *__restrict__ out, FpParams P) {
-    __shared__ uint4 tile[32][2][65];                               // [element][half][instance] (+1: bank spread)
-    const uint32_t k0 = blockIdx.x * 32, i0 = blockIdx.y * 64;
+    __shared__ uint4 tile[GM_TILE][2][65];                          // [element][half][instance] (+1: bank spread)
+    const uint32_t k0 = blockIdx.x * GM_TILE, i0 = blockIdx.y * 64;
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;  // 4 waves
-    for (uint32_t e = wv; e < 32; e += 4) {
+    for (uint32_t e = wv; e < GM_TILE; e += 4) {
         const uint32_t k = k0 + e;
         if (k < n_wit && i0 + lane < count) {
             const size_t base = (size_t)w2s[k] * 2 * Bp + first + i0 + lane;
@@ -1104,12 +1110,18 @@ cw_gather_many_kernel(const uint4 *__restrict__ V, const uint32_t *__restrict__ 
         }
     }
     __syncthreads();
-    // 64 consecutive 16-byte pieces of one instance's row = 32 elements x 2 halves
-    const uint32_t piece = threadIdx.x & 63, e = piece >> 1, h = piece & 1;
-    for (uint32_t ii = wv; ii < 64; ii += 4) {
+    // 2 * GM_TILE consecutive 16-byte pieces of one instance's row = GM_TILE elements x 2 halves; a wave writes 64 / (2 *
+    // GM_TILE) instances per store instruction, streaming (nothing reads the image back on this device)
+    constexpr uint32_t PIECES = 2 * GM_TILE, PER = 64 / PIECES;
+    const uint32_t piece = lane % PIECES, sub = lane / PIECES, e = piece >> 1, h = piece & 1;
+    for (uint32_t ii = wv * PER + sub; ii < 64; ii += 4 * PER) {
         const uint32_t k = k0 + e;
-        if (k < n_wit && i0 + ii < count)
-            out[((size_t)(i0 + ii) * n_wit + k) * 2 + h] = tile[e][h][ii];
+        if (k < n_wit && i0 + ii < count) {
+            const uint4 v = tile[e][h][ii];
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 w = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(w, (u32x4 *)&out[((size_t)(i0 + ii) * n_wit + k) * 2 + h]);
+        }
     }
 }
 
@@ -1290,7 +1302,7 @@ hipError_t cwk_gather(hipStream_t s, const void *V, const uint32_t *w2s, uint32_
 hipError_t cwk_gather_many(hipStream_t s, const void *V, const uint32_t *w2s, uint32_t n_wit, uint32_t Bp, uint32_t first,
                            uint32_t count, void *out, bool mont, const FpParams &P) {
     if (!count || !n_wit) return hipSuccess;
-    dim3 g((n_wit + 31) / 32, (count + 63) / 64);
+    dim3 g((n_wit + GM_TILE - 1) / GM_TILE, (count + 63) / 64);
     if (mont)
         hipLaunchKernelGGL(cw_gather_many_kernel<true>, g, dim3(256), 0, s, (const uint4 *)V, w2s, n_wit, Bp, first, count, (uint4 *)out, P);
     else
