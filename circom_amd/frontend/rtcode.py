@@ -193,7 +193,147 @@ class RtFunction:
         for c in self.code:
             if c[0] in (F_JZ, F_JMP) and c[1] is None:
                 raise RtError("unresolved jump")
+        self.code_built, self.n_regs_built, self.ret_base_built = self.code, self.n_regs, self.ret_base   # as written (tests)
+        self._optimise()
         self.id = None                # set by Program.register_function
+
+    # ---- bytecode optimisation ------------------------------------------------------------------------------------
+    # The builder is SSA-flavoured: every operator result and every `var` gets a fresh register and `var = expr` is an
+    # operator followed by a COPY.  On the device a register is a 32-byte column of the value table and every
+    # instruction is a round trip to it (csrc/cw_kernels.hip eval_call), so both the instruction count and the size of
+    # the register window (does it stay in the L2?) are the cost.  Two passes, both on the finished bytecode:
+    #   1. an operator whose result is only read by the COPY right behind it writes the COPY's destination itself;
+    #   2. registers are renumbered by live range (backward dataflow over the jumps, then a linear scan): arguments keep
+    #      their places, results follow them, blocks addressed through F_LDX / F_STX stay contiguous and live throughout.
+    @staticmethod
+    def _reads(c):
+        """(scalar registers read, array windows (base, n) touched) of one instruction"""
+        op = c[0]
+        regs, wins = [], []
+        if op == F_RET or op == F_JMP:
+            return regs, wins
+        if op == F_JZ:
+            return [c[2][1]], wins
+        if op == F_LDX:
+            return [c[3][0]], [(c[2], c[3][1])]
+        if op == F_STX:
+            regs.append(c[3][0])
+            if c[2][0] == 'r':
+                regs.append(c[2][1])
+            return regs, [(c[1], c[3][1])]
+        for o in (c[2], c[3]):
+            if o is not None and o[0] == 'r':
+                regs.append(o[1])
+        return regs, wins
+
+    def _optimise(self):
+        code = self.code
+        n = len(code)
+        in_block = set()                       # registers inside an indexed window (and the argument views of them)
+        for c in code:
+            for base, ln in self._reads(c)[1]:
+                in_block.update(range(base, base + ln))
+        fixed = set(range(self.n_args)) | set(range(self.ret_base, self.ret_base + self.n_ret)) | in_block
+        targets = {c[1] for c in code if c[0] in (F_JZ, F_JMP)}
+        uses, defs = {}, {}
+        for c in code:
+            for r in self._reads(c)[0]:
+                uses[r] = uses.get(r, 0) + 1
+            if c[0] not in (F_JZ, F_JMP, F_RET, F_STX):
+                defs[c[1]] = defs.get(c[1], 0) + 1
+        # pass 1: fold `t = a op b; v = t` into `v = a op b`
+        keep = [True] * n
+        out = list(code)
+        for i in range(n - 1):
+            c, d = out[i], out[i + 1]
+            if c[0] in (F_JZ, F_JMP, F_RET, F_STX) or d[0] != O.COPY or d[2] != ('r', c[1]):
+                continue
+            t = c[1]
+            if t in fixed or uses.get(t, 0) != 1 or defs.get(t, 0) != 1 or (i + 1) in targets or d[1] in in_block:
+                continue
+            out[i] = (c[0], d[1], c[2], c[3])
+            keep[i + 1] = False
+        remap, k = [], 0
+        for i in range(n):
+            remap.append(k)
+            k += keep[i]
+        remap.append(k)
+        code = [((c[0], remap[c[1]], c[2], c[3]) if c[0] in (F_JZ, F_JMP) else c) for c, kp in zip(out, keep) if kp]
+        n = len(code)
+        # pass 2: live ranges
+        succ = []
+        for i, c in enumerate(code):
+            if c[0] == F_RET:
+                succ.append(())
+            elif c[0] == F_JMP:
+                succ.append((c[1],))
+            elif c[0] == F_JZ:
+                succ.append((i + 1, c[1]))
+            else:
+                succ.append((i + 1,))
+        use_s = [frozenset(r for r in self._reads(c)[0] if r not in fixed) for c in code]
+        def_s = [None if (c[0] in (F_JZ, F_JMP, F_RET, F_STX) or c[1] in fixed) else c[1] for c in code]
+        live_in = [frozenset()] * (n + 1)
+        changed = True
+        while changed:
+            changed = False
+            for i in range(n - 1, -1, -1):
+                lo = frozenset().union(*[live_in[j] for j in succ[i]]) if succ[i] else frozenset()
+                li = use_s[i] | (lo - {def_s[i]} if def_s[i] is not None else lo)
+                if li != live_in[i]:
+                    live_in[i] = li
+                    changed = True
+        first, last = {}, {}
+        for i in range(n):
+            lo = frozenset().union(*[live_in[j] for j in succ[i]]) if succ[i] else frozenset()
+            here = set(live_in[i]) | set(lo)
+            if def_s[i] is not None:
+                here.add(def_s[i])
+            for r in here:
+                first.setdefault(r, i)
+                last[r] = i
+        # fixed registers: arguments stay, results right behind them, then every indexed window (order kept)
+        new = {r: r for r in range(self.n_args)}
+        nxt = self.n_args
+        for r in range(self.ret_base, self.ret_base + self.n_ret):
+            new[r] = nxt
+            nxt += 1
+        for r in sorted(in_block):
+            if r not in new:
+                new[r] = nxt
+                nxt += 1
+        import heapq
+        free, active = [], []                  # free physical registers; (last position, physical register) of live ranges
+        for r in sorted(first, key=lambda r: (first[r], r)):
+            while active and active[0][0] < first[r]:      # a range that ended BEFORE this position frees its register
+                heapq.heappush(free, heapq.heappop(active)[1])
+            if free:
+                p = heapq.heappop(free)
+            else:
+                p = nxt
+                nxt += 1
+            new[r] = p
+            heapq.heappush(active, (last[r], p))
+
+        def opnd(o):
+            return o if o is None or o[0] != 'r' else ('r', new[o[1]])
+
+        res = []
+        for c in code:
+            op = c[0]
+            if op in (F_JMP, F_RET):
+                res.append(c)
+            elif op == F_JZ:
+                res.append((op, c[1], opnd(c[2]), None))
+            elif op == F_LDX:
+                res.append((op, new[c[1]], new[c[2]], (new[c[3][0]], c[3][1])))
+            elif op == F_STX:
+                res.append((op, new[c[1]], opnd(c[2]), (new[c[3][0]], c[3][1])))
+            else:
+                res.append((op, new[c[1]], opnd(c[2]), opnd(c[3])))
+        self.code = res
+        self.n_regs = nxt
+        self.ret_base = self.n_args
 
     # ---- builder ------------------------------------------------------------------------------------------------
     def new_reg(self):

@@ -279,3 +279,48 @@ def test_gpu_bigint_mult_mod_p_bls12381(tmp_path):
         if i % 10 == 0:
             assert w == _flat(fc, {fc.main_input_start + j: v for j, v in enumerate(vals)})[0]
     b.close(); c.close()
+
+
+def test_bytecode_optimiser_keeps_the_function(tmp_path):
+    """frontend/rtcode.py folds `t = a op b; v = t` and renumbers registers by live range (794 -> 35 registers, 1266 -> 968
+    instructions for long_div(32, 3)): the optimised bytecode computes what the bytecode as written computes, on loops,
+    branches, indexed arrays and the long division with its correction branches"""
+    from circom_amd.circuits.bigint import BigMultModP
+    from oracle.field import Field
+    from oracle.tape_eval import run_function
+    rnd = random.Random(9)
+    for prog, gen in ((Program(LongDiv()), lambda q: [rnd.randrange(1 << 20), rnd.randrange(1, 1 << 12)]),
+                      (Program(Pick()), lambda q: [rnd.randrange(q) for _ in range(8)] + [rnd.randrange(8)]),
+                      (Program(BigMultModP(32, 3), prime="bls12381"), None)):
+        fc = flatten(prog)
+        q = fc.fp.q
+        f = Field(q)
+        for fn_obj, fn in zip(prog.functions, fc.functions):
+            assert fn["n_regs"] <= fn_obj.n_regs_built and len(fn["code"]) <= len(fn_obj.code_built)
+            built = {"code": [list(c) for c in fn_obj.code_built]}
+            cid = {v: i for i, v in enumerate(fc.constants)}
+            # the flat form names constants by index; the code as built carries values: intern them the same way
+            for c in built["code"]:
+                for k in (2, 3):
+                    if isinstance(c[k], tuple) and c[k][0] == 'c':
+                        c[k] = ('c', cid.setdefault(c[k][1], len(cid)))
+            consts = [None] * len(cid)
+            for v, i in cid.items():
+                consts[i] = v
+            for _ in range(60):
+                if gen is not None:
+                    args = gen(q)[:fn["n_args"]]
+                    args += [rnd.randrange(1, 1 << 12) for _ in range(fn["n_args"] - len(args))]
+                else:
+                    p = rnd.randrange(1 << 95, 1 << 96)
+                    a2 = rnd.randrange(p * p)
+                    args = _limbs(a2, 32, 6) + _limbs(p, 32, 3)
+                r1 = list(args) + [0] * fn_obj.n_regs_built
+                r2 = list(args) + [0] * fn["n_regs"]
+                ok1 = run_function(f, built, r1, 0, consts)
+                ok2 = run_function(f, fn, r2, 0, fc.constants)
+                assert ok1 == ok2
+                if ok1:
+                    assert r1[fn_obj.ret_base_built:fn_obj.ret_base_built + fn["n_ret"]] == r2[fn["ret_base"]:fn["ret_base"] + fn["n_ret"]]
+    fn = flatten(Program(BigMultModP(32, 3), prime="bls12381")).functions[0]
+    assert fn["n_regs"] < 64 and len(fn["code"]) < 1000
