@@ -348,7 +348,7 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-small", action="store_true", help="skip the batch-4096 side measurement (profiling runs)")
     ap.add_argument("--fp-bench-lanes", type=int, default=1 << 24)
-    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("CW_IN_FLIGHT", "2")),
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("CW_IN_FLIGHT", "0")),
                     help="batches in flight on separate HIP streams (consecutive steps alternate between them, so the R1CS "
                          "check of one step overlaps the evaluation of the next); 1 = strictly sequential steps")
     args = ap.parse_args()
@@ -426,7 +426,15 @@ def main():
     # stream each) take the steps in turn; the evaluation of step k+1 (vector-memory / issue bound) runs while the R1CS check
     # of step k (scalar-load / latency bound) is still going.  Every step is a complete pass: ingest + evaluation + check of
     # all B instances.  The first warm-up step runs alone on the first batch: the `isolated` timings of the JSON line.
-    n_fl = max(1, args.in_flight)
+    # Default (0): two; a batch whose workgroups cover a quarter of the chip or less (a small shard on the 256-bit engine: one
+    # workgroup per 16 instances, each a dependency chain of tens of milliseconds on ONE CU) gets as many batches in flight
+    # as fill the 256 CUs, at most four - measured on the 1 024-instance Semaphore shard: 2 -> 63.6 K, 4 -> 112.9 K, 8 ->
+    # 113.2 K witnesses/s.
+    n_fl = args.in_flight
+    if n_fl <= 0:
+        wgs = (B + batch.lanes - 1) // max(1, batch.lanes)
+        n_fl = 2 if batch.bitmode else max(2, min(4, 256 // max(1, wgs)))
+    n_fl = max(1, n_fl)
     streams, batches = [stream], [batch]
     for _ in range(n_fl - 1):
         try:

@@ -1315,12 +1315,15 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
         // resolve the schedule for this batch: slot numbers -> byte offsets (CwDRow), streams padded with NOPs
         const Variant &v = *b->var;
         const uint64_t stride = (uint64_t)2 * b->Bp * 16;            // bytes per value slot
+        // an LDS hand-over slot holds the lanes IN USE (32 bytes each): a workgroup of 16 instances needs 36 KB for 72 slots,
+        // not 144 KB, so that the workgroups of several batches in flight share a CU (bench.py --in-flight)
+        const uint64_t lds_slot = (uint64_t)b->lanes * 32;
         auto resolve = [&](uint32_t kind, uint32_t idx) -> uint64_t {
             switch (kind) {
             case K_SIG: return (uint64_t)idx * stride;
             case K_TMP: return ((uint64_t)c->n_signals + idx) * stride;
             case K_CONST: return (uint64_t)idx * 32;
-            case K_LDS: return (uint64_t)idx * 2048;
+            case K_LDS: return (uint64_t)idx * lds_slot;
             default: return 0;
             }
         };
@@ -1377,7 +1380,7 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
         std::vector<uint64_t> dex(v.extras.size());
         for (size_t k = 0; k < v.extras.size(); k++) {
             uint32_t x = v.extras[k];
-            if (x & X_LDS) dex[k] = (1ull << 63) | ((uint64_t)(x & 0x3FFFFFFFu) * 2048);
+            if (x & X_LDS) dex[k] = (1ull << 63) | ((uint64_t)(x & 0x3FFFFFFFu) * lds_slot);
             else dex[k] = resolve((x & X_TMP) ? K_TMP : K_SIG, x & 0x3FFFFFFFu);
         }
         // stream offsets now refer to the padded array: stream s starts at doff[s] + 3*s ... keep explicit table

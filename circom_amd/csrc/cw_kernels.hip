@@ -141,6 +141,7 @@ struct EvalCtx {                         // per-wave constants of the interprete
     uint32_t tp;                         // ... and the running position in it
     uint32_t vlo, vhi;                   // this lane's byte offsets of the lo/hi half inside a value slot
     uint32_t lane16;                     // lane * 16 (LDS)
+    uint32_t lds_hi;                     // bytes from the lo half of an LDS slot to its hi half (16 x the lanes a slot holds)
     const uint4 *fcode;                  // bytecode of circom functions (D_CALL), all functions concatenated
     const uint4 *ftab;                   // per function {first instruction, n instructions, n registers, -}
     uint64_t slot_stride;                // bytes between consecutive value slots (2 * Bp * 16)
@@ -148,7 +149,7 @@ struct EvalCtx {                         // per-wave constants of the interprete
 
 __device__ __forceinline__ fe lds_load_off(uint32_t slot_off, const EvalCtx &c) {
     const char *p = (const char *)cw_lds + slot_off + c.lane16;
-    const uint4 lo = *(const uint4 *)p, hi = *(const uint4 *)(p + 1024);
+    const uint4 lo = *(const uint4 *)p, hi = *(const uint4 *)(p + c.lds_hi);
     fe r;
     r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
     r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
@@ -157,7 +158,7 @@ __device__ __forceinline__ fe lds_load_off(uint32_t slot_off, const EvalCtx &c) 
 __device__ __forceinline__ void lds_store_off(uint32_t slot_off, const EvalCtx &c, const fe &x) {
     char *p = (char *)cw_lds + slot_off + c.lane16;
     *(uint4 *)p = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
-    *(uint4 *)(p + 1024) = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+    *(uint4 *)(p + c.lds_hi) = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
 }
 // branch-free operand fetch: wave-uniform base (SGPR pair) + per-lane 32-bit offset (saddr addressing).
 // Constants: every lane reads the same 32 B.  Kinds resolved at execution time (PREV, LDS) read slot 0.
@@ -594,6 +595,7 @@ cw_eval_kernel(const CwDRow *__restrict__ rows, const uint32_t *__restrict__ str
     c.vlo = i * 16u;
     c.vhi = i * 16u + Bp * 16u;
     c.lane16 = lane * 16u;
+    c.lds_hi = lanes * 16u;
     c.Lb = lconsts;
     c.fcode = fcode;
     c.ftab = ftab;
@@ -822,6 +824,7 @@ cw_pipe_kernel(const CwPRow *__restrict__ rows, uint32_t n_rows, const uint32_t 
         c.vlo = i * 16u;
         c.vhi = i * 16u + Bp * 16u;
         c.lane16 = lane * 16u;
+        c.lds_hi = 1024u;                                            // the pipelined variant's entries are sized for 64 lanes
         c.Lb = lconsts;
         c.fcode = nullptr;
         c.ftab = nullptr;
@@ -1216,7 +1219,7 @@ hipError_t cwk_eval(hipStream_t s, bool full, bool wide_linsum, const CwDRow *ro
                     const uint32_t *fncode, const uint32_t *fntab, uint64_t slot_stride,
                     uint32_t Bp, uint32_t batch, uint32_t lanes, uint32_t prio_mask, uint32_t *status, const FpParams &P) {
     dim3 grid((batch + lanes - 1) / lanes), block(64 * n_strands);
-    const size_t lds_bytes = (size_t)n_lds * 2048;
+    const size_t lds_bytes = (size_t)n_lds * lanes * 32;           // hand-over slots hold the lanes in use
     typedef void (*kern_t)(const CwDRow *, const uint32_t *, const uint64_t *, const uint32_t *, const uint64_t *,
                            const uint32_t *, uint4 *, const uint32_t *, const uint32_t *, const uint4 *, const uint4 *, uint64_t,
                            uint32_t, uint32_t, uint32_t, uint32_t, uint32_t *, FpParams);
