@@ -428,16 +428,19 @@ def main():
     # all B instances.  The first warm-up step runs alone on the first batch: the `isolated` timings of the JSON line.
     # Default (0): two; a batch whose workgroups cover a quarter of the chip or less (a small shard on the 256-bit engine: one
     # workgroup per 16 instances, each a dependency chain of tens of milliseconds on ONE CU) gets as many batches in flight
-    # as fill the 256 CUs, at most four - measured on the 1 024-instance Semaphore shard: 2 -> 63.6 K, 4 -> 112.9 K, 8 ->
-    # 113.2 K witnesses/s.
+    # as fill the 256 CUs twice, at most eight - measured on the 1 024-instance Semaphore shard: 2 -> 63.6 K, 4 -> 112.9 K,
+    # 8 -> 113.2 K witnesses/s.
     n_fl = args.in_flight
     if n_fl <= 0:
         if batch.bitmode:           # one wave per SIMD and group slice: 1 024 of them fill the chip (Sha256(512) x 4 096 = 256 waves:
             waves = ((B + 63) // 64) * (64 // max(1, batch.lanes))     # 2 in flight -> 20.0 M, 4 -> 34.1 M, 8 -> 33.0 M witnesses/s)
             n_fl = max(2, min(4, 1024 // max(1, waves)))
         else:
+            # twice the batches that fill the 256 CUs, at most eight: the dispatcher does not always put the workgroups of
+            # four 64-workgroup batches on four disjoint quarters of the chip (tools/sema_inflight.py: 4 in flight gave 62.8 K
+            # in one process and 119 K in another, 8 gave 118.9 K and 118.5 K)
             wgs = (B + batch.lanes - 1) // max(1, batch.lanes)
-            n_fl = max(2, min(4, 256 // max(1, wgs)))
+            n_fl = max(2, min(8, 512 // max(1, wgs)))
     n_fl = max(1, n_fl)
     streams, batches = [stream], [batch]
     for _ in range(n_fl - 1):
