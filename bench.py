@@ -691,7 +691,10 @@ def main():
                          "kernel_ms": gen_k, "strands": batch.strands, "lanes_per_workgroup": batch.lanes}
             roof_r1cs = {"bound": "hbm", "kernel": rk, "achieved": chk_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": chk_gbs / HBM_PEAK_GBS, "traffic": prof.get("r1cs"), "algorithmic_bytes_per_launch": alg_chk,
-                         "kernel_ms": chk_k}
+                         "kernel_ms": chk_k,
+                         # the check of an arithmetic circuit is bound by instruction issue, not by bytes (Poseidon(2): 7.1e8 wave
+                         # instructions per launch, most of them half-rate 32-bit multiplies): fraction of the 2-clock VALU peak
+                         "valu_issue_frac": (prof["r1cs_valu_insts"] / (chk_k * 1e-3) / valu_peak) if prof.get("r1cs_valu_insts") else None}
             fpk = circ.n_mmul * B / (gen_k * 1e-3)
             roof_valu = {"bound": "valu", "kernel": ek, "unit": "Fp-mul/s", "achieved": fpk, "peak": fp_mul_per_s,
                          "frac": fpk / fp_mul_per_s if fp_mul_per_s else None,
