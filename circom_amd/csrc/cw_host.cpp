@@ -1990,7 +1990,8 @@ extern "C" int cw_run(cw_batch *b) {
         return CW_OK;
     }
     HIPCHK(cwk_eval(b->stream, c->need_full, b->var->wide_linsum, b->d_rows, b->d_stream_off, b->d_extras, b->d_extra_off, b->d_terms,
-                    b->d_term_off, b->var->n_strands, b->var->n_lds, b->d_V, b->d_consts, b->d_lconsts, b->d_fncode, b->d_fntab,
+                    b->d_term_off, b->var->n_strands, b->var->n_lds, b->d_V, b->d_consts, b->d_lconsts,
+                    c->fn_tab.empty() ? nullptr : b->d_fncode /* non-null selects the single-wave interpreter build */, b->d_fntab,
                     (uint64_t)2 * b->Bp * 16, b->Bp, b->batch, b->lanes, b->prio_mask, b->d_status, c->P));
     b->ran = true;
     return CW_OK;

@@ -322,7 +322,7 @@ __device__ __forceinline__ bool fn_index(const fe &v, uint32_t n, uint32_t *out)
     *out = v.v[0];
     return hi == 0 && v.v[0] < n;
 }
-__device__ __noinline__ void eval_call(uint32_t fn, uint64_t reg_off, uint32_t row_id, uint32_t &st, const EvalCtx &c, const FpParams &P) {
+__device__ __forceinline__ void eval_call_body(uint32_t fn, uint64_t reg_off, uint32_t row_id, uint32_t &st, const EvalCtx &c, const FpParams &P) {
     const uint4 ft = c.ftab[fn];
     const uint4 *code = c.fcode + ft.x;
     char *regs = (char *)c.Vb + reg_off;
@@ -413,9 +413,16 @@ __device__ __noinline__ void eval_call(uint32_t fn, uint64_t reg_off, uint32_t r
     }
 }
 
+// Out of line in the strand kernels (launch bound 1024 = 128 VGPRs per wave: inlined, the interpreter would squeeze the
+// row loop); inlined in the single-wave kernels of circuits with functions (launch bound 64: up to 512 VGPRs; BigMultModP
+// x 65 536: 13.8 -> 19.1 M witnesses/s).
+__device__ __noinline__ void eval_call(uint32_t fn, uint64_t reg_off, uint32_t row_id, uint32_t &st, const EvalCtx &c, const FpParams &P) {
+    eval_call_body(fn, reg_off, row_id, st, c, P);
+}
+
 // One interpreter step: executes `row` with operands (xa, xb) while the operands of `nrow` are requested into
 // (ya, yb).  The loop calls it twice per iteration with the two register sets swapped (no rotation moves).
-template <bool FULL_OPS, int LW>
+template <bool FULL_OPS, int LW, bool CALL_INLINE = false>
 __device__ __forceinline__ void eval_step(const CwDRow &row, const fe &xa, const fe &xb, const CwDRow &nrow, fe &ya,
                                           fe &yb, fe &prev, uint64_t &selmask, uint32_t &st, uint32_t r,
                                           const uint64_t *__restrict__ extras, uint32_t &xp, EvalCtx &c,
@@ -511,7 +518,8 @@ __device__ __forceinline__ void eval_step(const CwDRow &row, const fe &xa, const
             switch (op) {
             case D_INV: d = fe_inv(a, P); break;
             case D_CALL:
-                eval_call(row.aux, row.b_off, (uint32_t)row.dst_off, st, c, P);
+                if (CALL_INLINE) eval_call_body(row.aux, row.b_off, (uint32_t)row.dst_off, st, c, P);
+                else eval_call(row.aux, row.b_off, (uint32_t)row.dst_off, st, c, P);
                 has_d = false;
                 break;
             case D_POW: d = fe_pow(a, b, P); break;
@@ -568,8 +576,11 @@ __device__ __forceinline__ void eval_step(const CwDRow &row, const fe &xa, const
 //  * barriers never drain vmcnt (see (3) above): global stores stay in flight across them;
 //  * products of small signed values take the per-wave short path (fp256.hip.h).
 // FULL_OPS selects the variant that also carries the slow-path operators (INV/IDIV/MOD/POW).
-template <bool FULL_OPS, int LW>
-__global__ void __launch_bounds__(1024)
+// MAXT = the largest workgroup the instantiation is launched with: 1024 (16 strands: 128 VGPRs per wave) for every
+// strand schedule; 64 for the single-strand schedules of circuits with run-time functions, where the interpreter is
+// inlined (see eval_call).
+template <bool FULL_OPS, int LW, int MAXT>
+__global__ void __launch_bounds__(MAXT)
 cw_eval_kernel(const CwDRow *__restrict__ rows, const uint32_t *__restrict__ stream_off,
                const uint64_t *__restrict__ extras, const uint32_t *__restrict__ extra_off,
                const uint64_t *__restrict__ terms, const uint32_t *__restrict__ term_off, uint4 *V,
@@ -617,11 +628,11 @@ cw_eval_kernel(const CwDRow *__restrict__ rows, const uint32_t *__restrict__ str
     while (r < end) {
         CwDRow r2 = rows[r + 2];
         CW_PROF_BEGIN();
-        eval_step<FULL_OPS, LW>(r0, a0, b0, r1, a1, b1, prev, selmask, st, r, extras, xp, c, P);
+        eval_step<FULL_OPS, LW, MAXT == 64>(r0, a0, b0, r1, a1, b1, prev, selmask, st, r, extras, xp, c, P);
         CW_PROF_END(r0);
         r0 = rows[r + 3];
         CW_PROF_BEGIN();
-        eval_step<FULL_OPS, LW>(r1, a1, b1, r2, a0, b0, prev, selmask, st, r + 1, extras, xp, c, P);
+        eval_step<FULL_OPS, LW, MAXT == 64>(r1, a1, b1, r2, a0, b0, prev, selmask, st, r + 1, extras, xp, c, P);
         CW_PROF_END(r1);
         r1 = r0;
         r0 = r2;
@@ -1223,8 +1234,10 @@ hipError_t cwk_eval(hipStream_t s, bool full, bool wide_linsum, const CwDRow *ro
     typedef void (*kern_t)(const CwDRow *, const uint32_t *, const uint64_t *, const uint32_t *, const uint64_t *,
                            const uint32_t *, uint4 *, const uint32_t *, const uint32_t *, const uint4 *, const uint4 *, uint64_t,
                            uint32_t, uint32_t, uint32_t, uint32_t, uint32_t *, FpParams);
-    kern_t k = full ? (wide_linsum ? (kern_t)cw_eval_kernel<true, 4> : (kern_t)cw_eval_kernel<true, 2>)
-                    : (wide_linsum ? (kern_t)cw_eval_kernel<false, 4> : (kern_t)cw_eval_kernel<false, 2>);
+    kern_t k = full ? (wide_linsum ? (kern_t)cw_eval_kernel<true, 4, 1024> : (kern_t)cw_eval_kernel<true, 2, 1024>)
+                    : (wide_linsum ? (kern_t)cw_eval_kernel<false, 4, 1024> : (kern_t)cw_eval_kernel<false, 2, 1024>);
+    if (full && n_strands == 1 && fncode)       // circuits with run-time functions: one wave per workgroup, no register ceiling
+        k = wide_linsum ? (kern_t)cw_eval_kernel<true, 4, 64> : (kern_t)cw_eval_kernel<true, 2, 64>;
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;

@@ -641,8 +641,16 @@ __device__ __noinline__ fe fe_pow(const fe &x, const fe &y, const FpParams &P) {
 // Restoring shift-subtract division; y == 0 is reported by the caller.
 __device__ __noinline__ void fe_divmod(const fe &x, const fe &y, fe *quo, fe *rem) {
     fe q = fe_zero(), r = fe_zero();
+    // leading words that are zero in EVERY lane are skipped (wave-uniform test): the integer divisions of witness code are
+    // mostly on limb-sized values (bigint long division: 64..96-bit numerators - 2-3 of the 8 words), and a word costs
+    // 32 x ~80 instructions
+    bool started = false;
     FE_UNROLL for (int w = 7; w >= 0; w--) {
         const uint32_t xw = x.v[w];
+        if (!started) {
+            if (!__any(xw != 0)) continue;
+            started = true;
+        }
         uint32_t qw = 0;
         for (int b = 31; b >= 0; b--) {
             // r = (r << 1) | bit(x)
