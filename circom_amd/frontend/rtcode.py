@@ -9,7 +9,8 @@ cannot unroll that: the trip count differs per input.  Here a function is a smal
   * the oracle interprets on Python ints (oracle/tape_eval.py),
   * oracle/emit_ref_cpp.py prints as C++ over the reference's own `Fr_*` calls (so the reference RUNTIME executes it),
   * the HIP kernel interprets per lane with a per-lane program counter (csrc/cw_kernels.hip, D_CALL): lanes of a wave
-    that sit at different instructions take turns (divergence), every lane stops after CALL_STEP_LIMIT instructions.
+    that sit at different instructions take turns (divergence, lowest program counter first), every lane stops after
+    CALL_STEP_LIMIT instructions.
 
 Registers are field elements (one 256-bit value per instance).  Instruction = (opcode, dst, a, b):
   ALU      opcode = circom_amd.opcodes (ADD .. LNOT, COPY, NEG, BNOT): dst <- a op b; operands are registers or constants
