@@ -1,5 +1,6 @@
 """Throughput of small Semaphore shards with several batches in flight, per strand count:
-python tools/sema_inflight.py   (1 024 instances per batch, own HIP stream per batch)"""
+python tools/sema_inflight.py [wide]   (1 024 instances per batch, own HIP stream per batch; wide = 64 / 32 lanes per
+workgroup with 8 / 16 / 32 batches in flight: the throughput end of the latency / throughput trade-off)"""
 import os
 import sys
 import tempfile
@@ -18,9 +19,9 @@ c = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
 h = bench.synth_inputs(name, c.q, B, c.n_inputs, 3)
 dev = torch.device("cuda", 0)
 d_in = torch.from_numpy(h).to(dev)
-for S in (16, 8, 4, 2):
-    for lanes in (16, 32):
-        for nfl in (4, 8, 16):
+for S in ((16,) if len(sys.argv) > 1 else (16, 8, 4, 2)):
+    for lanes in ((64, 32) if len(sys.argv) > 1 else (16, 32)):
+        for nfl in ((8, 16, 32) if len(sys.argv) > 1 else (4, 8, 16)):
             os.environ["CW_STRANDS"] = str(S)
             os.environ["CW_LANES"] = str(lanes)
             streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
