@@ -36,3 +36,14 @@ def test_bench_refuses_a_world_that_is_not_what_was_asked_for(tmp_path):
     r = _run(["--gpus", "2", "--host-only", "--workload", "poseidon2"], tmp_path,
              {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+
+
+def test_bench_gpus_8_weak_scaling_launch(tmp_path):
+    """the launch the driver uses for the scaling curve: 8 ranks, weak scaling (every rank its own --batch instances)"""
+    r = _run(["--gpus", "8", "--host-only", "--workload", "poseidon2", "--batch", "37"], tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["host_only"] is True
+    assert out["gathered"] == {"status_words": 8 * 37, "public_signal_rows": 8 * 37}
