@@ -209,6 +209,20 @@ class BoolInputs:
         return out
 
 
+def auto_in_flight(bitmode: bool, B: int, lanes: int) -> int:
+    """Batches in flight for `--in-flight 0`.  Two keep the check of one step next to the evaluation of the next; a batch
+    that covers a fraction of the chip gets more, so that the rest of the chip works through the length of its dependency
+    chain."""
+    if bitmode:             # one wave per SIMD and group slice: 1 024 of them fill the chip (Sha256(512) x 4 096 = 256 waves:
+        waves = ((B + 63) // 64) * (64 // max(1, lanes))     # 2 in flight -> 20.0 M, 4 -> 34.1 M, 8 -> 33.0 M witnesses/s)
+        return max(2, min(4, 1024 // max(1, waves)))
+    # 256-bit engine: twice the batches that fill the 256 CUs, at most eight: the dispatcher does not always put the
+    # workgroups of four 64-workgroup batches on four disjoint quarters of the chip (tools/sema_inflight.py: 4 in flight gave
+    # 62.8 K in one process and 119 K in another, 8 gave 118.9 K and 118.5 K)
+    wgs = (B + lanes - 1) // max(1, lanes)
+    return max(2, min(8, 512 // max(1, wgs)))
+
+
 def parity_check(cp, circ, batch, h_in, workload: str, n_sample: int = 4):
     """Oracle comparison at the benchmark batch (after the timed region).  Returns a dict for the JSON line; raises
     AssertionError on any mismatch (a fast wrong answer is not a result)."""
@@ -432,15 +446,7 @@ def main():
     # 8 -> 113.2 K witnesses/s.
     n_fl = args.in_flight
     if n_fl <= 0:
-        if batch.bitmode:           # one wave per SIMD and group slice: 1 024 of them fill the chip (Sha256(512) x 4 096 = 256 waves:
-            waves = ((B + 63) // 64) * (64 // max(1, batch.lanes))     # 2 in flight -> 20.0 M, 4 -> 34.1 M, 8 -> 33.0 M witnesses/s)
-            n_fl = max(2, min(4, 1024 // max(1, waves)))
-        else:
-            # twice the batches that fill the 256 CUs, at most eight: the dispatcher does not always put the workgroups of
-            # four 64-workgroup batches on four disjoint quarters of the chip (tools/sema_inflight.py: 4 in flight gave 62.8 K
-            # in one process and 119 K in another, 8 gave 118.9 K and 118.5 K)
-            wgs = (B + batch.lanes - 1) // max(1, batch.lanes)
-            n_fl = max(2, min(8, 512 // max(1, wgs)))
+        n_fl = auto_in_flight(batch.bitmode, B, batch.lanes)
     n_fl = max(1, n_fl)
     streams, batches = [stream], [batch]
     for _ in range(n_fl - 1):

@@ -47,3 +47,13 @@ def test_bench_gpus_8_weak_scaling_launch(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["host_only"] is True
     assert out["gathered"] == {"status_words": 8 * 37, "public_signal_rows": 8 * 37}
+
+
+def test_batches_in_flight_follow_the_fill_of_the_chip():
+    sys.path.insert(0, str(ROOT))
+    import bench
+    # bit-plane: waves = groups x slices; the 65 536-instance headline fills the SIMDs (two in flight), 4 096 a quarter (four)
+    assert bench.auto_in_flight(True, 65536, 64) == 2 and bench.auto_in_flight(True, 4096, 16) == 4
+    # 256-bit engine: the 1 024-instance shard of BASELINE config 4 is 64 workgroups (eight), 8 192 is the whole chip (two)
+    assert bench.auto_in_flight(False, 1024, 16) == 8 and bench.auto_in_flight(False, 8192, 32) == 2
+    assert bench.auto_in_flight(False, 65536, 64) == 2
