@@ -69,6 +69,26 @@ VALU_KERNEL(k_mov, B8(OP_PKFMA))
 VALU_KERNEL(k_bfi_dep, B8(OP_BFI_DEP))
 VALU_KERNEL(k_bitop3_dep, B8(OP_BITOP3_DEP))
 
+// v_mad_u64_u32 (32 x 32 + 64 -> 64: the workhorse of the 29-bit-limb Montgomery product): 8 independent 64-bit accumulators
+__global__ void __launch_bounds__(256) k_mad64(uint64_t *out, uint32_t seed) {
+    uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    uint32_t a = t * 2654435761u + seed, b = (t ^ seed) * 40503u + 7u;
+    uint64_t c0 = a, c1 = a + 1, c2 = a + 2, c3 = a + 3, c4 = a + 4, c5 = a + 5, c6 = a + 6, c7 = a + 7;
+    uint64_t t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < TRIPS; it++) {
+        asm volatile(".rept 8\n"
+                     "v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %8, %9, %1\n v_mad_u64_u32 %2, vcc, %8, %9, %2\n"
+                     "v_mad_u64_u32 %3, vcc, %8, %9, %3\n v_mad_u64_u32 %4, vcc, %8, %9, %4\n v_mad_u64_u32 %5, vcc, %8, %9, %5\n"
+                     "v_mad_u64_u32 %6, vcc, %8, %9, %6\n v_mad_u64_u32 %7, vcc, %8, %9, %7\n"
+                     ".endr\n"
+                     : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7)
+                     : "v"(a), "v"(b)
+                     : "vcc");
+    }
+    uint64_t t1 = __builtin_readcyclecounter();
+    out[t] = (uint64_t)(uint32_t)(c0 ^ c1 ^ c2 ^ c3 ^ c4 ^ c5 ^ c6 ^ c7) | ((t1 - t0) << 32);
+}
+
 typedef void (*valu_kern_t)(uint64_t *, uint32_t);
 
 static void run_valu(const char *name, valu_kern_t k, FILE *js, bool &first) {
@@ -317,6 +337,7 @@ int main(int argc, char **argv) {
     run_valu("v_lshl_or_b32", k_lshlor, js, first);
     run_valu("v_and_or_b32", k_andor, js, first);
     run_valu("v_mul_lo_u32", k_mullo, js, first);
+    run_valu("v_mad_u64_u32", k_mad64, js, first);
     run_valu("v_fma_f32", k_fma, js, first);
     run_valu("v_mov_b32", k_mov, js, first);
     run_valu("v_bfi_b32.dep", k_bfi_dep, js, first);
