@@ -94,6 +94,13 @@ __global__ void __launch_bounds__(CW_BLOCK) cw_ingest_kernel(const uint4 *__rest
 // every interpreter step per (strand, opcode), operand waits included.
 #ifdef CW_PROFILE
 __device__ unsigned long long cw_prof[16 * 64 * 2];
+// strand 0 of workgroup 0, per opcode: clocks until the operands are in registers | arithmetic | destinations + extras
+__device__ unsigned long long cw_prof_seg[64 * 4];
+#define CW_PROF_SEG(k, opc, t_from)                                                                    \
+    do {                                                                                              \
+        if (blockIdx.x == 0 && threadIdx.x == 0)                                                      \
+            atomicAdd(&cw_prof_seg[((opc) & 63u) * 4 + (k)], (unsigned long long)(__builtin_readcyclecounter() - (t_from))); \
+    } while (0)
 #define CW_PROF_BEGIN() prof_t0 = __builtin_readcyclecounter()
 #define CW_PROF_END(row)                                                                              \
     do {                                                                                              \
@@ -104,6 +111,9 @@ __device__ unsigned long long cw_prof[16 * 64 * 2];
             atomicAdd(&cw_prof[prof_k + 1], 1ull);                                                    \
         }                                                                                             \
     } while (0)
+extern "C" int cw_debug_profile_seg(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(cw_prof_seg), sizeof(cw_prof_seg)) == hipSuccess ? 0 : -1;
+}
 extern "C" int cw_debug_profile(unsigned long long *out, int reset) {
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(cw_prof), sizeof(cw_prof)) != hipSuccess) return -1;
     if (reset) {
@@ -115,6 +125,7 @@ extern "C" int cw_debug_profile(unsigned long long *out, int reset) {
 #else
 #define CW_PROF_BEGIN()
 #define CW_PROF_END(row)
+#define CW_PROF_SEG(k, opc, t_from)
 #endif
 extern __shared__ uint4 cw_lds[];       // [slot][2 halves][64 lanes] x 16 B
 
@@ -454,6 +465,12 @@ __device__ __forceinline__ void eval_step(const CwDRow &row, const fe &xa, const
     else if (bk == K_LDS) b = lds_load_off((uint32_t)row.b_off, c);
     fe d;
     bool has_d = true;
+#ifdef CW_PROFILE
+    const uint64_t seg_t0 = __builtin_readcyclecounter();
+    asm volatile("" ::"v"(a.v[0]), "v"(a.v[7]), "v"(b.v[0]), "v"(b.v[7]));      // the operands are in registers here
+    uint64_t seg_t1 = __builtin_readcyclecounter();
+    CW_PROF_SEG(0, op, seg_t0);
+#endif
     switch (op) {
     case D_COPY: d = a; break;
     case D_ADD: d = fe_add(a, b, P); break;
@@ -542,6 +559,11 @@ __device__ __forceinline__ void eval_step(const CwDRow &row, const fe &xa, const
         }
         break;
     }
+#ifdef CW_PROFILE
+    if (has_d) asm volatile("" ::"v"(d.v[0]), "v"(d.v[7]));
+    CW_PROF_SEG(1, op, seg_t1);
+    seg_t1 = __builtin_readcyclecounter();
+#endif
     if (has_d) {
         prev = d;
         if (dk == K_LDS) lds_store_off((uint32_t)row.dst_off, c, d);
@@ -558,6 +580,10 @@ __device__ __forceinline__ void eval_step(const CwDRow &row, const fe &xa, const
         }
     }
     xp += nx;
+#ifdef CW_PROFILE
+    CW_PROF_SEG(2, op, seg_t1);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cw_prof_seg[(op & 63u) * 4 + 3], 1ull);
+#endif
 }
 
 // ---- schedule evaluation (the hot path) ---------------------------------------------------------------

@@ -45,3 +45,11 @@ if os.environ.get("CW_LIB"):
                 print("PROF strand %2d total %.2f Mclk: " % (w, s_ / 1e6) + "  ".join("%s %.0f%% (%d x %.0f)" % (nm, 100.0 * t / s_, n, t / n) for t, nm, n in sorted(line, reverse=True)[:7]))
         s_ = sum(v[0] for v in tot.values())
         print("PROF all strands: " + "  ".join("%s %.1f%% (avg %.0f clk)" % (k, 100.0 * v[0] / s_, v[0] / v[1]) for k, v in sorted(tot.items(), key=lambda kv: -kv[1][0])))
+
+    seg = (ctypes.c_ulonglong * (64 * 4))()
+    if hasattr(L, "cw_debug_profile_seg") and L.cw_debug_profile_seg(seg) == 0:
+        for op in range(64):
+            n = seg[op * 4 + 3]
+            if n:
+                nm = D_NAMES[op] if op < len(D_NAMES) else str(op)
+                print("SEG strand 0 %-10s x %6d: operands ready %6.0f clk | arithmetic %6.0f | destinations %6.0f" % (nm, n, seg[op * 4] / n, seg[op * 4 + 1] / n, seg[op * 4 + 2] / n))
