@@ -96,6 +96,9 @@ __global__ void __launch_bounds__(CW_BLOCK) cw_ingest_kernel(const uint4 *__rest
 __device__ unsigned long long cw_prof[16 * 64 * 2];
 // strand 0 of workgroup 0, per opcode: clocks until the operands are in registers | arithmetic | destinations + extras
 __device__ unsigned long long cw_prof_seg[64 * 4];
+// workgroup 0: shader clock at which strand s ARRIVES at its k-th barrier (k < CW_PROF_LEVELS): who is last, level by level
+#define CW_PROF_LEVELS 4096
+__device__ unsigned long long cw_prof_arrive[CW_PROF_LEVELS * 16];
 #define CW_PROF_SEG(k, opc, t_from)                                                                    \
     do {                                                                                              \
         if (blockIdx.x == 0 && threadIdx.x == 0)                                                      \
@@ -111,6 +114,9 @@ __device__ unsigned long long cw_prof_seg[64 * 4];
             atomicAdd(&cw_prof[prof_k + 1], 1ull);                                                    \
         }                                                                                             \
     } while (0)
+extern "C" int cw_debug_profile_arrive(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(cw_prof_arrive), sizeof(cw_prof_arrive)) == hipSuccess ? 0 : -1;
+}
 extern "C" int cw_debug_profile_seg(unsigned long long *out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(cw_prof_seg), sizeof(cw_prof_seg)) == hipSuccess ? 0 : -1;
 }
@@ -156,6 +162,9 @@ struct EvalCtx {                         // per-wave constants of the interprete
     const uint4 *fcode;                  // bytecode of circom functions (D_CALL), all functions concatenated
     const uint4 *ftab;                   // per function {first instruction, n instructions, n registers, -}
     uint64_t slot_stride;                // bytes between consecutive value slots (2 * Bp * 16)
+#ifdef CW_PROFILE
+    uint32_t prof_level;                 // barriers this strand has passed (profiling build)
+#endif
 };
 
 __device__ __forceinline__ fe lds_load_off(uint32_t slot_off, const EvalCtx &c) {
@@ -442,6 +451,11 @@ __device__ __forceinline__ void eval_step(const CwDRow &row, const fe &xa, const
     const uint32_t dk = (row.w0 >> SH_DK) & 7, ak = (row.w0 >> SH_AK) & 7, bk = (row.w0 >> SH_BK) & 7;
     const uint32_t nx = (row.w0 >> SH_NX) & 0xFFF;
     if (op == D_BARRIER) {                                           // nothing is prefetched across a barrier
+#ifdef CW_PROFILE
+        if (blockIdx.x == 0 && (threadIdx.x & 63u) == 0 && c.prof_level < CW_PROF_LEVELS)
+            cw_prof_arrive[c.prof_level * 16 + (threadIdx.x >> 6)] = __builtin_readcyclecounter();
+        c.prof_level++;
+#endif
         if (row.aux) {
             __syncthreads();                                         // FULL: values cross strands through the value table
         } else {
@@ -637,6 +651,9 @@ cw_eval_kernel(const CwDRow *__restrict__ rows, const uint32_t *__restrict__ str
     c.fcode = fcode;
     c.ftab = ftab;
     c.slot_stride = slot_stride;
+#ifdef CW_PROFILE
+    c.prof_level = 0;
+#endif
     c.terms = terms;
     c.tp = term_off[wave];
     // every stream is padded with 3 NOP rows, so rows[r+1..r+3] are always readable

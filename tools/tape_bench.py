@@ -53,3 +53,23 @@ if os.environ.get("CW_LIB"):
             if n:
                 nm = D_NAMES[op] if op < len(D_NAMES) else str(op)
                 print("SEG strand 0 %-10s x %6d: operands ready %6.0f clk | arithmetic %6.0f | destinations %6.0f" % (nm, n, seg[op * 4] / n, seg[op * 4 + 1] / n, seg[op * 4 + 2] / n))
+
+    arr = (ctypes.c_ulonglong * (4096 * 16))()
+    if hasattr(L, "cw_debug_profile_arrive") and L.cw_debug_profile_arrive(arr) == 0:
+        import collections
+        a = np.frombuffer(arr, dtype=np.uint64).reshape(4096, 16).astype(np.int64)
+        S = b.strands
+        lv = [k for k in range(4096) if (a[k, :S] > 0).all()]
+        if len(lv) > 2:
+            last = collections.Counter()
+            spread, dur = [], []
+            for k in lv:
+                row = a[k, :S]
+                last[int(row.argmax())] += 1
+                spread.append(int(row.max() - row.min()))
+            for k0, k1 in zip(lv[:-1], lv[1:]):
+                if k1 == k0 + 1:
+                    dur.append(int(a[k1, :S].max() - a[k0, :S].max()))
+            print("ARRIVE %d levels: level duration avg %.0f clk (median %.0f); first-to-last arrival spread avg %.0f clk (median %.0f)" % (
+                len(lv), np.mean(dur), np.median(dur), np.mean(spread), np.median(spread)))
+            print("ARRIVE last strand at the barrier: " + "  ".join("s%d %.0f%%" % (s_, 100.0 * n / len(lv)) for s_, n in last.most_common(8)))
