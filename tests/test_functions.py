@@ -324,3 +324,93 @@ def test_bytecode_optimiser_keeps_the_function(tmp_path):
                     assert r1[fn_obj.ret_base_built:fn_obj.ret_base_built + fn["n_ret"]] == r2[fn["ret_base"]:fn["ret_base"] + fn["n_ret"]]
     fn = flatten(Program(BigMultModP(32, 3), prime="bls12381")).functions[0]
     assert fn["n_regs"] < 64 and len(fn["code"]) < 1000
+
+
+def _random_function_builder(seed, n_args):
+    """a random structured function over the builder API of frontend/rtcode.py: mutable vars, nested if / else, bounded
+    loops, a local array written and read through run-time indices - every shape the optimiser's liveness has to survive"""
+    def build(f, *args):
+        rnd = random.Random(seed)
+        vars_ = [f.var(a) for a in args] + [f.var(rnd.randrange(1, 50)) for _ in range(3)]
+        arr = f.array(4, [rnd.randrange(9) for _ in range(4)])
+
+        def expr(depth=0):
+            a, b = rnd.choice(vars_), rnd.choice(vars_)
+            k = rnd.randrange(8)
+            if k == 0: return a + b
+            if k == 1: return a - b
+            if k == 2: return a * (rnd.randrange(1, 7))
+            if k == 3: return (a & 255) + (b & 15)
+            if k == 4: return a.lt(b)
+            if k == 5: return arr.load((a & 3))
+            if k == 6: return (a >> 1) + 1
+            return a.eq(b) + 2
+
+        def block(depth):
+            for _ in range(rnd.randrange(2, 5)):
+                k = rnd.randrange(7 if depth < 2 else 4)
+                if k <= 2:
+                    rnd.choice(vars_).set(expr())
+                elif k == 3:
+                    arr.store(rnd.choice(vars_) & 3, expr())
+                elif k == 4:
+                    with f.if_((rnd.choice(vars_) & 1).eq(rnd.randrange(2))):
+                        block(depth + 1)
+                    if rnd.randrange(2):
+                        with f.else_():
+                            block(depth + 1)
+                elif k == 5:
+                    cnt = f.var(rnd.randrange(1, 4))
+                    with f.loop() as L:
+                        L.break_unless(cnt.neq(0))
+                        block(depth + 1)
+                        cnt.set(cnt - 1)
+                else:
+                    with f.if_(rnd.choice(vars_).gt(rnd.choice(vars_))):
+                        rnd.choice(vars_).set(expr())
+        block(0)
+        return [vars_[0] + vars_[1], rnd.choice(vars_), arr.load(vars_[2] & 3)]
+    return build
+
+
+def test_bytecode_optimiser_on_random_structured_functions():
+    from circom_amd.frontend.rtcode import RtFunction
+    from circom_amd.field import Fp, PRIMES
+    from oracle.field import Field
+    from oracle.tape_eval import run_function
+    fp = Fp(PRIMES["bn128"], "bn128")
+    f = Field(fp.q)
+    shrunk = 0
+    for seed in range(60):
+        n_args = 2 + seed % 3
+        fn = RtFunction("rnd%d" % seed, n_args, _random_function_builder(seed, n_args), fp)
+        # constants by value -> a shared table, as Program.register_function does
+        consts, cid = [], {}
+
+        def intern(code):
+            out = []
+            for c in code:
+                c = list(c)
+                for k in (2, 3):
+                    if isinstance(c[k], tuple) and c[k][0] == 'c':
+                        c[k] = ('c', cid.setdefault(c[k][1], len(cid)))
+                out.append(c)
+            return out
+
+        built, opt = {"code": intern(fn.code_built)}, {"code": intern(fn.code)}
+        consts = [None] * len(cid)
+        for v, i in cid.items():
+            consts[i] = v
+        assert fn.n_regs <= fn.n_regs_built and len(fn.code) <= len(fn.code_built)
+        shrunk += fn.n_regs < fn.n_regs_built
+        rnd = random.Random(1000 + seed)
+        for _ in range(25):
+            args = [rnd.randrange(0, 64) for _ in range(n_args)]
+            r1 = args + [0] * fn.n_regs_built
+            r2 = args + [0] * fn.n_regs
+            ok1 = run_function(f, built, r1, 0, consts)
+            ok2 = run_function(f, opt, r2, 0, consts)
+            assert ok1 == ok2, seed
+            if ok1:
+                assert r1[fn.ret_base_built:fn.ret_base_built + fn.n_ret] == r2[fn.ret_base:fn.ret_base + fn.n_ret], seed
+    assert shrunk >= 50
