@@ -158,6 +158,17 @@ def time_reference(cp, workload: str, seconds_budget: float = 15.0):
             pool = [b"".join(v.to_bytes(32, "little") for v in H.semaphore_inputs(q, int(workload[9:].rstrip("p") or 20), r)[0])
                     for _ in range(min(n, 16))]
             return b"".join(pool[i % len(pool)] for i in range(n))
+        if workload.startswith("bigmultmodp"):
+            # limbs of a, b < p (random field elements would trip the circuit's range checks: the reference aborts)
+            import random
+            nb, k = ([int(x) for x in workload.split("_")[1:3]] if "_" in workload else (32, 3))
+            r = random.Random(1)
+            out = []
+            for _ in range(n):
+                p_ = r.randrange(1 << (nb * k - 1), 1 << (nb * k))
+                for x in (r.randrange(p_), r.randrange(p_), p_):
+                    out.extend(((x >> (nb * i)) & ((1 << nb) - 1)).to_bytes(32, "little") for i in range(k))
+            return b"".join(out)
         vals = [int.from_bytes(rng.bytes(32), "little") % q for _ in range(n * n_in)]
         return b"".join(v.to_bytes(32, "little") for v in vals)
     # calibrate on one core, then a short pilot on all usable cores, and size the sample from the loaded rate
@@ -234,7 +245,9 @@ def build_default_circuits():
     d = _t.mkdtemp(prefix="cw_refbuild_")
     from circom_amd.circuits.sha256 import Sha256
     from circom_amd.circuits.eddsa import SemaphoreStyle
+    from circom_amd.circuits.bigint import BigMultModP
     for name, prog in (("multiplier2", Program(Multiplier2())), ("poseidon2", Program(Poseidon(2))),
+                       ("bigmultmodp", Program(BigMultModP(32, 3), prime="bls12381")),
                        ("sha256_512", Program(Sha256(512))), ("semaphore20", Program(SemaphoreStyle(20))),
                        ("semaphore20p", Program(SemaphoreStyle(20, True))), ("sha256_2048", Program(Sha256(2048)))):
         cp = compile_program(prog, d, name, sym=False)
