@@ -33,6 +33,13 @@ SYM1 = {NEG: "Fr_neg", BNOT: "Fr_bnot", LNOT: "Fr_lnot", COPY: "Fr_copy"}
 CHUNK = 1500
 ARGS_DECL = "Circom_CalcWit* ctx, FrElement* signalValues, FrElement* circuitConstants, FrElement* expaux, u64 mySignalStart, u32* mySubcomponents, u64 myId"
 ARGS_CALL = "ctx, signalValues, circuitConstants, expaux, mySignalStart, mySubcomponents, myId"
+# The 64-bit runtime (`--prime goldilocks`: goldilocks/fr.hpp + common64/{main,calcwit}.cpp) holds field elements as plain
+# u64 VALUES: the reference emits `lvar[i] = Fr_add(a, b);` instead of `Fr_add(&lvar[i], &a, &b);`, constants as literals
+# (value_bucket.rs:82-86) and no constant table (compute_bucket.rs:353, store_bucket.rs:575-657, call_bucket.rs:474-533).
+W64 = False
+ARGS_DECL64 = "Circom_CalcWit* ctx, u64* signalValues, u64* expaux, u64 mySignalStart, u32* mySubcomponents, u64 myId"
+ARGS_CALL64 = "ctx, signalValues, expaux, mySignalStart, mySubcomponents, myId"
+CONSTS64 = []
 
 
 def _child_of(inst, off):
@@ -76,6 +83,15 @@ def _mapped(child, o):
 
 
 def _ref(inst, k, v):
+    if W64:
+        if k == K_CONST:
+            return "%dull" % CONSTS64[v]
+        r = _ref_ptr(inst, k, v)
+        return r[1:] if r.startswith("&") else "(*%s)" % r
+    return _ref_ptr(inst, k, v)
+
+
+def _ref_ptr(inst, k, v):
     if k == K_SIG:
         if v < inst.n_local:
             return "&signalValues[mySignalStart + %d]" % v
@@ -130,21 +146,35 @@ def _emit_instance(inst, out):
             stmts.append("{ printf(\"\\n\"); }" if dv[i] else "{ printf(\" \"); }")
             continue
         if o == CALL:               # CallBucket (call_bucket.rs:466-533): the callee works on its own lvar arena
+            if W64:
+                raise ValueError("run-time functions are not emitted for the 64-bit runtime")
             stmts.append("rtfn_%d(ctx,&expaux[%d]);" % (av[i], bv[i]))
             continue
         if o == ASSERT_EQ or o == ASSERT_NZ:
-            if o == ASSERT_EQ:
+            if o == ASSERT_EQ and W64:
+                cond = "aux_assert = Fr_eq(%s,%s);" % (_ref(inst, ak[i], av[i]), _ref(inst, bk[i], bv[i]))
+                test = "aux_assert"
+            elif o == ASSERT_EQ:
                 cond = "Fr_eq(&aux_assert,%s,%s);" % (_ref(inst, ak[i], av[i]), _ref(inst, bk[i], bv[i]))
                 test = "&aux_assert"
             else:
                 cond = ""
                 test = _ref(inst, ak[i], av[i])
-            stmts.append("{ FrElement aux_assert; %s if (!Fr_isTrue(%s)) { std::cout << \"Failed assert in template/function \" "
+            stmts.append("{ " + ("u64" if W64 else "FrElement") + " aux_assert; %s if (!Fr_isTrue(%s)) { std::cout << \"Failed assert in template/function \" "
                          "<< \"%s\" << \" op %d\" << std::endl; std::cout << \"Followed trace of components: \" << "
                          "ctx->getTrace(myId) << std::endl; assert(false); } }" % (cond, test, inst.name, i))
             continue
         dst = _ref(inst, dk[i], dv[i])
-        if o in SYM:
+        if W64 and o in SYM:
+            s = "%s = %s(%s,%s);" % (dst, SYM[o], _ref(inst, ak[i], av[i]), _ref(inst, bk[i], bv[i]))
+        elif W64 and o == COPY:
+            s = "%s = %s;" % (dst, _ref(inst, ak[i], av[i]))
+        elif W64 and o in SYM1:
+            s = "%s = %s(%s);" % (dst, SYM1[o], _ref(inst, ak[i], av[i]))
+        elif W64 and o == SELECT:
+            s = "if (Fr_isTrue(%s)) { %s = %s; } else { %s = %s; }" % (
+                _ref(inst, ak[i], av[i]), dst, _ref(inst, bk[i], bv[i]), dst, _ref(inst, ck[i], cv[i]))
+        elif o in SYM:
             s = "%s(%s,%s,%s);" % (SYM[o], dst, _ref(inst, ak[i], av[i]), _ref(inst, bk[i], bv[i]))
         elif o in SYM1:
             s = "%s(%s,%s);" % (SYM1[o], dst, _ref(inst, ak[i], av[i]))
@@ -174,15 +204,20 @@ def _emit_instance(inst, out):
     # ---- body chunks ----
     chunks = [stmts[i:i + CHUNK] for i in range(0, len(stmts), CHUNK)] or [[]]
     for ci, ch in enumerate(chunks):
-        out.append("static void %s_body%d(%s){" % (h, ci, ARGS_DECL))
+        out.append("static void %s_body%d(%s){" % (h, ci, ARGS_DECL64 if W64 else ARGS_DECL))
         out.extend(ch)
         out.append("}")
     # ---- run (template.rs:281-472) ----
     out.append("void %s_run(uint ctx_index,Circom_CalcWit* ctx){" % h)
-    out.append("FrElement* circuitConstants = ctx->circuitConstants;")
-    out.append("FrElement* signalValues = ctx->signalValues;")
-    out.append("std::vector<FrElement> expaux_v(%d);" % max(inst.n_temps, 1))
-    out.append("FrElement* expaux = expaux_v.data();")
+    if W64:
+        out.append("u64* signalValues = ctx->signalValues;")
+        out.append("std::vector<u64> expaux_v(%d);" % max(inst.n_temps, 1))
+        out.append("u64* expaux = expaux_v.data();")
+    else:
+        out.append("FrElement* circuitConstants = ctx->circuitConstants;")
+        out.append("FrElement* signalValues = ctx->signalValues;")
+        out.append("std::vector<FrElement> expaux_v(%d);" % max(inst.n_temps, 1))
+        out.append("FrElement* expaux = expaux_v.data();")
     out.append("u64 mySignalStart = ctx->componentMemory[ctx_index].signalStart;")
     out.append("u64 myId = ctx_index;")
     out.append("u32* mySubcomponents = ctx->componentMemory[ctx_index].subcomponents;")
@@ -191,7 +226,7 @@ def _emit_instance(inst, out):
         out.append("mySubcomponents[%d] = ctx_index + %d; %s_create(mySignalStart + %d, ctx_index + %d, ctx, \"%s\", myId);"
                    % (k, coff, cinst.header, soff, coff, nm))
     for ci in range(len(chunks)):
-        out.append("%s_body%d(%s);" % (h, ci, ARGS_CALL))
+        out.append("%s_body%d(%s);" % (h, ci, ARGS_CALL64 if W64 else ARGS_CALL))
     out.append("for (uint i = 0; i < %d; i++){" % nsub)
     out.append("uint index_subc = ctx->componentMemory[ctx_index].subcomponents[i];")
     out.append("if (index_subc != 0){ assert(!(ctx->componentMemory[index_subc].inputCounter)); release_memory_component(ctx,index_subc); }")
@@ -230,10 +265,13 @@ def _emit_function(fid, fn, out):
 
 def emit(fc, path, hashmap_size: int):
     """fc: circom_amd FlatCircuit (duck-typed: .prog.inst_list, .prog.main, sizes)."""
+    global W64, CONSTS64
+    W64 = fc.prime == "goldilocks"
+    CONSTS64 = [int(c) % fc.fp.q for c in fc.constants]
     prog = fc.prog
     insts = prog.inst_list
     out = ["#include <stdio.h>", "#include <iostream>", "#include <vector>", "#include <assert.h>",
-           "#include \"circom.hpp\"", "#include \"calcwit.hpp\""]
+           "#include \"circom.hpp\"", "#include \"calcwit.hpp\""] + (["#include \"fr.hpp\""] if W64 else [])
     for t in insts:
         out.append("void %s_create(uint soffset,uint coffset,Circom_CalcWit* ctx,std::string componentName,uint componentFather);" % t.header)
         out.append("void %s_run(uint ctx_index,Circom_CalcWit* ctx);" % t.header)
@@ -246,7 +284,8 @@ def emit(fc, path, hashmap_size: int):
     out.append("uint get_number_of_components() {return %d;}" % fc.n_components)
     out.append("uint get_size_of_input_hashmap() {return %d;}" % hashmap_size)
     out.append("uint get_size_of_witness() {return %d;}" % fc.n_signals)
-    out.append("uint get_size_of_constants() {return %d;}" % len(fc.constants))
+    if not W64:
+        out.append("uint get_size_of_constants() {return %d;}" % len(fc.constants))
     out.append("uint get_size_of_io_map() {return %d;}" % len(getattr(fc, "io_map", ())))
     out.append("uint get_size_of_bus_field_map() {return 0;}")
     # generate_function_release_memory_component, c_code_generator.rs:914-933

@@ -252,3 +252,45 @@ def build_default_circuits():
                        ("semaphore20p", Program(SemaphoreStyle(20, True))), ("sha256_2048", Program(Sha256(2048)))):
         cp = compile_program(prog, d, name, sym=False)
         build_circuit(cp)
+
+
+# ---- the 64-bit runtime (`--prime goldilocks`): oracle side only -------------------------------------------------------
+# The device path refuses this prime (DESIGN 9 / NOTES: its "q is large" shortcuts); the oracle is pinned against the
+# reference's own 64-bit runtime here so that a later round only has device work left.
+def write_dat64(path, fc):
+    """`.dat` as common64/main.cpp reads it (loadCircuit there: hash map, witness list, io map - no constant table: the
+    reference inlines constants as literals for this prime, value_bucket.rs:82-86)"""
+    import struct
+    import numpy as np
+    from circom_amd.hip_elements.writers import hashmap_size, build_hash_map, dat_io_map
+    size = hashmap_size(len(fc.inputs))
+    with open(path, "wb") as f:
+        f.write(b"".join(struct.pack("<QQQ", *e) for e in build_hash_map(fc.inputs, size)))
+        f.write(np.arange(fc.n_signals, dtype="<u8").tobytes())
+        f.write(dat_io_map(getattr(fc, "io_map", ())))
+    return size
+
+
+def build_circuit64(fc, name: str):
+    """reference CLI of a goldilocks circuit: oracle/_ref/goldilocks/<name> (emit_ref_cpp in its 64-bit mode + oracle/Makefile
+    circuit64).  Needs the reference tree."""
+    from . import emit_ref_cpp
+    assert fc.prime == "goldilocks"
+    if not REF_ROOT.exists():
+        raise RuntimeError("the reference tree is absent")
+    d = ref_dir("goldilocks")
+    d.mkdir(parents=True, exist_ok=True)
+    size = write_dat64(d / (name + ".dat"), fc)
+    emit_ref_cpp.emit(fc, d / (name + ".cpp"), size)
+    subprocess.run(["make", "-C", str(ROOT), "circuit64", "NAME=" + name, "REF=" + str(REF_ROOT)], check=True, capture_output=True)
+    return d / name
+
+
+def run_cli64(cli: Path, input_json: str, out_wtns: Path):
+    with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+        f.write(input_json)
+        p = f.name
+    try:
+        return subprocess.run([str(cli), p, str(out_wtns)], capture_output=True, text=True)
+    finally:
+        os.unlink(p)

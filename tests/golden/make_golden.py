@@ -110,11 +110,61 @@ def make_logs():
         json.dump(result, f, indent=1)
 
 
+def goldilocks_cases():
+    """name -> (builder, input rows): circuits on the 64-bit Goldilocks prime, run through the reference's OWN 64-bit
+    runtime (goldilocks/fr.hpp + common64/{main,calcwit}.cpp).  The device path does not take this prime yet (DESIGN 9);
+    the fixtures pin the ORACLE for it."""
+    from circom_amd.circuits.basic import Multiplier2, IsZero, Num2Bits
+    from circom_amd.circuits.opzoo import OperatorZoo
+    from circom_amd.circuits.poseidon import Poseidon
+    q = PRIMES["goldilocks"]
+    r = random.Random(64)
+    return {
+        "multiplier2": (lambda: Program(Multiplier2(), prime="goldilocks"), [[3, 11], [0, 0], [q - 1, q - 1], [r.randrange(q), r.randrange(q)]]),
+        "iszero": (lambda: Program(IsZero(), prime="goldilocks"), [[0], [1], [q - 1], [r.randrange(q)]]),
+        "num2bits16": (lambda: Program(Num2Bits(16), prime="goldilocks"), [[0], [1], [43690], [65535]]),
+        "opzoo": (lambda: Program(OperatorZoo(), prime="goldilocks"),
+                  [[3, 11], [0, 0], [q - 1, q - 1], [(q >> 1) + 1, 63], [1 << 40, q - 3], [q - 2, 7], [12345678901234567890 % q, 64],
+                   [r.randrange(q), r.randrange(q)], [r.randrange(q), r.randrange(64)]]),
+        "poseidon2": (lambda: Program(Poseidon(2), prime="goldilocks"), [[1, 2], [0, 0], [q - 1, q - 1], [r.randrange(q), r.randrange(q)]]),
+    }
+
+
+def make_goldilocks():
+    from circom_amd.frontend.flatten import flatten
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_wtns_goldilocks.json")
+    result = {"generator": "tests/golden/make_golden.py goldilocks",
+              "runtime": "reference goldilocks/fr.hpp + common64/{main,calcwit}.cpp (oracle/Makefile circuit64)", "cases": {}}
+    for name, (mk, rows) in goldilocks_cases().items():
+        fc = flatten(mk())
+        cli = ref_build.build_circuit64(fc, name)
+        d = tempfile.mkdtemp(prefix="golden64_")
+        entries = []
+        for row in rows:
+            obj, pos = {}, 0
+            for nm, _, size in fc.inputs:
+                dims = fc.input_dims.get(nm) or []
+                obj[nm] = str(row[pos]) if not dims else [str(v) for v in row[pos:pos + size]]
+                pos += size
+            out = os.path.join(d, "o.wtns")
+            r = ref_build.run_cli64(cli, json.dumps(obj), out)
+            assert r.returncode == 0, r.stderr
+            b = open(out, "rb").read()
+            entries.append({"inputs": [str(v) for v in row], "wtns_sha256": hashlib.sha256(b).hexdigest(), "wtns_len": len(b),
+                            "wtns_hex": b.hex() if len(b) <= 4096 else None})
+        result["cases"][name] = {"prime": "goldilocks", "vectors": entries}
+        print(name, len(rows), "vectors", entries[0]["wtns_len"], "bytes each")
+    with open(path, "w") as f:
+        json.dump(result, f, indent=1)
+
+
 def main():
     """`make_golden.py` regenerates everything; `make_golden.py NAME...` only (re)generates the named cases and keeps
     the other entries of the JSON as they are."""
     if sys.argv[1:] == ["logs"]:
         return make_logs()
+    if sys.argv[1:] == ["goldilocks"]:
+        return make_goldilocks()
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_wtns.json")
     only = set(sys.argv[1:])
     result = {"generator": "tests/golden/make_golden.py", "runtime": "reference common/{main,calcwit}.cpp + generic/fr.cpp (GMP, no asm)",
