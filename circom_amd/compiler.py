@@ -23,6 +23,7 @@ class Compiled:
     flat: FlatCircuit
     tape: Tape
     bittape: object = None          # hip_elements.bitsched.BitTape when the circuit got a bit-plane program
+    jit: object = None              # hip_elements.bitjit.JitProgram: the same network as emitted gfx950 code (large batches)
 
 
 DEFAULT_STRANDS = (1, 4, 16)
@@ -63,6 +64,7 @@ def lower_bitplane(fc: FlatCircuit, bits="auto"):
     """The bit-plane program of a circuit whose signals are all boolean for 0/1 inputs (SHA-256 and friends), or None.
     bits: True = whenever the analysis succeeds, False = never, "auto" = only for circuits large enough to matter (an
     instance whose inputs are not 0/1 is re-run by the 256-bit schedule, so tiny arithmetic circuits gain nothing)."""
+    lower_bitplane.net = None
     if bits is False or (bits == "auto" and fc.n_signals < BITS_AUTO_MIN_SIGNALS) or fc.n_main_inputs == 0:
         return None
     if (fc.code["op"] == O.LOG).any():
@@ -72,6 +74,7 @@ def lower_bitplane(fc: FlatCircuit, bits="auto"):
     net = bitblast(fc)
     if net is None:
         return None
+    lower_bitplane.net = net
     from .hip_elements.bitmap import map_network
     bt = lower_bits(map_network(net), fc)
     # Evidence that the circuit really is bit-level: the analysis only proves "boolean IF the inputs are 0/1" - a Num2Bits or
@@ -83,6 +86,26 @@ def lower_bitplane(fc: FlatCircuit, bits="auto"):
     return bt
 
 
+lower_bitplane.net = None           # the gate network of the last call (compile_program hands it to the code emitter)
+
+JIT_AUTO_MIN_GATES = 20_000         # "auto": circuits below this never see batches where the emitted code wins
+
+
+def emit_jit(net, fc, jit="auto"):
+    """The bit-plane program as emitted gfx950 code (hip_elements/bitjit.py), assembled; None when not wanted / nothing to
+    evaluate.  jit: True, False or "auto" (circuits with at least JIT_AUTO_MIN_GATES gates); CW_JIT=0/1 overrides."""
+    if os.environ.get("CW_JIT"):
+        jit = os.environ["CW_JIT"] != "0"
+    if net is None or jit is False or (jit == "auto" and net.stats.get("gates", 0) < JIT_AUTO_MIN_GATES):
+        return None
+    from .hip_elements import bitjit
+    jp = bitjit.lower_jit(net, fc)
+    if jp is None:
+        return None
+    jp.code = bitjit.assemble(bitjit.to_asm(jp))
+    return jp
+
+
 # The pipelined single-wave variant (hip_elements/pipe.py) is opt-in: measured on MI355X it matches the plain single-strand
 # schedule at high occupancy and loses to the multi-strand variants at small batches, where one wave per 64 instances
 # leaves most SIMDs idle (Poseidon(2) x 8 192: 1.2 ms against 0.67 ms with 4 strands; NOTES.md round 2).
@@ -90,13 +113,15 @@ DEFAULT_PIPE = None
 
 
 def compile_program(prog: Program, outdir: str, name: str, sym: bool = True, strands=DEFAULT_STRANDS, bits="auto",
-                    pipe=DEFAULT_PIPE, mont="auto") -> Compiled:
+                    pipe=DEFAULT_PIPE, mont="auto", jit="auto") -> Compiled:
     """strands: strand counts to lower the schedule for (one variant each; the runtime picks per batch).
     pipe: (rows, loads) per batch of the pipelined variant, e.g. (8, 8), which is added last; None = no pipelined variant.
     mont: signals in Montgomery form on the device (True / False / "auto" = choose_mont); CW_MONT=0/1 overrides."""
     os.makedirs(outdir, exist_ok=True)
     fc = flatten(prog)
     bittape = None if os.environ.get("CW_BITS", "1") == "0" else lower_bitplane(fc, bits)      # CW_BITS=0: no bit program in the tape
+    jp = emit_jit(lower_bitplane.net, fc, jit) if bittape is not None else None
+    lower_bitplane.net = None
     if bittape is not None:
         # the 256-bit schedule serves the instances re-run with non-boolean inputs - possibly the whole batch (a caller that
         # feeds field-valued inputs): small circuits keep their multi-strand variants, for a 1M-signal circuit one
@@ -119,9 +144,9 @@ def compile_program(prog: Program, outdir: str, name: str, sym: bool = True, str
         tapes.append(lower(fc, pipe=pipe, mont=mont))
     tape = tapes[0]
     p = lambda ext: os.path.join(outdir, name + ext)
-    writers.write_tape(p(".cwt"), tapes, bittape)
+    writers.write_tape(p(".cwt"), tapes, bittape, jp)
     writers.write_dat(p(".dat"), fc)
     writers.write_r1cs(p(".r1cs"), fc)
     if sym:
         writers.write_sym(p(".sym"), fc)
-    return Compiled(name, outdir, p(".cwt"), p(".dat"), p(".r1cs"), p(".sym"), fc, tape, bittape)
+    return Compiled(name, outdir, p(".cwt"), p(".dat"), p(".r1cs"), p(".sym"), fc, tape, bittape, jp)

@@ -21,15 +21,32 @@
 #include "fp256.hip.h"
 
 
+// ---- table layout ---------------------------------------------------------------------------------------------------------
+// Two layouts share every kernel below through the shift `sh` (a launch parameter):
+//   sh = 0   T[group][slot]                      the interpreter's table: a group's slots are consecutive uint64 (rows of 64 slots)
+//   sh = 5   T[chunk][slot][group in chunk]      the emitted code's table (hip_elements/bitjit.py): a chunk = 32 groups = 2 048
+//                                                instances, a slot of a chunk = one 256-byte row (lane l of the emitting wave
+//                                                holds dword l: instances 32 l .. 32 l + 31 of the chunk)
+// element (group g, slot s) = T[(((g >> sh) * slots + s) << sh) + (g & ((1 << sh) - 1))]: the slots of a group are
+// (1 << sh) uint64 apart, starting at bits_group(T, slots, sh, g).
+__device__ __forceinline__ uint64_t *bits_group(uint64_t *T, uint64_t slots, uint32_t sh, uint32_t g) {
+    return T + (((size_t)(g >> sh) * slots) << sh) + (g & ((1u << sh) - 1u));
+}
+__device__ __forceinline__ const uint64_t *bits_group(const uint64_t *T, uint64_t slots, uint32_t sh, uint32_t g) {
+    return T + (((size_t)(g >> sh) * slots) << sh) + (g & ((1u << sh) - 1u));
+}
+
 // ---- init: constant slots, flags -------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) cw_bits_init_kernel(uint64_t *T, uint64_t slots, uint32_t n_groups, uint64_t *fbmask,
-                                                            uint32_t *status, uint32_t *first_bad, uint32_t Bp) {
+__global__ void __launch_bounds__(256) cw_bits_init_kernel(uint64_t *T, uint64_t slots, uint32_t sh, uint32_t n_groups, uint64_t *fbmask,
+                                                            uint64_t *r1flag, uint32_t *status, uint32_t *first_bad, uint32_t Bp) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < n_groups) {
-        T[(size_t)i * slots + 0] = 0;
-        T[(size_t)i * slots + 1] = ~0ull;
-        T[(size_t)i * slots + 2] = 0;
+        uint64_t *Tg = bits_group(T, slots, sh, i);
+        Tg[(size_t)0 << sh] = 0;
+        Tg[(size_t)1 << sh] = ~0ull;
+        Tg[(size_t)2 << sh] = 0;
         fbmask[i] = 0;
+        if (r1flag) r1flag[i] = 0;
     }
     if (i < Bp) {
         status[i] = 0;
@@ -43,7 +60,7 @@ __global__ void __launch_bounds__(256) cw_bits_init_kernel(uint64_t *T, uint64_t
 // 2 KiB contiguous (64 consecutive inputs of one instance) and the lane shifts the value's low bit into its own mask;
 // the 64 masks leave as one coalesced 512-byte store.  Values other than 0/1 flag their instance.
 __global__ void __launch_bounds__(64) cw_bits_ingest_kernel(const uint4 *__restrict__ in, uint64_t *__restrict__ T,
-                                                             uint64_t slots, uint32_t input_slot0, uint32_t n_in,
+                                                             uint64_t slots, uint32_t sh, uint32_t input_slot0, uint32_t n_in,
                                                              uint32_t batch, uint64_t *fbmask) {
     const uint32_t lane = threadIdx.x, g = blockIdx.x, k = blockIdx.y * 64 + lane;
     const bool have = k < n_in;
@@ -60,7 +77,7 @@ __global__ void __launch_bounds__(64) cw_bits_ingest_kernel(const uint4 *__restr
         mine |= (uint64_t)(lo.x & 1u) << ii;
         if (__any(!isbit)) badmask |= 1ull << ii;                   // wave-uniform
     }
-    if (have) T[(size_t)g * slots + input_slot0 + k] = mine;
+    if (have) bits_group(T, slots, sh, g)[(size_t)(input_slot0 + k) << sh] = mine;
     if (lane == 0 && badmask) atomicOr((unsigned long long *)&fbmask[g], (unsigned long long)badmask);
 }
 
@@ -389,7 +406,7 @@ cw_bits_assert_kernel(const uint64_t *__restrict__ T, uint64_t slots, const uint
 // kernel ran one thread per element with two dependent index loads per 32 bytes: 0.53 of the HBM peak.
 #define BITS_GATHER_RUN 4      // consecutive 1 KiB pieces (32 elements each) a wave writes per instance: 4 KiB runs, 16 KiB per block
 __global__ void __launch_bounds__(256)
-cw_bits_gather_kernel(const uint64_t *__restrict__ T, uint64_t slots, const uint32_t *__restrict__ wslot, uint32_t n_wit,
+cw_bits_gather_kernel(const uint64_t *__restrict__ T, uint64_t slots, uint32_t lsh, const uint32_t *__restrict__ wslot, uint32_t n_wit,
                       uint32_t first, uint32_t count, uint4 *__restrict__ out) {
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t k0 = (blockIdx.x * 4 + wv) * 32 * BITS_GATHER_RUN;        // this wave's elements
@@ -406,8 +423,8 @@ cw_bits_gather_kernel(const uint64_t *__restrict__ T, uint64_t slots, const uint
         win[r] = 0;
         if (have[r]) {
             const uint32_t sl = wslot[k];
-            win[r] = T[(size_t)g * slots + sl] >> sh;
-            if (two) win[r] |= T[(size_t)(g + 1) * slots + sl] << (64 - sh);
+            win[r] = bits_group(T, slots, lsh, g)[(size_t)sl << lsh] >> sh;
+            if (two) win[r] |= bits_group(T, slots, lsh, g + 1)[(size_t)sl << lsh] << (64 - sh);
         }
     }
     const uint32_t nj = min(64u, count - j0);
@@ -428,14 +445,14 @@ cw_bits_gather_kernel(const uint64_t *__restrict__ T, uint64_t slots, const uint
 
 // packed main inputs (cw_set_inputs_bits*): masks[group][k] -> bit-table slot input_slot0 + k
 __global__ void __launch_bounds__(256)
-cw_bits_ingest_packed_kernel(const uint64_t *__restrict__ masks, uint64_t *__restrict__ T, uint64_t slots, uint32_t input_slot0,
+cw_bits_ingest_packed_kernel(const uint64_t *__restrict__ masks, uint64_t *__restrict__ T, uint64_t slots, uint32_t sh, uint32_t input_slot0,
                              uint32_t n_in, uint32_t batch) {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
     if (k >= n_in) return;
     uint64_t m = masks[(size_t)g * n_in + k];
     const uint32_t live = batch - g * 64;                            // instances of the last group beyond the batch read as 0
     if (live < 64) m &= (1ull << live) - 1;
-    T[(size_t)g * slots + input_slot0 + k] = m;
+    bits_group(T, slots, sh, g)[(size_t)(input_slot0 + k) << sh] = m;
 }
 // canonical inputs of the listed instances from packed masks / from the AoS input image (rows of the side batch that
 // re-runs them on the 256-bit schedule): out[j][k] = input k of instance inst[j]
@@ -463,14 +480,16 @@ cw_bits_collect_inputs_kernel(const uint64_t *__restrict__ masks, const uint4 *_
 struct ERec { uint32_t w[5]; uint32_t tt, row, pad; };
 __global__ void __launch_bounds__(64)
 cw_bits_r1cs_lut_kernel(const uint4 *__restrict__ recs, uint32_t n_vrows, uint32_t vrows_per_chunk, const uint64_t *__restrict__ T,
-                        uint64_t slots, uint32_t batch, uint32_t *status, uint32_t *first_bad) {
+                        uint64_t slots, uint32_t sh, const uint64_t *__restrict__ only, uint32_t batch, uint32_t *status, uint32_t *first_bad) {
     const uint32_t lane = threadIdx.x, g = blockIdx.x;
-    const char *Tg = (const char *)(T + (size_t)g * slots);
+    if (only && only[g] == 0) return;           // audit of flagged groups only (the emitted code checked every constraint itself)
+    const char *Tg = (const char *)bits_group(T, slots, sh, g);
     const uint32_t v0 = blockIdx.y * vrows_per_chunk, v1 = min(n_vrows, v0 + vrows_per_chunk);
     for (uint32_t v = v0; v < v1; v++) {
         const uint4 x = recs[((size_t)v * 64 + lane) * 2], y = recs[((size_t)v * 64 + lane) * 2 + 1];
-        const uint64_t w0 = *(const uint64_t *)(Tg + x.x), w1 = *(const uint64_t *)(Tg + x.y), w2 = *(const uint64_t *)(Tg + x.z),
-                       w3 = *(const uint64_t *)(Tg + x.w), w4 = *(const uint64_t *)(Tg + y.x);
+        const uint64_t w0 = *(const uint64_t *)(Tg + ((size_t)x.x << sh)), w1 = *(const uint64_t *)(Tg + ((size_t)x.y << sh)),
+                       w2 = *(const uint64_t *)(Tg + ((size_t)x.z << sh)), w3 = *(const uint64_t *)(Tg + ((size_t)x.w << sh)),
+                       w4 = *(const uint64_t *)(Tg + ((size_t)y.x << sh));
         const uint32_t tt = y.y;
         const uint64_t f00 = lut3(w0, w1, w2, tt & 0xFFu), f01 = lut3(w0, w1, w2, (tt >> 8) & 0xFFu),
                        f10 = lut3(w0, w1, w2, (tt >> 16) & 0xFFu), f11 = lut3(w0, w1, w2, tt >> 24);
@@ -497,11 +516,12 @@ cw_bits_r1cs_lut_kernel(const uint4 *__restrict__ recs, uint32_t n_vrows, uint32
 __global__ void __launch_bounds__(64)
 cw_bits_r1cs_wide_kernel(const uint4 *__restrict__ chunk, uint32_t n_chunks, const uint2 *__restrict__ terms,
                          const uint32_t *__restrict__ ctab, const uint32_t *__restrict__ row_orig,
-                         const uint64_t *__restrict__ T, uint64_t slots, uint32_t batch, uint32_t *status,
-                         uint32_t *first_bad, FpParams P) {
+                         const uint64_t *__restrict__ T, uint64_t slots, uint32_t sh, const uint64_t *__restrict__ only,
+                         uint32_t batch, uint32_t *status, uint32_t *first_bad, FpParams P) {
     const uint32_t lane = threadIdx.x, g = blockIdx.x;
     const uint32_t i = g * 64 + lane;
-    const char *Tg = (const char *)(T + (size_t)g * slots);
+    if (only && only[g] == 0) return;
+    const char *Tg = (const char *)bits_group(T, slots, sh, g);
     uint32_t bad = 0xFFFFFFFFu;
     for (uint32_t cix = blockIdx.y; cix < n_chunks; cix += gridDim.y) {
         const uint4 ch = chunk[cix];                                // first term, n terms, -, first row
@@ -511,7 +531,7 @@ cw_bits_r1cs_wide_kernel(const uint4 *__restrict__ chunk, uint32_t n_chunks, con
         for (uint32_t k = 0; k < ch.y; k++) {
             const uint2 t = tp[k];
             const uint32_t off = t.x & 0x0FFFFFFFu, part = (t.x >> 28) & 3u, last = t.x >> 31, endrow = (t.x >> 30) & 1u;
-            const uint64_t m = *(const uint64_t *)(Tg + off);      // wave-uniform address
+            const uint64_t m = *(const uint64_t *)(Tg + ((size_t)off << sh));      // wave-uniform address
             const bool bit = (m >> lane) & 1ull;
             const fe cf = fe_from(ctab + (size_t)t.y * 8);
             fe w;
@@ -593,17 +613,18 @@ __device__ __forceinline__ uint32_t bits_transpose32(uint32_t x, const BitsTr &t
 // the word of every instance from the 32 masks of a whole word (slots s .. s + 31 = bits 0 .. 31): lane l loads the
 // (l >> 5)-th dword of mask l & 31 - one coalesced 256-byte load, lanes 0..31 then hold the rows of the instances 0..31
 // and lanes 32..63 those of the instances 32..63 - and the transpose hands lane i the word of instance i
-__device__ __forceinline__ uint32_t bits_word_load(const uint64_t *__restrict__ Tg, uint32_t slot, uint32_t lane) {
-    return ((const uint32_t *)(Tg + slot))[(lane & 31u) * 2u + (lane >> 5)];
+__device__ __forceinline__ uint32_t bits_word_load(const uint64_t *__restrict__ Tg, uint32_t sh, uint32_t slot, uint32_t lane) {
+    return ((const uint32_t *)(Tg + ((size_t)(slot + (lane & 31u)) << sh)))[lane >> 5];
 }
 __global__ void __launch_bounds__(64)
 cw_bits_r1cs_int_kernel(const uint4 *__restrict__ chunk, uint32_t n_chunks, const uint32_t *__restrict__ words,
                         const uint2 *__restrict__ itab, const uint32_t *__restrict__ row_orig,
-                        const uint64_t *__restrict__ T, uint64_t slots, uint32_t batch, uint32_t *status,
-                        uint32_t *first_bad) {
+                        const uint64_t *__restrict__ T, uint64_t slots, uint32_t sh, const uint64_t *__restrict__ only,
+                        uint32_t batch, uint32_t *status, uint32_t *first_bad) {
     const uint32_t lane = threadIdx.x, g = blockIdx.x;
     const uint32_t i = g * 64 + lane;
-    const uint64_t *Tg = T + (size_t)g * slots;
+    if (only && only[g] == 0) return;
+    const uint64_t *Tg = bits_group(T, slots, sh, g);
     const BitsTr TR = bits_tr_setup(lane);
     uint32_t bad = 0xFFFFFFFFu;
     for (uint32_t cix = blockIdx.y; cix < n_chunks; cix += gridDim.y) {
@@ -623,7 +644,7 @@ cw_bits_r1cs_int_kernel(const uint4 *__restrict__ chunk, uint32_t n_chunks, cons
 #pragma unroll
                     for (int k = 0; k < 4; k++) e[k] = wp[j + k];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) x[k] = bits_word_load(Tg, e[k] & 0x3FFFFFFFu, lane);   // padding entries name slot 0: valid memory, unused
+                    for (int k = 0; k < 4; k++) x[k] = bits_word_load(Tg, sh, e[k] & 0x3FFFFFFFu, lane);   // padding entries name slot 0: valid memory, unused
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const uint32_t y = j + k < nb ? bits_transpose32(x[k], TR) : 0u;
@@ -642,12 +663,12 @@ cw_bits_r1cs_int_kernel(const uint4 *__restrict__ chunk, uint32_t n_chunks, cons
 #pragma unroll
                     for (int k = 0; k < 8; k++) w[k] = wp[k];
                     if (w[0] >> 31) {                                          // 8 consecutive slots: one 64-byte scalar load
-                        const uint64_t *mp = Tg + ((w[0] & 0x7FFFFFFFu) >> 5);
+                        const uint64_t *mp = Tg + ((size_t)((w[0] & 0x7FFFFFFFu) >> 5) << sh);
 #pragma unroll
-                        for (int k = 0; k < 8; k++) m[k] = mp[k];
+                        for (int k = 0; k < 8; k++) m[k] = mp[(size_t)k << sh];
                     } else {
 #pragma unroll
-                        for (int k = 0; k < 8; k++) m[k] = Tg[w[k] >> 5];       // wave-uniform addresses: scalar loads
+                        for (int k = 0; k < 8; k++) m[k] = Tg[(size_t)(w[k] >> 5) << sh];       // wave-uniform addresses: scalar loads
                     }
 #pragma unroll
                     for (int k = 0; k < 8; k++) acc |= bits_lane_bit(m[k]) << (w[k] & 31u);
@@ -658,7 +679,7 @@ cw_bits_r1cs_int_kernel(const uint4 *__restrict__ chunk, uint32_t n_chunks, cons
                 for (uint32_t blk = 0; blk < nb; blk++, wp += 8) {
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        const uint64_t m = Tg[wp[2 * k]];
+                        const uint64_t m = Tg[(size_t)wp[2 * k] << sh];
                         const uint2 cw = itab[wp[2 * k + 1]];
                         const int64_t cf = (int64_t)(((uint64_t)cw.y << 32) | cw.x);
                         cur += bits_lane_bit(m) ? cf : 0;
@@ -688,19 +709,19 @@ cw_bits_r1cs_int_kernel(const uint4 *__restrict__ chunk, uint32_t n_chunks, cons
 }
 
 // ---- launch wrappers ---------------------------------------------------------------------------------------------------
-hipError_t cwk_bits_init(hipStream_t s, void *T, uint64_t slots, uint32_t n_groups, void *fbmask, uint32_t *status,
-                         uint32_t *first_bad, uint32_t Bp) {
+hipError_t cwk_bits_init(hipStream_t s, void *T, uint64_t slots, uint32_t sh, uint32_t n_groups, void *fbmask, void *r1flag,
+                         uint32_t *status, uint32_t *first_bad, uint32_t Bp) {
     const uint32_t n = n_groups > Bp ? n_groups : Bp;
-    hipLaunchKernelGGL(cw_bits_init_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (uint64_t *)T, slots, n_groups,
-                       (uint64_t *)fbmask, status, first_bad, Bp);
+    hipLaunchKernelGGL(cw_bits_init_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (uint64_t *)T, slots, sh, n_groups,
+                       (uint64_t *)fbmask, (uint64_t *)r1flag, status, first_bad, Bp);
     return hipGetLastError();
 }
-hipError_t cwk_bits_ingest(hipStream_t s, const void *in, void *T, uint64_t slots, uint32_t input_slot0, uint32_t n_in,
+hipError_t cwk_bits_ingest(hipStream_t s, const void *in, void *T, uint64_t slots, uint32_t sh, uint32_t input_slot0, uint32_t n_in,
                            uint32_t batch, void *fbmask) {
     if (n_in == 0) return hipSuccess;
     dim3 g((batch + 63) / 64, (n_in + 63) / 64);
     if (g.y > 65535u) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(cw_bits_ingest_kernel, g, dim3(64), 0, s, (const uint4 *)in, (uint64_t *)T, slots, input_slot0, n_in,
+    hipLaunchKernelGGL(cw_bits_ingest_kernel, g, dim3(64), 0, s, (const uint4 *)in, (uint64_t *)T, slots, sh, input_slot0, n_in,
                        batch, (uint64_t *)fbmask);
     return hipGetLastError();
 }
@@ -718,22 +739,22 @@ hipError_t cwk_bits_eval(hipStream_t s, const void *recs, const uint32_t *cmds, 
                            n_groups, (uint64_t *)fbmask);
     return hipGetLastError();
 }
-hipError_t cwk_bits_gather(hipStream_t s, const void *T, uint64_t slots, const uint32_t *wslot, uint32_t n_wit, uint32_t first,
+hipError_t cwk_bits_gather(hipStream_t s, const void *T, uint64_t slots, uint32_t sh, const uint32_t *wslot, uint32_t n_wit, uint32_t first,
                            uint32_t count, void *out) {
     if (!count || !n_wit) return hipSuccess;
     for (uint32_t done = 0; done < count; done += 65535u * 64u) {       // grid.y limit
         const uint32_t n = count - done < 65535u * 64u ? count - done : 65535u * 64u;
-        hipLaunchKernelGGL(cw_bits_gather_kernel, dim3((n_wit + 128 * BITS_GATHER_RUN - 1) / (128 * BITS_GATHER_RUN), (n + 63) / 64), dim3(256), 0, s, (const uint64_t *)T, slots,
+        hipLaunchKernelGGL(cw_bits_gather_kernel, dim3((n_wit + 128 * BITS_GATHER_RUN - 1) / (128 * BITS_GATHER_RUN), (n + 63) / 64), dim3(256), 0, s, (const uint64_t *)T, slots, sh,
                            wslot, n_wit, first + done, n, (uint4 *)out + (size_t)done * n_wit * 2);
     }
     return hipGetLastError();
 }
-hipError_t cwk_bits_ingest_packed(hipStream_t s, const void *masks, void *T, uint64_t slots, uint32_t input_slot0, uint32_t n_in,
+hipError_t cwk_bits_ingest_packed(hipStream_t s, const void *masks, void *T, uint64_t slots, uint32_t sh, uint32_t input_slot0, uint32_t n_in,
                                   uint32_t batch) {
     if (n_in == 0) return hipSuccess;
     dim3 g((n_in + 255) / 256, (batch + 63) / 64);
     if (g.y > 65535u) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(cw_bits_ingest_packed_kernel, g, dim3(256), 0, s, (const uint64_t *)masks, (uint64_t *)T, slots, input_slot0, n_in,
+    hipLaunchKernelGGL(cw_bits_ingest_packed_kernel, g, dim3(256), 0, s, (const uint64_t *)masks, (uint64_t *)T, slots, sh, input_slot0, n_in,
                        batch);
     return hipGetLastError();
 }
@@ -750,7 +771,9 @@ hipError_t cwk_bits_collect_inputs(hipStream_t s, const void *masks, const void 
 hipError_t cwk_bits_r1cs(hipStream_t s, const void *erecs, uint32_t n_evrows, const uint32_t *chunk, uint32_t n_chunks,
                          const uint32_t *terms, const uint32_t *ctab, const uint32_t *row_orig, const uint32_t *ichunk,
                          uint32_t n_ichunks, const uint32_t *iterms, const uint32_t *itab, const uint32_t *irow_orig, const void *T,
-                         uint64_t slots, uint32_t n_groups, uint32_t batch, uint32_t *status, uint32_t *first_bad, const FpParams &P) {
+                         uint64_t slots, uint32_t sh, const void *only, uint32_t n_groups, uint32_t batch, uint32_t *status, uint32_t *first_bad,
+                         const FpParams &P) {
+    const uint64_t *onl = (const uint64_t *)only;
     if (n_evrows) {
         // the kernel is bound by the latency of its 5 mask loads per lane: ~8 waves per SIMD (8192 on the chip) hide it
         uint32_t chunks = (8192 + n_groups - 1) / n_groups;
@@ -760,17 +783,17 @@ hipError_t cwk_bits_r1cs(hipStream_t s, const void *erecs, uint32_t n_evrows, co
         const uint32_t per = (n_evrows + chunks - 1) / chunks;
         chunks = (n_evrows + per - 1) / per;
         hipLaunchKernelGGL(cw_bits_r1cs_lut_kernel, dim3(n_groups, chunks), dim3(64), 0, s, (const uint4 *)erecs, n_evrows, per,
-                           (const uint64_t *)T, slots, batch, status, first_bad);
+                           (const uint64_t *)T, slots, sh, onl, batch, status, first_bad);
     }
     if (n_ichunks) {
         dim3 g(n_groups, n_ichunks < 65535u ? n_ichunks : 65535u);
         hipLaunchKernelGGL(cw_bits_r1cs_int_kernel, g, dim3(64), 0, s, (const uint4 *)ichunk, n_ichunks, iterms,
-                           (const uint2 *)itab, irow_orig, (const uint64_t *)T, slots, batch, status, first_bad);
+                           (const uint2 *)itab, irow_orig, (const uint64_t *)T, slots, sh, onl, batch, status, first_bad);
     }
     if (n_chunks) {
         dim3 g(n_groups, n_chunks < 65535u ? n_chunks : 65535u);
         hipLaunchKernelGGL(cw_bits_r1cs_wide_kernel, g, dim3(64), 0, s, (const uint4 *)chunk, n_chunks, (const uint2 *)terms, ctab,
-                           row_orig, (const uint64_t *)T, slots, batch, status, first_bad, P);
+                           row_orig, (const uint64_t *)T, slots, sh, onl, batch, status, first_bad, P);
     }
     return hipGetLastError();
 }

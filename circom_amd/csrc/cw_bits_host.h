@@ -28,6 +28,29 @@ struct Program {                             // hip_elements/bitsched.py::BitTap
     std::vector<uint32_t> assert_slots;      // slots that must be zero in every instance (unproved `===`)
 };
 
+// The same network as emitted gfx950 code (hip_elements/bitjit.py): a code object with ONE kernel that runs one wave per chunk
+// of 2 048 instances on the table layout T[chunk][slot][32 groups] (cw_bits.hip, sh = 5).  The section is machine code, as
+// the reference's compiled <name>.cpp is: a .cwt is as trusted as an executable (CW_BITS_JIT=0 never loads it); what IS
+// checked are the sizes and the slot map the host-side kernels index the table with.
+struct JitProgram {
+    uint64_t n_slots = 0;                    // rows (256 bytes) per chunk
+    std::vector<uint32_t> sig_slot;          // signal -> row
+    std::vector<uint8_t> code;               // ELF code object (hipModuleLoadData)
+    bool check_complete = false;             // the fused R1CS check covers every constraint of the circuit
+    uint32_t n_vgpr = 0, n_agpr = 0;
+};
+constexpr const char *JIT_KERNEL = "cw_bits_jit";
+constexpr uint32_t JIT_MIN_BATCH = 1u << 18;
+inline const char *validate_jit(const JitProgram &p, uint32_t n_signals, uint32_t n_inputs) {
+    if (p.n_slots < (uint64_t)IN_BASE + n_inputs || p.n_slots * 256 >= (1ull << 32)) return "emitted program: slot count";
+    if (p.sig_slot.size() != n_signals) return "emitted program: signal map size";
+    for (uint32_t s : p.sig_slot)
+        if (s >= p.n_slots || s == 2) return "emitted program: signal slot out of range";
+    if (p.code.size() < 64 || memcmp(p.code.data(), "\177ELF", 4)) return "emitted program: not a code object";
+    if (p.n_vgpr + p.n_agpr > 512 || p.n_vgpr < 8) return "emitted program: register counts";
+    return nullptr;
+}
+
 // Every offset a record or a command carries is checked once at load time (files are untrusted input): LDS operands
 // inside ring / cache / constants, results inside ring / cache, rows inside the group's bit table, flushes never onto
 // the rows of the constants and main inputs.  (Races are the lowering's business: oracle/tape_eval.py replays the

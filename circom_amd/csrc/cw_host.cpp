@@ -246,6 +246,10 @@ struct cw_circuit {
     // bit-plane program (cw_bits.hip) when every signal of the circuit is provably boolean for 0/1 inputs
     bool has_bits = false;
     cwbits::Program bits;
+    // the same gate network as EMITTED gfx950 code (hip_elements/bitjit.py) for large batches: a code object, its own slot map
+    bool has_jit = false;
+    cwbits::JitProgram jit;
+    std::map<int, std::pair<hipModule_t, hipFunction_t>> jit_mod;   // device -> loaded module
     std::vector<uint32_t> r_cc, r_cctab;   // per term: id of its canonical coefficient in r_cctab (8 words each)
     // log(...) statements (LogBucket): the LAST n_logv of n_signals are hidden signals holding their arguments
     uint32_t n_logv = 0;
@@ -410,7 +414,7 @@ static int load_tape(cw_circuit *c, const char *path) {
     if (!read_file(path, b)) return fail(CW_EIO, std::string("tape file not found: ") + path);
     if (b.size() < 16 + 32 + 48 || memcmp(b.data(), "CWTP", 4)) return fail(CW_EIO, "bad tape magic");
     const uint32_t *h = (const uint32_t *)(b.data() + 4);
-    if (h[0] != 10) return fail(CW_EIO, "unsupported tape version");
+    if (h[0] != 11) return fail(CW_EIO, "unsupported tape version");
     if (h[1] != 4) return fail(CW_EIO, "only 4x64-bit primes are supported (bn128, bls12381, ...)");
     uint32_t n_variants = h[2];
     size_t off = 16;
@@ -441,7 +445,7 @@ static int load_tape(cw_circuit *c, const char *path) {
         return fail(CW_EIO, "tape header: section counts");
     if (c->n_logv && n_bit_programs) return fail(CW_EIO, "tape header: log values cannot be combined with a bit-plane program");
     if (n_functions > (1u << 16)) return fail(CW_EIO, "tape header: too many functions");
-    if (n_bit_programs > 1) return fail(CW_EIO, "tape header: more than one bit-plane program");
+    if (n_bit_programs > 2) return fail(CW_EIO, "tape header: more than two bit-plane programs");
     if (c->mont && (n_bit_programs || n_functions))
         return fail(CW_EIO, "tape header: Montgomery-form signals cannot be combined with a bit-plane program or run-time functions");
     // shape of the main component: slot 0 is the constant 1, outputs from slot 1, inputs right after them
@@ -741,6 +745,29 @@ static int load_tape(cw_circuit *c, const char *path) {
         if (const char *why = cwbits::validate(bp, c->n_signals, c->n_inputs)) return fail(CW_EIO, std::string("tape: ") + why);
         c->has_bits = true;
     }
+    if (n_bit_programs > 1) {
+        // emitted code: 8 x u32 {format 1, n_slots lo, hi, code bytes, flags (bit 0: the fused R1CS check covers every
+        // constraint), VGPRs, AccVGPRs, 0}, signal -> slot map, the code object (padded to 4 bytes)
+        if (off + 32 > b.size()) return fail(CW_EIO, "tape emitted program truncated");
+        uint32_t jh[8];
+        memcpy(jh, b.data() + off, 32);
+        off += 32;
+        if (jh[0] != 1 || jh[7]) return fail(CW_EIO, "tape emitted program: unknown format version (lowered by another release)");
+        cwbits::JitProgram &jp = c->jit;
+        jp.n_slots = (uint64_t)jh[1] | ((uint64_t)jh[2] << 32);
+        const uint64_t code_bytes = jh[3], padded = (code_bytes + 3) & ~3ull;
+        jp.check_complete = jh[4] & 1u;
+        jp.n_vgpr = jh[5];
+        jp.n_agpr = jh[6];
+        if ((uint64_t)c->n_signals * 4 + padded > b.size() - off) return fail(CW_EIO, "tape emitted program truncated");
+        jp.sig_slot.resize(c->n_signals);
+        memcpy(jp.sig_slot.data(), b.data() + off, (size_t)c->n_signals * 4);
+        off += (size_t)c->n_signals * 4;
+        jp.code.assign(b.data() + off, b.data() + off + code_bytes);
+        off += (size_t)padded;
+        if (const char *why = cwbits::validate_jit(jp, c->n_signals, c->n_inputs)) return fail(CW_EIO, std::string("tape: ") + why);
+        c->has_jit = true;
+    }
     // hash map as generate_hash_map builds it (c_code_generator.rs:575-587); replaced by the .dat's if given
     c->hashmap.assign(hsize, HashEntry{0, 0, 0});
     // insertion order must be the reference's (main input list order = slot order)
@@ -1007,7 +1034,13 @@ extern "C" int cw_load(const char *tape_path, const char *dat_path, const char *
     *out = c;
     return CW_OK;
 }
-extern "C" void cw_free(cw_circuit *c) { delete c; }
+extern "C" void cw_free(cw_circuit *c) {
+    if (!c) return;
+    for (auto &kv : c->jit_mod) {               // modules of the emitted bit-plane code, one per device that ran it
+        if (hipSetDevice(kv.first) == hipSuccess) hipModuleUnload(kv.second.first);
+    }
+    delete c;
+}
 extern "C" uint32_t cw_io_map_size(const cw_circuit *c) { return c ? (uint32_t)c->io_map.size() : 0; }
 extern "C" int64_t cw_io_map_offset(const cw_circuit *c, uint32_t template_id, uint32_t signal_code) {
     if (!c) return -1;
@@ -1132,6 +1165,13 @@ struct cw_batch {
     std::vector<uint32_t> fb_inst;                    // side-batch position -> instance
     std::vector<int32_t> fb_index;                    // instance -> side-batch position or -1
     bool resolved = false, checked = false;
+    // layout of the bit table (cw_bits.hip): slots per group / per chunk, shift (0 = interpreter, 5 = emitted code)
+    uint64_t bits_slots = 0;
+    uint32_t bits_sh = 0, n_groups_padded = 0;
+    const std::vector<uint32_t> *bits_sigslot = nullptr;
+    bool jit = false, table_dirty = false;             // emitted code runs this batch; the caller holds a raw pointer to the table
+    hipFunction_t jit_fn = nullptr;
+    uint64_t *d_r1flag = nullptr;                      // per group: instances whose fused R1CS check fired (emitted code)
 };
 
 template <typename T>
@@ -1152,7 +1192,7 @@ extern "C" void cw_batch_free(cw_batch *b) {
     hipSetDevice(b->device);
     hipStreamSynchronize(b->stream);
     if (b->fb) cw_batch_free(b->fb);
-    void *bptrs[] = {b->d_T, b->d_fbmask, b->d_brecs, b->d_bcmds, b->d_aslots, b->d_wslot, b->d_fbinst, b->d_erecs, b->d_wchunk, b->d_wterms, b->d_wctab, b->d_wrow,
+    void *bptrs[] = {b->d_T, b->d_fbmask, b->d_r1flag, b->d_brecs, b->d_bcmds, b->d_aslots, b->d_wslot, b->d_fbinst, b->d_erecs, b->d_wchunk, b->d_wterms, b->d_wctab, b->d_wrow,
                      b->d_ichunk, b->d_iterms, b->d_itab, b->d_irow, b->d_sigslot};
     for (void *p : bptrs)
         if (p) hipFree(p);
@@ -1817,12 +1857,41 @@ static int bits_batch_setup(cw_batch *b) {
     cw_circuit *c = b->c;
     const cwbits::Program &bp = c->bits;
     b->n_groups = (b->batch + 63) / 64;
-    b->t_bytes = (uint64_t)b->n_groups * bp.n_slots * 8;
+    // Which engine: the interpreter (cw_bits_eval_kernel) finishes a batch of 65 536 in about a millisecond and scales
+    // linearly beyond; the emitted code needs ~4 ms for its 1.5 M instructions whatever the batch (a wave = 2 048 instances)
+    // and is then bound by the table's bytes: it wins from a few hundred thousand instances.  CW_BITS_JIT = 0 / 1 overrides.
+    b->jit = c->has_jit && b->batch >= cwbits::JIT_MIN_BATCH;
+    if (const char *ev = getenv("CW_BITS_JIT")) b->jit = c->has_jit && atoi(ev) != 0;
+    if (b->jit) {
+        auto it = c->jit_mod.find(b->device);
+        if (it == c->jit_mod.end()) {
+            hipModule_t mod = nullptr;
+            hipFunction_t fn = nullptr;
+            hipError_t e1 = hipModuleLoadData(&mod, c->jit.code.data());
+            if (e1 == hipSuccess) e1 = hipModuleGetFunction(&fn, mod, cwbits::JIT_KERNEL);
+            if (e1 != hipSuccess)
+                return fail(CW_EDEVICE, std::string("loading the emitted bit-plane code failed: ") + hipGetErrorString(e1));
+            it = c->jit_mod.emplace(b->device, std::make_pair(mod, fn)).first;
+        }
+        b->jit_fn = it->second.second;
+        b->bits_slots = c->jit.n_slots;
+        b->bits_sh = 5;
+        b->bits_sigslot = &c->jit.sig_slot;
+        b->n_groups_padded = (b->n_groups + 31) / 32 * 32;
+    } else {
+        b->bits_slots = bp.n_slots;
+        b->bits_sh = 0;
+        b->bits_sigslot = &bp.sig_slot;
+        b->n_groups_padded = b->n_groups;
+    }
+    const std::vector<uint32_t> &sig_slot = *b->bits_sigslot;
+    b->t_bytes = (uint64_t)b->n_groups_padded * b->bits_slots * 8;
     hipError_t e = hipMalloc((void **)&b->d_T, b->t_bytes);
     if (e != hipSuccess)
         return fail(CW_EDEVICE, "hipMalloc of the bit table failed (" + std::to_string(b->t_bytes) + " bytes): " + hipGetErrorString(e));
-    BTRY(hipMalloc((void **)&b->d_fbmask, (size_t)b->n_groups * 8));
-    {
+    BTRY(hipMalloc((void **)&b->d_fbmask, (size_t)b->n_groups_padded * 8));
+    BTRY(hipMalloc((void **)&b->d_r1flag, (size_t)b->n_groups_padded * 8));
+    if (!b->jit) {
         std::vector<uint32_t> dev, cmds;
         b->bits_steps = cwbits::device_stream(bp, dev, cmds);
         BTRY(upload(&b->d_brecs, dev, b->stream));
@@ -1838,10 +1907,10 @@ static int bits_batch_setup(cw_batch *b) {
         if (w == 16 || w == 32 || w == 64) b->bits_width = (uint32_t)w;
     }
     BTRY(upload(&b->d_w2s, c->w2s, b->stream));
-    BTRY(upload(&b->d_sigslot, bp.sig_slot, b->stream));
+    BTRY(upload(&b->d_sigslot, sig_slot, b->stream));
     {
         std::vector<uint32_t> wslot(c->w2s.size());
-        for (size_t k = 0; k < wslot.size(); k++) wslot[k] = bp.sig_slot[c->w2s[k]];
+        for (size_t k = 0; k < wslot.size(); k++) wslot[k] = sig_slot[c->w2s[k]];
         BTRY(upload(&b->d_wslot, wslot, b->stream));
         BTRY(hipStreamSynchronize(b->stream));
     }
@@ -1850,7 +1919,7 @@ static int bits_batch_setup(cw_batch *b) {
     if (c->n_constraints) {
         uint32_t tpc = 1024;         // terms per chunk = per wave (measured on Sha256(2048) x 65 536: 256 -> 1.35 ms, 1024 -> 1.26, 4096 -> 1.32)
         if (const char *ev = getenv("CW_R1CS_TERMS")) tpc = (uint32_t)std::max(8, atoi(ev));
-        cwbits::R1Plan p = cwbits::build_r1cs(c->r_ptr, c->r_slot, c->r_cc, c->r_cctab, c->r_orig, bp.sig_slot, c->q.w, tpc);
+        cwbits::R1Plan p = cwbits::build_r1cs(c->r_ptr, c->r_slot, c->r_cc, c->r_cctab, c->r_orig, sig_slot, c->q.w, tpc);
         BTRY(upload(&b->d_erecs, p.erecs, b->stream));
         BTRY(upload(&b->d_wchunk, p.chunk, b->stream));
         BTRY(upload(&b->d_wterms, p.terms, b->stream));
@@ -1873,7 +1942,7 @@ static int bits_batch_setup(cw_batch *b) {
     }
     BTRY(hipMalloc(&b->d_in, std::max<size_t>((size_t)b->batch * c->n_inputs * 32, 32)));
     BTRY(hipMalloc(&b->d_gather, std::max<size_t>((size_t)c->n_witness * 32, 32)));
-    BTRY(cwk_bits_init(b->stream, b->d_T, bp.n_slots, b->n_groups, b->d_fbmask, b->d_status, b->d_first_bad, b->Bp));
+    BTRY(cwk_bits_init(b->stream, b->d_T, b->bits_slots, b->bits_sh, b->n_groups_padded, b->d_fbmask, b->d_r1flag, b->d_status, b->d_first_bad, b->Bp));
     BTRY(hipStreamSynchronize(b->stream));
     b->fb_index.assign(b->batch, -1);
     return CW_OK;
@@ -1882,13 +1951,23 @@ static int bits_batch_setup(cw_batch *b) {
 static int bits_run(cw_batch *b, const void *in) {
     cw_circuit *c = b->c;
     const cwbits::Program &bp = c->bits;
-    BTRY(cwk_bits_init(b->stream, b->d_T, bp.n_slots, b->n_groups, b->d_fbmask, b->d_status, b->d_first_bad, b->Bp));
+    BTRY(cwk_bits_init(b->stream, b->d_T, b->bits_slots, b->bits_sh, b->n_groups_padded, b->d_fbmask, b->d_r1flag, b->d_status, b->d_first_bad, b->Bp));
     if (b->packed_in)
-        BTRY(cwk_bits_ingest_packed(b->stream, b->packed_in, b->d_T, bp.n_slots, cwbits::IN_BASE, c->n_inputs, b->batch));
+        BTRY(cwk_bits_ingest_packed(b->stream, b->packed_in, b->d_T, b->bits_slots, b->bits_sh, cwbits::IN_BASE, c->n_inputs, b->batch));
     else
-        BTRY(cwk_bits_ingest(b->stream, in, b->d_T, bp.n_slots, cwbits::IN_BASE, c->n_inputs, b->batch, b->d_fbmask));
-    BTRY(cwk_bits_eval(b->stream, b->d_brecs, b->d_bcmds, b->bits_steps, bp.ring, bp.cache, b->d_T, bp.n_slots, b->n_groups, b->bits_width,
-                       b->d_aslots, (uint32_t)bp.assert_slots.size(), b->d_fbmask));
+        BTRY(cwk_bits_ingest(b->stream, in, b->d_T, b->bits_slots, b->bits_sh, cwbits::IN_BASE, c->n_inputs, b->batch, b->d_fbmask));
+    if (b->jit) {
+        // one wave per chunk of 2 048 instances runs the circuit's emitted code: gates on registers, every signal value stored
+        // once, assertion gates and the fused R1CS check OR-ed into the two flag arrays
+        struct { void *T, *fb, *r1; } args = {b->d_T, b->d_fbmask, b->d_r1flag};
+        size_t asz = sizeof(args);
+        void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+        BTRY(hipModuleLaunchKernel(b->jit_fn, b->n_groups_padded / 32, 1, 1, 64, 1, 1, 0, b->stream, nullptr, cfg));
+        b->table_dirty = false;
+    } else {
+        BTRY(cwk_bits_eval(b->stream, b->d_brecs, b->d_bcmds, b->bits_steps, bp.ring, bp.cache, b->d_T, bp.n_slots, b->n_groups, b->bits_width,
+                           b->d_aslots, (uint32_t)bp.assert_slots.size(), b->d_fbmask));
+    }
     b->resolved = false;
     b->checked = false;
     return CW_OK;
@@ -2005,9 +2084,13 @@ extern "C" int cw_check_r1cs(cw_batch *b) {
     if (c->n_constraints == 0) return fail(CW_ESTATE, "no .r1cs was loaded for this circuit");
     HIPCHK(hipSetDevice(b->device));
     if (b->bitmode) {
+        // emitted code checked every constraint on its registers while it generated the witness: only the groups it flagged
+        // are audited (to name the first violated row of each instance).  A caller that took the raw table pointer
+        // (cw_device_bits) may have changed it: then, and with CW_R1CS_AUDIT=1, every group is audited from the table.
+        const void *only = b->jit && c->jit.check_complete && !b->table_dirty && !getenv("CW_R1CS_AUDIT") ? b->d_r1flag : nullptr;
         HIPCHK(cwk_bits_r1cs(b->stream, b->d_erecs, b->n_evrows, b->d_wchunk, b->n_wchunks, b->d_wterms, b->d_wctab, b->d_wrow,
-                             b->d_ichunk, b->n_ichunks, b->d_iterms, b->d_itab, b->d_irow, b->d_T, c->bits.n_slots, b->n_groups,
-                             b->batch, b->d_status, b->d_first_bad, c->P));
+                             b->d_ichunk, b->n_ichunks, b->d_iterms, b->d_itab, b->d_irow, b->d_T, b->bits_slots, b->bits_sh, only,
+                             b->n_groups, b->batch, b->d_status, b->d_first_bad, c->P));
         b->checked = true;
         if (b->resolved && b->fb) return cw_check_r1cs(b->fb);       // the side batch was already computed: check it too
         return CW_OK;
@@ -2068,7 +2151,7 @@ extern "C" int cw_get_witness(cw_batch *b, uint32_t instance, uint8_t *out) {
     if (b->bitmode) {
         if (int rc = bits_resolve(b)) return rc;
         if (b->fb_index[instance] >= 0) return cw_get_witness(b->fb, (uint32_t)b->fb_index[instance], out);
-        HIPCHK(cwk_bits_gather(b->stream, b->d_T, c->bits.n_slots, b->d_wslot, c->n_witness, instance, 1, b->d_gather));
+        HIPCHK(cwk_bits_gather(b->stream, b->d_T, b->bits_slots, b->bits_sh, b->d_wslot, c->n_witness, instance, 1, b->d_gather));
     } else
     HIPCHK(cwk_gather(b->stream, b->d_V, b->d_w2s, c->n_witness, b->Bp, instance, b->d_gather, c->mont, c->P));
     HIPCHK(hipMemcpyAsync(out, b->d_gather, (size_t)c->n_witness * 32, hipMemcpyDeviceToHost, b->stream));
@@ -2099,7 +2182,7 @@ extern "C" int cw_get_witnesses(cw_batch *b, uint32_t first, uint32_t count, uin
     for (uint32_t done = 0; done < count; done += per) {
         const uint32_t n = std::min(per, count - done);
         if (b->bitmode)
-            HIPCHK(cwk_bits_gather(b->stream, b->d_T, c->bits.n_slots, b->d_wslot, c->n_witness, first + done, n, b->d_bulk));
+            HIPCHK(cwk_bits_gather(b->stream, b->d_T, b->bits_slots, b->bits_sh, b->d_wslot, c->n_witness, first + done, n, b->d_bulk));
         else
             HIPCHK(cwk_gather_many(b->stream, b->d_V, b->d_w2s, c->n_witness, b->Bp, first + done, n, b->d_bulk, c->mont, c->P));
         HIPCHK(hipMemcpyAsync(out + (size_t)done * row, b->d_bulk, (size_t)n * row, hipMemcpyDeviceToHost, b->stream));
@@ -2129,7 +2212,7 @@ extern "C" int cw_get_witnesses_device(cw_batch *b, uint32_t first, uint32_t cou
     // the evaluation: the first egress of a run waits for it (one stream synchronisation + an 8-byte-per-group copy),
     // then everything below is asynchronous on the batch's stream
     if (int rc = bits_resolve(b)) return rc;
-    HIPCHK(cwk_bits_gather(b->stream, b->d_T, c->bits.n_slots, b->d_wslot, c->n_witness, first, count, d_out));
+    HIPCHK(cwk_bits_gather(b->stream, b->d_T, b->bits_slots, b->bits_sh, b->d_wslot, c->n_witness, first, count, d_out));
     if (b->resolved)
         for (size_t k = 0; k < b->fb_inst.size(); k++)
             if (b->fb_inst[k] >= first && b->fb_inst[k] < first + count) {
@@ -2175,7 +2258,7 @@ extern "C" int cw_get_public_device(cw_batch *b, void *d_out) {
     HIPCHK(hipSetDevice(b->device));
     if (b->bitmode) {
         if (int rc = bits_resolve(b)) return rc;
-        HIPCHK(cwk_bits_gather(b->stream, b->d_T, c->bits.n_slots, b->d_wslot + 1, np, 0, b->batch, d_out));
+        HIPCHK(cwk_bits_gather(b->stream, b->d_T, b->bits_slots, b->bits_sh, b->d_wslot + 1, np, 0, b->batch, d_out));
         if (!b->fb_inst.empty()) {
             void *tmp = nullptr;
             const size_t prow = (size_t)np * 32;
@@ -2221,7 +2304,9 @@ extern "C" int cw_get_signal(cw_batch *b, uint32_t instance, uint32_t slot, uint
         if (int rc = bits_resolve(b)) return rc;
         if (b->fb_index[instance] >= 0) return cw_get_signal(b->fb, (uint32_t)b->fb_index[instance], slot, out);
         uint64_t m = 0;
-        HIPCHK(hipMemcpyAsync(&m, b->d_T + (size_t)(instance >> 6) * b->c->bits.n_slots + b->c->bits.sig_slot[slot], 8, hipMemcpyDeviceToHost, b->stream));
+        const uint32_t g = instance >> 6, sh = b->bits_sh;
+        const size_t at = ((((size_t)(g >> sh) * b->bits_slots) + (*b->bits_sigslot)[slot]) << sh) + (g & ((1u << sh) - 1u));
+        HIPCHK(hipMemcpyAsync(&m, b->d_T + at, 8, hipMemcpyDeviceToHost, b->stream));
         HIPCHK(hipStreamSynchronize(b->stream));
         memset(out, 0, 32);
         out[0] = (uint8_t)((m >> (instance & 63)) & 1);
@@ -2438,9 +2523,21 @@ extern "C" const uint32_t *cw_signal_slots(const cw_circuit *c) { return c && c-
 extern "C" void *cw_device_bits(cw_batch *b, uint64_t *n_bytes, uint64_t *slots_per_group) {
     if (!b || !b->bitmode) return nullptr;
     if (n_bytes) *n_bytes = b->t_bytes;
-    if (slots_per_group) *slots_per_group = b->c->bits.n_slots;
+    if (slots_per_group) *slots_per_group = b->bits_slots;
+    b->table_dirty = true;                  // the caller may write through the pointer: the next R1CS check audits the table itself
     return b->d_T;
 }
+extern "C" int cw_batch_bits_layout(const cw_batch *b, uint64_t out[4]) {
+    if (!b || !out) return fail(CW_EINVAL, "null argument");
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (!b->bitmode) return CW_OK;
+    out[0] = b->bits_slots;
+    out[1] = b->bits_sh;
+    out[2] = b->n_groups_padded;
+    out[3] = b->jit ? 1 : 0;
+    return CW_OK;
+}
+extern "C" const uint32_t *cw_batch_signal_slots(const cw_batch *b) { return b && b->bitmode && b->bits_sigslot ? b->bits_sigslot->data() : nullptr; }
 
 // ---------------------------------------------------------------------------------------------------------
 // field micro-benchmark and unit-test hook

@@ -34,20 +34,23 @@ hipError_t cwk_fpop(hipStream_t s, uint32_t op, const void *a, const void *b, co
                     uint32_t n, const FpParams &P);
 
 // ---- bit-plane path (cw_bits.hip) ----
-hipError_t cwk_bits_init(hipStream_t s, void *T, uint64_t slots, uint32_t n_groups, void *fbmask, uint32_t *status,
-                         uint32_t *first_bad, uint32_t Bp);
-hipError_t cwk_bits_ingest(hipStream_t s, const void *in, void *T, uint64_t slots, uint32_t input_slot0, uint32_t n_in,
+// `sh` = layout shift of the bit table (cw_bits.hip: 0 = T[group][slot] of the interpreter, 5 = T[chunk][slot][group in chunk]
+// of the emitted code); `only` (R1CS audit): groups whose flag word is zero are skipped (nullptr = audit every group)
+hipError_t cwk_bits_init(hipStream_t s, void *T, uint64_t slots, uint32_t sh, uint32_t n_groups, void *fbmask, void *r1flag,
+                         uint32_t *status, uint32_t *first_bad, uint32_t Bp);
+hipError_t cwk_bits_ingest(hipStream_t s, const void *in, void *T, uint64_t slots, uint32_t sh, uint32_t input_slot0, uint32_t n_in,
                            uint32_t batch, void *fbmask);
 hipError_t cwk_bits_eval(hipStream_t s, const void *recs, const uint32_t *cmds, uint32_t n_batches, uint32_t ring, uint32_t cache,
                          void *T, uint64_t slots, uint32_t n_groups, uint32_t width, const uint32_t *aslots, uint32_t n_asserts,
                          void *fbmask);
-hipError_t cwk_bits_gather(hipStream_t s, const void *T, uint64_t slots, const uint32_t *wslot, uint32_t n_wit, uint32_t first,
+hipError_t cwk_bits_gather(hipStream_t s, const void *T, uint64_t slots, uint32_t sh, const uint32_t *wslot, uint32_t n_wit, uint32_t first,
                            uint32_t count, void *out);
-hipError_t cwk_bits_ingest_packed(hipStream_t s, const void *masks, void *T, uint64_t slots, uint32_t input_slot0, uint32_t n_in,
+hipError_t cwk_bits_ingest_packed(hipStream_t s, const void *masks, void *T, uint64_t slots, uint32_t sh, uint32_t input_slot0, uint32_t n_in,
                                   uint32_t batch);
 hipError_t cwk_bits_collect_inputs(hipStream_t s, const void *masks, const void *aos, const uint32_t *inst, uint32_t n_inst,
                                    uint32_t n_in, void *out);
 hipError_t cwk_bits_r1cs(hipStream_t s, const void *erecs, uint32_t n_evrows, const uint32_t *chunk, uint32_t n_chunks,
                          const uint32_t *terms, const uint32_t *ctab, const uint32_t *row_orig, const uint32_t *ichunk,
                          uint32_t n_ichunks, const uint32_t *iterms, const uint32_t *itab, const uint32_t *irow_orig, const void *T,
-                         uint64_t slots, uint32_t n_groups, uint32_t batch, uint32_t *status, uint32_t *first_bad, const FpParams &P);
+                         uint64_t slots, uint32_t sh, const void *only, uint32_t n_groups, uint32_t batch, uint32_t *status, uint32_t *first_bad,
+                         const FpParams &P);

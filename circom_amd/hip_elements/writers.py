@@ -93,10 +93,10 @@ def dat_io_map(io_map) -> bytes:
 
 
 TAPE_MAGIC = b"CWTP"
-TAPE_VERSION = 10
+TAPE_VERSION = 11
 
 
-def write_tape(path, tapes, bittape=None):
+def write_tape(path, tapes, bittape=None, jit=None):
     """`.cwt` layout (little endian).  `tapes` = one Tape or a list of Tapes of the SAME circuit lowered with
     different strand counts (the runtime picks the variant that fills the chip for the batch at hand).
          0  "CWTP" | u32 version | u32 n64 | u32 n_variants
@@ -123,6 +123,9 @@ def write_tape(path, tapes, bittape=None):
                             words), shape = NB | NLD << 8, n_lds = 2*NB + 2*NLD
             bit program     (if n_bit_programs, hip_elements/bitsched.py)  8 x u32: ring, n_vrows, n_slots lo, hi, cache, n_asserts, 2, 0;
                             records n_vrows*64 x 2 u32; command blocks n_vrows/8 x 24 u32; signal -> slot; assertion slots
+            emitted code    (if n_bit_programs == 2, hip_elements/bitjit.py)  8 x u32: 1, n_slots lo, hi, code bytes, flags (bit 0:
+                            the fused R1CS check covers every constraint), VGPRs, AccVGPRs, 0; signal -> slot; the gfx950 code
+                            object (ELF), padded to 4 bytes
     """
     if isinstance(tapes, Tape):
         tapes = [tapes]
@@ -138,7 +141,7 @@ def write_tape(path, tapes, bittape=None):
         f.write(struct.pack("<16I", t0.n_signals, t0.n_witness, len(t0.consts), t0.main_input_start, t0.n_main_inputs,
                             len(t0.inputs), hashmap_size(len(t0.inputs)), t0.rbits | (0x10000 if getattr(t0, "mont", False) else 0),
                             len(t0.lconsts), t0.n_pub_in,
-                            1 if bittape is not None else 0, len(t0.functions),
+                            (2 if jit is not None else 1) if bittape is not None else 0, len(t0.functions),
                             getattr(t0, "n_dat_consts", 0xFFFFFFFF), getattr(t0, "n_io_templates", 0),
                             len(getattr(t0, "log_prog", ())), sum(1 for _, items in getattr(t0, "log_prog", ()) for it in items if it[0] == "v")))
         f.write(b"".join(c.to_bytes(8 * n64, "little") for c in t0.consts))
@@ -179,6 +182,12 @@ def write_tape(path, tapes, bittape=None):
             f.write(np.ascontiguousarray(bittape.cmds, dtype="<u4").tobytes())
             f.write(np.ascontiguousarray(bittape.sig_slot, dtype="<u4").tobytes())
             f.write(np.ascontiguousarray(bittape.assert_slots, dtype="<u4").tobytes())
+        if jit is not None:
+            assert bittape is not None and jit.code is not None and jit.n_signals == t0.n_signals
+            f.write(struct.pack("<8I", 1, jit.n_slots & 0xFFFFFFFF, jit.n_slots >> 32, len(jit.code), 1 if jit.check_complete else 0,
+                                jit.n_vgpr, jit.n_agpr, 0))
+            f.write(np.ascontiguousarray(jit.sig_slot, dtype="<u4").tobytes())
+            f.write(jit.code + b"\0" * (-len(jit.code) % 4))
 
 
 def _le_key(k: int) -> bytes:

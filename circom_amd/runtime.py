@@ -77,6 +77,8 @@ _SIGS = {
     "cw_set_inputs_bits_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cw_stream_witnesses_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cw_signal_slots": (C.POINTER(C.c_uint32), [C.c_void_p]),
+    "cw_batch_signal_slots": (C.POINTER(C.c_uint32), [C.c_void_p]),
+    "cw_batch_bits_layout": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cw_get_staged_input": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p]),
     "cw_remaining_inputs": (C.c_int64, [C.c_void_p, C.c_uint32]),
     "cw_run": (C.c_int, [C.c_void_p]),
@@ -201,6 +203,19 @@ class Batch:
         self.pipelined = (pp & 0xFF, pp >> 8) if pp else None     # (rows per batch, loads per batch) of the pipelined variant
         self.lanes = lib().cw_batch_lanes(h)
         self.bitmode = bool(lib().cw_batch_bitmode(h))
+        lay = (C.c_uint64 * 4)()
+        _chk(lib().cw_batch_bits_layout(h, lay))
+        # bit table of this batch: element (group g, slot s) = T[(((g >> sh) * slots + s) << sh) + (g & ((1 << sh) - 1))]
+        self.bits_slots, self.bits_sh, self.bits_groups, self.jit = int(lay[0]), int(lay[1]), int(lay[2]), bool(lay[3])
+
+    def bits_index(self, group: int, slot: int) -> int:
+        """uint64 index of (group, slot) in the table behind cw_device_bits"""
+        sh = self.bits_sh
+        return (((group >> sh) * self.bits_slots + slot) << sh) + (group & ((1 << sh) - 1))
+
+    def signal_slots(self) -> np.ndarray:
+        p = lib().cw_batch_signal_slots(self.h)
+        return np.ctypeslib.as_array(p, shape=(self.circuit.n_signals,)).copy() if p else None
 
     def close(self):
         if self.h:

@@ -188,6 +188,17 @@ int cw_circuit_montgomery(const cw_circuit *c);
 void *cw_device_bits(cw_batch *b, uint64_t *n_bytes, uint64_t *slots_per_group);
 /* signal -> bit-table slot, n_signals entries (host memory owned by the circuit), NULL when there is no bit program */
 const uint32_t *cw_signal_slots(const cw_circuit *c);
+/* A circuit may carry its bit-plane program twice: interpreted (cw_bits_eval_kernel, T[group][slot]) and as EMITTED gfx950
+ * code (hip_elements/bitjit.py: the counterpart of the reference's per-circuit <name>.cpp, compiler/src/circuit_design/
+ * template.rs:174-474), which batches of >= 2^18 instances run (CW_BITS_JIT=0/1 overrides).  The emitted code has its
+ * own table layout and slot map, so a caller of cw_device_bits asks the BATCH:
+ *   out = {slots per group (sh = 0) or rows per chunk (sh = 5), sh, groups allocated, 1 if the emitted code runs}
+ *   element (group g, slot s) = T[(((g >> sh) * slots + s) << sh) + (g & ((1 << sh) - 1))]   (uint64, bit i = instance 64 g + i)
+ * cw_batch_signal_slots: signal -> slot for THIS batch (cw_signal_slots names the interpreter's map).
+ * Taking the raw pointer (cw_device_bits) makes the next cw_check_r1cs audit every group from the table instead of
+ * trusting the check the emitted code fused into the evaluation. */
+int cw_batch_bits_layout(const cw_batch *b, uint64_t out[4]);
+const uint32_t *cw_batch_signal_slots(const cw_batch *b);
 
 /* ---- field micro-benchmark + unit-test hooks (Fr_* seam 2: bn128/fr.hpp:28-81) --------------------- */
 /* n lanes x iters dependent Montgomery multiplications on the device; out[i] = a[i]*b[i]^iters (raw

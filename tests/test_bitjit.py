@@ -1,0 +1,193 @@
+"""Emitted gate code (hip_elements/bitjit.py): the bit-plane program as straight-line gfx950 code, one `v_bitop3_b32` per
+gate, with the R1CS check fused in.  CPU: the IR is executed by oracle/jit_eval.py (poisoned registers, in-order memory
+queue) and must reproduce the flat witness code for every signal under generous AND starved register files; the fused check
+must flag exactly the instances whose witness violates a constraint; the assembler accepts the text and the C-ABI loader
+the section.  The GPU side of the same engine runs through tests/test_bitplane.py (every GPU test there is parametrised over
+both engines) and tests/test_baseline_configs.py."""
+import os
+import random
+import shutil
+
+import numpy as np
+import pytest
+
+from circom_amd.compiler import compile_program
+from circom_amd.frontend.dsl import Program, template
+from circom_amd.frontend.flatten import flatten
+from circom_amd.circuits.sha256 import Sha256
+from circom_amd.hip_elements import bitblast as BB, bitjit as BJ
+from oracle.jit_eval import run_ir, JitHazard
+from oracle.tape_eval import eval_flat, check_r1cs
+
+from test_bitplane import BitGadget, BitAssert, BadBit, BadWeighted, BadWords
+
+
+def _rows(fc, n, seed):
+    r = random.Random(seed)
+    return [[r.randrange(2) for _ in range(fc.n_main_inputs)] for _ in range(n)]
+
+
+def _run(jp, fc, rows):
+    W = len(rows)
+    mem = {0: 0, 1: (1 << W) - 1}
+    for k in range(fc.n_main_inputs):
+        mem[BJ.IN_BASE + k] = sum((rows[i][k] & 1) << i for i in range(W))
+    return run_ir(jp, mem, W)
+
+
+def _flat(fc, row):
+    return eval_flat(fc.fp.q, fc.n_signals, fc.n_temps, fc.constants, fc.code, {fc.main_input_start + k: v for k, v in enumerate(row)})
+
+
+def _check_witnesses(jp, fc, rows, mem):
+    for i, row in enumerate(rows):
+        sig, failed = _flat(fc, row)
+        assert failed is None
+        got = [(mem[int(jp.sig_slot[s])] >> i) & 1 for s in range(fc.n_signals)]
+        assert got == sig, i
+
+
+@pytest.mark.parametrize("nv,na,pf", [(256, 256, 384), (24, 8, 16), (12, 0, 4), (16, 4, 0)])
+def test_emitted_program_reproduces_the_flat_code(nv, na, pf):
+    """generous registers, and register files so small that every level of the hierarchy is exercised: AccVGPR spills,
+    scratch rows, late loads, prefetches that are evicted again"""
+    fc = flatten(Program(BitGadget(16)))
+    net = BB.bitblast(fc)
+    jp = BJ.lower_jit(net, fc, n_vgpr=nv, n_agpr=na, prefetch=pf)
+    assert jp.check_complete
+    rows = _rows(fc, 40, 3)
+    mem, fb, bad = _run(jp, fc, rows)
+    assert fb == 0 and bad == 0
+    _check_witnesses(jp, fc, rows, mem)
+    if nv < 32:
+        assert jp.stats["scratch_stores"] + jp.stats["agpr_writes"] + jp.stats["late_loads"] > 0
+    assert jp.n_slots * BJ.ROW_BYTES < 1 << 32 and jp.n_slots % 16 == 0
+
+
+def test_sha256_block_through_the_emitted_program():
+    import hashlib
+    fc = flatten(Program(Sha256(64)))
+    net = BB.bitblast(fc)
+    jp = BJ.lower_jit(net, fc)
+    assert jp.check_complete and jp.stats["check_unchecked"] == 0 and jp.stats["check_int"] > 0 and jp.stats["check_lut"] > 0
+    # a register file of 253 + 256 keeps the whole block away from scratch rows
+    assert jp.stats["scratch_stores"] == 0 and jp.stats["late_loads"] < jp.stats["gates"] // 1000
+    rng = random.Random(1)
+    msgs = [bytes(rng.randrange(256) for _ in range(8)) for _ in range(33)]
+    rows = [[(m[k // 8] >> (7 - k % 8)) & 1 for k in range(64)] for m in msgs]
+    mem, fb, bad = _run(jp, fc, rows)
+    assert fb == 0 and bad == 0
+    for i, m in enumerate(msgs):
+        dg = hashlib.sha256(m).digest()
+        assert [(mem[int(jp.sig_slot[1 + k])] >> i) & 1 for k in range(256)] == [(dg[k // 8] >> (7 - k % 8)) & 1 for k in range(256)]
+    sig, _ = _flat(fc, rows[7])
+    assert [(mem[int(jp.sig_slot[s])] >> 7) & 1 for s in range(fc.n_signals)] == sig
+
+
+@pytest.mark.parametrize("prog", [Program(BadBit(12)), Program(BadWeighted(12, False)), Program(BadWords(13, False)),
+                                  Program(BadWords(31, True)), Program(BadWords(0, False))])
+def test_fused_check_flags_exactly_the_violating_instances(prog):
+    """circuits whose witness code disagrees with a constraint for some inputs: the gates the emitter adds for the constraints
+    (LUT class / integer class) must fire for those instances and for no other"""
+    fc = flatten(prog)
+    net = BB.bitblast(fc)
+    for nv, na, pf in ((256, 256, 384), (20, 6, 8)):
+        jp = BJ.lower_jit(net, fc, n_vgpr=nv, n_agpr=na, prefetch=pf)
+        assert jp.check_complete
+        rows = _rows(fc, 64, 11)
+        for i in range(0, 64, 3):
+            rows[i] = [0] * fc.n_main_inputs           # (BadBit is violated by every instance with a 1 among its inputs)
+        mem, fb, bad = _run(jp, fc, rows)
+        n_bad = 0
+        for i, row in enumerate(rows):
+            sig, _ = _flat(fc, row)
+            want = check_r1cs(fc.fp.q, fc.constraints, sig) is not None
+            assert bool((bad >> i) & 1) == want, i
+            n_bad += want
+        assert 0 < n_bad < 64
+
+
+@template
+def WideRow(c, n):
+    """a long linear row with field-sized weights over 2 n distinct wires (no exact integer comparison possible)"""
+    a = c.input("a", n)
+    b = c.input("b", n)
+    out = c.output("out", n)
+    lhs = c.const(0)
+    rhs = c.const(0)
+    for k in range(n):
+        c.hint(out[k], a[k] + b[k] - 2 * a[k] * b[k])
+        w = (1 << 200) * 3 ** k
+        lhs = lhs + out[k] * w
+        rhs = rhs + a[k] * w
+    c.enforce(lhs, rhs, runtime_check=False)
+
+
+def test_field_sized_rows_are_left_to_the_audit_kernels():
+    fc = flatten(Program(WideRow(8)))
+    jp = BJ.lower_jit(BB.bitblast(fc), fc)
+    assert not jp.check_complete and jp.stats["check_unchecked"] == 1
+    # ... while the same weights over few wires are a truth table like any other
+    fc = flatten(Program(BadWeighted(12, True)))
+    jp = BJ.lower_jit(BB.bitblast(fc), fc)
+    assert jp.check_complete and jp.stats["check_lut"] >= 1
+
+
+def test_assertion_gates_reach_the_fallback_mask():
+    fc = flatten(Program(BitAssert()))
+    net = BB.bitblast(fc)
+    assert net.asserts
+    jp = BJ.lower_jit(net, fc)
+    rows = [[i & 1, (i >> 1) & 1] for i in range(16)]
+    mem, fb, bad = _run(jp, fc, rows)
+    assert [(fb >> i) & 1 for i in range(16)] == [int(a != b) for a, b in rows]
+
+
+def test_replay_rejects_broken_programs():
+    """the executor's rules are enforced: a missing wait, a clobbered register, a row written twice"""
+    fc = flatten(Program(BitGadget(8)))
+    net = BB.bitblast(fc)
+    jp = BJ.lower_jit(net, fc, n_vgpr=16, n_agpr=4, prefetch=8)
+    rows = _rows(fc, 8, 5)
+    _run(jp, fc, rows)
+    good = list(jp.ir)
+    jp.ir = [ins for ins in good if ins[0] != "w"]            # no waits at all: the first use of a loaded value is a race
+    with pytest.raises(JitHazard):
+        _run(jp, fc, rows)
+    k = next(i for i, ins in enumerate(good) if ins[0] == "st")
+    jp.ir = good[:k + 1] + [good[k]] + good[k + 1:]
+    with pytest.raises(JitHazard):
+        _run(jp, fc, rows)
+    k = next(i for i, ins in enumerate(good) if ins[0] == "ld")
+    jp.ir = good[:k + 1] + [("g", good[k][1], -1, -1, -1, 0)] + good[k + 1:]
+    with pytest.raises(JitHazard):
+        _run(jp, fc, rows)
+
+
+def test_assembly_and_tape_section(tmp_path):
+    """the text assembles with the ROCm LLVM tools into a code object that names the kernel; the .cwt carries it and the
+    C-ABI loader accepts it (and refuses a damaged section)"""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang"):
+        pytest.skip("no ROCm assembler here")
+    from circom_amd import runtime as rt
+    cp = compile_program(Program(BitGadget(8)), str(tmp_path), "bg8j", sym=False, strands=(1,), bits=True, jit=True)
+    assert cp.jit is not None and cp.jit.code[:4] == b"\x7fELF" and BJ.KERNEL_NAME.encode() in cp.jit.code
+    asm = BJ.to_asm(cp.jit)
+    assert asm.count("v_bitop3_b32") == cp.jit.stats["gates"] and "s_endpgm" in asm
+    c = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
+    assert c.bits_info()
+    c.close()
+    raw = bytearray(open(cp.tape_path, "rb").read())
+    at = raw.rfind(b"\x7fELF")
+    bad = tmp_path / "bad.cwt"
+    for mutate in (lambda b: b.__setitem__(slice(at, at + 4), b"\x7fELG"),          # not a code object
+                   lambda b: b.__delitem__(slice(len(b) - 64, len(b)))):            # truncated
+        b2 = bytearray(raw)
+        mutate(b2)
+        bad.write_bytes(bytes(b2))
+        with pytest.raises(rt.CwError):
+            rt.Circuit(str(bad), cp.dat_path, cp.r1cs_path)
+    # a circuit compiled without the emitter still loads (one bit program)
+    cp2 = compile_program(Program(BitGadget(8)), str(tmp_path), "bg8i", sym=False, strands=(1,), bits=True, jit=False)
+    assert cp2.jit is None
+    rt.Circuit(cp2.tape_path, cp2.dat_path, cp2.r1cs_path).close()

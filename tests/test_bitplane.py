@@ -392,21 +392,29 @@ def test_loader_validates_the_bit_program(tmp_path):
 
 
 # ---- GPU ---------------------------------------------------------------------------------------------------------------
+@pytest.fixture(params=["interp", "jit"])
+def engine(request, monkeypatch):
+    """every GPU test of this file runs on both engines of the bit-plane path: the interpreter (cw_bits_eval_kernel) and the
+    circuit's emitted gfx950 code (hip_elements/bitjit.py; CW_BITS_JIT=1 selects it below its batch threshold)"""
+    monkeypatch.setenv("CW_BITS_JIT", "1" if request.param == "jit" else "0")
+    return request.param
+
+
 def _gpu(tmp_path, prog, name, **kw):
     from circom_amd import runtime as rt
-    cp = compile_program(prog, str(tmp_path), name, sym=False, strands=(1,), bits=True, **kw)
-    assert cp.bittape is not None
+    cp = compile_program(prog, str(tmp_path), name, sym=False, strands=(1,), bits=True, jit=True, **kw)
+    assert cp.bittape is not None and cp.jit is not None
     return cp, rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
 
 
 @pytest.mark.gpu
-def test_gpu_bitplane_matches_oracle_on_every_instance(tmp_path):
+def test_gpu_bitplane_matches_oracle_on_every_instance(tmp_path, engine):
     cp, c = _gpu(tmp_path, Program(BitGadget(16)), "bg16")
     fc = cp.flat
     B = 300                                                    # ragged last group
     rows = _rand_bits(fc, B, 7)
     b = c.batch(B)
-    assert b.bitmode
+    assert b.bitmode and b.jit == (engine == "jit")
     b.set_inputs(rows)
     b.run(); b.check_r1cs(); b.sync()
     assert (b.status() == 0).all()
@@ -424,7 +432,7 @@ def test_gpu_bitplane_matches_oracle_on_every_instance(tmp_path):
 
 
 @pytest.mark.gpu
-def test_gpu_non_boolean_inputs_are_rerun_by_the_wide_schedule(tmp_path):
+def test_gpu_non_boolean_inputs_are_rerun_by_the_wide_schedule(tmp_path, engine):
     cp, c = _gpu(tmp_path, Program(BitGadget(8)), "bg8")
     fc = cp.flat
     q = c.q
@@ -459,7 +467,7 @@ def test_gpu_non_boolean_inputs_are_rerun_by_the_wide_schedule(tmp_path):
 
 
 @pytest.mark.gpu
-def test_gpu_assertion_gate_flags_and_reruns(tmp_path):
+def test_gpu_assertion_gate_flags_and_reruns(tmp_path, engine):
     cp, c = _gpu(tmp_path, Program(BitAssert()), "bassert")
     rows = [[i & 1, (i >> 1) & 1] for i in range(200)]
     b = c.batch(200)
@@ -472,7 +480,7 @@ def test_gpu_assertion_gate_flags_and_reruns(tmp_path):
 
 
 @pytest.mark.gpu
-def test_gpu_bitplane_r1cs_check_reports_first_bad_row(tmp_path):
+def test_gpu_bitplane_r1cs_check_reports_first_bad_row(tmp_path, engine):
     cp, c = _gpu(tmp_path, Program(BadBit(12)), "badbit")
     fc = cp.flat
     B = 200
@@ -492,7 +500,7 @@ def test_gpu_bitplane_r1cs_check_reports_first_bad_row(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("big", [False, True])
-def test_gpu_bitplane_r1cs_long_rows(tmp_path, big):
+def test_gpu_bitplane_r1cs_long_rows(tmp_path, engine, big):
     cp, c = _gpu(tmp_path, Program(BadWeighted(12, big)), "badw%d" % big)
     fc = cp.flat
     B = 200
@@ -517,13 +525,13 @@ def test_gpu_bitplane_r1cs_long_rows(tmp_path, big):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("flip,second_only", [(0, False), (13, True), (31, False), (31, True)])
-def test_gpu_bitplane_r1cs_whole_words(tmp_path, flip, second_only):
+def test_gpu_bitplane_r1cs_whole_words(tmp_path, engine, flip, second_only):
     cp, c = _gpu(tmp_path, Program(BadWords(flip, second_only)), "badwords%d" % flip)
     fc = cp.flat
     B = 200
     rows = _rand_bits(fc, B, 40 + flip)
     b = c.batch(B)
-    assert b.bitmode
+    assert b.bitmode and b.jit == (engine == "jit")
     b.set_inputs(rows)
     b.run(); b.check_r1cs(); b.sync()
     st, fb = b.status(), b.r1cs_first_bad()
@@ -542,7 +550,7 @@ def test_gpu_bitplane_r1cs_whole_words(tmp_path, flip, second_only):
 
 
 @pytest.mark.gpu
-def test_gpu_sha256_two_blocks_bitplane(tmp_path):
+def test_gpu_sha256_two_blocks_bitplane(tmp_path, engine):
     cp, c = _gpu(tmp_path, Program(Sha256(512)), "sha256_512")
     fc = cp.flat
     B = 200
@@ -551,7 +559,7 @@ def test_gpu_sha256_two_blocks_bitplane(tmp_path):
     arr = np.zeros((B, 512, 32), dtype=np.uint8)
     arr[:, :, 0] = bits
     b = c.batch(B)
-    assert b.bitmode
+    assert b.bitmode and b.jit == (engine == "jit")
     b.set_inputs(arr)
     b.run(); b.check_r1cs(); b.sync()
     assert (b.status() == 0).all()
@@ -594,7 +602,7 @@ class _Hip:
 
 
 @pytest.mark.gpu
-def test_gpu_packed_inputs_and_chunked_egress(tmp_path):
+def test_gpu_packed_inputs_and_chunked_egress(tmp_path, engine):
     """cw_set_inputs_bits(_device): one bit per input and instance in, the same witnesses out; cw_stream_witnesses_device:
     the chunks, concatenated, are the image cw_get_witnesses returns (odd first/count/chunk: windows straddle groups)."""
     cp, c = _gpu(tmp_path, Program(BitGadget(16)), "bg16p")
