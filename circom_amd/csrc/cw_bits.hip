@@ -480,9 +480,12 @@ cw_bits_collect_inputs_kernel(const uint64_t *__restrict__ masks, const uint4 *_
 struct ERec { uint32_t w[5]; uint32_t tt, row, pad; };
 __global__ void __launch_bounds__(64)
 cw_bits_r1cs_lut_kernel(const uint4 *__restrict__ recs, uint32_t n_vrows, uint32_t vrows_per_chunk, const uint64_t *__restrict__ T,
-                        uint64_t slots, uint32_t sh, const uint64_t *__restrict__ only, uint32_t batch, uint32_t *status, uint32_t *first_bad) {
-    const uint32_t lane = threadIdx.x, g = blockIdx.x;
-    if (only && only[g] == 0) return;           // audit of flagged groups only (the emitted code checked every constraint itself)
+                        uint64_t slots, uint32_t sh, const uint64_t *__restrict__ only, uint32_t n_groups, uint32_t batch, uint32_t *status,
+                        uint32_t *first_bad) {
+    const uint32_t lane = threadIdx.x;
+    // audit of flagged groups only (the emitted code checked every constraint itself): a few workgroups walk the flag words
+    for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    if (only && only[g] == 0) continue;
     const char *Tg = (const char *)bits_group(T, slots, sh, g);
     const uint32_t v0 = blockIdx.y * vrows_per_chunk, v1 = min(n_vrows, v0 + vrows_per_chunk);
     for (uint32_t v = v0; v < v1; v++) {
@@ -507,6 +510,7 @@ cw_bits_r1cs_lut_kernel(const uint4 *__restrict__ recs, uint32_t n_vrows, uint32
             }
         }
     }
+    }
 }
 
 // Class W: any other constraint (long linear rows of BinSum / Bits2Num shape, field-sized coefficients).  One lane =
@@ -517,10 +521,11 @@ __global__ void __launch_bounds__(64)
 cw_bits_r1cs_wide_kernel(const uint4 *__restrict__ chunk, uint32_t n_chunks, const uint2 *__restrict__ terms,
                          const uint32_t *__restrict__ ctab, const uint32_t *__restrict__ row_orig,
                          const uint64_t *__restrict__ T, uint64_t slots, uint32_t sh, const uint64_t *__restrict__ only,
-                         uint32_t batch, uint32_t *status, uint32_t *first_bad, FpParams P) {
-    const uint32_t lane = threadIdx.x, g = blockIdx.x;
+                         uint32_t n_groups, uint32_t batch, uint32_t *status, uint32_t *first_bad, FpParams P) {
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
     const uint32_t i = g * 64 + lane;
-    if (only && only[g] == 0) return;
+    if (only && only[g] == 0) continue;
     const char *Tg = (const char *)bits_group(T, slots, sh, g);
     uint32_t bad = 0xFFFFFFFFu;
     for (uint32_t cix = blockIdx.y; cix < n_chunks; cix += gridDim.y) {
@@ -559,6 +564,7 @@ cw_bits_r1cs_wide_kernel(const uint4 *__restrict__ chunk, uint32_t n_chunks, con
     if (bad != 0xFFFFFFFFu && i < batch) {
         atomicMin(&first_bad[i], bad);
         atomicOr(&status[i], CW_ST_R1CS_FAILED);
+    }
     }
 }
 
@@ -620,12 +626,13 @@ __global__ void __launch_bounds__(64)
 cw_bits_r1cs_int_kernel(const uint4 *__restrict__ chunk, uint32_t n_chunks, const uint32_t *__restrict__ words,
                         const uint2 *__restrict__ itab, const uint32_t *__restrict__ row_orig,
                         const uint64_t *__restrict__ T, uint64_t slots, uint32_t sh, const uint64_t *__restrict__ only,
-                        uint32_t batch, uint32_t *status, uint32_t *first_bad) {
-    const uint32_t lane = threadIdx.x, g = blockIdx.x;
-    const uint32_t i = g * 64 + lane;
-    if (only && only[g] == 0) return;
-    const uint64_t *Tg = bits_group(T, slots, sh, g);
+                        uint32_t n_groups, uint32_t batch, uint32_t *status, uint32_t *first_bad) {
+    const uint32_t lane = threadIdx.x;
     const BitsTr TR = bits_tr_setup(lane);
+    for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    const uint32_t i = g * 64 + lane;
+    if (only && only[g] == 0) continue;
+    const uint64_t *Tg = bits_group(T, slots, sh, g);
     uint32_t bad = 0xFFFFFFFFu;
     for (uint32_t cix = blockIdx.y; cix < n_chunks; cix += gridDim.y) {
         const uint4 ch = chunk[cix];                                // first word, groups, -, first row
@@ -706,6 +713,7 @@ cw_bits_r1cs_int_kernel(const uint4 *__restrict__ chunk, uint32_t n_chunks, cons
         atomicMin(&first_bad[i], bad);
         atomicOr(&status[i], CW_ST_R1CS_FAILED);
     }
+    }
 }
 
 // ---- launch wrappers ---------------------------------------------------------------------------------------------------
@@ -774,26 +782,29 @@ hipError_t cwk_bits_r1cs(hipStream_t s, const void *erecs, uint32_t n_evrows, co
                          uint64_t slots, uint32_t sh, const void *only, uint32_t n_groups, uint32_t batch, uint32_t *status, uint32_t *first_bad,
                          const FpParams &P) {
     const uint64_t *onl = (const uint64_t *)only;
+    // audit of flagged groups: 1 024 workgroups walk the flag words (a launch of one workgroup per group costs ~14 ns each:
+    // 1.4 ms of nothing at 2 M instances)
+    const uint32_t gx = onl && n_groups > 1024u ? 1024u : n_groups;
     if (n_evrows) {
         // the kernel is bound by the latency of its 5 mask loads per lane: ~8 waves per SIMD (8192 on the chip) hide it
-        uint32_t chunks = (8192 + n_groups - 1) / n_groups;
+        uint32_t chunks = onl ? 4u : (8192 + n_groups - 1) / n_groups;
         if (chunks > n_evrows) chunks = n_evrows;
         if (chunks > 65535u) chunks = 65535u;
         if (chunks < 1) chunks = 1;
         const uint32_t per = (n_evrows + chunks - 1) / chunks;
         chunks = (n_evrows + per - 1) / per;
-        hipLaunchKernelGGL(cw_bits_r1cs_lut_kernel, dim3(n_groups, chunks), dim3(64), 0, s, (const uint4 *)erecs, n_evrows, per,
-                           (const uint64_t *)T, slots, sh, onl, batch, status, first_bad);
+        hipLaunchKernelGGL(cw_bits_r1cs_lut_kernel, dim3(gx, chunks), dim3(64), 0, s, (const uint4 *)erecs, n_evrows, per,
+                           (const uint64_t *)T, slots, sh, onl, n_groups, batch, status, first_bad);
     }
     if (n_ichunks) {
-        dim3 g(n_groups, n_ichunks < 65535u ? n_ichunks : 65535u);
+        dim3 g(gx, onl ? (n_ichunks < 4u ? n_ichunks : 4u) : n_ichunks < 65535u ? n_ichunks : 65535u);
         hipLaunchKernelGGL(cw_bits_r1cs_int_kernel, g, dim3(64), 0, s, (const uint4 *)ichunk, n_ichunks, iterms,
-                           (const uint2 *)itab, irow_orig, (const uint64_t *)T, slots, sh, onl, batch, status, first_bad);
+                           (const uint2 *)itab, irow_orig, (const uint64_t *)T, slots, sh, onl, n_groups, batch, status, first_bad);
     }
     if (n_chunks) {
-        dim3 g(n_groups, n_chunks < 65535u ? n_chunks : 65535u);
+        dim3 g(gx, onl ? (n_chunks < 4u ? n_chunks : 4u) : n_chunks < 65535u ? n_chunks : 65535u);
         hipLaunchKernelGGL(cw_bits_r1cs_wide_kernel, g, dim3(64), 0, s, (const uint4 *)chunk, n_chunks, (const uint2 *)terms, ctab,
-                           row_orig, (const uint64_t *)T, slots, sh, onl, batch, status, first_bad, P);
+                           row_orig, (const uint64_t *)T, slots, sh, onl, n_groups, batch, status, first_bad, P);
     }
     return hipGetLastError();
 }

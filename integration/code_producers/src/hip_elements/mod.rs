@@ -166,6 +166,69 @@ impl HipProducer {
         self.ops.push(FlatOp { op, dst, a, b, c });
     }
 
+    /// The constraints, read back from the `.r1cs` file circom has already written (`--hip` implies `--r1cs`,
+    /// circom/src/execution_user.rs:27-57): `compiler::Circuit` holds none (circuit_design/circuit.rs:17-20; they live in
+    /// `constraint_list`, which the `compiler` and `code_producers` crates do not depend on).  Layout as
+    /// constraint_writers/src/r1cs_writer.rs writes it: "r1cs" | version | n sections | sections {type u32, size u64}:
+    /// 1 = header (field size u32, prime, nWires u32, nPubOut, nPubIn, nPrvIn u32, nLabels u64, mConstraints u32),
+    /// 2 = constraints (3 x {n u32, n x {wire u32, coefficient}}), 3 = wire -> label (u64 each; label = signal id).
+    pub fn load_r1cs(&mut self, path: &Path) -> std::io::Result<()> {
+        use std::io::{Error, ErrorKind};
+        let bad = |m: &str| Error::new(ErrorKind::InvalidData, m.to_string());
+        let buf = std::fs::read(path)?;
+        let u32_at = |o: usize| -> std::io::Result<u32> {
+            buf.get(o..o + 4).map(|b| u32::from_le_bytes([b[0], b[1], b[2], b[3]])).ok_or_else(|| bad("r1cs truncated"))
+        };
+        let u64_at = |o: usize| -> std::io::Result<u64> {
+            buf.get(o..o + 8).map(|b| u64::from_le_bytes([b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7]])).ok_or_else(|| bad("r1cs truncated"))
+        };
+        if buf.len() < 12 || &buf[0..4] != b"r1cs" {
+            return Err(bad("not an r1cs file"));
+        }
+        let n_sections = u32_at(8)? as usize;
+        let mut at = 12usize;
+        let (mut hdr, mut cons, mut map) = (None, None, None);
+        for _ in 0..n_sections {
+            let (ty, size) = (u32_at(at)?, u64_at(at + 4)? as usize);
+            at += 12;
+            match ty {
+                1 => hdr = Some(at),
+                2 => cons = Some(at),
+                3 => map = Some((at, size / 8)),
+                _ => {}
+            }
+            at += size;
+        }
+        let (hdr, cons, (map_at, n_wires)) = match (hdr, cons, map) {
+            (Some(h), Some(c), Some(m)) => (h, c, m),
+            _ => return Err(bad("r1cs section missing")),
+        };
+        let fs = u32_at(hdr)? as usize;
+        let m_constraints = u32_at(hdr + 4 + fs + 4 + 4 + 4 + 4 + 8)? as usize;
+        let mut label = Vec::with_capacity(n_wires);
+        for w in 0..n_wires {
+            label.push(u64_at(map_at + 8 * w)? as u32);
+        }
+        let mut o = cons;
+        self.constraints.clear();
+        for _ in 0..m_constraints {
+            let mut parts: [Vec<(u32, BigInt)>; 3] = [Vec::new(), Vec::new(), Vec::new()];
+            for part in parts.iter_mut() {
+                let n = u32_at(o)? as usize;
+                o += 4;
+                for _ in 0..n {
+                    let wire = u32_at(o)? as usize;
+                    let coef = buf.get(o + 4..o + 4 + fs).ok_or_else(|| bad("r1cs truncated"))?;
+                    part.push((*label.get(wire).ok_or_else(|| bad("r1cs wire out of range"))?, BigInt::from_bytes_le(num_bigint_dig::Sign::Plus, coef)));
+                    o += 4 + fs;
+                }
+            }
+            let [a, b, c] = parts;
+            self.constraints.push(FlatConstraint { a, b, c });
+        }
+        Ok(())
+    }
+
     fn le_bytes(&self, v: &BigInt) -> Vec<u8> {
         let (_, mut bytes) = v.to_bytes_le();
         bytes.resize(8 * self.n64, 0);

@@ -36,6 +36,7 @@ use circom_algebra::modular_arithmetic as ma;
 pub enum HipError {
     RunTimeControl { line: usize, what: &'static str },
     Unsupported { line: usize, what: &'static str },
+    Internal(&'static str),
 }
 
 /// A value during the trace: known now, or living in a signal / temporary / constant-table slot at run time.
@@ -74,7 +75,11 @@ impl WriteHip for Circuit {
     fn produce_hip(&self, producer: &mut HipProducer) -> Result<(), HipError> {
         let n_cmp = self.c_producer.number_of_components;
         let mut t = Tracer { circuit: self, p: producer, components: (0..n_cmp).map(|_| None).collect() };
-        let main_id = self.c_producer.main_header_id();        // index of main's TemplateCode (main_header in CProducer)
+        // main's TemplateCode is the one whose header is CProducer::get_main_header() (c_elements/mod.rs:141; set by
+        // build.rs:259-298 from the main component's template instance, "Main_0" style)
+        let main_header = self.c_producer.get_main_header();
+        let main_id = self.templates.iter().position(|t| t.header == main_header)
+            .ok_or(HipError::Internal("main template not found among the circuit's templates"))?;
         t.create(main_id, 1, 0)?;
         if t.components[0].as_ref().unwrap().input_counter > 0 {
             // main's inputs are the circuit's inputs: they are set before run(), so the body runs now

@@ -67,3 +67,26 @@ def test_opcode_numbering_agrees():
         body = body[:body.index("\n}\n")]
         for o in ops:
             assert re.search(r"\b%s =>" % re.escape(o), body), (fn, o)
+
+
+def test_every_reference_accessor_the_rust_side_uses_exists():
+    """the sketch cannot be compiled here, but what it reads from the reference's own types can be checked against the
+    reference tree where that is present (the driver's container): fields / methods of `CProducer`, `Circuit`, `TemplateCode`"""
+    import pytest
+    ref = Path("/root/reference")
+    if not ref.exists():
+        pytest.skip("reference tree not present")
+    cprod = (ref / "code_producers" / "src" / "c_elements" / "mod.rs").read_text()
+    circuit = (ref / "compiler" / "src" / "circuit_design" / "circuit.rs").read_text()
+    template = (ref / "compiler" / "src" / "circuit_design" / "template.rs").read_text()
+    src = _strip(BACK) + _strip((ROOT / "integration" / "edits.md").read_text())
+    for name in set(re.findall(r"\bc_producer\.(\w+)", src)):
+        assert re.search(r"pub (fn )?%s\b" % name, cprod), "CProducer has no `%s`" % name
+    for name in set(re.findall(r"\b(?:self|circuit)\.circuit\.(\w+)|\bcircuit\.(\w+)\(", src)):
+        name = name[0] or name[1]
+        if name in ("produce_hip",):                      # the trait this repository adds
+            continue
+        assert re.search(r"pub (fn )?%s\b" % name, circuit), "compiler::Circuit has no `%s`" % name
+    for name in ("header", "number_of_inputs", "number_of_components", "body"):
+        assert re.search(r"pub %s\b" % name, template), name
+    assert "main_header_id" not in BACK and "constraints_for_hip" not in src
