@@ -40,7 +40,8 @@ VALU_CLK_PER_WAVE_INST = 2.0       # a SIMD-32 issues a wave64 VALU instruction 
 LONE_WAVE_CLK_PER_INST = 4.1       # ONE wave issues at most one instruction of any kind per ~4.1 clocks (tools/ubench_isa)
 BITS_VALU_PER_VROW = 10            # cw_bits_eval_kernel<64>, from the disassembly: 3 operand offsets, 2 mask expansions, 1 result
 BITS_INSTS_PER_VROW = 15           # offset, 4 v_bitop3  + 3 ds_read_b64, 1 ds_write_b64, 1 s_waitcnt
-DEFAULT_BATCH = {"bigmultmodp": 8192, "sha256_2048": 65536, "sha256_512": 4096, "poseidon2": 65536, "semaphore20": 8192, "semaphore20p": 8192}
+JIT_BATCH = 1 << 21                # the emitted bit-plane code runs one wave per 2 048 instances: 1 024 waves = one per SIMD
+DEFAULT_BATCH = {"bigmultmodp": 8192, "sha256_2048": JIT_BATCH, "sha256_512": 4096, "poseidon2": 65536, "semaphore20": 8192, "semaphore20p": 8192}
 
 
 def _semaphore_shape(name: str):
@@ -126,13 +127,20 @@ def get_compiled(name: str, batch: int, cache_root: str, rank: int, dist):
             strands = (1,)                  # the 256-bit schedule only serves instances re-run with non-boolean inputs
             mont = False
         tapes = [lower(fc, n_strands=s, mont=mont) for s in strands]
-        writers.write_tape(p(".cwt"), tapes, bittape)
+        jp = compiler.emit_jit(compiler.lower_bitplane.net, fc) if bittape is not None else None     # the same network as emitted code
+        compiler.lower_bitplane.net = None
+        writers.write_tape(p(".cwt"), tapes, bittape, jp)
+        json.dump(jp.stats if jp is not None else {}, open(p(".jit.json"), "w"))
         writers.write_dat(p(".dat"), fc)
         writers.write_r1cs(p(".r1cs"), fc)
         open(done, "w").write(fp)
     if dist:
         dist.barrier()
     cp = compiler.Compiled(name, d, p(".cwt"), p(".dat"), p(".r1cs"), p(".sym"), fc, None)
+    try:
+        cp.jit_stats = json.load(open(p(".jit.json")))
+    except Exception:
+        cp.jit_stats = {}
     return cp, time.perf_counter() - t0, cached
 
 
@@ -209,6 +217,14 @@ class BoolInputs:
         return out
 
 
+def dominant_roofline(roof_eval, roof_r1cs, roof_ingest, gen_ms, chk_ms, jit, packed):
+    """the roofline object of the kernel with the longest measured duration in this run"""
+    if jit:
+        cands = [roof_eval] + ([roof_ingest] if roof_ingest and not packed else [])
+        return max(cands, key=lambda r: r.get("kernel_ms") or 0.0)
+    return roof_eval if gen_ms >= chk_ms else roof_r1cs
+
+
 def auto_in_flight(bitmode: bool, B: int, lanes: int) -> int:
     """Batches in flight for `--in-flight 0`.  Two keep the check of one step next to the evaluation of the next; a batch
     that covers a fraction of the chip gets more, so that the rest of the chip works through the length of its dependency
@@ -223,7 +239,7 @@ def auto_in_flight(bitmode: bool, B: int, lanes: int) -> int:
     return max(2, min(8, 512 // max(1, wgs)))
 
 
-def parity_check(cp, circ, batch, h_in, workload: str, n_sample: int = 4):
+def parity_check(cp, circ, batch, h_in, workload: str, n_sample: int = 4, digest_bits=None):
     """Oracle comparison at the benchmark batch (after the timed region).  Returns a dict for the JSON line; raises
     AssertionError on any mismatch (a fast wrong answer is not a result)."""
     import numpy as np
@@ -264,15 +280,17 @@ def parity_check(cp, circ, batch, h_in, workload: str, n_sample: int = 4):
     out["wtns_sha256_first"] = hashlib.sha256(got[picks[0]]).hexdigest()
     if workload.startswith("sha256_"):
         # every instance's digest against hashlib (output bit k = bit 7-(k%8) of digest byte k/8, msb first)
-        pub = batch.public_signals()                     # [B][n_public][32]
-        assert not pub[:, :256, 1:].any(), "digest signals are not bits"
-        bits = pub[:, :256, 0]
+        if digest_bits is None:
+            pub = batch.public_signals()                     # [B][n_public][32]
+            assert not pub[:, :256, 1:].any(), "digest signals are not bits"
+            digest_bits = pub[:, :256, 0]
         nb = int(workload.split("_")[1])
-        msg_bits = h_in[:, :nb, 0]
-        for i in range(B):
-            msg = np.packbits(msg_bits[i]).tobytes()
-            dg = np.unpackbits(np.frombuffer(hashlib.sha256(msg).digest(), dtype=np.uint8))
-            assert (bits[i] == dg).all(), "PARITY FAILURE: digest of instance %d differs from hashlib" % i
+        msgs = np.packbits(h_in[:, :nb, 0], axis=1)          # [B][nb / 8] message bytes
+        sha = hashlib.sha256
+        want = np.frombuffer(b"".join(sha(msgs[i].tobytes()).digest() for i in range(B)), dtype=np.uint8).reshape(B, 32)
+        got = np.packbits(digest_bits, axis=1)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert bad.size == 0, "PARITY FAILURE: digest of instance %d differs from hashlib" % int(bad[0])
         out["digests_checked"] = B
     return out
 
@@ -425,12 +443,25 @@ def main():
         B //= 2                                              # the value table did not fit: halve the batch once
         batch = circ.batch(B, device=local_rank, stream=stream.cuda_stream)
     # synthetic inputs, resident in HBM before the timed region (different seed per rank = different shard)
-    if args.packed_inputs:
+    big_bool = batch.bitmode and args.workload.startswith("sha256_") and B * circ.n_inputs * 32 > (8 << 30)
+    if args.packed_inputs or big_bool:
         assert batch.bitmode and args.workload.startswith("sha256_"), "--packed-inputs needs a bit-plane circuit"
-        h_in = BoolInputs(np.random.default_rng(1 + rank).integers(0, 2, size=(B, circ.n_inputs), dtype=np.uint8))
-        main_masks = h_in.masks()
-        d_in = torch.from_numpy(main_masks.view(np.int64)).to(dev)
-        set_in = lambda b_: b_.set_inputs_bits_device(d_in.data_ptr())
+        # random message bits from the device's generator (2 M x 2 048 bits: seconds on the host); the host keeps one byte per
+        # bit (BoolInputs indexes like the 32-byte image), the 32-byte image itself - 137 GB for the default batch - only
+        # ever exists in HBM
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(1 + rank)
+        d_bits = torch.randint(0, 2, (B, circ.n_inputs), dtype=torch.uint8, device=dev, generator=gen)
+        h_in = BoolInputs(d_bits.cpu().numpy())
+        if args.packed_inputs:
+            main_masks = h_in.masks()
+            d_in = torch.from_numpy(main_masks.view(np.int64)).to(dev)
+            set_in = lambda b_: b_.set_inputs_bits_device(d_in.data_ptr())
+        else:
+            d_in = torch.zeros((B, circ.n_inputs, 32), dtype=torch.uint8, device=dev)
+            d_in[:, :, 0] = d_bits
+            set_in = lambda b_: b_.set_inputs_device(d_in.data_ptr())
+        del d_bits
     else:
         h_in = synth_inputs(args.workload, circ.q, B, circ.n_inputs, seed=1 + rank)
         d_in = torch.from_numpy(h_in).to(dev)
@@ -518,7 +549,11 @@ def main():
 
     parity = None
     if not args.no_parity:
-        parity = parity_check(cp, circ, batch, h_in, args.workload, args.parity_instances)   # every rank checks its own shard
+        dg_bits = None
+        if args.workload.startswith("sha256_") and circ.n_public >= 256:
+            assert not bool(pub_local[:, :256, 1:].any().item()), "digest signals are not bits"
+            dg_bits = pub_local[:, :256, 0].contiguous().cpu().numpy()          # reduced on the device: 256 bytes per instance
+        parity = parity_check(cp, circ, batch, h_in, args.workload, args.parity_instances, dg_bits)   # every rank checks its own shard
         parity["parity_checked"] = len(parity["instances"])
 
     # canonical egress: the 32-byte-per-element image a prover reads (SURVEY 8d's B_gen: what the reference's
@@ -543,7 +578,7 @@ def main():
         e_gbs = n_e * row_bytes / (e_ms * 1e-3) / 1e9
         step_ms = elapsed / args.steps * 1e3
         whole_ms = e_ms * B / n_e
-        egress = {"instances": n_e, "chunk_instances": chunk, "ms": e_ms, "GB/s": e_gbs, "frac_of_hbm_peak": e_gbs / HBM_PEAK_GBS,
+        egress = {"instances": n_e, "extrapolated_from": n_e if n_e < B else None, "chunk_instances": chunk, "ms": e_ms, "GB/s": e_gbs, "frac_of_hbm_peak": e_gbs / HBM_PEAK_GBS,
                   "whole_batch_ms": whole_ms, "witnesses_per_s_with_egress": B / ((step_ms + whole_ms) * 1e-3)}
         if n_fl > 1:
             # egress of this batch's slice on stream 0 while the other batch runs whole steps on stream 1
@@ -564,11 +599,7 @@ def main():
     # packed boolean inputs (cw_set_inputs_bits_device): one bit per input and instance instead of 32 bytes
     packed = None
     if rank == 0 and batch.bitmode and args.workload.startswith("sha256_") and not args.packed_inputs:
-        ng = (B + 63) // 64
-        bits01 = np.zeros((ng * 64, circ.n_inputs), dtype=np.uint8)
-        bits01[:B] = h_in[:, :, 0]
-        masks = np.packbits(bits01.reshape(ng, 64, circ.n_inputs), axis=1, bitorder="little")      # [ng][8][n_in] bytes
-        masks = np.ascontiguousarray(masks.transpose(0, 2, 1)).view(np.uint64).reshape(ng, circ.n_inputs)
+        masks = (h_in if isinstance(h_in, BoolInputs) else BoolInputs(np.ascontiguousarray(h_in[:, :, 0]))).masks()
         d_masks = torch.from_numpy(masks.view(np.int64)).to(dev)
         for b_ in batches:
             b_.set_inputs_bits_device(d_masks.data_ptr())
@@ -650,7 +681,49 @@ def main():
         rk = "cw_bits_r1cs_{lut,int,wide}_kernel" if batch.bitmode else "cw_r1cs_stream_kernel"
         clk = prof.get("eval_clock_hz") or NOMINAL_CLOCK_HZ
         valu_peak = N_SIMD * clk / VALU_CLK_PER_WAVE_INST     # wave64 VALU instructions per second the chip can issue
-        if batch.bitmode:
+        if batch.bitmode and batch.jit:
+            # Emitted code (hip_elements/bitjit.py): one wave per 2 048 instances runs the circuit as straight-line v_bitop3_b32
+            # instructions and writes every distinct signal value once - the bit table IS the witness (1 bit per value and
+            # instance).  Roofs: HBM for the table's bytes (plus the rows the code re-reads: its register file cannot hold a
+            # 1M-signal circuit), VALU issue for its instruction stream.  Durations are HIP-event intervals of THIS run (one step
+            # alone; the evaluation's own time comes from the packed-input steps, whose ingest is a 10 us copy); instruction and
+            # reload counts are the emitter's (it wrote every instruction: cp.jit_stats), counter figures from profiles/ if taken
+            # on this source.
+            js = getattr(cp, "jit_stats", {}) or {}
+            chunks = (B + 2047) // 2048
+            ek = "cw_bits_jit (emitted per circuit)"
+            kern_ms = isolated.get("eval_only_ms") or isolated["eval_ms"]
+            tab_bytes = 8.0 * batch.bits_slots * batch.bits_groups
+            reload_bytes = 256.0 * (js.get("prefetched", 0) + js.get("late_loads", 0)) * chunks
+            insts = float(js.get("instructions", 0)) * chunks
+            roof_eval = {"bound": "hbm", "kernel": ek, "unit": "GB/s", "achieved": tab_bytes / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                         "frac": tab_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": kern_ms,
+                         "kernel_ms_source": "HIP events in this run, one step alone, packed inputs (init + 10 us input copy + the emitted kernel)",
+                         "algorithmic_bytes_per_launch": tab_bytes,
+                         "algorithmic_bytes_are": "the bit table: one 256-byte row per distinct signal value (%d rows) and chunk of 2 048 instances, written once" % batch.bits_slots,
+                         "traffic": prof.get("eval"),
+                         "traffic_estimate": {"table_rows_written": tab_bytes, "rows_re_read": reload_bytes,
+                                              "GB/s_incl_re_reads": (tab_bytes + reload_bytes) / (kern_ms * 1e-3) / 1e9,
+                                              "frac_incl_re_reads": (tab_bytes + reload_bytes) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "waves": chunks, "instructions_per_wave": js.get("instructions"), "gates_per_wave": js.get("gates"),
+                         "valu_issue": {"wave_insts_per_s": insts / (kern_ms * 1e-3), "peak": valu_peak, "frac": insts / (kern_ms * 1e-3) / valu_peak,
+                                        "lone_wave_frac": (js.get("instructions", 0) / (kern_ms * 1e-3)) / (clk / LONE_WAVE_CLK_PER_INST)},
+                         "gate_evaluations_per_s": float(js.get("gates", 0)) * B / (kern_ms * 1e-3),
+                         "fused_r1cs_check": {k[6:]: v for k, v in js.items() if k.startswith("check_")}}
+            chk_kern_ms = isolated["r1cs_check_ms"]
+            roof_r1cs = {"bound": "none (fused)", "kernel": "fused into cw_bits_jit; cw_bits_r1cs_* audit only the groups it flags", "kernel_ms": chk_kern_ms,
+                         "frac": None, "traffic": prof.get("r1cs"),
+                         "note": "every non-trivial constraint is evaluated on the registers that hold its wires while the witness is generated "
+                                 "(SURVEY 8d: B_chk -> 0); the stand-alone kernels remain as the audit (CW_R1CS_AUDIT=1, or after cw_device_bits)"}
+            roof_valu = {"bound": "valu", "kernel": ek, "unit": "wave-instructions/s", "achieved": insts / (kern_ms * 1e-3), "peak": valu_peak,
+                         "frac": insts / (kern_ms * 1e-3) / valu_peak, "kernel_ms": kern_ms, "clock_hz": clk}
+            ing_ms = isolated.get("ingest_ms")
+            roof_ingest = None if not ing_ms else {"bound": "hbm", "kernel": "cw_bits_ingest_kernel", "unit": "GB/s", "achieved": 32.0 * n_in * B / (ing_ms * 1e-3) / 1e9,
+                           "peak": HBM_PEAK_GBS, "frac": 32.0 * n_in * B / (ing_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": ing_ms,
+                           "kernel_ms_source": "HIP events in this run: step with 32-byte inputs minus step with packed inputs",
+                           "algorithmic_bytes_per_launch": 32.0 * n_in * B,
+                           "algorithmic_bytes_are": "the boundary's input image: 32 bytes per input signal and instance, read once"}
+        elif batch.bitmode:
             # The bit-plane engine holds ONE BIT per distinct signal value and instance: its kernels neither read nor write
             # the 32-byte image, so SURVEY 8d's byte roof does not bind them (round 2 divided the image's bytes by their
             # time and reported "fractions" of 53 and 96).  Their roofs: instruction issue for the evaluation, the scalar /
@@ -722,7 +795,9 @@ def main():
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
-            "dtype": "bit-plane boolean gates on u64 instance masks (u256 Montgomery fallback for non-boolean instances)" if batch.bitmode
+            "dtype": ("bit-plane boolean gates (v_bitop3_b32 on u32 lanes of 32 instances, emitted per circuit; u256 Montgomery fallback for "
+                      "non-boolean instances)") if batch.bitmode and batch.jit else
+            "bit-plane boolean gates on u64 instance masks (u256 Montgomery fallback for non-boolean instances)" if batch.bitmode
             else "u256 (9x29-bit limbs, Montgomery multiply)",
             "data": "synthetic",
             "config": {"workload": "%s %s --O0 (%d constraints), batch=%d per GPU" % (args.workload, cp.flat.prime, circ.n_constraints, B),
@@ -732,9 +807,10 @@ def main():
                         "([signal][instance] order" + (", Montgomery form" if circ.montgomery else "") + "); value_canonical includes "
                         "writing the reference's image ([instance][witness element], canonical residues)"),
                        "n_signals": circ.n_signals, "n_witness": n_wit, "n_constraints": circ.n_constraints,
-                       "engine": "bit-plane (1 bit per signal value per instance)" if batch.bitmode else
+                       "engine": "bit-plane, emitted gfx950 code (one wave per 2 048 instances, 1 bit per signal value per instance)" if batch.bitmode and batch.jit else
+                       "bit-plane (1 bit per signal value per instance)" if batch.bitmode else
                        ("256-bit schedule, signals in Montgomery form" if circ.montgomery else "256-bit schedule"),
-                       "bit_program": bits, "r1cs_check_classes": (circ.bits_r1cs_plan_stats() if batch.bitmode else None),
+                       "bit_program": bits, "emitted_code": getattr(cp, "jit_stats", None) if batch.bitmode and batch.jit else None, "r1cs_check_classes": (circ.bits_r1cs_plan_stats() if batch.bitmode else None),
                        "schedule_rows": circ.n_rows, "fp_mul_per_witness": circ.n_mmul,
                        "parallelism": "instances sharded x%d, status + public-signal gather only" % world,
                        "inputs": "packed boolean masks (8 bytes per input and 64 instances)" if args.packed_inputs else
@@ -744,7 +820,7 @@ def main():
             "value_canonical": value_canonical,
             "value_canonical_hbm_frac": (egress["frac_of_hbm_peak"] if egress else None),
             # the dominant kernel of THIS run (longest measured duration)
-            "roofline": roof_eval if gen_ms >= chk_ms else roof_r1cs,
+            "roofline": dominant_roofline(roof_eval, roof_r1cs, roof_ingest, gen_ms, chk_ms, bool(batch.bitmode and batch.jit), args.packed_inputs),
             "roofline_eval": roof_eval,
             "roofline_r1cs": roof_r1cs,
             "roofline_ingest": roof_ingest,

@@ -1207,6 +1207,15 @@ extern "C" void cw_batch_free(cw_batch *b) {
 }
 
 static int bits_batch_setup(cw_batch *b);
+// device staging of host-side inputs: [batch][n_inputs][32]; bit-plane batches allocate it on first use
+static int ensure_d_in(cw_batch *b) {
+    if (b->d_in) return CW_OK;
+    const size_t n = std::max<size_t>((size_t)b->batch * b->c->n_inputs * 32, 32);
+    hipError_t e = hipMalloc(&b->d_in, n);
+    if (e != hipSuccess)
+        return fail(CW_EDEVICE, "hipMalloc of the input staging image failed (" + std::to_string(n) + " bytes): " + hipGetErrorString(e));
+    return CW_OK;
+}
 
 static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *stream, bool allow_bits, cw_batch **out) {
     if (!c || !out || batch == 0) return fail(CW_EINVAL, "cw_batch_create: bad argument");
@@ -1607,6 +1616,7 @@ extern "C" int cw_set_inputs(cw_batch *b, const uint8_t *le32) {
         return CW_OK;
     }
     HIPCHK(hipSetDevice(b->device));
+    if (int rc = ensure_d_in(b)) return rc;
     HIPCHK(hipMemcpyAsync(b->d_in, le32, n, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));   // caller may free le32 on return
     b->packed_in = nullptr;
@@ -1634,6 +1644,7 @@ extern "C" int cw_set_inputs_bits(cw_batch *b, const uint64_t *masks) {
     if (!b->bitmode) return fail(CW_ESTATE, "packed boolean inputs need a bit-plane batch (cw_batch_bitmode)");
     HIPCHK(hipSetDevice(b->device));
     // d_in holds 32 bytes per input and instance: the masks (1 bit each) always fit
+    if (int rc = ensure_d_in(b)) return rc;
     HIPCHK(hipMemcpyAsync(b->d_in, masks, (size_t)b->n_groups * b->c->n_inputs * 8, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     return cw_set_inputs_bits_device(b, b->d_in);
@@ -1940,7 +1951,9 @@ static int bits_batch_setup(cw_batch *b) {
                     (unsigned long long)p.n_wide);
         b->n_wchunks = p.n_chunks;
     }
-    BTRY(hipMalloc(&b->d_in, std::max<size_t>((size_t)b->batch * c->n_inputs * 32, 32)));
+    // the 32-byte staging image (d_in) of a bit-plane batch is allocated when a HOST-side setter first needs it: a caller that
+    // hands over device buffers (cw_set_inputs_device / cw_set_inputs_bits_device) never does - 137 GB for 2 M instances of
+    // Sha256(2048)
     BTRY(hipMalloc(&b->d_gather, std::max<size_t>((size_t)c->n_witness * 32, 32)));
     BTRY(cwk_bits_init(b->stream, b->d_T, b->bits_slots, b->bits_sh, b->n_groups_padded, b->d_fbmask, b->d_r1flag, b->d_status, b->d_first_bad, b->Bp));
     BTRY(hipStreamSynchronize(b->stream));
@@ -2050,6 +2063,7 @@ extern "C" int cw_run(cw_batch *b) {
     }
     HIPCHK(hipSetDevice(b->device));
     if (b->host_dirty) {
+        if (int rc = ensure_d_in(b)) return rc;
         HIPCHK(hipMemcpyAsync(b->d_in, b->h_in.data(), b->h_in.size(), hipMemcpyHostToDevice, b->stream));
         b->host_dirty = false;
     }

@@ -122,25 +122,13 @@ class _Gates:
         return nid
 
     def lut(self, leaves, tt):
-        """any function of `leaves` (table index bit j = leaves[j]) as a tree of 3-input gates (Shannon expansion)"""
-        n = len(leaves)
-        if n <= 3:
-            return self.gate(tt, leaves)
-        for j in range(n):                       # support reduction
-            lo = hi = 0
-            k = 0
-            for m in range(1 << n):
-                if not (m >> j) & 1:
-                    lo |= ((tt >> m) & 1) << k
-                    hi |= ((tt >> (m | (1 << j))) & 1) << k
-                    k += 1
-            if lo == hi:
-                return self.lut(leaves[:j] + leaves[j + 1:], lo)
-        j = n - 1
-        half = 1 << j
-        f0 = self.lut(leaves[:j], tt & ((1 << half) - 1))
-        f1 = self.lut(leaves[:j], tt >> half)
-        return self.gate(0xCA, (f0, f1, leaves[j]))          # s ? f1 : f0 over (f0, f1, s)
+        """any function of `leaves` (table index bit j = leaves[j]) as a small network of 3-input gates: the recipe is found
+        once per distinct table (`lut_recipe`: a circuit has a handful - Sha256: 16) and replayed on the leaves"""
+        steps = lut_recipe(len(leaves), tt)
+        val = []
+        for t8, ops in steps:
+            val.append(self.gate(t8, [leaves[o] if o >= 0 else val[-1 - o] for o in ops]))
+        return val[-1] if steps else (tt & 1)
 
     def sum_bits(self, terms):
         """bits (LSB first, node ids) of sum(coef * node), coef > 0: carry-save columns, oldest entries first"""
@@ -173,6 +161,157 @@ class _Gates:
             out.append(col[i] if len(col) > i else 0)
             k += 1
         return out
+
+
+# ---- 3-input-gate networks for functions of up to 6 variables -------------------------------------------------------------------
+# A recipe is a list of steps (table over its <= 3 operands, operands); an operand >= 0 is a variable, -1 - k is step k.
+# Search: functional decomposition on every bound set of three variables (column multiplicity 2: one gate feeds a gate over
+# the free variables; multiplicity <= 4: two gates encode the column class, every class encoding is tried) and Shannon
+# expansion on every variable, recursively on the residual function, cheapest first; memoised per (n, table).
+_RECIPES = {}
+
+
+def _cofactors(n, tt, j):
+    lo = hi = 0
+    k = 0
+    for m in range(1 << n):
+        if not (m >> j) & 1:
+            lo |= ((tt >> m) & 1) << k
+            hi |= ((tt >> (m | (1 << j))) & 1) << k
+            k += 1
+    return lo, hi
+
+
+def _shift_vars(steps, vmap, base):
+    """re-address a recipe: variable v -> vmap[v] (a variable >= 0 or a step reference < 0), its own steps start at `base`"""
+    out = []
+    for t8, ops in steps:
+        out.append((t8, tuple(vmap[o] if o >= 0 else -1 - (base + (-1 - o)) for o in ops)))
+    return out
+
+
+def lut_recipe(n, tt):
+    key = (n, tt)
+    r = _RECIPES.get(key)
+    if r is not None:
+        return r
+    full = (1 << (1 << n)) - 1
+    tt &= full
+    # support reduction
+    for j in range(n):
+        lo, hi = _cofactors(n, tt, j)
+        if lo == hi:
+            sub = lut_recipe(n - 1, lo)
+            vmap = [v if v < j else v + 1 for v in range(n - 1)]
+            r = _shift_vars(sub, vmap, 0)
+            _RECIPES[key] = r
+            return r
+    if n == 0:
+        r = []
+    elif n <= 3:
+        t8 = tt if n == 3 else (tt | (tt << 4)) if n == 2 else (0xAA if tt == 2 else 0x55)
+        r = [(t8 & 0xFF, tuple(range(n)))]
+    else:
+        import itertools
+        best = None
+
+        def consider(c):
+            nonlocal best
+            if c is not None and (best is None or len(c) < len(best)):
+                best = c
+
+        # Shannon expansion on every variable: mux(x_j, f1, f0)
+        for j in range(n):
+            lo, hi = _cofactors(n, tt, j)
+            vmap = [v if v < j else v + 1 for v in range(n - 1)]
+            r0 = _shift_vars(lut_recipe(n - 1, lo), vmap, 0)
+            r1 = _shift_vars(lut_recipe(n - 1, hi), vmap, len(r0))
+            # a cofactor that is a constant or a plain variable has an empty recipe
+            def ref(rec, f, off):
+                if rec:
+                    return -1 - (off + len(rec) - 1), None
+                # f over n-1 vars after reduction is constant or a single variable / its complement handled as a gate above;
+                # empty recipe = constant
+                return None, f & 1
+            a_ref, a_c = ref(r0, lo, 0)
+            b_ref, b_c = ref(r1, hi, len(r0))
+            steps = r0 + r1
+            ops = []
+            t = 0
+            # final gate over (f0, f1, x_j) with constants folded in
+            srcs = [(a_ref, a_c), (b_ref, b_c), (j, None)]
+            var_ops = [s_[0] for s_ in srcs if s_[0] is not None]
+            for m in range(1 << len(var_ops)):
+                vals = []
+                k = 0
+                for rf, cst in srcs:
+                    if rf is None:
+                        vals.append(cst)
+                    else:
+                        vals.append((m >> k) & 1)
+                        k += 1
+                f0v, f1v, sv = vals
+                t |= (f1v if sv else f0v) << m
+            nv = len(var_ops)
+            t8 = t if nv == 3 else (t | (t << 4)) if nv == 2 else (0xAA if t == 2 else 0x55)
+            consider(steps + [(t8 & 0xFF, tuple(var_ops))])
+        # decomposition on a bound set of three variables
+        for T in itertools.combinations(range(n), 3):
+            R = [v for v in range(n) if v not in T]
+            nr = len(R)
+            cols = []
+            for t in range(8):
+                col = 0
+                for rr in range(1 << nr):
+                    m = 0
+                    for i, v in enumerate(T):
+                        m |= ((t >> i) & 1) << v
+                    for i, v in enumerate(R):
+                        m |= ((rr >> i) & 1) << v
+                    col |= ((tt >> m) & 1) << rr
+                cols.append(col)
+            distinct = sorted(set(cols))
+            mu = len(distinct)
+            if mu == 2:
+                h = sum((1 << t) for t in range(8) if cols[t] == distinct[1])
+                # g over (h, R...): index bit 0 = h
+                g = 0
+                for m in range(1 << (1 + nr)):
+                    g |= ((distinct[m & 1] >> (m >> 1)) & 1) << m
+                sub = lut_recipe(1 + nr, g)
+                vmap = [-1] + R                            # variable 0 of g = step 0 (h)
+                consider([(h, T)] + _shift_vars(sub, vmap, 1))
+            elif mu <= 4 and nr <= 2:
+                for perm in itertools.permutations(range(4), mu):
+                    code = {d: perm[i] for i, d in enumerate(distinct)}
+                    h1 = sum((1 << t) for t in range(8) if code[cols[t]] & 1)
+                    h2 = sum((1 << t) for t in range(8) if code[cols[t]] & 2)
+                    if h1 in (0, 255) or h2 in (0, 255):
+                        continue
+                    used = {c: d for d, c in code.items()}
+                    fillers = [None] if mu == 4 else distinct
+                    for fill in fillers:
+                        g = 0
+                        for m in range(1 << (2 + nr)):
+                            col = used.get(m & 3, fill)
+                            g |= ((col >> (m >> 2)) & 1) << m
+                        sub = lut_recipe(2 + nr, g)
+                        vmap = [-1, -2] + R
+                        consider([(h1, T), (h2, T)] + _shift_vars(sub, vmap, 2))
+        r = best
+    _RECIPES[key] = r
+    return r
+
+
+def _recipe_eval(n, steps, m):
+    """value of a recipe under assignment m (tests)"""
+    val = []
+    for t8, ops in steps:
+        idx = 0
+        for k, o in enumerate(ops):
+            idx |= (((m >> o) & 1) if o >= 0 else val[-1 - o]) << k
+        val.append((t8 >> idx) & 1)
+    return val[-1]
 
 
 LUT_MAX_WIRES = 6
@@ -301,7 +440,7 @@ class JitProgram:
         self.code = None                # code object (ELF) bytes once assembled
 
 
-def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384, fuse_check: bool = True):
+def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384, fuse_check: bool = True, hoist: int = 256):
     """BitNet (bitblast.py) -> JitProgram with IR.  Returns None when there is nothing to evaluate."""
     n_eval = len(net.tt)
     if fuse_check and fc.constraints:
@@ -326,12 +465,23 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
     for nid in range(n_nodes - 1, 1, -1):
         if live[nid] and is_gate[nid]:
             live[A[nid]] = live[B[nid]] = live[C[nid]] = True
-    # order: evaluation gates in creation order (= program order of the witness code), every check gate right behind the
-    # youngest of its operands
+    # order: evaluation gates in creation order (= program order of the witness code) - except that a gate whose operands
+    # were ALL created long before it moves up behind the youngest of them (circomlib's SHA-256 computes a block twice: the
+    # `<--` hint function first, then the constrained components, whose values are the hint's gates again plus a few of
+    # their own - the `mid` products, partial sums: created a whole block later than everything they read and are read with);
+    # every check gate sits where the youngest wire of its constraint is produced
     key = np.zeros(n_nodes, dtype=np.int64)
-    key[:n_eval] = np.arange(n_eval)
+    kl = key.tolist()
+    for nid in range(2, n_eval):
+        if is_gate[nid]:
+            m = max(A[nid], B[nid], C[nid])
+            kl[nid] = nid if nid - m <= hoist else max(kl[A[nid]], kl[B[nid]], kl[C[nid]])
+        else:
+            kl[nid] = 0                        # inputs are there from the start
     for nid in range(n_eval, n_nodes):
-        key[nid] = max(G.rowkey[nid - n_eval], key[A[nid]], key[B[nid]], key[C[nid]])
+        i = nid - n_eval
+        kl[nid] = max(kl[G.rowkey[i]], kl[A[nid]], kl[B[nid]], kl[C[nid]])
+    key = np.asarray(kl, dtype=np.int64)
     gates = np.array([i for i in range(2, n_nodes) if is_gate[i] and live[i]], dtype=np.int64)
     if len(gates) == 0:
         return None
@@ -492,10 +642,13 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
             loc_a[node] = -1
 
     empty = frozenset()
+    held_viol = [-1]                              # VGPR of a violation value waiting for its partner (not in any heap: never evicted)
     for p in range(n_ops):
-        # -- prefetch what the gate PREFETCH positions ahead reads from memory
-        pf = p + prefetch
-        if pf < n_ops:
+        # -- prefetch what the gate PREFETCH positions ahead reads from memory; a second look a quarter of that distance ahead
+        # catches values that were resident at the first look and have been dropped since (they have a row: dropping is free)
+        for pf in (p + prefetch, p + prefetch // 4):
+            if pf >= n_ops or pf == p:
+                continue
             g2 = order[pf]
             for o in (A[g2], B[g2], C[g2]):
                 if o > 1 and loc_v[o] < 0 and loc_a[o] < 0 and mem_slot[o] >= 0:
@@ -554,12 +707,23 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
         if g in assert_set:
             emit(("acc", 1, d))
         if g in viol_set:
-            emit(("acc", 2, d))
+            # two violation values per v_or3_b32: the first of a pair waits in its register (pinned by `held`)
+            if held_viol[0] < 0 and nu == INF:
+                held_viol[0] = d
+                continue
+            if held_viol[0] >= 0:
+                emit(("acc3", 2, held_viol[0], d))
+                free_v.append(held_viol[0])
+                held_viol[0] = -1
+            else:
+                emit(("acc", 2, d))
         if nu == INF:
             free_v.append(d)
             loc_v[g] = -1
         else:
             heapq.heappush(vheap, (-nu, g))
+    if held_viol[0] >= 0:
+        emit(("acc", 2, held_viol[0]))
     if const_assert:
         emit(("accc", 1))
     if const_viol:
@@ -656,6 +820,8 @@ def to_asm(jp: JitProgram) -> str:
             add("  v_accvgpr_read_b32 v%d, a%d\n" % (ins[1], ins[2]))
         elif k == "acc":
             add("  v_or_b32 v%d, v%d, v%d\n" % (ins[1], ins[1], ins[2]))
+        elif k == "acc3":
+            add("  v_or3_b32 v%d, v%d, v%d, v%d\n" % (ins[1], ins[1], ins[2], ins[3]))
         elif k == "accc":
             add("  v_mov_b32 v%d, -1\n" % ins[1])
         else:

@@ -96,6 +96,8 @@ def run_ir(jp, rows: dict, width: int):
             wr(ins[1], A[ins[2]], i)
         elif k == "acc":
             V[ins[1]] |= rd(ins[2], i)
+        elif k == "acc3":
+            V[ins[1]] |= rd(ins[2], i) | rd(ins[3], i)
         elif k == "accc":
             V[ins[1]] = full
         else:

@@ -44,6 +44,11 @@ def build_circuit(cp, force=False):
     h = hashlib.sha256(open(cp.dat_path, "rb").read())          # numbering, hash map, witness list, constants
     for k in sorted(cp.flat.code):                                # the flat witness code (independent of the lowering)
         h.update(k.encode() + bytes(memoryview(cp.flat.code[k])))
+    for f in getattr(cp.flat, "functions", ()) or ():           # function bytecode (rewritten by the optimiser), log strings, io map
+        h.update(repr(sorted((k, (v.tobytes() if hasattr(v, "tobytes") else repr(v))) for k, v in f.items() if k != "consts")).encode())
+    h.update(repr(list(getattr(cp.flat, "log_strings", ()))).encode())
+    h.update(repr(getattr(cp.flat, "io_map", ())).encode())
+    h.update(open(Path(__file__).resolve().parent / "emit_ref_cpp.py", "rb").read())   # the emitter itself
     fp = h.hexdigest()
     fp_file = d / (cp.name + ".fp")
     fresh = fp_file.exists() and fp_file.read_text().strip() == fp
@@ -191,7 +196,11 @@ def time_reference(cp, workload: str, seconds_budget: float = 15.0):
            "cores_detail": {"os_cpu_count": os.cpu_count(), "sched_affinity": affinity, "cgroup_quota": quota},
            "sample": "%d instances (%d per core x %d cores) of %s through the reference C++ runtime "
                      "(common/calcwit.cpp + generic/fr.cpp --no_asm GMP build), compute-only in-process loop, "
-                     "wall %.1f s" % (n, n_per_core, cores, workload, wall)}
+                     "wall %.1f s" % (n, n_per_core, cores, workload, wall),
+           # the field library and the runtime are built at -O3 as the reference's makefile does (c_elements/generic/makefile:2);
+           # the circuit's own <name>.cpp - a straight line of calls into them, 10 MB of source per SHA-256 block pair - at -O1
+           # (oracle/Makefile CIRCUIT_OPT: -O3 on it costs tens of minutes of g++ per circuit for call-bound code)
+           "circuit_opt": "fr.cpp / calcwit.cpp / main.cpp -O3, <name>.cpp -O1 (oracle/Makefile CIRCUIT_OPT)"}
     # (i) end to end: JSON parse + process start + .dat load + compute + .wtns write, `cores` processes at a time
     try:
         res["end_to_end"] = _time_cli(cp, gen, cores, min(8.0, seconds_budget * 0.5))

@@ -27,7 +27,7 @@ hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
 res = {"workload": fname, "batch": B}
 for eng in (os.environ.get("ENGINES", "jit,interp").split(",")):
     os.environ["CW_BITS_JIT"] = "1" if eng == "jit" else "0"
-    c = rt.Circuit(os.path.join(d, fname + ".cwt"), os.path.join(d, fname + ".dat"), os.path.join(d, fname + ".r1cs"))
+    c = rt.Circuit(os.path.join(d, fname + ".cwt"), os.path.join(d, name + ".dat"), os.path.join(d, name + ".r1cs"))   # variants share the tables
     b = c.batch(B)
     assert b.bitmode and b.jit == (eng == "jit")
     rng = np.random.default_rng(1)

@@ -42,6 +42,4 @@ for spec in sys.argv[2:]:
     jp.code = bitjit.assemble(asm)
     p = base + "_" + tag
     writers.write_tape(p + ".cwt", tapes, bt, jp)
-    for ext in (".dat", ".r1cs"):
-        shutil.copyfile(base + ext, p + ext)
     print(tag, "%.0f s" % (time.time() - t0), json.dumps(jp.stats), flush=True)
