@@ -21,6 +21,9 @@
 #include "fp256.hip.h"
 
 
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 // ---- table layout ---------------------------------------------------------------------------------------------------------
 // Two layouts share every kernel below through the shift `sh` (a launch parameter):
 //   sh = 0   T[group][slot]                      the interpreter's table: a group's slots are consecutive uint64 (rows of 64 slots)
@@ -66,6 +69,8 @@ __global__ void __launch_bounds__(64) cw_bits_ingest_kernel(const uint4 *__restr
     const bool have = k < n_in;
     const uint32_t i0 = g * 64, ni = min(64u, batch - i0);
     uint64_t mine = 0, badmask = 0;
+    // (four instances in flight per wave with streaming loads were measured SLOWER: 26.4 ms against 24.4 ms for the 137 GB image
+    // of 2 M instances of Sha256(2048) - 5.2 against 5.6 TB/s)
     for (uint32_t ii = 0; ii < ni; ii++) {
         uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
         if (have) {
@@ -110,8 +115,6 @@ __global__ void __launch_bounds__(64) cw_bits_ingest_kernel(const uint4 *__restr
                               // loads wait behind slow stores: 1.24 -> 0.91 ms for Sha256(2048) x 65 536 (tools/bits_shape_bench.py)
 #endif
 #define BITS_OOR 0xFFFFFFF0u
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // v_bitop3_b32 table of a function of (s0, s1, s2): bit (s0 << 2 | s1 << 1 | s2)
 constexpr uint32_t bitop3_stage1() {           // (a, b, K) -> K ? a & b : a ^ b
