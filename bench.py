@@ -848,6 +848,17 @@ def main():
                          "public_signals_per_instance": circ.n_public},
             "cpu_baseline": None,
         }
+        if args.shard_of:
+            # BASELINE config 4 is ONE job of `total_batch` instances over `shard_of` GPUs: every GPU runs its shard once.  The
+            # steady-state `value` above keeps several shards in flight on this GPU; the job itself costs one shard's latency
+            # (a dependency chain, the same on every rank) plus the final gather of status words and public signals.
+            gather_bytes = (4 + 32 * circ.n_public) * args.total_batch
+            gather_ms = 0.05 + gather_bytes / 50e9 * 1e3          # RCCL gather over xGMI: ~50 us + bytes at ~50 GB/s into rank 0 (assumption, unmeasured)
+            one = isolated["ms_per_step"]
+            out["one_shot_job"] = {"shard_instances": B, "shard_ms_alone": one, "gather_ms_assumed": gather_ms,
+                                   "predicted_job_ms": one + gather_ms, "ranks": args.shard_of,
+                                   "predicted_witnesses_per_s": args.total_batch / ((one + gather_ms) * 1e-3),
+                                   "same_job_on_one_gpu_note": "run --total-batch %d without --shard-of for the one-GPU time of the whole job" % args.total_batch}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cp, args.workload)
         print(json.dumps(out))

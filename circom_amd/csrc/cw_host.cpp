@@ -2366,6 +2366,72 @@ extern "C" int cw_write_wtns(cw_batch *b, uint32_t instance, const char *path) {
     return CW_OK;
 }
 
+// The whole batch as ONE compact container (`<name>.wtnsb`, format below; reader + expander: circom_amd/wtnsb.py).  The
+// reference's product is one `.wtns` per witness (main.cpp:288-334: 32 bytes per element); for a boolean circuit that image
+// is 256x the information (Sha256(2048): 32 MB per instance against 18.7 KB of bit planes), and producing it bounds a
+// bit-plane batch to ~150 K witnesses/s however fast it was generated.  A prover that ingests batches takes the container
+// and widens the elements it needs where it needs them; every `.wtns` of the batch is recoverable from it bit for bit.
+//   "wtnb" | u32 version = 1 | u32 kind (0 = field elements, 1 = bit planes) | u32 n8 | prime, n8 bytes | u32 n_witness | u32 batch
+//   kind 0:  batch x n_witness x n8 bytes, canonical little-endian, instance-major (= the section-2 bodies of the .wtns files)
+//   kind 1:  u64 slots | u32 shift | u32 groups | n_witness x u32 (slot of every witness element) |
+//            groups x slots x u64: the bit table; element (group g, slot s) = word (((g >> shift) * slots + s) << shift) +
+//            (g & ((1 << shift) - 1)), bit i = instance 64 g + i; slot 0 / 1 = the constants 0 / 1 |
+//            u32 n_wide | n_wide x { u32 instance | n_witness x n8 bytes }: instances re-run by the 256-bit schedule (inputs
+//            that are not 0/1, tripped assertions) carry their field elements
+extern "C" int cw_write_wtnsb(cw_batch *b, const char *path) {
+    if (!b || !path) return fail(CW_EINVAL, "null argument");
+    NEED_DEVICE(b);
+    if (!b->ran) return fail(CW_ESTATE, "cw_write_wtnsb before cw_run");
+    cw_circuit *c = b->c;
+    HIPCHK(hipSetDevice(b->device));
+    if (int rc = bits_resolve(b)) return rc;
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(CW_EIO, std::string("cannot open for writing: ") + path);
+    const uint32_t version = 1, kind = b->bitmode ? 1u : 0u, n8 = 32, nw = c->n_witness, batch = b->batch;
+    bool ok = fwrite("wtnb", 4, 1, f) == 1;
+    ok &= fwrite(&version, 4, 1, f) == 1 && fwrite(&kind, 4, 1, f) == 1 && fwrite(&n8, 4, 1, f) == 1;
+    ok &= fwrite(c->q.w, 32, 1, f) == 1 && fwrite(&nw, 4, 1, f) == 1 && fwrite(&batch, 4, 1, f) == 1;
+    const size_t row = (size_t)nw * 32;
+    int rc = CW_OK;
+    if (!b->bitmode) {
+        const uint32_t per = (uint32_t)std::max<size_t>(1, std::min<size_t>(batch, ((size_t)256 << 20) / std::max<size_t>(row, 1)));
+        std::vector<uint8_t> buf((size_t)per * row);
+        for (uint32_t done = 0; done < batch && rc == CW_OK && ok; done += per) {
+            const uint32_t n = std::min(per, batch - done);
+            rc = cw_get_witnesses(b, done, n, buf.data());
+            if (rc == CW_OK) ok &= fwrite(buf.data(), row, n, f) == n;
+        }
+    } else {
+        const uint64_t slots = b->bits_slots;
+        const uint32_t shift = b->bits_sh, groups = b->n_groups_padded;
+        ok &= fwrite(&slots, 8, 1, f) == 1 && fwrite(&shift, 4, 1, f) == 1 && fwrite(&groups, 4, 1, f) == 1;
+        std::vector<uint32_t> wslot(nw);
+        for (uint32_t k = 0; k < nw; k++) wslot[k] = (*b->bits_sigslot)[c->w2s[k]];
+        ok &= fwrite(wslot.data(), 4, nw, f) == nw;
+        const size_t total = (size_t)b->t_bytes, piece = (size_t)256 << 20;
+        std::vector<uint8_t> buf(std::min(total, piece));
+        for (size_t at = 0; at < total && ok; at += piece) {
+            const size_t n = std::min(piece, total - at);
+            hipError_t e = hipMemcpy(buf.data(), (const uint8_t *)b->d_T + at, n, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) {
+                fclose(f);
+                return fail(CW_EDEVICE, std::string("copying the bit table: ") + hipGetErrorString(e));
+            }
+            ok &= fwrite(buf.data(), 1, n, f) == n;
+        }
+        const uint32_t n_wide = (uint32_t)b->fb_inst.size();
+        ok &= fwrite(&n_wide, 4, 1, f) == 1;
+        std::vector<uint8_t> w(row);
+        for (uint32_t k = 0; k < n_wide && rc == CW_OK && ok; k++) {
+            rc = cw_get_witness(b, b->fb_inst[k], w.data());
+            if (rc == CW_OK) ok &= fwrite(&b->fb_inst[k], 4, 1, f) == 1 && fwrite(w.data(), 1, row, f) == row;
+        }
+    }
+    ok &= fclose(f) == 0;
+    if (rc != CW_OK) return rc;
+    return ok ? CW_OK : fail(CW_EIO, std::string("short write: ") + path);
+}
+
 // Many instances -> many .wtns files (one bulk device transpose per 256 MiB instead of one gather per instance):
 // `pattern` is a printf pattern with one %u / %d (the instance number).  What a prover farm consumes.
 extern "C" int cw_write_wtns_many(cw_batch *b, uint32_t first, uint32_t count, const char *pattern) {

@@ -94,6 +94,7 @@ _SIGS = {
     "cw_write_wtns": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p]),
     "cw_get_r1cs_first_bad": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cw_write_wtns_many": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p]),
+    "cw_write_wtnsb": (C.c_int, [C.c_void_p, C.c_char_p]),
     "cw_explain": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_size_t]),
     "cw_n_log_statements": (C.c_uint32, [C.c_void_p]),
     "cw_get_log": (C.c_int64, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_size_t]),
@@ -320,6 +321,10 @@ class Batch:
 
     def write_wtns_many(self, first: int, count: int, pattern: str):
         _chk(lib().cw_write_wtns_many(self.h, first, count, os.fsencode(str(pattern))))
+
+    def write_wtnsb(self, path):
+        """the whole batch as one compact container (circom_amd/wtnsb.py reads / expands it)"""
+        _chk(lib().cw_write_wtnsb(self.h, os.fsencode(str(path))))
 
     def explain(self, instance: int, sym_path=None) -> str:
         buf = C.create_string_buffer(1 << 16)

@@ -156,6 +156,11 @@ int cw_get_signal(cw_batch *b, uint32_t instance, uint32_t slot, uint8_t out[32]
 int cw_write_wtns(cw_batch *b, uint32_t instance, const char *path);
 /* `count` .wtns files from one bulk device transpose; `pattern` = printf pattern with one %u (instance number) */
 int cw_write_wtns_many(cw_batch *b, uint32_t first, uint32_t count, const char *pattern);
+/* The whole batch as ONE compact container (<name>.wtnsb): field elements for 256-bit batches, the BIT TABLE (1 bit per
+ * distinct signal value and instance + the slot of every witness element + full values of the instances the 256-bit schedule
+ * re-ran) for bit-plane batches.  Format: csrc/cw_host.cpp at cw_write_wtnsb; reader / expander circom_amd/wtnsb.py
+ * (`expand(i)` = the bytes cw_write_wtns writes for instance i, main.cpp:288-334). */
+int cw_write_wtnsb(cw_batch *b, const char *path);
 /* human-readable trace of one instance into out[out_len]: decoded status word and, for a violated constraint, its index
  * and every wire with its name from <name>.sym (may be NULL) and value — the batch counterpart of the trace the
  * reference prints before aborting (c_code_generator.rs:461-468, calcwit.cpp:104-114) */

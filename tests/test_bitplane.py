@@ -656,3 +656,30 @@ def test_gpu_packed_inputs_and_chunked_egress(tmp_path, engine):
     with pytest.raises(Exception):
         b3.set_inputs_bits(masks[:1])
     b.close(); b2.close(); b3.close(); c.close()
+
+
+@pytest.mark.gpu
+def test_gpu_compact_container_round_trips_to_the_wtns_files(tmp_path, engine):
+    """cw_write_wtnsb: one file for the batch (bit planes + slot map + the field elements of the instances the 256-bit schedule
+    re-ran); circom_amd/wtnsb.py expands it to exactly the bytes cw_write_wtns writes, for boolean and non-boolean instances"""
+    from circom_amd import wtnsb
+    cp, c = _gpu(tmp_path, Program(BitGadget(16)), "bg16w")
+    fc = cp.flat
+    B = 150
+    rows = _rand_bits(fc, B, 31)
+    rows[70][3] = 5                                              # not a bit: re-run wide, carried as field elements
+    b = c.batch(B)
+    b.set_inputs(rows)
+    b.run(); b.check_r1cs(); b.sync()
+    p = tmp_path / "batch.wtnsb"
+    b.write_wtnsb(p)
+    w = wtnsb.load(p)
+    assert (w.kind, w.batch, w.n_witness, w.prime) == (1, B, c.n_witness, c.q) and 70 in w.wide
+    assert w.shift == (5 if engine == "jit" else 0)
+    for i in (0, 63, 64, 70, 149):
+        q = tmp_path / ("i%d.wtns" % i)
+        b.write_wtns(i, q)
+        assert w.expand(i) == q.read_bytes(), i
+    # the container is the compact form: ~1 bit per signal value and instance against 32 bytes per element
+    assert p.stat().st_size < B * c.n_witness * 32 // 4
+    b.close(); c.close()

@@ -369,3 +369,28 @@ def test_bulk_wtns_files_and_failure_trace(tmp_path):
             assert " = %d;" % w[sgn] in text
     assert "instance 5" in b.explain(5)                 # without a .sym: signal numbers
     b.close(); c.close()
+
+
+@pytest.mark.gpu
+def test_compact_container_of_a_256_bit_batch(tmp_path):
+    """cw_write_wtnsb on the 256-bit engine (Poseidon): field elements, instance-major; expand(i) = the .wtns of instance i"""
+    from circom_amd import runtime as rt, wtnsb
+    from circom_amd.compiler import compile_program
+    from circom_amd.frontend.dsl import Program
+    from circom_amd.circuits.poseidon import Poseidon
+    cp = compile_program(Program(Poseidon(2)), str(tmp_path), "poseidon2", sym=False, strands=(4,))
+    c = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
+    B = 100
+    rng = np.random.default_rng(2)
+    b = c.batch(B)
+    b.set_inputs([[int.from_bytes(rng.bytes(31), "little") for _ in range(2)] for _ in range(B)])
+    b.run(); b.sync()
+    p = tmp_path / "p.wtnsb"
+    b.write_wtnsb(p)
+    w = wtnsb.load(p)
+    assert (w.kind, w.batch, w.n_witness, w.prime) == (0, B, c.n_witness, c.q)
+    for i in (0, 57, 99):
+        q = tmp_path / ("i%d.wtns" % i)
+        b.write_wtns(i, q)
+        assert w.expand(i) == q.read_bytes()
+    b.close(); c.close()
