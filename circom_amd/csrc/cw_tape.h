@@ -49,7 +49,7 @@ struct CwDRow {      // 32 bytes, one scalar dwordx8 load
 // F_LDX / F_STX: b = index register | array length << 16 (address through Fr_toInt, generic/fr.cpp:1146-1170).
 enum : uint32_t { F_JZ = 100, F_JMP = 101, F_LDX = 102, F_STX = 103, F_RET = 104, F_DIV = 105 };
 #define FN_CONST 0x80000000u
-#define CW_CALL_STEP_LIMIT (1u << 20)   // instructions per call and lane before the instance is flagged (runaway loop)
+#define CW_CALL_STEP_LIMIT (1u << 24)   // instructions per call and lane before the instance is flagged (runaway loop)
 
 // Field parameters, passed by value as a kernel argument (lands in SGPRs).
 // The device Montgomery radix is R' = 2^261 (9 limbs x 29 bits, see fp256.hip.h), NOT the reference's

@@ -579,9 +579,11 @@ class Ctx:
         self._row(O.ASSERT_NZ, O.K_NONE, 0, cond)
 
     # ---- circom functions with run-time control flow (tier 2, frontend/rtcode.py) ---------------------------------
-    def function(self, name: str, n_args: int, build):
-        """`function name(...) {...}`: built once per program (build(f, *args) -> results, see rtcode.RtFunction)"""
-        return self.prog.function(name, n_args, build)
+    def function(self, name: str, n_args: int, build, native=None):
+        """`function name(...) {...}`: built once per program (build(f, *args) -> results, see rtcode.RtFunction).
+        native = (kind, n, k, modulus): the function is a pure big-integer routine with this closed form
+        (circuits/bigint_func.py native_eval): oracle and device may compute it directly instead of interpreting the body"""
+        return self.prog.function(name, n_args, build, native)
 
     def call(self, fn, args):
         """`name(args)` inside `<--` code: CallBucket (call_bucket.rs:466-533).  The function's registers are a block of
@@ -721,11 +723,12 @@ class Program:
             self.constants.append(v)
         return i
 
-    def function(self, name: str, n_args: int, build):
+    def function(self, name: str, n_args: int, build, native=None):
         fn = self.functions_by_name.get(name)
         if fn is None:
             from .rtcode import RtFunction
             fn = RtFunction(name, n_args, build, self.fp)
+            fn.native = native
             # constants of the body live in the program-wide constant table like every other constant
             fn.code = [tuple((x[0], self.const_id(x[1])) if isinstance(x, tuple) and len(x) == 2 and x[0] == 'c' else x
                              for x in ins) for ins in fn.code]

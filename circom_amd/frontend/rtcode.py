@@ -25,7 +25,7 @@ from __future__ import annotations
 from .. import opcodes as O
 
 F_JZ, F_JMP, F_LDX, F_STX, F_RET = 100, 101, 102, 103, 104
-CALL_STEP_LIMIT = 1 << 20
+CALL_STEP_LIMIT = 1 << 24
 
 
 class RtError(Exception):
@@ -197,6 +197,7 @@ class RtFunction:
         self.code_built, self.n_regs_built, self.ret_base_built = self.code, self.n_regs, self.ret_base   # as written (tests)
         self._optimise()
         self.id = None                # set by Program.register_function
+        self.native = None            # (kind, n, k, modulus): closed form of a pure big-integer function (circuits/bigint_func.py)
 
     # ---- bytecode optimisation ------------------------------------------------------------------------------------
     # The builder is SSA-flavoured: every operator result and every `var` gets a fresh register and `var = expr` is an
@@ -396,4 +397,4 @@ class RtFunction:
     # ---- plain-data form for the oracle / emitters ------------------------------------------------------------------
     def as_data(self):
         return {"name": self.name, "n_args": self.n_args, "n_ret": self.n_ret, "ret_base": self.ret_base, "n_regs": self.n_regs,
-                "code": [list(c) for c in self.code]}
+                "code": [list(c) for c in self.code], "native": self.native}

@@ -17,7 +17,8 @@ LT, GT, LEQ, GEQ, EQ, NEQ, LAND, LOR, LNOT = range(15, 24)
 SELECT, ASSERT_EQ, ASSERT_NZ, RUN, CALL, LOG = range(24, 30)
 K_SIG, K_TMP, K_CONST, K_NONE = 0, 1, 2, 3
 F_JZ, F_JMP, F_LDX, F_STX, F_RET = 100, 101, 102, 103, 104      # circom_amd/frontend/rtcode.py
-CALL_STEP_LIMIT = 1 << 20
+CALL_STEP_LIMIT = 1 << 24
+USE_NATIVE = True            # closed forms for functions that carry a `native` tag (False: always interpret the bytecode)
 
 _BIN = {ADD: "add", SUB: "sub", MUL: "mul", DIV: "div", IDIV: "idiv", MOD: "mod", POW: "pow",
         SHL: "shl", SHR: "shr", BAND: "band", BOR: "bor", BXOR: "bxor", LT: "lt", GT: "gt",
@@ -31,6 +32,17 @@ def run_function(f: Field, fn: dict, regs: list, base: int, constants) -> bool:
     compute_bucket.rs:361-363).  regs[base + r] = register r.  Returns False on an arithmetic error (integer division by
     zero, an array index outside its array, more than CALL_STEP_LIMIT instructions)."""
     q = f.q
+    nat = fn.get("native")
+    if nat is not None and USE_NATIVE:
+        # a pure big-integer function with a closed form (circuits/bigint_func.py): the same values the body computes, without
+        # ~10^6 interpreted steps per modular inverse; tests/test_ecdsa.py pins the two against each other and against the
+        # reference runtime executing the body
+        from circom_amd.circuits.bigint_func import native_eval
+        kind, n, k, modulus = nat
+        res = native_eval(kind, n, k, modulus, [regs[base + r] for r in range(fn["n_args"])])
+        for j, v in enumerate(res):
+            regs[base + fn["ret_base"] + j] = v
+        return True
     code = fn["code"]
     bins = {k: getattr(f, v) for k, v in _BIN.items()}
     uns = {k: getattr(f, v) for k, v in _UN.items()}
