@@ -495,12 +495,16 @@ static int load_tape(cw_circuit *c, const char *path) {
     }
     // circom functions (device bytecode): every register, constant, jump target and array window is checked here once
     std::vector<uint32_t> fn_regs;
+    std::vector<FpParams> fn_aux;                 // field parameters of the foreign primes of native big-integer functions
+    std::vector<std::pair<uint32_t, uint32_t>> fn_native;     // (function, aux index)
     for (uint32_t fi = 0; fi < n_functions; fi++) {
-        if (off + 8 > b.size()) return fail(CW_EIO, "tape functions truncated");
-        uint32_t fh[2];
-        memcpy(fh, b.data() + off, 8);
-        off += 8;
-        const uint32_t n_regs = fh[0], n_ins = fh[1];
+        if (off + 52 > b.size()) return fail(CW_EIO, "tape functions truncated");
+        uint32_t fh[5];
+        memcpy(fh, b.data() + off, 20);
+        U256 fmod;
+        memcpy(fmod.w, b.data() + off + 20, 32);
+        off += 52;
+        const uint32_t n_regs = fh[0], n_ins = fh[1], nat_kind = fh[2], nat_n = fh[3], nat_k = fh[4];
         if (n_regs == 0 || n_regs >= (1u << 16) || n_ins == 0 || n_ins > (1u << 24) || (size_t)n_ins * 16 > b.size() - off)
             return fail(CW_EIO, "tape function: bad size");
         const uint32_t first = (uint32_t)(c->fn_code.size() / 4);
@@ -533,8 +537,34 @@ static int load_tape(cw_circuit *c, const char *path) {
         c->fn_tab.push_back(n_ins);
         c->fn_tab.push_back(n_regs);
         c->fn_tab.push_back(0);
+        if (nat_kind) {
+            // a pure big-integer function with a closed form (circuits/bigint_func.py): mod_inv(a[k]) -> [k];
+            // ec_add(x1, y1, x2, y2) / ec_double(x1, y1) -> lambda, x3, y3 - arguments in the first registers, results behind them
+            const uint32_t n_args = nat_kind == 1 ? nat_k : nat_kind == 2 ? 4 * nat_k : 2 * nat_k;
+            const uint32_t n_ret = nat_kind == 1 ? nat_k : 3 * nat_k;
+            if (nat_kind > 3 || nat_n == 0 || nat_n > 64 || nat_k == 0 || nat_k > 15 || nat_n * nat_k > 256 || n_args + n_ret > n_regs ||
+                !prime_supported(fmod) || u256_bits(fmod) > nat_n * nat_k)
+                return fail(CW_EIO, "tape function: bad native tag");
+            fn_native.push_back({fi, (uint32_t)fn_aux.size()});
+            fn_aux.push_back(make_params(fmod));
+            c->fn_tab[c->fn_tab.size() - 1] = nat_kind | (nat_k << 4) | (nat_n << 8);
+        }
         fn_regs.push_back(n_regs);
         c->need_full = true;               // the interpreter lives in the full-operator kernel variant
+    }
+    // the field parameters of the native functions travel behind the function table (uint4 units from its start)
+    {
+        const uint32_t aux_words = (uint32_t)((sizeof(FpParams) + 15) / 16 * 4);
+        for (auto &na : fn_native) {
+            const uint32_t at = n_functions + na.second * (aux_words / 4);
+            if (at >= (1u << 16)) return fail(CW_EIO, "tape: too many native functions");
+            c->fn_tab[(size_t)na.first * 4 + 3] |= at << 16;
+        }
+        for (auto &P2 : fn_aux) {
+            const size_t w0 = c->fn_tab.size();
+            c->fn_tab.resize(w0 + aux_words, 0);
+            memcpy(&c->fn_tab[w0], &P2, sizeof(FpParams));
+        }
     }
     // log statements: strings and references to the hidden signals
     {

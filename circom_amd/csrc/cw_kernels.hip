@@ -342,10 +342,73 @@ __device__ __forceinline__ bool fn_index(const fe &v, uint32_t n, uint32_t *out)
     *out = v.v[0];
     return hi == 0 && v.v[0] < n;
 }
+// ---- native big-integer functions ---------------------------------------------------------------------------------------
+// circom-ecdsa's witness hints (`mod_inv` = mod_exp(a, p - 2), `secp256k1_addunequal_func`, `secp256k1_double_func`) are pure
+// functions of their arguments: k limbs of n bits per number, arithmetic modulo a FOREIGN prime (secp256k1's p or group
+// order inside a BLS12-381 circuit).  Interpreting their bytecode costs ~10^6 instructions per modular inverse; the same
+// values come from this file's own field code instantiated for the foreign prime - binary-GCD inverse, canonical products -
+// whose parameters the loader appended to the function table.  tests/test_ecdsa.py: device native == device bytecode ==
+// oracle == reference runtime.  ftab[fn].w = kind | k << 4 | n << 8 | (uint4 offset of the FpParams) << 16.
+__device__ __forceinline__ fe big_pack(const char *regs, uint32_t first, uint32_t k, uint32_t n, const EvalCtx &c) {
+    fe r = fe_zero();
+    for (uint32_t i = 0; i < k; i++) {
+        const fe l = fn_operand(first + i, regs, c);
+        const uint64_t v = ((uint64_t)l.v[1] << 32) | l.v[0];
+        const uint32_t sh = n * i, w = sh >> 5, bs = sh & 31u;                  // wave-uniform
+        const uint64_t lo = v << bs;
+        const uint32_t hi = bs ? (uint32_t)(v >> (64 - bs)) : 0u;
+        FE_UNROLL for (int j = 0; j < 8; j++)
+            r.v[j] |= ((uint32_t)j == w ? (uint32_t)lo : 0u) | ((uint32_t)j == w + 1 ? (uint32_t)(lo >> 32) : 0u) | ((uint32_t)j == w + 2 ? hi : 0u);
+    }
+    return r;
+}
+__device__ __forceinline__ void big_unpack(char *regs, uint32_t first, uint32_t k, uint32_t n, const EvalCtx &c, const fe &x) {
+    for (uint32_t i = 0; i < k; i++) {
+        fe l = fe_shr_raw(x, n * i);
+        const uint64_t m = n >= 64 ? ~0ull : ((1ull << n) - 1);
+        l.v[0] &= (uint32_t)m;
+        l.v[1] &= (uint32_t)(m >> 32);
+        FE_UNROLL for (int j = 2; j < 8; j++) l.v[j] = 0;
+        fn_store(first + i, regs, c, l);
+    }
+}
+__device__ __noinline__ void eval_call_native(uint32_t w, char *regs, const EvalCtx &c) {
+    const uint32_t kind = w & 15u, k = (w >> 4) & 15u, n = (w >> 8) & 255u;
+    const FpParams P2 = *(const FpParams *)(c.ftab + (w >> 16));               // wave-uniform: scalar loads
+    if (kind == 1) {                                                          // mod_inv(a) -> a^-1 (0 for 0)
+        const fe a = fe_csub_q(big_pack(regs, 0, k, n, c), P2);
+        big_unpack(regs, k, k, n, c, fe_inv(a, P2));
+        return;
+    }
+    const fe x1 = big_pack(regs, 0, k, n, c), y1 = big_pack(regs, k, k, n, c);
+    fe num, den, xo;
+    if (kind == 2) {                                                          // chord through (x1, y1), (x2, y2)
+        xo = big_pack(regs, 2 * k, k, n, c);
+        den = fe_sub(xo, x1, P2);
+        num = fe_sub(big_pack(regs, 3 * k, k, n, c), y1, P2);
+    } else {                                                                  // tangent: 3 x1^2 / (2 y1)
+        xo = x1;
+        const fe xx = fe_mul2(x1, x1, P2);
+        num = fe_add(fe_add(xx, xx, P2), xx, P2);
+        den = fe_add(y1, y1, P2);
+    }
+    const fe lam = fe_mul2(num, fe_inv(den, P2), P2);
+    const fe x3 = fe_sub(fe_sub(fe_mul2(lam, lam, P2), x1, P2), xo, P2);
+    const fe y3 = fe_sub(fe_mul2(lam, fe_sub(x1, x3, P2), P2), y1, P2);
+    const uint32_t rb = kind == 2 ? 4 * k : 2 * k;
+    big_unpack(regs, rb, k, n, c, lam);
+    big_unpack(regs, rb + k, k, n, c, x3);
+    big_unpack(regs, rb + 2 * k, k, n, c, y3);
+}
+
 __device__ __forceinline__ void eval_call_body(uint32_t fn, uint64_t reg_off, uint32_t row_id, uint32_t &st, const EvalCtx &c, const FpParams &P) {
     const uint4 ft = c.ftab[fn];
     const uint4 *code = c.fcode + ft.x;
     char *regs = (char *)c.Vb + reg_off;
+    if (ft.w & 15u) {
+        eval_call_native(ft.w, regs, c);
+        return;
+    }
     uint32_t pc = 0, steps = 0;
     bool done = false;
     const uint32_t lane = __lane_id();

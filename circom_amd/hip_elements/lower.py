@@ -1048,6 +1048,9 @@ _FN_ALU = {O.COPY: D_COPY, O.ADD: D_ADD, O.SUB: D_SUB, O.NEG: D_NEG, O.MUL: D_MU
            O.GT: D_GT, O.LEQ: D_LEQ, O.GEQ: D_GEQ, O.EQ: D_EQ, O.NEQ: D_NEQ, O.LAND: D_LAND, O.LOR: D_LOR, O.LNOT: D_LNOT}
 
 
+NATIVE_KINDS = {"mod_inv": 1, "ec_add": 2, "ec_double": 3}     # csrc/cw_kernels.hip eval_call_native
+
+
 def _encode_function(fn, cid, q):
     """rtcode bytecode -> device form (see the D_CALL comment at the top); constants go through the schedule's table"""
     from ..frontend import rtcode as R
@@ -1074,7 +1077,16 @@ def _encode_function(fn, cid, q):
             out[i] = (F_STX, d, opnd(a, consts), b[0] | (b[1] << 16))
         else:
             out[i] = (_FN_ALU[op], d, opnd(a, consts), opnd(b, consts))
-    return fn["n_regs"], out
+    # native closed form (circuits/bigint_func.py): the device computes the result directly when the modulus is a prime its
+    # field code takes (225..256 bits, with n k bits = its limb capacity); otherwise the body is interpreted
+    native = None
+    nat = fn.get("native")
+    if nat is not None:
+        kind, n_, k_, modulus = nat
+        if 225 <= modulus.bit_length() <= 256 and modulus & 1 and n_ <= 64 and k_ <= 15 and n_ * k_ >= modulus.bit_length() and n_ * k_ <= 256 \
+                and fn["ret_base"] == fn["n_args"]:
+            native = (NATIVE_KINDS[kind], n_, k_, modulus)
+    return fn["n_regs"], out, native
 
 
 def _finish_pipe(fc, stream, dconsts, lconsts, lcid, witness_map, pipe, stats):

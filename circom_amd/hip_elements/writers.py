@@ -111,7 +111,9 @@ def write_tape(path, tapes, bittape=None, jit=None):
             lconsts         n_lconsts x n64*8 bytes (coef*R' of D_DOTC terms; the runtime keeps them as 29-bit limbs)
             witness2signal  n_witness x u32
             input names     per name  u32 len | bytes | u32 start | u32 size
-            functions       n_functions x { u32 n_regs | u32 n_ins | n_ins x 4 x u32 }   (device bytecode, lower.py D_CALL)
+            functions       n_functions x { u32 n_regs | u32 n_ins | u32 native kind (0 none, 1 mod_inv, 2 ec_add, 3 ec_double) |
+                            u32 limb bits | u32 limbs | 32 bytes modulus | n_ins x 4 x u32 }   (device bytecode, lower.py D_CALL; the
+                            native closed form of a pure big-integer function, circuits/bigint_func.py)
             log program     n_log_statements x { u32 flat operation that ends the statement | u32 n_items |
                             n_items x { u32 0 | u32 len | bytes   (a string)   or   u32 1 | u32 j   (the j-th logged value) } }
             per variant     u32 n_strands | u32 n_tslots | u32 n_rows | u32 n_extras | u32 n_lds | u32 n_terms | u32 kind | u32 shape
@@ -150,8 +152,9 @@ def write_tape(path, tapes, bittape=None, jit=None):
         for name, start, size in t0.inputs:
             b = name.encode()
             f.write(struct.pack("<I", len(b)) + b + struct.pack("<II", start, size))
-        for n_regs, fcode in t0.functions:       # circom functions with run-time control flow (lower.py D_CALL)
-            f.write(struct.pack("<2I", n_regs, len(fcode)))
+        for n_regs, fcode, native in t0.functions:       # circom functions with run-time control flow (lower.py D_CALL)
+            kind, n_, k_, modulus = native or (0, 0, 0, 0)
+            f.write(struct.pack("<5I", n_regs, len(fcode), kind, n_, k_) + int(modulus).to_bytes(32, "little"))
             f.write(np.ascontiguousarray(fcode, dtype="<u4").tobytes())
         for at, items in getattr(t0, "log_prog", ()):
             f.write(struct.pack("<2I", at, len(items)))

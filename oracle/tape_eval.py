@@ -424,10 +424,17 @@ def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict,
             elif op == D_BIT:
                 res = (a >> b_) & 1 if b_ < 256 else 0
             elif op == D_CALL:                # a = function id, b = first register slot (pinned temps)
-                n_regs, fcode = functions[a_]
+                n_regs, fcode, native = functions[a_]
                 for k in range(n_regs):       # the interpreter reads and writes its registers in the value table
                     writer[(1, b_ + k)] = (state["epoch"], s)
-                if not run_dev_function(f, fcode, tmp, b_, consts):
+                if native is not None and USE_NATIVE:      # the device computes the closed form (eval_call_native)
+                    from circom_amd.circuits.bigint_func import native_eval
+                    kind, n_, k_, modulus = native
+                    kname = {1: "mod_inv", 2: "ec_add", 3: "ec_double"}[kind]
+                    n_args = {1: k_, 2: 4 * k_, 3: 2 * k_}[kind]
+                    for j, v in enumerate(native_eval(kname, n_, k_, modulus, [tmp[b_ + x] for x in range(n_args)])):
+                        tmp[b_ + n_args + j] = v
+                elif not run_dev_function(f, fcode, tmp, b_, consts):
                     fail(s, 2, r)
             elif op == D_SELECT:
                 sel[s] = a != 0               # latched lane mask; no value

@@ -151,7 +151,7 @@ def test_loader_validates_function_bytecode(tmp_path):
     from circom_amd import runtime as rt
     cp = compile_program(Program(Pick()), str(tmp_path), "pickfn", sym=False, strands=(1,))
     rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path).close()
-    n_regs, code = cp.tape.functions[0]
+    n_regs, code, _native = cp.tape.functions[0]
     tape = bytearray(open(cp.tape_path, "rb").read())
     blob = code.astype("<u4").tobytes()
     at = bytes(tape).index(blob)
