@@ -41,7 +41,7 @@ LONE_WAVE_CLK_PER_INST = 4.1       # ONE wave issues at most one instruction of 
 BITS_VALU_PER_VROW = 10            # cw_bits_eval_kernel<64>, from the disassembly: 3 operand offsets, 2 mask expansions, 1 result
 BITS_INSTS_PER_VROW = 15           # offset, 4 v_bitop3  + 3 ds_read_b64, 1 ds_write_b64, 1 s_waitcnt
 JIT_BATCH = 1 << 21                # the emitted bit-plane code runs one wave per 2 048 instances: 1 024 waves = one per SIMD
-DEFAULT_BATCH = {"bigmultmodp": 8192, "sha256_2048": JIT_BATCH, "sha256_512": 4096, "poseidon2": 65536, "semaphore20": 8192, "semaphore20p": 8192}
+DEFAULT_BATCH = {"bigmultmodp": 8192, "ecdsa_verify": 1024, "sha256_2048": JIT_BATCH, "sha256_512": 4096, "poseidon2": 65536, "semaphore20": 8192, "semaphore20p": 8192}
 
 
 def _semaphore_shape(name: str):
@@ -63,6 +63,12 @@ def make_program(name: str):
         from circom_amd.circuits.eddsa import SemaphoreStyle
         levels, proj = _semaphore_shape(name)
         return Program(SemaphoreStyle(levels, proj))
+    if name == "ecdsa_verify":
+        # BASELINE config 5: secp256k1 ECDSA verification (circom-ecdsa's shape) over the BLS12-381 scalar field: 2.47 M signals,
+        # 2.49 M constraints; the witness hints are circom functions - long_div interpreted per lane, the three that contain a
+        # modular inverse through their native device routines
+        from circom_amd.circuits import secp256k1 as S
+        return Program(S.ECDSAVerifyNoPubkeyCheck(64, 4, S.SECP256K1, 8), prime="bls12381")
     if name.startswith("bigmultmodp"):
         # circom-ecdsa's field multiplication (a * b mod p on k limbs of n bits; the witness comes from the run-time
         # functions long_div / short_div with value-dependent branches = tier 2) on the BLS12-381 scalar field:
@@ -117,6 +123,15 @@ def get_compiled(name: str, batch: int, cache_root: str, rank: int, dist):
     fc = flatten(make_program(name))
     done = os.path.join(d, "done")
     cached = os.path.exists(done)
+    if cached and rank == 0:
+        # large artefacts travel compressed (tools/prebuild_cache.py: the .r1cs of the ECDSA verifier is 407 MB, 34 MB gzipped)
+        import gzip
+        import shutil
+        for ext in (".cwt", ".dat", ".r1cs"):
+            if not os.path.exists(p(ext)) and os.path.exists(p(ext) + ".gz"):
+                with gzip.open(p(ext) + ".gz", "rb") as fi, open(p(ext) + ".tmp", "wb") as fo:
+                    shutil.copyfileobj(fi, fo, 1 << 24)
+                os.replace(p(ext) + ".tmp", p(ext))
     if rank == 0 and not cached:
         os.makedirs(d, exist_ok=True)
         bittape = None if os.environ.get("CW_BITS", "1") == "0" else compiler.lower_bitplane(fc)
@@ -152,6 +167,14 @@ def synth_inputs(name: str, q: int, batch: int, n_inputs: int, seed: int):
         arr = np.zeros((batch, n_inputs, 32), dtype=np.uint8)
         arr[:, :, 0] = bits
         return arr
+    if name == "ecdsa_verify":
+        # valid (r, s, msghash, pubkey) tuples synthesised on the host: 32 distinct ones, tiled
+        import random
+        from circom_amd.circuits import secp256k1 as S
+        rnd = random.Random(seed)
+        pool = [np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in S.sign(S.SECP256K1, 64, 4, rnd)), dtype=np.uint8).reshape(n_inputs, 32)
+                for _ in range(min(batch, 32))]
+        return np.ascontiguousarray(np.stack([pool[i % len(pool)] for i in range(batch)]))
     if name.startswith("bigmultmodp"):
         n, k = ([int(x) for x in name.split("_")[1:3]] if "_" in name else (32, 3))
         import random

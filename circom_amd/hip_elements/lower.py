@@ -525,7 +525,12 @@ def _batch_inversions(rows, n_vtemps, cid):
     depth = {}
     inv_idx = []
     sel_depth = 0
-    for idx, r in enumerate(rows):
+    n_calls = 0                          # D_CALL rows seen so far: a batch never spans one (a call writes its results into
+    calls_at = {}                        # its register window behind the row's back: rows that read them cannot be re-ordered
+    for idx, r in enumerate(rows):       # around a deferred call by the data-flow rule below)
+        if r.op == D_CALL:
+            n_calls += 1
+        calls_at[idx] = n_calls
         lv = 0
         for k, v in _value_operands(r):
             if k == K_SIG or k == K_TMP:
@@ -547,7 +552,7 @@ def _batch_inversions(rows, n_vtemps, cid):
     groups = []
     for idx, lv in inv_idx:
         g = open_group.get(lv)
-        if g is None or idx - g[-1] > INV_WINDOW or len(g) >= INV_GROUP:
+        if g is None or idx - g[-1] > INV_WINDOW or len(g) >= INV_GROUP or calls_at[g[-1]] != calls_at[idx]:
             g = []
             groups.append(g)
             open_group[lv] = g
@@ -1329,19 +1334,51 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None, mont
     else:
         free = []
         release = {}
+        owner = {}                              # slot -> the temporary it currently holds
         for v, t in tmp_last.items():
             release.setdefault(t, []).append(v)
         for (r, fl, t) in plan[0]:
             for v in release.get(t, ()):        # operands are read before the destination is written
-                if v in slot_of and v not in pinned:
+                if v in slot_of and v not in pinned and owner.get(slot_of[v]) == v:
                     free.append(slot_of[v])
+                    del owner[slot_of[v]]
             if r != "B" and r.dk == K_TMP and r.dv in tmp_last and r.dv not in pinned:
+                # a temporary written more than once (`var` of a `<--` computation: the trace re-targets it) keeps its slot
+                # while it is live: a second slot for the later value would leave the first one owned by nobody and free
+                # it under a value that is still going to be read
+                if r.dv in slot_of and owner.get(slot_of[r.dv]) == r.dv:
+                    continue
                 if free:
                     sl = free.pop()
                 else:
                     sl = n_tslots
                     n_tslots += 1
                 slot_of[r.dv] = sl
+                owner[sl] = r.dv
+
+        # the allocation is checked by replaying the slots' contents: every table read of a temporary must find that very
+        # temporary in its slot (a clobbered slot is a wrong witness that only SOME inputs reveal)
+        content = {}
+        for (r, fl, t) in plan[0]:
+            if r == "B":
+                continue
+            ops = [(r.ak, r.av, fl[0]), (r.bk, r.bv, fl[1]), (r.ck, r.cv, False)]
+            if r.terms:
+                ops.extend((tm[0], tm[1], pf) for tm, pf in zip(r.terms, fl[2]))
+            for k, v, is_prev in ops:
+                if k == K_TMP and not is_prev and v in slot_of and v not in pinned:
+                    if content.get(slot_of[v]) != v:
+                        if __import__("os").environ.get("CW_SLOT_DEBUG"):
+                            print("DEBUG tmp", v, "def_time", def_time.get(n_signals + v), "tmp_last", tmp_last.get(v), "read at", t,
+                                  "clobberer", content.get(slot_of[v]), "its def", def_time.get(n_signals + content.get(slot_of[v], 0)))
+                        raise AssertionError("temp slot allocation: slot %d holds temporary %s when temporary %d is read at row %d (op %d)"
+                                             % (slot_of[v], content.get(slot_of[v]), v, t, r.op))
+            if r.dk == K_TMP and r.dv in slot_of and r.dv not in pinned:
+                content[slot_of[r.dv]] = r.dv
+            if r.extra:
+                for xk, xv in r.extra:
+                    if xk == K_TMP and xv in slot_of and xv not in pinned:
+                        content[slot_of[xv]] = xv
 
     # ---- pass E: encode ------------------------------------------------------------------------------------------------
 

@@ -163,6 +163,13 @@ def time_reference(cp, workload: str, seconds_budget: float = 15.0):
             pool = [b"".join(v.to_bytes(32, "little") for v in H.semaphore_inputs(q, int(workload[9:].rstrip("p") or 20), r)[0])
                     for _ in range(min(n, 16))]
             return b"".join(pool[i % len(pool)] for i in range(n))
+        if workload.startswith("ecdsa"):
+            # valid secp256k1 signatures (anything else trips the verifier's range checks: the reference aborts), a pool tiled
+            import random
+            from circom_amd.circuits import secp256k1 as S
+            r = random.Random(1)
+            pool = [b"".join(int(v).to_bytes(32, "little") for v in S.sign(S.SECP256K1, 64, 4, r)) for _ in range(min(n, 8))]
+            return b"".join(pool[i % len(pool)] for i in range(n))
         if workload.startswith("bigmultmodp"):
             # limbs of a, b < p (random field elements would trip the circuit's range checks: the reference aborts)
             import random

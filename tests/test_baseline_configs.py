@@ -4,8 +4,8 @@ C++ runtime (tests/golden/reference_wtns.json) sitting inside the batch among ra
   configs[1]  Poseidon(2) x 65 536                      256-bit engine, Montgomery-form signals
   configs[2]  Sha256(512) x 4 096                       bit-plane interpreter
   configs[3]  Semaphore-style, ONE GPU's shard x 1 024  256-bit engine, 16 strands
-  configs[4]  BigMultModP (circom-ecdsa's field multiplication, bls12381) x 1 024: tier 2; no reference golden in the
-              fixtures - checked against the oracle's restatement of the emitted calculator (oracle/tape_eval.py)
+  configs[4]  circom-ecdsa secp256k1 verification on the BLS12-381 prime: one GPU's shard of 128 of the 1 024 instances, with
+              the reference runtime's goldens inside; and its building block BigMultModP x 1 024 (tier 2) against the oracle
   the metric  Sha256(2048), 1 020 832 constraints, x 2 097 152: the circuit's EMITTED code (hip_elements/bitjit.py), packed
               inputs (the 32-byte image of that batch is 137 GB; bench.py builds it on the device)
 
@@ -132,6 +132,40 @@ def test_config4_building_block_bigmultmodp_at_1024(tmp_path):
         a_, b2, p = (sum(rows[i][s * k + j] << (n * j) for j in range(k)) for s in range(3))
         out = sum(sig[1 + j] << (n * j) for j in range(k))
         assert out == a_ * b2 % p
+    b.close(); c.close()
+
+
+@pytest.mark.gpu
+def test_config5_ecdsa_verify_shard_at_128(tmp_path):
+    """configs[4] = circom-ecdsa secp256k1 verification on the BLS12-381 prime, 1 024 instances over 8 GPUs: one GPU's shard of
+    128.  The verifier (circuits/secp256k1.py: 2.47 M signals, 2.49 M constraints) with the reference runtime's goldens
+    (tests/golden/reference_wtns_ecdsa.json: the reference executed the witness functions' BODIES) inside the batch; the
+    device computes the three hints that contain a modular inverse with its native routines, long_div in the per-lane
+    interpreter; one corrupted signature among the valid ones must come out as result = 0 with every constraint satisfied."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    from circom_amd import runtime as rt
+    gold = json.load(open(os.path.join(HERE, "golden", "reference_wtns_ecdsa.json")))["cases"]["ecdsa_verify"]["vectors"]
+    B = 128
+    cache = os.path.join(ROOT, "gpurun_in", "cache")
+    cp, _, _ = bench.get_compiled("ecdsa_verify", B, cache if os.path.isdir(cache) else str(tmp_path), 0, None)
+    c = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
+    assert c.n_constraints > 2_000_000 and c.q == 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    rows = bench.synth_inputs("ecdsa_verify", c.q, B, c.n_inputs, seed=3)
+    at = [0, 77, 127, 100]
+    for pos, vec in zip(at, gold):
+        rows[pos] = np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in vec["inputs"]), dtype=np.uint8).reshape(c.n_inputs, 32)
+    b = c.batch(B)
+    b.set_inputs(rows)
+    b.run(); b.check_r1cs(); b.sync()
+    assert (b.status() == 0).all()
+    res = [b.signal(i, 1) for i in range(B)]
+    assert res[100] == 0 and all(v == 1 for i, v in enumerate(res) if i != 100)
+    for pos, vec in zip(at, gold):
+        p = tmp_path / ("g%d.wtns" % pos)
+        b.write_wtns(pos, p)
+        _check(vec, p.read_bytes())
     b.close(); c.close()
 
 

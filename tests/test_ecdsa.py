@@ -145,6 +145,9 @@ def test_reference_runtime_executes_the_toy_verifier(tmp_path):
 def test_full_size_verifier_on_the_oracle():
     """n = 64, k = 4, secp256k1, stride 8: the size BASELINE config 5 names (its "~1.5 M constraints": 2.49 M here - the slope
     is a range-checked signal and every modular relation pays its own quotient and carries)"""
+    import hashlib
+    import json
+    import os
     rnd = random.Random(5)
     fc = flatten(Program(S.ECDSAVerifyNoPubkeyCheck(64, 4, S.SECP256K1, 8), prime="bls12381"))
     assert fc.n_signals > 2_000_000 and len(fc.constraints) > 2_000_000
@@ -152,6 +155,16 @@ def test_full_size_verifier_on_the_oracle():
     sig, failed = _eval(fc, inp)
     assert failed is None and sig[1] == 1
     assert check_r1cs(fc.fp.q, fc.constraints, sig) is None
+    # golden vectors written by the REFERENCE RUNTIME (tests/golden/make_golden.py ecdsa: it executed the bodies of the witness
+    # functions); the oracle - with the closed forms - must reproduce the 79 MB files: a valid signature and the rejected one
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_wtns_ecdsa.json")))
+    assert gold["n_signals"] == fc.n_signals and gold["n_constraints"] == len(fc.constraints)
+    for vec in (gold["cases"]["ecdsa_verify"]["vectors"][1], gold["cases"]["ecdsa_verify"]["vectors"][3]):
+        sig, failed = _eval(fc, [int(v) for v in vec["inputs"]])
+        assert failed is None and [str(v) for v in sig[:8]] == vec["witness_head"]
+        b = wtns_bytes(fc.fp.q, sig)
+        assert len(b) == vec["wtns_len"] and hashlib.sha256(b).hexdigest() == vec["wtns_sha256"]
+    assert gold["cases"]["ecdsa_verify"]["vectors"][3]["witness_head"][1] == "0"
 
 
 @pytest.mark.gpu

@@ -11,3 +11,14 @@ root = os.path.join(str(bench.ROOT), "gpurun_in", "cache")
 os.makedirs(root, exist_ok=True)
 cp, s, _ = bench.get_compiled(name, batch, root, 0, None)
 print("cached", cp.dir, "%.1f s" % s)
+
+# big artefacts are gzipped for the snapshot (bench.get_compiled unpacks them on the GPU box)
+import glob, gzip, shutil
+total = sum(os.path.getsize(f) for f in glob.glob(os.path.join(cp.dir, name + ".*")) if not f.endswith(".gz"))
+if total > (200 << 20):
+    for ext in (".cwt", ".dat", ".r1cs"):
+        f = os.path.join(cp.dir, name + ext)
+        with open(f, "rb") as fi, gzip.open(f + ".gz", "wb", compresslevel=1) as fo:
+            shutil.copyfileobj(fi, fo, 1 << 24)
+        os.unlink(f)
+    print("gzipped", total >> 20, "MB")
