@@ -502,6 +502,11 @@ def main():
     if n_fl <= 0:
         n_fl = auto_in_flight(batch.bitmode, B, batch.lanes)
     n_fl = max(1, n_fl)
+    if not batch.bitmode:
+        # value tables of a million-signal circuit are tens of GB each (ECDSA verifier x 1 024: 85 GB): as many batches in
+        # flight as fit in ~2/3 of the HBM
+        est = 32.0 * circ.n_signals * ((B + 255) // 256 * 256) * 1.1
+        n_fl = max(1, min(n_fl, int(190e9 // max(est, 1.0))))
     streams, batches = [stream], [batch]
     for _ in range(n_fl - 1):
         try:
