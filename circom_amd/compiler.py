@@ -119,6 +119,18 @@ def compile_program(prog: Program, outdir: str, name: str, sym: bool = True, str
     mont: signals in Montgomery form on the device (True / False / "auto" = choose_mont); CW_MONT=0/1 overrides."""
     os.makedirs(outdir, exist_ok=True)
     fc = flatten(prog)
+    if fc.fp.n64 == 1:
+        # --prime goldilocks: the reference's 64-bit runtime (goldilocks/fr.hpp, common64/): its own small engine on the device
+        # (csrc/cw64.hip), the flat program as it stands (hip_elements/lower64.py), 8-byte file formats
+        from .hip_elements import lower64 as L64
+        t64 = L64.lower64(fc)
+        p64 = lambda ext: os.path.join(outdir, name + ext)
+        L64.write_tape64(p64(".cwt"), fc, t64)
+        L64.write_dat64(p64(".dat"), fc)
+        writers.write_r1cs(p64(".r1cs"), fc)
+        if sym:
+            writers.write_sym(p64(".sym"), fc)
+        return Compiled(name, outdir, p64(".cwt"), p64(".dat"), p64(".r1cs"), p64(".sym"), fc, t64)
     bittape = None if os.environ.get("CW_BITS", "1") == "0" else lower_bitplane(fc, bits)      # CW_BITS=0: no bit program in the tape
     jp = emit_jit(lower_bitplane.net, fc, jit) if bittape is not None else None
     lower_bitplane.net = None

@@ -34,6 +34,9 @@ static int fail(int code, const std::string &msg) {
 
 #define NEED_DEVICE(b) \
     if ((b)->device < 0) return fail(CW_EDEVICE, "host-only batch: no GPU attached (the hot path has no CPU fallback)")
+// entry points the 64-bit runtime (--prime goldilocks, cw64.hip) does not serve yet
+#define NOT_FOR_64(b, what) \
+    if ((b)->c->is64) return fail(CW_ESTATE, what " is not available for circuits of the 64-bit runtime (--prime goldilocks)")
 
 extern "C" const char *cw_last_error(void) { return g_err.c_str(); }
 extern "C" const char *cw_version(void) { return "circom_amd 0.1 (gfx950)"; }
@@ -247,6 +250,12 @@ struct cw_circuit {
     bool has_bits = false;
     cwbits::Program bits;
     // the same gate network as EMITTED gfx950 code (hip_elements/bitjit.py) for large batches: a code object, its own slot map
+    // the 64-bit runtime (--prime goldilocks, cw64.hip): the flat witness program, one 32-byte row per operation
+    bool is64 = false;
+    std::vector<uint32_t> rows64;          // n_rows * 8
+    std::vector<uint64_t> consts64;
+    uint32_t n_slots64 = 0;
+    std::vector<uint32_t> r1_terms64;      // R1CS terms {slot, part | end << 2, coefficient lo, hi}
     bool has_jit = false;
     cwbits::JitProgram jit;
     std::map<int, std::pair<hipModule_t, hipFunction_t>> jit_mod;   // device -> loaded module
@@ -409,9 +418,156 @@ static const char *validate_pipe_variant(const Variant &v, uint32_t n_signals, u
     return nullptr;
 }
 
+// ---- the 64-bit runtime's tape ("CW64", hip_elements/lower64.py) ------------------------------------------------------------
+//   "CW64" | u32 version = 1 | u64 prime | 12 x u32: n_signals, n_witness, n_consts, input_start, n_inputs, n_input_names,
+//   hashmap_size, n_public_inputs, n_slots, n_rows, io-map templates in the .dat, 0 | consts n_consts x u64 | witness2signal
+//   n_witness x u32 | input names { u32 len | bytes | u32 start | u32 size } | rows n_rows x 8 x u32 (cw64.hip)
+static const uint64_t GOLDILOCKS = 0xFFFFFFFF00000001ull;
+static int load_tape64(cw_circuit *c, const std::vector<uint8_t> &b) {
+    if (b.size() < 16 + 48) return fail(CW_EIO, "tape file truncated");
+    uint32_t ver;
+    memcpy(&ver, b.data() + 4, 4);
+    uint64_t prime;
+    memcpy(&prime, b.data() + 8, 8);
+    if (ver != 1) return fail(CW_EIO, "unsupported 64-bit tape version");
+    if (prime != GOLDILOCKS) return fail(CW_EIO, "the 64-bit runtime serves the Goldilocks prime only");
+    c->is64 = true;
+    c->q = U256{{prime, 0, 0, 0}};
+    uint32_t m[12];
+    memcpy(m, b.data() + 16, 48);
+    size_t off = 64;
+    c->n_signals = m[0];
+    c->n_witness = m[1];
+    c->n_consts = m[2];
+    c->input_start = m[3];
+    c->n_inputs = m[4];
+    const uint32_t n_names = m[5], hsize = m[6];
+    c->n_pub_in = m[7];
+    c->n_slots64 = m[8];
+    const uint32_t n_rows = m[9];
+    c->n_dat_consts = 0;                                       // the 64-bit .dat carries no constants (c_code_generator.rs:838-841)
+    c->n_io_templates = m[10];
+    if (c->n_signals == 0 || c->n_signals >= (1u << 26) || c->n_slots64 < c->n_signals || c->n_slots64 >= (1u << 28) || m[11] ||
+        c->input_start == 0 || (uint64_t)c->input_start + c->n_inputs > c->n_signals || c->n_pub_in > c->n_inputs || c->n_witness == 0 ||
+        c->n_witness > c->n_signals || hsize < 256 || (hsize & (hsize - 1)) || n_names > hsize || n_names > c->n_inputs + 1u ||
+        n_rows > (1u << 26) || c->n_consts > (1u << 26) || c->n_io_templates > (1u << 20))
+        return fail(CW_EIO, "64-bit tape header: inconsistent circuit shape");
+    if (b.size() - off < (size_t)c->n_consts * 8 + (size_t)c->n_witness * 4) return fail(CW_EIO, "tape file truncated");
+    c->consts64.resize(c->n_consts);
+    memcpy(c->consts64.data(), b.data() + off, (size_t)c->n_consts * 8);
+    off += (size_t)c->n_consts * 8;
+    for (uint64_t v : c->consts64)
+        if (v >= prime) return fail(CW_EIO, "64-bit tape: constant is not a canonical residue");
+    c->w2s.resize(c->n_witness);
+    memcpy(c->w2s.data(), b.data() + off, (size_t)c->n_witness * 4);
+    off += (size_t)c->n_witness * 4;
+    for (uint32_t v : c->w2s)
+        if (v >= c->n_signals) return fail(CW_EIO, "tape witness list refers to a signal out of range");
+    for (uint32_t i = 0; i < n_names; i++) {
+        if (off + 4 > b.size()) return fail(CW_EIO, "tape input names truncated");
+        uint32_t len;
+        memcpy(&len, b.data() + off, 4);
+        off += 4;
+        if (len > 4096 || off + len + 8 > b.size()) return fail(CW_EIO, "tape input names truncated");
+        std::string nm((const char *)b.data() + off, len);
+        off += len;
+        uint32_t ss[2];
+        memcpy(ss, b.data() + off, 8);
+        off += 8;
+        if (ss[0] < c->input_start || (uint64_t)ss[0] + ss[1] > (uint64_t)c->input_start + c->n_inputs) return fail(CW_EIO, "tape input name outside the main inputs");
+        if (!c->input_names.emplace(nm, std::make_pair(ss[0], ss[1])).second) return fail(CW_EIO, "tape input name appears twice");
+    }
+    if (b.size() - off != (size_t)n_rows * 32) return fail(CW_EIO, "64-bit tape: row section size");
+    c->rows64.resize((size_t)n_rows * 8);
+    memcpy(c->rows64.data(), b.data() + off, (size_t)n_rows * 32);
+    for (uint32_t r = 0; r < n_rows; r++) {                   // every operand is checked once, here
+        const uint32_t *w = &c->rows64[(size_t)r * 8];
+        const uint32_t op = w[0] & 0xFF, dk = (w[0] >> 8) & 3, ks[3] = {(w[0] >> 10) & 3, (w[0] >> 12) & 3, (w[0] >> 14) & 3};
+        const uint32_t vs[3] = {w[2], w[3], w[4]};
+        bool ok = op <= 26 && !(w[0] >> 16) && (dk == 3 || (dk == 0 && w[1] > 0 && w[1] < c->n_slots64));
+        for (int j = 0; j < 3; j++) ok = ok && (ks[j] == 3 || (ks[j] == 0 && vs[j] < c->n_slots64) || (ks[j] == 2 && vs[j] < c->n_consts));
+        if (!ok) return fail(CW_EIO, "64-bit tape: bad row");
+    }
+    c->n_rows = n_rows;
+    // hash map as generate_hash_map builds it (replaced by the .dat's if one is given)
+    c->hashmap.assign(hsize, HashEntry{0, 0, 0});
+    std::vector<std::pair<uint32_t, std::string>> order;
+    for (auto &kv : c->input_names) order.push_back({kv.second.first, kv.first});
+    std::sort(order.begin(), order.end());
+    for (auto &o : order) {
+        const uint64_t h = fnv1a(o.second.data(), o.second.size());
+        size_t pos = (size_t)(h % hsize);
+        while (c->hashmap[pos].signalid != 0) pos = (pos + 1) % hsize;
+        c->hashmap[pos] = HashEntry{h, o.first, c->input_names[o.second].second};
+    }
+    return CW_OK;
+}
+// .r1cs with 8-byte coefficients (field size 8: r1cs_writer.rs writes the prime's own byte length)
+static int load_r1cs64(cw_circuit *c, const char *path) {
+    std::vector<uint8_t> b;
+    if (!read_file(path, b)) return fail(CW_EIO, std::string(".r1cs file not found: ") + path);
+    if (b.size() < 12 || memcmp(b.data(), "r1cs", 4)) return fail(CW_EIO, "bad r1cs magic");
+    uint32_t nsec;
+    memcpy(&nsec, b.data() + 8, 4);
+    size_t off = 12;
+    const uint8_t *sec[4] = {0};
+    uint64_t seclen[4] = {0};
+    for (uint32_t s = 0; s < nsec; s++) {
+        if (off + 12 > b.size()) return fail(CW_EIO, "r1cs truncated");
+        uint32_t typ;
+        uint64_t len;
+        memcpy(&typ, b.data() + off, 4);
+        memcpy(&len, b.data() + off + 4, 8);
+        off += 12;
+        if (len > b.size() - off) return fail(CW_EIO, "r1cs section truncated");
+        if (typ < 4) {
+            sec[typ] = b.data() + off;
+            seclen[typ] = len;
+        }
+        off += len;
+    }
+    if (!sec[1] || !sec[2] || seclen[1] < 4 + 8 + 16 + 8 + 4) return fail(CW_EIO, "r1cs misses header or constraints section");
+    uint32_t fs;
+    memcpy(&fs, sec[1], 4);
+    uint64_t prime;
+    memcpy(&prime, sec[1] + 4, 8);
+    if (fs != 8 || prime != GOLDILOCKS) return fail(CW_EIO, "r1cs field differs from the tape's 64-bit prime");
+    uint32_t n_wires, n_cons;
+    memcpy(&n_wires, sec[1] + 12, 4);
+    memcpy(&n_cons, sec[1] + 12 + 16 + 8, 4);
+    if (n_wires != c->n_witness) return fail(CW_EIO, "r1cs wire count differs from the witness size");
+    const uint8_t *p = sec[2], *end = sec[2] + seclen[2];
+    c->r1_terms64.clear();
+    for (uint32_t k = 0; k < n_cons; k++) {
+        const size_t first = c->r1_terms64.size();
+        for (uint32_t part = 0; part < 3; part++) {
+            if (p + 4 > end) return fail(CW_EIO, "r1cs constraints truncated");
+            uint32_t nnz;
+            memcpy(&nnz, p, 4);
+            p += 4;
+            if ((size_t)(end - p) < (size_t)nnz * 12) return fail(CW_EIO, "r1cs constraints truncated");
+            for (uint32_t t = 0; t < nnz; t++) {
+                uint32_t wire;
+                uint64_t co;
+                memcpy(&wire, p, 4);
+                memcpy(&co, p + 4, 8);
+                p += 12;
+                if (wire >= n_wires || co >= prime) return fail(CW_EIO, "r1cs term out of range");
+                c->r1_terms64.insert(c->r1_terms64.end(), {c->w2s[wire], part, (uint32_t)co, (uint32_t)(co >> 32)});
+            }
+        }
+        if (c->r1_terms64.size() == first)                       // an empty constraint still closes a row: 0 * 0 = 0 on the constant wire
+            c->r1_terms64.insert(c->r1_terms64.end(), {0u, 2u, 0u, 0u});
+        c->r1_terms64[c->r1_terms64.size() - 3] |= 4u;
+    }
+    c->n_constraints = n_cons;
+    return CW_OK;
+}
+
 static int load_tape(cw_circuit *c, const char *path) {
     std::vector<uint8_t> b;
     if (!read_file(path, b)) return fail(CW_EIO, std::string("tape file not found: ") + path);
+    if (b.size() >= 4 && !memcmp(b.data(), "CW64", 4)) return load_tape64(c, b);
     if (b.size() < 16 + 32 + 48 || memcmp(b.data(), "CWTP", 4)) return fail(CW_EIO, "bad tape magic");
     const uint32_t *h = (const uint32_t *)(b.data() + 4);
     if (h[0] != 11) return fail(CW_EIO, "unsupported tape version");
@@ -1051,7 +1207,7 @@ extern "C" int cw_load(const char *tape_path, const char *dat_path, const char *
     try {                                   // a hostile size field must not take the host process down (no C++ exception crosses the C ABI)
         rc = load_tape(c, tape_path);
         if (rc == CW_OK && dat_path) rc = load_dat(c, dat_path);
-        if (rc == CW_OK && r1cs_path) rc = load_r1cs(c, r1cs_path);
+        if (rc == CW_OK && r1cs_path) rc = c->is64 ? load_r1cs64(c, r1cs_path) : load_r1cs(c, r1cs_path);
     } catch (const std::bad_alloc &) {
         rc = fail(CW_EIO, "cw_load: a table size in the files exceeds available memory");
     } catch (const std::exception &e) {
@@ -1201,6 +1357,9 @@ struct cw_batch {
     const std::vector<uint32_t> *bits_sigslot = nullptr;
     bool jit = false, table_dirty = false;             // emitted code runs this batch; the caller holds a raw pointer to the table
     hipFunction_t jit_fn = nullptr;
+    // 64-bit runtime: V64[slot][Bp], its program and R1CS terms
+    uint64_t *d_V64 = nullptr, *d_consts64 = nullptr;
+    uint32_t *d_rows64 = nullptr, *d_terms64 = nullptr;
     uint64_t *d_r1flag = nullptr;                      // per group: instances whose fused R1CS check fired (emitted code)
 };
 
@@ -1222,7 +1381,7 @@ extern "C" void cw_batch_free(cw_batch *b) {
     hipSetDevice(b->device);
     hipStreamSynchronize(b->stream);
     if (b->fb) cw_batch_free(b->fb);
-    void *bptrs[] = {b->d_T, b->d_fbmask, b->d_r1flag, b->d_brecs, b->d_bcmds, b->d_aslots, b->d_wslot, b->d_fbinst, b->d_erecs, b->d_wchunk, b->d_wterms, b->d_wctab, b->d_wrow,
+    void *bptrs[] = {b->d_V64, b->d_consts64, b->d_rows64, b->d_terms64, b->d_T, b->d_fbmask, b->d_r1flag, b->d_brecs, b->d_bcmds, b->d_aslots, b->d_wslot, b->d_fbinst, b->d_erecs, b->d_wchunk, b->d_wterms, b->d_wctab, b->d_wrow,
                      b->d_ichunk, b->d_iterms, b->d_itab, b->d_irow, b->d_sigslot};
     for (void *p : bptrs)
         if (p) hipFree(p);
@@ -1237,6 +1396,7 @@ extern "C" void cw_batch_free(cw_batch *b) {
 }
 
 static int bits_batch_setup(cw_batch *b);
+static int batch_setup64(cw_batch *b);
 // device staging of host-side inputs: [batch][n_inputs][32]; bit-plane batches allocate it on first use
 static int ensure_d_in(cw_batch *b) {
     if (b->d_in) return CW_OK;
@@ -1272,6 +1432,16 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
     b->batch = batch;
     b->Bp = (batch + 255) / 256 * 256;
     b->stream = (hipStream_t)stream;
+    if (c->is64) {
+        int rc = batch_setup64(b);
+        if (rc != CW_OK) {
+            cw_batch_free(b);
+            return rc;
+        }
+        b->remaining.assign(batch, c->n_inputs);
+        *out = b;
+        return CW_OK;
+    }
     if (allow_bits && c->has_bits) {
         // every signal is a bit: the bit-plane program replaces the 256-bit schedule (which stays in the file for the
         // instances whose inputs turn out not to be 0/1)
@@ -1659,6 +1829,7 @@ extern "C" int cw_set_inputs(cw_batch *b, const uint8_t *le32) {
 
 extern "C" int cw_set_inputs_bits_device(cw_batch *b, const void *d_masks) {
     if (!b || !d_masks) return fail(CW_EINVAL, "null argument");
+    NOT_FOR_64(b, "packed boolean inputs");
     NEED_DEVICE(b);
     if (!b->bitmode) return fail(CW_ESTATE, "packed boolean inputs need a bit-plane batch (cw_batch_bitmode)");
     b->packed_in = d_masks;
@@ -1670,6 +1841,7 @@ extern "C" int cw_set_inputs_bits_device(cw_batch *b, const void *d_masks) {
 }
 extern "C" int cw_set_inputs_bits(cw_batch *b, const uint64_t *masks) {
     if (!b || !masks) return fail(CW_EINVAL, "null argument");
+    NOT_FOR_64(b, "packed boolean inputs");
     NEED_DEVICE(b);
     if (!b->bitmode) return fail(CW_ESTATE, "packed boolean inputs need a bit-plane batch (cw_batch_bitmode)");
     HIPCHK(hipSetDevice(b->device));
@@ -1894,6 +2066,27 @@ extern "C" int cw_set_inputs_json(cw_batch *b, uint32_t instance, const char *js
         if (e2 != hipSuccess) return fail(CW_EDEVICE, std::string(#x ": ") + hipGetErrorString(e2)); \
     } while (0)
 
+// 64-bit runtime (cw64.hip): value table [slot][Bp] of uint64, the flat program, the R1CS terms
+static int batch_setup64(cw_batch *b) {
+    cw_circuit *c = b->c;
+    b->v_bytes = (size_t)c->n_slots64 * b->Bp * 8;
+    hipError_t e = hipMalloc((void **)&b->d_V64, b->v_bytes);
+    if (e != hipSuccess)
+        return fail(CW_EDEVICE, "hipMalloc of the value table failed (" + std::to_string(b->v_bytes) + " bytes): " + hipGetErrorString(e));
+    BTRY(hipMemsetAsync(b->d_V64, 0, b->v_bytes, b->stream));
+    BTRY(upload(&b->d_rows64, c->rows64, b->stream));
+    BTRY(upload(&b->d_consts64, c->consts64, b->stream));
+    BTRY(upload(&b->d_terms64, c->r1_terms64, b->stream));
+    BTRY(upload(&b->d_w2s, c->w2s, b->stream));
+    BTRY(hipMalloc((void **)&b->d_status, (size_t)b->Bp * 4));
+    BTRY(hipMalloc((void **)&b->d_first_bad, (size_t)b->Bp * 4));
+    BTRY(hipMalloc(&b->d_in, std::max<size_t>((size_t)b->batch * c->n_inputs * 32, 32)));
+    BTRY(hipMalloc(&b->d_gather, std::max<size_t>((size_t)c->n_witness * 32, 32)));
+    BTRY(cwk64_init(b->stream, b->d_V64, b->Bp, b->d_status, b->d_first_bad));
+    BTRY(hipStreamSynchronize(b->stream));
+    return CW_OK;
+}
+
 static int bits_batch_setup(cw_batch *b) {
     cw_circuit *c = b->c;
     const cwbits::Program &bp = c->bits;
@@ -2098,6 +2291,13 @@ extern "C" int cw_run(cw_batch *b) {
         b->host_dirty = false;
     }
     const void *in = b->ext_in ? b->ext_in : b->d_in;
+    if (c->is64) {
+        HIPCHK(cwk64_init(b->stream, b->d_V64, b->Bp, b->d_status, b->d_first_bad));
+        HIPCHK(cwk64_ingest(b->stream, in, b->d_V64, c->input_start, c->n_inputs, b->batch, b->Bp));
+        HIPCHK(cwk64_eval(b->stream, b->d_rows64, (uint32_t)(c->rows64.size() / 8), b->d_consts64, b->d_V64, b->Bp, b->batch, b->d_status));
+        b->ran = true;
+        return CW_OK;
+    }
     if (b->bitmode) {
         int rc = bits_run(b, in);
         if (rc == CW_OK) b->ran = true;
@@ -2127,6 +2327,10 @@ extern "C" int cw_check_r1cs(cw_batch *b) {
     if (!b->ran) return fail(CW_ESTATE, "cw_check_r1cs before cw_run");
     if (c->n_constraints == 0) return fail(CW_ESTATE, "no .r1cs was loaded for this circuit");
     HIPCHK(hipSetDevice(b->device));
+    if (c->is64) {
+        HIPCHK(cwk64_r1cs(b->stream, b->d_terms64, (uint32_t)(c->r1_terms64.size() / 4), b->d_V64, b->Bp, b->batch, b->d_status, b->d_first_bad));
+        return CW_OK;
+    }
     if (b->bitmode) {
         // emitted code checked every constraint on its registers while it generated the witness: only the groups it flagged
         // are audited (to name the first violated row of each instance).  A caller that took the raw table pointer
@@ -2192,7 +2396,9 @@ extern "C" int cw_get_witness(cw_batch *b, uint32_t instance, uint8_t *out) {
     if (!b->ran) return fail(CW_ESTATE, "cw_get_witness before cw_run");
     cw_circuit *c = b->c;
     HIPCHK(hipSetDevice(b->device));
-    if (b->bitmode) {
+    if (c->is64) {
+        HIPCHK(cwk64_gather(b->stream, b->d_V64, b->d_w2s, c->n_witness, b->Bp, instance, 1, b->d_gather));
+    } else if (b->bitmode) {
         if (int rc = bits_resolve(b)) return rc;
         if (b->fb_index[instance] >= 0) return cw_get_witness(b->fb, (uint32_t)b->fb_index[instance], out);
         HIPCHK(cwk_bits_gather(b->stream, b->d_T, b->bits_slots, b->bits_sh, b->d_wslot, c->n_witness, instance, 1, b->d_gather));
@@ -2225,7 +2431,9 @@ extern "C" int cw_get_witnesses(cw_batch *b, uint32_t first, uint32_t count, uin
     }
     for (uint32_t done = 0; done < count; done += per) {
         const uint32_t n = std::min(per, count - done);
-        if (b->bitmode)
+        if (c->is64)
+            HIPCHK(cwk64_gather(b->stream, b->d_V64, b->d_w2s, c->n_witness, b->Bp, first + done, n, b->d_bulk));
+        else if (b->bitmode)
             HIPCHK(cwk_bits_gather(b->stream, b->d_T, b->bits_slots, b->bits_sh, b->d_wslot, c->n_witness, first + done, n, b->d_bulk));
         else
             HIPCHK(cwk_gather_many(b->stream, b->d_V, b->d_w2s, c->n_witness, b->Bp, first + done, n, b->d_bulk, c->mont, c->P));
@@ -2243,6 +2451,7 @@ extern "C" int cw_get_witnesses(cw_batch *b, uint32_t first, uint32_t count, uin
 // ([count][n_witness][32]); no host copy.  In bit-plane batches this is where a bit becomes a field element again.
 extern "C" int cw_get_witnesses_device(cw_batch *b, uint32_t first, uint32_t count, void *d_out) {
     if (!b || !d_out) return fail(CW_EINVAL, "null argument");
+    NOT_FOR_64(b, "cw_get_witnesses_device");
     if ((uint64_t)first + count > b->batch) return fail(CW_EINVAL, "instance range out of the batch");
     NEED_DEVICE(b);
     if (!b->ran) return fail(CW_ESTATE, "cw_get_witnesses_device before cw_run");
@@ -2276,6 +2485,7 @@ extern "C" int cw_get_witnesses_device(cw_batch *b, uint32_t first, uint32_t cou
 extern "C" int cw_stream_witnesses_device(cw_batch *b, uint32_t first, uint32_t count, uint32_t chunk, void *d_buf0, void *d_buf1,
                                           cw_chunk_fn consume, void *user) {
     if (!b || !d_buf0 || !d_buf1 || !consume || chunk == 0) return fail(CW_EINVAL, "null argument / zero chunk");
+    NOT_FOR_64(b, "cw_stream_witnesses_device");
     if ((uint64_t)first + count > b->batch) return fail(CW_EINVAL, "instance range out of the batch");
     uint32_t n_chunk = 0;
     for (uint32_t done = 0; done < count; done += chunk, n_chunk++) {
@@ -2318,6 +2528,10 @@ extern "C" int cw_get_public_device(cw_batch *b, void *d_out) {
         }
         return CW_OK;
     }
+    if (c->is64) {
+        HIPCHK(cwk64_gather(b->stream, b->d_V64, b->d_w2s + 1, np, b->Bp, 0, b->batch, d_out));
+        return CW_OK;
+    }
     HIPCHK(cwk_gather_many(b->stream, b->d_V, b->d_w2s + 1, np, b->Bp, 0, b->batch, d_out, c->mont, c->P));
     return CW_OK;
 }
@@ -2344,6 +2558,12 @@ extern "C" int cw_get_signal(cw_batch *b, uint32_t instance, uint32_t slot, uint
     if (instance >= b->batch || slot >= b->c->n_signals) return fail(CW_EINVAL, "instance or slot out of range");
     NEED_DEVICE(b);
     HIPCHK(hipSetDevice(b->device));
+    if (b->c->is64) {
+        memset(out, 0, 32);
+        HIPCHK(hipMemcpyAsync(out, b->d_V64 + (size_t)slot * b->Bp + instance, 8, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+        return CW_OK;
+    }
     if (b->bitmode) {
         if (int rc = bits_resolve(b)) return rc;
         if (b->fb_index[instance] >= 0) return cw_get_signal(b->fb, (uint32_t)b->fb_index[instance], slot, out);
@@ -2379,7 +2599,8 @@ extern "C" int cw_write_wtns(cw_batch *b, uint32_t instance, const char *path) {
     if (rc) return rc;
     FILE *f = fopen(path, "wb");
     if (!f) return fail(CW_EIO, std::string("cannot open for writing: ") + path);
-    uint32_t version = 2, nsec = 2, id1 = 1, n8 = 32, id2 = 2, nw = c->n_witness;
+    // n8 = the prime's byte length: 32 for the 4-limb primes, 8 for the 64-bit runtime (common64/main.cpp writeBinWitness)
+    uint32_t version = 2, nsec = 2, id1 = 1, n8 = c->is64 ? 8 : 32, id2 = 2, nw = c->n_witness;
     uint64_t len1 = 8 + n8, len2 = (uint64_t)n8 * nw;
     fwrite("wtns", 4, 1, f);
     fwrite(&version, 4, 1, f);
@@ -2387,11 +2608,14 @@ extern "C" int cw_write_wtns(cw_batch *b, uint32_t instance, const char *path) {
     fwrite(&id1, 4, 1, f);
     fwrite(&len1, 8, 1, f);
     fwrite(&n8, 4, 1, f);
-    fwrite(c->q.w, 32, 1, f);
+    fwrite(c->q.w, n8, 1, f);
     fwrite(&nw, 4, 1, f);
     fwrite(&id2, 4, 1, f);
     fwrite(&len2, 8, 1, f);
-    fwrite(w.data(), 1, w.size(), f);
+    if (c->is64)
+        for (uint32_t k = 0; k < nw; k++) fwrite(&w[(size_t)k * 32], 8, 1, f);
+    else
+        fwrite(w.data(), 1, w.size(), f);
     fclose(f);
     return CW_OK;
 }
@@ -2410,6 +2634,7 @@ extern "C" int cw_write_wtns(cw_batch *b, uint32_t instance, const char *path) {
 //            that are not 0/1, tripped assertions) carry their field elements
 extern "C" int cw_write_wtnsb(cw_batch *b, const char *path) {
     if (!b || !path) return fail(CW_EINVAL, "null argument");
+    NOT_FOR_64(b, "cw_write_wtnsb");
     NEED_DEVICE(b);
     if (!b->ran) return fail(CW_ESTATE, "cw_write_wtnsb before cw_run");
     cw_circuit *c = b->c;
@@ -2466,6 +2691,7 @@ extern "C" int cw_write_wtnsb(cw_batch *b, const char *path) {
 // `pattern` is a printf pattern with one %u / %d (the instance number).  What a prover farm consumes.
 extern "C" int cw_write_wtns_many(cw_batch *b, uint32_t first, uint32_t count, const char *pattern) {
     if (!b || !pattern) return fail(CW_EINVAL, "null argument");
+    NOT_FOR_64(b, "cw_write_wtns_many");
     if ((uint64_t)first + count > b->batch) return fail(CW_EINVAL, "instance range out of the batch");
     {   // exactly one integer conversion, nothing else
         int convs = 0;
@@ -2529,6 +2755,7 @@ static std::string u256_dec(const uint8_t le[32]) {
 }
 extern "C" int cw_explain(cw_batch *b, uint32_t instance, const char *sym_path, char *out, size_t out_len) {
     if (!b || !out || out_len == 0) return fail(CW_EINVAL, "null argument");
+    NOT_FOR_64(b, "cw_explain");
     if (instance >= b->batch) return fail(CW_EINVAL, "instance out of range");
     cw_circuit *c = b->c;
     std::vector<uint32_t> st(b->batch), fb(b->batch);

@@ -274,17 +274,9 @@ def build_default_circuits():
 # The device path refuses this prime (DESIGN 9 / NOTES: its "q is large" shortcuts); the oracle is pinned against the
 # reference's own 64-bit runtime here so that a later round only has device work left.
 def write_dat64(path, fc):
-    """`.dat` as common64/main.cpp reads it (loadCircuit there: hash map, witness list, io map - no constant table: the
-    reference inlines constants as literals for this prime, value_bucket.rs:82-86)"""
-    import struct
-    import numpy as np
-    from circom_amd.hip_elements.writers import hashmap_size, build_hash_map, dat_io_map
-    size = hashmap_size(len(fc.inputs))
-    with open(path, "wb") as f:
-        f.write(b"".join(struct.pack("<QQQ", *e) for e in build_hash_map(fc.inputs, size)))
-        f.write(np.arange(fc.n_signals, dtype="<u8").tobytes())
-        f.write(dat_io_map(getattr(fc, "io_map", ())))
-    return size
+    """the product's own writer (hip_elements/lower64.py): the file the reference's 64-bit runtime loads"""
+    from circom_amd.hip_elements.lower64 import write_dat64 as w
+    return w(path, fc)
 
 
 def build_circuit64(fc, name: str):
