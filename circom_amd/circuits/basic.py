@@ -116,3 +116,5 @@ def LogDemo(c):
     c.assert_(a.neq(13))
     c.set(out, sq["out"] + a)
     c.log("out =", out, "(after the check)")
+    c.log("100%% of", 2, "checks passed")                       # the string is a printf format in the reference: prints "100% of"
+

@@ -74,6 +74,10 @@ def lower_bitplane(fc: FlatCircuit, bits="auto"):
     net = bitblast(fc)
     if net is None:
         return None
+    # Evidence that the circuit really is bit-level, tested BEFORE the mapping and the two scheduling passes (an
+    # arithmetic circuit with range checks used to pay the whole lowering just to be rejected)
+    if bits == "auto" and net.stats["gates"] * BITS_AUTO_MIN_SIGNALS_PER_GATE < fc.n_signals:
+        return None
     lower_bitplane.net = net
     from .hip_elements.bitmap import map_network
     bt = lower_bits(map_network(net), fc)

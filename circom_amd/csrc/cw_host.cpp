@@ -2441,9 +2441,14 @@ extern "C" int cw_get_witnesses(cw_batch *b, uint32_t first, uint32_t count, uin
         HIPCHK(hipStreamSynchronize(b->stream));
     }
     if (b->bitmode)
-        for (size_t k = 0; k < b->fb_inst.size(); k++)
-            if (b->fb_inst[k] >= first && b->fb_inst[k] < first + count)
-                if (int rc = cw_get_witness(b->fb, (uint32_t)k, out + (size_t)(b->fb_inst[k] - first) * row)) return rc;
+        for (size_t k = 0; k < b->fb_inst.size();) {              // runs of consecutive re-run instances: one bulk call each
+            size_t e = k + 1;
+            while (e < b->fb_inst.size() && b->fb_inst[e] == b->fb_inst[e - 1] + 1) e++;
+            const uint32_t lo = std::max(b->fb_inst[k], first), hi = (uint32_t)std::min<uint64_t>((uint64_t)b->fb_inst[e - 1] + 1, (uint64_t)first + count);
+            if (lo < hi)
+                if (int rc = cw_get_witnesses(b->fb, (uint32_t)(k + (lo - b->fb_inst[k])), hi - lo, out + (size_t)(lo - first) * row)) return rc;
+            k = e;
+        }
     return CW_OK;
 }
 
@@ -2465,14 +2470,24 @@ extern "C" int cw_get_witnesses_device(cw_batch *b, uint32_t first, uint32_t cou
     // the evaluation: the first egress of a run waits for it (one stream synchronisation + an 8-byte-per-group copy),
     // then everything below is asynchronous on the batch's stream
     if (int rc = bits_resolve(b)) return rc;
+    // the whole batch went through the 256-bit schedule (more than a quarter of it was not boolean: fb_inst is the identity):
+    // the side batch serves the range in ONE gather; the bit table is not consulted
+    if (b->resolved && b->fb && b->fb_inst.size() == b->batch) return cw_get_witnesses_device(b->fb, first, count, d_out);
     HIPCHK(cwk_bits_gather(b->stream, b->d_T, b->bits_slots, b->bits_sh, b->d_wslot, c->n_witness, first, count, d_out));
-    if (b->resolved)
-        for (size_t k = 0; k < b->fb_inst.size(); k++)
-            if (b->fb_inst[k] >= first && b->fb_inst[k] < first + count) {
-                const size_t row = (size_t)c->n_witness * 32;
-                int rc = cw_get_witnesses_device(b->fb, (uint32_t)k, 1, (char *)d_out + (size_t)(b->fb_inst[k] - first) * row);
+    if (b->resolved) {
+        // re-run instances: consecutive positions of the side batch that are consecutive instances leave in one gather
+        const size_t row = (size_t)c->n_witness * 32;
+        for (size_t k = 0; k < b->fb_inst.size();) {
+            size_t e = k + 1;
+            while (e < b->fb_inst.size() && b->fb_inst[e] == b->fb_inst[e - 1] + 1) e++;
+            const uint32_t lo = std::max(b->fb_inst[k], first), hi = std::min<uint64_t>((uint64_t)b->fb_inst[e - 1] + 1, (uint64_t)first + count);
+            if (lo < hi) {
+                int rc = cw_get_witnesses_device(b->fb, (uint32_t)(k + (lo - b->fb_inst[k])), hi - lo, (char *)d_out + (size_t)(lo - first) * row);
                 if (rc != CW_OK) return rc;
             }
+            k = e;
+        }
+    }
     return CW_OK;
 }
 
@@ -2816,15 +2831,34 @@ extern "C" int cw_explain(cw_batch *b, uint32_t instance, const char *sym_path, 
 // to the first failed run-time check (the reference process exits there: statements that end behind that operation of the
 // witness program are not printed).  Returns the length of the text (without the terminator) or a negative error code;
 // at most out_len - 1 characters are stored.
+// A log string reaches the reference binary as printf("<string>") (log_bucket.rs:126-133): the text is used as a FORMAT, so
+// "%%" prints one '%'.  (The string table holds the TEXT - the front-end resolved the source's escapes, and the emitters write
+// it back as a C literal - so only printf's own rule is applied here; any other conversion would read printf arguments that
+// do not exist: undefined in the reference, passed through here.)
+static std::string log_literal(const std::string &t) {
+    std::string o;
+    for (size_t i = 0; i < t.size(); i++) {
+        if (t[i] == '%' && i + 1 < t.size() && t[i + 1] == '%') i++;
+        o += t[i];
+    }
+    return o;
+}
+
 extern "C" int64_t cw_get_log(cw_batch *b, uint32_t instance, char *out, size_t out_len) {
     if (!b || (!out && out_len)) return fail(CW_EINVAL, "null argument");
     if (instance >= b->batch) return fail(CW_EINVAL, "instance out of range");
     cw_circuit *c = b->c;
     std::string t;
     if (!c->logs.empty()) {
-        std::vector<uint32_t> st(b->batch);
-        if (int rc = cw_get_status(b, st.data())) return rc;
-        const uint32_t s = st[instance];
+        // circuits with log statements never run as bit-plane batches (compiler.lower_bitplane), so the status word of ONE
+        // instance is one 4-byte copy (the CLI asks per instance: fetching the whole vector made a batch O(batch^2))
+        NEED_DEVICE(b);
+        if (!b->ran) return fail(CW_ESTATE, "cw_get_log before cw_run");
+        if (b->bitmode) return fail(CW_ESTATE, "log output of a bit-plane batch");
+        uint32_t s = 0;
+        HIPCHK(hipSetDevice(b->device));
+        HIPCHK(hipMemcpyAsync(&s, b->d_status + instance, 4, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
         const uint32_t stop = (s & (CW_ST_ASSERT_FAILED | CW_ST_ARITH)) ? (s >> 8) : 0xFFFFFFFFu;
         for (const auto &stmt : c->logs) {
             if (stmt.at >= stop) break;
@@ -2834,7 +2868,7 @@ extern "C" int64_t cw_get_log(cw_batch *b, uint32_t instance, char *out, size_t 
                     uint8_t v[32];
                     if (int rc = cw_get_signal(b, instance, c->n_signals - c->n_logv + it.value, v)) return rc;
                     t += u256_dec(v);
-                } else t += it.text;
+                } else t += log_literal(it.text);
                 if (k + 1 < stmt.items.size()) t += " ";
             }
             t += "\n";

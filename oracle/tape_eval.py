@@ -127,7 +127,7 @@ def eval_flat(q: int, n_signals: int, n_temps: int, constants, code, inputs: dic
             if int(ak[i]) != 3:             # K_NONE: a string (av = its id, -1 = no argument)
                 line.append(str(rd(int(ak[i]), int(av[i])) % q))
             elif int(av[i]) >= 0:
-                line.append(log_strings[int(av[i])])
+                line.append(log_strings[int(av[i])].replace("%%", "%"))     # the string is printf's FORMAT (log_bucket.rs:126-133)
             if int(dv[i]):
                 if log is not None and failed is None:
                     log.append(" ".join(line) + "\n")

@@ -32,12 +32,12 @@ def _oracle(fc, row):
 def test_flat_program_carries_one_row_per_argument():
     fc = flatten(Program(LogDemo()))
     op = fc.code["op"]
-    assert (op == O.LOG).sum() == 14 and fc.n_log_values == 7
+    assert (op == O.LOG).sum() == 17 and fc.n_log_values == 8
     stmts = log_program(fc)
-    assert [len(items) for _, items in stmts] == [3, 4, 1, 0, 2, 3]
+    assert [len(items) for _, items in stmts] == [3, 4, 1, 0, 2, 3, 3]
     # the sub-component's statement sits where the component fires: after main stored its last input, before main goes on
     assert [fc.log_strings[i[1]] for _, items in stmts for i in items if i[0] == "s"] == \
-        ["inputs:", "square of", "is", "constant", "out =", "(after the check)"]
+        ["inputs:", "square of", "is", "constant", "out =", "(after the check)", "100%% of", "checks passed"]
 
 
 def test_oracle_prints_what_the_reference_binary_prints():
@@ -54,17 +54,17 @@ def test_lowered_schedule_keeps_logged_values_in_hidden_signals(tmp_path):
     from circom_amd import runtime as rt
     cp = compile_program(Program(LogDemo()), str(tmp_path), "logdemo", sym=False)
     fc = cp.flat
-    assert cp.tape.n_signals == fc.n_signals + 7 and cp.tape.n_witness == fc.n_signals
+    assert cp.tape.n_signals == fc.n_signals + 8 and cp.tape.n_witness == fc.n_signals
     for v in GOLD[:3]:
         inp = {fc.main_input_start: int(v["inputs"]["a"]), fc.main_input_start + 1: int(v["inputs"]["b"])}
         sig, st = eval_tape(cp.tape, inp)
         assert st == 0
         want = [int(x) for line in v["log"].split("\n") for x in line.split() if x.isdigit()]
-        assert sig[fc.n_signals:fc.n_signals + 7] == want
+        assert sig[fc.n_signals:fc.n_signals + 8] == want
     # the C ABI: the hidden slots are no signals of the circuit, the witness list does not name them
     c = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
     assert c.n_signals == fc.n_signals and c.n_witness == fc.n_signals
-    assert rt.lib().cw_n_log_statements(c.h) == 6
+    assert rt.lib().cw_n_log_statements(c.h) == 7
     c.close()
     # no bit-plane program for a circuit that logs (the bit table has no place for field-sized log values)
     from circom_amd.compiler import lower_bitplane
