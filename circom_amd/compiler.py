@@ -24,6 +24,7 @@ class Compiled:
     tape: Tape
     bittape: object = None          # hip_elements.bitsched.BitTape when the circuit got a bit-plane program
     jit: object = None              # hip_elements.bitjit.JitProgram: the same network as emitted gfx950 code (large batches)
+    fpjit: tuple = ()               # hip_elements.fpjit.FpJitProgram per strand variant: the rows as emitted gfx950 code
 
 
 DEFAULT_STRANDS = (1, 4, 16)
@@ -110,6 +111,35 @@ def emit_jit(net, fc, jit="auto"):
     return jp
 
 
+FPJIT_MAX_ROWS = 400_000            # "auto": beyond this the code object (about 100 bytes per row) is not worth its size
+
+
+def emit_fpjit(tapes, fc, fpjit="auto"):
+    """The strand variants of the 256-bit schedule as emitted gfx950 code (hip_elements/fpjit.py), assembled.  fpjit: True,
+    False or "auto" (arithmetic circuits up to FPJIT_MAX_ROWS rows; circuits whose every instance normally takes the
+    bit-plane program keep the interpreter for the rare fallback instance); CW_FPJIT=0/1 overrides."""
+    if os.environ.get("CW_FPJIT"):
+        fpjit = os.environ["CW_FPJIT"] != "0"
+    if fpjit is False:
+        return ()
+    from .hip_elements import fpjit as FJ
+    out = []
+    for t in tapes:
+        if getattr(t, "kind", 0) != 0:
+            continue
+        if fpjit == "auto" and len(t.rows) > FPJIT_MAX_ROWS:
+            continue
+        try:
+            p = FJ.emit(t)
+        except NotImplementedError:
+            if fpjit is True:
+                raise
+            continue
+        FJ.assemble(p)
+        out.append(p)
+    return tuple(out)
+
+
 # The pipelined single-wave variant (hip_elements/pipe.py) is opt-in: measured on MI355X it matches the plain single-strand
 # schedule at high occupancy and loses to the multi-strand variants at small batches, where one wave per 64 instances
 # leaves most SIMDs idle (Poseidon(2) x 8 192: 1.2 ms against 0.67 ms with 4 strands; NOTES.md round 2).
@@ -117,7 +147,7 @@ DEFAULT_PIPE = None
 
 
 def compile_program(prog: Program, outdir: str, name: str, sym: bool = True, strands=DEFAULT_STRANDS, bits="auto",
-                    pipe=DEFAULT_PIPE, mont="auto", jit="auto") -> Compiled:
+                    pipe=DEFAULT_PIPE, mont="auto", jit="auto", fpjit="auto") -> Compiled:
     """strands: strand counts to lower the schedule for (one variant each; the runtime picks per batch).
     pipe: (rows, loads) per batch of the pipelined variant, e.g. (8, 8), which is added last; None = no pipelined variant.
     mont: signals in Montgomery form on the device (True / False / "auto" = choose_mont); CW_MONT=0/1 overrides."""
@@ -160,9 +190,10 @@ def compile_program(prog: Program, outdir: str, name: str, sym: bool = True, str
         tapes.append(lower(fc, pipe=pipe, mont=mont))
     tape = tapes[0]
     p = lambda ext: os.path.join(outdir, name + ext)
-    writers.write_tape(p(".cwt"), tapes, bittape, jp)
+    fps = emit_fpjit(tapes, fc, False if (bittape is not None and fpjit == "auto") else fpjit)
+    writers.write_tape(p(".cwt"), tapes, bittape, jp, fps)
     writers.write_dat(p(".dat"), fc)
     writers.write_r1cs(p(".r1cs"), fc)
     if sym:
         writers.write_sym(p(".sym"), fc)
-    return Compiled(name, outdir, p(".cwt"), p(".dat"), p(".r1cs"), p(".sym"), fc, tape, bittape, jp)
+    return Compiled(name, outdir, p(".cwt"), p(".dat"), p(".r1cs"), p(".sym"), fc, tape, bittape, jp, fps)

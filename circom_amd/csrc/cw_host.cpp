@@ -224,6 +224,15 @@ struct Variant {               // one lowering of the schedule for a given stran
     std::vector<uint32_t> seq_off, seqs;    // per strand: flat-operation index of every row that can fail a check, in row order
 };
 
+// the row stream of one strand variant as EMITTED gfx950 code (hip_elements/fpjit.py): straight-line code that loads the
+// operands of every row, calls the operator's body and stores the result - no descriptors, no dispatch, exact wait counts
+struct FpJit {
+    uint32_t n_strands = 1, lds_bytes = 0, scratch_bytes = 0, n_vgpr = 0;
+    std::vector<uint8_t> code;                                       // ELF code object (hipModuleLoadData)
+    std::map<int, std::pair<hipModule_t, hipFunction_t>> mod;        // device -> loaded module
+};
+constexpr const char *FPJIT_KERNEL = "cw_fp_jit";
+
 struct cw_circuit {
     U256 q;
     FpParams P;
@@ -232,6 +241,7 @@ struct cw_circuit {
     bool need_full = false;
     bool mont = false;                     // the value table holds Montgomery forms x R' (lower.py pass A6)
     std::vector<Variant> variants;
+    std::vector<FpJit> fpjit;              // emitted code of strand variants (at most one per strand count)
     uint32_t n_dat_consts = 0xFFFFFFFFu, n_io_templates = 0;   // sections of the .dat (0xFFFFFFFF: constants count unknown)
     struct IoDef { uint32_t offset = 0, size = 0, bus_id = 0; std::vector<uint32_t> lengths; };
     struct IoTemplate { uint32_t id = 0; std::vector<IoDef> defs; };
@@ -954,6 +964,36 @@ static int load_tape(cw_circuit *c, const char *path) {
         if (const char *why = cwbits::validate_jit(jp, c->n_signals, c->n_inputs)) return fail(CW_EIO, std::string("tape: ") + why);
         c->has_jit = true;
     }
+    // emitted 256-bit code (optional trailing section, hip_elements/fpjit.py): "FPJT" | u32 format 1 | u32 n, then per program
+    // 8 x u32 {n_strands, code bytes, LDS bytes, scratch bytes, VGPRs, 0, 0, 0} and the code object padded to 4 bytes
+    if (off + 12 <= b.size() && memcmp(b.data() + off, "FPJT", 4) == 0) {
+        uint32_t fh[2];
+        memcpy(fh, b.data() + off + 4, 8);
+        off += 12;
+        if (fh[0] != 1 || fh[1] > 8) return fail(CW_EIO, "tape emitted 256-bit code: unknown format version (lowered by another release)");
+        for (uint32_t k = 0; k < fh[1]; k++) {
+            if (off + 32 > b.size()) return fail(CW_EIO, "tape emitted 256-bit code truncated");
+            uint32_t ph[8];
+            memcpy(ph, b.data() + off, 32);
+            off += 32;
+            const uint64_t padded = ((uint64_t)ph[1] + 3) & ~3ull;
+            if (ph[0] == 0 || ph[0] > 16 || (ph[0] & (ph[0] - 1)) || ph[2] > 160 * 1024 || ph[3] > 4096 || ph[4] > 512 || ph[5] || ph[6] || ph[7] ||
+                ph[1] < 64 || padded > b.size() - off)
+                return fail(CW_EIO, "tape emitted 256-bit code: bad header");
+            if (memcmp(b.data() + off, "\x7f" "ELF", 4) != 0) return fail(CW_EIO, "tape emitted 256-bit code: not a code object");
+            bool have_variant = false;
+            for (auto &v : c->variants) have_variant |= (v.kind == 0 && v.n_strands == ph[0]);
+            if (!have_variant) return fail(CW_EIO, "tape emitted 256-bit code: no schedule variant with that strand count");
+            FpJit fj;
+            fj.n_strands = ph[0];
+            fj.lds_bytes = ph[2];
+            fj.scratch_bytes = ph[3];
+            fj.n_vgpr = ph[4];
+            fj.code.assign(b.data() + off, b.data() + off + ph[1]);
+            off += (size_t)padded;
+            c->fpjit.push_back(std::move(fj));
+        }
+    }
     // hash map as generate_hash_map builds it (c_code_generator.rs:575-587); replaced by the .dat's if given
     c->hashmap.assign(hsize, HashEntry{0, 0, 0});
     // insertion order must be the reference's (main input list order = slot order)
@@ -1225,6 +1265,9 @@ extern "C" void cw_free(cw_circuit *c) {
     for (auto &kv : c->jit_mod) {               // modules of the emitted bit-plane code, one per device that ran it
         if (hipSetDevice(kv.first) == hipSuccess) hipModuleUnload(kv.second.first);
     }
+    for (auto &fj : c->fpjit)
+        for (auto &kv : fj.mod)
+            if (hipSetDevice(kv.first) == hipSuccess) hipModuleUnload(kv.second.first);
     delete c;
 }
 extern "C" uint32_t cw_io_map_size(const cw_circuit *c) { return c ? (uint32_t)c->io_map.size() : 0; }
@@ -1355,6 +1398,8 @@ struct cw_batch {
     uint64_t bits_slots = 0;
     uint32_t bits_sh = 0, n_groups_padded = 0;
     const std::vector<uint32_t> *bits_sigslot = nullptr;
+    hipFunction_t fp_fn = nullptr;                     // emitted code of the chosen strand variant (nullptr: the interpreter runs it)
+    uint32_t fp_lds = 0;
     bool jit = false, table_dirty = false;             // emitted code runs this batch; the caller holds a raw pointer to the table
     hipFunction_t jit_fn = nullptr;
     // 64-bit runtime: V64[slot][Bp], its program and R1CS terms
@@ -1510,6 +1555,27 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
         b->lanes = lanes;
         b->prio_mask = best->prio_mask;
         if (const char *e = getenv("CW_PRIO_MASK")) b->prio_mask = (uint32_t)strtoul(e, nullptr, 0);   // diagnostics
+        // the variant's emitted code, when the tape carries it (CW_FP_JIT = 0: interpret the rows instead)
+        const char *fe_ = getenv("CW_FP_JIT");
+        if (best->kind == 0 && !(fe_ && atoi(fe_) == 0)) {
+            for (auto &fj : c->fpjit) {
+                if (fj.n_strands != best->n_strands) continue;
+                auto it = fj.mod.find(b->device);
+                if (it == fj.mod.end()) {
+                    hipModule_t mod = nullptr;
+                    hipFunction_t fn = nullptr;
+                    hipError_t e1 = hipModuleLoadData(&mod, fj.code.data());
+                    if (e1 == hipSuccess) e1 = hipModuleGetFunction(&fn, mod, FPJIT_KERNEL);
+                    if (e1 != hipSuccess) {
+                        delete b;
+                        return fail(CW_EDEVICE, std::string("loading the emitted 256-bit code failed: ") + hipGetErrorString(e1));
+                    }
+                    it = fj.mod.emplace(b->device, std::make_pair(mod, fn)).first;
+                }
+                b->fp_fn = it->second.second;
+                b->fp_lds = fj.lds_bytes;
+            }
+        }
     }
     size_t slots = (size_t)c->n_signals + b->var->n_tslots;
     b->v_bytes = slots * 2 * b->Bp * 16;
@@ -1746,6 +1812,7 @@ extern "C" uint32_t cw_batch_size(const cw_batch *b) { return b->batch; }
 extern "C" int cw_circuit_montgomery(const cw_circuit *c) { return c && c->mont ? 1 : 0; }
 extern "C" uint32_t cw_batch_strands(const cw_batch *b) { return b->var ? b->var->n_strands : 0; }
 extern "C" uint32_t cw_batch_pipelined(const cw_batch *b) { return b && b->var && b->var->kind == 1 ? b->var->nb | (b->var->nld << 8) : 0; }
+extern "C" uint32_t cw_batch_emitted(const cw_batch *b) { return b && b->fp_fn ? 1 : 0; }
 extern "C" uint32_t cw_batch_lanes(const cw_batch *b) { return b->bitmode ? b->bits_width : b->lanes; }
 
 static int ensure_host_staging(cw_batch *b) {
@@ -2309,6 +2376,24 @@ extern "C" int cw_run(cw_batch *b) {
         HIPCHK(cwk_eval_pipe(b->stream, c->need_full, false, b->var->nb, b->var->nld, b->d_prows, (uint32_t)(b->var->prows.size() / 8),
                              b->d_ploads, b->d_terms, b->d_V, b->d_consts, b->d_lconsts, (uint64_t)2 * b->Bp * 16, b->Bp, b->batch,
                              b->lanes, b->d_status, c->P));
+        b->ran = true;
+        return CW_OK;
+    }
+    if (b->fp_fn) {
+        // the variant's rows as straight-line code: one workgroup of n_strands waves per `lanes` instances, as cwk_eval
+        struct { void *V; uint32_t *status; uint32_t Bp, batch, lanes, pad; FpParams P; uint32_t pad2; } args;
+        static_assert(sizeof(FpParams) == 53 * 4, "the emitted code loads 53 parameter words");
+        memset(&args, 0, sizeof(args));
+        args.V = b->d_V;
+        args.status = b->d_status;
+        args.Bp = b->Bp;
+        args.batch = b->batch;
+        args.lanes = b->lanes;
+        args.P = c->P;
+        size_t asz = sizeof(args);
+        void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+        HIPCHK(hipModuleLaunchKernel(b->fp_fn, (b->batch + b->lanes - 1) / b->lanes, 1, 1, 64 * b->var->n_strands, 1, 1, 0, b->stream,
+                                     nullptr, cfg));
         b->ran = true;
         return CW_OK;
     }

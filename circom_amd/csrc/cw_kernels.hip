@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include "cw_kernels.h"
 #include "fp256.hip.h"
+#include "cw_rowops.hip.h"
 
 #define CW_BLOCK 256
 
@@ -138,18 +139,6 @@ extern __shared__ uint4 cw_lds[];       // [slot][2 halves][64 lanes] x 16 B
 // Status word of an instance = bits | index << 8, index = the flat operation of the failing check (cw_tape.h).  When several
 // checks fail - in any row order, on any strand - the smallest index wins: the check the reference's sequential program
 // stops at (assert_bucket.rs:75-77, calcwit.cpp:104-114).
-__device__ __forceinline__ void cw_fail(uint32_t &st, uint32_t bits, uint32_t idx) {
-    if (st == 0 || idx < (st >> 8)) st = bits | (idx << 8);
-}
-__device__ __forceinline__ void cw_publish_status(uint32_t *status, uint32_t i, uint32_t st) {
-    uint32_t old = status[i];
-    while (old == 0 || (st >> 8) < (old >> 8)) {
-        const uint32_t prev = atomicCAS(&status[i], old, st);
-        if (prev == old) break;
-        old = prev;
-    }
-}
-
 struct EvalCtx {                         // per-wave constants of the interpreter
     const char *Vb;                      // value table, bytes
     const char *Cb;                      // constant table, bytes
@@ -206,25 +195,6 @@ __device__ __forceinline__ void store_off(uint64_t off, const EvalCtx &c, const 
 // 64x64-bit products in two unsigned 192-bit accumulators (positive / negative terms) with no modular
 // reduction at all; a lane holding anything else sends the wave through the generic field path for that
 // term.  Result = g + P - N reduced once.  Terms are read at execution time, one ahead of their use.
-struct Acc192 { uint64_t w0, w1, w2; };
-__device__ __forceinline__ void acc192_add(Acc192 &a, uint64_t lo, uint64_t hi) {
-    const uint64_t s0 = a.w0 + lo;
-    const uint64_t c0 = s0 < lo;
-    const uint64_t s1 = a.w1 + hi;
-    const uint64_t c1 = s1 < hi;
-    const uint64_t s1b = s1 + c0;
-    const uint64_t c1b = s1b < c0;
-    a.w0 = s0;
-    a.w1 = s1b;
-    a.w2 += c1 + c1b;
-}
-__device__ __forceinline__ fe acc192_to_fe(const Acc192 &a) {
-    fe r = fe_zero();
-    r.v[0] = (uint32_t)a.w0; r.v[1] = (uint32_t)(a.w0 >> 32);
-    r.v[2] = (uint32_t)a.w1; r.v[3] = (uint32_t)(a.w1 >> 32);
-    r.v[4] = (uint32_t)a.w2; r.v[5] = (uint32_t)(a.w2 >> 32);
-    return r;
-}
 // LDS_ONLY: the pipelined kernel has no value-table operands (and must not contain a single vector-memory load: hipcc
 // would guard the merged registers with s_waitcnt vmcnt(small), which also drains the stores and LDS-DMA loads in flight)
 template <bool LDS_ONLY = false>
@@ -234,29 +204,6 @@ __device__ __forceinline__ fe term_load(uint64_t t0, const fe &prev, const EvalC
     if (kind == K_PREV) return prev;
     if (LDS_ONLY || kind == K_LDS) return lds_load_off((uint32_t)off, c);
     return fetch_off(K_SIG, off, c);
-}
-__device__ __forceinline__ void linsum_term(const fe &xc, uint64_t cf, fe &g, Acc192 &pos, Acc192 &neg, const FpParams &P) {
-    const uint64_t mag = cf & 0x7FFFFFFFFFFFFFFFull;
-    const bool cneg = cf >> 63;
-    if (__all(fe_hi_or(xc) == 0)) {
-        // 64x64 -> 128-bit product, accumulated without reduction
-        const uint32_t a0 = xc.v[0], a1 = xc.v[1], b0 = (uint32_t)mag, b1 = (uint32_t)(mag >> 32);
-        uint64_t t = (uint64_t)a0 * b0;
-        const uint32_t r0 = (uint32_t)t;
-        t = (uint64_t)a0 * b1 + (t >> 32);
-        const uint64_t t2 = (uint64_t)a1 * b0 + (uint32_t)t;
-        const uint64_t hi = (uint64_t)a1 * b1 + (t >> 32) + (t2 >> 32);
-        const uint64_t lo = ((uint64_t)(uint32_t)t2 << 32) | r0;
-        if (cneg) acc192_add(neg, lo, hi);
-        else acc192_add(pos, lo, hi);
-    } else if (mag) {
-        // generic: coef * x in the field (coef as a canonical element)
-        fe cm = fe_zero();
-        cm.v[0] = (uint32_t)mag;
-        cm.v[1] = (uint32_t)(mag >> 32);
-        const fe p = fe_mul2_auto(xc, cm, P);
-        g = cneg ? fe_sub(g, p, P) : fe_add(g, p, P);
-    }
 }
 // Terms are processed W at a time (W = 2 or 4): one scalar load brings the table entries, the W operand loads are in
 // flight together (memory-level parallelism), then the products are accumulated.  Entries past the row's last

@@ -493,6 +493,11 @@ __device__ __forceinline__ bool fe_lt(const fe &x, const fe &y, const FpParams &
 // keeping a = u*y, b = v*y (mod q).  After ceil((2*qbits - 1) / 30) rounds (17 for a 254-bit prime) b = 1 and
 // v = 1/y: ~22 K VALU instructions instead of ~100 K for the Fermat power y^(q-2).
 // oracle/bingcd_model.py restates this routine limb for limb; tests pin both against pow(y, -1, q).
+// slow-path operators: out of line in the interpreting kernels (one copy, registers of the lean variant unaffected), inlined
+// into the row bodies of the emitted code (fpjit.py: a body is a leaf, it cannot call)
+#ifndef CW_FE_SLOW
+#define CW_FE_SLOW __noinline__
+#endif
 #define INV_K 30
 struct w9 { uint32_t v[9]; };
 
@@ -554,7 +559,7 @@ __device__ __forceinline__ void inv_approx(const fe &a, const fe &b, uint64_t &x
     xa = exact ? ((uint64_t)a.v[1] << 32 | a.v[0]) : ta;
     xb = exact ? ((uint64_t)b.v[1] << 32 | b.v[0]) : tb;
 }
-__device__ __noinline__ fe fe_inv(const fe &y, const FpParams &P) {
+__device__ CW_FE_SLOW fe fe_inv(const fe &y, const FpParams &P) {
     fe a = y, b = fe_from(P.q), u = fe_small(1), v = fe_zero();
     uint32_t ninv = 1;                                              // -q^-1 mod 2^30 (wave-uniform, scalar unit)
     for (int i = 0; i < 5; i++) ninv *= 2u - P.q[0] * ninv;
@@ -621,25 +626,27 @@ __device__ __noinline__ fe fe_inv(const fe &y, const FpParams &P) {
     return v;
 }
 // x^y with a per-lane exponent (Fr_pow / mpz_powm, generic/fr.cpp:2877-2893; 0^0 = 1)
-__device__ __noinline__ fe fe_pow(const fe &x, const fe &y, const FpParams &P) {
+__device__ CW_FE_SLOW fe fe_pow(const fe &x, const fe &y, const FpParams &P) {
     fe29 r2;
     FE_UNROLL for (int k = 0; k < 9; k++) r2.l[k] = P.r2_29[k];
     const fe29 xm = fe29_mmul(fe_to29(x), r2, P);
     fe29 r = fe_to29(fe_from(P.one_m));
-    FE_UNROLL for (int w = 7; w >= 0; w--) {
-        const uint32_t ew = y.v[w];
-        for (int b = 31; b >= 0; b--) {
-            r = fe29_mmul(r, r, P);
-            const fe29 rx = fe29_mmul(r, xm, P);
-            const bool bit = (ew >> b) & 1;
-            FE_UNROLL for (int k = 0; k < 9; k++) r.l[k] = bit ? rx.l[k] : r.l[k];
-        }
+    // one loop over the 256 exponent bits; the word is picked by a select ladder on the (wave-uniform) index - indexing
+    // y.v[] with a loop variable would make the compiler park the exponent in scratch / LDS
+    for (int i = 255; i >= 0; i--) {
+        const int w = i >> 5;
+        const uint32_t ew = w == 0 ? y.v[0] : w == 1 ? y.v[1] : w == 2 ? y.v[2] : w == 3 ? y.v[3] : w == 4 ? y.v[4]
+                            : w == 5 ? y.v[5] : w == 6 ? y.v[6] : y.v[7];
+        r = fe29_mmul(r, r, P);
+        const fe29 rx = fe29_mmul(r, xm, P);
+        const bool bit = (ew >> (i & 31)) & 1;
+        FE_UNROLL for (int k = 0; k < 9; k++) r.l[k] = bit ? rx.l[k] : r.l[k];
     }
     return fe_from29(fe29_mmul(r, fe_to29(fe_small(1)), P));
 }
 // floor(x / y), x mod y on canonical integers (Fr_idiv/Fr_mod via mpz_fdiv_q/r, generic/fr.cpp:2835-2875).
 // Restoring shift-subtract division; y == 0 is reported by the caller.
-__device__ __noinline__ void fe_divmod(const fe &x, const fe &y, fe *quo, fe *rem) {
+__device__ CW_FE_SLOW void fe_divmod(const fe &x, const fe &y, fe *quo, fe *rem) {
     fe q = fe_zero(), r = fe_zero();
     // leading words that are zero in EVERY lane are skipped (wave-uniform test): the integer divisions of witness code are
     // mostly on limb-sized values (bigint long division: 64..96-bit numerators - 2-3 of the 8 words), and a word costs

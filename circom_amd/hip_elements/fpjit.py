@@ -1,0 +1,603 @@
+"""hip_elements, emitted 256-bit code, part 2: the row stream of a schedule as STRAIGHT-LINE gfx950 code.
+
+The reference's C back-end turns the witness program into code (one C++ function per template,
+compiler/src/circuit_design/template.rs:174-474; a `Fr_mul(&dst, &a, &b)` call per ComputeBucket,
+compute_bucket.rs:315-421); the 256-bit engine of rounds 1-3 INTERPRETS its schedule instead: `cw_eval_kernel` spends
+~300 instructions of glue per row (a 38-way switch, operand-kind tests, descriptor loads, conservative `s_waitcnt`s that
+also wait for the previous row's stores) around ~320 instructions of arithmetic.  This module is the emitting
+counterpart: a lowered schedule (`lower.Tape`: the rows of every strand with their operand kinds, extra destinations, term
+tables, barriers - exactly what the interpreter walks and what `oracle/tape_eval.py` replays and race-checks) is printed as
+one kernel in which every row is
+
+    [address arithmetic + loads of the NEXT step's operands]      prefetch, one step ahead, into the other register set
+    s_waitcnt vmcnt(N)                                             N counted exactly: the stores issued since are not waited for
+    [constants as literals, PREV as register moves]
+    s_swappc_b64 -> row body (fpjit_bodies.py)                     the operator, compiled from the interpreter's own C++
+    [address arithmetic + stores of the result]
+
+so the glue is ~20 instructions, nothing is decoded at run time, and a wave of strand s runs strand s's own code.  The
+execution model is the interpreter's (one-step-ahead prefetch, PREV forwarding, LDS hand-off slots, LIGHT/FULL barriers),
+so the schedule's race analysis carries over; what is new - wait counts, register sets, clobbers - is replayed on the CPU
+by `oracle/fpjit_eval.py` from the IR this module returns next to the text.
+
+Value table, constants, status words, Montgomery forms: unchanged (`csrc/cw_kernels.hip` ingest / check / egress kernels
+serve both engines).  LDS hand-off slots are 2 KiB here whatever the lane count (literal offsets).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from . import fpjit_bodies as FB
+from .lower import (D_COPY, D_ADD, D_SUB, D_NEG, D_MMUL, D_INV, D_IDIV, D_MOD, D_POW, D_SHL, D_SHR, D_BAND, D_BOR, D_BXOR,
+                    D_BNOT, D_LT, D_GT, D_LEQ, D_GEQ, D_EQ, D_NEQ, D_LAND, D_LOR, D_LNOT, D_SELECT, D_EXT, D_ASSERT_EQ,
+                    D_ASSERT_NZ, D_BARRIER, D_MUL2, D_MADD, D_MULC, D_MADDC, D_LINSUM, D_BIT, D_DOTC, D_CALL,
+                    SH_DK, SH_AK, SH_BK, SH_NX, SH_FLAG, X_TMP, X_LDS, K_LDS, KD_NONE, KO_PREV)
+
+KERNEL_NAME = "cw_fp_jit"
+K_SIG, K_TMP, K_CONST = 0, 1, 2
+LDS_SLOT = 2048
+PARK_BYTES = 4096             # start of the workgroup's LDS: 256 bytes per strand where inv_h's caller parks the status words
+KERNARG_BYTES = 32 + 4 * FB.N_PARAM_SGPRS + 4          # V, status, Bp, batch, lanes, pad, FpParams (53 dwords), pad -> 248
+VMCNT_MAX, LGKM_MAX = 63, 15
+
+# owned registers (fpjit_bodies.py keeps them live through every body)
+V_VLO, V_VHI, V_L16, V_ST, V_L16B, V_L16C, V_I = 120, 121, 122, 124, 125, 126, 127
+S_BATCH, S_VBASE, S_STATUS, S_RET, S_STRIDE, S_WGBASE = 93, 94, 96, 98, 100, 101
+
+_TWO = {D_ADD: "add", D_SUB: "sub", D_MMUL: "mmul", D_MUL2: "mul2", D_SHL: "shl", D_SHR: "shr", D_BAND: "band", D_BOR: "bor",
+        D_BXOR: "bxor", D_LT: "lt", D_GT: "gt", D_LEQ: "leq", D_GEQ: "geq", D_EQ: "eq", D_NEQ: "neq", D_LAND: "land",
+        D_LOR: "lor", D_MADD: "madd", D_EXT: "ext"}
+_ONE = {D_NEG: "neg", D_BNOT: "bnot", D_LNOT: "lnot"}
+_HEAVY = {D_INV: "inv_h", D_POW: "pow_h", D_IDIV: "idiv_h", D_MOD: "mod_h"}
+_NO_VALUE = (D_ASSERT_EQ, D_ASSERT_NZ, D_SELECT)
+
+
+class FpJitProgram:
+    def __init__(self):
+        self.n_strands = 1
+        self.asm = ""
+        self.code = None          # the code object (ELF) after assemble()
+        self.ir = None            # per strand: list of IR tuples (oracle/fpjit_eval.py)
+        self.lds_bytes = 0
+        self.scratch_bytes = 0
+        self.stats = {}
+
+
+def _limbs32(v):
+    return [(v >> (32 * k)) & 0xFFFFFFFF for k in range(8)]
+
+
+def _limbs29(v):
+    return [(v >> (29 * k)) & 0x1FFFFFFF for k in range(9)]
+
+
+class _Step:
+    """one call of a body (or an inline operation) with what it needs from memory and what it leaves there"""
+    __slots__ = ("loads", "pre", "body", "inline", "stores", "barrier", "heavy", "value", "sarg", "coef")
+
+    def __init__(self):
+        self.loads = []        # (which 'A' | 'B', kind, index)  kind: K_SIG / K_TMP (unified slot = index) or K_LDS
+        self.pre = []          # ("prev", which) | ("const", which | 'G', value) | ("zero", 'G') | ("zacc", n)
+        self.body = None       # body name without parity suffix ("mmul"), or full name for parity-less bodies
+        self.inline = None     # ("bit", k) | ("copy",)
+        self.stores = []       # (kind, index)
+        self.barrier = None    # None | 0 (LIGHT) | 1 (FULL): the step IS a barrier
+        self.heavy = False
+        self.value = False     # the step leaves a new value in D
+        self.sarg = None       # 64-bit literal for s[36:37]
+        self.coef = None       # nine 29-bit limbs for s[24:32]
+
+
+def expand_steps(tape, strand):
+    """rows of one strand -> steps.  Slots are unified: signal s -> s, temp slot t -> n_signals + t."""
+    rows = tape.rows
+    r0, r1 = int(tape.stream_off[strand]), int(tape.stream_off[strand + 1])
+    xp = int(tape.extra_off[strand])
+    tp = int(tape.term_off[strand])
+    sp = int(tape.seq_off[strand]) if len(tape.seq_off) > strand else 0
+    ns = tape.n_signals
+    consts = tape.consts
+    steps = []
+
+    def opnd(st, which, k, v):
+        if k == KO_PREV:
+            st.pre.append(("prev", which))
+        elif k == K_CONST:
+            st.pre.append(("const", which, consts[v]))
+        elif k == K_LDS:
+            st.loads.append((which, K_LDS, v))
+        elif k == K_SIG:
+            st.loads.append((which, K_SIG, v))
+        elif k == K_TMP:
+            st.loads.append((which, K_SIG, ns + v))
+        else:
+            raise ValueError("operand kind %d" % k)
+
+    for r in range(r0, r1):
+        w0, dst, a_, b_ = (int(x) for x in rows[r])
+        op, dk, ak, bk = w0 & 0xFF, (w0 >> SH_DK) & 7, (w0 >> SH_AK) & 7, (w0 >> SH_BK) & 7
+        nx, flag = (w0 >> SH_NX) & 0xFFF, (w0 >> SH_FLAG) & 3
+        if op == D_BARRIER:
+            st = _Step()
+            st.barrier = 1 if dst == 1 else 0
+            steps.append(st)
+            continue
+        seq = None
+        if op in (D_ASSERT_EQ, D_ASSERT_NZ, D_IDIV, D_MOD, D_CALL):
+            seq = int(tape.seqs[sp])
+            sp += 1
+        stores = []
+        if op not in _NO_VALUE and op != D_CALL:
+            if dk == K_SIG:
+                stores.append((K_SIG, dst))
+            elif dk == K_TMP:
+                stores.append((K_SIG, ns + dst))
+            elif dk == K_LDS:
+                stores.append((K_LDS, dst))
+            for e in tape.extras[xp:xp + nx]:
+                e = int(e)
+                if e & X_LDS:
+                    stores.append((K_LDS, e & 0x3FFFFFFF))
+                elif e & X_TMP:
+                    stores.append((K_SIG, ns + (e & 0x3FFFFFFF)))
+                else:
+                    stores.append((K_SIG, e))
+        elif nx:
+            raise ValueError("extra destinations on a row without a value")
+        xp += nx
+        st = _Step()
+        if op in _TWO:
+            st.body = _TWO[op]
+            opnd(st, "A", ak, a_)
+            opnd(st, "B", bk, b_)
+            st.value = True
+        elif op in _ONE:
+            st.body = _ONE[op]
+            opnd(st, "A", ak, a_)
+            st.value = True
+        elif op in _HEAVY:
+            st.body = _HEAVY[op]
+            st.heavy = True
+            opnd(st, "A", ak, a_)
+            if op != D_INV:
+                opnd(st, "B", bk, b_)
+            if seq is not None:
+                st.sarg = seq
+            st.value = True
+        elif op in (D_MULC, D_MADDC):
+            st.body = ("mulc0", "mulcp", "mulcn")[flag] + ("a" if op == D_MADDC else "")
+            opnd(st, "A", ak, a_)
+            assert bk == K_CONST
+            st.pre.append(("const", "B", consts[b_]))
+            if flag:
+                st.sarg = consts[b_ + 1]
+                assert st.sarg < (1 << 63)
+            st.value = True
+        elif op == D_COPY:
+            st.inline = ("copy",)
+            opnd(st, "A", ak, a_)
+            st.value = True
+        elif op == D_BIT:
+            st.inline = ("bit", b_)
+            opnd(st, "A", ak, a_)
+            st.value = True
+        elif op == D_SELECT:
+            st.body = "select"
+            opnd(st, "A", ak, a_)
+        elif op == D_ASSERT_EQ:
+            st.body = "asserteq"
+            opnd(st, "A", ak, a_)
+            opnd(st, "B", bk, b_)
+            st.sarg = seq
+        elif op == D_ASSERT_NZ:
+            st.body = "assertnz"
+            opnd(st, "A", ak, a_)
+            st.sarg = seq
+        elif op in (D_LINSUM, D_DOTC):
+            n = a_
+            c0 = consts[b_] if bk == K_CONST else None
+            terms = [tuple(int(x) for x in t) for t in tape.terms[tp:tp + n]]
+            tp += n
+            first = True
+            for j, (tk, tv, lo, hi) in enumerate(terms):
+                t = _Step()
+                kind = tk & 7
+                if first:
+                    t.pre.append(("const", "G", c0) if c0 is not None else ("zero", "G"))
+                    t.pre.append(("zacc", 12 if op == D_LINSUM else 36))
+                    first = False
+                opnd(t, "A", kind, tv)
+                if op == D_LINSUM:
+                    t.body = "linn" if tk >> 31 else "linp"
+                    t.sarg = lo | (hi << 32)
+                    assert t.sarg < (1 << 63)
+                else:
+                    t.body = "dotmac"
+                    t.coef = _limbs29(tape.lconsts[lo])
+                steps.append(t)
+                if op == D_DOTC and (j & 3) == 3 and j + 1 < n:
+                    t = _Step()
+                    t.body = "dotred"
+                    steps.append(t)
+            st.body = "linfin" if op == D_LINSUM else "dotfin"
+            if first:                       # no terms at all: the constant alone
+                st.pre.append(("const", "G", c0) if c0 is not None else ("zero", "G"))
+                st.pre.append(("zacc", 12 if op == D_LINSUM else 36))
+            st.value = True
+        elif op == D_CALL:
+            raise NotImplementedError("run-time functions (D_CALL) stay with the interpreting kernel")
+        else:
+            raise ValueError("device op %d has no emitted form" % op)
+        st.stores = stores
+        steps.append(st)
+    return steps
+
+
+class _Emitter:
+    def __init__(self, tape, bodies):
+        self.tape, self.bodies = tape, bodies
+        self.L = []
+        self.ir = []
+        self.used_bodies = set()
+        self.n_call = 0
+        self.vm_issued = 0          # vector-memory instructions issued so far by this strand (loads and stores, in order)
+        self.lg_issued = 0          # LDS instructions issued so far
+        self.acc_zero = 0           # leading ACC registers known to be zero
+        self.stats = {"steps": 0, "calls": 0, "glue": 0, "loads": 0, "stores": 0}
+
+    def add(self, s, glue=1):
+        self.L.append("  " + s + "\n")
+        self.stats["glue"] += glue
+
+    # ---- addresses -----------------------------------------------------------------------------------------------------
+    def table_addr(self, slot, sp):
+        """s[sp:sp+1] = V + slot * stride"""
+        if slot == 0:
+            self.add("s_mov_b64 s[%d:%d], s[%d:%d]" % (sp, sp + 1, S_VBASE, S_VBASE + 1))
+            return
+        self.add("s_mul_i32 s%d, s%d, 0x%x" % (sp, S_STRIDE, slot))
+        self.add("s_mul_hi_u32 s%d, s%d, 0x%x" % (sp + 1, S_STRIDE, slot))
+        self.add("s_add_u32 s%d, s%d, s%d" % (sp, sp, S_VBASE))
+        self.add("s_addc_u32 s%d, s%d, s%d" % (sp + 1, sp + 1, S_VBASE + 1))
+
+    @staticmethod
+    def lds_addr(slot):
+        off = PARK_BYTES + slot * LDS_SLOT
+        base = (V_L16, V_L16B, V_L16C)[off >> 16]
+        return base, off & 0xFFFF
+
+    def issue_load(self, reg, kind, idx, sp):
+        if kind == K_LDS:
+            base, off = self.lds_addr(idx)
+            self.add("ds_read_b128 v[%d:%d], v%d offset:%d" % (reg, reg + 3, base, off))
+            self.add("ds_read_b128 v[%d:%d], v%d offset:%d" % (reg + 4, reg + 7, base, off + 1024))
+            self.lg_issued += 2
+            self.ir.append(("ldl", reg, idx, self.lg_issued))
+        else:
+            self.table_addr(idx, sp)
+            self.add("global_load_dwordx4 v[%d:%d], v%d, s[%d:%d]" % (reg, reg + 3, V_VLO, sp, sp + 1))
+            self.add("global_load_dwordx4 v[%d:%d], v%d, s[%d:%d]" % (reg + 4, reg + 7, V_VHI, sp, sp + 1))
+            self.vm_issued += 2
+            self.ir.append(("ld", reg, idx, self.vm_issued))
+        self.stats["loads"] += 1
+
+    def issue_store(self, kind, idx):
+        d = FB.D_REG
+        if kind == K_LDS:
+            base, off = self.lds_addr(idx)
+            self.add("ds_write_b128 v%d, v[%d:%d] offset:%d" % (base, d, d + 3, off))
+            self.add("ds_write_b128 v%d, v[%d:%d] offset:%d" % (base, d + 4, d + 7, off + 1024))
+            self.lg_issued += 2
+            self.ir.append(("stl", idx, self.lg_issued))
+        else:
+            self.table_addr(idx, 4)
+            self.add("global_store_dwordx4 v%d, v[%d:%d], s[4:5]" % (V_VLO, d, d + 3))
+            self.add("global_store_dwordx4 v%d, v[%d:%d], s[4:5]" % (V_VHI, d + 4, d + 7))
+            self.vm_issued += 2
+            self.ir.append(("st", idx, self.vm_issued))
+        self.stats["stores"] += 1
+
+    def mov_fe(self, dst, src):
+        for k in range(8):
+            self.add("v_mov_b32 v%d, v%d" % (dst + k, src + k))
+        self.ir.append(("mov", dst, src))
+
+    def lit_fe(self, dst, value):
+        for k, w in enumerate(_limbs32(value)):
+            self.add("v_mov_b32 v%d, 0x%x" % (dst + k, w))
+        self.ir.append(("lit", dst, value))
+
+    def call(self, name):
+        b = self.bodies[name]
+        self.used_bodies.add(name)
+        k = self.n_call
+        self.n_call += 1
+        self.add("s_getpc_b64 s[2:3]")
+        self.L.append(".Lpc_%d_%d:\n" % (self.strand, k))
+        self.add("s_add_u32 s2, s2, fj_body_%s-.Lpc_%d_%d" % (name, self.strand, k))
+        self.add("s_addc_u32 s3, s3, 0")
+        self.add("s_swappc_b64 s[%d:%d], s[2:3]" % (S_RET, S_RET + 1))
+        self.stats["calls"] += 1
+        # which leading ACC registers are still zero afterwards
+        w = [r for r in b.vwritten if r >= FB.ACC_REG and r < FB.ACC_REG + 36]
+        if name in ("dotred", "dotfin"):
+            self.acc_zero = 36
+        elif w:
+            self.acc_zero = min(self.acc_zero, min(w) - FB.ACC_REG)
+        self.ir.append(("call", name))
+
+    def rederive(self):
+        """the owned vector registers from the lane number (after a heavy body, and in the prologue)"""
+        a = self.add
+        a("v_mbcnt_lo_u32_b32 v%d, -1, 0" % V_L16)
+        a("v_mbcnt_hi_u32_b32 v%d, -1, v%d" % (V_L16, V_L16))          # lane
+        a("v_add_u32 v%d, s%d, v%d" % (V_I, S_WGBASE, V_L16))             # instance
+        a("v_lshlrev_b32 v%d, 4, v%d" % (V_VLO, V_I))
+        a("s_lshr_b32 s4, s%d, 1" % S_STRIDE)                            # Bp * 16
+        a("v_add_u32 v%d, s4, v%d" % (V_VHI, V_VLO))
+        a("v_lshlrev_b32 v%d, 4, v%d" % (V_L16, V_L16))
+        a("v_add_u32 v%d, 0x10000, v%d" % (V_L16B, V_L16))
+        a("v_add_u32 v%d, 0x20000, v%d" % (V_L16C, V_L16))
+
+    # ---- one strand ------------------------------------------------------------------------------------------------------
+    def strand_code(self, strand, steps, prio, park_off):
+        self.strand = strand
+        self.vm_issued = self.lg_issued = 0
+        self.acc_zero = 0
+        self.ir = []
+        a = self.add
+        self.L.append("fj_strand_%d:\n" % strand)
+        debug = bool(os.environ.get("CW_FPJIT_DEBUG"))
+        if debug:        # diagnostics: bit `strand` of the status word = this strand started, bit 16 + strand = it finished
+            a("v_lshlrev_b32 v40, 2, v%d" % V_I)
+            a("v_mov_b32 v41, 0x%x" % (1 << strand))
+            a("global_atomic_or v40, v41, s[%d:%d]" % (S_STATUS, S_STATUS + 1))
+            a("s_waitcnt vmcnt(0)")
+        if prio:
+            a("s_setprio 3")
+        n = len(steps)
+
+        def regs_of(k):
+            p = k & 1
+            return (FB.A_E, FB.B_E) if p == 0 else (FB.A_O, FB.B_O)
+
+        load_seq = {}        # step -> (vm sequence number of its last table load | None, lgkm sequence number | None)
+
+        def issue_loads(k):
+            st = steps[k]
+            ra, rb = regs_of(k)
+            if st.heavy:
+                ra, rb = FB.A_E, FB.B_E
+            vm = lg = None
+            for j, (which, kind, idx) in enumerate(st.loads):
+                self.issue_load(ra if which == "A" else rb, kind, idx, 4 + 2 * j)
+                if kind == K_LDS:
+                    lg = self.lg_issued
+                else:
+                    vm = self.vm_issued
+            load_seq[k] = (vm, lg)
+
+        issued = set()
+        for k, st in enumerate(steps):
+            self.stats["steps"] += 1
+            if st.barrier is not None:
+                # LDS traffic of this wave is complete before any wave passes; global stores stay in flight (the waves of a
+                # workgroup share the CU's L1, which keeps a store ahead of another wave's later load - DESIGN 4.1 (6))
+                a("s_waitcnt lgkmcnt(0)")
+                a("s_barrier")
+                self.ir.append(("bar", st.barrier))
+                continue
+            if k not in issued:
+                issue_loads(k)
+                issued.add(k)
+            # prefetch the next step's operands unless a barrier or a heavy body separates the two
+            nxt = k + 1
+            if nxt < n and steps[nxt].barrier is None and not st.heavy and not steps[nxt].heavy:
+                issue_loads(nxt)
+                issued.add(nxt)
+            vm, lg = load_seq[k]
+            if vm is not None or lg is not None:
+                parts = []
+                if vm is not None:
+                    parts.append("vmcnt(%d)" % min(self.vm_issued - vm, VMCNT_MAX))
+                if lg is not None:
+                    parts.append("lgkmcnt(%d)" % min(self.lg_issued - lg, LGKM_MAX))
+                a("s_waitcnt " + " ".join(parts))
+                self.ir.append(("wait", vm, lg))
+            ra, rb = regs_of(k)
+            par = "eo"[k & 1]
+            if st.heavy:
+                ra, rb, par = FB.A_E, FB.B_E, "h"
+            for p in st.pre:
+                if p[0] == "prev":
+                    self.mov_fe(ra if p[1] == "A" else rb, FB.D_REG)
+                elif p[0] == "const":
+                    self.lit_fe({"A": ra, "B": rb, "G": FB.G_REG}[p[1]], p[2])
+                elif p[0] == "zero":
+                    self.lit_fe(FB.G_REG, 0)
+                elif p[0] == "zacc":
+                    for j in range(self.acc_zero, p[1]):
+                        a("v_mov_b32 v%d, 0" % (FB.ACC_REG + j))
+                    self.ir.append(("zacc", p[1], min(self.acc_zero, p[1])))
+                    self.acc_zero = max(self.acc_zero, p[1])
+            if st.sarg is not None:
+                a("s_mov_b32 s%d, 0x%x" % (FB.S_ARG, st.sarg & 0xFFFFFFFF))
+                a("s_mov_b32 s%d, 0x%x" % (FB.S_ARG + 1, st.sarg >> 32))
+                self.ir.append(("sarg", st.sarg))
+            if st.coef is not None:
+                for j, w in enumerate(st.coef):
+                    a("s_mov_b32 s%d, 0x%x" % (FB.S_COEF + j, w))
+                self.ir.append(("coef", tuple(st.coef)))
+            if st.inline is not None:
+                d = FB.D_REG
+                if st.inline[0] == "copy":
+                    self.mov_fe(d, ra)
+                else:
+                    kbit = st.inline[1]
+                    if kbit < 256:
+                        a("v_bfe_u32 v%d, v%d, %d, 1" % (d, ra + (kbit >> 5), kbit & 31))
+                    else:
+                        a("v_mov_b32 v%d, 0" % d)
+                    for j in range(1, 8):
+                        a("v_mov_b32 v%d, 0" % (d + j))
+                    self.ir.append(("bit", ra, kbit))
+            else:
+                name = st.body if st.body in self.bodies else "%s_%s" % (st.body, par)
+                b = self.bodies[name]
+                if st.heavy:
+                    if name == "inv_h":          # no register to spare for the status word: it waits in LDS
+                        a("v_lshrrev_b32 v%d, 2, v%d" % (V_L16B, V_L16))
+                        a("ds_write_b32 v%d, v%d offset:%d" % (V_L16B, V_ST, park_off))
+                        self.lg_issued += 1
+                    if b.scratch:
+                        a("s_waitcnt vmcnt(0)")
+                    self.call(name)
+                    if b.scratch:
+                        a("s_waitcnt vmcnt(0)")
+                    self.rederive()
+                    if name == "inv_h":
+                        a("v_lshrrev_b32 v%d, 2, v%d" % (V_ST, V_L16))
+                        a("ds_read_b32 v%d, v%d offset:%d" % (V_ST, V_ST, park_off))
+                        a("s_waitcnt lgkmcnt(0)")
+                        self.lg_issued += 1
+                    self.ir.append(("heavy_done",))
+                else:
+                    self.call(name)
+            for kind, idx in st.stores:
+                self.issue_store(kind, idx)
+            if any(kind != K_LDS for kind, _ in st.stores):
+                a("s_nop 1")      # a 128-bit store must have read its data registers before anything writes D again
+        # end of the strand: the first failed check of every instance reaches the status array
+        if debug:
+            a("s_waitcnt vmcnt(0)")
+            a("v_lshlrev_b32 v40, 2, v%d" % V_I)
+            a("v_mov_b32 v41, 0x%x" % (1 << (16 + strand)))
+            a("global_atomic_or v40, v41, s[%d:%d]" % (S_STATUS, S_STATUS + 1))
+            a("s_waitcnt vmcnt(0)")
+            a("s_endpgm")
+        self.call("publish")
+        a("s_endpgm")
+        return self.ir
+
+
+def emit(tape, bodies=None) -> FpJitProgram:
+    """the emitted kernel of one schedule variant (strand schedule, kind 0)"""
+    if getattr(tape, "kind", 0) != 0:
+        raise ValueError("only strand schedules have an emitted form")
+    if tape.functions and (np.asarray(tape.rows)[:, 0] & 0xFF == D_CALL).any():
+        raise NotImplementedError("run-time functions (D_CALL) stay with the interpreting kernel")
+    S = tape.n_strands
+    assert S & (S - 1) == 0 and 1 <= S <= 16
+    if bodies is None:
+        bodies = FB.build_bodies()
+    em = _Emitter(tape, bodies)
+    all_steps = [expand_steps(tape, s) for s in range(S)]
+    # strands that carry >= 80 % of the heaviest strand's work run at raised priority (as cw_eval_kernel's prio_mask)
+    cost = []
+    for steps in all_steps:
+        c = 0
+        for st in steps:
+            if st.body:
+                nm = st.body if st.body in bodies else st.body + "_e"
+                c += min(bodies[nm].n_instr, 2000)
+        cost.append(c)
+    heaviest = max(cost) if cost else 0
+    n_lds = int(tape.n_lds)
+    park = 0                                     # status words parked around inv_h: 256 bytes per strand, then the slots
+    L = em.L
+    L.append('.amdgcn_target "amdgcn-amd-amdhsa--gfx950"\n.text\n.globl %s\n.p2align 8\n.type %s,@function\n%s:\n'
+             % (KERNEL_NAME, KERNEL_NAME, KERNEL_NAME))
+    a = em.add
+    # s[0:1] kernarg, s2 = workgroup id; v0 = work-item id.  Kernel arguments: V, status, Bp, batch, lanes, pad, FpParams
+    a("s_load_dwordx4 s[4:7], s[0:1], 0x0")
+    a("s_load_dwordx4 s[8:11], s[0:1], 0x10")
+    off = 0x20
+    s = FB.S_PARAMS
+    left = FB.N_PARAM_SGPRS
+    while left:
+        w = 16 if left >= 16 else 4 if left >= 4 else 1
+        a("s_load_dword%s s%s, s[0:1], 0x%x" % ({16: "x16", 4: "x4", 1: ""}[w], "[%d:%d]" % (s, s + w - 1) if w > 1 else "%d" % s, off))
+        s += w
+        off += 4 * w
+        left -= w
+    a("v_lshrrev_b32 v1, 6, v0")
+    a("s_nop 1")                                          # a VGPR write needs a wait state before v_readfirstlane reads it
+    a("v_readfirstlane_b32 s3, v1")
+    a("s_waitcnt lgkmcnt(0)")
+    a("s_mov_b64 s[%d:%d], s[4:5]" % (S_VBASE, S_VBASE + 1))
+    a("s_mov_b64 s[%d:%d], s[6:7]" % (S_STATUS, S_STATUS + 1))
+    a("s_lshl_b32 s%d, s8, 5" % S_STRIDE)                  # bytes per value slot = 2 * Bp * 16
+    a("s_mov_b32 s%d, s9" % S_BATCH)
+    a("s_mul_i32 s%d, s2, s10" % S_WGBASE)                 # first instance of the workgroup = wg * lanes
+    # lanes beyond `lanes` are idle for the whole kernel (small batches of long schedules are spread over more workgroups)
+    a("s_cmp_ge_u32 s10, 64")
+    a("s_cbranch_scc1 .Lfull_wave")
+    a("s_bfm_b64 exec, s10, 0")
+    L.append(".Lfull_wave:\n")
+    # strand of this wave: rotated by the workgroup index (the critical strand does not sit on the same SIMD everywhere)
+    a("s_add_u32 s3, s3, s2")
+    a("s_and_b32 s3, s3, %d" % (S - 1))
+    em.strand = 0
+    em.rederive()
+    a("v_mov_b32 v%d, 0" % V_ST)
+    a("s_mov_b64 s[%d:%d], 0" % (FB.S_SEL, FB.S_SEL + 1))
+    for k in range(8):
+        a("v_mov_b32 v%d, 0" % (FB.D_REG + k))
+    for s_ in range(1, S):
+        a("s_cmp_eq_u32 s3, %d" % s_)
+        a("s_cbranch_scc1 .Ljump_%d" % s_)
+    if S > 1:
+        a("s_branch fj_strand_0")
+        for s_ in range(1, S):
+            L.append(".Ljump_%d:\n" % s_)
+            a("s_getpc_b64 s[4:5]")
+            L.append(".Ljpc_%d:\n" % s_)
+            a("s_add_u32 s4, s4, fj_strand_%d-.Ljpc_%d" % (s_, s_))
+            a("s_addc_u32 s5, s5, 0")
+            a("s_setpc_b64 s[4:5]")
+    prog = FpJitProgram()
+    prog.ir = []
+    for s_ in range(S):
+        prio = S > 1 and cost[s_] > 0 and cost[s_] >= 0.8 * heaviest
+        prog.ir.append(em.strand_code(s_, all_steps[s_], prio, park + 256 * s_))
+    # the bodies this schedule calls
+    scratch = 0
+    for name in sorted(em.used_bodies):
+        b = bodies[name]
+        L.append(".p2align 6\nfj_body_%s:\n" % name)
+        ret = "  s_setpc_b64 s[%d:%d]" % (S_RET, S_RET + 1)
+        L.extend((ret if t == FB.RET_MARK else t) + "\n" for t in b.text)
+        if FB.RET_MARK not in b.text:
+            L.append(ret + "\n")
+        scratch = max(scratch, b.scratch_bytes)
+    L.append(".Lend:\n.size %s, .Lend-%s\n" % (KERNEL_NAME, KERNEL_NAME))
+    lds_bytes = PARK_BYTES + n_lds * LDS_SLOT
+    L.append(".rodata\n.p2align 6\n.amdhsa_kernel %s\n"
+             "  .amdhsa_user_sgpr_kernarg_segment_ptr 1\n  .amdhsa_system_sgpr_workgroup_id_x 1\n  .amdhsa_system_vgpr_workitem_id 0\n"
+             "  .amdhsa_next_free_vgpr %d\n  .amdhsa_accum_offset %d\n  .amdhsa_next_free_sgpr 102\n  .amdhsa_reserve_vcc 1\n"
+             "  .amdhsa_group_segment_fixed_size %d\n  .amdhsa_private_segment_fixed_size %d\n%s  .amdhsa_kernarg_size %d\n"
+             ".end_amdhsa_kernel\n" % (KERNEL_NAME, FB.N_VGPR, FB.N_VGPR, lds_bytes, scratch,
+                                       "  .amdhsa_enable_private_segment 1\n" if scratch else "", KERNARG_BYTES))
+    L.append(".amdgpu_metadata\n---\namdhsa.version: [1, 2]\namdhsa.kernels:\n  - .name: %s\n    .symbol: %s.kd\n"
+             "    .kernarg_segment_size: %d\n    .group_segment_fixed_size: %d\n    .private_segment_fixed_size: %d\n"
+             "    .kernarg_segment_align: 8\n    .wavefront_size: 64\n    .sgpr_count: 108\n    .vgpr_count: %d\n    .agpr_count: 0\n"
+             "    .max_flat_workgroup_size: %d\n    .args:\n"
+             "      - {.size: 8, .offset: 0, .value_kind: global_buffer, .address_space: global}\n"
+             "      - {.size: 8, .offset: 8, .value_kind: global_buffer, .address_space: global}\n"
+             "      - {.size: %d, .offset: 16, .value_kind: by_value}\n"
+             "...\n.end_amdgpu_metadata\n" % (KERNEL_NAME, KERNEL_NAME, KERNARG_BYTES, lds_bytes, scratch, FB.N_VGPR, 64 * S,
+                                             KERNARG_BYTES - 16))
+    prog.n_strands = S
+    prog.asm = "".join(L)
+    prog.lds_bytes = lds_bytes
+    prog.scratch_bytes = scratch
+    prog.stats = dict(em.stats, bodies=len(em.used_bodies), n_lds=n_lds)
+    return prog
+
+
+def assemble(prog: FpJitProgram) -> bytes:
+    from .bitjit import assemble as _asm
+    prog.code = _asm(prog.asm)
+    return prog.code

@@ -96,7 +96,7 @@ TAPE_MAGIC = b"CWTP"
 TAPE_VERSION = 11
 
 
-def write_tape(path, tapes, bittape=None, jit=None):
+def write_tape(path, tapes, bittape=None, jit=None, fpjit=()):
     """`.cwt` layout (little endian).  `tapes` = one Tape or a list of Tapes of the SAME circuit lowered with
     different strand counts (the runtime picks the variant that fills the chip for the batch at hand).
          0  "CWTP" | u32 version | u32 n64 | u32 n_variants
@@ -125,6 +125,7 @@ def write_tape(path, tapes, bittape=None, jit=None):
                             words), shape = NB | NLD << 8, n_lds = 2*NB + 2*NLD
             bit program     (if n_bit_programs, hip_elements/bitsched.py)  8 x u32: ring, n_vrows, n_slots lo, hi, cache, n_asserts, 2, 0;
                             records n_vrows*64 x 2 u32; command blocks n_vrows/8 x 24 u32; signal -> slot; assertion slots
+            emitted 256-bit code (optional, after everything else; hip_elements/fpjit.py): see the end of this function
             emitted code    (if n_bit_programs == 2, hip_elements/bitjit.py)  8 x u32: 1, n_slots lo, hi, code bytes, flags (bit 0:
                             the fused R1CS check covers every constraint), VGPRs, AccVGPRs, 0; signal -> slot; the gfx950 code
                             object (ELF), padded to 4 bytes
@@ -191,6 +192,14 @@ def write_tape(path, tapes, bittape=None, jit=None):
                                 jit.n_vgpr, jit.n_agpr, 0))
             f.write(np.ascontiguousarray(jit.sig_slot, dtype="<u4").tobytes())
             f.write(jit.code + b"\0" * (-len(jit.code) % 4))
+        if fpjit:
+            # emitted 256-bit code of strand variants (hip_elements/fpjit.py), an optional trailing section: "FPJT" | u32 format
+            # 1 | u32 n | per program 8 x u32 {n_strands, code bytes, LDS bytes, scratch bytes, VGPRs, 0, 0, 0} + the code object
+            f.write(b"FPJT" + struct.pack("<II", 1, len(fpjit)))
+            for fp in fpjit:
+                assert fp.code is not None and any(t.n_strands == fp.n_strands and getattr(t, "kind", 0) == 0 for t in tapes)
+                f.write(struct.pack("<8I", fp.n_strands, len(fp.code), fp.lds_bytes, fp.scratch_bytes, 128, 0, 0, 0))
+                f.write(fp.code + b"\0" * (-len(fp.code) % 4))
 
 
 def _le_key(k: int) -> bytes:

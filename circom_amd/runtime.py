@@ -31,7 +31,7 @@ CLI_PATH = _HERE / "bin" / "cw_witness"     # process-level drop-in (csrc/cw_cli
 def build_library(force: bool = False) -> Path:
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     srcs = [_HERE / "csrc" / n for n in ("cw_kernels.hip", "cw_bits.hip", "cw64.hip", "cw_host.cpp", "cw_cli.cpp", "cw_kernels.h",
-                                         "cw_tape.h", "cw_r1cs_plan.h", "cw_bits_host.h", "fp256.hip.h")]
+                                         "cw_tape.h", "cw_r1cs_plan.h", "cw_bits_host.h", "fp256.hip.h", "cw_rowops.hip.h")]
     outs = [LIB_PATH, CLI_PATH]
     if not force and all(o.exists() and all(o.stat().st_mtime >= s.stat().st_mtime for s in srcs) for o in outs):
         return LIB_PATH
@@ -64,6 +64,7 @@ _SIGS = {
     "cw_batch_strands": (C.c_uint32, [C.c_void_p]),
     "cw_circuit_montgomery": (C.c_int, [C.c_void_p]),
     "cw_batch_pipelined": (C.c_uint32, [C.c_void_p]),
+    "cw_batch_emitted": (C.c_uint32, [C.c_void_p]),
     "cw_batch_lanes": (C.c_uint32, [C.c_void_p]),
     "cw_batch_bitmode": (C.c_int, [C.c_void_p]),
     "cw_bits_info": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -203,6 +204,7 @@ class Batch:
         pp = lib().cw_batch_pipelined(h)
         self.pipelined = (pp & 0xFF, pp >> 8) if pp else None     # (rows per batch, loads per batch) of the pipelined variant
         self.lanes = lib().cw_batch_lanes(h)
+        self.emitted = bool(lib().cw_batch_emitted(h))            # the variant's rows run as emitted code (hip_elements/fpjit.py)
         self.bitmode = bool(lib().cw_batch_bitmode(h))
         lay = (C.c_uint64 * 4)()
         _chk(lib().cw_batch_bits_layout(h, lay))

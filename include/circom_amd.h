@@ -82,6 +82,10 @@ uint32_t cw_batch_strands(const cw_batch *b);
 /* 0, or (rows per batch | loads per batch << 8) when the batch runs the pipelined single-wave variant of the schedule
    (LDS result ring + load lists issued one batch ahead: hip_elements/pipe.py; CW_PIPE=0/1 overrides the choice) */
 uint32_t cw_batch_pipelined(const cw_batch *b);
+/* 1 when the rows of the picked variant run as EMITTED gfx950 code (hip_elements/fpjit.py: the counterpart of the reference's
+   per-template C++, compiler/src/circuit_design/template.rs:174-474 - operand loads, a call of the operator's body and the
+   stores of every row as straight-line code), 0 when cw_eval_kernel interprets them.  CW_FP_JIT=0 forces the interpreter. */
+uint32_t cw_batch_emitted(const cw_batch *b);
 /* instances per workgroup (64, 32 or 16) the evaluation kernel uses for this batch */
 uint32_t cw_batch_lanes(const cw_batch *b);
 /* 1 if this batch runs the bit-plane program (circuits whose signals are all boolean for 0/1 inputs: one bit per

@@ -1,0 +1,220 @@
+"""The 256-bit schedule as EMITTED gfx950 code (hip_elements/fpjit.py + fpjit_bodies.py).
+
+CPU: the row bodies compile within their register budgets; the IR of the emitted kernels, replayed with poisoned registers
+and in-order memory queues (oracle/fpjit_eval.py), reproduces the schedule replay (oracle/tape_eval.py) on every operator,
+on Poseidon in both value forms and on a strand-parallel EdDSA-style circuit; a wrong wait count is caught.
+GPU: the emitted kernels against the interpreting kernel (same schedule, CW_FP_JIT=0) and against the oracle, bit for bit,
+status words included."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from circom_amd.compiler import compile_program
+from circom_amd.frontend.dsl import Program
+from circom_amd.frontend.flatten import flatten
+from circom_amd.circuits.basic import Multiplier2, IsZero, Num2Bits
+from circom_amd.circuits.opzoo import OperatorZoo
+from circom_amd.circuits.poseidon import Poseidon
+from circom_amd.hip_elements import fpjit, fpjit_bodies
+from circom_amd.hip_elements.lower import lower
+from oracle.field import PRIMES
+from oracle.fpjit_eval import replay_tape, JitHazard
+from oracle.tape_eval import eval_flat, eval_tape
+
+
+@pytest.fixture(scope="module")
+def bodies():
+    return fpjit_bodies.build_bodies()
+
+
+def test_bodies_respect_their_register_budgets(bodies):
+    """parse_bodies() has already refused any body that touches a register outside its budget or contains a memory
+    instruction; what is pinned here: the set exists in both parities, nothing but the heavy operators spills, and the
+    product is the ~320 instructions the design counts on"""
+    for base in ("add", "sub", "mmul", "mul2", "madd", "mulc0", "mulcp", "mulcn", "linp", "linn", "dotmac", "asserteq", "select", "ext"):
+        assert base + "_e" in bodies and base + "_o" in bodies
+    for name, b in bodies.items():
+        assert b.text and b.n_instr > 0
+        if b.parity != "h":
+            assert not b.scratch, name
+        if b.parity == "e":
+            assert not any(24 <= r < 40 for r in b.vwritten), name       # the odd rows' operands are in flight meanwhile
+        if b.parity == "o":
+            assert not any(r < 16 for r in b.vwritten), name
+        if b.parity != "m":
+            assert not any(r in b.vwritten for r in (120, 121, 122, 123, 125, 126, 127)) or b.parity == "h", name
+    assert 250 <= bodies["mmul_e"].n_instr <= 400
+
+
+def _inputs(fc, rng, q, small=False):
+    return {fc.main_input_start + k: (rng.randrange(300) if small else rng.randrange(q)) for k in range(fc.n_main_inputs)}
+
+
+@pytest.mark.parametrize("prime", ["bn128", "bls12381"])
+def test_replay_of_emitted_ir_matches_schedule_replay_on_every_operator(bodies, prime):
+    q = PRIMES[prime]
+    fc = flatten(Program(OperatorZoo(), prime=prime))
+    rng = random.Random(11)
+    half = q >> 1
+    cases = [(x, y) for x in (0, 1, 5, half, q - 1, 1 << 64) for y in (0, 1, 3, 255, q - 2)] + \
+            [(rng.randrange(q), rng.randrange(q)) for _ in range(6)] + [(rng.randrange(q), rng.randrange(300)) for _ in range(6)]
+    for S in (1, 4):
+        t = lower(fc, n_strands=S)
+        p = fpjit.emit(t, bodies)
+        fpjit.assemble(p)
+        assert p.code[:4] == b"\x7fELF"
+        for x, y in cases:
+            inp = {fc.main_input_start: x, fc.main_input_start + 1: y}
+            want, st0 = eval_tape(t, inp)
+            got, st1 = replay_tape(t, p, bodies, inp)
+            assert st0 == st1 and got == want, (S, hex(x), hex(y))
+
+
+@pytest.mark.parametrize("mont", [False, True])
+@pytest.mark.parametrize("S", [1, 4, 16])
+def test_replay_of_emitted_ir_poseidon(bodies, mont, S):
+    fc = flatten(Program(Poseidon(2)))
+    t = lower(fc, n_strands=S, mont=mont)
+    p = fpjit.emit(t, bodies)
+    rng = random.Random(S)
+    for _ in range(2):
+        inp = _inputs(fc, rng, fc.fp.q)
+        want, st0 = eval_tape(t, inp)
+        got, st1 = replay_tape(t, p, bodies, inp)
+        assert (got, st1) == (want, st0)
+    # the glue around a row is a few dozen instructions, not the interpreter's ~300
+    assert p.stats["glue"] / p.stats["steps"] < 40
+
+
+def test_replay_catches_a_wait_that_is_too_weak(bodies):
+    fc = flatten(Program(Poseidon(2)))
+    t = lower(fc, n_strands=1, mont=True)
+    p = fpjit.emit(t, bodies)
+    inp = _inputs(fc, random.Random(1), fc.fp.q)
+    ir = p.ir[0]
+    k = next(i for i, ins in enumerate(ir) if ins[0] == "wait" and ins[1] is not None)
+    saved = ir[k]
+    ir[k] = ("wait", saved[1] - 2, saved[2])          # as if vmcnt were 2 larger: the operand's second half is still in flight
+    with pytest.raises(JitHazard):
+        replay_tape(t, p, bodies, inp)
+    ir[k] = saved
+    # and a body that clobbers a register group somebody still needs
+    k = next(i for i, ins in enumerate(ir) if ins[0] == "call" and ins[1].startswith("mmul"))
+    info = {n: (set(b.vwritten), b.parity) for n, b in bodies.items()}
+    info[ir[k][1]] = (info[ir[k][1]][0] | set(range(0, 40)), info[ir[k][1]][1])
+    from oracle.fpjit_eval import replay
+    R = pow(2, t.rbits, t.q)
+    with pytest.raises(JitHazard):
+        replay(p.ir, info, t.q, t.n_signals, t.n_tslots, t.n_lds, {k2: v * R % t.q for k2, v in inp.items()}, t.rbits, R)
+
+
+def test_replay_semaphore_style_strands(bodies):
+    """EdDSA-style circuit (projective ladder hints): LINSUM rows of hundreds of terms, batched inversions, select / ext,
+    LDS hand-offs between 16 strands"""
+    from circom_amd.circuits import eddsa_host as H
+    from circom_amd.circuits.eddsa import SemaphoreStyle
+    q = PRIMES["bn128"]
+    fc = flatten(Program(SemaphoreStyle(3, True)))
+    row, _ = H.semaphore_inputs(q, 3, random.Random(5))
+    inp = {fc.main_input_start + k: v for k, v in enumerate(row)}
+    for S, mont in ((1, False), (16, True)):
+        t = lower(fc, n_strands=S, mont=mont)
+        p = fpjit.emit(t, bodies)
+        want, st0 = eval_tape(t, inp)
+        got, st1 = replay_tape(t, p, bodies, inp)
+        assert st0 == 0 and (got, st1) == (want, st0)
+    bad = dict(inp)
+    bad[fc.main_input_start + 2] = (row[2] + 1) % q           # tampered signature: the same status word
+    want, st0 = eval_tape(t, bad)
+    got, st1 = replay_tape(t, p, bodies, bad)
+    assert st0 != 0 and st1 == st0
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------------------
+def _run_both(cp, rows, monkeypatch, strands, lanes=None):
+    """witness tables + status words of the same batch through the emitted code and through the interpreting kernel"""
+    from circom_amd import runtime as rt
+    out = []
+    for emitted in (True, False):
+        monkeypatch.setenv("CW_FP_JIT", "1" if emitted else "0")
+        monkeypatch.setenv("CW_STRANDS", str(strands))
+        if lanes:
+            monkeypatch.setenv("CW_LANES", str(lanes))
+        else:
+            monkeypatch.delenv("CW_LANES", raising=False)
+        c = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
+        b = c.batch(len(rows))
+        assert b.emitted == emitted and b.strands == strands
+        b.set_inputs(rows)
+        b.run()
+        if c.n_constraints:
+            b.check_r1cs()
+        b.sync()
+        out.append((b.witnesses().copy(), b.status().copy()))
+        b.close(); c.close()
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prime", ["bn128", "bls12381", "secq256r1"])
+def test_gpu_emitted_code_every_operator(tmp_path, monkeypatch, prime):
+    from test_opzoo import _operands
+    q = PRIMES[prime]
+    cp = compile_program(Program(OperatorZoo(), prime=prime), str(tmp_path), "opzoo", sym=False, fpjit=True)
+    assert {p.n_strands for p in cp.fpjit} == {1, 4, 16}
+    fc = cp.flat
+    rows = _operands(q, 300, 9)
+    for strands, lanes in ((1, None), (4, 32), (16, 16)):
+        (w1, s1), (w0, s0) = _run_both(cp, rows, monkeypatch, strands, lanes)
+        assert (s1 == s0).all() and (s1 == 0).all()
+        assert w1.tobytes() == w0.tobytes(), (prime, strands)
+    for i in range(0, len(rows), 37):
+        inp = {fc.main_input_start: rows[i][0], fc.main_input_start + 1: rows[i][1]}
+        sig, failed = eval_flat(q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp)
+        assert failed is None and w1[i].tobytes() == b"".join(v.to_bytes(32, "little") for v in sig)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mont", [True, False])
+def test_gpu_emitted_code_poseidon(tmp_path, monkeypatch, mont):
+    from circom_amd.circuits.poseidon_constants import poseidon_hash
+    cp = compile_program(Program(Poseidon(2)), str(tmp_path), "poseidon2", sym=False, mont=mont, fpjit=True)
+    q = cp.flat.fp.q
+    rng = random.Random(3)
+    for n, strands, lanes in ((700, 1, None), (333, 4, None), (100, 16, 16), (64 * 70, 4, None)):
+        rows = [[rng.randrange(q), rng.randrange(q)] for _ in range(n)]
+        (w1, s1), (w0, s0) = _run_both(cp, rows, monkeypatch, strands, lanes)
+        assert (s1 == 0).all() and (s0 == 0).all()
+        assert w1.tobytes() == w0.tobytes(), (n, strands)
+        for i in (0, n // 2, n - 1):
+            assert int.from_bytes(w1[i][1].tobytes(), "little") == poseidon_hash(q, rows[i])
+
+
+@pytest.mark.gpu
+def test_gpu_emitted_code_semaphore_style_and_status_words(tmp_path, monkeypatch):
+    """the EdDSA-style circuit of BASELINE config 4 (projective hints) at a small tree depth: long LINSUM rows, batched
+    inversions (the heavy body with its parked status word), LDS hand-offs; every fourth instance carries a tampered
+    signature and must report the same first failing operation as the interpreter"""
+    from circom_amd.circuits import eddsa_host as H
+    from circom_amd.circuits.eddsa import SemaphoreStyle, SUBGROUP_ORDER
+    q = PRIMES["bn128"]
+    cp = compile_program(Program(SemaphoreStyle(4, True)), str(tmp_path), "sem4p", sym=False, fpjit=True)
+    fc = cp.flat
+    rng = random.Random(8)
+    rows = []
+    for i in range(150):
+        row, _ = H.semaphore_inputs(q, 4, rng)
+        row = list(row)
+        if i % 4 == 3:
+            row[2] = (row[2] + 1) % SUBGROUP_ORDER
+        rows.append(row)
+    for strands, lanes in ((16, 16), (4, None), (1, None)):
+        (w1, s1), (w0, s0) = _run_both(cp, rows, monkeypatch, strands, lanes)
+        assert (s1 == s0).all(), strands
+        assert all((s1[i] != 0) == (i % 4 == 3) for i in range(len(rows)))
+        ok = [i for i in range(len(rows)) if i % 4 != 3]
+        assert w1[ok].tobytes() == w0[ok].tobytes(), strands
+    sig, failed = eval_flat(q, fc.n_signals, fc.n_temps, fc.constants, fc.code, {fc.main_input_start + k: v for k, v in enumerate(rows[0])})
+    assert failed is None and w1[0].tobytes() == b"".join(v.to_bytes(32, "little") for v in sig)
