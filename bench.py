@@ -144,8 +144,11 @@ def get_compiled(name: str, batch: int, cache_root: str, rank: int, dist):
         tapes = [lower(fc, n_strands=s, mont=mont) for s in strands]
         jp = compiler.emit_jit(compiler.lower_bitplane.net, fc) if bittape is not None else None     # the same network as emitted code
         compiler.lower_bitplane.net = None
-        writers.write_tape(p(".cwt"), tapes, bittape, jp)
+        # arithmetic circuits: the rows of every strand variant as emitted code as well (hip_elements/fpjit.py)
+        fps = compiler.emit_fpjit(tapes, fc, False if bittape is not None else "auto")
+        writers.write_tape(p(".cwt"), tapes, bittape, jp, fps)
         json.dump(jp.stats if jp is not None else {}, open(p(".jit.json"), "w"))
+        json.dump([dict(fp_.stats, n_strands=fp_.n_strands, code_bytes=len(fp_.code)) for fp_ in fps], open(p(".fpjit.json"), "w"))
         writers.write_dat(p(".dat"), fc)
         writers.write_r1cs(p(".r1cs"), fc)
         open(done, "w").write(fp)

@@ -114,10 +114,14 @@ def emit_jit(net, fc, jit="auto"):
 FPJIT_MAX_ROWS = 400_000            # "auto": beyond this the code object (about 100 bytes per row) is not worth its size
 
 
-def emit_fpjit(tapes, fc, fpjit="auto"):
+def emit_fpjit(tapes, fc, fpjit="auto", fuse_check=True):
     """The strand variants of the 256-bit schedule as emitted gfx950 code (hip_elements/fpjit.py), assembled.  fpjit: True,
     False or "auto" (arithmetic circuits up to FPJIT_MAX_ROWS rows; circuits whose every instance normally takes the
-    bit-plane program keep the interpreter for the rare fallback instance); CW_FPJIT=0/1 overrides."""
+    bit-plane program keep the interpreter for the rare fallback instance); CW_FPJIT=0/1 overrides.  fuse_check: the code
+    also recomputes the R1CS rows of the classes it knows right behind the rows that produce their wires (CW_FPJIT_CHECK=0:
+    evaluation only, the stand-alone kernel checks every row)."""
+    if os.environ.get("CW_FPJIT_CHECK"):
+        fuse_check = os.environ["CW_FPJIT_CHECK"] != "0"
     if os.environ.get("CW_FPJIT"):
         fpjit = os.environ["CW_FPJIT"] != "0"
     if fpjit is False:
@@ -129,14 +133,19 @@ def emit_fpjit(tapes, fc, fpjit="auto"):
             continue
         if fpjit == "auto" and len(t.rows) > FPJIT_MAX_ROWS:
             continue
-        try:
-            p = FJ.emit(t)
-        except NotImplementedError:
-            if fpjit is True:
-                raise
-            continue
-        FJ.assemble(p)
-        out.append(p)
+        # two programs per variant: the rows alone, and the rows with the R1CS check fused in.  Which one a batch runs is the
+        # runtime's choice (cw_batch_create): recomputing the constraints inside the evaluation costs about as many instructions
+        # as the evaluation itself - it pays where the launch is throughput-bound (the wires are in registers and caches instead
+        # of a second pass over HBM), not where a small batch waits on its dependency chain
+        for cons in ((None, fc.constraints) if (fuse_check and fc.constraints) else (None,)):
+            try:
+                p = FJ.emit(t, constraints=cons)
+            except NotImplementedError:
+                if fpjit is True:
+                    raise
+                break
+            FJ.assemble(p)
+            out.append(p)
     return tuple(out)
 
 

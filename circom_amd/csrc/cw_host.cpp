@@ -228,6 +228,7 @@ struct Variant {               // one lowering of the schedule for a given stran
 // operands of every row, calls the operator's body and stores the result - no descriptors, no dispatch, exact wait counts
 struct FpJit {
     uint32_t n_strands = 1, lds_bytes = 0, scratch_bytes = 0, n_vgpr = 0;
+    std::vector<uint32_t> covered;                                   // bitmap over the .r1cs rows: checked by the code itself
     std::vector<uint8_t> code;                                       // ELF code object (hipModuleLoadData)
     std::map<int, std::pair<hipModule_t, hipFunction_t>> mod;        // device -> loaded module
 };
@@ -965,7 +966,8 @@ static int load_tape(cw_circuit *c, const char *path) {
         c->has_jit = true;
     }
     // emitted 256-bit code (optional trailing section, hip_elements/fpjit.py): "FPJT" | u32 format 1 | u32 n, then per program
-    // 8 x u32 {n_strands, code bytes, LDS bytes, scratch bytes, VGPRs, 0, 0, 0} and the code object padded to 4 bytes
+    // 8 x u32 {n_strands, code bytes, LDS bytes, scratch bytes, VGPRs, words of the fused-check bitmap, 0, 0}, the bitmap (one bit
+    // per .r1cs row: the emitted code recomputes that row itself) and the code object padded to 4 bytes
     if (off + 12 <= b.size() && memcmp(b.data() + off, "FPJT", 4) == 0) {
         uint32_t fh[2];
         memcpy(fh, b.data() + off + 4, 8);
@@ -977,9 +979,12 @@ static int load_tape(cw_circuit *c, const char *path) {
             memcpy(ph, b.data() + off, 32);
             off += 32;
             const uint64_t padded = ((uint64_t)ph[1] + 3) & ~3ull;
-            if (ph[0] == 0 || ph[0] > 16 || (ph[0] & (ph[0] - 1)) || ph[2] > 160 * 1024 || ph[3] > 4096 || ph[4] > 512 || ph[5] || ph[6] || ph[7] ||
-                ph[1] < 64 || padded > b.size() - off)
+            if (ph[0] == 0 || ph[0] > 16 || (ph[0] & (ph[0] - 1)) || ph[2] > 160 * 1024 || ph[3] > 4096 || ph[4] > 512 || ph[6] || ph[7] ||
+                ph[1] < 64 || (uint64_t)ph[5] * 4 > b.size() - off || padded > b.size() - off - (uint64_t)ph[5] * 4)
                 return fail(CW_EIO, "tape emitted 256-bit code: bad header");
+            std::vector<uint32_t> cov(ph[5]);
+            if (ph[5]) memcpy(cov.data(), b.data() + off, (size_t)ph[5] * 4);
+            off += (size_t)ph[5] * 4;
             if (memcmp(b.data() + off, "\x7f" "ELF", 4) != 0) return fail(CW_EIO, "tape emitted 256-bit code: not a code object");
             bool have_variant = false;
             for (auto &v : c->variants) have_variant |= (v.kind == 0 && v.n_strands == ph[0]);
@@ -989,6 +994,7 @@ static int load_tape(cw_circuit *c, const char *path) {
             fj.lds_bytes = ph[2];
             fj.scratch_bytes = ph[3];
             fj.n_vgpr = ph[4];
+            fj.covered = std::move(cov);
             fj.code.assign(b.data() + off, b.data() + off + ph[1]);
             off += (size_t)padded;
             c->fpjit.push_back(std::move(fj));
@@ -1400,6 +1406,7 @@ struct cw_batch {
     const std::vector<uint32_t> *bits_sigslot = nullptr;
     hipFunction_t fp_fn = nullptr;                     // emitted code of the chosen strand variant (nullptr: the interpreter runs it)
     uint32_t fp_lds = 0;
+    const std::vector<uint32_t> *fp_covered = nullptr; // .r1cs rows that code checks itself (findings: second half of d_status)
     bool jit = false, table_dirty = false;             // emitted code runs this batch; the caller holds a raw pointer to the table
     hipFunction_t jit_fn = nullptr;
     // 64-bit runtime: V64[slot][Bp], its program and R1CS terms
@@ -1558,8 +1565,24 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
         // the variant's emitted code, when the tape carries it (CW_FP_JIT = 0: interpret the rows instead)
         const char *fe_ = getenv("CW_FP_JIT");
         if (best->kind == 0 && !(fe_ && atoi(fe_) == 0)) {
+            // A variant may come in two programs: the rows alone, and the rows with the R1CS check fused in (recomputed behind
+            // the rows that produce the wires).  The fused one does about twice the arithmetic in one launch and saves the
+            // check's pass over the table: it wins where the launch is throughput-bound (4 waves per SIMD and more), the plain
+            // one + the stand-alone check kernel where a batch waits on its dependency chain (measured, evaluation + check:
+            // Poseidon(2) x 65 536, 4 waves per SIMD: 1.64 vs 2.07 ms; Semaphore-style x 8 192, 2 per SIMD: 21.1 vs 18.8 ms; its
+            // 1 024-instance shard: 18.0 vs 14.3 ms).  CW_FP_FUSED = 0 / 1 overrides.
+            const uint64_t waves = ((uint64_t)batch + lanes - 1) / lanes * best->n_strands;
+            bool want_fused = waves >= 4096 && c->n_constraints != 0;
+            if (const char *e2 = getenv("CW_FP_FUSED")) want_fused = atoi(e2) != 0;
+            FpJit *pick = nullptr;
             for (auto &fj : c->fpjit) {
                 if (fj.n_strands != best->n_strands) continue;
+                const bool fused = !fj.covered.empty();
+                if (fused && !(c->n_constraints && fj.covered.size() == (c->n_constraints + 31) / 32)) continue;   // another .r1cs
+                if (!pick || fused == want_fused) pick = &fj;
+            }
+            if (pick) {
+                FpJit &fj = *pick;
                 auto it = fj.mod.find(b->device);
                 if (it == fj.mod.end()) {
                     hipModule_t mod = nullptr;
@@ -1574,6 +1597,7 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
                 }
                 b->fp_fn = it->second.second;
                 b->fp_lds = fj.lds_bytes;
+                if (!fj.covered.empty()) b->fp_covered = &fj.covered;   // findings: second half of d_status (CW_R1CS_AUDIT: re-checked)
             }
         }
     }
@@ -1729,7 +1753,7 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
     TRY(upload(&b->d_fntab, c->fn_tab, b->stream));
     TRY(upload(&b->d_lconsts, c->lconsts, b->stream));
     TRY(upload(&b->d_w2s, c->w2s, b->stream));
-    TRY(hipMalloc((void **)&b->d_status, (size_t)b->Bp * 4));
+    TRY(hipMalloc((void **)&b->d_status, (size_t)b->Bp * 4 * 2));      // second half: findings of the emitted code's fused R1CS check
     TRY(hipMalloc((void **)&b->d_first_bad, (size_t)b->Bp * 4));
     if (c->n_constraints) {
         TRY(upload(&b->d_rctab, c->r_ctab, b->stream));
@@ -1758,8 +1782,11 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
         } else {
             uint32_t tpc = 192;
             if (const char *e = getenv("CW_R1CS_TERMS")) tpc = (uint32_t)std::max(8, atoi(e));
-            p = cwplan::build_stream(c->r_ptr, c->r_slot, c->r_coef, c->r_orig, tpc);
+            const bool audit = getenv("CW_R1CS_AUDIT") != nullptr;
+            p = cwplan::build_stream(c->r_ptr, c->r_slot, c->r_coef, c->r_orig, tpc, b->fp_fn && !audit ? b->fp_covered : nullptr);
         }
+        if (p.chunk.empty()) p.chunk.assign(4, 0);                   // every row is checked by the emitted code: nothing to stream
+        if (p.row_orig.empty()) p.row_orig.assign(1, 0);
         TRY(upload(&b->d_pchunk, p.chunk, b->stream));
         TRY(upload(&b->d_pterms, p.terms, b->stream));
         TRY(upload(&b->d_prow, p.row_orig, b->stream));
@@ -1812,7 +1839,7 @@ extern "C" uint32_t cw_batch_size(const cw_batch *b) { return b->batch; }
 extern "C" int cw_circuit_montgomery(const cw_circuit *c) { return c && c->mont ? 1 : 0; }
 extern "C" uint32_t cw_batch_strands(const cw_batch *b) { return b->var ? b->var->n_strands : 0; }
 extern "C" uint32_t cw_batch_pipelined(const cw_batch *b) { return b && b->var && b->var->kind == 1 ? b->var->nb | (b->var->nld << 8) : 0; }
-extern "C" uint32_t cw_batch_emitted(const cw_batch *b) { return b && b->fp_fn ? 1 : 0; }
+extern "C" uint32_t cw_batch_emitted(const cw_batch *b) { return b && b->fp_fn ? (b->fp_covered ? 2 : 1) : 0; }
 extern "C" uint32_t cw_batch_lanes(const cw_batch *b) { return b->bitmode ? b->bits_width : b->lanes; }
 
 static int ensure_host_staging(cw_batch *b) {
@@ -2390,6 +2417,7 @@ extern "C" int cw_run(cw_batch *b) {
         args.batch = b->batch;
         args.lanes = b->lanes;
         args.P = c->P;
+        HIPCHK(hipMemsetAsync(b->d_status + b->Bp, 0xFF, (size_t)b->Bp * 4, b->stream));    // "no constraint found violated"
         size_t asz = sizeof(args);
         void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
         HIPCHK(hipModuleLaunchKernel(b->fp_fn, (b->batch + b->lanes - 1) / b->lanes, 1, 1, 64 * b->var->n_strands, 1, 1, 0, b->stream,
@@ -2428,6 +2456,9 @@ extern "C" int cw_check_r1cs(cw_batch *b) {
         if (b->resolved && b->fb) return cw_check_r1cs(b->fb);       // the side batch was already computed: check it too
         return CW_OK;
     }
+    // rows the emitted evaluation code recomputed itself (hip_elements/fpjit.py plan_checks): its findings join the words the
+    // stand-alone kernel reports through; that kernel then only streams the rows the code left to it
+    if (b->fp_fn) HIPCHK(cwk_fused_merge(b->stream, b->d_status + b->Bp, b->batch, b->d_status, b->d_first_bad));
     if (b->r1_entries)
         HIPCHK(cwk_r1cs_staged(b->stream, b->d_pchunk, b->r1_chunks, b->d_prec, b->d_pterms, b->d_rctab, b->d_rctab29, b->d_prow,
                                b->r1_entries, b->d_V, b->Bp, b->batch, b->d_status, b->d_first_bad, c->mont, c->P));

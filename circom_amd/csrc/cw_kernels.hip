@@ -1328,6 +1328,21 @@ hipError_t cwk_eval_pipe(hipStream_t s, bool full, bool wide_linsum, uint32_t nb
                        slot_stride, Bp, batch, lanes, status, P);
     return hipGetLastError();
 }
+// findings of the fused R1CS check of the emitted code (second half of the status array: smallest violated constraint per
+// instance, 0xFFFFFFFF = none) -> the first_bad / status words the stand-alone kernels report through
+__global__ void __launch_bounds__(CW_BLOCK) cw_fused_merge_kernel(const uint32_t *__restrict__ found, uint32_t batch, uint32_t *status, uint32_t *first_bad) {
+    const uint32_t i = blockIdx.x * CW_BLOCK + threadIdx.x;
+    if (i >= batch) return;
+    const uint32_t f = found[i];
+    if (f != 0xFFFFFFFFu) {
+        atomicMin(&first_bad[i], f);
+        atomicOr(&status[i], CW_ST_R1CS_FAILED);
+    }
+}
+hipError_t cwk_fused_merge(hipStream_t s, const uint32_t *found, uint32_t batch, uint32_t *status, uint32_t *first_bad) {
+    hipLaunchKernelGGL(cw_fused_merge_kernel, blocks_for(batch), dim3(CW_BLOCK), 0, s, found, batch, status, first_bad);
+    return hipGetLastError();
+}
 hipError_t cwk_r1cs(hipStream_t s, const uint32_t *chunk, uint32_t n_chunks, const uint32_t *terms, const uint32_t *ctab,
                     const uint32_t *ctab29, const uint32_t *row_orig, const void *V, uint32_t Bp, uint32_t batch, uint32_t *status,
                     uint32_t *first_bad, bool mont, const FpParams &P) {

@@ -178,14 +178,20 @@ inline Plan build(const std::vector<uint32_t> &ptr, const std::vector<uint32_t> 
 
 // Stream plan (default kernel, cw_r1cs_stream_kernel): no LDS; the terms name value slots and are read from the
 // value table two terms ahead of their use.  chunk = {first term, n terms, 0, first index into row_orig}.
+// skip: optional bitmap over the constraints' indices in the .r1cs file - rows the emitted evaluation code has already checked
 inline Plan build_stream(const std::vector<uint32_t> &ptr, const std::vector<uint32_t> &slot,
-                         const std::vector<uint32_t> &coef, const std::vector<uint32_t> &orig, uint32_t terms_per_chunk) {
+                         const std::vector<uint32_t> &coef, const std::vector<uint32_t> &orig, uint32_t terms_per_chunk,
+                         const std::vector<uint32_t> *skip = nullptr) {
     Plan p;
     const uint32_t n_rows = (uint32_t)(ptr.size() / 3);
     uint32_t chunk_t0 = 0, chunk_row0 = 0;
     for (uint32_t row = 0; row < n_rows; row++) {
         const uint32_t pa = ptr[3 * row], pb = ptr[3 * row + 1], pc = ptr[3 * row + 2], pe = ptr[3 * row + 3];
         if (pe == pa) continue;
+        if (skip) {
+            const uint32_t o = orig[row] & 0x7FFFFFFFu;
+            if ((o >> 5) < skip->size() && (((*skip)[o >> 5] >> (o & 31)) & 1u)) continue;
+        }
         const bool lin = (pa == pb) || (pb == pc);
         const bool eq2 = (orig[row] >> 31) != 0;
         for (uint32_t t = pa; t < pe; t++) {

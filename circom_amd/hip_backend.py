@@ -1,6 +1,6 @@
 """`python -m circom_amd.hip_backend <name>.cwf [-o DIR]` - the hip_elements back-end as a process: lowers a flat circuit
 (`.cwf`, circom_amd/cwf.py: what a front-end's `--hip` target hands over) into the files the runtime loads:
-`<name>.cwt` (schedule variants + bit-plane program), `<name>.dat` (reference layout), `<name>.r1cs`.
+`<name>.cwt` (schedule variants + bit-plane program + emitted code), `<name>.dat` (reference layout), `<name>.r1cs`.
 
 This is the seam the Rust producer calls (integration/code_producers/src/hip_elements/mod.rs `HipProducer::finish`): the
 role `generic/makefile` + `g++` play for the `--c` target (compilation_user.rs:34-99 writes C++ and leaves the compile to
@@ -20,12 +20,15 @@ def lower_cwf(cwf_path: str, outdir: str, name: str, strands=(1, 4, 16), bits="a
     fc = read_cwf(cwf_path)
     os.makedirs(outdir, exist_ok=True)
     bittape = None if os.environ.get("CW_BITS", "1") == "0" else compiler.lower_bitplane(fc, bits)
+    jp = compiler.emit_jit(compiler.lower_bitplane.net, fc) if bittape is not None else None      # the gate network as emitted code
+    compiler.lower_bitplane.net = None
     mont = False if bittape is not None else compiler.choose_mont(fc)
     if bittape is not None and fc.n_signals >= compiler.BITS_KEEP_STRANDS_BELOW:
         strands = (1,)
     tapes = [lower(fc, n_strands=s, mont=mont) for s in strands]
     p = lambda ext: os.path.join(outdir, name + ext)
-    writers.write_tape(p(".cwt"), tapes, bittape)
+    fps = compiler.emit_fpjit(tapes, fc, False if bittape is not None else "auto")             # the rows as emitted code
+    writers.write_tape(p(".cwt"), tapes, bittape, jp, fps)
     writers.write_dat(p(".dat"), fc)
     writers.write_r1cs(p(".r1cs"), fc)
     return p(".cwt"), p(".dat"), p(".r1cs")

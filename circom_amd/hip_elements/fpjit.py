@@ -38,12 +38,13 @@ from .lower import (D_COPY, D_ADD, D_SUB, D_NEG, D_MMUL, D_INV, D_IDIV, D_MOD, D
 KERNEL_NAME = "cw_fp_jit"
 K_SIG, K_TMP, K_CONST = 0, 1, 2
 LDS_SLOT = 2048
-PARK_BYTES = 4096             # start of the workgroup's LDS: 256 bytes per strand where inv_h's caller parks the status words
+PARK_BYTES = 8192             # start of the workgroup's LDS: 512 bytes per strand where the caller of a heavy body parks the status
+                              # word and the fused check's finding (the body has no register to keep them in)
 KERNARG_BYTES = 32 + 4 * FB.N_PARAM_SGPRS + 4          # V, status, Bp, batch, lanes, pad, FpParams (53 dwords), pad -> 248
 VMCNT_MAX, LGKM_MAX = 63, 15
 
 # owned registers (fpjit_bodies.py keeps them live through every body)
-V_VLO, V_VHI, V_L16, V_ST, V_L16B, V_L16C, V_I = 120, 121, 122, 124, 125, 126, 127
+V_VLO, V_VHI, V_L16, V_FB, V_ST, V_L16B, V_L16C, V_I = 120, 121, 122, 123, 124, 125, 126, 127
 S_BATCH, S_VBASE, S_STATUS, S_RET, S_STRIDE, S_WGBASE = 93, 94, 96, 98, 100, 101
 
 _TWO = {D_ADD: "add", D_SUB: "sub", D_MMUL: "mmul", D_MUL2: "mul2", D_SHL: "shl", D_SHR: "shr", D_BAND: "band", D_BOR: "bor",
@@ -62,6 +63,7 @@ class FpJitProgram:
         self.ir = None            # per strand: list of IR tuples (oracle/fpjit_eval.py)
         self.lds_bytes = 0
         self.scratch_bytes = 0
+        self.covered = []         # per constraint: 1 = checked by the emitted code itself (the stand-alone kernel skips it)
         self.stats = {}
 
 
@@ -75,7 +77,7 @@ def _limbs29(v):
 
 class _Step:
     """one call of a body (or an inline operation) with what it needs from memory and what it leaves there"""
-    __slots__ = ("loads", "pre", "body", "inline", "stores", "barrier", "heavy", "value", "sarg", "coef")
+    __slots__ = ("loads", "pre", "body", "inline", "stores", "barrier", "heavy", "value", "sarg", "coef", "check")
 
     def __init__(self):
         self.loads = []        # (which 'A' | 'B', kind, index)  kind: K_SIG / K_TMP (unified slot = index) or K_LDS
@@ -88,6 +90,7 @@ class _Step:
         self.value = False     # the step leaves a new value in D
         self.sarg = None       # 64-bit literal for s[36:37]
         self.coef = None       # nine 29-bit limbs for s[24:32]
+        self.check = False     # a step of the fused R1CS check (plan_checks)
 
 
 def expand_steps(tape, strand):
@@ -235,6 +238,228 @@ def expand_steps(tape, strand):
     return steps
 
 
+def plan_checks(tape, constraints, all_steps):
+    """The fused R1CS check: every constraint of a class the emitted code knows becomes one or a few steps that recompute
+    it from the STORED wires (or from D while the wire just produced is still there) right behind the row that produces its
+    last wire, in that row's strand - the wires are in registers or the CU's caches, not in HBM.  A violated constraint
+    lowers the instance's `fb` (smallest violated index); the strand's last call publishes it.  Classes: wire equalities,
+    single products a * b = c, w1 + k = w2, linear rows (any coefficients; one reduction per four terms, as D_DOTC).
+    Constraints with a multi-term factor stay with the stand-alone kernel (`covered[i]` = 0), which then skips the others.
+    Returns covered: list of 0/1 per constraint."""
+    q, ns, S = tape.q, tape.n_signals, tape.n_strands
+    mont = bool(getattr(tape, "mont", False))
+    R = pow(2, tape.rbits, q)
+    one = R if mont else 1
+    # where and when every signal is produced: (strand, step index, epoch); epochs are counted in barriers
+    prod = {}
+    full_after = []                       # per barrier: is it FULL
+    for s_, steps in enumerate(all_steps):
+        ep = 0
+        for k, st in enumerate(steps):
+            if st.barrier is not None:
+                if s_ == 0:
+                    full_after.append(st.barrier == 1)
+                ep += 1
+                continue
+            for kind, idx in st.stores:
+                if kind == K_SIG and idx < ns:
+                    prod[idx] = (s_, k, ep)
+    # first step index of every epoch, per strand (the step right behind the barrier that closes the previous epoch)
+    ep_start = []
+    for steps in all_steps:
+        starts, ep = {0: 0}, 0
+        for k, st in enumerate(steps):
+            if st.barrier is not None:
+                ep += 1
+                starts[ep] = k + 1
+        ep_start.append(starts)
+    n_ep = len(full_after) + 1
+
+    def next_full(e):                     # first epoch whose rows see, through the table, what another strand stored in epoch e
+        for b in range(e, len(full_after)):
+            if full_after[b]:
+                return b + 1
+        return None
+
+    stats = {"same_register": 0}
+    plan_checks.stats = stats
+    inserts = [dict() for _ in range(S)]  # strand -> position (insert BEFORE step index) -> list of steps
+    load = [sum(300 if st.body else 20 for st in steps) for steps in all_steps]      # rough instruction counts per strand
+    covered = [0] * len(constraints)
+
+    def sval(v):
+        v %= q
+        return v - q if v > q // 2 else v
+
+    for ci, (A, B, C) in enumerate(constraints):
+        A = {k: v % q for k, v in A.items() if v % q}
+        B = {k: v % q for k, v in B.items() if v % q}
+        C = {k: v % q for k, v in C.items() if v % q}
+        quad = bool(A) and bool(B)
+        # ---- classify -------------------------------------------------------------------------------------------------------
+        plan = None
+        if quad:
+            if len(A) == 1 and len(B) == 1 and len(C) == 1:
+                (wa, ca), (wb, cb), (wc, cc) = next(iter(A.items())), next(iter(B.items())), next(iter(C.items()))
+                if wa and wb and wc and ca * cb % q == cc:
+                    plan = ("mul", wa, wb, wc)
+            if plan is None and len(A) == 1 and len(B) == 1 and 0 not in A and 0 not in B and len(C) <= 64:
+                # a * b = (a linear right-hand side): the row's C part, scaled by 1 / (ca cb), is summed like a linear row
+                (wa, ca), (wb, cb) = next(iter(A.items())), next(iter(B.items()))
+                sc = pow(ca * cb % q, -1, q)
+                k0 = C.get(0, 0) * sc % q
+                plan = ("mulc", wa, wb, [(w, v * sc % q) for w, v in sorted(C.items()) if w], k0)
+        else:
+            # a linear row: sum(terms) = 0.  A == {} or B == {}: the row is C = 0 (A * B vanishes)
+            lin = dict(C)
+            k0 = lin.pop(0, 0)             # the constant term (times the constant-one wire)
+            wires = sorted(lin)
+            if len(wires) == 2 and k0 == 0 and (lin[wires[0]] + lin[wires[1]]) % q == 0 and sval(lin[wires[0]]) in (1, -1):
+                plan = ("eq", wires[0], wires[1])
+            elif len(wires) == 2 and (lin[wires[0]] + lin[wires[1]]) % q == 0 and sval(lin[wires[0]]) in (1, -1):
+                # +w1 - w2 + k = 0  ->  w1 + k = w2
+                w1, w2 = (wires[0], wires[1]) if sval(lin[wires[0]]) == 1 else (wires[1], wires[0])
+                plan = ("add", w1, k0, w2)
+            elif 1 <= len(wires) <= 64:
+                # sum_i c_i w_i + k = rhs: one wire with coefficient -1 becomes the right-hand side when there is one
+                rhs = next((w for w in wires if sval(lin[w]) == -1), None)
+                plan = ("dot", [(w, lin[w]) for w in wires if w != rhs], k0, rhs)
+        if plan is None:
+            continue
+        if plan[0] == "eq" and plan[1] in prod and plan[2] in prod and prod[plan[1]][:2] == prod[plan[2]][:2]:
+            covered[ci] = 1                 # both wires are stored from D by one and the same row (component wiring): they ARE one
+            stats["same_register"] += 1     # register; nothing to recompute
+            continue
+        ws = [w for w in (plan[1:4] if plan[0] in ("mul", "eq") else [plan[1], plan[3]] if plan[0] == "add"
+                          else [plan[1], plan[2]] + [w for w, _ in plan[3]] if plan[0] == "mulc"
+                          else [w for w, _ in plan[1]] + ([plan[3]] if plan[3] is not None else [])) if w]
+        # ---- place: wires of other strands must have crossed a FULL barrier; among the strands that can see every wire the
+        # least loaded one takes the check (most strands of a strand-parallel schedule wait at barriers most of the time),
+        # the producer of the last wire first when loads tie
+        last, pos_key = 0, (-1, -1)
+        for w in ws:
+            if w in prod and (prod[w][2], prod[w][1]) > pos_key:
+                pos_key = (prod[w][2], prod[w][1])
+                last = prod[w][0]
+        best = None
+        for cand in sorted(range(S), key=lambda x: (load[x], x != last)):
+            pos, ok = 0, True
+            for w in ws:
+                if w not in prod:
+                    continue                              # a main input: there before the kernel starts
+                s_, k, ep = prod[w]
+                if s_ == cand:
+                    pos = max(pos, k + 1)
+                else:
+                    e2 = next_full(ep)
+                    if e2 is None or e2 not in ep_start[cand]:
+                        ok = False
+                        break
+                    pos = max(pos, ep_start[cand][e2])
+            if ok:
+                best = (cand, pos)
+                break
+        if best is None:
+            continue
+        owner, pos = best
+        load[owner] += {"eq": 60, "mul": 380, "add": 170}.get(plan[0], 0) or (400 + 180 * len(plan[3] if plan[0] == "mulc" else plan[1]))
+        # never inside the term steps of a LINSUM / DOTC row (they own G and the accumulators): move behind the row's end
+        steps = all_steps[owner]
+        while pos < len(steps) and pos > 0 and steps[pos - 1].body in ("linp", "linn", "dotmac", "dotred") and not steps[pos - 1].check:
+            pos += 1
+        inserts[owner].setdefault(pos, []).append((ci, plan))
+        covered[ci] = 1
+
+    # ---- build the steps ---------------------------------------------------------------------------------------------------------
+    for s_ in range(S):
+        steps = all_steps[s_]
+        out = []
+        prev_set = set()                   # slots the latest value step stored: their value is still in D
+        for k in range(len(steps) + 1):
+            for ci, plan in inserts[s_].get(k, ()):
+                def opnd(st, which, w):
+                    if w in prev_set:
+                        st.pre.append(("prev", which))
+                    else:
+                        st.loads.append((which, K_SIG, w))
+
+                def new():
+                    st = _Step()
+                    st.check = True
+                    return st
+
+                if plan[0] == "eq" and plan[1] in prev_set and plan[2] in prev_set:
+                    stats["same_register"] += 1           # both wires were stored from D by the same row: nothing to compare
+                    continue
+                if plan[0] == "eq":
+                    st = new()
+                    st.body = "chkeq"
+                    opnd(st, "A", plan[1]); opnd(st, "B", plan[2])
+                    st.sarg = ci
+                    out.append(st)
+                elif plan[0] in ("mul", "add"):
+                    st0 = new()                           # the right-hand side goes to G one step earlier (G cannot be prefetched into)
+                    st0.inline = ("stashg",)
+                    opnd(st0, "A", plan[3])
+                    out.append(st0)
+                    st = new()
+                    if plan[0] == "mul":
+                        st.body = "chkmul" if mont else "chkmul2"
+                        opnd(st, "A", plan[1]); opnd(st, "B", plan[2])
+                    else:
+                        st.body = "chkadd"
+                        opnd(st, "A", plan[1])
+                        st.pre.append(("const", "B", plan[2] * one % q))
+                    st.sarg = ci
+                    out.append(st)
+                else:
+                    if plan[0] == "mulc":
+                        terms, k0, rhs = plan[3], plan[4], None
+                    else:
+                        terms, k0, rhs = plan[1], plan[2], plan[3]
+                    first = True
+                    for j, (w, cf) in enumerate(terms):
+                        t = new()
+                        if first:
+                            t.pre.append(("const", "G", k0 * one % q))
+                            t.pre.append(("zacc", 36))
+                            first = False
+                        opnd(t, "A", w)
+                        t.body = "dotmac"
+                        t.coef = _limbs29(cf * R % q)
+                        out.append(t)
+                        if (j & 3) == 3 and j + 1 < len(terms):
+                            t = new()
+                            t.body = "dotred"
+                            out.append(t)
+                    st = new()
+                    if first:
+                        st.pre.append(("const", "G", k0 * one % q))
+                        st.pre.append(("zacc", 36))
+                    if plan[0] == "mulc":
+                        if not first:                     # G = the right-hand side; then the product against it
+                            st.body = "dotred"
+                            out.append(st)
+                            st = new()
+                        st.body = "chkmul" if mont else "chkmul2"
+                        opnd(st, "A", plan[1]); opnd(st, "B", plan[2])
+                    else:
+                        st.body = "chkdot"
+                        if rhs is not None:
+                            opnd(st, "A", rhs)
+                        else:
+                            st.pre.append(("const", "A", 0))
+                    st.sarg = ci
+                    out.append(st)
+            if k < len(steps):
+                st = steps[k]
+                out.append(st)
+                if st.value:
+                    prev_set = {idx for kind, idx in st.stores if kind == K_SIG}
+        all_steps[s_] = out
+    return covered
+
+
 class _Emitter:
     def __init__(self, tape, bodies):
         self.tape, self.bodies = tape, bodies
@@ -322,7 +547,7 @@ class _Emitter:
         self.stats["calls"] += 1
         # which leading ACC registers are still zero afterwards
         w = [r for r in b.vwritten if r >= FB.ACC_REG and r < FB.ACC_REG + 36]
-        if name in ("dotred", "dotfin"):
+        if name in ("dotred", "dotfin") or name.startswith("chkdot"):
             self.acc_zero = 36
         elif w:
             self.acc_zero = min(self.acc_zero, min(w) - FB.ACC_REG)
@@ -434,6 +659,8 @@ class _Emitter:
                 d = FB.D_REG
                 if st.inline[0] == "copy":
                     self.mov_fe(d, ra)
+                elif st.inline[0] == "stashg":
+                    self.mov_fe(FB.G_REG, ra)
                 else:
                     kbit = st.inline[1]
                     if kbit < 256:
@@ -447,8 +674,12 @@ class _Emitter:
                 name = st.body if st.body in self.bodies else "%s_%s" % (st.body, par)
                 b = self.bodies[name]
                 if st.heavy:
-                    if name == "inv_h":          # no register to spare for the status word: it waits in LDS
-                        a("v_lshrrev_b32 v%d, 2, v%d" % (V_L16B, V_L16))
+                    # a heavy body keeps nothing but the status word (inv_h not even that): what the emitted code owns waits in
+                    # LDS (the fused check's finding, the status word) or is re-derived from the lane number afterwards
+                    a("v_lshrrev_b32 v%d, 2, v%d" % (V_L16B, V_L16))
+                    a("ds_write_b32 v%d, v%d offset:%d" % (V_L16B, V_FB, park_off + 256))
+                    self.lg_issued += 1
+                    if name == "inv_h":
                         a("ds_write_b32 v%d, v%d offset:%d" % (V_L16B, V_ST, park_off))
                         self.lg_issued += 1
                     if b.scratch:
@@ -457,11 +688,13 @@ class _Emitter:
                     if b.scratch:
                         a("s_waitcnt vmcnt(0)")
                     self.rederive()
+                    a("v_lshrrev_b32 v%d, 2, v%d" % (V_FB, V_L16))
                     if name == "inv_h":
-                        a("v_lshrrev_b32 v%d, 2, v%d" % (V_ST, V_L16))
-                        a("ds_read_b32 v%d, v%d offset:%d" % (V_ST, V_ST, park_off))
-                        a("s_waitcnt lgkmcnt(0)")
+                        a("ds_read_b32 v%d, v%d offset:%d" % (V_ST, V_FB, park_off))
                         self.lg_issued += 1
+                    a("ds_read_b32 v%d, v%d offset:%d" % (V_FB, V_FB, park_off + 256))
+                    a("s_waitcnt lgkmcnt(0)")
+                    self.lg_issued += 1
                     self.ir.append(("heavy_done",))
                 else:
                     self.call(name)
@@ -482,8 +715,9 @@ class _Emitter:
         return self.ir
 
 
-def emit(tape, bodies=None) -> FpJitProgram:
-    """the emitted kernel of one schedule variant (strand schedule, kind 0)"""
+def emit(tape, bodies=None, constraints=None) -> FpJitProgram:
+    """the emitted kernel of one schedule variant (strand schedule, kind 0); constraints = the circuit's R1CS rows
+    (FlatCircuit.constraints) to fuse their check into the code (plan_checks)"""
     if getattr(tape, "kind", 0) != 0:
         raise ValueError("only strand schedules have an emitted form")
     if tape.functions and (np.asarray(tape.rows)[:, 0] & 0xFF == D_CALL).any():
@@ -494,6 +728,7 @@ def emit(tape, bodies=None) -> FpJitProgram:
         bodies = FB.build_bodies()
     em = _Emitter(tape, bodies)
     all_steps = [expand_steps(tape, s) for s in range(S)]
+    covered = plan_checks(tape, constraints, all_steps) if constraints else []
     # strands that carry >= 80 % of the heaviest strand's work run at raised priority (as cw_eval_kernel's prio_mask)
     cost = []
     for steps in all_steps:
@@ -542,6 +777,7 @@ def emit(tape, bodies=None) -> FpJitProgram:
     em.strand = 0
     em.rederive()
     a("v_mov_b32 v%d, 0" % V_ST)
+    a("v_mov_b32 v%d, -1" % V_FB)                        # no constraint found violated yet
     a("s_mov_b64 s[%d:%d], 0" % (FB.S_SEL, FB.S_SEL + 1))
     for k in range(8):
         a("v_mov_b32 v%d, 0" % (FB.D_REG + k))
@@ -561,7 +797,7 @@ def emit(tape, bodies=None) -> FpJitProgram:
     prog.ir = []
     for s_ in range(S):
         prio = S > 1 and cost[s_] > 0 and cost[s_] >= 0.8 * heaviest
-        prog.ir.append(em.strand_code(s_, all_steps[s_], prio, park + 256 * s_))
+        prog.ir.append(em.strand_code(s_, all_steps[s_], prio, park + 512 * s_))
     # the bodies this schedule calls
     scratch = 0
     for name in sorted(em.used_bodies):
@@ -593,7 +829,10 @@ def emit(tape, bodies=None) -> FpJitProgram:
     prog.asm = "".join(L)
     prog.lds_bytes = lds_bytes
     prog.scratch_bytes = scratch
-    prog.stats = dict(em.stats, bodies=len(em.used_bodies), n_lds=n_lds)
+    prog.covered = covered
+    prog.stats = dict(em.stats, bodies=len(em.used_bodies), n_lds=n_lds, constraints=len(covered), constraints_fused=sum(covered),
+                      check_steps=sum(1 for steps in all_steps for st in steps if st.check),
+                      same_register=getattr(plan_checks, "stats", {}).get("same_register", 0) if constraints else 0)
     return prog
 
 

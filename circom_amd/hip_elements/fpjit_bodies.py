@@ -38,6 +38,7 @@ CACHE_DIR = os.path.join(os.path.dirname(_HERE), "lib")
 A_E, B_E, D_REG, A_O, B_O = 0, 8, 16, 24, 32
 G_REG, ACC_REG = 76, 84
 V_OWNED = list(range(120, 128))
+V_FB = 123                    # smallest index of a constraint the fused R1CS check found violated (0xFFFFFFFF: none)
 S_ARG, S_SEL, S_COEF, S_PARAMS, S_OWNED = 36, 38, 24, 40, 93
 S_RET = 98
 N_VGPR = 128
@@ -61,7 +62,8 @@ def _p_pins():
 
 
 class Body:
-    def __init__(self, name, code, vin=(), vout=(), sin=(), sout=(), keep_d=False, acc=False, g=False, parity=None):
+    def __init__(self, name, code, vin=(), vout=(), sin=(), sout=(), keep_d=False, acc=False, g=False, parity=None, chk=False):
+        self.chk = chk
         self.name, self.code = name, code
         self.vin, self.vout, self.sin, self.sout = list(vin), list(vout), list(sin), list(sout)
         self.keep_d, self.acc, self.g, self.parity = keep_d, acc, g, parity
@@ -119,6 +121,17 @@ def _specs():
                       vin=_fe(ra, "a") + _fe(rb, "b"), sin=[(S_ARG, "sarg")], keep_d=True, parity=par))
         S.append(Body("assertnz_%s" % par, "if (fe_is_zero(a)) cw_fail(st, CW_ST_ASSERT_FAILED, (uint32_t)sarg);",
                       vin=_fe(ra, "a"), sin=[(S_ARG, "sarg")], keep_d=True, parity=par))
+        # fused R1CS check (fpjit.plan_checks): recomputed from the stored wires right after the row that produced the last
+        # one; fb (v123) = smallest index of a violated constraint of this instance so far, sarg = the constraint's index
+        S.append(Body("chkeq_%s" % par, "if (!fe_eq(a, b)) fb = min(fb, (uint32_t)sarg);",
+                      vin=_fe(ra, "a") + _fe(rb, "b"), sin=[(S_ARG, "sarg")], keep_d=True, parity=par, chk=True))
+        for nm, expr in (("chkmul", "fe_mmul(a, b, P)"), ("chkmul2", "fe_mul2_auto(a, b, P)"), ("chkadd", "fe_add(a, b, P)")):
+            S.append(Body("%s_%s" % (nm, par), "if (!fe_eq(%s, g)) fb = min(fb, (uint32_t)sarg);" % expr,
+                          vin=_fe(ra, "a") + _fe(rb, "b") + _fe(G_REG, "g"), sin=[(S_ARG, "sarg")], keep_d=True, parity=par, chk=True))
+        # a linear row: g + reduce(acc) must equal the wire (or literal) in the A operand
+        S.append(Body("chkdot_%s" % par, "{ const fe r = fe_add(g, fe_from29(fe29_reduce(acc, P)), P); for (int j = 0; j < 18; j++) acc[j] = 0;\n"
+                      "  if (!fe_eq(r, a)) fb = min(fb, (uint32_t)sarg); }",
+                      vin=_fe(ra, "a"), sin=[(S_ARG, "sarg")], keep_d=True, acc="dot", g=True, parity=par, chk=True))
         # LINSUM term: x in the A operand of the parity, |coefficient| in sarg; g / pos / neg accumulate across calls
         for sg, nm in ((0, "linp"), (1, "linn")):
             S.append(Body("%s_%s" % (nm, par), "linsum_term(a, sarg | %s, g, pos, neg, P);" % ("(1ull << 63)" if sg else "0ull"),
@@ -146,8 +159,11 @@ def _specs():
                   vout=_fe(D_REG, "d"), acc="dot", g=True))
     # end of the strand: the first failed check of the instance reaches the status array (the one body with memory
     # instructions: nothing of the emitted code is in flight behind it)
+    # (the findings of the fused R1CS check go to the second half of the status array - Bp words behind the first, Bp =
+    # slot stride / 32 - where cw_check_r1cs picks them up)
     S.append(Body("publish", "{ uint32_t *status = (uint32_t *)(((uint64_t)ks97 << 32) | ks96);\n"
-                  "  if (st && kv127 < ks93) cw_publish_status(status, kv127, st); }", keep_d=True, parity="m"))
+                  "  if (st && kv127 < ks93) cw_publish_status(status, kv127, st);\n"
+                  "  if (fb != 0xFFFFFFFFu && kv127 < ks93) atomicMin(&status[(ks100 >> 5) + kv127], fb); }", keep_d=True, parity="m", chk=True))
     return S
 
 
@@ -205,6 +221,11 @@ def _source(bodies, fe_slow_inline=True):
             outs.append('"={v%d}"(st)' % st_reg)
             ins.append('"{v%d}"(st)' % st_reg)
         keep_v.discard(st_reg)
+        if b.chk:
+            decl.append("uint32_t fb;")
+            outs.append('"={v%d}"(fb)' % V_FB)
+            ins.append('"{v%d}"(fb)' % V_FB)
+            keep_v.discard(V_FB)
         for r in sorted(keep_v):
             if r in vout:
                 continue
@@ -432,7 +453,7 @@ def parse_bodies(asm: str, bodies):
             text = text + [RET_MARK] + tail
         # the compiler's own markers around the asm statements
         text = [t for t in text if "#ASMSTART" not in t and "#ASMEND" not in t]
-        allowed_v = set(range(40, 120)) | {r for r, _ in b.vin} | {r for r, _ in b.vout} | {124}
+        allowed_v = set(range(40, 120)) | {r for r, _ in b.vin} | {r for r, _ in b.vout} | {124} | ({V_FB} if b.chk else set())
         if b.parity == "e":
             allowed_v |= set(range(A_E, A_E + 16))
         elif b.parity == "o":

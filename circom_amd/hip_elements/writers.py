@@ -194,11 +194,18 @@ def write_tape(path, tapes, bittape=None, jit=None, fpjit=()):
             f.write(jit.code + b"\0" * (-len(jit.code) % 4))
         if fpjit:
             # emitted 256-bit code of strand variants (hip_elements/fpjit.py), an optional trailing section: "FPJT" | u32 format
-            # 1 | u32 n | per program 8 x u32 {n_strands, code bytes, LDS bytes, scratch bytes, VGPRs, 0, 0, 0} + the code object
+            # 1 | u32 n | per program 8 x u32 {n_strands, code bytes, LDS bytes, scratch bytes, VGPRs, bitmap words, 0, 0} + the
+            # fused-check bitmap (bit i: the code itself recomputes row i of the .r1cs) + the code object
+            assert len(fpjit) <= 8
             f.write(b"FPJT" + struct.pack("<II", 1, len(fpjit)))
             for fp in fpjit:
                 assert fp.code is not None and any(t.n_strands == fp.n_strands and getattr(t, "kind", 0) == 0 for t in tapes)
-                f.write(struct.pack("<8I", fp.n_strands, len(fp.code), fp.lds_bytes, fp.scratch_bytes, 128, 0, 0, 0))
+                cov = np.zeros((len(fp.covered) + 31) // 32, dtype="<u4")
+                for i, cbit in enumerate(fp.covered):
+                    if cbit:
+                        cov[i >> 5] |= np.uint32(1 << (i & 31))
+                f.write(struct.pack("<8I", fp.n_strands, len(fp.code), fp.lds_bytes, fp.scratch_bytes, 128, len(cov), 0, 0))
+                f.write(cov.tobytes())
                 f.write(fp.code + b"\0" * (-len(fp.code) % 4))
 
 

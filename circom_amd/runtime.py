@@ -204,7 +204,9 @@ class Batch:
         pp = lib().cw_batch_pipelined(h)
         self.pipelined = (pp & 0xFF, pp >> 8) if pp else None     # (rows per batch, loads per batch) of the pipelined variant
         self.lanes = lib().cw_batch_lanes(h)
-        self.emitted = bool(lib().cw_batch_emitted(h))            # the variant's rows run as emitted code (hip_elements/fpjit.py)
+        em = lib().cw_batch_emitted(h)
+        self.emitted = bool(em)              # the variant's rows run as emitted code (hip_elements/fpjit.py)
+        self.fused_check = em == 2           # ... which also recomputes the R1CS rows it covers
         self.bitmode = bool(lib().cw_batch_bitmode(h))
         lay = (C.c_uint64 * 4)()
         _chk(lib().cw_batch_bits_layout(h, lay))

@@ -84,7 +84,10 @@ uint32_t cw_batch_strands(const cw_batch *b);
 uint32_t cw_batch_pipelined(const cw_batch *b);
 /* 1 when the rows of the picked variant run as EMITTED gfx950 code (hip_elements/fpjit.py: the counterpart of the reference's
    per-template C++, compiler/src/circuit_design/template.rs:174-474 - operand loads, a call of the operator's body and the
-   stores of every row as straight-line code), 0 when cw_eval_kernel interprets them.  CW_FP_JIT=0 forces the interpreter. */
+   stores of every row as straight-line code), 2 when that code also carries the R1CS check of the rows it covers (recomputed
+   from the stored wires behind the rows that produce them; chosen for throughput-bound batches, CW_FP_FUSED=0/1 overrides;
+   cw_check_r1cs then merges its findings and streams only the remaining rows), 0 when cw_eval_kernel interprets the rows.
+   CW_FP_JIT=0 forces the interpreter. */
 uint32_t cw_batch_emitted(const cw_batch *b);
 /* instances per workgroup (64, 32 or 16) the evaluation kernel uses for this batch */
 uint32_t cw_batch_lanes(const cw_batch *b);

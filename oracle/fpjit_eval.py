@@ -42,6 +42,7 @@ def replay(prog_ir, body_info, q: int, n_signals: int, n_tslots: int, n_lds: int
         mem[k] = v % q
     lds = [0] * max(n_lds, 1)
     status = [0]
+    fbmin = [None]                       # smallest index of a constraint the fused check found violated
     ns = len(prog_ir)
     pcs = [0] * ns
     state = []
@@ -190,18 +191,37 @@ def replay(prog_ir, body_info, q: int, n_signals: int, n_tslots: int, n_lds: int
                         res = g
                 elif base == "publish":
                     pass
+                elif base in ("chkeq", "chkmul", "chkmul2", "chkadd", "chkdot"):
+                    if base == "chkeq":
+                        bad = rd(st, ra, what) != rd(st, rb, what)
+                    elif base == "chkmul":
+                        bad = rd(st, ra, what) * rd(st, rb, what) * rinv % q != rd(st, G_REG, what)
+                    elif base == "chkmul2":
+                        bad = rd(st, ra, what) * rd(st, rb, what) % q != rd(st, G_REG, what)
+                    elif base == "chkadd":
+                        bad = (rd(st, ra, what) + rd(st, rb, what)) % q != rd(st, G_REG, what)
+                    else:
+                        if st["acc"] is None:
+                            raise JitHazard("%s reduces columns that were never cleared" % what)
+                        bad = (rd(st, G_REG, what) + st["acc"] * rinv) % q != rd(st, ra, what)
+                        st["acc"] = 0
+                        st["acc_zero"] = 36
+                    if bad and (fbmin[0] is None or st["sarg"] < fbmin[0]):
+                        fbmin[0] = st["sarg"]
                 else:
                     raise ValueError("no restatement of body %s" % name)
                 # everything the body may touch is garbage afterwards, except what it defines
                 for g in _GROUPS:
                     if g == G_REG and base in ("linp", "linn", "dotmac", "dotred"):
                         continue
+                    if g == D_REG and base.startswith("chk"):
+                        continue
                     if any(r in touched for r in range(g, g + 8)) and not isinstance(reg[g], _Pending):
                         if g == D_REG and res is None and base not in ("linfin", "dotfin"):
                             continue          # bodies without a value keep D (checked at build time: fpjit_bodies.parse_bodies)
                         reg[g] = POISON
                 wacc = [r - ACC_REG for r in touched if ACC_REG <= r < ACC_REG + 36]
-                if wacc and base not in ("linp", "linn", "dotmac", "dotred", "dotfin", "linfin"):
+                if wacc and base not in ("linp", "linn", "dotmac", "dotred", "dotfin", "linfin", "chkdot"):
                     st["acc"] = st["lin"] = None
                     st["acc_zero"] = min(st["acc_zero"], min(wacc))
                 if base == "linfin":
@@ -224,6 +244,7 @@ def replay(prog_ir, body_info, q: int, n_signals: int, n_tslots: int, n_lds: int
                 kinds.add(kd)
         if len(kinds) > 1:
             raise JitHazard("strands disagree on the barrier kind")
+    replay.first_bad = fbmin[0]
     return mem[:n_signals], status[0]
 
 

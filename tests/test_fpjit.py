@@ -44,7 +44,8 @@ def test_bodies_respect_their_register_budgets(bodies):
         if b.parity == "o":
             assert not any(r < 16 for r in b.vwritten), name
         if b.parity != "m":
-            assert not any(r in b.vwritten for r in (120, 121, 122, 123, 125, 126, 127)) or b.parity == "h", name
+            owned = (120, 121, 122, 125, 126, 127) + (() if b.chk else (123,))      # v123 = the fused check's finding
+            assert not any(r in b.vwritten for r in owned) or b.parity == "h", name
     assert 250 <= bodies["mmul_e"].n_instr <= 400
 
 
@@ -110,6 +111,50 @@ def test_replay_catches_a_wait_that_is_too_weak(bodies):
         replay(p.ir, info, t.q, t.n_signals, t.n_tslots, t.n_lds, {k2: v * R % t.q for k2, v in inp.items()}, t.rbits, R)
 
 
+from circom_amd.frontend.dsl import template  # noqa: E402
+
+
+@template
+def Flaky(c, n):
+    a = c.input("a")
+    b = c.input("b")
+    out = c.output("out")
+    x = c.signal("x", n + 1)
+    y = c.signal("y", n)
+    c.set(x[0], a + b)
+    for k in range(n):
+        c.hint(x[k + 1], x[k] * x[k] + b + (a % (2 * n + 3)).eq(k))      # a product row breaks for a mod (2n + 3) == k
+        c.enforce(x[k + 1], x[k] * x[k] + b, runtime_check=False)
+        c.hint(y[k], x[k + 1] * 5 + x[k] * 7 + 3 + (a % (2 * n + 3)).eq(n + k))  # a linear row for a mod (2n + 3) == n + k
+        c.enforce(y[k], x[k + 1] * 5 + x[k] * 7 + 3, runtime_check=False)
+    c.set(out, x[n] * 3 + y[0])
+
+
+def test_fused_check_finds_the_first_violated_row(bodies):
+    """witness code that disagrees with its constraint (`<--` + `===` with the run-time assert off): the check steps the
+    emitted code carries must name the row the oracle names, for every class of row they cover"""
+    from oracle.tape_eval import check_r1cs
+    from oracle import fpjit_eval
+
+    n = 6
+    fc = flatten(Program(Flaky(n)))
+    q = fc.fp.q
+    for S, mont in ((1, True), (4, False), (4, True)):
+        t = lower(fc, n_strands=S, mont=mont)
+        p = fpjit.emit(t, bodies, fc.constraints)
+        assert sum(p.covered) >= len(fc.constraints) - 2 * n          # (a mod 2n).eq(k) rows have multi-term factors
+        for a in range(2 * n + 3):
+            inp = {fc.main_input_start: a, fc.main_input_start + 1: 1000 + a}
+            sig, st = replay_tape(t, p, bodies, inp)
+            want = None
+            for ci, con in enumerate(fc.constraints):                 # the first violated row AMONG the fused ones
+                if p.covered[ci] and check_r1cs(q, [con], sig) is not None:
+                    want = ci
+                    break
+            assert fpjit_eval.replay.first_bad == want, (S, mont, a, fpjit_eval.replay.first_bad, want)
+            assert (want is not None) == (a < 2 * n)
+
+
 def test_replay_semaphore_style_strands(bodies):
     """EdDSA-style circuit (projective ladder hints): LINSUM rows of hundreds of terms, batched inversions, select / ext,
     LDS hand-offs between 16 strands"""
@@ -121,10 +166,13 @@ def test_replay_semaphore_style_strands(bodies):
     inp = {fc.main_input_start + k: v for k, v in enumerate(row)}
     for S, mont in ((1, False), (16, True)):
         t = lower(fc, n_strands=S, mont=mont)
-        p = fpjit.emit(t, bodies)
+        p = fpjit.emit(t, bodies, fc.constraints)
+        assert sum(p.covered) > 0.6 * len(fc.constraints)
         want, st0 = eval_tape(t, inp)
         got, st1 = replay_tape(t, p, bodies, inp)
         assert st0 == 0 and (got, st1) == (want, st0)
+        from oracle import fpjit_eval
+        assert fpjit_eval.replay.first_bad is None                    # a valid witness: no fused check fires
     bad = dict(inp)
     bad[fc.main_input_start + 2] = (row[2] + 1) % q           # tampered signature: the same status word
     want, st0 = eval_tape(t, bad)
@@ -133,7 +181,7 @@ def test_replay_semaphore_style_strands(bodies):
 
 
 # ---- GPU ---------------------------------------------------------------------------------------------------------------
-def _run_both(cp, rows, monkeypatch, strands, lanes=None):
+def _run_both(cp, rows, monkeypatch, strands, lanes=None, fused=None):
     """witness tables + status words of the same batch through the emitted code and through the interpreting kernel"""
     from circom_amd import runtime as rt
     out = []
@@ -144,15 +192,21 @@ def _run_both(cp, rows, monkeypatch, strands, lanes=None):
             monkeypatch.setenv("CW_LANES", str(lanes))
         else:
             monkeypatch.delenv("CW_LANES", raising=False)
+        if fused is None:
+            monkeypatch.delenv("CW_FP_FUSED", raising=False)
+        else:
+            monkeypatch.setenv("CW_FP_FUSED", "1" if fused else "0")
         c = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
         b = c.batch(len(rows))
         assert b.emitted == emitted and b.strands == strands
+        if emitted and fused is not None and c.n_constraints:
+            assert b.fused_check == fused
         b.set_inputs(rows)
         b.run()
         if c.n_constraints:
             b.check_r1cs()
         b.sync()
-        out.append((b.witnesses().copy(), b.status().copy()))
+        out.append((b.witnesses().copy(), b.status().copy(), b.r1cs_first_bad().copy() if c.n_constraints else None))
         b.close(); c.close()
     return out
 
@@ -163,11 +217,11 @@ def test_gpu_emitted_code_every_operator(tmp_path, monkeypatch, prime):
     from test_opzoo import _operands
     q = PRIMES[prime]
     cp = compile_program(Program(OperatorZoo(), prime=prime), str(tmp_path), "opzoo", sym=False, fpjit=True)
-    assert {p.n_strands for p in cp.fpjit} == {1, 4, 16}
+    assert {p.n_strands for p in cp.fpjit} == {1, 4, 16} and not any(p.covered for p in cp.fpjit)     # (no constraints)
     fc = cp.flat
     rows = _operands(q, 300, 9)
     for strands, lanes in ((1, None), (4, 32), (16, 16)):
-        (w1, s1), (w0, s0) = _run_both(cp, rows, monkeypatch, strands, lanes)
+        (w1, s1, _), (w0, s0, _) = _run_both(cp, rows, monkeypatch, strands, lanes)
         assert (s1 == s0).all() and (s1 == 0).all()
         assert w1.tobytes() == w0.tobytes(), (prime, strands)
     for i in range(0, len(rows), 37):
@@ -183,10 +237,10 @@ def test_gpu_emitted_code_poseidon(tmp_path, monkeypatch, mont):
     cp = compile_program(Program(Poseidon(2)), str(tmp_path), "poseidon2", sym=False, mont=mont, fpjit=True)
     q = cp.flat.fp.q
     rng = random.Random(3)
-    for n, strands, lanes in ((700, 1, None), (333, 4, None), (100, 16, 16), (64 * 70, 4, None)):
+    for n, strands, lanes, fused in ((700, 1, None, True), (333, 4, None, False), (100, 16, 16, True), (64 * 70, 4, None, None)):
         rows = [[rng.randrange(q), rng.randrange(q)] for _ in range(n)]
-        (w1, s1), (w0, s0) = _run_both(cp, rows, monkeypatch, strands, lanes)
-        assert (s1 == 0).all() and (s0 == 0).all()
+        (w1, s1, f1), (w0, s0, f0) = _run_both(cp, rows, monkeypatch, strands, lanes, fused)
+        assert (s1 == 0).all() and (s0 == 0).all() and (f1 == f0).all()
         assert w1.tobytes() == w0.tobytes(), (n, strands)
         for i in (0, n // 2, n - 1):
             assert int.from_bytes(w1[i][1].tobytes(), "little") == poseidon_hash(q, rows[i])
@@ -210,11 +264,40 @@ def test_gpu_emitted_code_semaphore_style_and_status_words(tmp_path, monkeypatch
         if i % 4 == 3:
             row[2] = (row[2] + 1) % SUBGROUP_ORDER
         rows.append(row)
-    for strands, lanes in ((16, 16), (4, None), (1, None)):
-        (w1, s1), (w0, s0) = _run_both(cp, rows, monkeypatch, strands, lanes)
-        assert (s1 == s0).all(), strands
+    for strands, lanes, fused in ((16, 16, True), (16, 16, False), (4, None, True), (1, None, True)):
+        (w1, s1, f1), (w0, s0, f0) = _run_both(cp, rows, monkeypatch, strands, lanes, fused)
+        assert (s1 == s0).all() and (f1 == f0).all(), strands
         assert all((s1[i] != 0) == (i % 4 == 3) for i in range(len(rows)))
         ok = [i for i in range(len(rows)) if i % 4 != 3]
         assert w1[ok].tobytes() == w0[ok].tobytes(), strands
     sig, failed = eval_flat(q, fc.n_signals, fc.n_temps, fc.constants, fc.code, {fc.main_input_start + k: v for k, v in enumerate(rows[0])})
     assert failed is None and w1[0].tobytes() == b"".join(v.to_bytes(32, "little") for v in sig)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mont", [True, False])
+def test_gpu_fused_check_names_the_first_violated_row(tmp_path, monkeypatch, mont):
+    """the check steps inside the emitted code + the stand-alone kernel on the rows they leave to it = the stand-alone
+    kernel on every row (interpreter run): same status words, same first violated row, for every instance"""
+    from oracle.tape_eval import check_r1cs
+    n = 40
+    cp = compile_program(Program(Flaky(n)), str(tmp_path), "flaky", sym=False, mont=mont, fpjit=True)
+    assert all(sum(p.covered) >= len(cp.flat.constraints) - 2 * n for p in cp.fpjit if p.covered)
+    assert sorted((p.n_strands, bool(p.covered)) for p in cp.fpjit) == [(1, False), (1, True), (4, False), (4, True), (16, False), (16, True)]
+    rows = [[a, 1000 + 7 * a] for a in range(300)]
+    for strands, lanes, fused in ((1, None, True), (4, None, True), (16, 16, True), (4, None, False)):
+        (w1, s1, f1), (w0, s0, f0) = _run_both(cp, rows, monkeypatch, strands, lanes, fused)
+        assert w1.tobytes() == w0.tobytes()
+        assert (s1 == s0).all() and (f1 == f0).all(), (strands, [(i, f1[i], f0[i]) for i in range(300) if f1[i] != f0[i]][:5])
+    from circom_amd import runtime as rt
+    q = cp.flat.fp.q
+    for i in (0, 5, n + 3, 2 * n + 1, 2 * n + 2, 299):
+        sig = [int.from_bytes(w1[i][k].tobytes(), "little") for k in range(w1.shape[1])]
+        want = check_r1cs(q, cp.flat.constraints, sig)
+        assert (want is None) == ((s1[i] & rt.ST_R1CS_FAILED) == 0)
+        if want is not None:
+            assert f1[i] == want
+    # CW_R1CS_AUDIT: the stand-alone kernel re-checks every row whatever the code covered - same words
+    monkeypatch.setenv("CW_R1CS_AUDIT", "1")
+    (w2, s2, f2), _ = _run_both(cp, rows, monkeypatch, 4, None, True)
+    assert (s2 == s1).all() and (f2 == f1).all()
