@@ -116,6 +116,8 @@ def get_compiled(name: str, batch: int, cache_root: str, rank: int, dist):
     from circom_amd.hip_elements.lower import lower
     fp = artefact_fingerprint()
     strands = compiler.strands_for(batch)
+    if os.environ.get("CW_BENCH_STRANDS"):          # experiments: lower (only) this strand count
+        strands = (int(os.environ["CW_BENCH_STRANDS"]),)
     d = os.path.join(cache_root, "%s_s%s_b%s_m%s_%s" % (name, "-".join(map(str, strands)), os.environ.get("CW_BITS", "1"),
                                                        os.environ.get("CW_MONT", "a"), fp))
     p = lambda ext: os.path.join(d, name + ext)
@@ -159,6 +161,10 @@ def get_compiled(name: str, batch: int, cache_root: str, rank: int, dist):
         cp.jit_stats = json.load(open(p(".jit.json")))
     except Exception:
         cp.jit_stats = {}
+    try:
+        cp.fpjit_stats = json.load(open(p(".fpjit.json")))
+    except Exception:
+        cp.fpjit_stats = []
     return cp, time.perf_counter() - t0, cached
 
 
@@ -792,13 +798,22 @@ def main():
                            "peak": HBM_PEAK_GBS, "frac": 32.0 * n_in * B / (ing_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": ing_ms,
                            "algorithmic_bytes_per_launch": 32.0 * n_in * B}
         else:
+            if getattr(batch, "emitted", False):
+                # the rows of the strand variant as emitted code (hip_elements/fpjit.py); with the fused check the kernel also
+                # recomputes the R1CS rows it covers (about as much arithmetic again: Fp-mul/s below counts the evaluation's only)
+                ek = "cw_fp_jit (emitted per circuit%s)" % (", R1CS check fused" if batch.fused_check else "")
+                if batch.fused_check:
+                    rk = "fused into cw_fp_jit; cw_r1cs_stream_kernel on the rows the code leaves + merge"
             gen_k = prof.get("eval_avg_us", 0.0) / 1e3 or isolated["eval_ms"]
             chk_k = prof.get("r1cs_avg_us", 0.0) / 1e3 or isolated["r1cs_check_ms"]
             gen_gbs = alg_gen / (gen_k * 1e-3) / 1e9
             chk_gbs = alg_chk / (chk_k * 1e-3) / 1e9
             roof_eval = {"bound": "hbm", "kernel": ek, "achieved": gen_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gen_gbs / HBM_PEAK_GBS, "traffic": prof.get("eval"), "algorithmic_bytes_per_launch": alg_gen,
-                         "kernel_ms": gen_k, "strands": batch.strands, "lanes_per_workgroup": batch.lanes}
+                         "kernel_ms": gen_k, "strands": batch.strands, "lanes_per_workgroup": batch.lanes,
+                         "emitted_code": ([e for e in getattr(cp, "fpjit_stats", []) if e.get("n_strands") == batch.strands and
+                                           bool(e.get("constraints_fused")) == bool(batch.fused_check)] or [None])[0]
+                         if getattr(batch, "emitted", False) else None}
             roof_r1cs = {"bound": "hbm", "kernel": rk, "achieved": chk_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": chk_gbs / HBM_PEAK_GBS, "traffic": prof.get("r1cs"), "algorithmic_bytes_per_launch": alg_chk,
                          "kernel_ms": chk_k,
@@ -840,7 +855,8 @@ def main():
                        "n_signals": circ.n_signals, "n_witness": n_wit, "n_constraints": circ.n_constraints,
                        "engine": "bit-plane, emitted gfx950 code (one wave per 2 048 instances, 1 bit per signal value per instance)" if batch.bitmode and batch.jit else
                        "bit-plane (1 bit per signal value per instance)" if batch.bitmode else
-                       ("256-bit schedule, signals in Montgomery form" if circ.montgomery else "256-bit schedule"),
+                       (("256-bit schedule as emitted gfx950 code" + (" with the R1CS check fused in" if batch.fused_check else ""))
+                        if getattr(batch, "emitted", False) else "256-bit schedule, interpreted") + (", signals in Montgomery form" if circ.montgomery else ""),
                        "bit_program": bits, "emitted_code": getattr(cp, "jit_stats", None) if batch.bitmode and batch.jit else None, "r1cs_check_classes": (circ.bits_r1cs_plan_stats() if batch.bitmode else None),
                        "schedule_rows": circ.n_rows, "fp_mul_per_witness": circ.n_mmul,
                        "parallelism": "instances sharded x%d, status + public-signal gather only" % world,

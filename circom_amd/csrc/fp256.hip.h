@@ -644,39 +644,82 @@ __device__ CW_FE_SLOW fe fe_pow(const fe &x, const fe &y, const FpParams &P) {
     }
     return fe_from29(fe29_mmul(r, fe_to29(fe_small(1)), P));
 }
-// floor(x / y), x mod y on canonical integers (Fr_idiv/Fr_mod via mpz_fdiv_q/r, generic/fr.cpp:2835-2875).
-// Restoring shift-subtract division; y == 0 is reported by the caller.
+// floor(x / y), x mod y on canonical integers (Fr_idiv/Fr_mod via mpz_fdiv_q/r, generic/fr.cpp:2835-2875); y == 0 is
+// reported by the caller.  Schoolbook long division in base 2^32 (Knuth's algorithm D) on operands normalised PER LANE:
+// V = y << s with s = the leading zeros of y (so V's top bit is set), X = x << s (up to 511 bits: its high half is the first
+// remainder, its low half supplies one digit per step); a quotient digit = one 64-by-32-bit estimate from the remainder's two
+// top words, refined with V's second word (then at most one too large), a 9-word multiply-subtract and a conditional
+// add-back.  ~150 instructions per digit instead of the 32 x ~80 of the restoring division it replaces (rounds 1-3), and a
+// digit that is zero in every lane of the wave (r < V everywhere: numerators of bigint long division are 2-3 words) costs
+// one comparison.
+__device__ __forceinline__ uint32_t fe_clz256(const fe &a) {         // leading zeros of a 256-bit value (256 for zero)
+    uint32_t n = 256;
+    FE_UNROLL for (int k = 0; k < 8; k++)
+        if (a.v[k]) n = (uint32_t)(32 * (7 - k)) + (uint32_t)__builtin_clz(a.v[k]);
+    return n;
+}
 __device__ CW_FE_SLOW void fe_divmod(const fe &x, const fe &y, fe *quo, fe *rem) {
-    fe q = fe_zero(), r = fe_zero();
-    // leading words that are zero in EVERY lane are skipped (wave-uniform test): the integer divisions of witness code are
-    // mostly on limb-sized values (bigint long division: 64..96-bit numerators - 2-3 of the 8 words), and a word costs
-    // 32 x ~80 instructions
-    bool started = false;
-    FE_UNROLL for (int w = 7; w >= 0; w--) {
-        const uint32_t xw = x.v[w];
-        if (!started) {
-            if (!__any(xw != 0)) continue;
-            started = true;
+    const uint32_t s = fe_clz256(y) & 255u;                           // y != 0: 0..255
+    const fe V = fe_shl_raw(y, s);
+    const fe Xlo = fe_shl_raw(x, s);
+    const fe Xhi_ = fe_shr_raw(x, (256u - s) & 255u);
+    uint32_t r[9];
+    FE_UNROLL for (int k = 0; k < 8; k++) r[k] = s ? Xhi_.v[k] : 0u;  // x >> (256 - s); nothing for s = 0
+    r[8] = 0;
+    fe q = fe_zero();
+    const uint32_t v7 = V.v[7], v6 = V.v[6];
+    FE_UNROLL for (int j = 7; j >= 0; j--) {
+        FE_UNROLL for (int k = 8; k >= 1; k--) r[k] = r[k - 1];       // r = r * 2^32 + next digit of X  (r < V before)
+        r[0] = Xlo.v[j];
+        // r >= V in some lane?  (9-word compare; r[8] != 0 implies r >= V)
+        bool lt = false, decided = r[8] != 0;
+        FE_UNROLL for (int k = 7; k >= 0; k--) {
+            if (!decided && r[k] != V.v[k]) { lt = r[k] < V.v[k]; decided = true; }
         }
-        uint32_t qw = 0;
-        for (int b = 31; b >= 0; b--) {
-            // r = (r << 1) | bit(x)
-            FE_UNROLL for (int k = 7; k >= 1; k--) r.v[k] = (r.v[k] << 1) | (r.v[k - 1] >> 31);
-            r.v[0] = (r.v[0] << 1) | ((xw >> b) & 1);
-            // if r >= y: r -= y, set quotient bit
-            fe d;
-            int64_t br = 0;
+        if (!__any(!lt)) continue;                                    // every lane's digit is zero
+        const uint64_t n = ((uint64_t)r[8] << 32) | r[7];
+        uint64_t qh = n / v7;
+        if (qh > 0xFFFFFFFFull) qh = 0xFFFFFFFFull;
+        uint64_t rh = n - qh * v7;
+        FE_UNROLL for (int t = 0; t < 2; t++) {
+            const bool dec = rh <= 0xFFFFFFFFull && qh * (uint64_t)v6 > ((rh << 32) | r[6]);
+            qh -= dec ? 1u : 0u;
+            rh += dec ? v7 : 0u;
+        }
+        const uint32_t qd = (uint32_t)qh;
+        // r -= qd * V
+        uint64_t carry = 0;
+        int64_t br = 0;
+        FE_UNROLL for (int k = 0; k < 8; k++) {
+            const uint64_t p = (uint64_t)qd * V.v[k] + carry;
+            carry = p >> 32;
+            const int64_t t = (int64_t)r[k] - (int64_t)(uint32_t)p + br;
+            r[k] = (uint32_t)t;
+            br = t >> 32;
+        }
+        const int64_t t8 = (int64_t)r[8] - (int64_t)carry + br;
+        r[8] = (uint32_t)t8;
+        bool neg = t8 < 0;
+        uint32_t qfix = 0;
+        FE_UNROLL for (int t = 0; t < 2; t++) {                       // add V back while the remainder is negative (at most once
+            uint64_t c = 0;                                           // after the refinement; twice costs nothing to allow)
+            uint32_t a9[9];
             FE_UNROLL for (int k = 0; k < 8; k++) {
-                int64_t t = (int64_t)r.v[k] - (int64_t)y.v[k] + br;
-                d.v[k] = (uint32_t)t;
-                br = t >> 32;
+                c += (uint64_t)r[k] + V.v[k];
+                a9[k] = (uint32_t)c;
+                c >>= 32;
             }
-            bool ge = (br == 0);
-            FE_UNROLL for (int k = 0; k < 8; k++) r.v[k] = ge ? d.v[k] : r.v[k];
-            qw |= (ge ? 1u : 0u) << b;
+            c += (uint64_t)r[8];
+            a9[8] = (uint32_t)c;
+            const bool wrapped = (c >> 32) != 0;                      // the sum crossed zero: non-negative again
+            FE_UNROLL for (int k = 0; k < 9; k++) r[k] = neg ? a9[k] : r[k];
+            qfix += neg ? 1u : 0u;
+            neg = neg && !wrapped;
         }
-        q.v[w] = qw;
+        q.v[j] = qd - qfix;
     }
+    fe rn;
+    FE_UNROLL for (int k = 0; k < 8; k++) rn.v[k] = r[k];
     *quo = q;
-    *rem = r;
+    *rem = fe_shr_raw(rn, s);
 }

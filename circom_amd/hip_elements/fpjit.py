@@ -460,6 +460,9 @@ def plan_checks(tape, constraints, all_steps):
     return covered
 
 
+_EXP = os.environ.get("CW_FPJIT_EXP", "")
+
+
 class _Emitter:
     def __init__(self, tape, bodies):
         self.tape, self.bodies = tape, bodies
@@ -473,6 +476,10 @@ class _Emitter:
         self.stats = {"steps": 0, "calls": 0, "glue": 0, "loads": 0, "stores": 0}
 
     def add(self, s, glue=1):
+        # timing experiments (results are garbage, tools/fpjit_timing_exp.sh): which part of a launch is what
+        if _EXP and ((_EXP == "nowait" and s.startswith("s_waitcnt vmcnt")) or (_EXP == "nobarrier" and s == "s_barrier") or
+                     (_EXP == "nostore" and s.startswith("global_store")) or (_EXP == "nocall" and s.startswith("s_swappc") and "publish" not in self.L[-2])):
+            return
         self.L.append("  " + s + "\n")
         self.stats["glue"] += glue
 

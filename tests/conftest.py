@@ -17,6 +17,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: takes more than ~20 s on CPU")
 
 
+def emit_for_gpu():
+    """`fpjit=` argument for fixtures that compile LARGE arithmetic circuits shared by CPU and GPU tests: the emitted code of a
+    40 000-signal circuit is six code objects of 12-18 MB (a minute of assembling) that only a GPU run ever executes, so the CPU
+    suite compiles those circuits without it; small circuits always carry it (tests/test_fpjit.py covers both sides)."""
+    import os
+    return "auto" if os.path.exists("/dev/kfd") else False
+
+
 def ensure_ref(prime: str) -> Path:
     """Make sure oracle/_ref/<prime>/ holds the compiled reference runtime; build it if the
     reference tree is present, otherwise skip (the GPU box only has the prebuilt files)."""

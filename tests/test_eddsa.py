@@ -52,7 +52,8 @@ def test_host_signatures_verify_and_tampering_fails():
 @pytest.fixture(scope="module")
 def sem(tmp_path_factory):
     d = tmp_path_factory.mktemp("sem")
-    return compile_program(Program(SemaphoreStyle(LEVELS)), str(d), "semaphore20", sym=False)
+    from conftest import emit_for_gpu
+    return compile_program(Program(SemaphoreStyle(LEVELS)), str(d), "semaphore20", sym=False, fpjit=emit_for_gpu())
 
 
 def test_semaphore_oracle_outputs_and_r1cs(sem):
@@ -132,7 +133,8 @@ def test_gpu_semaphore_matches_oracle_and_reference(sem, tmp_path):
 @pytest.fixture(scope="module")
 def semp(tmp_path_factory):
     d = tmp_path_factory.mktemp("semp")
-    return compile_program(Program(SemaphoreStyle(LEVELS, True)), str(d), "semaphore20p", sym=False)
+    from conftest import emit_for_gpu
+    return compile_program(Program(SemaphoreStyle(LEVELS, True)), str(d), "semaphore20p", sym=False, fpjit=emit_for_gpu())
 
 
 def test_projective_ladder_same_outputs_fewer_chained_inversions(semp):

@@ -62,7 +62,7 @@ if len(sys.argv) > 3:
             return "gather"
         if "assert_kernel" in k or "init_kernel" in k:
             return None
-        if "eval_kernel" in k or "pipe_kernel" in k or "cw_bits_jit" in k:
+        if "eval_kernel" in k or "pipe_kernel" in k or "cw_bits_jit" in k or "cw_fp_jit" in k:
             return "eval"
         if "r1cs" in k:
             return "r1cs"
