@@ -98,6 +98,8 @@ def artefact_fingerprint() -> str:
     h = hashlib.sha256()
     files = sorted((ROOT / "circom_amd" / "hip_elements").glob("*.py")) + sorted((ROOT / "circom_amd" / "frontend").glob("*.py")) \
         + sorted((ROOT / "circom_amd" / "circuits").glob("*.py")) + [ROOT / "circom_amd" / "csrc" / "cw_tape.h",
+                                                                    # (the emitted code's row bodies are compiled from these two)
+                                                                    ROOT / "circom_amd" / "csrc" / "fp256.hip.h", ROOT / "circom_amd" / "csrc" / "cw_rowops.hip.h",
                                                                     ROOT / "circom_amd" / "compiler.py", ROOT / "circom_amd" / "opcodes.py",
                                                                     ROOT / "circom_amd" / "field.py"]
     for f in files:

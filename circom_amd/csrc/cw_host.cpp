@@ -2408,7 +2408,9 @@ extern "C" int cw_run(cw_batch *b) {
     }
     if (b->fp_fn) {
         // the variant's rows as straight-line code: one workgroup of n_strands waves per `lanes` instances, as cwk_eval
-        struct { void *V; uint32_t *status; uint32_t Bp, batch, lanes, pad; FpParams P; uint32_t pad2; } args;
+        struct { void *V; uint32_t *status; uint32_t Bp, batch, lanes, pad; FpParams P; uint32_t pad2;
+                 const void *consts, *fcode, *ftab; } args;              // (the tables of tier 2: the D_CALL body loads their addresses)
+        static_assert(sizeof(args) == 272, "argument block of the emitted code (fpjit.KERNARG_BYTES)");
         static_assert(sizeof(FpParams) == 53 * 4, "the emitted code loads 53 parameter words");
         memset(&args, 0, sizeof(args));
         args.V = b->d_V;
@@ -2417,6 +2419,9 @@ extern "C" int cw_run(cw_batch *b) {
         args.batch = b->batch;
         args.lanes = b->lanes;
         args.P = c->P;
+        args.consts = b->d_consts;
+        args.fcode = b->d_fncode;
+        args.ftab = b->d_fntab;
         HIPCHK(hipMemsetAsync(b->d_status + b->Bp, 0xFF, (size_t)b->Bp * 4, b->stream));    // "no constraint found violated"
         size_t asz = sizeof(args);
         void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};

@@ -38,9 +38,11 @@ from .lower import (D_COPY, D_ADD, D_SUB, D_NEG, D_MMUL, D_INV, D_IDIV, D_MOD, D
 KERNEL_NAME = "cw_fp_jit"
 K_SIG, K_TMP, K_CONST = 0, 1, 2
 LDS_SLOT = 2048
-PARK_BYTES = 8192             # start of the workgroup's LDS: 512 bytes per strand where the caller of a heavy body parks the status
+PARK_STRAND = 768             # per strand: status words | fused-check findings | address of the kernel's argument block
+PARK_BYTES = 16 * PARK_STRAND             # start of the workgroup's LDS: 512 bytes per strand where the caller of a heavy body parks the status
                               # word and the fused check's finding (the body has no register to keep them in)
-KERNARG_BYTES = 32 + 4 * FB.N_PARAM_SGPRS + 4          # V, status, Bp, batch, lanes, pad, FpParams (53 dwords), pad -> 248
+KERNARG_BYTES = 32 + 4 * FB.N_PARAM_SGPRS + 4 + 24     # V, status, Bp, batch, lanes, pad, FpParams (53 dwords), pad, then the
+assert KERNARG_BYTES == 8 * (FB.KA_FTAB + 1)           # tables of tier 2: constants, function bytecode, function table -> 272
 VMCNT_MAX, LGKM_MAX = 63, 15
 
 # owned registers (fpjit_bodies.py keeps them live through every body)
@@ -77,7 +79,7 @@ def _limbs29(v):
 
 class _Step:
     """one call of a body (or an inline operation) with what it needs from memory and what it leaves there"""
-    __slots__ = ("loads", "pre", "body", "inline", "stores", "barrier", "heavy", "value", "sarg", "coef", "check")
+    __slots__ = ("loads", "pre", "body", "inline", "stores", "barrier", "heavy", "value", "sarg", "coef", "check", "call")
 
     def __init__(self):
         self.loads = []        # (which 'A' | 'B', kind, index)  kind: K_SIG / K_TMP (unified slot = index) or K_LDS
@@ -91,6 +93,7 @@ class _Step:
         self.sarg = None       # 64-bit literal for s[36:37]
         self.coef = None       # nine 29-bit limbs for s[24:32]
         self.check = False     # a step of the fused R1CS check (plan_checks)
+        self.call = None       # D_CALL: (function id, first slot of the register window (unified), index of the flat operation)
 
 
 def expand_steps(tape, strand):
@@ -230,7 +233,12 @@ def expand_steps(tape, strand):
                 st.pre.append(("zacc", 12 if op == D_LINSUM else 36))
             st.value = True
         elif op == D_CALL:
-            raise NotImplementedError("run-time functions (D_CALL) stay with the interpreting kernel")
+            # tier 2: the interpreter of csrc/cw_call.hip.h as one (heavy) body; arguments and results live in the call's
+            # register window in the value table, where ordinary rows stored / will load them
+            assert bk == K_TMP
+            st.body = "call_h"
+            st.heavy = True
+            st.call = (a_, ns + b_, seq)
         else:
             raise ValueError("device op %d has no emitted form" % op)
         st.stores = stores
@@ -589,6 +597,12 @@ class _Emitter:
             a("s_waitcnt vmcnt(0)")
         if prio:
             a("s_setprio 3")
+        if any(st.call for st in steps):          # the interpreter body finds its tables through the kernel's argument block
+            a("v_mov_b32 v40, s0")
+            a("v_mov_b32 v41, s1")
+            a("v_mov_b32 v42, 0")
+            a("ds_write_b64 v42, v[40:41] offset:%d" % (park_off + 512))
+            self.lg_issued += 1
         n = len(steps)
 
         def regs_of(k):
@@ -689,11 +703,23 @@ class _Emitter:
                     if name == "inv_h":
                         a("ds_write_b32 v%d, v%d offset:%d" % (V_L16B, V_ST, park_off))
                         self.lg_issued += 1
+                    if st.call:
+                        fn, slot0, seq = st.call
+                        a("v_mov_b32 v42, 0")
+                        a("ds_read_b64 v[40:41], v42 offset:%d" % (park_off + 512))
+                        a("s_waitcnt vmcnt(0) lgkmcnt(0)")               # the window's arguments are stored; the address is here
+                        a("v_readfirstlane_b32 s%d, v40" % (FB.S_COEF + 2))
+                        a("v_readfirstlane_b32 s%d, v41" % (FB.S_COEF + 3))
+                        a("s_mov_b32 s%d, 0x%x" % (FB.S_ARG, fn))
+                        a("s_mov_b32 s%d, 0x%x" % (FB.S_ARG + 1, slot0))
+                        a("s_mov_b32 s%d, 0x%x" % (FB.S_COEF, seq))
+                        self.lg_issued += 1
+                        self.ir.append(("callfn", fn, slot0, seq))
                     if b.scratch:
                         a("s_waitcnt vmcnt(0)")
                     self.call(name)
-                    if b.scratch:
-                        a("s_waitcnt vmcnt(0)")
+                    if b.scratch or st.call:
+                        a("s_waitcnt vmcnt(0) lgkmcnt(0)")
                     self.rederive()
                     a("v_lshrrev_b32 v%d, 2, v%d" % (V_FB, V_L16))
                     if name == "inv_h":
@@ -727,8 +753,6 @@ def emit(tape, bodies=None, constraints=None) -> FpJitProgram:
     (FlatCircuit.constraints) to fuse their check into the code (plan_checks)"""
     if getattr(tape, "kind", 0) != 0:
         raise ValueError("only strand schedules have an emitted form")
-    if tape.functions and (np.asarray(tape.rows)[:, 0] & 0xFF == D_CALL).any():
-        raise NotImplementedError("run-time functions (D_CALL) stay with the interpreting kernel")
     S = tape.n_strands
     assert S & (S - 1) == 0 and 1 <= S <= 16
     if bodies is None:
@@ -804,7 +828,7 @@ def emit(tape, bodies=None, constraints=None) -> FpJitProgram:
     prog.ir = []
     for s_ in range(S):
         prio = S > 1 and cost[s_] > 0 and cost[s_] >= 0.8 * heaviest
-        prog.ir.append(em.strand_code(s_, all_steps[s_], prio, park + 512 * s_))
+        prog.ir.append(em.strand_code(s_, all_steps[s_], prio, park + PARK_STRAND * s_))
     # the bodies this schedule calls
     scratch = 0
     for name in sorted(em.used_bodies):
@@ -817,25 +841,30 @@ def emit(tape, bodies=None, constraints=None) -> FpJitProgram:
         scratch = max(scratch, b.scratch_bytes)
     L.append(".Lend:\n.size %s, .Lend-%s\n" % (KERNEL_NAME, KERNEL_NAME))
     lds_bytes = PARK_BYTES + n_lds * LDS_SLOT
+    n_vgpr, n_agpr = FB.N_VGPR, 0
+    if "call_h" in em.used_bodies:                # the interpreter body was compiled for one wave per workgroup: up to 256 + 256
+        assert S == 1, "schedules with run-time functions are single-strand"
+        n_vgpr, n_agpr = 256, (bodies["call_h"].n_agpr + 7) // 8 * 8
     L.append(".rodata\n.p2align 6\n.amdhsa_kernel %s\n"
              "  .amdhsa_user_sgpr_kernarg_segment_ptr 1\n  .amdhsa_system_sgpr_workgroup_id_x 1\n  .amdhsa_system_vgpr_workitem_id 0\n"
              "  .amdhsa_next_free_vgpr %d\n  .amdhsa_accum_offset %d\n  .amdhsa_next_free_sgpr 102\n  .amdhsa_reserve_vcc 1\n"
              "  .amdhsa_group_segment_fixed_size %d\n  .amdhsa_private_segment_fixed_size %d\n%s  .amdhsa_kernarg_size %d\n"
-             ".end_amdhsa_kernel\n" % (KERNEL_NAME, FB.N_VGPR, FB.N_VGPR, lds_bytes, scratch,
+             ".end_amdhsa_kernel\n" % (KERNEL_NAME, n_vgpr + n_agpr, n_vgpr, lds_bytes, scratch,
                                        "  .amdhsa_enable_private_segment 1\n" if scratch else "", KERNARG_BYTES))
     L.append(".amdgpu_metadata\n---\namdhsa.version: [1, 2]\namdhsa.kernels:\n  - .name: %s\n    .symbol: %s.kd\n"
              "    .kernarg_segment_size: %d\n    .group_segment_fixed_size: %d\n    .private_segment_fixed_size: %d\n"
-             "    .kernarg_segment_align: 8\n    .wavefront_size: 64\n    .sgpr_count: 108\n    .vgpr_count: %d\n    .agpr_count: 0\n"
+             "    .kernarg_segment_align: 8\n    .wavefront_size: 64\n    .sgpr_count: 108\n    .vgpr_count: %d\n    .agpr_count: %d\n"
              "    .max_flat_workgroup_size: %d\n    .args:\n"
              "      - {.size: 8, .offset: 0, .value_kind: global_buffer, .address_space: global}\n"
              "      - {.size: 8, .offset: 8, .value_kind: global_buffer, .address_space: global}\n"
              "      - {.size: %d, .offset: 16, .value_kind: by_value}\n"
-             "...\n.end_amdgpu_metadata\n" % (KERNEL_NAME, KERNEL_NAME, KERNARG_BYTES, lds_bytes, scratch, FB.N_VGPR, 64 * S,
+             "...\n.end_amdgpu_metadata\n" % (KERNEL_NAME, KERNEL_NAME, KERNARG_BYTES, lds_bytes, scratch, n_vgpr + n_agpr, n_agpr, 64 * S,
                                              KERNARG_BYTES - 16))
     prog.n_strands = S
     prog.asm = "".join(L)
     prog.lds_bytes = lds_bytes
     prog.scratch_bytes = scratch
+    prog.n_vgpr = n_vgpr + n_agpr
     prog.covered = covered
     prog.stats = dict(em.stats, bodies=len(em.used_bodies), n_lds=n_lds, constraints=len(covered), constraints_fused=sum(covered),
                       check_steps=sum(1 for steps in all_steps for st in steps if st.check),

@@ -38,6 +38,7 @@ CACHE_DIR = os.path.join(os.path.dirname(_HERE), "lib")
 A_E, B_E, D_REG, A_O, B_O = 0, 8, 16, 24, 32
 G_REG, ACC_REG = 76, 84
 V_OWNED = list(range(120, 128))
+KA_CONSTS, KA_FCODE, KA_FTAB = 31, 32, 33       # 64-bit words of the emitted kernel's argument block (fpjit.KERNARG_BYTES)
 V_FB = 123                    # smallest index of a constraint the fused R1CS check found violated (0xFFFFFFFF: none)
 S_ARG, S_SEL, S_COEF, S_PARAMS, S_OWNED = 36, 38, 24, 40, 93
 S_RET = 98
@@ -71,6 +72,7 @@ class Body:
         self.n_instr = 0
         self.vwritten = set()
         self.scratch, self.scratch_bytes = False, 0
+        self.n_agpr = 0
 
 
 def _fe(reg, var):
@@ -148,6 +150,16 @@ def _specs():
                       "{ fe qq, rr; if (fe_is_zero(b)) { cw_fail(st, CW_ST_ARITH, (uint32_t)sarg); d = fe_zero(); }\n"
                       "  else { fe_divmod(a, b, &qq, &rr); d = %s; } }" % pick,
                       vin=_fe(A_E, "a") + _fe(B_E, "b"), vout=_fe(D_REG, "d"), sin=[(S_ARG, "sarg")], parity="h"))
+    # D_CALL: a circom function with run-time control flow (tier 2): the interpreter of csrc/cw_call.hip.h as ONE body - the one
+    # that works on memory (the call's register window in the value table, the bytecode, the constant table): sarg = function id
+    # | first window slot << 32, c0 = index of the flat operation, c2:c3 = address of the kernel's argument block (the tables'
+    # addresses are loaded from it: KA_* words), v120 / v121 = the lane's offsets.  Nothing else of the caller survives.
+    S.append(Body("call_h", "{ const uint64_t *ka = (const uint64_t *)(((uint64_t)c3 << 32) | c2);\n"
+                  "  EvalCtx c; c.Vb = (const char *)(((uint64_t)ks95 << 32) | ks94); c.Cb = (const char *)ka[%d];\n"
+                  "  c.fcode = (const uint4 *)ka[%d]; c.ftab = (const uint4 *)ka[%d]; c.Lb = nullptr; c.terms = nullptr; c.tp = 0;\n"
+                  "  c.vlo = vlo_; c.vhi = vhi_; c.lane16 = 0; c.lds_hi = 0; c.slot_stride = ks100;\n"
+                  "  eval_call_body((uint32_t)sarg, (uint64_t)(uint32_t)(sarg >> 32) * (uint64_t)ks100, c0, st, c, P); }" % (KA_CONSTS, KA_FCODE, KA_FTAB),
+                  vin=[(120, "vlo_"), (121, "vhi_")], sin=[(S_ARG, "sarg"), (S_COEF, "c0"), (S_COEF + 2, "c2"), (S_COEF + 3, "c3")], parity="c"))
     # row ends of the accumulating operators (no table operand, no parity)
     S.append(Body("linfin", "g = fe_add(g, acc192_to_fe(pos), P); d = fe_sub(g, acc192_to_fe(neg), P);",
                   vout=_fe(D_REG, "d"), acc="lin", g=True))
@@ -169,12 +181,12 @@ def _specs():
 
 def _source(bodies, fe_slow_inline=True):
     L = ['#include <hip/hip_runtime.h>', '#define CW_FE_SLOW __forceinline__' if fe_slow_inline else '',
-         '#include "%s/cw_rowops.hip.h"' % CSRC]
+         '#define CW_CALL_NATIVE __forceinline__', '#include "%s/cw_call.hip.h"' % CSRC]
     pins = _p_pins()
     for b in bodies:
         # heavy: the emitter re-derives its lane offsets afterwards; inv_h cannot even spare the status word's register
         # (the emitter parks it in LDS around the call)
-        keep_v = set(V_OWNED) if b.parity != "h" else {124}
+        keep_v = set(V_OWNED) if b.parity not in ("h", "c") else {124}
         no_st = b.name == "inv_h"
         if b.parity == "e":
             keep_v |= set(range(A_O, A_O + 16))
@@ -187,7 +199,7 @@ def _source(bodies, fe_slow_inline=True):
         vin = dict(b.vin)
         vout = dict(b.vout)
         st_reg = 124
-        decl = ["fe a = fe_zero(), b = fe_zero(), d = fe_zero(), g = fe_zero();", "uint32_t st; uint64_t sarg = 0, selmask = 0;",
+        decl = ["fe a = fe_zero(), b = fe_zero(), d = fe_zero(), g = fe_zero();", "uint32_t st, vlo_ = 0, vhi_ = 0; uint64_t sarg = 0, selmask = 0;",
                 "FpParams P;", "uint32_t c0, c1, c2, c3, c4, c5, c6, c7, c8;"]
         outs, ins = [], []         # of the BEGIN / END statements
         # vector inputs
@@ -264,7 +276,8 @@ def _source(bodies, fe_slow_inline=True):
         for r, e in pins:                  # the field parameters: defined at the start AND still there at the end
             outs.append('"={s%d}"(%s)' % (r, e))
             ins.append('"{s%d}"(%s)' % (r, e))
-        L.append("__global__ void __launch_bounds__(1024) body_%s(uint32_t *sink) {" % b.name)
+        # (the tier-2 interpreter only runs in single-strand programs: one wave per workgroup, up to 512 registers)
+        L.append("__global__ void __launch_bounds__(%d) body_%s(uint32_t *sink) {" % (64 if b.parity == "c" else 1024, b.name))
         L.extend("  " + x for x in decl)
         L.append('  asm volatile("; BODY_BEGIN %s" : %s);' % (b.name, ", ".join(outs)))
         if S_ARG in sin:
@@ -460,12 +473,14 @@ def parse_bodies(asm: str, bodies):
             allowed_v |= set(range(A_O, A_O + 16))
         elif b.parity == "h":
             allowed_v |= set(range(0, 128))
+        elif b.parity == "c":
+            allowed_v |= set(range(0, 256))
         if not b.keep_d:
             allowed_v |= set(range(D_REG, D_REG + 8))
         if b.acc and not b.g:
             allowed_v -= set(range(G_REG, G_REG + 8))
         allowed_s = set(range(0, 40)) | set(range(S_PARAMS, S_PARAMS + N_PARAM_SGPRS))
-        if b.parity == "m":         # the last call of a strand reads the emitter's registers (instance number, status array)
+        if b.parity in ("m", "c"):  # the strand's last call / the interpreter read the emitter's registers (status array, table)
             allowed_v |= set(V_OWNED)
             allowed_s |= set(range(S_OWNED, 102))
         out = []
@@ -473,8 +488,10 @@ def parse_bodies(asm: str, bodies):
             if t == RET_MARK:
                 out.append(t)
                 continue
-            if b.parity == "h" and _SCRATCH.match(t):
+            if b.parity in ("h", "c") and _SCRATCH.match(t):
                 b.scratch = True          # a heavy body may spill: the emitted kernel then owns a private segment
+            elif b.parity == "c" and re.match(r"^\s*(global_|flat_|s_load|s_waitcnt)", t):
+                pass                      # the tier-2 interpreter works on memory
             elif b.parity == "m" and re.match(r"^\s*(global_|flat_|s_waitcnt)", t):
                 pass
             elif _MEM.match(t):
@@ -493,6 +510,8 @@ def parse_bodies(asm: str, bodies):
             b.vwritten |= uv
             out.append(t)
         b.text = out
+        b.n_agpr = max([int(x) + 1 for t in out for x in re.findall(r"\ba(\d+)\b", t)] +
+                       [int(y) + 1 for t in out for _, y in re.findall(r"\ba\[(\d+):(\d+)\]", t)] + [0])
         # registers that hold something defined when the body is entered: its inputs and everything kept through it
         dv = {r for r, _ in b.vin} | set(V_OWNED) | {124}
         dv |= set(range(A_E, A_E + 16)) | set(range(A_O, A_O + 16))     # operand sets: own inputs, or kept for the other parity
@@ -521,7 +540,7 @@ def parse_bodies(asm: str, bodies):
     if missing:
         raise RuntimeError("bodies not found in the compiler output: %s" % missing)
     for b in bodies:
-        if b.parity != "h":
+        if b.parity not in ("h", "c"):
             assert not getattr(b, "scratch", False)
     return bodies
 

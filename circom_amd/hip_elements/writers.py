@@ -204,7 +204,7 @@ def write_tape(path, tapes, bittape=None, jit=None, fpjit=()):
                 for i, cbit in enumerate(fp.covered):
                     if cbit:
                         cov[i >> 5] |= np.uint32(1 << (i & 31))
-                f.write(struct.pack("<8I", fp.n_strands, len(fp.code), fp.lds_bytes, fp.scratch_bytes, 128, len(cov), 0, 0))
+                f.write(struct.pack("<8I", fp.n_strands, len(fp.code), fp.lds_bytes, fp.scratch_bytes, getattr(fp, "n_vgpr", 128), len(cov), 0, 0))
                 f.write(cov.tobytes())
                 f.write(fp.code + b"\0" * (-len(fp.code) % 4))
 

@@ -31,7 +31,7 @@ CLI_PATH = _HERE / "bin" / "cw_witness"     # process-level drop-in (csrc/cw_cli
 def build_library(force: bool = False) -> Path:
     """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     srcs = [_HERE / "csrc" / n for n in ("cw_kernels.hip", "cw_bits.hip", "cw64.hip", "cw_host.cpp", "cw_cli.cpp", "cw_kernels.h",
-                                         "cw_tape.h", "cw_r1cs_plan.h", "cw_bits_host.h", "fp256.hip.h", "cw_rowops.hip.h")]
+                                         "cw_tape.h", "cw_r1cs_plan.h", "cw_bits_host.h", "fp256.hip.h", "cw_rowops.hip.h", "cw_call.hip.h")]
     outs = [LIB_PATH, CLI_PATH]
     if not force and all(o.exists() and all(o.stat().st_mtime >= s.stat().st_mtime for s in srcs) for o in outs):
         return LIB_PATH

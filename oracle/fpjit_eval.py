@@ -32,7 +32,8 @@ class _Pending:
 POISON = object()
 
 
-def replay(prog_ir, body_info, q: int, n_signals: int, n_tslots: int, n_lds: int, inputs: dict, rbits: int = 261, one: int = 1):
+def replay(prog_ir, body_info, q: int, n_signals: int, n_tslots: int, n_lds: int, inputs: dict, rbits: int = 261, one: int = 1,
+           functions=(), consts=()):
     """prog_ir: per strand list of IR tuples; body_info: name -> (set of VGPRs the body may touch, parity)."""
     f = Field(q)
     rinv = pow(1 << rbits, -1, q)
@@ -115,10 +116,25 @@ def replay(prog_ir, body_info, q: int, n_signals: int, n_tslots: int, n_lds: int
                 return "full" if ins[1] else "light"
             elif k == "heavy_done":
                 pass
+            elif k == "callfn":
+                # D_CALL: the interpreter body reads and writes the call's register window in the value table (tape_eval's
+                # restatement of the bytecode / of the native closed forms)
+                from . import tape_eval as TE
+                fn, slot0, seq = ins[1], ins[2], ins[3]
+                n_regs, fcode, native = functions[fn]
+                if native is not None and TE.USE_NATIVE:
+                    from circom_amd.circuits.bigint_func import native_eval
+                    kind, n_, k_, modulus = native
+                    kname = {1: "mod_inv", 2: "ec_add", 3: "ec_double"}[kind]
+                    n_args = {1: k_, 2: 4 * k_, 3: 2 * k_}[kind]
+                    for j2, v2 in enumerate(native_eval(kname, n_, k_, modulus, [mem[slot0 + x] for x in range(n_args)])):
+                        mem[slot0 + n_args + j2] = v2
+                elif not TE.run_dev_function(f, fcode, mem, slot0, consts):
+                    fail(2, seq)
             elif k == "call":
                 name = ins[1]
                 touched, parity = body_info[name]
-                base = name.rsplit("_", 1)[0] if parity in ("e", "o", "h") else name
+                base = name.rsplit("_", 1)[0] if parity in ("e", "o", "h", "c") else name
                 ra, rb = (A_O, B_O) if parity == "o" else (A_E, B_E)
                 what = "body " + name
                 # a load in flight to a register the body may write would land in the middle of its arithmetic
@@ -189,7 +205,7 @@ def replay(prog_ir, body_info, q: int, n_signals: int, n_tslots: int, n_lds: int
                         reg[G_REG] = g
                     else:
                         res = g
-                elif base == "publish":
+                elif base in ("publish", "call"):
                     pass
                 elif base in ("chkeq", "chkmul", "chkmul2", "chkadd", "chkdot"):
                     if base == "chkeq":
@@ -256,7 +272,8 @@ def replay_tape(tape, prog, bodies, inputs: dict):
     if mont:
         inputs = {k: v % q * R % q for k, v in inputs.items()}
     info = {n: (set(b.vwritten), b.parity) for n, b in bodies.items()}
-    sig, st = replay(prog.ir, info, q, tape.n_signals, tape.n_tslots, tape.n_lds, inputs, tape.rbits, R if mont else 1)
+    sig, st = replay(prog.ir, info, q, tape.n_signals, tape.n_tslots, tape.n_lds, inputs, tape.rbits, R if mont else 1,
+                     getattr(tape, "functions", ()), tape.consts)
     if mont:
         rinv = pow(R, -1, q)
         sig = [v * rinv % q for v in sig]

@@ -301,3 +301,29 @@ def test_gpu_fused_check_names_the_first_violated_row(tmp_path, monkeypatch, mon
     monkeypatch.setenv("CW_R1CS_AUDIT", "1")
     (w2, s2, f2), _ = _run_both(cp, rows, monkeypatch, 4, None, True)
     assert (s2 == s1).all() and (f2 == f1).all()
+
+
+@pytest.mark.gpu
+def test_gpu_emitted_code_runs_circom_functions(tmp_path, monkeypatch):
+    """tier 2 inside the emitted code: BigMultModP's witness comes from long_div / short_div (value-dependent loops and
+    branches, run-time indexed arrays) - the interpreter of csrc/cw_call.hip.h as one body of the straight-line program;
+    every instance takes its own path through the functions"""
+    from circom_amd.circuits.bigint import BigMultModP
+    n, k = 32, 3
+    cp = compile_program(Program(BigMultModP(n, k), prime="bls12381"), str(tmp_path), "bigmultmodp", sym=False, fpjit=True)
+    assert cp.fpjit and all(p.n_strands == 1 for p in cp.fpjit)
+    rnd = random.Random(12)
+    rows = []
+    for _ in range(500):
+        p = rnd.randrange(1 << (n * k - 1), 1 << (n * k))
+        a, b = rnd.randrange(p), rnd.randrange(p)
+        rows.append([(x >> (n * i)) & ((1 << n) - 1) for x in (a, b, p) for i in range(k)])
+    for fused in (False, True):
+        (w1, s1, f1), (w0, s0, f0) = _run_both(cp, rows, monkeypatch, 1, None, fused)
+        assert (s1 == 0).all() and (s0 == 0).all() and (f1 == f0).all()
+        assert w1.tobytes() == w0.tobytes()
+    fc = cp.flat
+    for i in (0, 17, 499):
+        sig, failed = eval_flat(fc.fp.q, fc.n_signals, fc.n_temps, fc.constants, fc.code,
+                                {fc.main_input_start + j: v for j, v in enumerate(rows[i])}, functions=fc.functions)
+        assert failed is None and w1[i].tobytes() == b"".join(v.to_bytes(32, "little") for v in sig)
