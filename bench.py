@@ -41,14 +41,16 @@ LONE_WAVE_CLK_PER_INST = 4.1       # ONE wave issues at most one instruction of 
 BITS_VALU_PER_VROW = 10            # cw_bits_eval_kernel<64>, from the disassembly: 3 operand offsets, 2 mask expansions, 1 result
 BITS_INSTS_PER_VROW = 15           # offset, 4 v_bitop3  + 3 ds_read_b64, 1 ds_write_b64, 1 s_waitcnt
 JIT_BATCH = 1 << 21                # the emitted bit-plane code runs one wave per 2 048 instances: 1 024 waves = one per SIMD
-DEFAULT_BATCH = {"bigmultmodp": 8192, "ecdsa_verify": 1024, "sha256_2048": JIT_BATCH, "sha256_512": 4096, "poseidon2": 65536, "semaphore20": 8192, "semaphore20p": 8192}
+DEFAULT_BATCH = {"bigmultmodp": 8192, "ecdsa_verify": 1024, "sha256_2048": JIT_BATCH, "sha256_512": 4096, "poseidon2": 65536, "semaphore20": 8192, "semaphore20p": 8192,
+                 "semaphore20w": 8192}
 
 
 def _semaphore_shape(name: str):
-    """semaphore<levels>[p]: p = the witness hints walk the scalar multiplications on a projective ladder"""
+    """semaphore<levels>[p|w]: p = the witness hints walk the scalar multiplications on a projective ladder; w = circomlib's
+    structure (windowed EscalarMulFix, Montgomery-form EscalarMulAny: circuits/escalarmul.py)"""
     tail = name[len("semaphore"):]
-    proj = tail.endswith("p")
-    return int(tail.rstrip("p") or 20), proj
+    proj = "window" if tail.endswith("w") else tail.endswith("p")
+    return int(tail.rstrip("pw") or 20), proj
 
 
 def make_program(name: str):

@@ -11,6 +11,7 @@ Expected outputs are pinned against plain-integer arithmetic (eddsa_host.py) in 
 from ..frontend.dsl import template
 from .basic import IsZero, Num2Bits
 from .babyjub import BabyAdd, BabyDbl, ScalarMulBits, ScalarMulBitsProj, BASE8
+from .escalarmul import EscalarMulAny, EscalarMulFix
 from .merkle import MerkleTreeInclusionProof
 from .poseidon import Poseidon
 
@@ -82,7 +83,10 @@ def ForceEqualIfEnabled(c):
 
 @template
 def EdDSAPoseidonVerifier(c, proj=False):
-    """proj: compute the two scalar multiplications' witnesses on a projective ladder (babyjub.ScalarMulBitsProj)"""
+    """proj = False: bit-serial affine ladders (babyjub.ScalarMulBits); True: the same relation with the witnesses walked on a
+    projective ladder (ScalarMulBitsProj); "window": circomlib's structure - EscalarMulAny (Montgomery-form ladder in
+    segments) for h * 8A and EscalarMulFix (3-bit windows) for S * B8 (circuits/escalarmul.py)"""
+    window = proj == "window"
     Mul = ScalarMulBitsProj if proj else ScalarMulBits
     enabled = c.input("enabled")
     Ax = c.input("Ax"); Ay = c.input("Ay")
@@ -114,26 +118,33 @@ def EdDSAPoseidonVerifier(c, proj=False):
     c.set(az["in"], d3["xout"])
     c.enforce(az["out"] * enabled, 0)                     # A is not in the small subgroup
 
-    mul_any = c.component("mulAny", Mul(254))
+    mul_any = c.component("mulAny", EscalarMulAny(254) if window else Mul(254))
     for i in range(254):
         c.set(mul_any["e"][i], h2b["out"][i])
-    c.set(mul_any["px"], d3["xout"]); c.set(mul_any["py"], d3["yout"])
+    if window:
+        c.set(mul_any["p"][0], d3["xout"]); c.set(mul_any["p"][1], d3["yout"])
+        any_out = (mul_any["out"][0], mul_any["out"][1])
+    else:
+        c.set(mul_any["px"], d3["xout"]); c.set(mul_any["py"], d3["yout"])
+        any_out = (mul_any["outx"], mul_any["outy"])
 
     # right = R8 + right2
     add1 = c.component("add1", BabyAdd())
     c.set(add1["x1"], R8x); c.set(add1["y1"], R8y)
-    c.set(add1["x2"], mul_any["outx"]); c.set(add1["y2"], mul_any["outy"])
+    c.set(add1["x2"], any_out[0]); c.set(add1["y2"], any_out[1])
 
     # left = S * B8
-    mul_fix = c.component("mulFix", Mul(253))
+    mul_fix = c.component("mulFix", EscalarMulFix(253, BASE8) if window else Mul(253))
     for i in range(253):
         c.set(mul_fix["e"][i], snum["out"][i])
-    c.set(mul_fix["px"], BASE8[0]); c.set(mul_fix["py"], BASE8[1])
+    if not window:
+        c.set(mul_fix["px"], BASE8[0]); c.set(mul_fix["py"], BASE8[1])
+    fix_out = (mul_fix["out"][0], mul_fix["out"][1]) if window else (mul_fix["outx"], mul_fix["outy"])
 
     ex = c.component("eqCheckX", ForceEqualIfEnabled())
-    c.set(ex["enabled"], enabled); c.set(ex["in"][0], mul_fix["outx"]); c.set(ex["in"][1], add1["xout"])
+    c.set(ex["enabled"], enabled); c.set(ex["in"][0], fix_out[0]); c.set(ex["in"][1], add1["xout"])
     ey = c.component("eqCheckY", ForceEqualIfEnabled())
-    c.set(ey["enabled"], enabled); c.set(ey["in"][0], mul_fix["outy"]); c.set(ey["in"][1], add1["yout"])
+    c.set(ey["enabled"], enabled); c.set(ey["in"][0], fix_out[1]); c.set(ey["in"][1], add1["yout"])
 
 
 @template

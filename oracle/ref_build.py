@@ -265,8 +265,10 @@ def build_default_circuits():
     for name, prog in (("multiplier2", Program(Multiplier2())), ("poseidon2", Program(Poseidon(2))),
                        ("bigmultmodp", Program(BigMultModP(32, 3), prime="bls12381")),
                        ("sha256_512", Program(Sha256(512))), ("semaphore20", Program(SemaphoreStyle(20))),
-                       ("semaphore20p", Program(SemaphoreStyle(20, True))), ("sha256_2048", Program(Sha256(2048)))):
-        cp = compile_program(prog, d, name, sym=False)
+                       ("semaphore20p", Program(SemaphoreStyle(20, True))), ("semaphore20w", Program(SemaphoreStyle(20, "window"))),
+                       ("sha256_2048", Program(Sha256(2048)))):
+        # (only the flat circuit and the .dat are needed here: one strand variant, no emitted code)
+        cp = compile_program(prog, d, name, sym=False, strands=(1,), jit=False, fpjit=False)
         build_circuit(cp)
 
 
