@@ -139,7 +139,12 @@ def emit_fpjit(tapes, fc, fpjit="auto", fuse_check=True):
         # of a second pass over HBM), not where a small batch waits on its dependency chain
         for cons in ((None, fc.constraints) if (fuse_check and fc.constraints) else (None,)):
             try:
-                p = FJ.emit(t, constraints=cons)
+                # (beyond ~300 K rows the text goes to a file as it is produced: tens of millions of lines)
+                spool = None
+                if len(t.rows) > 300_000:
+                    import tempfile
+                    spool = os.path.join(tempfile.mkdtemp(prefix="cw_fpjit_"), "k.s")
+                p = FJ.emit(t, constraints=cons, spool_path=spool)
             except NotImplementedError:
                 if fpjit is True:
                     raise

@@ -471,11 +471,46 @@ def plan_checks(tape, constraints, all_steps):
 _EXP = os.environ.get("CW_FPJIT_EXP", "")
 
 
+class _Spool(list):
+    """the program text; a circuit of millions of rows does not fit a Python list of lines (the ECDSA verifier: ~80 M lines),
+    so beyond a threshold the lines go to a file as they are produced (the last few stay for the emitter's look-behind)"""
+
+    def __init__(self, path=None, limit=2_000_000):
+        super().__init__()
+        self.path, self.limit, self.f = path, limit, None
+
+    def append(self, x):
+        list.append(self, x)
+        if self.path and len(self) >= self.limit:
+            self._flush(keep=4)
+
+    def _flush(self, keep):
+        if self.f is None:
+            self.f = open(self.path, "w")
+        n = len(self) - keep
+        self.f.write("".join(self[:n]))
+        del self[:n]
+
+    def finish(self):
+        """the whole text as a string, or None when it went to `path`"""
+        if self.f is None:
+            return "".join(self)
+        self._flush(keep=0)
+        self.f.close()
+        return None
+
+
+class _NoIR(list):
+    def append(self, x):
+        pass
+
+
 class _Emitter:
-    def __init__(self, tape, bodies):
+    def __init__(self, tape, bodies, spool_path=None):
         self.tape, self.bodies = tape, bodies
-        self.L = []
-        self.ir = []
+        self.L = _Spool(spool_path)
+        self.keep_ir = spool_path is None
+        self.ir = [] if self.keep_ir else _NoIR()
         self.used_bodies = set()
         self.n_call = 0
         self.vm_issued = 0          # vector-memory instructions issued so far by this strand (loads and stores, in order)
@@ -586,7 +621,7 @@ class _Emitter:
         self.strand = strand
         self.vm_issued = self.lg_issued = 0
         self.acc_zero = 0
-        self.ir = []
+        self.ir = [] if self.keep_ir else _NoIR()
         a = self.add
         self.L.append("fj_strand_%d:\n" % strand)
         debug = bool(os.environ.get("CW_FPJIT_DEBUG"))
@@ -748,16 +783,17 @@ class _Emitter:
         return self.ir
 
 
-def emit(tape, bodies=None, constraints=None) -> FpJitProgram:
+def emit(tape, bodies=None, constraints=None, spool_path=None) -> FpJitProgram:
     """the emitted kernel of one schedule variant (strand schedule, kind 0); constraints = the circuit's R1CS rows
-    (FlatCircuit.constraints) to fuse their check into the code (plan_checks)"""
+    (FlatCircuit.constraints) to fuse their check into the code (plan_checks); spool_path: write the text to this file as it
+    is produced instead of keeping it (and the replay IR) in memory - for circuits of millions of rows"""
     if getattr(tape, "kind", 0) != 0:
         raise ValueError("only strand schedules have an emitted form")
     S = tape.n_strands
     assert S & (S - 1) == 0 and 1 <= S <= 16
     if bodies is None:
         bodies = FB.build_bodies()
-    em = _Emitter(tape, bodies)
+    em = _Emitter(tape, bodies, spool_path)
     all_steps = [expand_steps(tape, s) for s in range(S)]
     covered = plan_checks(tape, constraints, all_steps) if constraints else []
     # strands that carry >= 80 % of the heaviest strand's work run at raised priority (as cw_eval_kernel's prio_mask)
@@ -861,7 +897,8 @@ def emit(tape, bodies=None, constraints=None) -> FpJitProgram:
              "...\n.end_amdgpu_metadata\n" % (KERNEL_NAME, KERNEL_NAME, KERNARG_BYTES, lds_bytes, scratch, n_vgpr + n_agpr, n_agpr, 64 * S,
                                              KERNARG_BYTES - 16))
     prog.n_strands = S
-    prog.asm = "".join(L)
+    prog.asm = L.finish()
+    prog.asm_path = spool_path if prog.asm is None else None
     prog.lds_bytes = lds_bytes
     prog.scratch_bytes = scratch
     prog.n_vgpr = n_vgpr + n_agpr
@@ -873,6 +910,16 @@ def emit(tape, bodies=None, constraints=None) -> FpJitProgram:
 
 
 def assemble(prog: FpJitProgram) -> bytes:
-    from .bitjit import assemble as _asm
+    from .bitjit import assemble as _asm, _llvm_bin
+    if getattr(prog, "asm_path", None):           # spooled text: assemble the file where it lies
+        import subprocess
+        llvm, s = _llvm_bin(), prog.asm_path
+        subprocess.run([os.path.join(llvm, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", s, "-o", s + ".o"],
+                       check=True, capture_output=True)
+        subprocess.run([os.path.join(llvm, "ld.lld"), "-shared", s + ".o", "-o", s + ".co"], check=True, capture_output=True)
+        prog.code = open(s + ".co", "rb").read()
+        for f in (s, s + ".o", s + ".co"):
+            os.unlink(f)
+        return prog.code
     prog.code = _asm(prog.asm)
     return prog.code
