@@ -89,6 +89,21 @@ def test_replay_of_emitted_ir_poseidon(bodies, mont, S):
     assert p.stats["glue"] / p.stats["steps"] < 40
 
 
+def test_spooled_text_assembles_to_the_same_code_object(bodies, tmp_path, monkeypatch):
+    """programs of millions of rows write their text to a file as it is produced (the ECDSA verifier: ~80 M lines); forced
+    here with a tiny threshold: the code object is the one the in-memory path assembles"""
+    fc = flatten(Program(Poseidon(2)))
+    t = lower(fc, n_strands=4, mont=True)
+    a = fpjit.emit(t, bodies, fc.constraints)
+    fpjit.assemble(a)
+    orig = fpjit._Spool.__init__
+    monkeypatch.setattr(fpjit._Spool, "__init__", lambda self, path=None, limit=0: orig(self, path, 997))
+    b = fpjit.emit(t, bodies, fc.constraints, spool_path=str(tmp_path / "k.s"))
+    assert b.asm is None and b.asm_path and b.ir == [[], [], [], []]
+    fpjit.assemble(b)
+    assert b.code == a.code and not (tmp_path / "k.s").exists()
+
+
 def test_replay_catches_a_wait_that_is_too_weak(bodies):
     fc = flatten(Program(Poseidon(2)))
     t = lower(fc, n_strands=1, mont=True)
