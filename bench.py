@@ -151,7 +151,10 @@ def get_compiled(name: str, batch: int, cache_root: str, rank: int, dist):
         jp = compiler.emit_jit(compiler.lower_bitplane.net, fc) if bittape is not None else None     # the same network as emitted code
         compiler.lower_bitplane.net = None
         # arithmetic circuits: the rows of every strand variant as emitted code as well (hip_elements/fpjit.py)
-        fps = compiler.emit_fpjit(tapes, fc, False if bittape is not None else "auto")
+        # (config 5's verifier is beyond the automatic size limit - 3.3 M rows, a 590 MB code object, a quarter of an hour
+        # of lowering - and worth it: 2.5x the interpreter; its batches never reach the fused check's regime)
+        big = name == "ecdsa_verify"
+        fps = compiler.emit_fpjit(tapes, fc, False if bittape is not None else (True if big else "auto"), fuse_check=not big)
         writers.write_tape(p(".cwt"), tapes, bittape, jp, fps)
         json.dump(jp.stats if jp is not None else {}, open(p(".jit.json"), "w"))
         json.dump([dict(fp_.stats, n_strands=fp_.n_strands, code_bytes=len(fp_.code)) for fp_ in fps], open(p(".fpjit.json"), "w"))
