@@ -12,6 +12,15 @@ if str(ROOT) not in sys.path:
 REF_ROOT = Path(os.environ.get("CIRCOM_REF", "/root/reference"))
 
 
+# The CPU suite does not assemble code objects that only a GPU can run: compile_program's default ("auto") emits the rows of
+# every strand variant of every arithmetic circuit as gfx950 code (6 programs per circuit, ~150 compilations in this suite =
+# a quarter of an hour of assembling).  Without a GPU device node the default is switched off here; tests/test_fpjit.py builds
+# and replays the emitted code explicitly (hip_elements.fpjit.emit), the loader-robustness test re-enables it for its two
+# circuits, and on a GPU box nothing is switched off: every arithmetic circuit of the GPU suite runs through the emitted code.
+if not os.path.exists("/dev/kfd"):
+    os.environ.setdefault("CW_FPJIT", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with gpurun)")
     config.addinivalue_line("markers", "slow: takes more than ~20 s on CPU")

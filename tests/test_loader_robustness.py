@@ -82,10 +82,12 @@ from circom_amd.frontend.dsl import Program
 from circom_amd.circuits.poseidon import Poseidon
 from circom_amd.circuits.basic import Num2Bits
 d = %r
+os.environ.pop("CW_FPJIT", None)          # (the .cwt under test carries the emitted-code section as well)
 rng = random.Random(5)
 n_ok = n_bad = 0
 for name, prog, js in (("n2b", Num2Bits(8), '{"in": "5"}'), ("pos", Poseidon(2), '{"inputs": ["5", "6"]}')):
-    cp = compile_program(Program(prog), d, name, sym=False)
+    cp = compile_program(Program(prog), d, name, sym=False, fpjit=True)
+    assert cp.fpjit and b"FPJT" in open(cp.tape_path, "rb").read()
     files = {k: open(p, "rb").read() for k, p in (("cwt", cp.tape_path), ("dat", cp.dat_path), ("r1cs", cp.r1cs_path))}
     for it in range(700):
         which = rng.choice(["cwt", "cwt", "dat", "r1cs"])
