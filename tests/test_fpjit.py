@@ -342,3 +342,29 @@ def test_gpu_emitted_code_runs_circom_functions(tmp_path, monkeypatch):
         sig, failed = eval_flat(fc.fp.q, fc.n_signals, fc.n_temps, fc.constants, fc.code,
                                 {fc.main_input_start + j: v for j, v in enumerate(rows[i])}, functions=fc.functions)
         assert failed is None and w1[i].tobytes() == b"".join(v.to_bytes(32, "little") for v in sig)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_circuits_through_the_emitted_ir(bodies, seed):
+    """the random circuits of tests/test_schedule_fuzz.py (long small-coefficient sums, field-sized coefficients, bit
+    extraction, batched inversions, selects, wide fan-out, sub-components firing late) through the emitter: the replay of the
+    emitted IR - rows and fused check, with poisoned registers and counted waits - reproduces the flat semantics for 1, 4
+    and 16 strands, canonical and Montgomery-form tables, and no check step fires on a valid witness"""
+    from test_schedule_fuzz import _random_template, Q
+    from oracle import fpjit_eval
+    rng = random.Random(2000 + seed)
+    fc = flatten(Program(_random_template(seed, 40 + 26 * (seed % 11))))
+    for S, mont in ((1, False), (4, True), (16, False), (16, True)):
+        t = lower(fc, n_strands=S, mont=mont)
+        p = fpjit.emit(t, bodies, fc.constraints)
+        for trial in range(3):
+            row = ([rng.randrange(Q) for _ in range(4)] if trial == 0 else [rng.randrange(4) for _ in range(4)] if trial == 1
+                   else [Q - 1 - rng.randrange(3), 0, rng.randrange(Q), 1])
+            inp = {fc.main_input_start + k: v for k, v in enumerate(row)}
+            sig, failed = eval_flat(Q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp)
+            assert failed is None
+            got, st = replay_tape(t, p, bodies, inp)
+            assert st == 0 and got == sig, (seed, S, mont, trial)
+            assert fpjit_eval.replay.first_bad is None, (seed, S, mont, trial, fpjit_eval.replay.first_bad)
+    if seed < 3:
+        fpjit.assemble(p)                          # the text is valid gfx950 assembly
