@@ -519,10 +519,13 @@ def main():
         n_fl = auto_in_flight(batch.bitmode, B, batch.lanes)
     n_fl = max(1, n_fl)
     if not batch.bitmode:
-        # value tables of a million-signal circuit are tens of GB each (ECDSA verifier x 1 024: 85 GB): as many batches in
-        # flight as fit in ~2/3 of the HBM
+        # value tables of a million-signal circuit are tens of GB each (ECDSA verifier x 1 024: 81 GB): as many batches in
+        # flight as fit the HBM
         est = 32.0 * circ.n_signals * ((B + 255) // 256 * 256) * 1.1
-        n_fl = max(1, min(n_fl, int(190e9 // max(est, 1.0))))
+        # (a batch that does not get its table anymore is caught below: fewer in flight.  ECDSA verifier x 1 024: three tables
+        # of 81 GB fit the 288 GB; measured 174 witnesses/s with one batch, 268 with two, 389 with three in flight)
+        cap = float(os.environ.get("CW_BENCH_HBM_CAP", "0")) or 0.95 * torch.cuda.get_device_properties(dev).total_memory
+        n_fl = max(1, min(n_fl, int(cap // max(est, 1.0))))
     streams, batches = [stream], [batch]
     for _ in range(n_fl - 1):
         try:
