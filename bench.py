@@ -120,6 +120,10 @@ def get_compiled(name: str, batch: int, cache_root: str, rank: int, dist):
     from circom_amd.hip_elements.lower import lower
     fp = artefact_fingerprint()
     strands = compiler.strands_for(batch)
+    if (batch + 63) // 64 >= 1024 and 1 not in strands:
+        # a batch that fills every SIMD with one strand: the runtime prefers the single-strand emitted program with the fused
+        # check (cw_batch_create) - lower that variant as well (bit-level circuits lower one strand anyway)
+        strands = (1,) + tuple(strands)
     if os.environ.get("CW_BENCH_STRANDS"):          # experiments: lower (only) this strand count
         strands = (int(os.environ["CW_BENCH_STRANDS"]),)
     d = os.path.join(cache_root, "%s_s%s_b%s_m%s_%s" % (name, "-".join(map(str, strands)), os.environ.get("CW_BITS", "1"),
@@ -276,6 +280,15 @@ def auto_in_flight(bitmode: bool, B: int, lanes: int) -> int:
     # 62.8 K in one process and 119 K in another, 8 gave 118.9 K and 118.5 K)
     wgs = (B + lanes - 1) // max(1, lanes)
     return max(2, min(8, 512 // max(1, wgs)))
+
+
+def in_flight_for(batch) -> int:
+    """... and a single-strand emitted program on a chip-filling batch (one wave per SIMD per batch) wants a third batch in
+    flight: Poseidon(2) x 65 536: 2 -> 59.2 M, 3 -> 62.1 M, 4 -> 58.4 M witnesses/s (tools/fpjit_poseidon_inflight.sh)"""
+    n = auto_in_flight(batch.bitmode, batch.n, batch.lanes)
+    if not batch.bitmode and getattr(batch, "emitted", False) and batch.strands == 1 and (batch.n + 63) // 64 >= 1024:
+        n = max(n, 3)
+    return n
 
 
 def parity_check(cp, circ, batch, h_in, workload: str, n_sample: int = 4, digest_bits=None):
@@ -516,7 +529,7 @@ def main():
     # 8 -> 113.2 K witnesses/s.
     n_fl = args.in_flight
     if n_fl <= 0:
-        n_fl = auto_in_flight(batch.bitmode, B, batch.lanes)
+        n_fl = in_flight_for(batch)
     n_fl = max(1, n_fl)
     if not batch.bitmode:
         # value tables of a million-signal circuit are tens of GB each (ECDSA verifier x 1 024: 81 GB): as many batches in

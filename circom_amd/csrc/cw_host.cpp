@@ -1524,6 +1524,23 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
         if (!best)
             for (auto &v : c->variants)
                 if (!v.kind && (!best || v.n_strands < best->n_strands)) best = &v;
+        // A batch that fills every SIMD with ONE strand (>= 1 024 groups) and whose R1CS check can ride in the rows runs the
+        // single-strand emitted program with the check fused in: no barriers, no hand-offs, no waiting for the slowest strand -
+        // a lone wave per SIMD issues at one instruction per ~4.5 clocks, and the next batch in flight (another wave per SIMD)
+        // fills the gaps.  Poseidon(2) x 65 536, rows + check: 59-62 M witnesses/s against 52 M with four strands
+        // (tools/fpjit_poseidon_strands.sh, fpjit_poseidon_inflight.sh).  CW_STRANDS / CW_FP_JIT = 0 / CW_FP_FUSED = 0 override.
+        {
+            const char *fj0 = getenv("CW_FP_JIT"), *ff0 = getenv("CW_FP_FUSED");
+            if (best && best->n_strands > 1 && !getenv("CW_STRANDS") && !(fj0 && atoi(fj0) == 0) && !(ff0 && atoi(ff0) == 0) &&
+                c->n_constraints && groups >= 1024) {
+                bool have_code = false;
+                for (auto &fj : c->fpjit)
+                    have_code |= fj.n_strands == 1 && !fj.covered.empty() && fj.covered.size() == (c->n_constraints + 31) / 32;
+                if (have_code)
+                    for (auto &v : c->variants)
+                        if (!v.kind && v.n_strands == 1) best = &v;
+            }
+        }
         if (const char *e = best ? getenv("CW_STRANDS") : nullptr) {
             uint32_t want = (uint32_t)std::max(1, atoi(e));
             for (auto &v : c->variants) {
@@ -1572,7 +1589,7 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
             // Poseidon(2) x 65 536, 4 waves per SIMD: 1.64 vs 2.07 ms; Semaphore-style x 8 192, 2 per SIMD: 21.1 vs 18.8 ms; its
             // 1 024-instance shard: 18.0 vs 14.3 ms).  CW_FP_FUSED = 0 / 1 overrides.
             const uint64_t waves = ((uint64_t)batch + lanes - 1) / lanes * best->n_strands;
-            bool want_fused = waves >= 4096 && c->n_constraints != 0;
+            bool want_fused = (waves >= 4096 || (best->n_strands == 1 && waves >= 1024)) && c->n_constraints != 0;
             if (const char *e2 = getenv("CW_FP_FUSED")) want_fused = atoi(e2) != 0;
             FpJit *pick = nullptr;
             for (auto &fj : c->fpjit) {
