@@ -229,6 +229,7 @@ struct Variant {               // one lowering of the schedule for a given stran
 struct FpJit {
     uint32_t n_strands = 1, lds_bytes = 0, scratch_bytes = 0, n_vgpr = 0;
     std::vector<uint32_t> covered;                                   // bitmap over the .r1cs rows: checked by the code itself
+    uint32_t n_covered = 0;
     std::vector<uint8_t> code;                                       // ELF code object (hipModuleLoadData)
     std::map<int, std::pair<hipModule_t, hipFunction_t>> mod;        // device -> loaded module
 };
@@ -995,6 +996,7 @@ static int load_tape(cw_circuit *c, const char *path) {
             fj.scratch_bytes = ph[3];
             fj.n_vgpr = ph[4];
             fj.covered = std::move(cov);
+            for (uint32_t w : fj.covered) fj.n_covered += (uint32_t)__builtin_popcount(w);
             fj.code.assign(b.data() + off, b.data() + off + ph[1]);
             off += (size_t)padded;
             c->fpjit.push_back(std::move(fj));
@@ -1535,7 +1537,8 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
                 c->n_constraints && groups >= 1024) {
                 bool have_code = false;
                 for (auto &fj : c->fpjit)
-                    have_code |= fj.n_strands == 1 && !fj.covered.empty() && fj.covered.size() == (c->n_constraints + 31) / 32;
+                    have_code |= fj.n_strands == 1 && !fj.covered.empty() && fj.covered.size() == (c->n_constraints + 31) / 32 &&
+                                 (uint64_t)fj.n_covered * 2 >= c->n_constraints;
                 if (have_code)
                     for (auto &v : c->variants)
                         if (!v.kind && v.n_strands == 1) best = &v;
@@ -1596,6 +1599,8 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
                 if (fj.n_strands != best->n_strands) continue;
                 const bool fused = !fj.covered.empty();
                 if (fused && !(c->n_constraints && fj.covered.size() == (c->n_constraints + 31) / 32)) continue;   // another .r1cs
+                if (fused && !getenv("CW_FP_FUSED") && (uint64_t)fj.n_covered * 2 < c->n_constraints)
+                    continue;                       // the code covers a minority of the rows: not worth its steps (unless asked for)
                 if (!pick || fused == want_fused) pick = &fj;
             }
             if (pick) {
