@@ -368,3 +368,31 @@ def test_random_circuits_through_the_emitted_ir(bodies, seed):
             assert fpjit_eval.replay.first_bad is None, (seed, S, mont, trial, fpjit_eval.replay.first_bad)
     if seed < 3:
         fpjit.assemble(p)                          # the text is valid gfx950 assembly
+
+
+def test_replay_of_emitted_ir_with_circom_functions(bodies):
+    """tier 2 in the emitted code (CPU side): D_CALL steps of BigMultModP's long_div / short_div replayed through the IR -
+    the call reads its arguments from and leaves its results in the register window of the value table - and an integer
+    division by zero inside a function reaches the status word with the flat operation's index"""
+    from circom_amd.circuits.bigint import BigMultModP
+    from oracle import fpjit_eval
+    n, k = 16, 2
+    fc = flatten(Program(BigMultModP(n, k), prime="bls12381"))
+    t = lower(fc, n_strands=1)
+    p = fpjit.emit(t, bodies, fc.constraints)
+    assert any(ins[0] == "callfn" for ins in p.ir[0]) and p.n_vgpr > 256          # the interpreter body's register budget
+    fpjit.assemble(p)
+    rnd = random.Random(4)
+    for it in range(6):
+        pp = rnd.randrange(1 << (n * k - 1), 1 << (n * k))
+        a, b = rnd.randrange(pp), rnd.randrange(pp)
+        vals = [(x >> (n * i)) & ((1 << n) - 1) for x in (a, b, pp) for i in range(k)]
+        inp = {fc.main_input_start + j: v for j, v in enumerate(vals)}
+        want, st0 = eval_tape(t, inp)
+        got, st1 = replay_tape(t, p, bodies, inp)
+        assert st0 == 0 and (got, st1) == (want, st0) and fpjit_eval.replay.first_bad is None
+    # p = 0: long_div divides by zero inside the function
+    inp = {fc.main_input_start + j: v for j, v in enumerate([5, 0, 7, 0, 0, 0])}
+    want, st0 = eval_tape(t, inp)
+    got, st1 = replay_tape(t, p, bodies, inp)
+    assert st0 != 0 and st1 == st0
