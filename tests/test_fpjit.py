@@ -396,3 +396,47 @@ def test_replay_of_emitted_ir_with_circom_functions(bodies):
     want, st0 = eval_tape(t, inp)
     got, st1 = replay_tape(t, p, bodies, inp)
     assert st0 != 0 and st1 == st0
+
+
+def test_replay_of_emitted_ir_library_circuits(bodies):
+    """further shapes through the emitter and the IR replay: batched inversions with zero denominators (the reference's
+    inv(0) = 0 inside a Montgomery-trick batch), a Merkle path of switchers and Poseidons, the affine BabyJubjub ladder
+    (one inversion per step ON the chain: the heavy body with its parked registers, hundreds of times)"""
+    from test_more_circuits import ThreeDivs, _merkle_case
+    from circom_amd.circuits.merkle import MerkleTreeInclusionProof
+    from circom_amd.circuits.babyjub import ScalarMulBits, BASE8
+    from oracle import fpjit_eval
+    q = PRIMES["bn128"]
+    rng = random.Random(17)
+    # (1) zero denominators in a batch of inversions
+    fc = flatten(Program(ThreeDivs()))
+    for S, mont in ((1, False), (4, True)):
+        t = lower(fc, n_strands=S, mont=mont)
+        p = fpjit.emit(t, bodies, fc.constraints)
+        for zeros in range(8):
+            row = [rng.randrange(q) for _ in range(3)] + [5 if (zeros >> i) & 1 else rng.randrange(q) for i in range(3)]
+            inp = {fc.main_input_start + k: v for k, v in enumerate(row)}
+            want, st0 = eval_tape(t, inp)
+            got, st1 = replay_tape(t, p, bodies, inp)
+            assert (got, st1) == (want, st0), (S, mont, zeros)
+    # (2) Merkle path of depth 6
+    fc = flatten(Program(MerkleTreeInclusionProof(6)))
+    leaf, idx, sib, root = _merkle_case(q, 6, rng)
+    row = [leaf] + idx + sib
+    inp = {fc.main_input_start + k: v for k, v in enumerate(row)}
+    for S in (1, 16):
+        t = lower(fc, n_strands=S, mont=True)
+        p = fpjit.emit(t, bodies, fc.constraints)
+        got, st = replay_tape(t, p, bodies, inp)
+        assert st == 0 and got[1] == root and fpjit_eval.replay.first_bad is None
+        assert sum(p.covered) > 0.8 * len(fc.constraints)          # (the switchers' `s * (1 - s) = 0` has a two-term factor)
+    # (3) affine ladder, 12 bits
+    fc = flatten(Program(ScalarMulBits(12)))
+    k = 0xB2D
+    row = [(k >> i) & 1 for i in range(12)] + [BASE8[0], BASE8[1]]
+    inp = {fc.main_input_start + j: v for j, v in enumerate(row)}
+    t = lower(fc, n_strands=4, mont=True)
+    p = fpjit.emit(t, bodies, fc.constraints)
+    want, st0 = eval_tape(t, inp)
+    got, st1 = replay_tape(t, p, bodies, inp)
+    assert st0 == 0 and (got, st1) == (want, st0) and fpjit_eval.replay.first_bad is None
