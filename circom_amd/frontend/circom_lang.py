@@ -85,10 +85,10 @@ def tokenize(src: Source):
     i, n = 0, len(text)
     while i < n:
         m = _TOKEN.match(text, i)
+        if text.startswith("/*", i) and (m is None or m.lastgroup != "bc"):
+            ln, col = src.line_col(i)
+            raise CircomSyntaxError("unterminated /* */ comment", src.name, ln, col)
         if m is None:
-            if text.startswith("/*", i):
-                ln, col = src.line_col(i)
-                raise CircomSyntaxError("unterminated /* */ comment", src.name, ln, col)
             ln, col = src.line_col(i)
             raise CircomSyntaxError("illegal character %r" % text[i], src.name, ln, col)
         k = m.lastgroup
@@ -187,7 +187,9 @@ class Parser:
                     parts.append(n[1])
                     self.p += 1
                     if k < 2:
-                        self.take_op(".")
+                        if not self.at_op("."):
+                            self.err("unrecognized version")      # ReportCode::UnrecognizedVersion
+                        self.p += 1
                 version = tuple(parts)
             elif t[0] == "id" and t[1] == "custom_templates":
                 self.p += 1

@@ -1,0 +1,426 @@
+"""circom SOURCE TEXT through the whole CPU side ("which signals and constraints exist and their ids"):
+
+  * the circuits of circom_amd/circuits/circomlib/*.circom + tests/circom/*.circom, parsed and executed by
+    frontend/circom_lang.py + circom_exec.py, against
+      - the documentation's own listings (constraints-json.md, sym.md, Multiplier2 3 * 11 = 33),
+      - the GOLDEN `.wtns` digests of the reference C++ runtime (tests/golden/reference_wtns.json, reference_logs.json),
+      - the same circuits authored against the Python eDSL (identical flat circuits: signals, constraints, operations);
+  * the language semantics the executor restates from constraint_generation/src/execute.rs: scopes, arrays by value,
+    functions at compile time / inlined on signals / compiled to tier-2 bytecode, run-time conditions if-converted,
+    anonymous components and tuples, buses, tags, and the errors the reference reports.
+"""
+import hashlib
+import json
+import os
+
+import pytest
+
+from circom_amd.frontend.circom_exec import program_from_file, program_from_text
+from circom_amd.frontend.dsl import CircuitError, Program
+from circom_amd.frontend.flatten import flatten
+from circom_amd.hip_elements import writers
+from circom_amd.hip_elements.writers import wtns_bytes
+from oracle.field import PRIMES
+from oracle.tape_eval import eval_flat, check_r1cs
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(ROOT, "circom_amd", "circuits", "circomlib")
+SRC = os.path.join(HERE, "circom")
+GOLD = json.load(open(os.path.join(HERE, "golden", "reference_wtns.json")))["cases"]
+Q = PRIMES["bn128"]
+
+
+@pytest.fixture(scope="module")
+def libs(tmp_path_factory):
+    """the library path: the checked-in circom texts + a directory with the Poseidon constants rendered for bn128"""
+    from circom_amd.circuits.poseidon_constants import circom_text
+    d = tmp_path_factory.mktemp("poseidon_constants")
+    (d / "poseidon_constants.circom").write_text(circom_text(Q))
+    return [LIB, str(d)]
+
+
+def run(fc, ins):
+    inp = {fc.main_input_start + k: int(v) % fc.fp.q for k, v in enumerate(ins)}
+    return eval_flat(fc.fp.q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp, functions=fc.functions)
+
+
+def from_text(src, ins, prime="bn128"):
+    fc = flatten(program_from_text(src, prime))
+    sig, failed = run(fc, ins)
+    return fc, sig, failed
+
+
+def same_flat(a, b):
+    assert a.n_signals == b.n_signals and a.inputs == b.inputs and a.n_outputs == b.n_outputs
+    assert a.constraints == b.constraints
+    assert a.constants == b.constants
+    for k in a.code:
+        assert len(a.code[k]) == len(b.code[k]) and (a.code[k] == b.code[k]).all(), k
+
+
+# ---- the documentation's listings ---------------------------------------------------------------------------------------------
+DOCS_BASIC = """
+pragma circom 2.0.0;
+
+template Internal() {
+   signal input in[2];
+   signal output out;
+   out <== in[0]*in[1];
+}
+
+template Main() {
+   signal input in[2];
+   signal output out;
+   component c = Internal ();
+   c.in[0] <== in[0];
+   c.in[1] <== in[1]+2*in[0]+1;
+   c.out ==> out;
+}
+
+component main = Main();
+"""
+
+
+def test_docs_basic_circom_constraints_and_sym(tmp_path):
+    # mkdocs/docs/circom-language/formats/constraints-json.md:31-47 (source), :84-93 (--O0 listing); sym.md:67-74
+    from tests.test_frontend_golden import GOLDEN_O0, GOLDEN_SYM_O0
+    fc = flatten(program_from_text(DOCS_BASIC))
+    got = [[{str(k): str(v) for k, v in part.items()} for part in con] for con in fc.constraints]
+    assert got == GOLDEN_O0
+    writers.write_sym(tmp_path / "b.sym", fc)
+    assert (tmp_path / "b.sym").read_text() == GOLDEN_SYM_O0
+
+
+def test_multiplier2_from_the_getting_started_page():
+    # mkdocs/docs/getting-started/writing-circuits.md:19-37, computing-the-witness.md: {"a": "3", "b": "11"} -> 33
+    fc = flatten(program_from_file(os.path.join(SRC, "multiplier2.circom")))
+    sig, failed = run(fc, [3, 11])
+    assert failed is None and sig == [1, 33, 3, 11]
+    assert fc.inputs == [("a", 2, 1), ("b", 3, 1)]
+
+
+# ---- golden .wtns of the reference runtime ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["multiplier2", "num2bits16", "iszero", "opzoo", "mixed_array", "poseidon2", "sha256_512"])
+def test_circom_text_reproduces_reference_runtime_goldens(name, libs):
+    fc = flatten(program_from_file(os.path.join(SRC, name + ".circom"), libs))
+    for vec in GOLD[name]["vectors"]:
+        sig, failed = run(fc, vec["inputs"])
+        assert failed is None
+        b = wtns_bytes(fc.fp.q, sig)
+        assert len(b) == vec["wtns_len"] and hashlib.sha256(b).hexdigest() == vec["wtns_sha256"]
+        assert check_r1cs(fc.fp.q, fc.constraints, sig) is None
+
+
+def test_log_statements_from_text_print_what_the_reference_binary_prints():
+    gold = json.load(open(os.path.join(HERE, "golden", "reference_logs.json")))["cases"]["logdemo"]["vectors"]
+    fc = flatten(program_from_file(os.path.join(SRC, "logdemo.circom")))
+    for v in gold:
+        inp = {fc.main_input_start + k: int(v["inputs"][n]) for k, n in enumerate(("a", "b"))}
+        lines = []
+        sig, failed = eval_flat(fc.fp.q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp, fc.functions, lines, fc.log_strings)
+        assert "".join(lines) == v["log"] and (failed is None) == v["ok"]
+        if v["ok"]:
+            assert hashlib.sha256(wtns_bytes(fc.fp.q, sig)).hexdigest() == v["wtns_sha256"]
+
+
+# ---- the same circuits from the eDSL ------------------------------------------------------------------------------------------------
+def test_text_and_edsl_give_identical_flat_circuits(libs):
+    from circom_amd.circuits.basic import BasicMain, LogDemo, MixedArray
+    from circom_amd.circuits.poseidon import Poseidon
+    from circom_amd.circuits.sha256 import Sha256
+    from circom_amd.circuits.stdlib import SortPair
+    same_flat(flatten(program_from_text(DOCS_BASIC)), flatten(Program(BasicMain())))
+    same_flat(flatten(program_from_file(os.path.join(SRC, "sortpair.circom"), libs)), flatten(Program(SortPair(16))))
+    same_flat(flatten(program_from_file(os.path.join(SRC, "poseidon2.circom"), libs)), flatten(Program(Poseidon(2))))
+    same_flat(flatten(program_from_file(os.path.join(SRC, "mixed_array.circom"), libs)),
+              flatten(Program(MixedArray(((2, 3), (1, 5), (3, 2), (2, 3))))))
+    a, b = flatten(program_from_file(os.path.join(SRC, "logdemo.circom"))), flatten(Program(LogDemo()))
+    same_flat(a, b)
+    assert a.log_strings == b.log_strings
+    # 204 329 signals, 204 576 constraints, 414 256 operations; the witness-side function sha256compression(hin, inp) is
+    # called on SIGNALS and unrolls into the rows of the calling component
+    a, b = flatten(program_from_file(os.path.join(SRC, "sha256_64.circom"), libs)), flatten(Program(Sha256(64)))
+    same_flat(a, b)
+    assert a.n_signals == 204329 and len(a.constraints) == 204576
+
+
+def test_r1cs_sym_dat_bytes_are_identical_to_the_edsl_build(tmp_path, libs):
+    from circom_amd.circuits.stdlib import SortPair
+    a = flatten(program_from_file(os.path.join(SRC, "sortpair.circom"), libs))
+    b = flatten(Program(SortPair(16)))
+    for k, fc in enumerate((a, b)):
+        writers.write_r1cs(tmp_path / ("%d.r1cs" % k), fc)
+        writers.write_sym(tmp_path / ("%d.sym" % k), fc)
+        writers.write_dat(tmp_path / ("%d.dat" % k), fc)
+    for ext in ("r1cs", "sym", "dat"):
+        assert (tmp_path / ("0." + ext)).read_bytes() == (tmp_path / ("1." + ext)).read_bytes()
+
+
+# ---- functions ------------------------------------------------------------------------------------------------------------------------
+def test_function_with_run_time_control_flow_becomes_tier2_bytecode(libs):
+    """long_div of bigint_func.circom: comparisons of limbs are run-time branches, the loops over limbs unroll; the circuit
+    BigMultModP(32, 3) on the BLS12-381 prime computes the same witnesses as the eDSL circuit whose function was written
+    against the bytecode builder by hand"""
+    import random
+    from circom_amd.circuits.bigint import BigMultModP
+    a = flatten(program_from_file(os.path.join(SRC, "bigmultmodp.circom"), libs, prime="bls12381"))
+    b = flatten(Program(BigMultModP(32, 3), prime="bls12381"))
+    assert a.n_signals == b.n_signals and a.constraints == b.constraints
+    assert [f["name"] for f in a.functions] == ["long_div$0"] and a.functions[0]["n_args"] == 9 and a.functions[0]["n_ret"] == 8
+    rng = random.Random(1)
+    for t in range(12):
+        p = [rng.getrandbits(32) for _ in range(3)]
+        p[2] |= (1 << 31) if t % 2 else 1                  # normalised and barely normalised divisors
+        if t == 5:
+            p = [0xFFFFFFFF] * 3
+        x = [rng.getrandbits(32) for _ in range(3)]
+        y = [rng.getrandbits(32) for _ in range(3)] if t != 7 else [0xFFFFFFFF] * 3
+        sa, fa = run(a, x + y + p)
+        sb, fb = run(b, x + y + p)
+        assert fa is None and fb is None and sa == sb
+        n = lambda l: sum(v << (32 * i) for i, v in enumerate(l))
+        assert n(sa[1:4]) == n(x) * n(y) % n(p)
+        assert check_r1cs(a.fp.q, a.constraints, sa) is None
+
+
+RT_SRC = """
+pragma circom 2.0.0;
+// run-time loops, a run-time index, a run-time while whose trip count depends on the value, early returns
+function isqrt(x) {
+    var r = 0;
+    while ((r + 1) * (r + 1) <= x) { r++; }
+    return r;
+}
+function collatz(x) {
+    var n = 0;
+    while (x != 1) {
+        if (x % 2 == 0) { x = x \\ 2; } else { x = 3 * x + 1; }
+        n++;
+    }
+    return n;
+}
+function pick(t, i) {
+    var tab[4] = [t, t * t, 7, t + 100];
+    if (i >= 4) { return 0; }
+    return tab[i];
+}
+function hist(a, b, c) {
+    var h[3];
+    var v[3] = [a, b, c];
+    for (var k = 0; k < 3; k++) { h[v[k] % 3] += 1; }
+    return h;
+}
+template T() {
+    signal input x; signal input i;
+    signal output o[7];
+    o[0] <-- isqrt(x);
+    o[1] <-- collatz(x + 1);
+    o[2] <-- pick(x, i);
+    var h[3] = hist(x, x + i, 5);
+    o[3] <-- h[0]; o[4] <-- h[1]; o[5] <-- h[2];
+    o[6] <-- isqrt(49);
+}
+component main = T();
+"""
+
+
+def test_run_time_loops_indices_and_early_returns():
+    fc = flatten(program_from_text(RT_SRC))
+    assert sorted(f["name"] for f in fc.functions) == ["collatz$0", "hist$0", "isqrt$0", "pick$0"]     # isqrt(49) folded
+
+    def collatz(x):
+        n = 0
+        while x != 1:
+            x = x // 2 if x % 2 == 0 else 3 * x + 1
+            n += 1
+        return n
+    import math
+    for x, i in ((10, 1), (0, 0), (99, 3), (26, 9), (1000, 2)):
+        sig, failed = run(fc, [x, i])
+        assert failed is None
+        tab = [x, x * x, 7, x + 100]
+        h = [0, 0, 0]
+        for v in (x, x + i, 5):
+            h[v % 3] += 1
+        assert sig[1:8] == [math.isqrt(x), collatz(x + 1), tab[i] if i < 4 else 0] + h + [7]
+
+
+def test_function_on_signals_without_run_time_control_is_inlined():
+    src = """
+    function dot(a, b, n) { var s = 0; for (var i = 0; i < n; i++) { s += a[i] * b[i]; } return s; }
+    function twice(v) { var r[2]; r[0] = v[0] + v[0]; r[1] = v[1] + v[1]; return r; }
+    template T() { signal input a[2]; signal input b[2]; signal output o; signal output p[2];
+        o <== dot(a, [3, 4], 2) + dot([1, 2], [3, 4], 2);      // linear in the signals: accepted by <==
+        p <== twice(twice(b)); }
+    component main = T();"""
+    fc, sig, failed = from_text(src, [5, 6, 7, 8])
+    assert failed is None and fc.functions == [] and sig[1:4] == [5 * 3 + 6 * 4 + 11, 28, 32]
+    assert check_r1cs(fc.fp.q, fc.constraints, sig) is None
+
+
+def test_compile_time_functions_recursion_and_arrays_by_value():
+    src = """
+    function fact(n) { if (n == 0) { return 1; } return n * fact(n - 1); }
+    function bump(a) { a[0] = 99; return a[0] + a[1]; }
+    template T(n) { signal input x; signal output o;
+        var a[2] = [1, 2];
+        var s = bump(a);                 // arrays are passed by value: a stays [1, 2]
+        var m[2][2] = [[1, 2], [3, 4]];
+        var row[2] = m[1];
+        row[0] = 50;
+        o <== x * (fact(n) + s + a[0] + m[1][0] + row[0]); }
+    component main = T(5);"""
+    fc, sig, failed = from_text(src, [2])
+    assert sig[1] == 2 * (120 + 101 + 1 + 3 + 50)
+
+
+# ---- run-time conditions in template bodies ------------------------------------------------------------------------------------------
+def test_if_on_a_signal_is_if_converted():
+    src = """
+    template T() { signal input a; signal output o; signal output p;
+        var x = 3; var y[2] = [1, 2];
+        if (a > 10) { x = a * 2; y[1] = a; o <-- a + 1; } else { x = x + 1; o <-- 7; }
+        p <-- x + y[1]; }
+    component main = T();"""
+    for a in (5, 20):
+        fc, sig, failed = from_text(src, [a])
+        assert sig[1:3] == ([7, 6] if a <= 10 else [a + 1, 3 * a])
+    with pytest.raises(CircuitError, match="both branches"):
+        from_text("template T() { signal input a; signal output o; if (a > 1) { o <-- 1; } } component main = T();", [1])
+    with pytest.raises(CircuitError, match="constraint cannot be generated under a run-time condition"):
+        from_text("template T() { signal input a; signal output o; if (a > 1) { o <== 1; } else { o <== 2; } } component main = T();", [1])
+    with pytest.raises(CircuitError, match="must be known at compile time"):
+        from_text("template T() { signal input a; signal output o; var i = 0; while (i < a) { i++; } o <-- i; } component main = T();", [1])
+
+
+# ---- sugar: anonymous components, tuples, buses, tags ------------------------------------------------------------------------------------
+def test_anonymous_components_and_tuples():
+    src = """pragma circom 2.1.0;
+template A(n){ signal input a, b; signal output c; c <== a*b + n; }
+template B(){ signal input x; signal output y, z; y <== x + 1; z <== x * x; }
+template Main(){
+  signal input in[3];
+  signal output o1, o2, o3;
+  o1 <== A(5)(in[0], in[1]);
+  (o2, _) <== B()(in[2]);
+  signal t[2];
+  for (var i = 0; i < 2; i++) { t[i] <== A(i)(b <== in[i], a <== in[i+1]); }
+  o3 <== t[0] + t[1];
+}
+component main {public [in]} = Main();
+"""
+    fc, sig, failed = from_text(src, [3, 4, 5])
+    assert failed is None and sig[1:4] == [17, 6, 12 + 21] and fc.n_pub_in == 3
+    # syntax_sugar_remover.rs:453: <template>_<line>_<offset of the expression>; inside a loop an array indexed by the trip
+    names = [(c[0], c[1]) for c in fc.prog.main.children]
+    where = lambda s: "%s_%d_%d" % (s[0], src[:src.index(s)].count("\n") + 1, src.index(s))
+    assert names == [(where("A(i)("), (0,)), (where("A(i)("), (1,)), (where("A(5)("), ()), (where("B()("), ())]
+    assert check_r1cs(fc.fp.q, fc.constraints, sig) is None
+    with pytest.raises(CircuitError, match="must coincide"):
+        from_text("template A(){ signal input a; signal output c; c <== a; } template M(){ signal input x; signal output o; "
+                  "o <== A()(x, x); } component main = M();", [1])
+    with pytest.raises(CircuitError, match="main component cannot contain an anonymous call"):
+        from_text("template A(){ signal input a; signal output c; c <== a; } component main = A()(1);", [1])
+
+
+def test_buses_flatten_in_field_order():
+    src = """pragma circom 2.2.0;
+bus Point(n) { signal x[n]; signal y; }
+bus Seg() { Point(2) a; Point(2) b[2]; signal w; }
+template Len(){ input Seg() s; output signal o; output Point(2) q;
+  o <== s.a.x[0] * s.b[1].y + s.w;
+  q <== s.b[0];
+}
+template Main(){ signal input v[10]; signal output o; signal output r[3];
+  Seg() s;
+  s.a.x[0] <== v[0]; s.a.x[1] <== v[1]; s.a.y <== v[2];
+  for (var i=0;i<2;i++){ s.b[i].x[0] <== v[3+3*i]; s.b[i].x[1] <== v[4+3*i]; s.b[i].y <== v[5+3*i]; }
+  s.w <== v[9];
+  component l = Len();
+  l.s <== s;
+  o <== l.o;
+  r[0] <== l.q.x[0]; r[1] <== l.q.x[1]; r[2] <== l.q.y;
+}
+component main = Main();
+"""
+    fc, sig, failed = from_text(src, list(range(1, 11)))
+    assert failed is None and sig[1] == 1 * 9 + 10 and sig[2:5] == [4, 5, 6]
+    assert check_r1cs(fc.fp.q, fc.constraints, sig) is None
+    with pytest.raises(CircuitError, match="has no field"):
+        from_text("bus P() { signal x; } template M(){ signal input i; signal output o; P() p; p.z <== i; o <== i; } "
+                  "component main = M();", [1])
+
+
+def test_tags_declared_values_are_readable_inside_the_template():
+    src = """template T() { signal input {maxbit} in; signal output {binary} out;
+        in.maxbit = 5;
+        out <== in * (in.maxbit + 1); }
+    component main = T();"""
+    fc, sig, failed = from_text(src, [3])
+    assert sig[1] == 18
+
+
+# ---- scopes and errors ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("src,msg", [
+    ("template T() { signal input a; signal output o; o <== a * a * a; } component main = T();", "Non quadratic"),
+    ("template T() { signal input a; signal output o; o <== a; o <== a; } component main = T();", "assigned twice"),
+    ("template T() { signal input a; signal output o; o <== b; } component main = T();", "undeclared symbol b"),
+    ("template T() { signal input a; signal output o; var a = 1; o <== 1; } component main = T();", "declared twice"),
+    ("template T() { signal input a; signal output o; { var t = 2; } o <== t; } component main = T();", "undeclared symbol t"),
+    ("template T() { signal input a[2]; signal output o; o <== a[2]; } component main = T();", "out of bounds"),
+    ("template T() { signal input a; signal output o; var v[2]; o <== v[a]; } component main = T();", "not known at compile time"),
+    ("template T() { signal input a; signal output o; o <== 1 / 0; } component main = T();", "division by zero"),
+    ("template T() { signal input a; signal output o; assert(1 == 2); o <== a; } component main = T();", "assert failed"),
+    ("template T() { signal input a; signal output o; component c; c.x <== a; o <== a; } component main = T();", "before it is instantiated"),
+    ("template S() { signal input x; signal output y; y <== x; } template T() { signal input a; signal output o; component c = S(); "
+     "o <== c.y; } component main = T();", "never received all its inputs"),
+    ("template T() { signal input a; signal output o; o = a; } component main = T();", "assigned with <== or <--"),
+    ("template T() { signal input a; signal output o; var x; x <== a; o <== a; } component main = T();", "assigned with ="),
+    ("function f(x) { signal s; return x; } template T() { signal input a; signal output o; o <== f(1); } component main = T();",
+     "cannot be declared inside functions"),
+    ("function f(x) { x = 1; } template T() { signal input a; signal output o; o <== f(1); } component main = T();",
+     "ends without a return"),
+    ("template T(n) { signal input a; signal output o; o <== a; } component main = T();", "takes 1 parameters"),
+    ("template T() { signal input a; signal output o; o <== a; } component main {public [o]} = T();", "not an input of main"),
+    ("template T() { signal input a; signal output o; o <== a; }", "No main specified"),
+    ("template custom G() { signal input a; signal output o; o <-- a; } component main = G();", "custom / extern_c"),
+])
+def test_semantic_errors(src, msg):
+    with pytest.raises(CircuitError, match=msg):
+        from_text(src, [1])
+
+
+def test_semantic_errors_carry_the_source_position():
+    with pytest.raises(CircuitError, match=r"^bad\.circom:3:20: undeclared symbol zz"):
+        flatten(program_from_text("template T() {\n signal input a; signal output o;\n          o <==    zz; }\ncomponent main = T();",
+                                  name="bad.circom"))
+
+
+# ---- the driver ---------------------------------------------------------------------------------------------------------------------------
+def test_cli_writes_r1cs_sym_json_and_the_hip_target(tmp_path, libs, capsys):
+    from circom_amd import circom as cli
+    args = [os.path.join(SRC, "sortpair.circom"), "--r1cs", "--sym", "--json", "--hip", "-o", str(tmp_path), "--strands", "1"]
+    for l in libs:
+        args += ["-l", l]
+    assert cli.main(args) == 0
+    out = capsys.readouterr().out
+    assert "template instances: 10" in out and "non-linear constraints: 69" in out and "linear constraints: 76" in out
+    assert "wires: 144" in out and "Everything went okay" in out
+    for f in ("sortpair.r1cs", "sortpair.sym", "sortpair_constraints.json", "sortpair_hip/sortpair.cwt", "sortpair_hip/sortpair.dat"):
+        assert (tmp_path / f).exists(), f
+    cons = json.load(open(tmp_path / "sortpair_constraints.json"))["constraints"]
+    assert len(cons) == 145 and all(len(c) == 3 for c in cons)
+    # the lowered schedule evaluates to the oracle's witness
+    import io
+    from oracle.tape_eval import eval_tape
+    fc = cli.compile_file(os.path.join(SRC, "sortpair.circom"), str(tmp_path / "again"), libs, hip=True, strands=(1,), out=io.StringIO())[0]
+    tape = fc.compiled.tape
+    sig, st = eval_tape(tape, {fc.main_input_start: 40000, fc.main_input_start + 1: 123})
+    want, failed = run(fc, [40000, 123])
+    assert st == 0 and failed is None and sig[:fc.n_signals] == want and want[1:5] == [123, 40000, 0, 40123]
+    # errors: message on stderr, status 1
+    (tmp_path / "bad.circom").write_text("template T() { signal input a }\ncomponent main = T();")
+    assert cli.main([str(tmp_path / "bad.circom")]) == 1
+    assert "missing semicolon" in capsys.readouterr().err
+    assert cli.main([os.path.join(SRC, "multiplier2.circom"), "--O2"]) == 1
