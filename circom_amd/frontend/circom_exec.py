@@ -944,7 +944,7 @@ class World:
             ctx.inst.decl_order = []
             ctx.inst.sig_tags = {}
             ctx.inst.bus_iface = {}
-            ctx._bus_decls = []
+            ctx._bus_decls = ctx.inst._bus_decls = []
             ex.run_block(body[1])
             world.finish_instance(ctx)
         body_fn.__name__ = name
@@ -1098,7 +1098,54 @@ def build_program(archive: Archive, prime="bn128"):
     world.prog = prog
     prog.world = world
     dsl.Program.__init__(prog, spec, public=tuple(public), prime=prime)
+    _qualify_main_bus_inputs(prog)
     return prog
+
+
+def _accesses(dims):
+    """("[i][j]", element index) of every element of an array, row-major (build.rs:324-346 get_accesses)"""
+    if not dims:
+        return [("", 0)]
+    inner = _accesses(dims[1:])
+    stride = 1
+    for d in dims[1:]:
+        stride *= d
+    return [("[%d]%s" % (i, a), i * stride + s) for i in range(dims[0]) for a, s in inner]
+
+
+def _qualified_names(layout, start, prefix, out):
+    """one input-list entry per signal field of a bus, named <prefix>.<field> (build.rs:348-382 get_qualified_names)"""
+    for fname in layout.order:
+        off, dims, sub = layout.fields[fname]
+        name = "%s.%s" % (prefix, fname)
+        if sub is not None:
+            for a, s in _accesses(dims):
+                _qualified_names(sub, start + off + s * sub.size, name + a, out)
+        else:
+            size = 1
+            for d in dims:
+                size *= d
+            out.append((name, start + off, size))
+
+
+def _qualify_main_bus_inputs(prog):
+    """Bus-typed inputs of main enter the input list (the `.dat` hash map) once per signal field under their qualified names
+    - the keys main.cpp's qualify_input makes of nested JSON objects - and once more as the whole bus, behind every other
+    entry (compiler/src/circuit_design/build.rs:300-425 main_input_list)."""
+    m = prog.main
+    buses = {name: bus for name, cat, bus in getattr(m, "_bus_decls", ()) if cat == "i"}
+    if not buses:
+        return
+    out, tail = [], []
+    for name, off, size in m.input_names:
+        if name in buses:
+            layout, dims = buses[name]
+            for a, s in _accesses(dims):
+                _qualified_names(layout, off + s * layout.size, name + a, out)
+            tail.append((name, off, size))
+        else:
+            out.append((name, off, size))
+    m.input_names = out + tail
 
 
 def program_from_file(path, libs=(), prime="bn128"):

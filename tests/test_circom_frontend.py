@@ -424,3 +424,34 @@ def test_cli_writes_r1cs_sym_json_and_the_hip_target(tmp_path, libs, capsys):
     assert cli.main([str(tmp_path / "bad.circom")]) == 1
     assert "missing semicolon" in capsys.readouterr().err
     assert cli.main([os.path.join(SRC, "multiplier2.circom"), "--O2"]) == 1
+
+
+def test_bus_inputs_of_main_enter_the_input_list_qualified(tmp_path):
+    """compiler/src/circuit_design/build.rs:300-425: one entry per signal field (`s.b[1].y`), then the whole bus; the C host
+    qualifies nested JSON objects the way main.cpp:221-241 does and finds them in the `.dat` hash map"""
+    src = """pragma circom 2.2.0;
+bus Point(n) { signal x[n]; signal y; }
+bus Seg() { Point(2) a; Point(2) b[2]; signal w; }
+template Main() { signal input k; input Seg() s; input Point(1) ps[2]; signal output o;
+  o <== s.a.x[1] * s.b[1].y + s.w + ps[1].y + k; }
+component main = Main();
+"""
+    prog = program_from_text(src)
+    fc = flatten(prog)
+    assert fc.inputs == [("k", 2, 1), ("s.a.x", 3, 2), ("s.a.y", 5, 1), ("s.b[0].x", 6, 2), ("s.b[0].y", 8, 1), ("s.b[1].x", 9, 2),
+                         ("s.b[1].y", 11, 1), ("s.w", 12, 1), ("ps[0].x", 13, 1), ("ps[0].y", 14, 1), ("ps[1].x", 15, 1),
+                         ("ps[1].y", 16, 1), ("s", 3, 10), ("ps", 13, 4)]
+    from circom_amd import runtime as rt
+    from circom_amd.compiler import compile_program
+    cp = compile_program(prog, str(tmp_path), "businp", sym=False, strands=(1,))
+    c = rt.Circuit(cp.tape_path, cp.dat_path, None)
+    b = c.batch(2, device=-1)
+    b.set_inputs_json(0, '{"k": 1, "s": {"a": {"x": [2, 3], "y": 4}, "b": [{"x": [5, 6], "y": 7}, {"x": [8, 9], "y": 10}], "w": 11},'
+                         ' "ps": [{"x": [12], "y": 13}, {"x": [14], "y": 15}]}')
+    assert [b.staged_input(0, k) for k in range(15)] == list(range(1, 16))
+    # the flat spelling of the same input: the whole bus as one array
+    b.set_inputs_json(1, '{"k": 1, "s": [2, 3, 4, 5, 6, 7, 8, 9, 10, 11], "ps": [12, 13, 14, 15]}')
+    assert [b.staged_input(1, k) for k in range(15)] == list(range(1, 16))
+    b.close(); c.close()
+    sig, failed = run(fc, list(range(1, 16)))
+    assert failed is None and sig[1] == 3 * 10 + 11 + 15 + 1
