@@ -1,0 +1,128 @@
+"""Circuits compiled from circom SOURCE TEXT against the reference's own runtime and on the GPU.
+
+CPU: oracle/emit_ref_cpp.py prints the flat circuit the text front-end produced in the reference's emission format
+(`<name>.cpp` + `.dat`), the REFERENCE runtime (common/main.cpp + calcwit.cpp + generic/fr.cpp, built by oracle/Makefile
+into oracle/_ref) executes it, and its `.wtns` files equal the oracle's byte for byte - including a function that the
+text front-end compiled to tier-2 bytecode (the reference runs it as C++ control flow over its own Fr_* calls).
+GPU (-m gpu): the same circuits through the C ABI on the device: witness bytes == oracle, R1CS check green."""
+import hashlib
+import os
+import random
+
+import numpy as np
+import pytest
+
+from circom_amd.compiler import compile_program
+from circom_amd.frontend.circom_exec import program_from_file
+from circom_amd.hip_elements.writers import wtns_bytes
+from oracle.tape_eval import eval_flat
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(ROOT, "circom_amd", "circuits", "circomlib")
+SRC = os.path.join(HERE, "circom")
+
+
+@pytest.fixture(scope="module")
+def libs(tmp_path_factory):
+    from circom_amd.circuits.poseidon_constants import circom_text
+    from oracle.field import PRIMES
+    out = [LIB]
+    for prime in ("bn128", "bls12381"):
+        d = tmp_path_factory.mktemp("poseidon_" + prime)
+        (d / "poseidon_constants.circom").write_text(circom_text(PRIMES[prime]))
+        out.append(str(d))
+    return out
+
+
+def _libs_for(libs, prime):
+    return [libs[0], libs[1] if prime == "bn128" else libs[2]]
+
+
+def _oracle(fc, vals):
+    inp = {fc.main_input_start + k: int(v) for k, v in enumerate(vals)}
+    sig, failed = eval_flat(fc.fp.q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp, functions=fc.functions)
+    assert failed is None
+    return sig
+
+
+def _rows(name, fc, n, seed):
+    rng = random.Random(seed)
+    q = fc.fp.q
+    if name == "bigmultmodp":
+        rows = []
+        for t in range(n):
+            p = [rng.getrandbits(32) for _ in range(3)]
+            p[2] |= (1 << 31) if t % 2 else 1
+            rows.append([rng.getrandbits(32) for _ in range(6)] + p)
+        return rows
+    if name == "sortpair":
+        return [[rng.getrandbits(16), rng.getrandbits(16)] for _ in range(n - 1)] + [[777, 777]]
+    return [[rng.randrange(q) for _ in range(fc.n_main_inputs)] for _ in range(n)]
+
+
+@pytest.mark.parametrize("name,prime", [("sortpair", "bn128"), ("poseidon2", "bls12381"), ("bigmultmodp", "bls12381"),
+                                        ("opzoo", "bn128")])
+def test_reference_runtime_executes_circuits_compiled_from_text(name, prime, libs, tmp_path):
+    from oracle import ref_build
+    if not os.path.isdir(os.path.join(os.path.dirname(ref_build.__file__), "_ref", prime)) and not ref_build.REF_ROOT.exists():
+        pytest.skip("no reference build for " + prime)
+    prog = program_from_file(os.path.join(SRC, name + ".circom"), _libs_for(libs, prime), prime=prime)
+    cp = compile_program(prog, str(tmp_path), "txt_%s_%s" % (name, prime), sym=False, strands=(1,), fpjit=False)
+    fc = cp.flat
+    rows = _rows(name, fc, 6, 11)
+    if name == "opzoo":
+        q = fc.fp.q
+        rows += [[3, 11], [0, 0], [q - 1, q - 1], [(q >> 1) + 1, 255], [1 << 200, q - 3]]
+    ref_build.build_circuit(cp)
+    raw = b"".join(int(v).to_bytes(32, "little") for r in rows for v in r)
+    ref_build.run_loop(cp, raw, len(rows), 1, wtns_prefix=str(tmp_path / "w_"))
+    for i, r in enumerate(rows):
+        assert (tmp_path / ("w_%d.wtns" % i)).read_bytes() == wtns_bytes(fc.fp.q, _oracle(fc, r)), (name, i)
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------------------------
+def _gpu_batch(cp, rows):
+    from circom_amd import runtime as rt
+    c = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
+    b = c.batch(len(rows))
+    b.set_inputs(rows)
+    b.run(); b.check_r1cs(); b.sync()
+    return c, b
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,prime,n", [("sortpair", "bn128", 200), ("poseidon2", "bn128", 300), ("bigmultmodp", "bls12381", 96)])
+def test_gpu_runs_circuits_compiled_from_text(name, prime, n, libs, tmp_path):
+    prog = program_from_file(os.path.join(SRC, name + ".circom"), _libs_for(libs, prime), prime=prime)
+    cp = compile_program(prog, str(tmp_path), "txt_" + name, sym=False)
+    fc = cp.flat
+    rows = _rows(name, fc, n, 5)
+    c, b = _gpu_batch(cp, rows)
+    assert (b.status() == 0).all()
+    for i in (0, 1, n // 2, n - 1):
+        assert b.witness(i) == _oracle(fc, rows[i]), (name, i)
+        p = tmp_path / ("g%d.wtns" % i)
+        b.write_wtns(i, p)
+        assert p.read_bytes() == wtns_bytes(fc.fp.q, _oracle(fc, rows[i]))
+    b.close(); c.close()
+
+
+@pytest.mark.gpu
+def test_gpu_sha256_from_text_through_the_bit_plane_engine(libs, tmp_path):
+    """Sha256(64) written in circom (circuits/circomlib/sha256/*.circom): bit-plane program, digests against hashlib, one
+    golden-style full witness against the oracle"""
+    prog = program_from_file(os.path.join(SRC, "sha256_64.circom"), libs[:2])
+    cp = compile_program(prog, str(tmp_path), "txt_sha256_64", sym=False, bits=True)
+    fc = cp.flat
+    rng = np.random.default_rng(9)
+    n = 96
+    msgs = [rng.bytes(8) for _ in range(n)]
+    rows = [[(m[k // 8] >> (7 - k % 8)) & 1 for k in range(64)] for m in msgs]
+    c, b = _gpu_batch(cp, rows)
+    assert b.bitmode and (b.status() == 0).all()
+    for i in (0, 31, 32, 95):
+        digest = hashlib.sha256(msgs[i]).digest()
+        assert [b.signal(i, 1 + k) for k in range(256)] == [(digest[k // 8] >> (7 - k % 8)) & 1 for k in range(256)]
+    assert b.witness(33) == _oracle(fc, rows[33])
+    b.close(); c.close()
