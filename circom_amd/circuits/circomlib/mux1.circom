@@ -7,3 +7,12 @@ template Mux1() {
     signal output out;
     out <== (c[1] - c[0]) * s + c[0];
 }
+
+template MultiMux1(n) {
+    signal input c[n][2];
+    signal input s;
+    signal output out[n];
+    for (var i = 0; i < n; i++) {
+        out[i] <== (c[i][1] - c[i][0]) * s + c[i][0];
+    }
+}

@@ -36,7 +36,7 @@ def libs(tmp_path_factory):
     """the library path: the checked-in circom texts + a directory with the Poseidon constants rendered for bn128"""
     from circom_amd.circuits.poseidon_constants import circom_text
     d = tmp_path_factory.mktemp("poseidon_constants")
-    (d / "poseidon_constants.circom").write_text(circom_text(Q))
+    (d / "poseidon_constants.circom").write_text(circom_text(Q, (3, 4, 6)))
     return [LIB, str(d)]
 
 
@@ -101,7 +101,8 @@ def test_multiplier2_from_the_getting_started_page():
 
 
 # ---- golden .wtns of the reference runtime ---------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["multiplier2", "num2bits16", "iszero", "opzoo", "mixed_array", "poseidon2", "sha256_512"])
+@pytest.mark.parametrize("name", ["multiplier2", "num2bits16", "iszero", "opzoo", "mixed_array", "poseidon2", "sha256_512", "semaphore20",
+                                  "semaphore20p"])
 def test_circom_text_reproduces_reference_runtime_goldens(name, libs):
     fc = flatten(program_from_file(os.path.join(SRC, name + ".circom"), libs))
     for vec in GOLD[name]["vectors"]:
@@ -143,6 +144,12 @@ def test_text_and_edsl_give_identical_flat_circuits(libs):
     a, b = flatten(program_from_file(os.path.join(SRC, "sha256_64.circom"), libs)), flatten(Program(Sha256(64)))
     same_flat(a, b)
     assert a.n_signals == 204329 and len(a.constraints) == 204576
+    # BASELINE config 4's relation (Poseidon Merkle depth 20 + EdDSA-Poseidon), both hint variants: 42 784 / 36 700 signals
+    from circom_amd.circuits.eddsa import SemaphoreStyle
+    for name, proj, n_sig in (("semaphore20", False, 42784), ("semaphore20p", True, 36700)):
+        a, b = flatten(program_from_file(os.path.join(SRC, name + ".circom"), libs)), flatten(Program(SemaphoreStyle(20, proj)))
+        same_flat(a, b)
+        assert a.n_signals == n_sig
 
 
 def test_r1cs_sym_dat_bytes_are_identical_to_the_edsl_build(tmp_path, libs):
