@@ -1,14 +1,17 @@
 /*
     EdDSA-Poseidon signature verification over BabyJubjub and a Semaphore-style membership circuit (BASELINE config 4:
     "Poseidon Merkle depth 20 + EdDSA"), in the shape of circomlib's eddsaposeidon.circom / compconstant.circom /
-    aliascheck.circom; the two scalar multiplications are the bit-serial ladders of babyjub.circom
-    (proj = 0: affine hints, 1: projective hints, same constraints).  The circom text of circom_amd/circuits/eddsa.py.
+    aliascheck.circom; the two scalar multiplications are the bit-serial ladders of babyjub.circom (proj = 0: affine hints,
+    1: projective hints, same constraints) or circomlib's own structure (proj = 2: EscalarMulAny in Montgomery form for
+    h * 8A, windowed EscalarMulFix for S * B8).  The circom text of circom_amd/circuits/eddsa.py.
 */
 pragma circom 2.0.0;
 
 include "bitify.circom";
 include "comparators.circom";
 include "babyjub.circom";
+include "escalarmulany.circom";
+include "escalarmulfix.circom";
 include "merkle.circom";
 include "poseidon.circom";
 
@@ -126,7 +129,9 @@ template EdDSAPoseidonVerifier(proj) {
     isZero.out * enabled === 0;               // A is not in the small subgroup
 
     component mulAny;
-    if (proj == 1) {
+    if (proj == 2) {
+        mulAny = EscalarMulAny(254);
+    } else if (proj == 1) {
         mulAny = ScalarMulBitsProj(254);
     } else {
         mulAny = ScalarMulBits(254);
@@ -134,15 +139,23 @@ template EdDSAPoseidonVerifier(proj) {
     for (i = 0; i < 254; i++) {
         mulAny.e[i] <== h2bits.out[i];
     }
-    mulAny.px <== dbl3.xout;
-    mulAny.py <== dbl3.yout;
+    var anyOut[2];
+    if (proj == 2) {
+        mulAny.p[0] <== dbl3.xout;
+        mulAny.p[1] <== dbl3.yout;
+        anyOut = [mulAny.out[0], mulAny.out[1]];
+    } else {
+        mulAny.px <== dbl3.xout;
+        mulAny.py <== dbl3.yout;
+        anyOut = [mulAny.outx, mulAny.outy];
+    }
 
     // right = R8 + right2
     component add1 = BabyAdd();
     add1.x1 <== R8x;
     add1.y1 <== R8y;
-    add1.x2 <== mulAny.outx;
-    add1.y2 <== mulAny.outy;
+    add1.x2 <== anyOut[0];
+    add1.y2 <== anyOut[1];
 
     // left = S * B8
     var BASE8[2] = [
@@ -150,7 +163,9 @@ template EdDSAPoseidonVerifier(proj) {
         16950150798460657717958625567821834550301663161624707787222815936182638968203
     ];
     component mulFix;
-    if (proj == 1) {
+    if (proj == 2) {
+        mulFix = EscalarMulFix(253, BASE8);
+    } else if (proj == 1) {
         mulFix = ScalarMulBitsProj(253);
     } else {
         mulFix = ScalarMulBits(253);
@@ -158,16 +173,22 @@ template EdDSAPoseidonVerifier(proj) {
     for (i = 0; i < 253; i++) {
         mulFix.e[i] <== snum2bits.out[i];
     }
-    mulFix.px <== BASE8[0];
-    mulFix.py <== BASE8[1];
+    var fixOut[2];
+    if (proj == 2) {
+        fixOut = [mulFix.out[0], mulFix.out[1]];
+    } else {
+        mulFix.px <== BASE8[0];
+        mulFix.py <== BASE8[1];
+        fixOut = [mulFix.outx, mulFix.outy];
+    }
 
     component eqCheckX = ForceEqualIfEnabled();
     eqCheckX.enabled <== enabled;
-    eqCheckX.in[0] <== mulFix.outx;
+    eqCheckX.in[0] <== fixOut[0];
     eqCheckX.in[1] <== add1.xout;
     component eqCheckY = ForceEqualIfEnabled();
     eqCheckY.enabled <== enabled;
-    eqCheckY.in[0] <== mulFix.outy;
+    eqCheckY.in[0] <== fixOut[1];
     eqCheckY.in[1] <== add1.yout;
 }
 

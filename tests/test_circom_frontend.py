@@ -146,7 +146,9 @@ def test_text_and_edsl_give_identical_flat_circuits(libs):
     assert a.n_signals == 204329 and len(a.constraints) == 204576
     # BASELINE config 4's relation (Poseidon Merkle depth 20 + EdDSA-Poseidon), both hint variants: 42 784 / 36 700 signals
     from circom_amd.circuits.eddsa import SemaphoreStyle
-    for name, proj, n_sig in (("semaphore20", False, 42784), ("semaphore20p", True, 36700)):
+    # ... and with circomlib's EdDSA structure (Montgomery-form EscalarMulAny in 148-bit segments, windowed EscalarMulFix behind
+    # MultiMux3 tables): semaphore20w, 46 841 signals
+    for name, proj, n_sig in (("semaphore20", False, 42784), ("semaphore20p", True, 36700), ("semaphore20w", "window", 46841)):
         a, b = flatten(program_from_file(os.path.join(SRC, name + ".circom"), libs)), flatten(Program(SemaphoreStyle(20, proj)))
         same_flat(a, b)
         assert a.n_signals == n_sig
