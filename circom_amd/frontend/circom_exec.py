@@ -612,6 +612,10 @@ class Executor:
             self.fail("signals and components cannot be declared inside functions", pos)
         if self.cond_stack:
             self.fail("signals and components cannot be declared under a run-time condition", pos)
+        if self.loop_stack:
+            # scoping.md: signals, buses and components live in the top-level block of their template or, since 2.1.5, in
+            # `if` blocks with known conditions - never in the block of a loop
+            self.fail("%s Is outside the initial scope" % name, pos)
         if t == "component":
             self.declare(name, CompSlot(name, dims), pos)
             return
@@ -709,6 +713,8 @@ class Executor:
             self.fail("signals are assigned with <== or <--", pos)
         if r[0] == "comp":
             self.fail("a component is initialised with =", pos)
+        if isinstance(slot, (SigSlot, BusSlot)) and slot.kind == "input":
+            self.fail("the input signal %s of the template cannot be assigned inside it" % name, pos)
         dst = r[1]
         self.store_signals(dst, v, op, pos)
 
