@@ -124,3 +124,77 @@ function long_div(n, k, m, a, b) {
     }
     return out;
 }
+
+// a * b on k limbs: 2k limbs (column sums first - k products of 2n bits stay far below the field's size - then one carry pass)
+function prod(n, k, a, b) {
+    var prod_val[2 * k - 1];
+    for (var i = 0; i < 2 * k - 1; i++) {
+        if (i < k) {
+            for (var a_idx = 0; a_idx <= i; a_idx++) {
+                prod_val[i] = prod_val[i] + a[a_idx] * b[i - a_idx];
+            }
+        } else {
+            for (var a_idx = i - k + 1; a_idx < k; a_idx++) {
+                prod_val[i] = prod_val[i] + a[a_idx] * b[i - a_idx];
+            }
+        }
+    }
+    var out[2 * k];
+    var carry = 0;
+    for (var i = 0; i < 2 * k - 1; i++) {
+        var t = prod_val[i] + carry;
+        out[i] = t % (1 << n);
+        carry = t \ (1 << n);
+    }
+    out[2 * k - 1] = carry;
+    return out;
+}
+
+// a * b mod p on k limbs
+function prod_mod(n, k, a, b, p) {
+    var t[2 * k] = prod(n, k, a, b);
+    var qr[2][k + 1] = long_div(n, k, k, t, p);
+    var out[k];
+    for (var i = 0; i < k; i++) {
+        out[i] = qr[1][i];
+    }
+    return out;
+}
+
+// a^e mod p by square-and-multiply from the top bit of e down: n * k trips whose body is two long products and divisions -
+// the compiler leaves the loop to run time after the first trips (its counter then indexes eBits at run time)
+function mod_exp(n, k, a, p, e) {
+    var eBits[n * k];
+    for (var i = 0; i < k; i++) {
+        for (var j = 0; j < n; j++) {
+            eBits[i * n + j] = (e[i] >> j) & 1;
+        }
+    }
+    var out[k];
+    out[0] = 1;
+    for (var i = k * n - 1; i >= 0; i--) {
+        out = prod_mod(n, k, out, out, p);
+        if (eBits[i] == 1) {
+            out = prod_mod(n, k, out, a, p);
+        }
+    }
+    return out;
+}
+
+// a^(p - 2) mod p for a prime p (0 for a = 0)
+function mod_inv(n, k, a, p) {
+    var isZero = 1;
+    for (var i = 0; i < k; i++) {
+        if (a[i] != 0) {
+            isZero = 0;
+        }
+    }
+    var zeros[k];
+    if (isZero == 1) {
+        return zeros;
+    }
+    var two[k];
+    two[0] = 2;
+    var pm2[k] = long_sub(n, k, p, two);
+    return mod_exp(n, k, a, p, pm2);
+}

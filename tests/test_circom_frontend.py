@@ -464,3 +464,34 @@ component main = Main();
     b.close(); c.close()
     sig, failed = run(fc, list(range(1, 16)))
     assert failed is None and sig[1] == 3 * 10 + 11 + 15 + 1
+
+
+def test_modular_inverse_by_fermat_from_text_runs_its_loop_at_run_time(tmp_path):
+    """mod_inv -> mod_exp of circomlib/bigint_func.circom: a KNOWN loop of n * k trips whose body is two long products and
+    divisions.  The compiler unrolls while the body is small and hands the remaining trips to a run-time loop once 4 096
+    instructions have been emitted (circom_rt.UNROLL_BUDGET): the counter becomes a register, `eBits[i]` a run-time indexed
+    block access, `i >= 0` a signed comparison that ends the loop when the counter wraps to p - 1."""
+    import random
+    from circom_amd.frontend.circom_exec import build_program
+    from circom_amd.frontend.circom_lang import parse_program
+    from circom_amd.frontend.rtcode import F_JMP, F_LDX
+    src = """include "bigint_func.circom";
+template ModInv(n, k) { signal input a[k]; signal input p[k]; signal output out[k];
+    var r[k] = mod_inv(n, k, a, p);
+    for (var i = 0; i < k; i++) { out[i] <-- r[i]; } }
+component main = ModInv(%d, %d);
+"""
+    for n, k, p, count in ((16, 2, 2147483647, 6), (64, 4, 2 ** 256 - 2 ** 32 - 977, 2)):
+        f = tmp_path / ("modinv_%d_%d.circom" % (n, k))
+        f.write_text(src % (n, k))
+        fc = flatten(build_program(parse_program(str(f), [LIB]), "bls12381"))
+        fn = fc.functions[0]
+        ops = [c[0] for c in fn["code"]]
+        assert fn["name"] == "mod_inv$0" and F_LDX in ops and F_JMP in ops
+        assert len(ops) < 12000                                  # 2 n k products + divisions unrolled would be > 500 000
+        rng = random.Random(3)
+        lim = lambda x: [(x >> (n * i)) & ((1 << n) - 1) for i in range(k)]
+        for a in ([0, 1, p - 1] + [rng.randrange(1, p) for _ in range(count)])[:count + 1]:
+            sig, failed = run(fc, lim(a) + lim(p))
+            assert failed is None
+            assert sum(v << (n * i) for i, v in enumerate(sig[1:1 + k])) == (pow(a, p - 2, p) if a else 0)
