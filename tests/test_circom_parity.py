@@ -56,13 +56,17 @@ def _rows(name, fc, n, seed):
             p[2] |= (1 << 31) if t % 2 else 1
             rows.append([rng.getrandbits(32) for _ in range(6)] + p)
         return rows
+    if name == "modinv":
+        p = 2147483647                       # 2^31 - 1 on two 16-bit limbs
+        lim = lambda x: [x & 0xFFFF, x >> 16]
+        return [lim(a) + lim(p) for a in [0, 1, p - 1] + [rng.randrange(1, p) for _ in range(max(0, n - 3))]]
     if name == "sortpair":
         return [[rng.getrandbits(16), rng.getrandbits(16)] for _ in range(n - 1)] + [[777, 777]]
     return [[rng.randrange(q) for _ in range(fc.n_main_inputs)] for _ in range(n)]
 
 
 @pytest.mark.parametrize("name,prime", [("sortpair", "bn128"), ("poseidon2", "bls12381"), ("bigmultmodp", "bls12381"),
-                                        ("opzoo", "bn128")])
+                                        ("opzoo", "bn128"), ("modinv", "bls12381")])
 def test_reference_runtime_executes_circuits_compiled_from_text(name, prime, libs, tmp_path):
     from oracle import ref_build
     if not os.path.isdir(os.path.join(os.path.dirname(ref_build.__file__), "_ref", prime)) and not ref_build.REF_ROOT.exists():
