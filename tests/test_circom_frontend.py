@@ -495,3 +495,96 @@ component main = ModInv(%d, %d);
             sig, failed = run(fc, lim(a) + lim(p))
             assert failed is None
             assert sum(v << (n * i) for i, v in enumerate(sig[1:1 + k])) == (pow(a, p - 2, p) if a else 0)
+
+
+# ---- random expressions: printed with the FEWEST parentheses the grammar allows, evaluated through the text front-end ---------------
+_TIERS = [("||",), ("&&",), ("==", "!=", "<", ">", "<=", ">="), ("|",), ("^",), ("&",), ("<<", ">>"), ("+", "-"), ("*", "/", "\\", "%"),
+          ("**",)]
+_TIER_OF = {op: t for t, ops in enumerate(_TIERS) for op in ops}
+_FP = {"+": "add", "-": "sub", "*": "mul", "/": "div", "\\": "idiv", "%": "mod", "**": "pow", "<<": "shl", ">>": "shr", "&": "band",
+       "|": "bor", "^": "bxor", "<": "lt", ">": "gt", "<=": "leq", ">=": "geq", "==": "eq", "!=": "neq", "&&": "land", "||": "lor"}
+
+
+def _rand_tree(rng, depth):
+    if depth == 0 or rng.random() < 0.15:
+        return ("v", rng.choice("abc")) if rng.random() < 0.7 else ("n", rng.choice([0, 1, 2, 3, 7, 255, 1 << 20, (1 << 64) + 5]))
+    r = rng.random()
+    if r < 0.12:
+        return ("u", rng.choice("-!~"), _rand_tree(rng, depth - 1))
+    if r < 0.2:
+        return ("t", _rand_tree(rng, depth - 1), _rand_tree(rng, depth - 1), _rand_tree(rng, depth - 1))
+    op = rng.choice([o for ops in _TIERS for o in ops if o not in ("/", "\\", "%", "**")] + ["**", "\\", "%", "/"])
+    return ("b", op, _rand_tree(rng, depth - 1), _rand_tree(rng, depth - 1))
+
+
+def _show(t, ctx):
+    """ctx = the tier an operand must have at least (0 = any binary expression, 10 = prefix operand, 11 = atom); parentheses
+    only where the grammar needs them: a right operand of the SAME tier (every tier is left associative), a looser operator
+    under a tighter one, anything but an atom under a prefix operator, a switch anywhere but at the top"""
+    k = t[0]
+    if k == "v":
+        return t[1]
+    if k == "n":
+        return str(t[1])
+    if k == "u":
+        s = t[1] + _show(t[2], 11)
+        return s if ctx <= 10 else "(" + s + ")"
+    if k == "t":
+        s = "%s ? %s : %s" % (_show(t[1], 0), _show(t[2], 0), _show(t[3], 0))
+        return s if ctx < 0 else "(" + s + ")"
+    tier = _TIER_OF[t[1]]
+    s = "%s %s %s" % (_show(t[2], tier), t[1], _show(t[3], tier + 1))
+    return s if tier >= ctx else "(" + s + ")"
+
+
+def _value(t, env, fp):
+    k = t[0]
+    if k == "v":
+        return env[t[1]]
+    if k == "n":
+        return t[1] % fp.q
+    if k == "u":
+        return {"-": fp.neg, "!": fp.lnot, "~": fp.bnot}[t[1]](_value(t[2], env, fp))
+    if k == "t":
+        return _value(t[2], env, fp) if _value(t[1], env, fp) else _value(t[3], env, fp)
+    a, b = _value(t[2], env, fp), _value(t[3], env, fp)
+    return getattr(fp, _FP[t[1]])(a, b)
+
+
+def test_random_expressions_printed_with_minimal_parentheses_evaluate_like_their_trees():
+    import random
+    from circom_amd.field import fp_for
+    fp = fp_for("bn128")
+    rng = random.Random(2024)
+    trees = []
+    while len(trees) < 250:
+        t = _rand_tree(rng, 4)
+        if t[0] in ("v", "n"):
+            continue
+        trees.append(t)
+    # `**` on a run-time exponent is masked the same way on both sides (a 254-bit exponent is legal but slow in the oracle)
+    def mask_pow(t):
+        if t[0] == "b":
+            l, r = mask_pow(t[2]), mask_pow(t[3])
+            if t[1] == "**":
+                return ("b", t[1], l, ("b", "&", r, ("n", 1023)))
+            if t[1] in ("\\", "%"):
+                # a divisor in 1 .. 1024: \ and % by zero abort the reference (GMP), set status bits here
+                return ("b", t[1], l, ("b", "+", ("b", "&", r, ("n", 1023)), ("n", 1)))
+            return ("b", t[1], l, r)
+        if t[0] == "u":
+            return ("u", t[1], mask_pow(t[2]))
+        if t[0] == "t":
+            return ("t", mask_pow(t[1]), mask_pow(t[2]), mask_pow(t[3]))
+        return t
+    trees = [mask_pow(t) for t in trees]
+    lines = ["    out[%d] <-- %s;" % (i, _show(t, -1)) for i, t in enumerate(trees)]
+    src = "template T() { signal input a; signal input b; signal input c; signal output out[%d];\n%s\n}\ncomponent main = T();" \
+          % (len(trees), "\n".join(lines))
+    fc = flatten(program_from_text(src))
+    for trial in range(6):
+        env = {v: rng.choice([0, 1, 2, 5, fp.q - 1, fp.q >> 1, (fp.q >> 1) + 1, rng.randrange(fp.q), rng.randrange(1 << 40)]) for v in "abc"}
+        sig, failed = run(fc, [env["a"], env["b"], env["c"]])
+        assert failed is None
+        for i, t in enumerate(trees):
+            assert sig[1 + i] == _value(t, env, fp), (lines[i], env)
