@@ -2,8 +2,9 @@
 """bench.py — witnesses/sec of the batched HIP witness calculator (BASELINE.json's metric).
 
 Default workload = the metric's: `sha256_2048`, a SHA-256 circuit of 5 compression blocks = 1 020 832 constraints at
-`--O0` (>= 1M, asserted), batch 4096 on one MI355X.  Other workloads (parity-test configurations of BASELINE.json):
-poseidon2 (configs[1], batch 65536), sha256_512 (configs[2]), semaphore<levels> (configs[3]'s circuit).
+`--O0` (>= 1M, asserted), batch 2 097 152 per MI355X through the circuit's emitted code (DEFAULT_BATCH; `--batch 65536` = the
+interpreting kernels).  Other workloads (parity-test configurations of BASELINE.json): poseidon2 (configs[1], batch 65536),
+sha256_512 (configs[2], batch 4096), semaphore20 / 20p / 20w (configs[3]'s relation), bigmultmodp and ecdsa_verify (configs[4]).
 
 A "step" = one pass of the hot path over one batch of synthetic inputs that are already resident in HBM:
 ingest (AoS -> value-table input slots) + schedule evaluation (witness generation) + R1CS check.
