@@ -9,8 +9,12 @@ type analysis -> execution -> compilation):
     -o DIR                  output directory (default .)
     -l DIR                  library directory for `include` (repeatable; include_logic.rs)
     -p / --prime NAME       bn128 (default) bls12381 goldilocks grumpkin pallas vesta secq256r1 bls12377
-    --O0                    the only simplification level of this front-end: every signal is a witness entry and every
-                            constraint is kept (execute + flatten reproduce `circom --O0`); --O1 / --O2 are refused
+    --O1                    (the DEFAULT, as in the reference: input_user.rs:264-283) constant and renaming simplifications:
+                            `.r1cs` / `.sym` / JSON are written from the simplified system (frontend/circom_simplify.py), the
+                            witness keeps fewer signals; <name>_hip/<name>.w2s lists them (u32 LE) - the device still generates
+                            and checks the full system, `reduce_wtns` cuts the O1 `.wtns` out of its output
+    --O0                    no simplification: every signal is a witness entry and every constraint is kept
+    --O2                    refused (the reference's Gaussian elimination with its signal-choice heuristics is not implemented)
     --inspect               print the summary the reference prints after construction (template instances, constraints,
                             inputs / outputs / wires / labels: dag/src/lib.rs:417-456, summary of circom/src/execution_user.rs)
 
@@ -28,7 +32,7 @@ import sys
 
 
 def compile_file(path, outdir=".", libs=(), prime="bn128", r1cs=False, sym=False, json_out=False, hip=False, inspect=False,
-                 strands=None, out=sys.stdout):
+                 strands=None, out=sys.stdout, level="O1"):
     from .frontend.circom_exec import program_from_file
     from .frontend.flatten import flatten
     from .hip_elements import writers
@@ -38,34 +42,43 @@ def compile_file(path, outdir=".", libs=(), prime="bn128", r1cs=False, sym=False
     os.makedirs(outdir, exist_ok=True)
     written = []
     # the summary lines of the reference (circom/src/execution_user.rs + dag/src/lib.rs:417-456)
-    n_lin = sum(1 for a, b, c in fc.constraints if not a or not b)
+    sm = None
+    if level == "O1":
+        from .frontend import circom_simplify
+        sm = circom_simplify.simplify_o1(fc)
+    cons = fc.constraints if sm is None else sm.constraints
+    n_lin = sum(1 for a, b, c in cons if not a or not b)
     print("template instances: %d" % len(prog.inst_list), file=out)
-    print("non-linear constraints: %d" % (len(fc.constraints) - n_lin), file=out)
+    print("non-linear constraints: %d" % (len(cons) - n_lin), file=out)
     print("linear constraints: %d" % n_lin, file=out)
     print("public inputs: %d" % fc.n_pub_in, file=out)
-    print("private inputs: %d" % fc.n_prv_in, file=out)
+    n_prv = fc.n_prv_in if sm is None else sm.n_prv_in
+    print("private inputs: %d%s" % (fc.n_prv_in, "" if n_prv == fc.n_prv_in else " (%d belong to witness)" % n_prv), file=out)
     print("public outputs: %d" % fc.n_outputs, file=out)
-    print("wires: %d" % fc.n_signals, file=out)
+    print("wires: %d" % (fc.n_signals if sm is None else sm.n_wires), file=out)
     print("labels: %d" % fc.n_signals, file=out)
     for line in getattr(prog, "world").compile_log:
         print(line, file=out)
     if r1cs:
         p = os.path.join(outdir, name + ".r1cs")
-        writers.write_r1cs(p, fc)
+        if sm is None:
+            writers.write_r1cs(p, fc)
+        else:
+            circom_simplify.write_r1cs(p, sm)
         written.append(p)
     if sym:
         p = os.path.join(outdir, name + ".sym")
-        writers.write_sym(p, fc)
+        if sm is None:
+            writers.write_sym(p, fc)
+        else:
+            circom_simplify.write_sym(p, sm)
         written.append(p)
     if json_out:
         # constraint_writers/src/json_writer.rs: {"constraints": [[A, B, C], ...]} with decimal strings
         p = os.path.join(outdir, name + "_constraints.json")
+        from .frontend.circom_simplify import constraints_json
         with open(p, "w") as fh:
-            fh.write('{\n"constraints": [\n')
-            for k, con in enumerate(fc.constraints):
-                parts = ["{" + ",".join('"%d":"%d"' % (w, v) for w, v in sorted(part.items())) + "}" for part in con]
-                fh.write("[" + ",".join(parts) + "]" + (",\n" if k + 1 < len(fc.constraints) else "\n"))
-            fh.write("]\n}")
+            fh.write(constraints_json(cons))
         written.append(p)
     if hip:
         from . import compiler
@@ -74,6 +87,13 @@ def compile_file(path, outdir=".", libs=(), prime="bn128", r1cs=False, sym=False
         cp = compiler.compile_program(prog, hdir, name, sym=False, **kw)
         written += [cp.tape_path, cp.dat_path, cp.r1cs_path]
         fc.compiled = cp
+        if sm is not None:
+            # the device generates and checks the full system; the simplified witness is its output read through this list
+            import numpy as np
+            p = os.path.join(hdir, name + ".w2s")
+            np.asarray(sm.witness2signal, dtype="<u4").tofile(p)
+            written.append(p)
+    fc.simplified = sm
     for p in written:
         print("Written successfully: %s" % p, file=out)
     if inspect:
@@ -112,12 +132,13 @@ def main(argv=None):
     if args.c or args.wasm:
         print("error: --c / --wasm are the reference's targets; this front-end produces --hip", file=sys.stderr)
         return 1
-    if args.O1 or args.O2:
-        print("error: only --O0 is implemented (no constraint simplification)", file=sys.stderr)
+    if args.O2:
+        print("error: --O2 is not implemented (use --O1, the default, or --O0)", file=sys.stderr)
         return 1
     try:
         compile_file(args.input, args.output, args.libs, args.prime, args.r1cs, args.sym, args.json, args.hip, args.inspect,
-                     None if args.strands is None else tuple(int(x) for x in args.strands.split(",")))
+                     None if args.strands is None else tuple(int(x) for x in args.strands.split(",")),
+                     level="O0" if args.O0 else "O1")
     except (CircomSyntaxError, CircuitError, FileNotFoundError) as ex:
         print("error: %s" % ex, file=sys.stderr)
         print("previous errors were found", file=sys.stderr)

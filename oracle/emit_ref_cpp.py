@@ -263,7 +263,7 @@ def _emit_function(fid, fn, out):
     out.append("}")
 
 
-def emit(fc, path, hashmap_size: int):
+def emit(fc, path, hashmap_size: int, n_witness=None):
     """fc: circom_amd FlatCircuit (duck-typed: .prog.inst_list, .prog.main, sizes)."""
     global W64, CONSTS64
     W64 = fc.prime == "goldilocks"
@@ -283,7 +283,8 @@ def emit(fc, path, hashmap_size: int):
     out.append("uint get_total_signal_no() {return %d;}" % fc.n_signals)
     out.append("uint get_number_of_components() {return %d;}" % fc.n_components)
     out.append("uint get_size_of_input_hashmap() {return %d;}" % hashmap_size)
-    out.append("uint get_size_of_witness() {return %d;}" % fc.n_signals)
+    # (--O0: every signal is a witness entry; a simplified system keeps fewer: the list itself is in the .dat)
+    out.append("uint get_size_of_witness() {return %d;}" % (fc.n_signals if n_witness is None else n_witness))
     if not W64:
         out.append("uint get_size_of_constants() {return %d;}" % len(fc.constants))
     out.append("uint get_size_of_io_map() {return %d;}" % len(getattr(fc, "io_map", ())))

@@ -69,6 +69,24 @@ def build_circuit(cp, force=False):
     return cli, loop
 
 
+def build_cli_with_witness_list(cp, witness2signal, name: str):
+    """The reference CLI for the circuit of `cp` with a SIMPLIFIED witness (--O1): `get_size_of_witness()` returns the length of
+    the list and the `.dat` carries it (c_code_generator.rs:818-865 writes witness2signal there; calcwit.hpp:54-56 reads the
+    witness through it).  Returns the binary; built under oracle/_ref/<prime>/<name>."""
+    from . import emit_ref_cpp
+    from circom_amd.hip_elements.writers import hashmap_size, write_dat
+    if not REF_ROOT.exists():
+        raise RuntimeError("the reference tree is absent")
+    prime = cp.flat.prime
+    d = ref_dir(prime)
+    d.mkdir(parents=True, exist_ok=True)
+    emit_ref_cpp.emit(cp.flat, d / (name + ".cpp"), hashmap_size(len(cp.flat.inputs)), n_witness=len(witness2signal))
+    write_dat(d / (name + ".dat"), cp.flat, witness2signal=witness2signal)
+    subprocess.run(["make", "-C", str(ROOT), "circuit", "PRIME=" + prime, "NAME=" + name, "REF=" + str(REF_ROOT)],
+                   check=True, capture_output=True)
+    return d / name
+
+
 def run_cli(cp, input_json: str, out_wtns: Path):
     """The reference CLI exactly as a user runs it (main.cpp:336-373)."""
     cli, _ = binaries(cp.flat.prime, cp.name)

@@ -13,6 +13,7 @@ import hashlib
 import json
 import os
 
+import numpy as np
 import pytest
 
 from circom_amd.frontend.circom_exec import program_from_file, program_from_text
@@ -412,7 +413,15 @@ def test_cli_writes_r1cs_sym_json_and_the_hip_target(tmp_path, libs, capsys):
     args = [os.path.join(SRC, "sortpair.circom"), "--r1cs", "--sym", "--json", "--hip", "-o", str(tmp_path), "--strands", "1"]
     for l in libs:
         args += ["-l", l]
+    # the default level is --O1, as in the reference: 66 renaming constraints and as many wires disappear
     assert cli.main(args) == 0
+    out = capsys.readouterr().out
+    assert "non-linear constraints: 69" in out and "linear constraints: 10" in out and "wires: 78" in out and "labels: 144" in out
+    assert len(json.load(open(tmp_path / "sortpair_constraints.json"))["constraints"]) == 79
+    assert (tmp_path / "sortpair.sym").read_text().count(",-1,") == 144 - 78
+    w2s = np.fromfile(tmp_path / "sortpair_hip" / "sortpair.w2s", dtype="<u4")
+    assert len(w2s) == 78 and list(w2s[:7]) == [0, 1, 2, 3, 4, 5, 6]
+    assert cli.main(args + ["--O0"]) == 0
     out = capsys.readouterr().out
     assert "template instances: 10" in out and "non-linear constraints: 69" in out and "linear constraints: 76" in out
     assert "wires: 144" in out and "Everything went okay" in out
