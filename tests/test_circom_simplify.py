@@ -88,6 +88,12 @@ def test_simplified_systems_of_larger_circuits(libs):
     assert fc.n_signals == 1108 and sm.n_wires < 700 and len(sm.constraints) < 700
     fc = flatten(program_from_file(os.path.join(SRC, "mixed_array.circom"), libs))
     _invariants(fc, simplify_o1(fc), [[rng.randrange(Q) for _ in range(8)]])
+    # one SHA-256 block: 204 329 signals of wiring at --O0, 31 017 wires / 31 264 constraints once renamings and constants are
+    # gone (169 936 renamed signals, 3 376 constants) - the size the circuit is usually quoted with (~30 K per block)
+    fc = flatten(program_from_file(os.path.join(SRC, "sha256_64.circom"), libs))
+    sm = simplify_o1(fc)
+    assert (sm.n_wires, len(sm.constraints), len(sm.substituted), len(sm.constants), len(sm.unused)) == (31017, 31264, 169936, 3376, 0)
+    _invariants(fc, sm, [[rng.randrange(2) for _ in range(64)]])
 
 
 def test_public_inputs_are_kept_private_ones_may_go():
