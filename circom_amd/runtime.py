@@ -335,8 +335,17 @@ class Batch:
         _chk(lib().cw_explain(self.h, instance, None if sym_path is None else os.fsencode(str(sym_path)), buf, len(buf)))
         return buf.value.decode()
 
-    def write_wtns(self, instance: int, path):
+    def write_wtns(self, instance: int, path, witness2signal=None):
+        """witness2signal: the kept signals of a simplified constraint system (`--O1`: frontend/circom_simplify.py, the
+        `<name>.w2s` file of the driver): the file then holds the witness of THAT system - the entries of the full witness at
+        these positions, which is what the reference binary writes when its `.dat` carries the list (main.cpp:288-334)"""
         _chk(lib().cw_write_wtns(self.h, instance, os.fsencode(str(path))))
+        if witness2signal is not None:
+            from .frontend.circom_simplify import reduce_wtns
+            with open(path, "rb") as f:
+                full = f.read()
+            with open(path, "wb") as f:
+                f.write(reduce_wtns(full, witness2signal))
 
     def log(self, instance: int) -> str:
         """what the reference binary prints on stdout for this instance (its log(...) statements)"""
