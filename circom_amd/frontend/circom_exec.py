@@ -20,9 +20,13 @@ Run-time control flow inside `<--` code:
     schedule wants; if a `while` condition, an array index or a `return` depends on an unknown value, the function is
     compiled to tier-2 bytecode (frontend/circom_rt.py -> rtcode.RtFunction) and called (CallBucket, call_bucket.rs:466-533).
 
-Not supported (each raises CircuitError with the source position): custom templates / `extern_c`, tags that carry values
-across component boundaries (tags are parsed, declared tag values can be read and written inside the template that owns the
-signal), `while` on an unknown condition in a TEMPLATE body.
+Tags (mkdocs circom-language/tags.md): a signal assigned from a tagged signal inherits its tags and their values; an input of
+a sub-component declared with tags only accepts a signal that carries them; a valued tag is frozen once its signal has a
+value; a parent reads `component.out.tag`.  A tag VALUE does not flow INTO a component (its body is traced once per
+parameter set, before the parent assigns its inputs).
+
+Not supported (each raises CircuitError with the source position): custom templates / `extern_c`, `while` on an unknown
+condition in a TEMPLATE body.
 """
 from __future__ import annotations
 
@@ -183,7 +187,7 @@ class Executor:
         self.cond_stack = []       # if-conversion frames: dict(hints={pid: (dst, value)})
         self.loop_counts = {}      # while statement position -> completed iterations (anonymous component indices)
         self.loop_stack = []
-        self.declared_tags = {}
+        self.assigned_tagsets = set()     # id() of the tag tables of signals that already received a value
 
     # ---- errors ---------------------------------------------------------------------------------------------------------
     def fail(self, msg, pos):
@@ -627,8 +631,9 @@ class Executor:
                 obj = mk(name, *dims)
             except CircuitError as ex:
                 self.fail(str(ex), pos)
-            self.declare(name, SigSlot(obj, kind, tags, dims), pos)
-            self.w.note_decl(ctx, name, {"input": "i", "output": "o", "mid": "m"}[kind], tags)
+            slot = SigSlot(obj, kind, tags, dims)
+            self.declare(name, slot, pos)
+            self.w.note_decl(ctx, name, {"input": "i", "output": "o", "mid": "m"}[kind], slot.tags)
             return
         if t == "bus":
             _, bname, args, kind, tags = xtype
@@ -645,8 +650,9 @@ class Executor:
                 obj = mk(name, n) if (dims or n != 1 or True) else mk(name)
             except CircuitError as ex:
                 self.fail(str(ex), pos)
-            self.declare(name, BusSlot(layout, dims, obj.base, kind, tags), pos)
-            self.w.note_decl(ctx, name, {"input": "i", "output": "o", "mid": "m"}[kind], tags, bus=(layout, dims))
+            slot = BusSlot(layout, dims, obj.base, kind, tags)
+            self.declare(name, slot, pos)
+            self.w.note_decl(ctx, name, {"input": "i", "output": "o", "mid": "m"}[kind], slot.tags, bus=(layout, dims))
             return
         self.fail("unexpected declaration", pos)
 
@@ -668,7 +674,60 @@ class Executor:
             self.eval(rhe)          # evaluated for its effects (an anonymous component), the value is dropped
             return
         v = self.eval(rhe)
+        if op != "=" and not self.in_function:
+            self._check_and_inherit_tags(target, rhe, pos)
         self.assign(target, op, v, pos)
+
+    # .. tags (mkdocs circom-language/tags.md) ..
+    def _tags_of(self, e):
+        """the tags a right-hand side carries: only a plain signal reference (own signal, or input / output of a
+        sub-component) has any; an expression has none"""
+        if e[0] != "var" or e[1] == "_":
+            return None
+        slot = None
+        for sc in reversed(self.scopes):
+            slot = sc.get(e[1])
+            if slot is not None:
+                break
+        if isinstance(slot, (SigSlot, BusSlot)):
+            return slot.tags if all(a[0] == "idx" for a in e[2]) else None
+        if isinstance(slot, CompSlot):
+            fields = [a for a in e[2] if a[0] == "field"]
+            if len(fields) != 1:
+                return None
+            for ref in slot.refs.values():
+                return getattr(ref.inst, "sig_tags", {}).get(fields[0][1], {})
+        return None
+
+    def _check_and_inherit_tags(self, target, rhe, pos):
+        """a signal assigned from a tagged signal inherits its tags (with their values); an input of a sub-component that is
+        declared with tags only accepts a signal that carries them ("the compiler checks if the array assigned to the input
+        array has the tag")"""
+        slot = None
+        for sc in reversed(self.scopes):
+            slot = sc.get(target[1])
+            if slot is not None:
+                break
+        src = self._tags_of(rhe)
+        if isinstance(slot, (SigSlot, BusSlot)):
+            if all(a[0] == "idx" for a in target[2]):
+                if src:
+                    for t, val in src.items():
+                        if slot.tags.get(t) is None:
+                            slot.tags[t] = val
+                self.assigned_tagsets.add(id(slot.tags))
+            return
+        if isinstance(slot, CompSlot):
+            fields = [a for a in target[2] if a[0] == "field"]
+            if len(fields) != 1:
+                return
+            for ref in slot.refs.values():
+                need = getattr(ref.inst, "sig_tags", {}).get(fields[0][1], {})
+                for t in need:
+                    if src is None or t not in src:
+                        self.fail("the signal assigned to %s.%s does not carry the tag %s its declaration asks for"
+                                  % (target[1], fields[0][1], t), pos)
+                break
 
     def assign(self, target, op, v, pos):
         name, access = target[1], target[2]
@@ -721,6 +780,8 @@ class Executor:
     def _set_tag(self, r, v, pos):
         if not isinstance(v, int):
             self.fail("tag values must be known at compile time", pos)
+        if id(r[1]) in self.assigned_tagsets:
+            self.fail("Invalid assignment: tags cannot be assigned to a signal already initialized", pos)
         r[1][r[2]] = v
 
     def assign_var(self, slot, name, access, v, pos):
@@ -958,8 +1019,7 @@ class World:
 
     def note_decl(self, ctx, name, cat, tags, bus=None):
         ctx.inst.decl_order.append((name, cat))
-        if tags:
-            ctx.inst.sig_tags[name] = {t: None for t in tags}
+        ctx.inst.sig_tags[name] = tags            # the slot's own table: values set in the body are seen by the parent
         if bus is not None:
             ctx._bus_decls.append((name, cat, bus))
 

@@ -597,3 +597,34 @@ def test_random_expressions_printed_with_minimal_parentheses_evaluate_like_their
         assert failed is None
         for i, t in enumerate(trees):
             assert sig[1 + i] == _value(t, env, fp), (lines[i], env)
+
+
+def test_tags_are_inherited_required_and_frozen_once_the_signal_has_a_value():
+    # mkdocs circom-language/tags.md: inheritance through substitutions, the check at a tagged component input, valued tags
+    ok = """
+    template Bits2Num(n) { signal input {binary} in[n]; signal output {maxbit} out;
+        var lc1 = 0; var e2 = 1;
+        for (var i = 0; i < n; i++) { lc1 += in[i] * e2; e2 = e2 + e2; }
+        out.maxbit = n;
+        lc1 ==> out; }
+    template Bit() { signal input in; signal output {binary} out; out <== in; in * (in - 1) === 0; }
+    template Main() { signal input x[3]; signal output o; signal output width;
+        component b[3];
+        signal bits[3];
+        for (var i = 0; i < 3; i++) { b[i] = Bit(); b[i].in <== x[i]; }
+        bits[0] <== b[0].out; bits[1] <== b[1].out; bits[2] <== b[2].out;     // bits inherits {binary}
+        component n = Bits2Num(3);
+        n.in <== bits;
+        o <== n.out;
+        width <== n.out.maxbit + o.maxbit; }                                     // the value set inside Bits2Num, inherited by o
+    component main = Main();"""
+    fc, sig, failed = from_text(ok, [1, 0, 1])
+    assert failed is None and sig[1:3] == [5, 6]
+    with pytest.raises(CircuitError, match="does not carry the tag binary"):
+        from_text(ok.replace("n.in <== bits;", "n.in <== x;"), [1, 0, 1])
+    with pytest.raises(CircuitError, match="does not carry the tag binary"):
+        from_text(ok.replace("n.in <== bits;", "n.in[0] <== x[0] * x[1]; n.in[1] <== bits[1]; n.in[2] <== bits[2];"), [1, 0, 1])
+    with pytest.raises(CircuitError, match="tags cannot be assigned to a signal already initialized"):
+        from_text(ok.replace("out.maxbit = n;\n        lc1 ==> out;", "lc1 ==> out;\n        out.maxbit = n;"), [1, 0, 1])
+    with pytest.raises(CircuitError, match="tag maxbit has no value"):
+        from_text(ok.replace("out.maxbit = n;", ""), [1, 0, 1])
