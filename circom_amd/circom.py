@@ -37,8 +37,10 @@ def compile_file(path, outdir=".", libs=(), prime="bn128", r1cs=False, sym=False
     from .frontend.flatten import flatten
     from .hip_elements import writers
     name = os.path.splitext(os.path.basename(path))[0]
-    prog = program_from_file(path, libs, prime)
+    prog = program_from_file(path, libs, prime, inspect=inspect)
     fc = flatten(prog)
+    for w in prog.world.warnings:                    # --inspect: dag/src/constraint_correctness_analysis.rs (CA01 / CA02)
+        print("warning[%s]: %s" % ("CA02" if "ubcomponent" in w else "CA01", w), file=out)
     os.makedirs(outdir, exist_ok=True)
     written = []
     # the summary lines of the reference (circom/src/execution_user.rs + dag/src/lib.rs:417-456)

@@ -188,6 +188,7 @@ class Executor:
         self.loop_counts = {}      # while statement position -> completed iterations (anonymous component indices)
         self.loop_stack = []
         self.assigned_tagsets = set()     # id() of the tag tables of signals that already received a value
+        self.underscored = set()           # pids named in `_ <== ...` (not reported by --inspect)
 
     # ---- errors ---------------------------------------------------------------------------------------------------------
     def fail(self, msg, pos):
@@ -671,7 +672,10 @@ class Executor:
                 self.assign(t, op, x, pos)
             return
         if target[1] == "_":
-            self.eval(rhe)          # evaluated for its effects (an anonymous component), the value is dropped
+            v = self.eval(rhe)      # evaluated for its effects (an anonymous component); `_ <== x` also tells --inspect that
+            for x in (_flat(v, []) if isinstance(v, list) else [v]):     # x is left unconstrained on purpose
+                if isinstance(x, Expr) and x.kind == O.K_SIG:
+                    self.underscored.add(x.val)
             return
         v = self.eval(rhe)
         if op != "=" and not self.in_function:
@@ -990,6 +994,8 @@ class World:
         self._rt_functions = {}
         self._fn_kind = {}
         self.prog = None
+        self.inspect = False          # --inspect: collect the warnings of constraint_correctness_analysis.rs
+        self.warnings = []
 
     # ---- templates ----------------------------------------------------------------------------------------------------------
     def spec(self, name, vals, pos):
@@ -1013,9 +1019,54 @@ class World:
             ctx.inst.bus_iface = {}
             ctx._bus_decls = ctx.inst._bus_decls = []
             ex.run_block(body[1])
+            if world.inspect:
+                world.inspect_instance(ctx, ex, name, pvals)
             world.finish_instance(ctx)
         body_fn.__name__ = name
         return TemplateSpec(name, body_fn, frozen)
+
+    def inspect_instance(self, ctx, ex, name, pvals):
+        """--inspect (dag/src/constraint_correctness_analysis.rs): signals of the instance, and inputs / outputs of its
+        sub-components, that appear in no constraint of this template (and were not handed to `_`)"""
+        seen = set(ex.underscored)
+        for a, b, c in ctx.cons:
+            seen.update(a)
+            seen.update(b)
+            seen.update(c)
+        title = "%s(%s)" % (name, ", ".join(str(_thaw(v)).replace(" ", "") for v in pvals))
+
+        def names_of(base, dims):
+            if not dims:
+                return [base]
+            out = [base]
+            for d in dims:
+                out = [n + "[%d]" % i for n in out for i in range(d)]
+            return out
+
+        def report(kind, base, dims, pid0, size):
+            missing = [k for k in range(size) if pid0 + k not in seen]
+            if not missing:
+                return
+            nm = names_of(base, dims)
+            if len(missing) == 1:
+                what = "Local signal %s does not appear in any constraint" if kind == "local" else \
+                    "Subcomponent input/output signal %s does not appear in any constraint of the father component"
+                self.warnings.append('In template "%s": ' % title + what % nm[missing[0]])
+            else:
+                what = "Array of local signals %s contains a total of %d signals that do not appear in any constraint" if kind == "local" \
+                    else "Array of subcomponent input/output signals %s contains a total of %d signals that do not appear in any " \
+                         "constraint of the father component"
+                self.warnings.append('In template "%s": ' % title + what % (base, len(missing))
+                                     + " = For example: %s, %s." % (nm[missing[0]], nm[missing[1]]))
+        for cat, sname, dims, pid0, size in ctx.own:
+            report("local", sname, dims, pid0, size)
+        for ref in ctx.comps:
+            cname = ref.name + "".join("[%d]" % i for i in ref.index)
+            for sname, (off, dims, cat) in ref.inst.iface.items():
+                size = 1
+                for d in dims:
+                    size *= d
+                report("io", cname + "." + sname, dims, ref.pid0 + off, size)
 
     def note_decl(self, ctx, name, cat, tags, bus=None):
         ctx.inst.decl_order.append((name, cat))
@@ -1144,12 +1195,13 @@ class World:
 
 
 # ---- entry points ----------------------------------------------------------------------------------------------------------
-def build_program(archive: Archive, prime="bn128"):
+def build_program(archive: Archive, prime="bn128", inspect=False):
     """archive -> dsl.Program (main component instantiated, public inputs ordered)"""
     if archive.main is None:
         raise CircuitError("No main specified in the project structure")          # ReportCode::NoMain
     sys.setrecursionlimit(max(20000, sys.getrecursionlimit()))
     world = World(archive, prime)
+    world.inspect = inspect
     _, public, init, pos = archive.main
     ex = Executor(world, "const")
     if init[0] == "anon":
@@ -1214,9 +1266,9 @@ def _qualify_main_bus_inputs(prog):
     m.input_names = out + tail
 
 
-def program_from_file(path, libs=(), prime="bn128"):
-    return build_program(parse_program(path, libs), prime)
+def program_from_file(path, libs=(), prime="bn128", inspect=False):
+    return build_program(parse_program(path, libs), prime, inspect)
 
 
-def program_from_text(text, prime="bn128", name="<text>"):
-    return build_program(parse_text(text, name), prime)
+def program_from_text(text, prime="bn128", name="<text>", inspect=False):
+    return build_program(parse_text(text, name), prime, inspect)

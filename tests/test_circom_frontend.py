@@ -628,3 +628,28 @@ def test_tags_are_inherited_required_and_frozen_once_the_signal_has_a_value():
         from_text(ok.replace("out.maxbit = n;\n        lc1 ==> out;", "lc1 ==> out;\n        out.maxbit = n;"), [1, 0, 1])
     with pytest.raises(CircuitError, match="tag maxbit has no value"):
         from_text(ok.replace("out.maxbit = n;", ""), [1, 0, 1])
+
+
+def test_inspect_reports_what_the_documentation_shows(tmp_path, capsys):
+    # mkdocs circom-language/code-quality/inspect.md: the two programs and the warnings printed under them, word for word
+    a3 = """template B() { signal input in; signal output out; out <== in + 1; }
+template A(n) { signal aux; signal out;
+  if(n == 2) { aux <== 2; out <== B()(aux); } else { out <== 5; } }
+component main = A(3);"""
+    p = program_from_text(a3, inspect=True)
+    assert p.world.warnings == ['In template "A(3)": Local signal aux does not appear in any constraint']
+    assert program_from_text(a3.replace("else { out <== 5; }", "else { _ <== aux; out <== 5; }"), inspect=True).world.warnings == []
+    assert program_from_text(a3).world.warnings == []                      # only under --inspect
+    bits = """template Num2Bits(n) { signal input in; signal output out[n]; var lc1=0; var e2=1;
+  for (var i = 0; i<n; i++) { out[i] <-- (in >> i) & 1; out[i] * (out[i] -1 ) === 0; lc1 += out[i] * e2; e2 = e2+e2; } lc1 === in; }
+template check_bits(n) { signal input in; component check = Num2Bits(n); check.in <== in; }
+component main = check_bits(10);"""
+    assert program_from_text(bits, inspect=True).world.warnings == [
+        'In template "check_bits(10)": Array of subcomponent input/output signals check.out contains a total of 10 signals that do '
+        'not appear in any constraint of the father component = For example: check.out[0], check.out[1].']
+    assert program_from_text(bits.replace("check.in <== in; }", "check.in <== in; _ <== check.out; }"), inspect=True).world.warnings == []
+    # the driver prints them as the reference does
+    from circom_amd import circom as cli
+    (tmp_path / "a3.circom").write_text(a3)
+    assert cli.main([str(tmp_path / "a3.circom"), "--inspect", "-o", str(tmp_path)]) == 0
+    assert 'warning[CA01]: In template "A(3)": Local signal aux does not appear in any constraint' in capsys.readouterr().out
