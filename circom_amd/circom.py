@@ -32,8 +32,9 @@ import sys
 
 
 def compile_file(path, outdir=".", libs=(), prime="bn128", r1cs=False, sym=False, json_out=False, hip=False, inspect=False,
-                 strands=None, out=sys.stdout, level="O1"):
+                 strands=None, out=None, level="O1"):
     from .frontend.circom_exec import program_from_file
+    out = out or sys.stdout
     from .frontend.flatten import flatten
     from .hip_elements import writers
     name = os.path.splitext(os.path.basename(path))[0]
