@@ -15,8 +15,10 @@ type analysis -> execution -> compilation):
                             and checks the full system, `reduce_wtns` cuts the O1 `.wtns` out of its output
     --O0                    no simplification: every signal is a witness entry and every constraint is kept
     --O2                    refused (the reference's Gaussian elimination with its signal-choice heuristics is not implemented)
-    --inspect               print the summary the reference prints after construction (template instances, constraints,
-                            inputs / outputs / wires / labels: dag/src/lib.rs:417-456, summary of circom/src/execution_user.rs)
+    --inspect               the warnings of dag/src/constraint_correctness_analysis.rs (warning[CA01] local signals, warning[CA02]
+                            inputs / outputs of sub-components that appear in no constraint of the template), then one line per
+                            template instance; the summary lines (template instances, constraints, inputs / outputs / wires /
+                            labels: dag/src/lib.rs:417-456) are always printed, as by the reference
 
 The reference's own front-end is Rust (parser, type_analysis, constraint_generation, dag, compiler); this image has no
 cargo, so the language is implemented again here (frontend/circom_lang.py, circom_exec.py, circom_rt.py) on top of the

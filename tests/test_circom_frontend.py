@@ -653,3 +653,10 @@ component main = check_bits(10);"""
     (tmp_path / "a3.circom").write_text(a3)
     assert cli.main([str(tmp_path / "a3.circom"), "--inspect", "-o", str(tmp_path)]) == 0
     assert 'warning[CA01]: In template "A(3)": Local signal aux does not appear in any constraint' in capsys.readouterr().out
+
+
+def test_the_metrics_circuit_from_source_text(libs):
+    """Sha256(2048) - bench.py's default workload - from circuits/circomlib/sha256/*.circom: the numbers of the bench line
+    (1 021 321 signals, 1 020 832 constraints at --O0; one Sha256compression instance is traced once and placed five times)"""
+    fc = flatten(program_from_file(os.path.join(SRC, "sha256_2048.circom"), libs))
+    assert (fc.n_signals, len(fc.constraints), fc.n_main_inputs, fc.n_outputs) == (1021321, 1020832, 2048, 256)
