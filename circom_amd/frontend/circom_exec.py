@@ -1200,6 +1200,8 @@ def build_program(archive: Archive, prime="bn128", inspect=False):
     if archive.main is None:
         raise CircuitError("No main specified in the project structure")          # ReportCode::NoMain
     sys.setrecursionlimit(max(20000, sys.getrecursionlimit()))
+    from .circom_check import check_archive
+    check_archive(archive)                 # the static part of type_analysis: also over code that is never executed
     world = World(archive, prime)
     world.inspect = inspect
     _, public, init, pos = archive.main

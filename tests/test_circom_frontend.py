@@ -390,7 +390,7 @@ def test_tags_declared_values_are_readable_inside_the_template():
     ("function f(x) { signal s; return x; } template T() { signal input a; signal output o; o <== f(1); } component main = T();",
      "cannot be declared inside functions"),
     ("function f(x) { x = 1; } template T() { signal input a; signal output o; o <== f(1); } component main = T();",
-     "ends without a return"),
+     "there are paths without return"),
     ("template T(n) { signal input a; signal output o; o <== a; } component main = T();", "takes 1 parameters"),
     ("template T() { signal input a; signal output o; o <== a; } component main {public [o]} = T();", "not an input of main"),
     ("template T() { signal input a; signal output o; o <== a; }", "No main specified"),
@@ -660,3 +660,28 @@ def test_the_metrics_circuit_from_source_text(libs):
     (1 021 321 signals, 1 020 832 constraints at --O0; one Sha256compression instance is traced once and placed five times)"""
     fc = flatten(program_from_file(os.path.join(SRC, "sha256_2048.circom"), libs))
     assert (fc.n_signals, len(fc.constraints), fc.n_main_inputs, fc.n_outputs) == (1021321, 1020832, 2048, 256)
+
+
+@pytest.mark.parametrize("src,msg", [
+    # errors in code that is never executed: a template that is not instantiated, a branch that is not taken
+    ("template U() { signal input a; signal output o; o <== zz; } template T() { signal input a; signal output o; o <== a; } "
+     "component main = T();", "undeclared symbol zz"),
+    ("template T(n) { signal input a; signal output o; if (n == 1) { o <== nope(a); } else { o <== a; } } component main = T(0);",
+     "undeclared function or template nope"),
+    ("function f(x) { if (x == 0) { return 1; } } template T() { signal input a; signal output o; o <== a; } component main = T();",
+     "In function f there are paths without return"),
+    ("function f(x) { return g(x, 1); } function g(y) { return y; } template T() { signal input a; signal output o; o <== a; } "
+     "component main = T();", "function g takes 1 arguments"),
+    ("function f(x) { x === 1; return x; } template T() { signal input a; signal output o; o <== a; } component main = T();",
+     "functions cannot generate constraints"),
+    ("template T() { signal input a; signal output o; o <== a; return 1; } component main = T();", "return outside a function"),
+    ("template T(n) { signal input a; signal output o; var i = 0; while (i < n) { component c; i++; } o <== a; } component main = T(0);",
+     "c Is outside the initial scope"),
+    ("bus B() { signal x; component c; } template T() { signal input a; signal output o; o <== a; } component main = T();",
+     "a bus cannot declare components"),
+    ("template T(n, n) { signal input a; signal output o; o <== a; } component main = T(1, 2);", "two parameters of the same name"),
+    ("template T() { signal input a; signal output o; o <== a; var a2 = b2; var b2 = 1; } component main = T();", "undeclared symbol b2"),
+])
+def test_static_checks_reach_code_that_never_runs(src, msg):
+    with pytest.raises(CircuitError, match=msg):
+        program_from_text(src)
