@@ -644,16 +644,24 @@ class Executor:
                     self.fail("bus parameters must be known at compile time", pos)
             layout = self.w.bus_layout(bname, vals, pos)
             mk = {"input": ctx.input, "output": ctx.output, "mid": ctx.signal}[kind]
-            n = layout.size
-            for d in dims:
-                n *= d
+            # every signal field is declared under its qualified name (`s.b[1].x`: what the `.sym` file and the input list
+            # call it), one after the other: the bus is the contiguous block that starts at the first one
+            leaves = []
+            for a, _s in _accesses(dims):
+                _qualified_names(layout, 0, name + a, leaves, with_dims=True)
+            first = None
             try:
-                obj = mk(name, n) if (dims or n != 1 or True) else mk(name)
+                for lname, _off, ldims in leaves:
+                    obj = mk(lname, *ldims)
+                    if first is None:
+                        first = obj.base if isinstance(obj, SigArray) else obj.val
             except CircuitError as ex:
                 self.fail(str(ex), pos)
-            slot = BusSlot(layout, dims, obj.base, kind, tags)
+            if first is None:
+                self.fail("bus %s has no signals" % bname, pos)
+            slot = BusSlot(layout, dims, first, kind, tags)
             self.declare(name, slot, pos)
-            self.w.note_decl(ctx, name, {"input": "i", "output": "o", "mid": "m"}[kind], slot.tags, bus=(layout, dims))
+            self.w.note_decl(ctx, name, {"input": "i", "output": "o", "mid": "m"}[kind], slot.tags, bus=(layout, dims, leaves[0][0]))
             return
         self.fail("unexpected declaration", pos)
 
@@ -759,6 +767,11 @@ class Executor:
             idx = r[2]
             if idx in slot.refs:
                 self.fail("component %s is instantiated twice" % name, pos)
+            for other in slot.refs.values():
+                if other.inst.name != v.spec.name:
+                    # (the elements may differ in their PARAMETERS - a Mixed cluster - but not in their template)
+                    self.fail("all components of the array %s must be instances of the same template" % name, pos)
+                break
             try:
                 slot.refs[idx] = self.ctx.component(name, v.spec, index=idx)
             except CircuitError as ex:
@@ -1085,9 +1098,9 @@ class World:
         # offsets are only known after Ctx.finalize (outputs, inputs, intermediates are renumbered): resolve lazily
         class _LazyIface(dict):
             def get(self_inner, key, default=None):
-                for name, cat, (layout, dims) in decls:
+                for name, cat, (layout, dims, first) in decls:
                     if name == key and cat in ("i", "o"):
-                        off = inst.iface[name][0]
+                        off = inst.iface[first][0]
                         return (off, dims, layout, cat)
                 return default
         inst.bus_iface = _LazyIface()
@@ -1217,7 +1230,25 @@ def build_program(archive: Archive, prime="bn128", inspect=False):
     prog = dsl.Program.__new__(dsl.Program)
     world.prog = prog
     prog.world = world
-    dsl.Program.__init__(prog, spec, public=tuple(public), prime=prime)
+    dsl.Program.__init__(prog, spec, public=(), prime=prime)
+    # the public list names signals and buses of main: a bus stands for all its fields
+    m = prog.main
+    buses = {bname: bus for bname, cat, bus in getattr(m, "_bus_decls", ()) if cat == "i"}
+    expanded = []
+    for pname in public:
+        if pname in buses:
+            layout, dims, _first = buses[pname]
+            leaves = []
+            for a, _s in _accesses(dims):
+                _qualified_names(layout, 0, pname + a, leaves)
+            expanded += [l[0] for l in leaves]
+        elif pname in m.iface and m.iface[pname][2] == "i":
+            expanded.append(pname)
+        else:
+            ex.fail("public signal %s is not an input of main" % pname, pos)
+    if expanded:
+        prog.public = tuple(expanded)
+        prog._reorder_main_public()
     _qualify_main_bus_inputs(prog)
     return prog
 
@@ -1233,19 +1264,20 @@ def _accesses(dims):
     return [("[%d]%s" % (i, a), i * stride + s) for i in range(dims[0]) for a, s in inner]
 
 
-def _qualified_names(layout, start, prefix, out):
-    """one input-list entry per signal field of a bus, named <prefix>.<field> (build.rs:348-382 get_qualified_names)"""
+def _qualified_names(layout, start, prefix, out, with_dims=False):
+    """one entry per signal field of a bus, named <prefix>.<field> (build.rs:348-382 get_qualified_names):
+    (name, offset, size), or (name, offset, dims) with with_dims"""
     for fname in layout.order:
         off, dims, sub = layout.fields[fname]
         name = "%s.%s" % (prefix, fname)
         if sub is not None:
             for a, s in _accesses(dims):
-                _qualified_names(sub, start + off + s * sub.size, name + a, out)
+                _qualified_names(sub, start + off + s * sub.size, name + a, out, with_dims)
         else:
             size = 1
             for d in dims:
                 size *= d
-            out.append((name, start + off, size))
+            out.append((name, start + off, tuple(dims) if with_dims else size))
 
 
 def _qualify_main_bus_inputs(prog):
@@ -1253,19 +1285,15 @@ def _qualify_main_bus_inputs(prog):
     - the keys main.cpp's qualify_input makes of nested JSON objects - and once more as the whole bus, behind every other
     entry (compiler/src/circuit_design/build.rs:300-425 main_input_list)."""
     m = prog.main
-    buses = {name: bus for name, cat, bus in getattr(m, "_bus_decls", ()) if cat == "i"}
-    if not buses:
-        return
-    out, tail = [], []
-    for name, off, size in m.input_names:
-        if name in buses:
-            layout, dims = buses[name]
-            for a, s in _accesses(dims):
-                _qualified_names(layout, off + s * layout.size, name + a, out)
-            tail.append((name, off, size))
-        else:
-            out.append((name, off, size))
-    m.input_names = out + tail
+    tail = []
+    for name, cat, (layout, dims, first) in getattr(m, "_bus_decls", ()):
+        if cat != "i":
+            continue
+        size = layout.size
+        for d in dims:
+            size *= d
+        tail.append((name, m.iface[first][0], size))      # (the fields themselves are declared under their qualified names)
+    m.input_names = list(m.input_names) + tail
 
 
 def program_from_file(path, libs=(), prime="bn128", inspect=False):
