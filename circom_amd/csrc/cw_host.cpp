@@ -1289,6 +1289,27 @@ extern "C" uint32_t cw_n_signals(const cw_circuit *c) { return c->n_signals - c-
 extern "C" uint32_t cw_n_log_statements(const cw_circuit *c) { return c ? (uint32_t)c->logs.size() : 0; }
 extern "C" uint32_t cw_n_witness(const cw_circuit *c) { return c->n_witness; }
 extern "C" uint32_t cw_n_inputs(const cw_circuit *c) { return c->n_inputs; }
+// The witness of a SIMPLIFIED constraint system.  Without a flag the reference simplifies at --O1 (constraint_list/src/
+// constraint_simplification.rs): the `.r1cs` a prover takes keeps a subset of the signals, and the emitted calculator writes
+// exactly those (witness2signal of the `.dat`, calcwit.hpp:54-56).  The evaluation and the R1CS check of this library work
+// on the full system the circuit was loaded with (every term of the `.r1cs` was resolved to a value slot by cw_load); this
+// call only changes what the egress paths hand out - cw_get_witness(es)(_device), cw_write_wtns(_many), cw_write_wtnsb -
+// for batches created AFTER it.  `signals`: strictly increasing signal ids starting with 0 whose first 1 + cw_n_public
+// entries are the ones of the current list (outputs and public inputs are never simplified away).
+extern "C" int cw_set_witness_list(cw_circuit *c, const uint32_t *signals, uint32_t n) {
+    if (!c || !signals || n == 0) return fail(CW_EINVAL, "cw_set_witness_list: bad argument");
+    const uint32_t np = 1 + cw_n_public(c);
+    if (n < np || n > c->n_signals - c->n_logv) return fail(CW_EINVAL, "cw_set_witness_list: list length out of range");
+    for (uint32_t i = 0; i < n; i++) {
+        if (signals[i] >= c->n_signals - c->n_logv || (i && signals[i] <= signals[i - 1]))
+            return fail(CW_EINVAL, "cw_set_witness_list: signal ids must increase and stay below cw_n_signals");
+        if (i < np && (i >= c->w2s.size() || signals[i] != c->w2s[i]))
+            return fail(CW_EINVAL, "cw_set_witness_list: the constant, the outputs and the public inputs must stay where they are");
+    }
+    c->w2s.assign(signals, signals + n);
+    c->n_witness = n;
+    return CW_OK;
+}
 extern "C" uint32_t cw_input_start(const cw_circuit *c) { return c->input_start; }
 extern "C" uint32_t cw_n_constraints(const cw_circuit *c) { return c->n_constraints; }
 // public signals = main's outputs then its public inputs = witness positions 1 .. n_public (r1cs header nPubOut/nPubIn)

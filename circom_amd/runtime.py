@@ -51,6 +51,7 @@ _SIGS = {
     "cw_io_map_offset": (C.c_int64, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "cw_n_witness": (C.c_uint32, [C.c_void_p]),
     "cw_n_inputs": (C.c_uint32, [C.c_void_p]),
+    "cw_set_witness_list": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]),
     "cw_input_start": (C.c_uint32, [C.c_void_p]),
     "cw_n_constraints": (C.c_uint32, [C.c_void_p]),
     "cw_n_public": (C.c_uint32, [C.c_void_p]),
@@ -157,6 +158,13 @@ class Circuit:
         buf = C.create_string_buffer(32)
         L.cw_prime(h, buf)
         self.q = int.from_bytes(buf.raw, "little")
+
+    def set_witness_list(self, signals):
+        """egress of every batch created from now on hands out these signals (the witness of a simplified system: `--O1`,
+        frontend/circom_simplify.py); evaluation and R1CS check stay on the full system"""
+        arr = np.ascontiguousarray(signals, dtype=np.uint32)
+        _chk(lib().cw_set_witness_list(self.h, arr.ctypes.data_as(C.POINTER(C.c_uint32)), len(arr)))
+        self.n_witness = lib().cw_n_witness(self.h)
 
     def bits_info(self) -> dict:
         """shape of the bit-plane program ({} when the circuit has none)"""

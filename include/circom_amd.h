@@ -61,6 +61,13 @@ uint32_t cw_io_map_size(const cw_circuit *c);
 int64_t cw_io_map_offset(const cw_circuit *c, uint32_t template_id, uint32_t signal_code);
 uint32_t cw_n_witness(const cw_circuit *c);          /* get_size_of_witness() */
 uint32_t cw_n_inputs(const cw_circuit *c);           /* get_main_input_signal_no() */
+/* The witness of a SIMPLIFIED constraint system (the reference's default --O1, constraint_list/src/constraint_simplification.rs,
+ * keeps a subset of the signals; the emitted calculator writes those: witness2signal of the .dat, calcwit.hpp:54-56,
+ * main.cpp:288-334).  `signals`: n strictly increasing signal ids starting with 0; the first 1 + cw_n_public entries stay as
+ * they are.  Evaluation and R1CS check keep working on the full system cw_load was given; every egress of batches created
+ * AFTER this call (cw_get_witness(es)(_device), cw_write_wtns(_many), cw_write_wtnsb) hands out these entries, and
+ * cw_n_witness() returns n. */
+int cw_set_witness_list(cw_circuit *c, const uint32_t *signals, uint32_t n);
 uint32_t cw_input_start(const cw_circuit *c);        /* get_main_input_signal_start() */
 uint32_t cw_n_constraints(const cw_circuit *c);      /* from the .r1cs header, 0 if none loaded */
 uint32_t cw_n_public(const cw_circuit *c);     /* nPubOut + nPubIn of the r1cs header */
