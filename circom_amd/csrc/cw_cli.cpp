@@ -71,6 +71,16 @@ int main(int argc, char **argv) {
     if (probe) fclose(probe);
     cw_circuit *c = nullptr;
     CHECK(cw_load((name + ".cwt").c_str(), (name + ".dat").c_str(), probe ? r1cs.c_str() : nullptr, &c));
+    // <name>.w2s beside the tape (written by `python -m circom_amd.circom` at its default level --O1): the signals the
+    // simplified constraint system keeps, u32 little endian.  The files written below then hold THAT witness - what the
+    // reference's calculator writes for the `.r1cs` it produced with the same flags.
+    if (FILE *wl = fopen((name + ".w2s").c_str(), "rb")) {
+        std::vector<uint32_t> list;
+        uint32_t v;
+        while (fread(&v, 4, 1, wl) == 1) list.push_back(v);
+        fclose(wl);
+        if (!list.empty()) CHECK(cw_set_witness_list(c, list.data(), (uint32_t)list.size()));
+    }
     const std::vector<std::string> ins = elements(slurp(argv[2]));
     if (ins.empty()) { fprintf(stderr, "no input objects in %s\n", argv[2]); return 2; }
     const int device = getenv("CW_DEVICE") ? atoi(getenv("CW_DEVICE")) : 0;
