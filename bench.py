@@ -114,6 +114,21 @@ def artefact_fingerprint() -> str:
     return h.hexdigest()[:16]
 
 
+def _o1_size(fc):
+    """What the circuit shrinks to at `--O1`, the level the reference applies when no flag is given (constant and renaming
+    substitutions, frontend/circom_simplify.py): reported beside the --O0 sizes the device evaluates and checks row by row.
+    Never lets the bench fail: None when the count could not be taken."""
+    try:
+        if os.environ.get("CW_BENCH_NO_O1") or fc.n_signals > 3_000_000:
+            return None
+        from circom_amd.frontend.circom_simplify import simplify_o1
+        sm = simplify_o1(fc)
+        return {"wires": sm.n_wires, "constraints": len(sm.constraints),
+                "note": "the device generates and checks the --O0 system; cw_set_witness_list hands out these wires"}
+    except Exception as ex:                                       # noqa: BLE001
+        return {"error": repr(ex)[:200]}
+
+
 def get_compiled(name: str, batch: int, cache_root: str, rank: int, dist):
     """Rank 0 traces + lowers the circuit once (or finds the artefacts of this exact source in the cache); the other
     ranks wait and load the files.  Every rank traces + flattens (seconds) to have the flat code for the oracle."""
@@ -879,6 +894,7 @@ def main():
                         "([signal][instance] order" + (", Montgomery form" if circ.montgomery else "") + "); value_canonical includes "
                         "writing the reference's image ([instance][witness element], canonical residues)"),
                        "n_signals": circ.n_signals, "n_witness": n_wit, "n_constraints": circ.n_constraints,
+                       "at_reference_default_O1": _o1_size(cp.flat),
                        "engine": "bit-plane, emitted gfx950 code (one wave per 2 048 instances, 1 bit per signal value per instance)" if batch.bitmode and batch.jit else
                        "bit-plane (1 bit per signal value per instance)" if batch.bitmode else
                        (("256-bit schedule as emitted gfx950 code" + (" with the R1CS check fused in" if batch.fused_check else ""))
