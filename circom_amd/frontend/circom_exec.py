@@ -801,14 +801,31 @@ class Executor:
             self.fail("Invalid assignment: tags cannot be assigned to a signal already initialized", pos)
         r[1][r[2]] = v
 
+    def _weak(self, old, v, name, pos):
+        """`var` arrays of different lengths (program_structure/src/utils/memory_slice.rs:129-160, 300-320: variables are not
+        strict): the overlapping positions are assigned, the others keep their values; a warning is recorded
+        (execute.rs:3949-3965).  Same number of dimensions only."""
+        so, sv = _shape(old), _shape(v)
+        if so == sv:
+            return v
+        if len(so) != len(sv) or not so:
+            self.fail("assignee and assigned arrays of %s have different numbers of dimensions" % name, pos)
+        self.w.note_typing_warning(self, so, sv, pos)
+
+        def merge(o, x):
+            if not isinstance(o, list):
+                return x
+            return [merge(o[i], x[i]) if i < len(x) else o[i] for i in range(len(o))]
+        return merge(old, v)
+
     def assign_var(self, slot, name, access, v, pos):
         v = _deep_copy(v)
         if not access:
             old = slot.value
-            if isinstance(old, list) and _shape(old) != _shape(v):
-                # execute.rs: assigning an array of another size to an array variable is an error
-                # (a smaller array is accepted by recent versions and padded; kept strict here)
-                self.fail("assignee and assigned arrays of %s have different sizes" % name, pos)
+            if isinstance(old, list):
+                if not isinstance(v, list):
+                    self.fail("a single value is assigned to the array %s" % name, pos)
+                v = self._weak(old, v, name, pos)
             slot.value = v
             return
         cur = slot.value
@@ -822,9 +839,9 @@ class Executor:
             if i >= len(cur):
                 self.fail("array index out of bounds: %s[%d] of %d" % (name, i, len(cur)), pos)
             if n == len(access) - 1:
-                if _shape(cur[i]) != _shape(v):
+                if isinstance(cur[i], list) != isinstance(v, list):
                     self.fail("assignee and assigned arrays of %s have different sizes" % name, pos)
-                cur[i] = v
+                cur[i] = self._weak(cur[i], v, name, pos) if isinstance(v, list) else v
             else:
                 cur = cur[i]
 
@@ -1009,6 +1026,7 @@ class World:
         self.prog = None
         self.inspect = False          # --inspect: collect the warnings of constraint_correctness_analysis.rs
         self.warnings = []
+        self.typing_warnings = []     # arrays of different lengths assigned to variables (execute.rs:3949-3965)
 
     # ---- templates ----------------------------------------------------------------------------------------------------------
     def spec(self, name, vals, pos):
@@ -1037,6 +1055,22 @@ class World:
             world.finish_instance(ctx)
         body_fn.__name__ = name
         return TemplateSpec(name, body_fn, frozen)
+
+    def note_typing_warning(self, ex, expected, given, pos):
+        if ex.mode == "abstract":
+            return
+        fn, ln, col = self.archive.where(pos)
+        n_exp, n_giv = 1, 1
+        for d in expected:
+            n_exp *= d
+        for d in given:
+            n_giv *= d
+        kind = "smaller length, the remaining positions are not modified. Initially all variables are initialized to 0." \
+            if n_giv < n_exp else "greater length, the remaining positions of the expression are not assigned to the array."
+        msg = "%s:%d:%d: Typing warning: Mismatched dimensions, assigning to an array an expression of %s\n  Expected length: %d, given %d" \
+            % (fn, ln, col, kind, n_exp, n_giv)
+        if msg not in self.typing_warnings:
+            self.typing_warnings.append(msg)
 
     def inspect_instance(self, ctx, ex, name, pvals):
         """--inspect (dag/src/constraint_correctness_analysis.rs): signals of the instance, and inputs / outputs of its

@@ -373,8 +373,8 @@ class RtCompiler:
             return
         v = self._own(v)
         if not idxs:
-            if isinstance(cur, list) and X._shape(cur) != X._shape(v):
-                self.fail("assignee and assigned arrays of %s have different sizes" % name, pos)
+            if isinstance(cur, list):
+                v = self._weak(cur, v, name, pos)
             slot.value = v
             return
         for n, i in enumerate(idxs):
@@ -384,11 +384,23 @@ class RtCompiler:
             if i >= len(cur):
                 self.fail("array index out of bounds: %s[%d] of %d" % (name, i, len(cur)), pos)
             if n == len(idxs) - 1:
-                if X._shape(cur[i]) != X._shape(v):
-                    self.fail("assignee and assigned arrays of %s have different sizes" % name, pos)
-                cur[i] = v
+                cur[i] = self._weak(cur[i], v, name, pos) if isinstance(cur[i], list) else v
             else:
                 cur = cur[i]
+
+    def _weak(self, old, v, name, pos):
+        """arrays of different lengths into a variable (memory_slice.rs:129-160): overlapping positions only"""
+        so, sv = X._shape(old), X._shape(v)
+        if so == sv:
+            return v
+        if len(so) != len(sv) or not so:
+            self.fail("assignee and assigned arrays of %s have different numbers of dimensions" % name, pos)
+
+        def merge(o, x):
+            if not isinstance(o, list):
+                return x
+            return [merge(o[i], x[i]) if i < len(x) else o[i] for i in range(len(o))]
+        return merge(old, v)
 
     def _store_pinned(self, p: Pinned, idxs, v, pos):
         f = self.f
@@ -408,7 +420,15 @@ class RtCompiler:
                 base += i * stride
                 dims.pop(0)
             if X._shape(v) != tuple(dims):
-                self.fail("assignee and assigned arrays have different sizes", pos)
+                # variables are not strict: the overlapping positions are assigned, the others keep their registers
+                def view(b, dd):
+                    if not dd:
+                        return RtVar(self.f, 'r', b)
+                    st = 1
+                    for d in dd[1:]:
+                        st *= d
+                    return [view(b + k * st, dd[1:]) for k in range(dd[0])]
+                v = self._weak(view(base, dims), v, "the array", pos)
             leaves = X._flat(v, []) if isinstance(v, list) else [v]
             # an array assigned from (a view of) itself must not be overwritten while it is read: stage through temporaries
             srcs = [self.rt(x) for x in leaves]
