@@ -44,6 +44,8 @@ def compile_file(path, outdir=".", libs=(), prime="bn128", r1cs=False, sym=False
     fc = flatten(prog)
     for w in prog.world.warnings:                    # --inspect: dag/src/constraint_correctness_analysis.rs (CA01 / CA02)
         print("warning[%s]: %s" % ("CA02" if "ubcomponent" in w else "CA01", w), file=out)
+    for w in prog.world.typing_warnings:             # arrays of different lengths into variables (execute.rs:3949-3965)
+        print("warning[T3001]: %s" % w, file=out)
     os.makedirs(outdir, exist_ok=True)
     written = []
     # the summary lines of the reference (circom/src/execution_user.rs + dag/src/lib.rs:417-456)
