@@ -60,13 +60,15 @@ def _rows(name, fc, n, seed):
         p = 2147483647                       # 2^31 - 1 on two 16-bit limbs
         lim = lambda x: [x & 0xFFFF, x >> 16]
         return [lim(a) + lim(p) for a in [0, 1, p - 1] + [rng.randrange(1, p) for _ in range(max(0, n - 3))]]
+    if name == "multiand5":
+        return [[1] * 5, [1, 1, 0, 1, 1]] + [[rng.randrange(2) for _ in range(5)] for _ in range(max(0, n - 2))]
     if name == "sortpair":
         return [[rng.getrandbits(16), rng.getrandbits(16)] for _ in range(n - 1)] + [[777, 777]]
     return [[rng.randrange(q) for _ in range(fc.n_main_inputs)] for _ in range(n)]
 
 
 @pytest.mark.parametrize("name,prime", [("sortpair", "bn128"), ("poseidon2", "bls12381"), ("bigmultmodp", "bls12381"),
-                                        ("opzoo", "bn128"), ("modinv", "bls12381")])
+                                        ("opzoo", "bn128"), ("modinv", "bls12381"), ("multiand5", "bn128")])
 def test_reference_runtime_executes_circuits_compiled_from_text(name, prime, libs, tmp_path):
     from oracle import ref_build
     if not os.path.isdir(os.path.join(os.path.dirname(ref_build.__file__), "_ref", prime)) and not ref_build.REF_ROOT.exists():
