@@ -45,6 +45,19 @@ class Pinned:
         return n
 
 
+class Cell:
+    """ONE element of an array variable that lives in a register (the elements a run-time region assigns; the others stay
+    plain values)"""
+    __slots__ = ("reg",)
+
+    def __init__(self, reg):
+        self.reg = reg
+
+
+class _Repin(Exception):
+    """a run-time region assigned an array element its scout did not see: the region is rebuilt with every element pinned"""
+
+
 class _Frame:
     """one (inlined) function activation"""
 
@@ -54,7 +67,8 @@ class _Frame:
         self.ret_shape = None
         self.ret_base = None
         self.jumps = []
-        self.returned_at_top = False
+        self.direct = None         # the value of a function whose only return is reached on every path (no result registers)
+        self.region0 = 0           # depth of run-time regions at which the activation started
 
 
 class _Stop(Exception):
@@ -73,6 +87,9 @@ class RtCompiler:
         self.pinned_regs = set()
         self.call_pos = pos
         self.depth = 0
+        self.scouting = False      # a region is being built once to learn which array elements it assigns
+        self.scout_log = {}        # id(slot) -> set of element paths | "rt" (indexed by a run-time value)
+        self.region_visible = []   # per open region: ids of the slots that existed when it was entered
 
     # ---- helpers ------------------------------------------------------------------------------------------------------
     def fail(self, msg, pos):
@@ -145,6 +162,16 @@ class RtCompiler:
                 stride *= d
             return [rec(base + i * stride, dims[1:]) for i in range(dims[0])]
         return rec(p.base, p.dims)
+
+    def _view(self, v):
+        """a variable's value with its pinned elements as register aliases"""
+        if isinstance(v, list):
+            return [self._view(x) for x in v]
+        if isinstance(v, Cell):
+            return RtVar(self.f, 'r', v.reg)
+        if isinstance(v, Pinned):
+            return self._unpin_view(v)
+        return v
 
     def _own(self, v):
         """a value about to be bound to a variable / array element / result: aliases of pinned registers are copied"""
@@ -225,7 +252,7 @@ class RtCompiler:
                 self.fail("a variable has no field %s" % a[1], pos)
             idxs.append(self.eval(a[1]))
         if not idxs:
-            return self._unpin_view(v) if isinstance(v, Pinned) else v
+            return self._view(v)
         if all(self.known(i) for i in idxs):
             if isinstance(v, Pinned):
                 v = self._unpin_view(v)
@@ -236,14 +263,14 @@ class RtCompiler:
                 if i >= len(v):
                     self.fail("array index out of bounds: %s[%d] of %d" % (name, i, len(v)), pos)
                 v = v[i]
-            return v
+            return self._view(v)
         # run-time index: a block access
         if isinstance(v, Pinned):
             p = v
         else:
             if not isinstance(v, list):
                 self.fail("too many indices for %s" % name, pos)
-            p = self._pin_value(v)              # materialised copy (the variable itself stays as it is)
+            p = self._pin_value(self._view(v))  # materialised copy (the variable itself stays as it is)
         lin = self._linear_index(p.dims, idxs, pos)
         return RtArray(self.f, p.base, p.size).load(self.rt(lin))
 
@@ -283,10 +310,11 @@ class RtCompiler:
         self.frames.append(fr)
         self.depth += 1
         saved_region = self.region
+        fr.region0 = self.region
         try:
             try:
                 self.run_block(body[1])
-                if not fr.jumps:
+                if not fr.jumps and fr.direct is None:
                     self.fail("function %s ends without a return" % name, pos)
             except _Stop:
                 pass
@@ -294,6 +322,8 @@ class RtCompiler:
             self.region = saved_region
             self.depth -= 1
             self.frames.pop()
+        if fr.direct is not None:
+            return fr.direct[0]
         end = len(self.f.code)
         for j in fr.jumps:
             self.f.code[j][1] = end
@@ -367,26 +397,70 @@ class RtCompiler:
             self._store_pinned(cur, idxs, v, pos)
             return
         if not all(self.known(i) for i in idxs):
-            # a run-time index on an unpinned array: pin it now
-            slot.value = cur = self._pin_value(cur)
+            # a run-time index on an unpinned array: the whole array becomes a block now
+            if self.scouting:
+                self.scout_log[id(slot)] = "rt"
+            elif self._is_outer(slot):
+                raise _Repin()
+            slot.value = cur = self._pin_value(self._view(cur))
             self._store_pinned(cur, idxs, v, pos)
             return
         v = self._own(v)
         if not idxs:
             if isinstance(cur, list):
-                v = self._weak(cur, v, name, pos)
-            slot.value = v
+                self._store_elements(slot, cur, (), self._weak(self._view(cur), v, name, pos))
+            else:
+                slot.value = v
             return
+        path = []
         for n, i in enumerate(idxs):
             i = self.kval(i)
             if not isinstance(cur, list):
                 self.fail("too many indices for %s" % name, pos)
             if i >= len(cur):
                 self.fail("array index out of bounds: %s[%d] of %d" % (name, i, len(cur)), pos)
+            path.append(i)
             if n == len(idxs) - 1:
-                cur[i] = self._weak(cur[i], v, name, pos) if isinstance(cur[i], list) else v
+                if isinstance(cur[i], list):
+                    self._store_elements(slot, cur[i], tuple(path), self._weak(self._view(cur[i]), v, name, pos))
+                else:
+                    if isinstance(v, list):
+                        self.fail("an array is assigned to one element of %s" % name, pos)
+                    self._store_leaf(slot, cur, i, tuple(path), v)
             else:
                 cur = cur[i]
+
+    def _is_outer(self, slot):
+        return any(id(slot) in vis for vis in self.region_visible)
+
+    def _store_leaf(self, slot, container, i, path, v):
+        old = container[i]
+        if isinstance(old, Cell):
+            x = self.rt(v)
+            if not (x.kind == 'r' and x.val == old.reg):
+                self.f.code.append((O.COPY, old.reg, (x.kind, x.val), None))
+            if self.scouting:
+                log = self.scout_log.setdefault(id(slot), set())
+                if log != "rt":
+                    log.add(path)
+            return
+        if self._is_outer(slot):
+            raise _Repin()                     # an element this region's scout did not see assigned
+        container[i] = v
+
+    def _store_elements(self, slot, container, path, v):
+        """v (same shape as container, leaves already owned) into the elements of an array variable"""
+        for i in range(len(container)):
+            if isinstance(container[i], list):
+                self._store_elements(slot, container[i], path + (i,), v[i])
+            else:
+                x = v[i]
+                old = container[i]
+                if isinstance(old, Cell) and isinstance(x, RtVar) and x.kind == 'r' and x.val == old.reg:
+                    continue                   # (a position the weak rule left as it was)
+                if not isinstance(old, Cell) and (x is old or (isinstance(x, int) and isinstance(old, int) and x == old)):
+                    continue
+                self._store_leaf(slot, container, i, path + (i,), x)
 
     def _weak(self, old, v, name, pos):
         """arrays of different lengths into a variable (memory_slice.rs:129-160): overlapping positions only"""
@@ -462,18 +536,93 @@ class RtCompiler:
             self._assigned_names(s[2], out)
         return out
 
-    def _pin_assigned(self, stmts, pos):
+    def _assigned_slots(self, stmts):
         names = set()
         for s in stmts:
             if s is not None:
                 self._assigned_names(s, names)
+        out = []
         for nm in names:
             for sc in reversed(self.scopes):
                 slot = sc.get(nm)
                 if slot is not None:
-                    if not isinstance(slot.value, Pinned):
-                        slot.value = self._pin_value(slot.value)
+                    out.append(slot)
                     break
+        return out
+
+    def _pin_leaves(self, slot, which):
+        """which: None = every element, else a set of element paths"""
+        def rec(v, path):
+            for i in range(len(v)):
+                if isinstance(v[i], list):
+                    rec(v[i], path + (i,))
+                elif not isinstance(v[i], Cell) and (which is None or path + (i,) in which):
+                    r = self.f.var(self.rt(v[i]))
+                    self.pinned_regs.add(r.val)
+                    v[i] = Cell(r.val)
+        rec(slot.value, ())
+
+    def _snapshot(self):
+        cp = lambda v: [cp(x) for x in v] if isinstance(v, list) else v
+        slots = [(sl, cp(sl.value)) for fr in self.frames for sc in fr.scopes for sl in sc.values()]
+        return (len(self.f.code), self.f.n_regs, self.f.last_if, set(self.pinned_regs), self.region,
+                [(fr, fr.ret_shape, fr.ret_base, list(fr.jumps)) for fr in self.frames], slots)
+
+    def _restore(self, snap):
+        cp = lambda v: [cp(x) for x in v] if isinstance(v, list) else v
+        n_code, n_regs, last_if, pinned, region, frames, slots = snap
+        del self.f.code[n_code:]
+        self.f.n_regs = n_regs
+        self.f.last_if = last_if
+        self.pinned_regs = set(pinned)
+        self.region = region
+        for fr, shape, base, jumps in frames:
+            fr.ret_shape, fr.ret_base, fr.jumps = shape, base, list(jumps)
+        for sl, val in slots:
+            sl.value = cp(val)
+
+    def _region(self, stmts, build):
+        """Build a run-time region.  Scalars it assigns are pinned to a register; of the ARRAYS it assigns only the elements
+        it assigns are (circom-ecdsa's functions carry 100-entry arrays of which a handful of entries is ever touched): the
+        region is built once as a scout with every element pinned, the builder's state is rolled back, and the region is
+        built again with the elements the scout saw assigned; an array indexed by a run-time value becomes a block."""
+        slots = self._assigned_slots(stmts)
+        arrays = [sl for sl in slots if isinstance(sl.value, list)]
+        for sl in slots:
+            if not isinstance(sl.value, (list, Pinned)):
+                sl.value = self._pin_value(sl.value)
+        if not arrays or self.scouting:
+            for sl in arrays:
+                self._pin_leaves(sl, None)
+            build()
+            return
+        snap = self._snapshot()
+        self.scouting, self.scout_log = True, {}
+        try:
+            for sl in arrays:
+                self._pin_leaves(sl, None)
+            build()
+        finally:
+            self.scouting = False
+        log = self.scout_log
+        self._restore(snap)
+        for sl in arrays:
+            seen = log.get(id(sl))
+            if seen == "rt":
+                sl.value = self._pin_value(self._view(sl.value))
+            elif seen:
+                self._pin_leaves(sl, seen)
+        self.region_visible.append({id(sl) for fr in self.frames for sc in fr.scopes for sl in sc.values()})
+        try:
+            try:
+                build()
+            finally:
+                self.region_visible.pop()
+        except _Repin:
+            self._restore(snap)
+            for sl in arrays:
+                self._pin_leaves(sl, None)
+            build()
 
     def exec_if(self, s):
         _, cond, then, other, pos = s
@@ -486,15 +635,18 @@ class RtCompiler:
             elif other is not None:
                 self.run_block([other])
             return
-        self._pin_assigned([then, other], pos)
         f = self.f
-        self.region += 1
-        with f.if_(self.rt(c)):
-            self.run_block([then])
-        if other is not None:
-            with f.else_():
-                self.run_block([other])
-        self.region -= 1
+        cr = self.rt(c)
+
+        def build():
+            self.region += 1
+            with f.if_(cr):
+                self.run_block([then])
+            if other is not None:
+                with f.else_():
+                    self.run_block([other])
+            self.region -= 1
+        self._region([then, other], build)
 
     def exec_while(self, s):
         _, cond, body, pos = s
@@ -517,20 +669,22 @@ class RtCompiler:
             if n > self.w.max_loop:
                 self.fail("loop does not terminate", pos)
         # run-time loop: everything the body or the condition's variables assign lives in registers from here on
-        self._pin_assigned([body], pos)
         f = self.f
-        self.region += 1
-        with f.loop() as L:
-            c = self.eval(cond)
-            if self.known(c):
-                # the pinning turned the condition's variables into registers: it cannot be known any more unless it
-                # does not depend on them at all
-                if self.kval(c) == 0:
-                    self.fail("unexpected constant-false loop condition", pos)
-                c = f.var(1)
-            L.break_unless(self.rt(c))
-            self.run_block([body])
-        self.region -= 1
+
+        def build():
+            self.region += 1
+            with f.loop() as L:
+                c = self.eval(cond)
+                if self.known(c):
+                    # the pinning turned the condition's variables into registers: it cannot be known any more unless it
+                    # does not depend on them at all
+                    if self.kval(c) == 0:
+                        self.fail("unexpected constant-false loop condition", pos)
+                    c = f.var(1)
+                L.break_unless(self.rt(c))
+                self.run_block([body])
+            self.region -= 1
+        self._region([body], build)
 
     def exec_return(self, s):
         fr = self.frames[-1]
@@ -539,6 +693,11 @@ class RtCompiler:
             v = self._unpin_view(v)
         shape = X._shape(v)
         f = self.f
+        top = self.region == fr.region0
+        if top and fr.ret_shape is None:
+            # no path left the function earlier: its value is this one, whatever registers or constants it is made of
+            fr.direct = (self._view(v),)
+            raise _Stop()
         if fr.ret_shape is None:
             fr.ret_shape = shape
             n = 1
@@ -554,7 +713,7 @@ class RtCompiler:
             f.code.append((O.COPY, fr.ret_base + n, (x.kind, x.val), None))
         fr.jumps.append(len(f.code))
         f.code.append([F_JMP, None, None, None])
-        if self.region == 0:
+        if top:
             raise _Stop()
 
 
