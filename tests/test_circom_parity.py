@@ -60,6 +60,13 @@ def _rows(name, fc, n, seed):
         p = 2147483647                       # 2^31 - 1 on two 16-bit limbs
         lim = lambda x: [x & 0xFFFF, x >> 16]
         return [lim(a) + lim(p) for a in [0, 1, p - 1] + [rng.randrange(1, p) for _ in range(max(0, n - 3))]]
+    if name == "bigmult_style":
+        rows = []
+        lim = lambda x: [(x >> (28 * i)) & ((1 << 28) - 1) for i in range(3)]
+        for t in range(n):
+            p = (rng.getrandbits(84) | (1 << 83)) if t % 2 else (rng.getrandbits(64) | (1 << 56))
+            rows.append(lim(rng.randrange(p)) + lim(rng.randrange(p)) + lim(p))
+        return rows
     if name == "multiand5":
         return [[1] * 5, [1, 1, 0, 1, 1]] + [[rng.randrange(2) for _ in range(5)] for _ in range(max(0, n - 2))]
     if name == "sortpair":
@@ -68,7 +75,8 @@ def _rows(name, fc, n, seed):
 
 
 @pytest.mark.parametrize("name,prime", [("sortpair", "bn128"), ("poseidon2", "bls12381"), ("bigmultmodp", "bls12381"),
-                                        ("opzoo", "bn128"), ("modinv", "bls12381"), ("multiand5", "bn128")])
+                                        ("opzoo", "bn128"), ("modinv", "bls12381"), ("multiand5", "bn128"),
+                                        ("bigmult_style", "bls12381")])
 def test_reference_runtime_executes_circuits_compiled_from_text(name, prime, libs, tmp_path):
     from oracle import ref_build
     if not os.path.isdir(os.path.join(os.path.dirname(ref_build.__file__), "_ref", prime)) and not ref_build.REF_ROOT.exists():
