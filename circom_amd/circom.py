@@ -28,7 +28,6 @@ prints a Report and "previous errors were found").
 from __future__ import annotations
 
 import argparse
-import json
 import os
 import sys
 

@@ -35,7 +35,7 @@ import sys
 from .. import opcodes as O
 from ..field import fp_for
 from . import dsl
-from .dsl import CircuitError, Expr, SigArray, TemplateSpec, K_CONST
+from .dsl import CircuitError, Expr, SigArray, TemplateSpec
 from .circom_lang import Archive, parse_program, parse_text
 
 

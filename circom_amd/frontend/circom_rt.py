@@ -23,7 +23,7 @@ from __future__ import annotations
 
 from .. import opcodes as O
 from .dsl import CircuitError
-from .rtcode import RtVar, RtArray, F_JMP, F_LDX, F_STX
+from .rtcode import RtVar, RtArray, F_JMP
 from . import circom_exec as X
 
 
