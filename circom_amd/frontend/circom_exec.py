@@ -1027,6 +1027,7 @@ class World:
         self.inspect = False          # --inspect: collect the warnings of constraint_correctness_analysis.rs
         self.warnings = []
         self.typing_warnings = []     # arrays of different lengths assigned to variables (execute.rs:3949-3965)
+        self.template_depth = 0
 
     # ---- templates ----------------------------------------------------------------------------------------------------------
     def spec(self, name, vals, pos):
@@ -1049,7 +1050,16 @@ class World:
             ctx.inst.sig_tags = {}
             ctx.inst.bus_iface = {}
             ctx._bus_decls = ctx.inst._bus_decls = []
-            ex.run_block(body[1])
+            # a template that instantiates itself without ever reaching its base case must end as an error, not as a
+            # stack overflow of the interpreter
+            world.template_depth += 1
+            try:
+                if world.template_depth > 150:
+                    fn_, ln, col = world.archive.where(tpos)
+                    raise CircuitError("%s:%d:%d: template %s: instantiations nested more than 150 deep" % (fn_, ln, col, name))
+                ex.run_block(body[1])
+            finally:
+                world.template_depth -= 1
             if world.inspect:
                 world.inspect_instance(ctx, ex, name, pvals)
             world.finish_instance(ctx)
