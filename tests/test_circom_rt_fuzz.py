@@ -83,3 +83,12 @@ def test_compile_time_and_run_time_execution_agree(seed):
         got, failed = eval_flat(Q, run_time.n_signals, run_time.n_temps, run_time.constants, run_time.code,
                                 {run_time.main_input_start: a, run_time.main_input_start + 1: b}, functions=run_time.functions)
         assert failed is None and got[1] == want[1], (fn, a, b)
+        if run_time.functions:
+            # the bytecode alone, every register but the arguments poisoned: nothing is read before it is written
+            from oracle.field import Field
+            from oracle.tape_eval import run_function
+            f0 = run_time.functions[0]
+            regs = [None] * f0["n_regs"]
+            regs[:2] = [a % Q, b % Q]
+            assert f0["n_args"] == 2 and run_function(Field(Q), f0, regs, 0, run_time.constants)
+            assert regs[f0["ret_base"]] == want[1]
