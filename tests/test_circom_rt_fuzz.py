@@ -34,10 +34,15 @@ def _cond(rng):
     return "(%s %% 7) %s (%s %% 5)" % (_expr(rng, 1), rng.choice(["<", ">", "==", "!=", "<=", ">="]), _expr(rng, 1))
 
 
-def _stmts(rng, depth, n, loop_id):
+def _stmts(rng, depth, n, loop_id, inline_only=False):
     out = []
     for _ in range(n):
         r = rng.random()
+        if inline_only:
+            # only what a trace can if-convert: assignments and `if` / `else` on run-time conditions, known indices
+            r = r * 0.5 if r < 0.68 else 0.7
+            if 0.5 <= r < 0.68:
+                r = 0.1
         if r < 0.35:
             out.append("%s = %s;" % (rng.choice(VARS), _expr(rng)))
         elif r < 0.5:
@@ -47,9 +52,9 @@ def _stmts(rng, depth, n, loop_id):
         elif r < 0.68:
             out.append("%s = t[(%s) %% 4] + 1;" % (rng.choice(VARS), _expr(rng, 1)))
         elif r < 0.85 and depth > 0:
-            s = "if (%s) { %s }" % (_cond(rng), " ".join(_stmts(rng, depth - 1, rng.randint(1, 3), loop_id)))
+            s = "if (%s) { %s }" % (_cond(rng), " ".join(_stmts(rng, depth - 1, rng.randint(1, 3), loop_id, inline_only)))
             if rng.random() < 0.6:
-                s += " else { %s }" % " ".join(_stmts(rng, depth - 1, rng.randint(1, 2), loop_id))
+                s += " else { %s }" % " ".join(_stmts(rng, depth - 1, rng.randint(1, 2), loop_id, inline_only))
             out.append(s)
         elif r < 0.95 and depth > 0:
             loop_id[0] += 1
@@ -63,8 +68,8 @@ def _stmts(rng, depth, n, loop_id):
     return out
 
 
-def _function(rng):
-    body = _stmts(rng, 2, rng.randint(3, 6), [0])
+def _function(rng, inline_only=False):
+    body = _stmts(rng, 2, rng.randint(3, 6), [0], inline_only)
     return ("function f(a, b) {\n    var x = a; var y = b; var z = 1; var t[4] = [1, a, b, 2];\n    %s\n    return %s + t[0] + t[3];\n}\n"
             % ("\n    ".join(body), _expr(rng)))
 
@@ -92,3 +97,22 @@ def test_compile_time_and_run_time_execution_agree(seed):
             regs[:2] = [a % Q, b % Q]
             assert f0["n_args"] == 2 and run_function(Field(Q), f0, regs, 0, run_time.constants)
             assert regs[f0["ret_base"]] == want[1]
+
+
+@pytest.mark.parametrize("seed", range(80))
+def test_if_converted_functions_agree_with_compile_time_execution(seed):
+    """functions without loops, early returns or value-dependent indices are INLINED into the component: their run-time `if`s
+    are if-converted (both arms traced, variables and array elements merged through selects)"""
+    rng = random.Random(9000 + seed)
+    fn = _function(rng, inline_only=True)
+    run_time = flatten(program_from_text(fn + "template T() { signal input a; signal input b; signal output o; o <-- f(a, b); }\n"
+                                              "component main = T();"))
+    assert not run_time.functions
+    for a, b in [(3, 7), (0, 0), (rng.randrange(50), rng.randrange(50)), (Q - 1, 2)]:
+        known = flatten(program_from_text(fn + "template C() { signal input u; signal output o; o <== f(%d, %d) + 0 * u; }\n"
+                                               "component main = C();" % (a, b)))
+        want, failed = eval_flat(Q, known.n_signals, known.n_temps, known.constants, known.code, {known.main_input_start: 0})
+        assert failed is None
+        got, failed = eval_flat(Q, run_time.n_signals, run_time.n_temps, run_time.constants, run_time.code,
+                                {run_time.main_input_start: a, run_time.main_input_start + 1: b})
+        assert failed is None and got[1] == want[1], (fn, a, b)
