@@ -116,3 +116,31 @@ def test_if_converted_functions_agree_with_compile_time_execution(seed):
         got, failed = eval_flat(Q, run_time.n_signals, run_time.n_temps, run_time.constants, run_time.code,
                                 {run_time.main_input_start: a, run_time.main_input_start + 1: b})
         assert failed is None and got[1] == want[1], (fn, a, b)
+
+
+@pytest.mark.parametrize("seed", [501, 507, 523, 540, 577, 611])
+def test_reference_runtime_executes_the_fuzzed_bytecode(seed, tmp_path):
+    """the REFERENCE runtime runs the function as C++ control flow over its own Fr_* calls (oracle/emit_ref_cpp.py prints the
+    bytecode): its witness equals the oracle's"""
+    import os
+    from oracle import ref_build
+    if not ref_build.REF_ROOT.exists():
+        pytest.skip("the reference tree is absent")
+    from circom_amd.compiler import compile_program
+    from circom_amd.hip_elements.writers import wtns_bytes
+    rng = random.Random(seed)
+    fn = _function(rng)
+    prog = program_from_text(fn + "template T() { signal input a; signal input b; signal output o; o <-- f(a, b); }\ncomponent main = T();")
+    cp = compile_program(prog, str(tmp_path), "txt_fuzz_%d" % seed, sym=False, strands=(1,), fpjit=False)
+    fc = cp.flat
+    if not fc.functions:
+        pytest.skip("this one was inlined")
+    rows = [(3, 7), (0, 0), (rng.randrange(50), rng.randrange(50)), (Q - 1, 2), (rng.randrange(Q), rng.randrange(1000))]
+    ref_build.build_circuit(cp)
+    raw = b"".join(int(v).to_bytes(32, "little") for r in rows for v in r)
+    ref_build.run_loop(cp, raw, len(rows), 1, wtns_prefix=str(tmp_path / "w_"))
+    for i, (a, b) in enumerate(rows):
+        sig, failed = eval_flat(Q, fc.n_signals, fc.n_temps, fc.constants, fc.code,
+                                {fc.main_input_start: a, fc.main_input_start + 1: b}, functions=fc.functions)
+        assert failed is None
+        assert (tmp_path / ("w_%d.wtns" % i)).read_bytes() == wtns_bytes(Q, sig)
