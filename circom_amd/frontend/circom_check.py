@@ -40,8 +40,10 @@ class _Checker:
                     self.expr(a[1], scopes, kind)
             return
         if k == "bin":
-            self.expr(e[2], scopes, kind)
-            self.expr(e[3], scopes, kind)
+            while e[0] == "bin":                     # left-deep chains without recursion
+                self.expr(e[3], scopes, kind)
+                e = e[2]
+            self.expr(e, scopes, kind)
         elif k == "un":
             self.expr(e[2], scopes, kind)
         elif k == "tern":

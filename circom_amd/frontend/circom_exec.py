@@ -269,10 +269,16 @@ class Executor:
         if k == "var":
             return self.read(e)
         if k == "bin":
-            op = e[1]
-            a = self.eval(e[2])
-            b = self.eval(e[3])
-            return self.binop(op, a, b, e[-1])
+            # a long sum is a LEFT-deep tree (every infix tier is left associative): walked with a loop, not by recursion
+            chain = []
+            node = e
+            while node[0] == "bin":
+                chain.append(node)
+                node = node[2]
+            acc = self.eval(node)
+            for nd in reversed(chain):
+                acc = self.binop(nd[1], acc, self.eval(nd[3]), nd[-1])
+            return acc
         if k == "un":
             return self.unop(e[1], self.eval(e[2]), e[-1])
         if k == "tern":
@@ -1274,7 +1280,10 @@ def build_program(archive: Archive, prime="bn128", inspect=False):
     prog = dsl.Program.__new__(dsl.Program)
     world.prog = prog
     prog.world = world
-    dsl.Program.__init__(prog, spec, public=(), prime=prime)
+    try:
+        dsl.Program.__init__(prog, spec, public=(), prime=prime)
+    except RecursionError:
+        raise CircuitError("%s: expressions, calls or components nested too deeply" % archive.where(pos)[0]) from None
     # the public list names signals and buses of main: a bus stands for all its fields
     m = prog.main
     buses = {bname: bus for bname, cat, bus in getattr(m, "_bus_decls", ()) if cat == "i"}

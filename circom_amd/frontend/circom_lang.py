@@ -442,6 +442,15 @@ class Parser:
         return t[0] == "id" and t[1] == kw
 
     def statement(self):
+        self.sdepth = getattr(self, "sdepth", 0) + 1
+        try:
+            if self.sdepth > self.MAX_NESTING:
+                self.err("block nested too deeply")
+            return self._statement()
+        finally:
+            self.sdepth -= 1
+
+    def _statement(self):
         t0 = self.peek()
         pos = self.pos(t0)
         if self.at_kw("if"):
@@ -570,12 +579,20 @@ class Parser:
             out.append(self.expression())
         return out
 
+    MAX_NESTING = 200      # parentheses / brackets / calls inside one another, blocks inside one another
+
     def expression(self):
         t0 = self.peek()
-        if self.at_kw("parallel"):
-            self.p += 1
-            return ("parallel", self.expression1(), self.pos(t0))
-        return self.expression1()
+        self.depth = getattr(self, "depth", 0) + 1
+        try:
+            if self.depth > self.MAX_NESTING:
+                self.err("expression nested too deeply")
+            if self.at_kw("parallel"):
+                self.p += 1
+                return ("parallel", self.expression1(), self.pos(t0))
+            return self.expression1()
+        finally:
+            self.depth -= 1
 
     def expression1(self):
         t0 = self.peek()
@@ -746,7 +763,10 @@ def _load(path, libs, archive, text=None, name=None):
             nm = p
         src = Source(len(ar.sources), nm, text)
         ar.sources.append(src)
-        ast = Parser(src).parse_file()
+        try:
+            ast = Parser(src).parse_file()
+        except RecursionError:
+            raise CircomSyntaxError("expression or block nested too deeply", nm) from None
         if first:
             ar.version = ast["version"]
         ar.custom_templates = ar.custom_templates or ast["custom_templates"]

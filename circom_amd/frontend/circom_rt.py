@@ -206,9 +206,15 @@ class RtCompiler:
         if k == "var":
             return self.read(e)
         if k == "bin":
-            a = self.eval(e[2])
-            b = self.eval(e[3])
-            return self.binop(e[1], a, b, e[-1])
+            chain = []
+            node = e
+            while node[0] == "bin":
+                chain.append(node)
+                node = node[2]
+            acc = self.eval(node)
+            for nd in reversed(chain):
+                acc = self.binop(nd[1], acc, self.eval(nd[3]), nd[-1])
+            return acc
         if k == "un":
             return self.unop(e[1], self.eval(e[2]), e[-1])
         if k == "tern":

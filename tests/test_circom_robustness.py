@@ -52,3 +52,14 @@ def test_runaway_template_recursion_is_an_error():
     with pytest.raises(CircuitError, match="nested too deeply"):
         program_from_text("function f(n) { return f(n + 1); } template T() { signal input a; signal output o; o <== a * f(0); } "
                           "component main = T();")
+
+
+def test_pathological_nesting_is_a_front_end_error():
+    deep = "(" * 3000 + "a" + ")" * 3000
+    with pytest.raises((CircomSyntaxError, CircuitError), match="nested too deeply"):
+        program_from_text("template T() { signal input a; signal output o; o <== %s; }\ncomponent main = T();" % deep)
+    # a LONG expression is not a deep one: 12 000 terms
+    from circom_amd.frontend.flatten import flatten
+    src = "template T() { signal input a; signal output o; o <== %s; }\ncomponent main = T();" \
+          % " + ".join("a * %d" % (i % 7 + 1) for i in range(12000))
+    assert len(flatten(program_from_text(src)).constraints) == 1
