@@ -9,15 +9,17 @@ control flow over `Fr_isTrue` (loop_bucket.rs:76-91, branch_bucket.rs:100-122) a
   * a value is a Python int (known while compiling), a register / constant of the function (RtVar), or a nested list;
     arguments that are known at the call site (limb sizes, counts) are baked into the specialisation, so the loops over
     limbs unroll and only data-dependent control flow is left as jumps;
-  * before a run-time region (an `if` or `while` on a register) is entered, every visible variable the region assigns is
-    PINNED: scalars to a register, arrays to a contiguous block.  Inside and after the region assignments to a pinned
-    variable are in-place copies, so values flow around the loop and out of both arms without merges;
+  * before a run-time region (an `if` or `while` on a register) is entered, what the region assigns is PINNED: a scalar
+    variable to a register, of an array variable the ELEMENTS the region assigns (`Cell`; the region is built once as a scout
+    to learn them, the builder is rolled back, and the region is built again - `_region`), an array that is indexed by a
+    run-time value to a contiguous block.  Inside and after the region assignments to a pinned location are in-place copies,
+    so values flow around the loop and out of both arms without merges;
   * a pinned register bound to another variable, stored into an array or returned is copied first (a pinned register is a
     location, not a value);
   * an array read or written at a run-time index is a block access (F_LDX / F_STX; the linear index of a multi-dimensional
     array is computed at run time); an unpinned array read that way is materialised into a block first;
-  * `return` copies into the function's result registers and jumps to its end; nested calls are inlined (their arguments by
-    value, their own result registers and end label).
+  * `return` copies into the function's result registers and jumps to its end - unless it is the function's only exit, whose
+    value is handed back as it is; nested calls are inlined (their arguments by value, their own result registers and end label).
 """
 from __future__ import annotations
 
