@@ -109,6 +109,8 @@ def files_fingerprint(files) -> str:
 def artefact_fingerprint() -> str:
     """Hash of what shapes the compiled artefacts (.cwt/.dat/.r1cs): the Python front-end and lowering, the circuit
     library and the tape format - NOT the kernels, so that a kernel change does not invalidate a cached schedule."""
+    if os.environ.get("CW_ARTEFACT_FP"):          # experiments: artefacts prebuilt under this key (tools/), whatever the tree says now
+        return os.environ["CW_ARTEFACT_FP"]
     h = hashlib.sha256()
     # (frontend/circom_*.py, the front-end for circom SOURCE TEXT, is left out: the bench's circuits are traced from the eDSL)
     files = sorted((ROOT / "circom_amd" / "hip_elements").glob("*.py")) \
@@ -161,6 +163,13 @@ def get_compiled(name: str, batch: int, cache_root: str, rank: int, dist):
     t0 = time.perf_counter()
     fc = flatten(make_program(name))
     done = os.path.join(d, "done")
+    lock = None
+    if rank == 0:
+        # several processes of one box may want the same artefacts (pytest-xdist workers): one lowers, the others wait and load
+        import fcntl
+        os.makedirs(cache_root, exist_ok=True)
+        lock = open(d + ".lock", "w")
+        fcntl.flock(lock, fcntl.LOCK_EX)
     cached = os.path.exists(done)
     if cached and rank == 0:
         # large artefacts travel compressed (tools/prebuild_cache.py: the .r1cs of the ECDSA verifier is 407 MB, 34 MB gzipped)
@@ -183,17 +192,17 @@ def get_compiled(name: str, batch: int, cache_root: str, rank: int, dist):
         tapes = [lower(fc, n_strands=s, mont=mont) for s in strands]
         jp = compiler.emit_jit(compiler.lower_bitplane.net, fc) if bittape is not None else None     # the same network as emitted code
         compiler.lower_bitplane.net = None
-        # arithmetic circuits: the rows of every strand variant as emitted code as well (hip_elements/fpjit.py)
-        # (config 5's verifier is beyond the automatic size limit - 3.3 M rows, a 590 MB code object, a quarter of an hour
-        # of lowering - and worth it: 2.5x the interpreter; its batches never reach the fused check's regime)
-        big = name == "ecdsa_verify"
-        fps = compiler.emit_fpjit(tapes, fc, False if bittape is not None else (True if big else "auto"), fuse_check=not big)
+        # arithmetic circuits: the rows of every strand variant as emitted code as well (hip_elements/fpjit.py); schedules with
+        # run-time functions on several strands / with the native long_div (config 5's verifier) run on the interpreting kernel
+        fps = compiler.emit_fpjit(tapes, fc, False if bittape is not None else "auto")
         writers.write_tape(p(".cwt"), tapes, bittape, jp, fps)
         json.dump(jp.stats if jp is not None else {}, open(p(".jit.json"), "w"))
         json.dump([dict(fp_.stats, n_strands=fp_.n_strands, code_bytes=len(fp_.code)) for fp_ in fps], open(p(".fpjit.json"), "w"))
         writers.write_dat(p(".dat"), fc)
         writers.write_r1cs(p(".r1cs"), fc)
         open(done, "w").write(fp)
+    if lock is not None:
+        lock.close()                    # (releases the flock)
     if dist:
         dist.barrier()
     cp = compiler.Compiled(name, d, p(".cwt"), p(".dat"), p(".r1cs"), p(".sym"), fc, None)

@@ -132,6 +132,11 @@ def mod_inv(f, n, k, a, p):
 
 
 # ---- whole functions (what a template calls) ----------------------------------------------------------------------------------
+def native_n_args(kind: str, k: int, p: int) -> int:
+    """arguments a native form reads (its results follow them); for "long_div" the tag's last field is m"""
+    return {"mod_inv": k, "ec_add": 4 * k, "ec_double": 2 * k, "long_div": 2 * k + p}[kind]
+
+
 def build_long_div(n, k, m):
     """long_div(n, k, m, a[k + m], b[k]) -> div[m + 1] ++ mod[k]"""
     def build(f, *args):
@@ -198,4 +203,13 @@ def native_eval(kind: str, n: int, k: int, p: int, args):
         x3 = (lam * lam - 2 * x1) % p
         y3 = (lam * (x1 - x3) - y1) % p
         return limbs_of(lam, n, k) + limbs_of(x3, n, k) + limbs_of(y3, n, k)
+    if kind == "long_div":
+        # the fourth field of the tag is m, not a modulus: a[k + m], b[k] -> div[m + 1] ++ mod[k].  Contract: proper limbs and
+        # b[k-1] != 0 (then div fits m + 1 limbs and the pair is unique, so Knuth D in base 2^n - the body - finds the same one);
+        # templates only tag calls whose divisor is a compile-time constant (CheckZeroModP divides by the foreign prime)
+        m = p
+        a, b = int_of(args[:k + m], n), int_of(args[k + m:2 * k + m], n)
+        if args[2 * k + m - 1] == 0:
+            raise ZeroDivisionError("long_div native form: the divisor's top limb is zero (contract of the tag)")
+        return limbs_of(a // b, n, m + 1) + limbs_of(a % b, n, k)
     raise ValueError(kind)

@@ -112,7 +112,10 @@ def CheckZeroModP(c, n, k, m, B, p):
         t = (inp[i] + C[i] + carry) if i < m else carry
         proper.append(t % (1 << n))
         carry = t // (1 << n)
-    fn = c.function("long_div_%d_%d_%d" % (n, k, M - k), M + k, BF.build_long_div(n, k, M - k))
+    # the divisor is the constant prime (top limb != 0) and the dividend's limbs are proper by construction: the quotient /
+    # remainder pair is unique, so the function carries its closed form (bigint_func.native_eval "long_div")
+    fn = c.function("long_div_%d_%d_%d" % (n, k, M - k), M + k, BF.build_long_div(n, k, M - k),
+                    native=("long_div", n, k, M - k) if BF.limbs_of(p, n, k)[k - 1] != 0 else None)
     res = c.call(fn, proper + BF.limbs_of(p, n, k))
     Lq = M - k + 1
     q = c.signal("q", Lq)

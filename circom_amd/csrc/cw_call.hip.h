@@ -87,6 +87,159 @@ __device__ __forceinline__ void big_unpack(char *regs, uint32_t first, uint32_t 
         fn_store(first + i, regs, c, l);
     }
 }
+// long_div (kind 4): a[k + m], b[k] -> div[m + 1] ++ mod[k] with a = div * b + mod, 0 <= mod < b (bigint_func.circom long_div:
+// Knuth D in base 2^n on registers, ~10^5 interpreted instructions per call).  Contract of the tag (circuits/bigint_func.py):
+// proper limbs (< 2^n), b[k-1] != 0 - then the quotient has m + 1 limbs and the pair is unique, whatever algorithm finds it.
+// Here: Knuth D in base 2^32 on the packed numbers - the divisor normalised per lane to 256 bits (as fe_divmod), the dividend
+// (up to CW_LD_WORDS words) shifted along; ftab[fn].w = 4 | k << 4 | n << 8 | m << 16.  A lane whose divisor breaks the
+// contract is flagged (CW_ST_ARITH): templates only tag calls whose divisor is a compile-time constant.
+#define CW_LD_WORDS 20
+__device__ CW_CALL_NATIVE void eval_call_long_div(uint32_t w, char *regs, uint32_t row_id, uint32_t &st, const EvalCtx &c) {
+    const uint32_t k = (w >> 4) & 15u, n = (w >> 8) & 255u, m = w >> 16;
+    constexpr int NW = CW_LD_WORDS, NX = CW_LD_WORDS + 8;
+    uint32_t X[NX];
+    FE_UNROLL for (int j = 0; j < NX; j++) X[j] = 0;
+    const fe B0 = big_pack(regs, k + m, k, n, c);
+    {   // the top limb of the divisor (contract) - and with it B0 != 0
+        const fe top = fn_operand(2 * k + m - 1, regs, c);
+        uint32_t any = 0;
+        FE_UNROLL for (int j = 0; j < 8; j++) any |= top.v[j];
+        if (any == 0) cw_fail(st, CW_ST_ARITH, row_id);
+    }
+    fe B = B0;
+    if (fe_is_zero(B)) B.v[0] = 1;
+    // dividend: limb i at bit n * i (wave-uniform positions)
+    if (n == 64) {
+        FE_UNROLL for (int i = 0; i < NW / 2; i++)
+            if ((uint32_t)i < k + m) {
+                const fe l = fn_operand(i, regs, c);
+                X[2 * i] = l.v[0];
+                X[2 * i + 1] = l.v[1];
+            }
+    } else if (n == 32) {
+        FE_UNROLL for (int i = 0; i < NW; i++)
+            if ((uint32_t)i < k + m) X[i] = fn_operand(i, regs, c).v[0];
+    } else {
+        for (uint32_t i = 0; i < k + m; i++) {
+            const fe l = fn_operand(i, regs, c);
+            const uint64_t v = ((uint64_t)l.v[1] << 32) | l.v[0];
+            const uint32_t sh = n * i, w0 = sh >> 5, bs = sh & 31u;                 // wave-uniform
+            const uint64_t lo = v << bs;
+            const uint32_t hi = bs ? (uint32_t)(v >> (64 - bs)) : 0u;
+            FE_UNROLL for (int j = 0; j < NW; j++)
+                X[j] |= ((uint32_t)j == w0 ? (uint32_t)lo : 0u) | ((uint32_t)j == w0 + 1 ? (uint32_t)(lo >> 32) : 0u) | ((uint32_t)j == w0 + 2 ? hi : 0u);
+        }
+    }
+    // normalise: V = B << s has its top bit set; the dividend moves by the same (per-lane) amount
+    const uint32_t s = fe_clz256(B) & 255u;
+    const fe V = fe_shl_raw(B, s);
+    {
+        const bool s4 = s & 128, s2 = s & 64, s1 = s & 32;
+        FE_UNROLL for (int j = NX - 1; j >= 0; j--) X[j] = s4 ? (j >= 4 ? X[j >= 4 ? j - 4 : 0] : 0u) : X[j];
+        FE_UNROLL for (int j = NX - 1; j >= 0; j--) X[j] = s2 ? (j >= 2 ? X[j >= 2 ? j - 2 : 0] : 0u) : X[j];
+        FE_UNROLL for (int j = NX - 1; j >= 0; j--) X[j] = s1 ? (j >= 1 ? X[j >= 1 ? j - 1 : 0] : 0u) : X[j];
+        const uint32_t bs = s & 31u, rs = (32u - bs) & 31u;
+        FE_UNROLL for (int j = NX - 1; j >= 1; j--) X[j] = bs ? __builtin_amdgcn_alignbit(X[j], X[j - 1], rs) : X[j];
+        X[0] <<= bs;
+    }
+    // the quotient is below 2^(32 NW): the eight top words of the shifted dividend are the first partial remainder (< V)
+    uint32_t r[9];
+    FE_UNROLL for (int j = 0; j < 8; j++) r[j] = X[NW + j];
+    r[8] = 0;
+    const uint32_t v7 = V.v[7], v6 = V.v[6];
+    // One digit per trip, as a LOOP (unrolled it is NW copies of ~300 instructions): the dividend leaves X at the top while the
+    // quotient enters at the bottom, so every trip works on fixed registers and X[0 .. NW) ends as the quotient.
+#pragma clang loop unroll(disable)
+    for (int it = 0; it < NW; it++) {
+        FE_UNROLL for (int t = 8; t >= 1; t--) r[t] = r[t - 1];
+        r[0] = X[NW - 1];
+        FE_UNROLL for (int t = NW - 1; t >= 1; t--) X[t] = X[t - 1];
+        X[0] = 0;                                                     // this trip's quotient digit
+        bool lt = false, decided = r[8] != 0;
+        FE_UNROLL for (int t = 7; t >= 0; t--) {
+            if (!decided && r[t] != V.v[t]) { lt = r[t] < V.v[t]; decided = true; }
+        }
+        if (!__any(!lt)) continue;                                    // every lane's digit is zero
+        const uint64_t nn = ((uint64_t)r[8] << 32) | r[7];
+        uint64_t qh = nn / v7;
+        if (qh > 0xFFFFFFFFull) qh = 0xFFFFFFFFull;
+        uint64_t rh = nn - qh * v7;
+        FE_UNROLL for (int t = 0; t < 2; t++) {
+            const bool dec = rh <= 0xFFFFFFFFull && qh * (uint64_t)v6 > ((rh << 32) | r[6]);
+            qh -= dec ? 1u : 0u;
+            rh += dec ? v7 : 0u;
+        }
+        const uint32_t qd = (uint32_t)qh;
+        uint64_t carry = 0;
+        int64_t br = 0;
+        FE_UNROLL for (int t = 0; t < 8; t++) {
+            const uint64_t p = (uint64_t)qd * V.v[t] + carry;
+            carry = p >> 32;
+            const int64_t d = (int64_t)r[t] - (int64_t)(uint32_t)p + br;
+            r[t] = (uint32_t)d;
+            br = d >> 32;
+        }
+        const int64_t t8 = (int64_t)r[8] - (int64_t)carry + br;
+        r[8] = (uint32_t)t8;
+        bool neg = t8 < 0;
+        uint32_t qfix = 0;
+        FE_UNROLL for (int t = 0; t < 2; t++) {
+            uint64_t cc = 0;
+            uint32_t a9[9];
+            FE_UNROLL for (int u = 0; u < 8; u++) {
+                cc += (uint64_t)r[u] + V.v[u];
+                a9[u] = (uint32_t)cc;
+                cc >>= 32;
+            }
+            cc += (uint64_t)r[8];
+            a9[8] = (uint32_t)cc;
+            const bool wrapped = (cc >> 32) != 0;
+            FE_UNROLL for (int u = 0; u < 9; u++) r[u] = neg ? a9[u] : r[u];
+            qfix += neg ? 1u : 0u;
+            neg = neg && !wrapped;
+        }
+        X[0] = qd - qfix;
+    }
+    // results behind the arguments: div[m + 1], then mod[k]
+    const uint32_t rb = 2 * k + m;
+    fe rn;
+    FE_UNROLL for (int j = 0; j < 8; j++) rn.v[j] = r[j];
+    big_unpack(regs, rb + m + 1, k, n, c, fe_shr_raw(rn, s));
+    if (n == 64) {
+        FE_UNROLL for (int i = 0; i < NW / 2; i++)
+            if ((uint32_t)i <= m) {
+                fe l = fe_zero();
+                l.v[0] = X[2 * i];
+                l.v[1] = X[2 * i + 1];
+                fn_store(rb + i, regs, c, l);
+            }
+    } else if (n == 32) {
+        FE_UNROLL for (int i = 0; i < NW; i++)
+            if ((uint32_t)i <= m) {
+                fe l = fe_zero();
+                l.v[0] = X[i];
+                fn_store(rb + i, regs, c, l);
+            }
+    } else {
+        for (uint32_t i = 0; i <= m; i++) {
+            const uint32_t sh = n * i, w0 = sh >> 5, bs = sh & 31u;                 // wave-uniform
+            uint32_t x0 = 0, x1 = 0, x2 = 0;
+            FE_UNROLL for (int j = 0; j < NW; j++) {
+                x0 |= (uint32_t)j == w0 ? X[j] : 0u;
+                x1 |= (uint32_t)j == w0 + 1 ? X[j] : 0u;
+                x2 |= (uint32_t)j == w0 + 2 ? X[j] : 0u;
+            }
+            const uint64_t lo = (((uint64_t)x1 << 32) | x0) >> bs;
+            const uint64_t v = lo | (bs ? ((uint64_t)x2 << (64 - bs)) : 0ull);
+            const uint64_t mk = n >= 64 ? ~0ull : ((1ull << n) - 1);
+            fe l = fe_zero();
+            l.v[0] = (uint32_t)(v & mk);
+            l.v[1] = (uint32_t)((v & mk) >> 32);
+            fn_store(rb + i, regs, c, l);
+        }
+    }
+}
+
 __device__ CW_CALL_NATIVE void eval_call_native(uint32_t w, char *regs, const EvalCtx &c) {
     const uint32_t kind = w & 15u, k = (w >> 4) & 15u, n = (w >> 8) & 255u;
     const FpParams P2 = *(const FpParams *)(c.ftab + (w >> 16));               // wave-uniform: scalar loads
@@ -120,6 +273,12 @@ __device__ __forceinline__ void eval_call_body(uint32_t fn, uint64_t reg_off, ui
     const uint4 ft = c.ftab[fn];
     const uint4 *code = c.fcode + ft.x;
     char *regs = (char *)c.Vb + reg_off;
+#ifndef CW_NO_NATIVE_LONG_DIV            // (the emitted code's `call` body is built without it: fpjit.py keeps such programs on the interpreting kernel)
+    if ((ft.w & 15u) == 4u) {
+        eval_call_long_div(ft.w, regs, row_id, st, c);
+        return;
+    }
+#endif
     if (ft.w & 15u) {
         eval_call_native(ft.w, regs, c);
         return;

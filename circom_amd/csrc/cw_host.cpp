@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <string>
 #include <unordered_map>
@@ -277,6 +278,9 @@ struct cw_circuit {
     struct LogItem { bool is_value = false; uint32_t value = 0; std::string text; };
     struct LogStmt { uint32_t at = 0; std::vector<LogItem> items; };      // at = flat operation that ends the statement
     std::vector<LogStmt> logs;
+    // batches alive on this circuit (side batches included): their device images of the witness list (d_w2s, d_wslot,
+    // d_gather) are sized once at creation, so the list may only change while this is zero (cw_set_witness_list)
+    std::atomic<int> live_batches{0};
 };
 
 static uint64_t fnv1a(const char *s, size_t n) {   // calcwit.cpp:17-24
@@ -346,10 +350,16 @@ static const char *validate_variant(const Variant &v, uint32_t n_signals, uint32
                 if (bk == K_CONST ? row.b >= n_consts : (bk != 0 || row.b != 0)) return "constant out of range";
             } else if (op == D_BIT) {
                 if (!operand_ok(ak, row.a)) return "operand out of range";
+            } else if (op == D_BITS) {
+                // b = first bit; the destinations are the extra entries (X_NEXT = next bit), value-table slots below 2^29
+                if (!operand_ok(ak, row.a) || dk != KD_NONE || row.b >= 256 || nx == 0) return "bit-field row malformed";
+                if (n_signals >= X_NEXT || v.n_tslots >= X_NEXT) return "bit-field rows need slot numbers below 2^29";
+                uint32_t last = row.b;
+                for (uint32_t e = 0; e < nx && xp + e < nextras; e++) last += (v.extras[xp + e] & X_NEXT) ? 1u : 0u;
+                if (last >= 256) return "bit-field row runs past bit 255";
             } else if (op == D_CALL) {
                 // a = function id; b = first register: the whole window must lie inside the temp slots
                 if (row.a >= fn_regs.size() || bk != K_TMP || (uint64_t)row.b + fn_regs[row.a] > v.n_tslots) return "function call out of range";
-                if (v.n_strands != 1) return "function calls need a single-strand schedule";
             } else {
                 if (!operand_ok(ak, row.a)) return "operand out of range";
                 const bool pair = (op == D_MULC || op == D_MADDC);
@@ -357,7 +367,11 @@ static const char *validate_variant(const Variant &v, uint32_t n_signals, uint32
             }
             if (xp + nx > v.extra_off[st + 1]) return "extra destinations overrun their strand";
             for (uint32_t e = 0; e < nx; e++) {
-                const uint32_t x = v.extras[xp + e];
+                uint32_t x = v.extras[xp + e];
+                if (op == D_BITS) {
+                    if (x & X_LDS) return "bit-field destinations live in the value table";
+                    x &= ~X_NEXT;
+                }
                 if (x & X_TMP ? (x & 0x3FFFFFFFu) >= v.n_tslots : x & X_LDS ? (x & 0x3FFFFFFFu) >= v.n_lds : x >= n_signals)
                     return "extra destination out of range";
             }
@@ -705,7 +719,16 @@ static int load_tape(cw_circuit *c, const char *path) {
         c->fn_tab.push_back(n_ins);
         c->fn_tab.push_back(n_regs);
         c->fn_tab.push_back(0);
-        if (nat_kind) {
+        if (nat_kind == 4) {
+            // long_div(a[k + m], b[k]) -> div[m + 1] ++ mod[k] (csrc/cw_call.hip.h eval_call_long_div): m travels in the modulus field
+            const uint32_t nat_m = fmod.w[0];
+            bool small = true;
+            for (int t = 1; t < 8; t++) small = small && fmod.w[t] == 0;
+            if (!small || nat_n < 32 || nat_n > 64 || nat_k == 0 || nat_k > 15 || nat_n * nat_k > 256 || nat_m == 0 || nat_m > 15 ||
+                (nat_k + nat_m) * nat_n > 640 || 3 * nat_k + 2 * nat_m + 1 > n_regs)
+                return fail(CW_EIO, "tape function: bad native tag");
+            c->fn_tab[c->fn_tab.size() - 1] = 4u | (nat_k << 4) | (nat_n << 8) | (nat_m << 16);
+        } else if (nat_kind) {
             // a pure big-integer function with a closed form (circuits/bigint_func.py): mod_inv(a[k]) -> [k];
             // ec_add(x1, y1, x2, y2) / ec_double(x1, y1) -> lambda, x3, y3 - arguments in the first registers, results behind them
             const uint32_t n_args = nat_kind == 1 ? nat_k : nat_kind == 2 ? 4 * nat_k : 2 * nat_k;
@@ -1209,6 +1232,7 @@ static int load_r1cs(cw_circuit *c, const char *path) {
             if (dk == K_SIG && row.dst < c->n_signals) defpos[row.dst] = (uint32_t)r + 1;
             for (uint32_t e = 0; e < nx; e++) {
                 uint32_t x = v0.extras[xp + e];
+                if (op == D_BITS) x &= ~X_NEXT;
                 if (!(x & (X_TMP | X_LDS)) && x < c->n_signals) defpos[x] = (uint32_t)r + 1;
             }
             xp += nx;
@@ -1298,6 +1322,9 @@ extern "C" uint32_t cw_n_inputs(const cw_circuit *c) { return c->n_inputs; }
 // entries are the ones of the current list (outputs and public inputs are never simplified away).
 extern "C" int cw_set_witness_list(cw_circuit *c, const uint32_t *signals, uint32_t n) {
     if (!c || !signals || n == 0) return fail(CW_EINVAL, "cw_set_witness_list: bad argument");
+    if (c->live_batches.load() > 0)
+        return fail(CW_EINVAL, "cw_set_witness_list: the circuit has live batches (their device images of the list are sized at creation): "
+                               "set the list before cw_batch_create, or free the batches first");
     const uint32_t np = 1 + cw_n_public(c);
     if (n < np || n > c->n_signals - c->n_logv) return fail(CW_EINVAL, "cw_set_witness_list: list length out of range");
     for (uint32_t i = 0; i < n; i++) {
@@ -1436,7 +1463,12 @@ struct cw_batch {
     uint64_t *d_V64 = nullptr, *d_consts64 = nullptr;
     uint32_t *d_rows64 = nullptr, *d_terms64 = nullptr;
     uint64_t *d_r1flag = nullptr;                      // per group: instances whose fused R1CS check fired (emitted code)
+    // cw_batch_set_timing: events on the batch's stream around the parts of cw_run / cw_check_r1cs (their own intervals, measured
+    // where they run - bench.py's roofline figures): 0 run begins | 1 inputs ingested | 2 evaluation done | 3 check begins | 4 check done
+    bool timing = false;
+    hipEvent_t tev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
+#define TMARK(b, k) do { if ((b)->timing) hipEventRecord((b)->tev[k], (b)->stream); } while (0)
 
 template <typename T>
 static hipError_t upload(T **dst, const std::vector<T> &src, hipStream_t s) {
@@ -1449,12 +1481,15 @@ static hipError_t upload(T **dst, const std::vector<T> &src, hipStream_t s) {
 
 extern "C" void cw_batch_free(cw_batch *b) {
     if (!b) return;
+    if (b->c) b->c->live_batches--;
     if (b->device < 0) {
         delete b;
         return;
     }
     hipSetDevice(b->device);
     hipStreamSynchronize(b->stream);
+    for (hipEvent_t e : b->tev)
+        if (e) hipEventDestroy(e);
     if (b->fb) cw_batch_free(b->fb);
     void *bptrs[] = {b->d_V64, b->d_consts64, b->d_rows64, b->d_terms64, b->d_T, b->d_fbmask, b->d_r1flag, b->d_brecs, b->d_bcmds, b->d_aslots, b->d_wslot, b->d_fbinst, b->d_erecs, b->d_wchunk, b->d_wterms, b->d_wctab, b->d_wrow,
                      b->d_ichunk, b->d_iterms, b->d_itab, b->d_irow, b->d_sigslot};
@@ -1490,6 +1525,7 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
         // anything that computes fails loudly.
         cw_batch *hb = new cw_batch();
         hb->c = c;
+        c->live_batches++;
         hb->device = -1;
         hb->batch = batch;
         hb->Bp = (batch + 255) / 256 * 256;
@@ -1503,6 +1539,7 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
     HIPCHK(hipSetDevice(device));
     cw_batch *b = new cw_batch();
     b->c = c;
+    c->live_batches++;
     b->device = device;
     b->batch = batch;
     b->Bp = (batch + 255) / 256 * 256;
@@ -1711,9 +1748,10 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
         };
         std::vector<CwDRow> drows;
         std::vector<uint32_t> doff(1, 0);
+        std::vector<uint8_t> bits_entry(v.extras.size(), 0);          // extra-destination entries of D_BITS rows
         drows.reserve(v.rows.size() + 3 * v.n_strands);
         for (uint32_t st = 0; st < v.n_strands; st++) {
-            size_t sq = v.seq_off[st];
+            size_t sq = v.seq_off[st], xq = v.extra_off[st];
             for (uint32_t r = v.stream_off[st]; r < v.stream_off[st + 1]; r++) {
                 const CwRow &row = v.rows[r];
                 uint32_t op = row.w0 & 0xFF, dk = (row.w0 >> SH_DK) & 7, ak = (row.w0 >> SH_AK) & 7,
@@ -1735,17 +1773,22 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
                     d.dst_off = seq;                                 // reported if the function fails (no destination)
                     d.a_off = 0;
                     d.b_off = resolve(K_TMP, row.b);                 // first register of the call's window
-                } else if (op == D_BIT) {
-                    d.aux = row.b;                                   // bit index k
+                } else if (op == D_BIT || op == D_BITS) {
+                    d.aux = row.b;                                   // bit index k (D_BITS: of the first bit)
                     d.dst_off = dk == KD_NONE ? 0 : resolve(dk, row.dst);
                     d.a_off = resolve(ak, row.a);
                     d.b_off = 0;
+                    if (op == D_BITS) {                              // its entries carry X_NEXT (bit 29 is not part of their slot number)
+                        const uint32_t nx = (row.w0 >> SH_NX) & 0xFFF;
+                        for (uint32_t e = 0; e < nx; e++) bits_entry[xq + e] = 1;
+                    }
                 } else {
                     d.aux = seq;                                     // flat operation, reported in the status word
                     d.dst_off = dk == KD_NONE ? 0 : resolve(dk, row.dst);
                     d.a_off = resolve(ak, row.a);
                     d.b_off = resolve(bk, row.b);
                 }
+                if (op != D_BARRIER) xq += (row.w0 >> SH_NX) & 0xFFF;
                 drows.push_back(d);
             }
             doff.push_back((uint32_t)drows.size());
@@ -1762,7 +1805,8 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
         std::vector<uint64_t> dex(v.extras.size());
         for (size_t k = 0; k < v.extras.size(); k++) {
             uint32_t x = v.extras[k];
-            if (x & X_LDS) dex[k] = (1ull << 63) | ((uint64_t)(x & 0x3FFFFFFFu) * lds_slot);
+            if (bits_entry[k]) dex[k] = ((x & X_NEXT) ? X_NEXT_DEV : 0ull) | resolve((x & X_TMP) ? K_TMP : K_SIG, x & 0x1FFFFFFFu);
+            else if (x & X_LDS) dex[k] = (1ull << 63) | ((uint64_t)(x & 0x3FFFFFFFu) * lds_slot);
             else dex[k] = resolve((x & X_TMP) ? K_TMP : K_SIG, x & 0x3FFFFFFFu);
         }
         // stream offsets now refer to the padded array: stream s starts at doff[s] + 3*s ... keep explicit table
@@ -2324,11 +2368,13 @@ static int bits_batch_setup(cw_batch *b) {
 static int bits_run(cw_batch *b, const void *in) {
     cw_circuit *c = b->c;
     const cwbits::Program &bp = c->bits;
+    TMARK(b, 0);
     BTRY(cwk_bits_init(b->stream, b->d_T, b->bits_slots, b->bits_sh, b->n_groups_padded, b->d_fbmask, b->d_r1flag, b->d_status, b->d_first_bad, b->Bp));
     if (b->packed_in)
         BTRY(cwk_bits_ingest_packed(b->stream, b->packed_in, b->d_T, b->bits_slots, b->bits_sh, cwbits::IN_BASE, c->n_inputs, b->batch));
     else
         BTRY(cwk_bits_ingest(b->stream, in, b->d_T, b->bits_slots, b->bits_sh, cwbits::IN_BASE, c->n_inputs, b->batch, b->d_fbmask));
+    TMARK(b, 1);
     if (b->jit) {
         // one wave per chunk of 2 048 instances runs the circuit's emitted code: gates on registers, every signal value stored
         // once, assertion gates and the fused R1CS check OR-ed into the two flag arrays
@@ -2341,6 +2387,7 @@ static int bits_run(cw_batch *b, const void *in) {
         BTRY(cwk_bits_eval(b->stream, b->d_brecs, b->d_bcmds, b->bits_steps, bp.ring, bp.cache, b->d_T, bp.n_slots, b->n_groups, b->bits_width,
                            b->d_aslots, (uint32_t)bp.assert_slots.size(), b->d_fbmask));
     }
+    TMARK(b, 2);
     b->resolved = false;
     b->checked = false;
     return CW_OK;
@@ -2440,12 +2487,15 @@ extern "C" int cw_run(cw_batch *b) {
         if (rc == CW_OK) b->ran = true;
         return rc;
     }
+    TMARK(b, 0);
     HIPCHK(cwk_init(b->stream, b->d_V, b->Bp, b->d_status, b->d_first_bad, c->mont, c->P));
     HIPCHK(cwk_ingest(b->stream, in, b->d_V, c->input_start, c->n_inputs, b->batch, b->Bp, c->mont, c->P));
+    TMARK(b, 1);
     if (b->var->kind == 1) {
         HIPCHK(cwk_eval_pipe(b->stream, c->need_full, false, b->var->nb, b->var->nld, b->d_prows, (uint32_t)(b->var->prows.size() / 8),
                              b->d_ploads, b->d_terms, b->d_V, b->d_consts, b->d_lconsts, (uint64_t)2 * b->Bp * 16, b->Bp, b->batch,
                              b->lanes, b->d_status, c->P));
+        TMARK(b, 2);
         b->ran = true;
         return CW_OK;
     }
@@ -2470,6 +2520,7 @@ extern "C" int cw_run(cw_batch *b) {
         void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
         HIPCHK(hipModuleLaunchKernel(b->fp_fn, (b->batch + b->lanes - 1) / b->lanes, 1, 1, 64 * b->var->n_strands, 1, 1, 0, b->stream,
                                      nullptr, cfg));
+        TMARK(b, 2);
         b->ran = true;
         return CW_OK;
     }
@@ -2477,7 +2528,38 @@ extern "C" int cw_run(cw_batch *b) {
                     b->d_term_off, b->var->n_strands, b->var->n_lds, b->d_V, b->d_consts, b->d_lconsts,
                     c->fn_tab.empty() ? nullptr : b->d_fncode /* non-null selects the single-wave interpreter build */, b->d_fntab,
                     (uint64_t)2 * b->Bp * 16, b->Bp, b->batch, b->lanes, b->prio_mask, b->d_status, c->P));
+    TMARK(b, 2);
     b->ran = true;
+    return CW_OK;
+}
+
+extern "C" int cw_batch_set_timing(cw_batch *b, int on) {
+    if (!b) return fail(CW_EINVAL, "null batch");
+    NEED_DEVICE(b);
+    HIPCHK(hipSetDevice(b->device));
+    if (on)
+        for (hipEvent_t &e : b->tev)
+            if (!e) HIPCHK(hipEventCreate(&e));
+    b->timing = on != 0;
+    return CW_OK;
+}
+
+// ms[0] = table init + input ingest, ms[1] = the evaluation kernel(s), ms[2] = cw_check_r1cs, of the LAST run / check of the batch
+// (the stream is drained first); a part that has not run since timing was switched on reads -1
+extern "C" int cw_batch_kernel_ms(cw_batch *b, float ms[3]) {
+    if (!b || !ms) return fail(CW_EINVAL, "cw_batch_kernel_ms: bad argument");
+    NEED_DEVICE(b);
+    if (!b->timing) return fail(CW_ESTATE, "cw_batch_kernel_ms: timing is off (cw_batch_set_timing)");
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    const int pairs[3][2] = {{0, 1}, {1, 2}, {3, 4}};
+    for (int k = 0; k < 3; k++) {
+        ms[k] = -1.0f;
+        if (hipEventQuery(b->tev[pairs[k][0]]) == hipSuccess && hipEventQuery(b->tev[pairs[k][1]]) == hipSuccess) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, b->tev[pairs[k][0]], b->tev[pairs[k][1]]) == hipSuccess) ms[k] = t;
+        }
+    }
     return CW_OK;
 }
 
@@ -2497,13 +2579,16 @@ extern "C" int cw_check_r1cs(cw_batch *b) {
         // are audited (to name the first violated row of each instance).  A caller that took the raw table pointer
         // (cw_device_bits) may have changed it: then, and with CW_R1CS_AUDIT=1, every group is audited from the table.
         const void *only = b->jit && c->jit.check_complete && !b->table_dirty && !getenv("CW_R1CS_AUDIT") ? b->d_r1flag : nullptr;
+        TMARK(b, 3);
         HIPCHK(cwk_bits_r1cs(b->stream, b->d_erecs, b->n_evrows, b->d_wchunk, b->n_wchunks, b->d_wterms, b->d_wctab, b->d_wrow,
                              b->d_ichunk, b->n_ichunks, b->d_iterms, b->d_itab, b->d_irow, b->d_T, b->bits_slots, b->bits_sh, only,
                              b->n_groups, b->batch, b->d_status, b->d_first_bad, c->P));
+        TMARK(b, 4);
         b->checked = true;
         if (b->resolved && b->fb) return cw_check_r1cs(b->fb);       // the side batch was already computed: check it too
         return CW_OK;
     }
+    TMARK(b, 3);
     // rows the emitted evaluation code recomputed itself (hip_elements/fpjit.py plan_checks): its findings join the words the
     // stand-alone kernel reports through; that kernel then only streams the rows the code left to it
     if (b->fp_fn) HIPCHK(cwk_fused_merge(b->stream, b->d_status + b->Bp, b->batch, b->d_status, b->d_first_bad));
@@ -2513,6 +2598,7 @@ extern "C" int cw_check_r1cs(cw_batch *b) {
     else
         HIPCHK(cwk_r1cs(b->stream, b->d_pchunk, b->r1_chunks, b->d_pterms, b->d_rctab, b->d_rctab29, b->d_prow, b->d_V, b->Bp, b->batch,
                         b->d_status, b->d_first_bad, c->mont, c->P));
+    TMARK(b, 4);
     return CW_OK;
 }
 

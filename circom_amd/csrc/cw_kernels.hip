@@ -322,6 +322,27 @@ __device__ __forceinline__ void eval_step(const CwDRow &row, const fe &xa, const
         d = fe_small(k < 256 ? (limb >> (k & 31)) & 1u : 0u);
         break;
     }
+    case D_BITS: {
+        // consecutive bits of a, from bit row.aux: every entry of the row's extra-destination list is one store of the current
+        // bit; an entry flagged X_NEXT_DEV moves on to the next bit first (cw_tape.h).  One row for a whole Num2Bits.
+        uint32_t k = row.aux;
+        uint64_t y0 = x0, y1 = x1, y2 = x2, y3 = x3;
+        for (uint32_t e = 0; e < nx; e += 4) {
+            if (e) { y0 = extras[xp + e]; y1 = extras[xp + e + 1]; y2 = extras[xp + e + 2]; y3 = extras[xp + e + 3]; }
+            const uint64_t ys[4] = {y0, y1, y2, y3};
+            FE_UNROLL for (int t = 0; t < 4; t++) {
+                if (e + t < nx) {
+                    k += (uint32_t)(ys[t] >> 62) & 1u;               // wave-uniform
+                    const uint32_t w = k >> 5;
+                    const uint32_t limb = w == 0 ? a.v[0] : w == 1 ? a.v[1] : w == 2 ? a.v[2] : w == 3 ? a.v[3] : w == 4 ? a.v[4]
+                                          : w == 5 ? a.v[5] : w == 6 ? a.v[6] : a.v[7];
+                    store_off(ys[t] & ~X_NEXT_DEV, c, fe_small((limb >> (k & 31)) & 1u));
+                }
+            }
+        }
+        has_d = false;
+        break;
+    }
     case D_SHL: d = fe_shl(a, b, P); break;
     case D_SHR: d = fe_shr(a, b, P); break;
     case D_BAND: d = fe_band(a, b, P); break;

@@ -6,7 +6,7 @@
 enum : uint32_t {
     D_COPY = 0, D_ADD, D_SUB, D_NEG, D_MMUL, D_INV, D_IDIV, D_MOD, D_POW, D_SHL, D_SHR, D_BAND, D_BOR, D_BXOR,
     D_BNOT, D_LT, D_GT, D_LEQ, D_GEQ, D_EQ, D_NEQ, D_LAND, D_LOR, D_LNOT, D_SELECT, D_EXT, D_ASSERT_EQ,
-    D_ASSERT_NZ, D_ALSO, D_BARRIER, D_MUL2, D_MADD, D_MULC, D_MADDC, D_LINSUM, D_BIT, D_DOTC, D_CALL, D_NOPS
+    D_ASSERT_NZ, D_ALSO, D_BARRIER, D_MUL2, D_MADD, D_MULC, D_MADDC, D_LINSUM, D_BIT, D_DOTC, D_CALL, D_BITS, D_NOPS
 };
 
 // row.w0 = op[0:8) | dk[8:11) | ak[11:14) | bk[14:17) | n_extra[17:29) | const flags[29:31)
@@ -22,6 +22,13 @@ enum : uint32_t { KD_NONE = 2 };   // destination kind "no store" (value only fo
 // extra-destination table entries: slot number | flags
 #define X_TMP 0x80000000u
 #define X_LDS 0x40000000u
+// D_BITS: consecutive bits of operand a, first index in field b, one row instead of one D_BIT row per bit (Num2Bits).  It has no
+// destination of its own: its extra-destination entries list, bit after bit, where each bit goes - an entry with X_NEXT set
+// belongs to the next bit (so a bit can have several destinations: the signal and its elided copies).  Value-table
+// destinations only; slot numbers of such a schedule stay below 2^29.  D_ALSO rows do nothing (a spacer the lowering puts
+// between a D_BITS row and a row that reads one of its bits as a prefetched operand).
+#define X_NEXT 0x20000000u
+#define X_NEXT_DEV (1ull << 62)
 
 struct CwRow {       // 16 bytes, read with one scalar dwordx4 load
     uint32_t w0;     // see SH_* above; BARRIER rows: dst = 1 -> also drain global stores

@@ -468,10 +468,15 @@ class Executor:
                 self.fail("too many indices for component %s" % name, pos)
             k += 1
             binfo = ref.inst.bus_iface.get(a[1]) if hasattr(ref.inst, "bus_iface") else None
+            if not for_write and not ref.ran:
+                # execute.rs:3973 / 4115: an output (signal, bus field or tag) of a component that has not received all its
+                # inputs does not exist yet - the reading row would be scheduled ahead of the component's own rows
+                fcat = binfo[3] if binfo is not None else ref.inst.iface.get(a[1], (0, (), "?"))[2]
+                if fcat == "o":
+                    self.fail("Exception caused by invalid access: trying to access to an output signal of a component with not all "
+                              "its inputs initialized (%s.%s, %d inputs missing)" % (name, a[1], ref.pending), pos)
             if binfo is not None:
                 off, bdims, layout, cat = binfo
-                if not for_write and cat == "i":
-                    pass
                 return self._walk_bus((self.ctx, ref.pid0 + off, ref), bdims, layout, access, k, name, pos, {})
             try:
                 obj = ref[a[1]]

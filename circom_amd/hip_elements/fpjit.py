@@ -791,6 +791,14 @@ def emit(tape, bodies=None, constraints=None, spool_path=None) -> FpJitProgram:
         raise ValueError("only strand schedules have an emitted form")
     S = tape.n_strands
     assert S & (S - 1) == 0 and 1 <= S <= 16
+    if S > 1 and tape.functions and (np.asarray(tape.rows)[:, 0] & 0xFF == D_CALL).any():
+        # the interpreter body of run-time functions is compiled for one wave per workgroup (256 VGPRs + AccVGPRs); a workgroup
+        # of several strands leaves a wave 128: those schedules run on the interpreting kernel (cw_eval_kernel)
+        raise NotImplementedError("emitted code of a multi-strand schedule with function calls")
+    if any(f[2] is not None and f[2][0] == 4 for f in (tape.functions or ())):
+        # native long_div (csrc/cw_call.hip.h) is not part of the `call` body (it would push the body past the reach of its
+        # branches and its SGPR budget): the interpreting kernel runs these schedules
+        raise NotImplementedError("emitted code for a schedule whose functions include the native long_div")
     if bodies is None:
         bodies = FB.build_bodies()
     em = _Emitter(tape, bodies, spool_path)
@@ -871,7 +879,8 @@ def emit(tape, bodies=None, constraints=None, spool_path=None) -> FpJitProgram:
         b = bodies[name]
         L.append(".p2align 6\nfj_body_%s:\n" % name)
         ret = "  s_setpc_b64 s[%d:%d]" % (S_RET, S_RET + 1)
-        L.extend((ret if t == FB.RET_MARK else t) + "\n" for t in b.text)
+        for t in b.text:
+            L.extend(x + "\n" for x in ([ret] if t == FB.RET_MARK else FB.expand_long_branch(t)))
         if FB.RET_MARK not in b.text:
             L.append(ret + "\n")
         scratch = max(scratch, b.scratch_bytes)

@@ -27,6 +27,7 @@ from __future__ import annotations
 
 import hashlib
 import os
+import pickle
 import re
 import subprocess
 import tempfile
@@ -181,7 +182,7 @@ def _specs():
 
 def _source(bodies, fe_slow_inline=True):
     L = ['#include <hip/hip_runtime.h>', '#define CW_FE_SLOW __forceinline__' if fe_slow_inline else '',
-         '#define CW_CALL_NATIVE __forceinline__', '#include "%s/cw_call.hip.h"' % CSRC]
+         '#define CW_CALL_NATIVE __forceinline__', '#define CW_NO_NATIVE_LONG_DIV 1', '#include "%s/cw_call.hip.h"' % CSRC]
     pins = _p_pins()
     for b in bodies:
         # heavy: the emitter re-derives its lane offsets afterwards; inv_h cannot even spare the status word's register
@@ -302,6 +303,48 @@ _MEM = re.compile(r"^\s*(global_|flat_|buffer_|scratch_|ds_|s_load|s_buffer_load
 _VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 _SREG = re.compile(r"\bs(\d+)\b|\bs\[(\d+):(\d+)\]")
 _LABEL = re.compile(r"^(\.LBB\d+_\d+):")
+_PGLABEL = re.compile(r"^(\.Lpost_getpc\d+):")
+LONG_BRANCH = "  s_branch_long"          # pseudo instruction of a body's text: `s_branch_long <label> s[a:b]` (expand_long_branch)
+
+
+def _collapse_long_branches(text):
+    """The compiler relaxes a branch that cannot reach its target (+-128 KB) into
+        s_getpc_b64 s[a:b] / .Lpost_getpcN: / s_add_u32 sa, sa, (T-.Lpost_getpcN)&4294967295 / s_addc_u32 sb, sb, (T-...)>>32 /
+        s_setpc_b64 s[a:b]
+    which is an unconditional branch to T: one pseudo line here (the checks treat it as s_branch), the five instructions again
+    when a program prints the body (expand_long_branch)."""
+    out, i = [], 0
+    while i < len(text):
+        t = text[i].strip()
+        if t.startswith("s_getpc_b64") and i + 4 < len(text):
+            pair = t.split()[1]
+            lab = _PGLABEL.match(text[i + 1].strip())
+            m1 = re.match(r"s_add_u32 s(\d+), s\1, \((\.LBB\d+_\d+)-(\.Lpost_getpc\d+)\)&4294967295$", text[i + 2].strip())
+            m2 = re.match(r"s_addc_u32 s(\d+), s\1, \((\.LBB\d+_\d+)-(\.Lpost_getpc\d+)\)>>32$", text[i + 3].strip())
+            m3 = re.match(r"s_setpc_b64 (s\[\d+:\d+\])$", text[i + 4].strip())
+            if lab and m1 and m2 and m3 and m3.group(1) == pair and m1.group(2) == m2.group(2) and m1.group(3) == lab.group(1) == m2.group(3):
+                out.append("%s %s %s" % (LONG_BRANCH, m1.group(2), pair))
+                i += 5
+                continue
+        out.append(text[i])
+        i += 1
+    return out
+
+
+_long_branch_serial = [0]
+
+
+def expand_long_branch(t):
+    """the instructions of a `s_branch_long` pseudo line (any other line: itself)"""
+    if not t.startswith(LONG_BRANCH):
+        return [t]
+    _, lbl, pair = t.split()
+    m = re.match(r"s\[(\d+):(\d+)\]", pair)
+    a, b_ = m.group(1), m.group(2)
+    _long_branch_serial[0] += 1
+    pg = ".Lfj_pg%d" % _long_branch_serial[0]
+    return ["  s_getpc_b64 %s" % pair, "%s:" % pg, "  s_add_u32 s%s, s%s, (%s-%s)&4294967295" % (a, a, lbl, pg),
+            "  s_addc_u32 s%s, s%s, (%s-%s)>>32" % (b_, b_, lbl, pg), "  s_setpc_b64 %s" % pair]
 
 
 def _regs(rx, text):
@@ -341,7 +384,7 @@ def _use_before_def(b, defined_v, defined_s):
             label_of[t[:-1]] = len(blocks)
             continue
         cur.append(t)
-        if t.startswith("s_branch") or t.startswith("s_cbranch"):
+        if t.startswith("s_branch") or t.startswith("s_cbranch"):      # (s_branch_long included)
             blocks.append(cur)
             cur = []
     blocks.append(cur)
@@ -374,6 +417,9 @@ def _use_before_def(b, defined_v, defined_s):
             op = parts[0]
             opnds = [x.strip() for x in parts[1].split(",")] if len(parts) > 1 else []
             nd = 0 if _NO_DST.match(op) else 2 if _TWO_DST.match(op) else 1
+            if op == "s_branch_long":                  # `s_branch_long <label> s[a:b]`: writes the pair, reads nothing
+                live |= {key("s", r) for r in _regs(_SREG, t.split()[2])}
+                continue
             dsts, srcs = opnds[:nd], opnds[nd:]
             if op.startswith("v_swap"):
                 srcs = opnds
@@ -460,12 +506,13 @@ def parse_bodies(asm: str, bodies):
             if not seen_end:
                 seen_end = ln.strip() == "s_endpgm"
                 continue
-            if ln.strip() and (not ln.strip().startswith(".") or _LABEL.match(ln.strip())):
+            if ln.strip() and (not ln.strip().startswith(".") or _LABEL.match(ln.strip()) or _PGLABEL.match(ln.strip())):
                 tail.append(ln)                 # an instruction or a block label; assembler directives are not code
         if tail:
             text = text + [RET_MARK] + tail
         # the compiler's own markers around the asm statements
         text = [t for t in text if "#ASMSTART" not in t and "#ASMEND" not in t]
+        text = _collapse_long_branches(text)
         allowed_v = set(range(40, 120)) | {r for r, _ in b.vin} | {r for r, _ in b.vout} | {124} | ({V_FB} if b.chk else set())
         if b.parity == "e":
             allowed_v |= set(range(A_E, A_E + 16))
@@ -487,6 +534,13 @@ def parse_bodies(asm: str, bodies):
         for t in text:
             if t == RET_MARK:
                 out.append(t)
+                continue
+            if t.startswith(LONG_BRANCH):                 # (bodies beyond the 128 KB reach of s_branch: the interpreter)
+                _, lbl, pair = t.split()
+                us = _regs(_SREG, pair)
+                if not us <= allowed_s:
+                    raise RuntimeError("body %s: long branch through SGPRs outside its budget: %s" % (b.name, pair))
+                out.append("%s %s %s" % (LONG_BRANCH, re.sub(r"\.LBB(\d+_\d+)", lambda mm: ".Lfj_%s_%s" % (b.name, mm.group(1)), lbl), pair))
                 continue
             if b.parity in ("h", "c") and _SCRATCH.match(t):
                 b.scratch = True          # a heavy body may spill: the emitted kernel then owns a private segment
@@ -534,7 +588,7 @@ def parse_bodies(asm: str, bodies):
                 if m2:
                     break
             b.scratch_bytes = int(m2.group(1))
-        b.n_instr = sum(1 for t in out if not t.strip().endswith(":") and t != RET_MARK)
+        b.n_instr = sum(4 if t.startswith(LONG_BRANCH) else 1 for t in out if not t.strip().endswith(":") and t != RET_MARK)
         i = j + 1
     missing = [b.name for b in bodies if b.text is None]
     if missing:
@@ -549,15 +603,34 @@ def _hipcc():
     return os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
+_PARSED = {}
+
+
 def build_bodies(names=None, cache=True):
     """name -> Body with its instruction text; compiled once per source (cached under circom_amd/lib)"""
     bodies = _specs()
     if names is not None:
         bodies = [b for b in bodies if b.name in names]
     src = _source(bodies)
-    deps = b"".join(open(os.path.join(CSRC, n), "rb").read() for n in ("fp256.hip.h", "cw_rowops.hip.h", "cw_tape.h"))
+    deps = b"".join(open(os.path.join(CSRC, n), "rb").read() for n in ("fp256.hip.h", "cw_rowops.hip.h", "cw_tape.h", "cw_call.hip.h"))
     key = hashlib.sha256(src.encode() + deps + open(__file__, "rb").read()).hexdigest()[:16]
     path = os.path.join(CACHE_DIR, "fpjit_bodies_%s.s" % key)
+    # Cutting the bodies out of the text and checking their register use is 3 s of regular expressions: done once per process
+    # (every emitted program of a session shares the dict: bodies are read-only after parsing) and once per source across
+    # processes (the parsed bodies are pickled next to the assembly they came from)
+    memo = (key, None if names is None else tuple(sorted(names)))
+    if cache and memo in _PARSED:
+        return _PARSED[memo]
+    ppath = path[:-2] + (".pkl" if names is None else ".%s.pkl" % hashlib.sha256(repr(memo[1]).encode()).hexdigest()[:8])
+    if cache and os.path.exists(ppath):
+        try:
+            with open(ppath, "rb") as f:
+                got = pickle.load(f)
+            if isinstance(got, dict) and all(getattr(b, "text", None) for b in got.values()):
+                _PARSED[memo] = got
+                return got
+        except Exception:
+            pass                                    # a torn or stale file: parse again below
     asm = None
     if cache and os.path.exists(path):
         asm = open(path).read()
@@ -581,4 +654,14 @@ def build_bodies(names=None, cache=True):
                 f.write(asm)
             os.replace(tmp, path)
     parse_bodies(asm, bodies)
-    return {b.name: b for b in bodies}
+    got = {b.name: b for b in bodies}
+    if cache:
+        _PARSED[memo] = got
+        try:
+            tmp = ppath + ".%d" % os.getpid()
+            with open(tmp, "wb") as f:
+                pickle.dump(got, f, protocol=4)
+            os.replace(tmp, ppath)
+        except OSError:
+            pass
+    return got

@@ -53,10 +53,16 @@ from ..frontend.flatten import FlatCircuit
 # device opcodes (csrc/cw_tape.h must match)
 (D_COPY, D_ADD, D_SUB, D_NEG, D_MMUL, D_INV, D_IDIV, D_MOD, D_POW, D_SHL, D_SHR, D_BAND, D_BOR, D_BXOR,
  D_BNOT, D_LT, D_GT, D_LEQ, D_GEQ, D_EQ, D_NEQ, D_LAND, D_LOR, D_LNOT, D_SELECT, D_EXT, D_ASSERT_EQ,
- D_ASSERT_NZ, D_ALSO, D_BARRIER, D_MUL2, D_MADD, D_MULC, D_MADDC, D_LINSUM, D_BIT, D_DOTC, D_CALL) = range(38)
+ D_ASSERT_NZ, D_ALSO, D_BARRIER, D_MUL2, D_MADD, D_MULC, D_MADDC, D_LINSUM, D_BIT, D_DOTC, D_CALL, D_BITS) = range(39)
 D_NAMES = ["copy", "add", "sub", "neg", "mmul", "inv", "idiv", "mod", "pow", "shl", "shr", "band", "bor",
            "bxor", "bnot", "lt", "gt", "leq", "geq", "eq", "neq", "land", "lor", "lnot", "select", "ext",
-           "assert_eq", "assert_nz", "also", "barrier", "mul2", "madd", "mulc", "maddc", "linsum", "bit", "dotc", "call"]
+           "assert_eq", "assert_nz", "also", "barrier", "mul2", "madd", "mulc", "maddc", "linsum", "bit", "dotc", "call", "bits"]
+# D_BITS  : consecutive bits of operand a starting at bit b (a raw number): one row for a whole Num2Bits instead of one D_BIT
+#           row per bit.  No destination of its own; its extra-destination entries list, bit after bit, where each bit goes
+#           (X_NEXT on an entry = "the next bit starts here": the bit's signal, then its elided copies).  Only in schedules
+#           the interpreting kernel runs (circuits with run-time functions: pass A7 _fuse_bits); D_ALSO = a row that does
+#           nothing, put between a D_BITS row and a following row of its strand that takes one of the bits as a (prefetched)
+#           a / b operand.
 # D_CALL  : run the register bytecode of a circom function (frontend/rtcode.py) per lane: field a = function id, operand b
 #           = first of the function's registers, which are CONSECUTIVE pinned temp slots (arguments were stored there by
 #           ordinary rows, results are read from there by the rows after the BARRIER that follows every D_CALL: the
@@ -91,7 +97,9 @@ _DIRECT = {O.COPY: D_COPY, O.ADD: D_ADD, O.SUB: D_SUB, O.NEG: D_NEG, O.IDIV: D_I
            O.POW: D_POW, O.SHL: D_SHL, O.SHR: D_SHR, O.BAND: D_BAND, O.BOR: D_BOR, O.BXOR: D_BXOR,
            O.BNOT: D_BNOT, O.LT: D_LT, O.GT: D_GT, O.LEQ: D_LEQ, O.GEQ: D_GEQ, O.EQ: D_EQ, O.NEQ: D_NEQ,
            O.LAND: D_LAND, O.LOR: D_LOR, O.LNOT: D_LNOT, O.ASSERT_EQ: D_ASSERT_EQ, O.ASSERT_NZ: D_ASSERT_NZ}
-_COST = {D_MMUL: 10.0, D_MUL2: 20.0, D_MADD: 11.0, D_MULC: 10.0, D_MADDC: 11.0, D_INV: 1000.0, D_POW: 6000.0, D_IDIV: 8000.0, D_MOD: 8000.0}
+# (unit ~ 500 clocks of a lone wave, tools/profile_ops.sh on the ECDSA verifier: a bit row 3.2 K clk, mulc 4.9 K, mul2 5.2 K,
+#  idiv / mod 15 K with Knuth D, inv 136 K)
+_COST = {D_MMUL: 10.0, D_MUL2: 20.0, D_MADD: 11.0, D_MULC: 10.0, D_MADDC: 11.0, D_INV: 250.0, D_POW: 6000.0, D_IDIV: 30.0, D_MOD: 30.0}
 _NO_VALUE = (D_ASSERT_EQ, D_ASSERT_NZ, D_SELECT)
 # rows that can set the status word of an instance; the word carries the index of the flat operation (24 bits), and when
 # several checks of one instance fail - on any strand, in any schedule order - the smallest index is reported: the check
@@ -159,7 +167,7 @@ def _dce(code, n_temps, nregs=()):
 
 
 class _Row:
-    __slots__ = ("op", "dk", "dv", "ak", "av", "bk", "bv", "ck", "cv", "extra", "level", "strand", "flag", "coef", "terms", "seq")
+    __slots__ = ("op", "dk", "dv", "ak", "av", "bk", "bv", "ck", "cv", "extra", "level", "strand", "flag", "coef", "terms", "seq", "multi")
 
     def __init__(self, op, dk, dv, ak, av, bk=K_NONE, bv=0, ck=K_NONE, cv=0):
         self.op, self.dk, self.dv = op, dk, dv
@@ -168,6 +176,7 @@ class _Row:
         self.flag = 0            # D_MULC/D_MADDC: 1 = constant is a small positive integer, 2 = small negative
         self.coef = None         # D_MULC: the plain constant (python int, canonical)
         self.terms = None        # D_LINSUM: list of [kind, id, signed coefficient]
+        self.multi = None        # D_BITS: [(signal, [extra destinations] | None)] per bit
         self.level = 0
         self.strand = 0
         self.seq = 0             # index of the flat operation this row comes from (reported when the row fails a check)
@@ -436,6 +445,36 @@ def _fuse_linear(rows, consts_plain, q, cid):
             continue
         out.append(repl.get(idx, r))
     return out, n_lin, n_bit
+
+
+def _fold_bit_sums(rows, q, cid):
+    """Pass A3b: a D_LINSUM that puts the bits of ONE signal back together - sum_i 2^i bit_i(x), i = 0 .. n-1, what the
+    `lc1 += out[i] * e2` loop of Num2Bits traces into - is x & (2^n - 1): one operand instead of n (each bit is its own
+    32-byte slot of the value table; the ECDSA verifier spends a tenth of its time fetching them back).  Exact for every x:
+    the sum of the bits is that integer, and it stays below q for n < bitlength(q)."""
+    bit_of = {}                   # bit signal -> (source kind, source id, bit index); signals are assigned once
+    for r in rows:
+        if r.op == D_BIT and r.dk == K_SIG and r.ak == K_SIG:
+            bit_of[r.dv] = (r.av, r.bv)
+    out, n_folded = [], 0
+    for r in rows:
+        if r.op == D_LINSUM and r.bk != K_CONST and r.terms and 2 <= len(r.terms) < q.bit_length():
+            src, ok, seen = None, True, 0
+            for k, v, cf in r.terms:
+                b = bit_of.get(v) if k == K_SIG else None
+                if b is None or (src is not None and b[0] != src) or cf != (1 << b[1]) or (seen >> b[1]) & 1:
+                    ok = False
+                    break
+                src = b[0]
+                seen |= 1 << b[1]
+            if ok and seen == (1 << len(r.terms)) - 1:
+                nr = _Row(D_BAND, r.dk, r.dv, K_SIG, src, K_CONST, cid(seen))
+                nr.extra, nr.seq = r.extra, r.seq
+                out.append(nr)
+                n_folded += 1
+                continue
+        out.append(r)
+    return out, n_folded
 
 
 def _reassociate(rows, n_vtemps):
@@ -916,8 +955,55 @@ def _alias(rows, n_signals):
     return out, n_elided
 
 
-def _schedule(rows, n_signals, n_strands):
-    """Pass C.  Returns list of streams; each stream is a list whose items are _Row or the string 'B'."""
+MAX_BITS_ROW = 64
+
+
+def _defs(r):
+    """(kind, id) of every value a row defines (D_BITS: one per bit)"""
+    if r.multi:
+        return [(K_SIG, dv) for dv, _ in r.multi]
+    return [(r.dk, r.dv)] if r.dk in (K_SIG, K_TMP) else []
+
+
+def _fuse_bits(rows):
+    """Pass A7 (schedules of the interpreting kernel): runs of D_BIT rows that take consecutive bits of the same operand into
+    signals - what Num2Bits traces into - become one D_BITS row.  A 64-bit range check is then 1 row with 64 stores instead of
+    64 rows that each fetch the operand again (the ECDSA verifier: 2.3 M of its 3.3 M rows are such bit rows)."""
+    out, n_fused = [], 0
+    i, n = 0, len(rows)
+    while i < n:
+        r = rows[i]
+        if r.op == D_BIT and r.dk == K_SIG and r.ak in (K_SIG, K_TMP):
+            j = i + 1
+            ex = len(r.extra or ())
+            while j < n and j - i < MAX_BITS_ROW:
+                t = rows[j]
+                if not (t.op == D_BIT and t.dk == K_SIG and t.ak == r.ak and t.av == r.av and t.bv == r.bv + (j - i)):
+                    break
+                if ex + len(t.extra or ()) + (j - i + 1) > EXTRA_CAP:
+                    break
+                ex += len(t.extra or ())
+                j += 1
+            if j - i >= 2:
+                nr = _Row(D_BITS, KD_NONE, 0, r.ak, r.av, K_NONE, r.bv)
+                nr.multi = [(t.dv, list(t.extra) if t.extra else None) for t in rows[i:j]]
+                nr.seq = r.seq
+                out.append(nr)
+                n_fused += j - i
+                i = j
+                continue
+        out.append(r)
+        i += 1
+    return out, n_fused
+
+
+def _schedule(rows, n_signals, n_strands, functions=()):
+    """Pass C.  Returns (streams, number of barriers, ordinals of the barriers that must be FULL); each stream is a list whose
+    items are _Row or the string 'B'.
+    A D_CALL (a circom function with run-time control flow) reads its arguments from and writes its results to its register
+    window in the VALUE TABLE: with several strands it is a heavy unit of its level on one strand, and the barriers in front of
+    and behind that level drain global stores (FULL), so that arguments stored by any strand are in memory when the call
+    starts and its results are when the next level reads them."""
     if n_strands <= 1:
         st = []
         nb = 0
@@ -927,7 +1013,7 @@ def _schedule(rows, n_signals, n_strands):
             if r.op == D_CALL:      # operands of the next row must not be prefetched before the call has run
                 st.append("B")
                 nb += 1
-        return [st], nb
+        return [st], nb, set()
 
     def vid(k, v):
         return v if k == K_SIG else n_signals + v
@@ -955,8 +1041,11 @@ def _schedule(rows, n_signals, n_strands):
                         lv = pl + 1
         for r in unit:
             r.level = lv
-            if r.dk in (K_SIG, K_TMP):
-                prod_level[vid(r.dk, r.dv)] = lv
+            for dk_, dv_ in _defs(r):
+                prod_level[vid(dk_, dv_)] = lv
+            if r.op == D_CALL:      # every register of the window is the call's from here on (results, scratch)
+                for k in range(functions[r.av]["n_regs"]):
+                    prod_level[vid(K_TMP, r.bv + k)] = lv
         while len(levels) <= lv:
             levels.append([])
         levels[lv].append(unit)
@@ -966,7 +1055,12 @@ def _schedule(rows, n_signals, n_strands):
         c = 0.0
         for r in unit:
             c += ROW_OVERHEAD
-            if r.op == D_DOTC:
+            if r.op == D_CALL:
+                nat = functions[r.av].get("native")
+                c += CALL_COST if not nat else CALL_COST_LONG_DIV if nat[0] == "long_div" else CALL_COST_NATIVE
+            elif r.op == D_BITS:
+                c += 1.0 * len(r.multi) + EXTRA_COST * sum(len(x or ()) for _, x in r.multi)
+            elif r.op == D_DOTC:
                 c += 5.0 + 4.5 * len(r.terms)
             elif r.op == D_LINSUM:
                 c += 3.0 + 1.2 * len(r.terms)
@@ -981,7 +1075,10 @@ def _schedule(rows, n_signals, n_strands):
     # strand simply follow each other in its stream).
     fresh = {}          # value id -> producing strand, for values produced since the last barrier
     n_barriers = 0
+    forced_full = set()
+    after_call = False
     for lv, lunits in enumerate(levels):
+        has_call = any(u[0].op == D_CALL for u in lunits)
         total = sum(ucost(u) for u in lunits)
         cap = total / n_strands * AFFINITY_SLACK + 4.0
         load = [0.0] * n_strands
@@ -1013,21 +1110,27 @@ def _schedule(rows, n_signals, n_strands):
                 for k, v in _value_operands(r):
                     if (k == K_SIG or k == K_TMP) and fresh.get(vid(k, v), pref) != pref:
                         need = True
-        if need:
+        if need or has_call or after_call:
+            if has_call or after_call:
+                forced_full.add(n_barriers)
             for st in streams:
                 st.append("B")
             fresh.clear()
             n_barriers += 1
+        after_call = has_call
         for unit, pref in placed:
             for r in unit:
                 r.strand = pref
                 streams[pref].append(r)
-                if r.dk in (K_SIG, K_TMP):
-                    prod_strand[vid(r.dk, r.dv)] = pref
-                    fresh[vid(r.dk, r.dv)] = pref
-    return streams, n_barriers
+                for dk_, dv_ in _defs(r):
+                    prod_strand[vid(dk_, dv_)] = pref
+                    fresh[vid(dk_, dv_)] = pref
+    return streams, n_barriers, forced_full
 
 
+CALL_COST = float(os.environ.get("CW_CALL_COST", "20000"))               # an interpreted function (long_div: ~10^5 instructions)
+CALL_COST_NATIVE = float(os.environ.get("CW_CALL_COST_NATIVE", "300"))   # a native routine (one binary-GCD inverse + products: ~150 K clk)
+CALL_COST_LONG_DIV = float(os.environ.get("CW_CALL_COST_LONG_DIV", "40"))  # native long_div (a dozen Knuth digits)
 ROW_OVERHEAD = float(os.environ.get("CW_ROW_OVERHEAD", "4"))   # scheduler cost units charged to every row
 EXTRA_COST = float(os.environ.get("CW_EXTRA_COST", "2"))     # ... and to every extra destination (two 1-KiB stores)
 FULL_PERIOD = 8        # every FULL_PERIOD-th barrier also drains global stores
@@ -1046,6 +1149,7 @@ MAX_EXTRA = 4095
 EXTRA_CAP = 4000       # copies folded into one row (leaves room for the LDS hand-off entry; the field holds 4095)
 K_LDS = 4             # operand / destination kind: LDS slot of the workgroup (cross-strand hand-off)
 X_TMP, X_LDS = 1 << 31, 1 << 30       # flags of an entry of the extra-destination table
+X_NEXT = 1 << 29                      # ... of a D_BITS row: this entry belongs to the next bit
 
 
 _FN_ALU = {O.COPY: D_COPY, O.ADD: D_ADD, O.SUB: D_SUB, O.NEG: D_NEG, O.MUL: D_MUL2, O.DIV: F_DIV, O.IDIV: D_IDIV, O.MOD: D_MOD,
@@ -1053,7 +1157,7 @@ _FN_ALU = {O.COPY: D_COPY, O.ADD: D_ADD, O.SUB: D_SUB, O.NEG: D_NEG, O.MUL: D_MU
            O.GT: D_GT, O.LEQ: D_LEQ, O.GEQ: D_GEQ, O.EQ: D_EQ, O.NEQ: D_NEQ, O.LAND: D_LAND, O.LOR: D_LOR, O.LNOT: D_LNOT}
 
 
-NATIVE_KINDS = {"mod_inv": 1, "ec_add": 2, "ec_double": 3}     # csrc/cw_kernels.hip eval_call_native
+NATIVE_KINDS = {"mod_inv": 1, "ec_add": 2, "ec_double": 3, "long_div": 4}     # csrc/cw_call.hip.h eval_call_native / eval_call_long_div
 
 
 def _encode_function(fn, cid, q):
@@ -1088,7 +1192,14 @@ def _encode_function(fn, cid, q):
     nat = fn.get("native")
     if nat is not None:
         kind, n_, k_, modulus = nat
-        if 225 <= modulus.bit_length() <= 256 and modulus & 1 and n_ <= 64 and k_ <= 15 and n_ * k_ >= modulus.bit_length() and n_ * k_ <= 256 \
+        if kind == "long_div":
+            # (the tag's last field is m) the device routine takes limbs of 32..64 bits, a divisor of at most 256 and a
+            # dividend of at most 640 bits
+            m_ = modulus
+            if 32 <= n_ <= 64 and 1 <= k_ <= 15 and 1 <= m_ <= 15 and n_ * k_ <= 256 and (k_ + m_) * n_ <= 640 \
+                    and fn["n_args"] == 2 * k_ + m_ and fn["ret_base"] == fn["n_args"] and fn["n_ret"] == m_ + 1 + k_:
+                native = (NATIVE_KINDS[kind], n_, k_, m_)
+        elif 225 <= modulus.bit_length() <= 256 and modulus & 1 and n_ <= 64 and k_ <= 15 and n_ * k_ >= modulus.bit_length() and n_ * k_ <= 256 \
                 and fn["ret_base"] == fn["n_args"]:
             native = (NATIVE_KINDS[kind], n_, k_, modulus)
     return fn["n_regs"], out, native
@@ -1147,9 +1258,11 @@ def _finish_pipe(fc, stream, dconsts, lconsts, lcid, witness_map, pipe, stats):
     return t
 
 
-def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None, mont: bool = False) -> Tape:
+def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None, mont: bool = False, fuse_bits=None) -> Tape:
     """pipe = (rows per batch, loads per batch): lower to the pipelined single-wave variant (pipe.py) instead of strands.
-    mont: signals in Montgomery form (pass A6; every variant of a circuit must use the same setting)"""
+    mont: signals in Montgomery form (pass A6; every variant of a circuit must use the same setting)
+    fuse_bits: runs of bit rows as D_BITS rows (pass A7); None = where the interpreting kernel runs the schedule anyway
+    (circuits with run-time functions)"""
     q = fc.fp.q
     if not 225 <= q.bit_length() <= 256:
         raise ValueError("hip_elements targets circom's 253..256-bit primes (4 x 64-bit limbs); prime %s has %d bits "
@@ -1174,12 +1287,14 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None, mont
     if pipe is not None:
         n_strands = 1
     if functions and (fc.code["op"] == O.CALL).any():
-        n_strands = 1               # tier-2 code is the slow path: program order, one wave per 64 instances
+        if os.environ.get("CW_CALL_STRANDS", "1") == "0":
+            n_strands = 1           # (experiments) tier-2 code in program order, one wave per 64 instances
         if pipe is not None:
             raise ValueError("circuits that call run-time functions have no pipelined variant")
     rows, dconsts, n_vtemps, cid, plain = _expand(fc)
     rows, n_vtemps, n_inv_batches = _batch_inversions(rows, n_vtemps, cid)
     rows, n_lin, n_bit = _fuse_linear(rows, plain, q, cid)
+    rows, n_bitsums = _fold_bit_sums(rows, q, cid) if os.environ.get("CW_FOLD_BITSUMS", "1") != "0" else (rows, 0)
     n_conv = 0
     if mont:
         if functions and (fc.code["op"] == O.CALL).any():
@@ -1209,7 +1324,30 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None, mont
     n_madd = 0
     if n_strands == 1:
         rows, n_madd = _fuse_madd(rows)
-    streams, n_levels = _schedule(rows, n_signals, n_strands)
+    n_bits_fused = 0
+    has_calls = bool(functions) and any(r.op == D_CALL for r in rows)
+    if fuse_bits is None:
+        # only schedules that the interpreting kernel runs anyway (the emitted code has no body for the row)
+        # (a single-strand schedule of such a circuit still has an emitted form, fpjit.py, which has no body for the row)
+        fuse_bits = has_calls and n_strands > 1 and pipe is None and os.environ.get("CW_FUSE_BITS", "1") != "0"
+    if fuse_bits:
+        if n_signals >= X_NEXT:
+            raise ValueError("bit-field rows need signal numbers below 2^29")
+        rows, n_bits_fused = _fuse_bits(rows)
+    streams, n_levels, forced_full = _schedule(rows, n_signals, n_strands, functions)
+    if n_bits_fused:
+        # a row that takes a bit of the D_BITS row right in front of it as a / b / c operand would have requested it before
+        # the bits were stored (operands are fetched one row ahead): a spacer row in between
+        for si, st in enumerate(streams):
+            out_, last = [], None
+            for it in st:
+                if it != "B" and last is not None and any((k, v) in last for k, v in ((it.ak, it.av), (it.bk, it.bv), (it.ck, it.cv))):
+                    sp = _Row(D_ALSO, KD_NONE, 0, K_SIG, 0)
+                    sp.strand = si
+                    out_.append(sp)
+                out_.append(it)
+                last = {(K_SIG, dv) for dv, _ in it.multi} if (it != "B" and it.multi) else None
+            streams[si] = out_
     multi = n_strands > 1
     if pipe is not None:
         t = _finish_pipe(fc, streams[0], dconsts, lconsts, lcid, witness_map, pipe,
@@ -1225,6 +1363,7 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None, mont
     # ---- pass D1: walk the streams; find PREV-forwarded operands, cross-strand flows, liveness ---------------------
     # time unit: row position for one strand, barrier epoch for several
     prod_strand, def_time = {}, {}
+    bits_vals = set()   # values stored by D_BITS rows (no register, no LDS copy)
     plan = []           # per stream: list of [row | 'B', (prev_a, prev_b), time]
     for si, s in enumerate(streams):
         prev_val = None
@@ -1245,6 +1384,10 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None, mont
                 if r.dk in (K_SIG, K_TMP):
                     prod_strand[vid(r.dk, r.dv)] = si
                     def_time[vid(r.dk, r.dv)] = t
+                for dv_, _ in (r.multi or ()):        # D_BITS: every bit is a value of this strand, in the value table only
+                    prod_strand[vid(K_SIG, dv_)] = si
+                    def_time[vid(K_SIG, dv_)] = t
+                    bits_vals.add(vid(K_SIG, dv_))
         plan.append(items)
     # Cross-strand flows.  A value produced in epoch d by one strand and read by another must be visible to the
     # reader: either through an LDS slot (LIGHT barriers suffice) or through the value table, which needs a FULL
@@ -1253,9 +1396,20 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None, mont
     # before it need an LDS slot (and only until that barrier: bounded LDS lifetime).
     mem_last = {}       # value id -> last time it is read from the value table
     x_uses = {}         # value id -> sorted epochs at which ANOTHER strand reads it
+    call_regs = set()   # registers of function calls: pinned slots of the value table, read and written through memory only
+    for r in rows:
+        if r.op == D_CALL:
+            call_regs.update(vid(K_TMP, r.bv + k) for k in range(functions[r.av]["n_regs"]))
     for si, items in enumerate(plan):
         for r, fl, t in items:
             if r == "B":
+                continue
+            if r.op == D_CALL:
+                # the arguments are read from the value table whatever strand stored them (FULL barriers around the call's
+                # level, _schedule): never an LDS hand-off, never forwarded
+                for tm in r.terms:
+                    x = vid(tm[0], tm[1])
+                    mem_last[x] = max(mem_last.get(x, -1), t)
                 continue
             ops = [(r.ak, r.av, fl[0]), (r.bk, r.bv, fl[1]), (r.ck, r.cv, False)]
             if r.terms:
@@ -1264,7 +1418,7 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None, mont
                 if k not in (K_SIG, K_TMP) or is_prev:
                     continue
                 x = vid(k, v)
-                if multi and x in prod_strand and prod_strand[x] != si:
+                if multi and x in prod_strand and prod_strand[x] != si and x not in call_regs:
                     x_uses.setdefault(x, []).append(t)
                 else:
                     mem_last[x] = max(mem_last.get(x, -1), t)
@@ -1278,6 +1432,7 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None, mont
         K = FULL_PERIOD
         n_epochs = n_levels + 1
         full_after.update(e for e in range(n_epochs) if (e + 1) % K == 0)
+        full_after.update(forced_full)          # the barriers around a function call's level
 
         def next_full(d):       # first epoch >= d whose closing barrier is periodic-FULL
             return d + (K - 1 - d % K)
@@ -1295,6 +1450,10 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None, mont
             if far:
                 mem_last[x] = max(mem_last.get(x, -1), max(far))
             if not near:
+                continue
+            if x in bits_vals:                          # a bit of a D_BITS row: through the value table, behind a FULL barrier
+                full_after.add(t)
+                mem_last[x] = max(mem_last.get(x, -1), max(near))
                 continue
             if free:
                 sl = free.pop()
@@ -1318,7 +1477,7 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None, mont
             n_tslots += functions[r.av]["n_regs"]
     tmp_last = {x - n_signals: t for x, t in mem_last.items() if x >= n_signals}
     if multi:
-        by_time = sorted((def_time[n_signals + v], v) for v in tmp_last)
+        by_time = sorted((def_time[n_signals + v], v) for v in tmp_last if v not in pinned)
         free_at, free, cur = {}, [], -1
         for t, v in by_time:
             while cur < t - 1:
@@ -1375,8 +1534,8 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None, mont
                                              % (slot_of[v], content.get(slot_of[v]), v, t, r.op))
             if r.dk == K_TMP and r.dv in slot_of and r.dv not in pinned:
                 content[slot_of[r.dv]] = r.dv
-            if r.extra:
-                for xk, xv in r.extra:
+            for exl in ([r.extra] if r.extra else []) + [x for _, x in (r.multi or ()) if x]:
+                for xk, xv in exl:
                     if xk == K_TMP and xv in slot_of and xv not in pinned:
                         content[slot_of[xv]] = xv
 
@@ -1418,7 +1577,7 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None, mont
                     else:
                         terms.append((tk, tv, tm[2]))
                     n_prev += pf
-            elif r.op == D_BIT:
+            elif r.op == D_BIT or r.op == D_BITS:
                 ka, va = o_enc(r.ak, r.av, fl[0])
                 kb, vb = 0, r.bv
                 n_prev += fl[0]
@@ -1448,6 +1607,14 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None, mont
                         ex.append(v)
                     elif v in slot_of:
                         ex.append(X_TMP | slot_of[v])
+            if r.multi:                                  # D_BITS: per bit its signal, then its copies; X_NEXT starts a new bit
+                for j, (dv_, exl) in enumerate(r.multi):
+                    ex.append(dv_ | (X_NEXT if j else 0))
+                    for k, v in (exl or ()):
+                        if k == K_SIG:
+                            ex.append(v)
+                        elif v in slot_of:
+                            ex.append(X_TMP | slot_of[v])
             assert len(ex) <= MAX_EXTRA, "fan-out of one value exceeds the extra-destination field"
             if r.op in _FAIL_OPS:
                 seqs.append(r.seq)
@@ -1513,6 +1680,7 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None, mont
         "fused_madd": n_madd,
         "inv": int((dops == D_INV).sum()),
         "inv_batches": n_inv_batches,
+        "bits_rows": int((dops == D_BITS).sum()), "bits_fused": n_bits_fused, "bit_sums_folded": n_bitsums,
         "linsum_splits": n_split,
         "barriers": n_levels,
         "full_barriers": len(full_after),

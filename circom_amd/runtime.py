@@ -85,6 +85,8 @@ _SIGS = {
     "cw_remaining_inputs": (C.c_int64, [C.c_void_p, C.c_uint32]),
     "cw_run": (C.c_int, [C.c_void_p]),
     "cw_check_r1cs": (C.c_int, [C.c_void_p]),
+    "cw_batch_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "cw_batch_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "cw_sync": (C.c_int, [C.c_void_p]),
     "cw_get_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cw_get_witness": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
@@ -285,6 +287,16 @@ class Batch:
 
     def sync(self):
         _chk(lib().cw_sync(self.h))
+
+    def set_timing(self, on=True):
+        """HIP events around the parts of run() / check_r1cs() on this batch's stream (cw_batch_set_timing)"""
+        _chk(lib().cw_batch_set_timing(self.h, 1 if on else 0))
+
+    def kernel_ms(self):
+        """{"ingest": ms, "eval": ms, "check": ms} of the last run / check (None: that part has not run); drains the stream"""
+        out = (C.c_float * 3)()
+        _chk(lib().cw_batch_kernel_ms(self.h, out))
+        return {k: (float(v) if v >= 0 else None) for k, v in zip(("ingest", "eval", "check"), out)}
 
     # -- results ------------------------------------------------------------------------------------
     def status(self) -> np.ndarray:

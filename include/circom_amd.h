@@ -66,7 +66,8 @@ uint32_t cw_n_inputs(const cw_circuit *c);           /* get_main_input_signal_no
  * main.cpp:288-334).  `signals`: n strictly increasing signal ids starting with 0; the first 1 + cw_n_public entries stay as
  * they are.  Evaluation and R1CS check keep working on the full system cw_load was given; every egress of batches created
  * AFTER this call (cw_get_witness(es)(_device), cw_write_wtns(_many), cw_write_wtnsb) hands out these entries, and
- * cw_n_witness() returns n. */
+ * cw_n_witness() returns n.  CW_EINVAL while any batch of the circuit is alive: a batch sizes its device images of the list
+ * when it is created, so the list is fixed before the first cw_batch_create (or after the last cw_batch_free). */
 int cw_set_witness_list(cw_circuit *c, const uint32_t *signals, uint32_t n);
 uint32_t cw_input_start(const cw_circuit *c);        /* get_main_input_signal_start() */
 uint32_t cw_n_constraints(const cw_circuit *c);      /* from the .r1cs header, 0 if none loaded */
@@ -140,6 +141,12 @@ int64_t cw_remaining_inputs(const cw_batch *b, uint32_t instance);
 int cw_run(cw_batch *b);
 /* A*w o B*w = C*w over the loaded .r1cs for all instances (second kernel of the north-star). */
 int cw_check_r1cs(cw_batch *b);
+/* Event timing of the parts of cw_run / cw_check_r1cs on the batch's stream (HIP events recorded where the kernels are launched;
+ * no reference counterpart: the reference's runtime is one process per witness - this is what bench.py's roofline figures read).
+ * cw_batch_kernel_ms drains the stream and returns, for the LAST run / check: ms[0] = table init + input ingest, ms[1] = the
+ * evaluation kernel(s), ms[2] = the R1CS check; -1 for a part that has not run since timing was switched on. */
+int cw_batch_set_timing(cw_batch *b, int on);
+int cw_batch_kernel_ms(cw_batch *b, float ms[3]);
 int cw_sync(cw_batch *b);
 
 /* results (synchronise the stream first) */

@@ -125,10 +125,14 @@ def replay(prog_ir, body_info, q: int, n_signals: int, n_tslots: int, n_lds: int
                 if native is not None and TE.USE_NATIVE:
                     from circom_amd.circuits.bigint_func import native_eval
                     kind, n_, k_, modulus = native
-                    kname = {1: "mod_inv", 2: "ec_add", 3: "ec_double"}[kind]
-                    n_args = {1: k_, 2: 4 * k_, 3: 2 * k_}[kind]
-                    for j2, v2 in enumerate(native_eval(kname, n_, k_, modulus, [mem[slot0 + x] for x in range(n_args)])):
-                        mem[slot0 + n_args + j2] = v2
+                    from circom_amd.circuits.bigint_func import native_n_args
+                    kname = {1: "mod_inv", 2: "ec_add", 3: "ec_double", 4: "long_div"}[kind]
+                    n_args = native_n_args(kname, k_, modulus)
+                    try:
+                        for j2, v2 in enumerate(native_eval(kname, n_, k_, modulus, [mem[slot0 + x] for x in range(n_args)])):
+                            mem[slot0 + n_args + j2] = v2
+                    except ZeroDivisionError:     # long_div on a divisor outside its contract: the device flags the lane
+                        fail(2, seq)
                 elif not TE.run_dev_function(f, fcode, mem, slot0, consts):
                     fail(2, seq)
             elif k == "call":

@@ -39,10 +39,14 @@ def run_function(f: Field, fn: dict, regs: list, base: int, constants) -> bool:
         # reference runtime executing the body
         from circom_amd.circuits.bigint_func import native_eval
         kind, n, k, modulus = nat
-        res = native_eval(kind, n, k, modulus, [regs[base + r] for r in range(fn["n_args"])])
-        for j, v in enumerate(res):
-            regs[base + fn["ret_base"] + j] = v
-        return True
+        try:
+            res = native_eval(kind, n, k, modulus, [regs[base + r] for r in range(fn["n_args"])])
+        except ZeroDivisionError:
+            res = None                   # long_div outside the contract of its tag: the body decides (the reference's semantics)
+        if res is not None:
+            for j, v in enumerate(res):
+                regs[base + fn["ret_base"] + j] = v
+            return True
     code = fn["code"]
     bins = {k: getattr(f, v) for k, v in _BIN.items()}
     uns = {k: getattr(f, v) for k, v in _UN.items()}
@@ -183,7 +187,8 @@ def check_r1cs(q: int, constraints, w) -> int | None:
 # D_* numbering of circom_amd/csrc/cw_tape.h
 (D_COPY, D_ADD, D_SUB, D_NEG, D_MMUL, D_INV, D_IDIV, D_MOD, D_POW, D_SHL, D_SHR, D_BAND, D_BOR, D_BXOR,
  D_BNOT, D_LT, D_GT, D_LEQ, D_GEQ, D_EQ, D_NEQ, D_LAND, D_LOR, D_LNOT, D_SELECT, D_EXT, D_ASSERT_EQ,
- D_ASSERT_NZ, D_ALSO, D_BARRIER, D_MUL2, D_MADD, D_MULC, D_MADDC, D_LINSUM, D_BIT, D_DOTC, D_CALL) = range(38)   # D_ALSO unused
+ D_ASSERT_NZ, D_ALSO, D_BARRIER, D_MUL2, D_MADD, D_MULC, D_MADDC, D_LINSUM, D_BIT, D_DOTC, D_CALL, D_BITS) = range(39)   # D_ALSO: a spacer that does nothing
+X_NEXT = 1 << 29
 DF_JZ, DF_JMP, DF_LDX, DF_STX, DF_RET, DF_DIV = 100, 101, 102, 103, 104, 105     # device bytecode of circom functions (lower.py)
 FN_CONST = 1 << 31
 _DBIN = {D_ADD: "add", D_SUB: "sub", D_IDIV: "idiv", D_MOD: "mod", D_POW: "pow", D_SHL: "shl", D_SHR: "shr",
@@ -351,7 +356,7 @@ def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict,
         op = w0 & 0xFF
         if op == D_BARRIER or op == D_LINSUM or op == D_DOTC or op == D_CALL:
             return None, None                      # LINSUM / DOTC / CALL read their operands at execution time
-        if op == D_BIT:
+        if op == D_BIT or op == D_BITS:
             return fetch(s, (w0 >> SH_AK) & 7, a_), None
         ak, bk = (w0 >> SH_AK) & 7, (w0 >> SH_BK) & 7
         a = fetch(s, ak, a_)
@@ -423,17 +428,39 @@ def eval_rows(q: int, n_signals: int, n_tslots: int, consts, rows, inputs: dict,
                 res = acc % q
             elif op == D_BIT:
                 res = (a >> b_) & 1 if b_ < 256 else 0
+            elif op == D_BITS:                # consecutive bits of a from bit b: the entries of the extra table say where each goes
+                bit = b_
+                for e in extras[xp[s]:xp[s] + nx]:
+                    if e & X_LDS:
+                        raise ValueError("bit-field destinations live in the value table")
+                    if e & X_NEXT:
+                        bit += 1
+                    if bit >= 256:
+                        raise ValueError("bit-field row runs past bit 255")
+                    mem_write(s, 1 if e & X_TMP else 0, e & 0x1FFFFFFF, (a >> bit) & 1)
+                xp[s] += nx
+                nx = 0
+            elif op == D_ALSO:
+                pass
             elif op == D_CALL:                # a = function id, b = first register slot (pinned temps)
                 n_regs, fcode, native = functions[a_]
-                for k in range(n_regs):       # the interpreter reads and writes its registers in the value table
-                    writer[(1, b_ + k)] = (state["epoch"], s)
+                for k in range(n_regs):       # the interpreter reads and writes its registers in the value table: what another
+                    w_ = writer.get((1, b_ + k))   # strand stored there (the arguments) must be behind a FULL barrier
+                    if w_ is not None and w_[1] != s:
+                        mem_read(s, 1, b_ + k)
+                for k in range(n_regs):
+                    mem_write(s, 1, b_ + k, tmp[b_ + k])
                 if native is not None and USE_NATIVE:      # the device computes the closed form (eval_call_native)
                     from circom_amd.circuits.bigint_func import native_eval
                     kind, n_, k_, modulus = native
-                    kname = {1: "mod_inv", 2: "ec_add", 3: "ec_double"}[kind]
-                    n_args = {1: k_, 2: 4 * k_, 3: 2 * k_}[kind]
-                    for j, v in enumerate(native_eval(kname, n_, k_, modulus, [tmp[b_ + x] for x in range(n_args)])):
-                        tmp[b_ + n_args + j] = v
+                    from circom_amd.circuits.bigint_func import native_n_args
+                    kname = {1: "mod_inv", 2: "ec_add", 3: "ec_double", 4: "long_div"}[kind]
+                    n_args = native_n_args(kname, k_, modulus)
+                    try:
+                        for j, v in enumerate(native_eval(kname, n_, k_, modulus, [tmp[b_ + x] for x in range(n_args)])):
+                            tmp[b_ + n_args + j] = v
+                    except ZeroDivisionError:     # long_div on a divisor outside its contract: the device flags the lane
+                        fail(s, 2, r)
                 elif not run_dev_function(f, fcode, tmp, b_, consts):
                     fail(s, 2, r)
             elif op == D_SELECT:

@@ -384,7 +384,7 @@ def test_tags_declared_values_are_readable_inside_the_template():
     ("template T() { signal input a; signal output o; assert(1 == 2); o <== a; } component main = T();", "assert failed"),
     ("template T() { signal input a; signal output o; component c; c.x <== a; o <== a; } component main = T();", "before it is instantiated"),
     ("template S() { signal input x; signal output y; y <== x; } template T() { signal input a; signal output o; component c = S(); "
-     "o <== c.y; } component main = T();", "never received all its inputs"),
+     "o <== c.y; } component main = T();", "not all its inputs initialized"),
     ("template T() { signal input a; signal output o; o = a; } component main = T();", "assigned with <== or <--"),
     ("template T() { signal input a; signal output o; var x; x <== a; o <== a; } component main = T();", "assigned with ="),
     ("function f(x) { signal s; return x; } template T() { signal input a; signal output o; o <== f(1); } component main = T();",

@@ -66,3 +66,17 @@ def test_declaration_forms_and_compile_time_tables():
     sig, failed = _run(fc, [5])
     # outputs in declaration order: out[4], prod, hinted
     assert failed is None and sig[1:7] == [5, 15, 15, 5, 225, 10] and check_r1cs(Q, fc.constraints, sig) is None
+
+
+def test_output_of_a_component_without_all_its_inputs_is_refused():
+    """execute.rs:3973: `o <== c.z; c.x <== a;` - the reference refuses to read c.z before c has every input; reading an
+    INPUT of the component, or the output once the inputs are in, stays allowed"""
+    from circom_amd.frontend.dsl import CircuitError as CircomError
+    sq = "template Sq() { signal input x; signal output z; z <== x*x; }\n"
+    bad = sq + "template M() { signal input a; signal output o; component c = Sq(); o <== c.z; c.x <== a; }\ncomponent main = M();\n"
+    with pytest.raises(CircomError, match="not all its inputs initialized"):
+        flatten(program_from_text(bad))
+    good = sq + "template M() { signal input a; signal output o; component c = Sq(); c.x <== a; o <== c.z + c.x; }\ncomponent main = M();\n"
+    fc = flatten(program_from_text(good))
+    sig, failed = _run(fc, [5])
+    assert failed is None and sig[1] == 30

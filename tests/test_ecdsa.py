@@ -218,3 +218,145 @@ def test_gpu_native_curve_functions_on_secp256k1(tmp_path):
             assert (st[i] & 1) == (0 if failed is None else 1), (name, i)
             assert bool(st[i] & 4) == (check_r1cs(cp.flat.fp.q, cp.flat.constraints, sig) is not None), (name, i)
         b.close(); c.close()
+
+
+# ---- long_div with its closed form (the quotient hint of CheckZeroModP) ----------------------------------------------------------
+def _long_div_cases(n, k, m, rnd, count):
+    """argument vectors inside the tag's contract (proper limbs, b[k-1] != 0), with the edges Knuth D cares about: quotient
+    digits of all ones, a divisor of minimal / maximal top limb, a dividend just below and at a multiple of the divisor"""
+    top = (1 << n) - 1
+    out = []
+    for it in range(count):
+        kind = it % 6
+        if kind == 0:
+            b = rnd.randrange(1 << (n * (k - 1)), 1 << (n * k))
+        elif kind == 1:
+            b = (1 << (n * (k - 1))) + rnd.randrange(1 << (n * (k - 1)))            # smallest top limb
+        elif kind == 2:
+            b = (1 << (n * k)) - 1 - rnd.randrange(1 << 8)                          # all-ones divisor
+        else:
+            b = rnd.randrange(1 << (n * k - 1), 1 << (n * k))
+        if kind == 3:
+            a = b * rnd.randrange(1 << (n * m)) - 1                                 # remainder b - 1
+        elif kind == 4:
+            a = b * rnd.randrange(1 << (n * m))                                     # remainder 0
+        elif kind == 5:
+            a = (1 << (n * (k + m))) - 1 - rnd.randrange(1 << 16)                   # the largest dividends
+        else:
+            a = rnd.randrange(1 << (n * (k + m)))
+        a = max(a, 0) % (1 << (n * (k + m)))
+        out.append(BF.limbs_of(a, n, k + m) + BF.limbs_of(b, n, k))
+    out.append([top] * (k + m) + [0] * (k - 1) + [1])                               # b = 2^(n (k-1)): pure limb shift
+    out.append([0] * (k + m) + [top] * k)
+    return out
+
+
+@pytest.mark.parametrize("n,k,m", [(8, 2, 3), (64, 4, 5), (32, 3, 3), (50, 3, 2)])
+def test_long_div_body_equals_its_closed_form(n, k, m):
+    rnd = random.Random(n * 100 + k * 10 + m)
+    f_div = RtFunction("long_div", 2 * k + m, BF.build_long_div(n, k, m), _FP)
+    assert f_div.ret_base == 2 * k + m and f_div.n_ret == m + 1 + k
+    for args in _long_div_cases(n, k, m, rnd, 6 if n >= 50 else 18):
+        got = _run_bytecode(f_div, args)
+        assert got == BF.native_eval("long_div", n, k, m, args)
+        a, b = BF.int_of(args[:k + m], n), BF.int_of(args[k + m:], n)
+        assert BF.int_of(got[:m + 1], n) * b + BF.int_of(got[m + 1:], n) == a and BF.int_of(got[m + 1:], n) < b
+    with pytest.raises(ZeroDivisionError):                       # outside the contract the closed form refuses (the oracle then runs the body)
+        BF.native_eval("long_div", n, k, m, [1] * (k + m) + [1] * (k - 1) + [0])
+
+
+def _long_div_program(n, k, m, native=True):
+    from circom_amd.frontend.dsl import template
+
+    @template
+    def LongDivHint(c, n, k, m):
+        a = c.input("a", k + m)
+        b = c.input("b", k)
+        out = c.output("out", m + 1 + k)
+        fn = c.function("long_div_%d_%d_%d" % (n, k, m), 2 * k + m, BF.build_long_div(n, k, m),
+                        native=("long_div", n, k, m) if native else None)
+        res = c.call(fn, [a[i] for i in range(k + m)] + [b[i] for i in range(k)])
+        for i in range(m + 1 + k):
+            c.hint(out[i], res[i])
+    return Program(LongDivHint(n, k, m), prime="bls12381")
+
+
+def test_long_div_tag_reaches_the_tape(tmp_path):
+    cp = compile_program(_long_div_program(64, 4, 5), str(tmp_path), "ld", sym=False, strands=(1,), fpjit=False)
+    assert [f[2] for f in cp.tape.functions] == [(4, 64, 4, 5)]
+    cp = compile_program(_long_div_program(8, 2, 3), str(tmp_path), "ld8", sym=False, strands=(1,), fpjit=False)
+    assert [f[2] for f in cp.tape.functions] == [None]           # limbs below 32 bits: the device interprets the body
+    # the schedule replay (oracle of the device's rows) takes the closed form as well
+    from oracle.tape_eval import eval_tape
+    cp = compile_program(_long_div_program(32, 3, 3), str(tmp_path), "ld32", sym=False, strands=(1,), fpjit=False)
+    rnd = random.Random(5)
+    for args in _long_div_cases(32, 3, 3, rnd, 6):
+        sig, st = eval_tape(cp.tape, {cp.flat.main_input_start + i: v for i, v in enumerate(args)})
+        assert st == 0 and sig[1:1 + 7] == BF.native_eval("long_div", 32, 3, 3, args)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k,m", [(64, 4, 5), (32, 3, 3), (50, 3, 2), (64, 4, 4), (64, 2, 7)])
+def test_gpu_native_long_div(tmp_path, n, k, m):
+    """the device's Knuth D on packed 32-bit words (csrc/cw_call.hip.h eval_call_long_div: word-aligned and generic limb
+    widths) against Python integers, one argument vector per lane incl. the edge cases; one lane outside the contract
+    (top limb of the divisor 0) is flagged instead of answered"""
+    from circom_amd import runtime as rt
+    cp = compile_program(_long_div_program(n, k, m), str(tmp_path), "ld", sym=False, strands=(1,))
+    assert cp.tape.functions[0][2] == (4, n, k, m)
+    c = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
+    rnd = random.Random(n + k + m)
+    rows = _long_div_cases(n, k, m, rnd, 190)
+    bad = 17
+    rows[bad] = rows[bad][:k + m] + rows[bad][k + m:2 * k + m - 1] + [0]
+    b = c.batch(len(rows))
+    b.set_inputs(rows)
+    b.run(); b.sync()
+    st = b.status()
+    for i, args in enumerate(rows):
+        if i == bad:
+            assert st[i] & 3
+            continue
+        assert st[i] == 0, i
+        assert b.witness(i)[1:1 + m + 1 + k] == BF.native_eval("long_div", n, k, m, args), (i, args)
+    b.close(); c.close()
+
+
+@pytest.mark.parametrize("which", ["add", "double", "verify"])
+def test_schedules_with_calls_on_several_strands(which):
+    """circuits with run-time functions on 1 / 4 / 16 strands: a call is a heavy unit of its level between FULL barriers, the
+    bit rows of the range checks travel as D_BITS rows (lower.py passes A7 / C) - the replay of the rows (oracle/tape_eval.py,
+    which reports every cross-strand hand-off without the barrier it needs and fetches operands one row ahead like the kernel)
+    gives the flat program's witness"""
+    from circom_amd.hip_elements.lower import lower, D_BITS
+    from oracle.tape_eval import eval_tape
+    rnd = random.Random(11)
+    n, k, cv = TN, TK, TOY
+    P1, P2 = _point(cv, rnd), _point(cv, rnd)
+    if which == "add":
+        prog, inputs = Program(S.EcAddUnequal(n, k, cv), prime="bls12381"), _limbs(P1, n, k) + _limbs(P2, n, k)
+    elif which == "double":
+        prog, inputs = Program(S.EcDouble(n, k, cv), prime="bls12381"), _limbs(P1, n, k)
+    else:
+        prog, inputs = Program(S.ECDSAVerifyNoPubkeyCheck(n, k, cv, 2), prime="bls12381"), S.sign(cv, n, k, rnd)
+    fc = flatten(prog)
+    inp = {fc.main_input_start + i: v for i, v in enumerate(inputs)}
+    want, failed = _eval(fc, inputs)
+    assert failed is None
+    for S_ in (1, 4, 16):
+        t = lower(fc, n_strands=S_)
+        t1 = t
+        if S_ == 1:
+            assert t.stats["bits_rows"] == 0                  # (one strand keeps the rows the emitted code has bodies for)
+            t = lower(fc, n_strands=1, fuse_bits=True)
+        assert t.n_strands == S_ and t.stats["bits_rows"] > 0 and t.stats["bits_fused"] > 2 * t.stats["bits_rows"]
+        for tt in {id(t): t, id(t1): t1}.values():
+            got, st = eval_tape(tt, inp)
+            assert st == 0 and got == want, S_
+        if S_ > 1:
+            assert t.stats["full_barriers"] > 0
+    # without the fusion: the same witness from one row per bit
+    t = lower(fc, n_strands=4, fuse_bits=False)
+    assert t.stats["bits_rows"] == 0
+    got, st = eval_tape(t, inp)
+    assert st == 0 and got == want

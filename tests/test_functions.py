@@ -107,18 +107,23 @@ def test_oracle_interprets_loops_branches_and_indexed_arrays():
 @pytest.mark.parametrize("tmpl", [LongDiv, Pick])
 def test_lowered_schedule_runs_the_function(tmpl):
     fc = flatten(Program(tmpl()))
-    t = lower(fc, n_strands=4)
-    assert t.n_strands == 1 and len(t.functions) == 1          # tier-2 code: one strand, program order
     rnd = random.Random(2)
-    for _ in range(40):
-        if tmpl is LongDiv:
-            inp = {3: rnd.randrange(1 << 20), 4: rnd.randrange(1, 1 << 10)}
-        else:
-            inp = {2 + k: rnd.randrange(fc.fp.q) for k in range(8)}
-            inp[10] = rnd.randrange(8)
-        a, fa = _flat(fc, inp)
-        b, st = eval_tape(t, inp)
-        assert fa is None and st == 0 and a == b
+    for S in (1, 4, 16):
+        # a call is a heavy unit of its level on ONE strand; the barriers around that level drain global stores (the register
+        # window lives in the value table) - eval_tape reports any argument or result that crosses strands without one
+        t = lower(fc, n_strands=S)
+        assert t.n_strands == S and len(t.functions) == 1
+        if S > 1:
+            assert t.stats["full_barriers"] >= 2
+        for _ in range(20):
+            if tmpl is LongDiv:
+                inp = {3: rnd.randrange(1 << 20), 4: rnd.randrange(1, 1 << 10)}
+            else:
+                inp = {2 + k: rnd.randrange(fc.fp.q) for k in range(8)}
+                inp[10] = rnd.randrange(8)
+            a, fa = _flat(fc, inp)
+            b, st = eval_tape(t, inp)
+            assert fa is None and st == 0 and a == b
 
 
 def test_reference_runtime_executes_the_same_function(tmp_path, ref_dir_bn128):

@@ -4,4 +4,4 @@
 set -e
 cd "$(dirname "$0")/../circom_amd/csrc"
 mkdir -p ../../gpurun_in
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DCW_PROFILE -Wno-unused-value -shared -x hip cw_kernels.hip cw_bits.hip cw_host.cpp -o ../../gpurun_in/libcircom_amd_prof.so
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DCW_PROFILE -Wno-unused-value -shared -x hip cw_kernels.hip cw_bits.hip cw64.hip cw_host.cpp -o ../../gpurun_in/libcircom_amd_prof.so
