@@ -588,6 +588,10 @@ def main():
         streams.append(st_)
         batches.append(b_)
     n_fl = len(batches)
+    # HIP events around the parts of cw_run / cw_check_r1cs ON the stream each batch launches its kernels on (the C ABI records
+    # them: cw_batch_set_timing / cw_batch_kernel_ms) - the kernels' own intervals, alone and inside the timed region
+    for b_ in batches:
+        b_.set_timing(True)
 
     def step(i, ev=None):
         b, s_ = batches[i % n_fl], streams[i % n_fl]
@@ -607,6 +611,7 @@ def main():
     torch.cuda.synchronize()
     isolated = {"eval_ms": iso[0].elapsed_time(iso[1]), "r1cs_check_ms": iso[1].elapsed_time(iso[2]),
                 "ms_per_step": iso[0].elapsed_time(iso[2])}
+    isolated["kernels_ms"] = batch.kernel_ms()           # {ingest (+ table init), eval, check}: each part's own event pair
     for i in range(max(args.warmup, n_fl)):
         step(i)
     torch.cuda.synchronize()
@@ -625,6 +630,10 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # the parts' intervals of the LAST timed step of every batch in flight (they ran beside each other)
+    in_step_k = [b_.kernel_ms() for b_ in batches[:min(n_fl, args.steps)]]
+    in_step = {k: (sum(d_[k] for d_ in in_step_k if d_[k] is not None) / max(1, sum(1 for d_ in in_step_k if d_[k] is not None)))
+               if any(d_[k] is not None for d_ in in_step_k) else None for k in ("ingest", "eval", "check")}
     for b_ in batches[1:]:                                   # every batch in flight computed the same instances
         assert (b_.status() == batch.status()).all()
 
@@ -796,21 +805,29 @@ def main():
             js = getattr(cp, "jit_stats", {}) or {}
             chunks = (B + 2047) // 2048
             ek = "cw_bits_jit (emitted per circuit)"
-            kern_ms = isolated.get("eval_only_ms") or isolated["eval_ms"]
+            kern_ms = isolated["kernels_ms"]["eval"] or isolated.get("eval_only_ms") or isolated["eval_ms"]
             tab_bytes = 8.0 * batch.bits_slots * batch.bits_groups
             reload_bytes = 256.0 * (js.get("prefetched", 0) + js.get("late_loads", 0)) * chunks
             insts = float(js.get("instructions", 0)) * chunks
+            # VALU instructions only (what the 2-clock issue roof is a roof of): SQ_INSTS_VALU when profiles/ holds the counter
+            # of this source, else the emitter's own count (every instruction that is not a memory instruction or a wait)
+            non_valu = sum(js.get(k_, 0) for k_ in ("stores", "prefetched", "late_loads", "loads_for_check", "waits", "scratch_stores"))
+            valu_insts = prof.get("eval_valu_insts") or float(js.get("instructions", 0) - non_valu) * chunks
+            valu_src = "SQ_INSTS_VALU (profiles/)" if prof.get("eval_valu_insts") else "the emitter's count: instructions that are neither memory nor wait"
             roof_eval = {"bound": "hbm", "kernel": ek, "unit": "GB/s", "achieved": tab_bytes / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "frac": tab_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": kern_ms,
-                         "kernel_ms_source": "HIP events in this run, one step alone, packed inputs (init + 10 us input copy + the emitted kernel)",
+                         "kernel_ms_source": "HIP events around the emitted kernel on its stream (cw_batch_kernel_ms), one step alone; in_step_ms = "
+                                             "the same interval inside the timed region, other batches in flight",
+                         "in_step_ms": in_step["eval"],
                          "algorithmic_bytes_per_launch": tab_bytes,
                          "algorithmic_bytes_are": "the bit table: one 256-byte row per distinct signal value (%d rows) and chunk of 2 048 instances, written once" % batch.bits_slots,
-                         "traffic": prof.get("eval"), "traffic_source": prof.get("counters_from"),
+                         "traffic": prof.get("eval"), "traffic_source": prof.get("counters_from"), "traffic_measured_in_run": False,
                          "traffic_estimate": {"table_rows_written": tab_bytes, "rows_re_read": reload_bytes,
                                               "GB/s_incl_re_reads": (tab_bytes + reload_bytes) / (kern_ms * 1e-3) / 1e9,
                                               "frac_incl_re_reads": (tab_bytes + reload_bytes) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          "waves": chunks, "instructions_per_wave": js.get("instructions"), "gates_per_wave": js.get("gates"),
-                         "valu_issue": {"wave_insts_per_s": insts / (kern_ms * 1e-3), "peak": valu_peak, "frac": insts / (kern_ms * 1e-3) / valu_peak,
+                         "valu_issue": {"wave_insts_per_s": valu_insts / (kern_ms * 1e-3), "peak": valu_peak, "frac": valu_insts / (kern_ms * 1e-3) / valu_peak,
+                                        "valu_insts_source": valu_src, "all_instructions_per_s": insts / (kern_ms * 1e-3),
                                         "lone_wave_frac": (js.get("instructions", 0) / (kern_ms * 1e-3)) / (clk / LONE_WAVE_CLK_PER_INST)},
                          "gate_evaluations_per_s": float(js.get("gates", 0)) * B / (kern_ms * 1e-3),
                          "fused_r1cs_check": {k[6:]: v for k, v in js.items() if k.startswith("check_")}}
@@ -819,15 +836,17 @@ def main():
                          "frac": None, "traffic": prof.get("r1cs"),
                          "note": "every non-trivial constraint is evaluated on the registers that hold its wires while the witness is generated "
                                  "(SURVEY 8d: B_chk -> 0); the stand-alone kernels remain as the audit (CW_R1CS_AUDIT=1, or after cw_device_bits)"}
-            roof_valu = {"bound": "valu", "kernel": ek, "unit": "wave-instructions/s", "achieved": insts / (kern_ms * 1e-3), "peak": valu_peak,
-                         "frac": insts / (kern_ms * 1e-3) / valu_peak, "kernel_ms": kern_ms, "clock_hz": clk}
-            ing_ms = isolated.get("ingest_ms")
+            roof_valu = {"bound": "valu", "kernel": ek, "unit": "VALU wave-instructions/s", "achieved": valu_insts / (kern_ms * 1e-3), "peak": valu_peak,
+                         "frac": valu_insts / (kern_ms * 1e-3) / valu_peak, "valu_insts_source": valu_src, "kernel_ms": kern_ms, "clock_hz": clk}
+            ing_ms = (isolated["kernels_ms"]["ingest"] if not args.packed_inputs else None) or isolated.get("ingest_ms")
             roof_ingest = None if not ing_ms else {"bound": "hbm", "kernel": "cw_bits_ingest_kernel", "unit": "GB/s", "achieved": 32.0 * n_in * B / (ing_ms * 1e-3) / 1e9,
                            "peak": HBM_PEAK_GBS, "frac": 32.0 * n_in * B / (ing_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": ing_ms,
-                           "kernel_ms_source": "HIP events in this run: step with 32-byte inputs minus step with packed inputs",
+                           "kernel_ms_source": "HIP events around table init + cw_bits_ingest_kernel on their stream (cw_batch_kernel_ms), one step "
+                                               "alone; in_step_ms = the same interval inside the timed region, other batches in flight",
+                           "in_step_ms": in_step["ingest"],
                            "algorithmic_bytes_per_launch": 32.0 * n_in * B,
                            "algorithmic_bytes_are": "the boundary's input image: 32 bytes per input signal and instance, read once",
-                           "traffic": prof.get("ingest"), "traffic_source": prof.get("counters_from")}
+                           "traffic": prof.get("ingest"), "traffic_source": prof.get("counters_from"), "traffic_measured_in_run": False}
         elif batch.bitmode:
             # The bit-plane engine holds ONE BIT per distinct signal value and instance: its kernels neither read nor write
             # the 32-byte image, so SURVEY 8d's byte roof does not bind them (round 2 divided the image's bytes by their
@@ -872,18 +891,22 @@ def main():
                 ek = "cw_fp_jit (emitted per circuit%s)" % (", R1CS check fused" if batch.fused_check else "")
                 if batch.fused_check:
                     rk = "fused into cw_fp_jit; cw_r1cs_stream_kernel on the rows the code leaves + merge"
-            gen_k = prof.get("eval_avg_us", 0.0) / 1e3 or isolated["eval_ms"]
-            chk_k = prof.get("r1cs_avg_us", 0.0) / 1e3 or isolated["r1cs_check_ms"]
+            gen_k = prof.get("eval_avg_us", 0.0) / 1e3 or isolated["kernels_ms"]["eval"] or isolated["eval_ms"]
+            chk_k = prof.get("r1cs_avg_us", 0.0) / 1e3 or isolated["kernels_ms"]["check"] or isolated["r1cs_check_ms"]
             gen_gbs = alg_gen / (gen_k * 1e-3) / 1e9
-            chk_gbs = alg_chk / (chk_k * 1e-3) / 1e9
+            # (a fused check reads no witness image: its rows are recomputed on the evaluation's registers - no byte fraction)
+            chk_gbs = None if getattr(batch, "fused_check", False) else alg_chk / (chk_k * 1e-3) / 1e9
             roof_eval = {"bound": "hbm", "kernel": ek, "achieved": gen_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gen_gbs / HBM_PEAK_GBS, "traffic": prof.get("eval"), "algorithmic_bytes_per_launch": alg_gen,
-                         "kernel_ms": gen_k, "strands": batch.strands, "lanes_per_workgroup": batch.lanes,
+                         "kernel_ms": gen_k, "in_step_ms": in_step["eval"], "strands": batch.strands, "lanes_per_workgroup": batch.lanes,
+                         "kernel_ms_source": "rocprofv3 kernel trace (profiles/)" if prof.get("eval_avg_us") else
+                         "HIP events around the evaluation kernel on its stream (cw_batch_kernel_ms), one step alone",
                          "emitted_code": ([e for e in getattr(cp, "fpjit_stats", []) if e.get("n_strands") == batch.strands and
                                            bool(e.get("constraints_fused")) == bool(batch.fused_check)] or [None])[0]
                          if getattr(batch, "emitted", False) else None}
             roof_r1cs = {"bound": "hbm", "kernel": rk, "achieved": chk_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": chk_gbs / HBM_PEAK_GBS, "traffic": prof.get("r1cs"), "algorithmic_bytes_per_launch": alg_chk,
+                         "frac": None if chk_gbs is None else chk_gbs / HBM_PEAK_GBS, "traffic": prof.get("r1cs"),
+                         "algorithmic_bytes_per_launch": None if chk_gbs is None else alg_chk,
                          "kernel_ms": chk_k,
                          # the check of an arithmetic circuit is bound by instruction issue, not by bytes (Poseidon(2): 7.1e8 wave
                          # instructions per launch, most of them half-rate 32-bit multiplies): fraction of the 2-clock VALU peak
@@ -957,6 +980,7 @@ def main():
             "eval_ms": gen_ms,
             "r1cs_check_ms": chk_ms,
             "isolated": isolated,
+            "in_step_kernels_ms": in_step,             # ingest / eval / check: event pairs on each batch's stream, inside the timed region
             "failed_instances": n_bad,
             "parity": parity,
             "parity_checked": parity["parity_checked"] if parity else 0,

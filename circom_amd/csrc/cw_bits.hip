@@ -450,7 +450,7 @@ cw_bits_gather_kernel(const uint64_t *__restrict__ T, uint64_t slots, uint32_t l
 __global__ void __launch_bounds__(256)
 cw_bits_ingest_packed_kernel(const uint64_t *__restrict__ masks, uint64_t *__restrict__ T, uint64_t slots, uint32_t sh, uint32_t input_slot0,
                              uint32_t n_in, uint32_t batch) {
-    const uint32_t k = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    const uint32_t k = blockIdx.y * 256 + threadIdx.x, g = blockIdx.x;   // (groups in x: 65 536 of them at 2^22 instances)
     if (k >= n_in) return;
     uint64_t m = masks[(size_t)g * n_in + k];
     const uint32_t live = batch - g * 64;                            // instances of the last group beyond the batch read as 0
@@ -763,7 +763,7 @@ hipError_t cwk_bits_gather(hipStream_t s, const void *T, uint64_t slots, uint32_
 hipError_t cwk_bits_ingest_packed(hipStream_t s, const void *masks, void *T, uint64_t slots, uint32_t sh, uint32_t input_slot0, uint32_t n_in,
                                   uint32_t batch) {
     if (n_in == 0) return hipSuccess;
-    dim3 g((n_in + 255) / 256, (batch + 63) / 64);
+    dim3 g((batch + 63) / 64, (n_in + 255) / 256);
     if (g.y > 65535u) return hipErrorInvalidValue;
     hipLaunchKernelGGL(cw_bits_ingest_packed_kernel, g, dim3(256), 0, s, (const uint64_t *)masks, (uint64_t *)T, slots, sh, input_slot0, n_in,
                        batch);

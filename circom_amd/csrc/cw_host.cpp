@@ -721,9 +721,8 @@ static int load_tape(cw_circuit *c, const char *path) {
         c->fn_tab.push_back(0);
         if (nat_kind == 4) {
             // long_div(a[k + m], b[k]) -> div[m + 1] ++ mod[k] (csrc/cw_call.hip.h eval_call_long_div): m travels in the modulus field
-            const uint32_t nat_m = fmod.w[0];
-            bool small = true;
-            for (int t = 1; t < 8; t++) small = small && fmod.w[t] == 0;
+            const uint32_t nat_m = (uint32_t)fmod.w[0];
+            const bool small = fmod.w[0] < 16 && fmod.w[1] == 0 && fmod.w[2] == 0 && fmod.w[3] == 0;
             if (!small || nat_n < 32 || nat_n > 64 || nat_k == 0 || nat_k > 15 || nat_n * nat_k > 256 || nat_m == 0 || nat_m > 15 ||
                 (nat_k + nat_m) * nat_n > 640 || 3 * nat_k + 2 * nat_m + 1 > n_regs)
                 return fail(CW_EIO, "tape function: bad native tag");

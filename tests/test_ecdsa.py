@@ -284,6 +284,8 @@ def _long_div_program(n, k, m, native=True):
 def test_long_div_tag_reaches_the_tape(tmp_path):
     cp = compile_program(_long_div_program(64, 4, 5), str(tmp_path), "ld", sym=False, strands=(1,), fpjit=False)
     assert [f[2] for f in cp.tape.functions] == [(4, 64, 4, 5)]
+    from circom_amd import runtime as rt
+    rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path).close()     # the loader accepts the tag (shape checks of cw_load)
     cp = compile_program(_long_div_program(8, 2, 3), str(tmp_path), "ld8", sym=False, strands=(1,), fpjit=False)
     assert [f[2] for f in cp.tape.functions] == [None]           # limbs below 32 bits: the device interprets the body
     # the schedule replay (oracle of the device's rows) takes the closed form as well

@@ -325,7 +325,8 @@ def test_gpu_emitted_code_runs_circom_functions(tmp_path, monkeypatch):
     every instance takes its own path through the functions"""
     from circom_amd.circuits.bigint import BigMultModP
     n, k = 32, 3
-    cp = compile_program(Program(BigMultModP(n, k), prime="bls12381"), str(tmp_path), "bigmultmodp", sym=False, fpjit=True)
+    # (one strand: schedules with calls on several strands run on the interpreting kernel - tests/test_functions.py)
+    cp = compile_program(Program(BigMultModP(n, k), prime="bls12381"), str(tmp_path), "bigmultmodp", sym=False, strands=(1,), fpjit=True)
     assert cp.fpjit and all(p.n_strands == 1 for p in cp.fpjit)
     rnd = random.Random(12)
     rows = []
