@@ -136,10 +136,19 @@ def _o1_size(fc):
             return None
         from circom_amd.frontend.circom_simplify import simplify_o1
         sm = simplify_o1(fc)
+        _o1_size.witness2signal = np_asarray_u32(sm.witness2signal)      # kept for the O1 egress measurement below
         return {"wires": sm.n_wires, "constraints": len(sm.constraints),
                 "note": "the device generates and checks the --O0 system; cw_set_witness_list hands out these wires"}
     except Exception as ex:                                       # noqa: BLE001
         return {"error": repr(ex)[:200]}
+
+
+_o1_size.witness2signal = None
+
+
+def np_asarray_u32(x):
+    import numpy as np
+    return np.ascontiguousarray(x, dtype=np.uint32)
 
 
 def get_compiled(name: str, batch: int, cache_root: str, rank: int, dist):
@@ -298,6 +307,21 @@ class BoolInputs:
         return out
 
 
+XGMI_LINK_GBS = 153.0            # per point-to-point link (MI355X_MICROARCH.md); every peer reaches rank 0 over its own link
+
+
+def xgmi_gather_ms(n_public: int, rows_per_peer: int) -> float:
+    """the job's one exchange, predicted: each peer's status words + public signals to rank 0, links in parallel"""
+    return 0.02 + (4 + 32 * n_public) * rows_per_peer / (XGMI_LINK_GBS * 1e9) * 1e3
+
+
+def batch_witness_bytes(b, i, n_wit):
+    """the witness of instance i as the per-instance egress hands it out (cw_get_witness): n_wit x 32 bytes"""
+    wb = b.witness_bytes(i)
+    assert len(wb) == n_wit * 32
+    return wb
+
+
 def dominant_roofline(roof_eval, roof_r1cs, roof_ingest, gen_ms, chk_ms, jit, packed):
     """the roofline object of the kernel with the longest measured duration in this run"""
     if jit:
@@ -433,18 +457,138 @@ def host_only_rehearsal(args, world, rank):
     words = torch.tensor([batch.staged_input(k, 0) % (1 << 20) for k in range(B)], dtype=torch.int32)
     got = gather_status(words, dist, rank, world)
     rows = gather_rows(torch.from_numpy(np.ascontiguousarray(h_in[:, :1, :])), dist, rank, world)
+    shard_sizes = gather_status(torch.tensor([B], dtype=torch.int32), dist, rank, world)       # what every rank owns
     if rank == 0:
         print(json.dumps({"metric": "witnesses/sec (batched inputs)", "value": None, "unit": "witnesses/s", "n_gpus": world,
                           "steps": 0, "warmup": 0, "ms_per_step": None, "higher_is_better": True, "scaling": scaling,
                           "vs_baseline": None, "dtype": "none (host-only rehearsal)", "data": "synthetic", "host_only": True,
                           "config": {"workload": "%s, batch=%d per rank (host-only rehearsal of the launch path)" % (args.workload, B),
                                      "compile_s": compile_s, "compile_cached": cached},
-                          "gathered": {"status_words": int(got.numel()), "public_signal_rows": int(rows.shape[0])}}))
+                          "gathered": {"status_words": int(got.numel()), "public_signal_rows": int(rows.shape[0])},
+                          "shards": [int(x) for x in shard_sizes.tolist()],
+                          # the job's one exchange on the GPU path: status word + public signals of every instance, peer -> rank 0
+                          "gather_bytes_per_peer": (4 + 32 * circ.n_public) * B,
+                          "predicted_gather_ms": xgmi_gather_ms(circ.n_public, B) if world > 1 else 0.0}))
     batch.close()
     circ.close()
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def goldilocks_bench(args):
+    """`--workload poseidon2_goldilocks`: SURVEY row f4 measured - Poseidon(2) on the reference's 64-bit runtime prime (`--prime
+    goldilocks`: goldilocks/fr.hpp + common64/), its own small engine on the device (csrc/cw64.hip: one 8-byte value per signal
+    and instance, one row per operation).  One JSON line of the usual shape; parity = full n8 = 8 `.wtns` files against the
+    reference's 64-bit runtime (oracle/_ref/goldilocks/poseidon2, built by build()) or, where that binary is absent, against the
+    Python oracle; cpu_baseline = that runtime's CLI, one process per witness (it has no in-process loop build)."""
+    import numpy as np
+    import torch
+    from circom_amd import runtime as rt, compiler
+    from circom_amd.frontend.dsl import Program
+    from circom_amd.circuits.poseidon import Poseidon
+    from circom_amd.hip_elements.writers import wtns_bytes
+    name, B = "poseidon2", args.batch or 65536
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    d = tempfile.mkdtemp(prefix="cw_gl_")
+    t0 = time.perf_counter()
+    cp = compiler.compile_program(Program(Poseidon(2), prime="goldilocks"), d, name, sym=False)
+    compile_s = time.perf_counter() - t0
+    circ = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
+    q, n_in, n_wit = circ.q, circ.n_inputs, circ.n_witness
+    rng = np.random.default_rng(7)
+    vals = rng.integers(0, q, size=(B, n_in), dtype=np.uint64)
+    h_in = np.zeros((B, n_in, 32), dtype=np.uint8)
+    h_in[:, :, :8] = vals.view(np.uint8).reshape(B, n_in, 8)
+    d_in = torch.from_numpy(h_in).to(dev)
+    n_fl = max(1, args.in_flight or 2)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_fl)]
+    batches = [circ.batch(B, device=0, stream=s_.cuda_stream) for s_ in streams]
+    for b_ in batches:
+        b_.set_inputs_device(d_in.data_ptr())
+        b_.set_timing(True)
+
+    def step(i):
+        b_ = batches[i % n_fl]
+        b_.run()
+        b_.check_r1cs()
+    step(0); torch.cuda.synchronize()
+    step(0); torch.cuda.synchronize()
+    iso = batches[0].kernel_ms()
+    for i in range(max(args.warmup, n_fl)):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    st = batches[0].status()
+    assert (st == 0).all(), "failed instances on the goldilocks workload"
+    # parity: full .wtns bytes of a few instances
+    picks = sorted({0, 1, B // 2, B - 1})
+    cli = ROOT / "oracle" / "_ref" / "goldilocks" / name
+    par = {"instances": picks}
+    for i in picks:
+        p_ = os.path.join(d, "g%d.wtns" % i)
+        batches[0].write_wtns(i, p_)
+        got = open(p_, "rb").read()
+        row = [int(v) for v in vals[i]]
+        if cli.exists():
+            from oracle import ref_build
+            out_w = Path(d) / ("r%d.wtns" % i)
+            r_ = ref_build.run_cli64(cli, json.dumps({"inputs": [str(x) for x in row]}), out_w)
+            assert r_.returncode == 0, r_.stderr[-300:]
+            want = out_w.read_bytes()
+            par["oracle"] = "reference 64-bit runtime (oracle/_ref/goldilocks/%s: goldilocks/fr.hpp + common64/), full .wtns bytes" % name
+        else:
+            from oracle.tape_eval import eval_flat
+            fc = cp.flat
+            sig, failed = eval_flat(q, fc.n_signals, fc.n_temps, fc.constants, fc.code, {fc.main_input_start + k: v for k, v in enumerate(row)})
+            assert failed is None
+            want = wtns_bytes(q, sig)
+            par["oracle"] = "oracle/tape_eval.eval_flat on the Goldilocks prime (pinned to the reference's 64-bit runtime by tests/test_goldilocks_oracle.py)"
+        assert got == want, "PARITY FAILURE: goldilocks .wtns of instance %d" % i
+    par["parity_checked"] = len(picks)
+    # the kernels' own intervals and their byte roof: 8 bytes per value (SURVEY 8d with n8 = 8)
+    alg_gen, alg_chk = 8.0 * (n_in + n_wit) * B, 8.0 * n_wit * B
+    roof = {"bound": "hbm", "kernel": "cw64_eval_kernel (one row per operation, 8-byte values)", "unit": "GB/s",
+            "achieved": alg_gen / (iso["eval"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "frac": alg_gen / (iso["eval"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "traffic": None, "traffic_measured_in_run": False, "algorithmic_bytes_per_launch": alg_gen, "kernel_ms": iso["eval"],
+            "kernel_ms_source": "HIP events around the kernel on its stream (cw_batch_kernel_ms), one step alone",
+            "rows_per_witness": int(circ.n_rows), "field_ops_per_s": circ.n_rows * B / (iso["eval"] * 1e-3)}
+    roof_chk = {"bound": "hbm", "kernel": "cw64_r1cs_kernel", "unit": "GB/s", "achieved": alg_chk / (iso["check"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                "frac": alg_chk / (iso["check"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": iso["check"], "algorithmic_bytes_per_launch": alg_chk}
+    cpu = None
+    if not args.no_cpu_baseline and cli.exists():
+        from oracle import ref_build
+        import concurrent.futures as cf
+        cores = ref_build.host_cores()[0]
+        n = 8 * cores
+
+        def one(i):
+            row = [int(v) for v in vals[i % B]]
+            return ref_build.run_cli64(cli, json.dumps({"inputs": [str(x) for x in row]}), Path(d) / ("c%d.wtns" % i)).returncode
+        t1 = time.perf_counter()
+        with cf.ThreadPoolExecutor(max_workers=cores) as ex:
+            rcs = list(ex.map(one, range(n)))
+        wall = time.perf_counter() - t1
+        cpu = {"value": n / wall, "unit": "witnesses/s", "cores": cores, "kind": "reference",
+               "sample": "%d runs of `./%s input.json out.wtns` (the reference's 64-bit runtime), %d at a time, wall %.1f s; process start "
+                         "included: this runtime has no in-process loop build" % (n, name, cores, wall), "failed_runs": sum(1 for r_ in rcs if r_)}
+    total = B * args.steps
+    print(json.dumps({
+        "metric": "witnesses/sec (batched inputs)", "value": total / elapsed, "unit": "witnesses/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64 (Goldilocks: 2^64 = 2^32 - 1 reduction)", "data": "synthetic",
+        "config": {"workload": "poseidon2 goldilocks --O0 (%d constraints), batch=%d" % (circ.n_constraints, B), "n_signals": circ.n_signals,
+                   "n_witness": n_wit, "engine": "64-bit runtime on the device (csrc/cw64.hip)", "in_flight": n_fl, "compile_s": compile_s},
+        "roofline": roof, "roofline_r1cs": roof_chk, "isolated": {"kernels_ms": iso}, "parity": par, "parity_checked": par["parity_checked"],
+        "failed_instances": 0, "cpu_baseline": cpu}))
+    for b_ in batches:
+        b_.close()
+    circ.close()
 
 
 def main():
@@ -500,6 +644,9 @@ def main():
                          "n_gpus would not be what was asked for" % (args.gpus, world))
     if args.host_only:
         return host_only_rehearsal(args, world, rank)
+    if args.workload == "poseidon2_goldilocks":
+        assert world == 1, "the goldilocks line is a single-GPU measurement"
+        return goldilocks_bench(args)
     dist = None
     if world > 1 or os.environ.get("CW_FORCE_DIST"):      # CW_FORCE_DIST: exercise the RCCL path on a single GPU
         import torch.distributed as dist
@@ -992,15 +1139,81 @@ def main():
             # BASELINE config 4 is ONE job of `total_batch` instances over `shard_of` GPUs: every GPU runs its shard once.  The
             # steady-state `value` above keeps several shards in flight on this GPU; the job itself costs one shard's latency
             # (a dependency chain, the same on every rank) plus the final gather of status words and public signals.
-            gather_bytes = (4 + 32 * circ.n_public) * args.total_batch
-            gather_ms = 0.05 + gather_bytes / 50e9 * 1e3          # RCCL gather over xGMI: ~50 us + bytes at ~50 GB/s into rank 0 (assumption, unmeasured)
+            gather_ms = xgmi_gather_ms(circ.n_public, B)
             one = isolated["ms_per_step"]
             out["one_shot_job"] = {"shard_instances": B, "shard_ms_alone": one, "gather_ms_assumed": gather_ms,
                                    "predicted_job_ms": one + gather_ms, "ranks": args.shard_of,
                                    "predicted_witnesses_per_s": args.total_batch / ((one + gather_ms) * 1e-3),
                                    "same_job_on_one_gpu_note": "run --total-batch %d without --shard-of for the one-GPU time of the whole job" % args.total_batch}
+        if world == 1:
+            # What this line predicts for the N-GPU launches the driver runs (bench.py --gpus N: the same batch on every rank,
+            # no exchange inside the timed steps; status words + public signals gathered once at the end): falsifiable numbers,
+            # computed from this run's own measurements.  `steady_state`: N times this value (the ranks share nothing but the
+            # host).  `one_shot`: one batch per rank run ONCE - its latency alone on the GPU plus the final gather (every peer
+            # sends its rows to rank 0 over its own xGMI link: bytes / 153 GB/s + ~20 us).
+            one = isolated["ms_per_step"]
+            out["multi_gpu_prediction"] = {
+                "assumptions": "xGMI link 153 GB/s per peer -> rank 0, 20 us per gather (MI355X_MICROARCH.md); unmeasured on this 1-GPU box",
+                "by_ranks": {str(n_): {"steady_state_witnesses_per_s": n_ * value,
+                                        "one_shot_job_ms": one + (xgmi_gather_ms(circ.n_public, B) if n_ > 1 else 0.0),
+                                        "one_shot_witnesses_per_s": n_ * B / ((one + (xgmi_gather_ms(circ.n_public, B) if n_ > 1 else 0.0)) * 1e-3),
+                                        "gather_bytes_per_peer": (4 + 32 * circ.n_public) * B} for n_ in (1, 2, 4, 8)},
+                "latency_bound": bool(not batch.bitmode and (B + batch.lanes - 1) // batch.lanes < 2 * 256),
+                "latency_bound_note": "a batch whose workgroups do not cover the chip twice runs for the length of its dependency chain whatever "
+                                      "its size: sharding such a job over more GPUs does not shorten it (DESIGN 7)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cp, args.workload)
+        if world == 1 and batch.bitmode and _o1_size.witness2signal is not None and not args.no_small and not args.batch:
+            # What a prover takes (VERDICT r4 #4b): the witness of the system the reference builds by DEFAULT (--O1: constant and
+            # renaming substitutions), as 32-byte field elements, for EVERY instance of the batch - no sample, no extrapolation.
+            # The device still generates and checks the --O0 system; cw_set_witness_list makes every egress hand out the O1
+            # wires (main.cpp:288-334 writes witness2signal's entries; constraint_list/src/lib.rs:187-193 builds that map).
+            try:
+                for b_ in batches:
+                    b_.close()
+                w2s = _o1_size.witness2signal
+                circ.set_witness_list(w2s)
+                b1 = circ.batch(B, device=local_rank, stream=stream.cuda_stream)
+                masks = (h_in if isinstance(h_in, BoolInputs) else BoolInputs(np.ascontiguousarray(h_in[:, :, 0]))).masks()
+                d_masks = torch.from_numpy(masks.view(np.int64)).to(dev)
+                b1.set_inputs_bits_device(d_masks.data_ptr())
+                b1.run(); b1.check_r1cs(); b1.sync()
+                assert (b1.status() == 0).all()
+                row_bytes = len(w2s) * 32
+                chunk = max(1, min(B, (1 << 30) // row_bytes))
+                bufs = [torch.empty((chunk, len(w2s), 32), dtype=torch.uint8, device=dev) for _ in range(2)]
+                seen = [0]
+
+                def count(first, n, ptr, st):
+                    seen[0] += n
+                    return 0
+                b1.stream_witnesses_device(0, min(B, 2 * chunk), chunk, bufs[0].data_ptr(), bufs[1].data_ptr(), lambda *a: 0)   # warm-up
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t1 = time.perf_counter()
+                e0.record(stream)
+                b1.stream_witnesses_device(0, B, chunk, bufs[0].data_ptr(), bufs[1].data_ptr(), count)
+                e1.record(stream)
+                torch.cuda.synchronize()
+                wall_ms = (time.perf_counter() - t1) * 1e3
+                e_ms = e0.elapsed_time(e1)
+                assert seen[0] == B
+                # one instance of the last chunk against the full witness of the same instance (the O1 wires of the O0 image)
+                k_last = (B - 1) % chunk
+                got = bufs[((B - 1) // chunk) % 2][k_last].cpu().numpy()
+                full = np.frombuffer(batch_witness_bytes(b1, B - 1, len(w2s)), dtype=np.uint8).reshape(len(w2s), 32)
+                assert (got == full).all(), "O1 egress differs from the per-instance egress"
+                step_ms = elapsed / args.steps * 1e3
+                out["value_canonical_O1"] = {
+                    "witnesses_per_s": B / ((step_ms + e_ms) * 1e-3), "egress_only_witnesses_per_s": B / (e_ms * 1e-3),
+                    "instances": B, "extrapolated": False, "wires": int(len(w2s)), "bytes_per_witness": row_bytes,
+                    "egress_ms": e_ms, "egress_wall_ms": wall_ms, "GB/s": B * row_bytes / (e_ms * 1e-3) / 1e9,
+                    "frac_of_hbm_peak": B * row_bytes / (e_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "chunk_instances": chunk,
+                    "is": "the reference's default-level (--O1) witness as 32-byte elements for the WHOLE batch, written chunk by chunk "
+                          "into two rotating 1 GiB device buffers (cw_stream_witnesses_device); witnesses_per_s = the step plus this egress"}
+                b1.close()
+            except Exception as ex:                                   # noqa: BLE001  (a report, never a reason to fail the line)
+                out["value_canonical_O1"] = {"error": repr(ex)[:300]}
         print(json.dumps(out))
     for b_ in batches:
         b_.close()

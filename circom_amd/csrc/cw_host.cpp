@@ -1801,7 +1801,7 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
             // LINSUM: sign | |coef| ; DOTC: index into the limb-form constant table (the kernel multiplies by 48)
             dterms[k / 2 + 1] = ((uint64_t)(kw >> 31) << 63) | ((uint64_t)v.terms[k + 3] << 32) | v.terms[k + 2];
         }
-        std::vector<uint64_t> dex(v.extras.size());
+        std::vector<uint64_t> dex(v.extras.size() + 16, 0);            // (padded: a D_BITS row reads sixteen entries per trip)
         for (size_t k = 0; k < v.extras.size(); k++) {
             uint32_t x = v.extras[k];
             if (bits_entry[k]) dex[k] = ((x & X_NEXT) ? X_NEXT_DEV : 0ull) | resolve((x & X_TMP) ? K_TMP : K_SIG, x & 0x1FFFFFFFu);
@@ -2475,9 +2475,12 @@ extern "C" int cw_run(cw_batch *b) {
     }
     const void *in = b->ext_in ? b->ext_in : b->d_in;
     if (c->is64) {
+        TMARK(b, 0);
         HIPCHK(cwk64_init(b->stream, b->d_V64, b->Bp, b->d_status, b->d_first_bad));
         HIPCHK(cwk64_ingest(b->stream, in, b->d_V64, c->input_start, c->n_inputs, b->batch, b->Bp));
+        TMARK(b, 1);
         HIPCHK(cwk64_eval(b->stream, b->d_rows64, (uint32_t)(c->rows64.size() / 8), b->d_consts64, b->d_V64, b->Bp, b->batch, b->d_status));
+        TMARK(b, 2);
         b->ran = true;
         return CW_OK;
     }
@@ -2570,7 +2573,9 @@ extern "C" int cw_check_r1cs(cw_batch *b) {
     if (c->n_constraints == 0) return fail(CW_ESTATE, "no .r1cs was loaded for this circuit");
     HIPCHK(hipSetDevice(b->device));
     if (c->is64) {
+        TMARK(b, 3);
         HIPCHK(cwk64_r1cs(b->stream, b->d_terms64, (uint32_t)(c->r1_terms64.size() / 4), b->d_V64, b->Bp, b->batch, b->d_status, b->d_first_bad));
+        TMARK(b, 4);
         return CW_OK;
     }
     if (b->bitmode) {

@@ -324,13 +324,15 @@ __device__ __forceinline__ void eval_step(const CwDRow &row, const fe &xa, const
     }
     case D_BITS: {
         // consecutive bits of a, from bit row.aux: every entry of the row's extra-destination list is one store of the current
-        // bit; an entry flagged X_NEXT_DEV moves on to the next bit first (cw_tape.h).  One row for a whole Num2Bits.
+        // bit; an entry flagged X_NEXT_DEV moves on to the next bit first (cw_tape.h).  One row for a whole Num2Bits.  Sixteen
+        // entries per trip: their scalar loads are in flight together (the device table is padded by sixteen, entries past the row's end
+        // are skipped), so a 64-bit range check waits for the table four times, not sixteen.
         uint32_t k = row.aux;
-        uint64_t y0 = x0, y1 = x1, y2 = x2, y3 = x3;
-        for (uint32_t e = 0; e < nx; e += 4) {
-            if (e) { y0 = extras[xp + e]; y1 = extras[xp + e + 1]; y2 = extras[xp + e + 2]; y3 = extras[xp + e + 3]; }
-            const uint64_t ys[4] = {y0, y1, y2, y3};
-            FE_UNROLL for (int t = 0; t < 4; t++) {
+        for (uint32_t e = 0; e < nx; e += 16) {
+            uint64_t ys[16];
+            const uint64_t *ex = extras + xp + e;
+            FE_UNROLL for (int t = 0; t < 16; t++) ys[t] = ex[t];
+            FE_UNROLL for (int t = 0; t < 16; t++) {
                 if (e + t < nx) {
                     k += (uint32_t)(ys[t] >> 62) & 1u;               // wave-uniform
                     const uint32_t w = k >> 5;

@@ -369,6 +369,17 @@ def _fuse_linear(rows, consts_plain, q, cid):
     absorbed = [False] * len(rows)
     repl = {}
     half = q >> 1
+    # signals that are ONE BIT of another signal (the BAND(SHR(x, k), 1) pattern below, recognised ahead of the walk): a sum that
+    # puts the bits of x back together is x & (2^n - 1), whatever the size of its coefficients (see the fusion branch)
+    bit_of = {}
+    for r in rows:
+        if r.op == D_BAND and r.dk == K_SIG and r.bk == K_CONST and consts_plain.get(r.bv) == 1 and r.ak == K_TMP and uses.get(r.av) == 1:
+            pi = prod.get(r.av)
+            if pi is not None and rows[pi].op == D_SHR and rows[pi].bk == K_CONST and rows[pi].extra is None and rows[pi].ak == K_SIG:
+                kk = consts_plain.get(rows[pi].bv)
+                if kk is not None and kk < 256:
+                    bit_of[r.dv] = (rows[pi].av, kk)
+    n_bitsum = 0
 
     def sval(c):            # signed value of a canonical constant
         return c - q if c > half else c
@@ -424,6 +435,26 @@ def _fuse_linear(rows, consts_plain, q, cid):
             terms.append([k, v, cf])
         if not ok or len(took) < 3 or len(terms) > 4000:
             continue
+        if c0 == 0 and 2 <= len(terms) < q.bit_length():
+            # sum_i 2^i bit_i(x), i = 0 .. n-1 (the `lc1 += out[i] * e2` loop of Num2Bits): that integer is x & (2^n - 1) and stays
+            # below q - ONE operand instead of n, each of which is its own 32-byte slot of the value table.  (For n > 63 the
+            # coefficients do not fit a D_LINSUM term either: the chain used to stay 2 n rows.)
+            src, seen = None, 0
+            for k, v, cf in terms:
+                b = bit_of.get(v) if k == K_SIG else None
+                if b is None or (src is not None and b[0] != src) or cf != (1 << b[1]) or (seen >> b[1]) & 1:
+                    seen = -1
+                    break
+                src = b[0]
+                seen |= 1 << b[1]
+            if seen == (1 << len(terms)) - 1:
+                for pi in took:
+                    absorbed[pi] = True
+                nr = _Row(D_BAND, r.dk, r.dv, K_SIG, src, K_CONST, cid(seen))
+                nr.extra = r.extra
+                repl[idx] = nr
+                n_bitsum += 1
+                continue
         small = all(abs(t[2]) < (1 << 63) for t in terms)
         if not small:
             if len(terms) > 16:          # long sums with field-sized coefficients: leave to the MADDC chain
@@ -444,37 +475,8 @@ def _fuse_linear(rows, consts_plain, q, cid):
         if absorbed[idx]:
             continue
         out.append(repl.get(idx, r))
+    _fuse_linear.n_bitsum = n_bitsum
     return out, n_lin, n_bit
-
-
-def _fold_bit_sums(rows, q, cid):
-    """Pass A3b: a D_LINSUM that puts the bits of ONE signal back together - sum_i 2^i bit_i(x), i = 0 .. n-1, what the
-    `lc1 += out[i] * e2` loop of Num2Bits traces into - is x & (2^n - 1): one operand instead of n (each bit is its own
-    32-byte slot of the value table; the ECDSA verifier spends a tenth of its time fetching them back).  Exact for every x:
-    the sum of the bits is that integer, and it stays below q for n < bitlength(q)."""
-    bit_of = {}                   # bit signal -> (source kind, source id, bit index); signals are assigned once
-    for r in rows:
-        if r.op == D_BIT and r.dk == K_SIG and r.ak == K_SIG:
-            bit_of[r.dv] = (r.av, r.bv)
-    out, n_folded = [], 0
-    for r in rows:
-        if r.op == D_LINSUM and r.bk != K_CONST and r.terms and 2 <= len(r.terms) < q.bit_length():
-            src, ok, seen = None, True, 0
-            for k, v, cf in r.terms:
-                b = bit_of.get(v) if k == K_SIG else None
-                if b is None or (src is not None and b[0] != src) or cf != (1 << b[1]) or (seen >> b[1]) & 1:
-                    ok = False
-                    break
-                src = b[0]
-                seen |= 1 << b[1]
-            if ok and seen == (1 << len(r.terms)) - 1:
-                nr = _Row(D_BAND, r.dk, r.dv, K_SIG, src, K_CONST, cid(seen))
-                nr.extra, nr.seq = r.extra, r.seq
-                out.append(nr)
-                n_folded += 1
-                continue
-        out.append(r)
-    return out, n_folded
 
 
 def _reassociate(rows, n_vtemps):
@@ -955,7 +957,7 @@ def _alias(rows, n_signals):
     return out, n_elided
 
 
-MAX_BITS_ROW = 64
+MAX_BITS_ROW = 128
 
 
 def _defs(r):
@@ -997,7 +999,10 @@ def _fuse_bits(rows):
     return out, n_fused
 
 
-def _schedule(rows, n_signals, n_strands, functions=()):
+_COST_INTERP = {D_MULC: 8.0, D_MADDC: 8.0, D_MUL2: 10.0, D_MMUL: 7.5, D_MADD: 8.0, D_IDIV: 23.0, D_MOD: 23.0, D_INV: 180.0, D_POW: 6000.0}
+
+
+def _schedule(rows, n_signals, n_strands, functions=(), interp_costs=False):
     """Pass C.  Returns (streams, number of barriers, ordinals of the barriers that must be FULL); each stream is a list whose
     items are _Row or the string 'B'.
     A D_CALL (a circom function with run-time control flow) reads its arguments from and writes its results to its register
@@ -1051,7 +1056,30 @@ def _schedule(rows, n_signals, n_strands, functions=()):
         levels[lv].append(unit)
     streams = [[] for _ in range(n_strands)]
 
+    def ucost_interp(unit):
+        """schedules the interpreting kernel runs (circuits with run-time functions): MEASURED clocks per row of the 16-strand
+        ECDSA verifier (tools/profile_ops.sh, profiles/r05c_ecdsa_prof.log; unit = 900 clk, four waves per SIMD): every row costs
+        ~5 K clk whatever it computes, a term of a sum is a dependent table read, a call is a binary-GCD inverse or a long division"""
+        c = 0.0
+        for r in unit:
+            if r.op == D_CALL:
+                nat = functions[r.av].get("native")
+                c += CALL_COST if not nat else 130.0 if nat[0] == "long_div" else 170.0
+            elif r.op == D_BITS:
+                c += 6.0 + BITS_ENTRY_COST * (len(r.multi) + sum(len(x or ()) for _, x in r.multi))
+            elif r.op == D_LINSUM:
+                c += 6.0 + 4.8 * len(r.terms)
+            elif r.op == D_DOTC:
+                c += 6.0 + 6.0 * len(r.terms)
+            else:
+                c += _COST_INTERP.get(r.op, 6.0)
+            if r.extra:
+                c += 0.5 * len(r.extra)
+        return c
+
     def ucost(unit):      # ~ VALU instructions / 32, plus a fixed part per row (operand fetch + dispatch latency)
+        if interp_costs:
+            return ucost_interp(unit)
         c = 0.0
         for r in unit:
             c += ROW_OVERHEAD
@@ -1059,7 +1087,8 @@ def _schedule(rows, n_signals, n_strands, functions=()):
                 nat = functions[r.av].get("native")
                 c += CALL_COST if not nat else CALL_COST_LONG_DIV if nat[0] == "long_div" else CALL_COST_NATIVE
             elif r.op == D_BITS:
-                c += 1.0 * len(r.multi) + EXTRA_COST * sum(len(x or ()) for _, x in r.multi)
+                # (per entry: a scalar table read shared by four, the bit, two 16-byte stores that nothing waits for)
+                c += BITS_ENTRY_COST * (len(r.multi) + sum(len(x or ()) for _, x in r.multi))
             elif r.op == D_DOTC:
                 c += 5.0 + 4.5 * len(r.terms)
             elif r.op == D_LINSUM:
@@ -1080,9 +1109,34 @@ def _schedule(rows, n_signals, n_strands, functions=()):
     for lv, lunits in enumerate(levels):
         has_call = any(u[0].op == D_CALL for u in lunits)
         total = sum(ucost(u) for u in lunits)
-        cap = total / n_strands * AFFINITY_SLACK + 4.0
+        cap = total / n_strands * (AFFINITY_SLACK_INTERP if interp_costs else AFFINITY_SLACK) + 4.0
         load = [0.0] * n_strands
         placed = []
+        if interp_costs:
+            # Interpreted rows cost ~5 K clocks each whatever they compute and hand everything over through memory or LDS anyway
+            # (measured on the ECDSA verifier: 47 % of the strands' time was waiting at barriers, 70 % of a level the spread between
+            # the first and the last strand to arrive): balance first - longest unit first onto the least loaded strand, the
+            # producer of its operands only as the tie-break - and keep program order inside every strand.
+            costs = [ucost(u) for u in lunits]
+            where = [0] * len(lunits)
+            for ui in sorted(range(len(lunits)), key=lambda i_: -costs[i_]):
+                unit = lunits[ui]
+                lo = min(load)
+                best, best_votes = -1, -1
+                votes = {}
+                for r in unit:
+                    for k, v in _value_operands(r):
+                        if k == K_SIG or k == K_TMP:
+                            ps = prod_strand.get(vid(k, v))
+                            if ps is not None:
+                                votes[ps] = votes.get(ps, 0) + 1
+                for s_ in range(n_strands):
+                    if load[s_] <= lo + 1.0 and votes.get(s_, 0) > best_votes:
+                        best, best_votes = s_, votes.get(s_, 0)
+                where[ui] = best
+                load[best] += costs[ui]
+            placed = [(u, where[i_]) for i_, u in enumerate(lunits)]
+            lunits = ()
         for unit in lunits:
             cost = ucost(unit)
             # affinity: the strand that produced most of the unit's operands (most recent level first) keeps the
@@ -1128,13 +1182,15 @@ def _schedule(rows, n_signals, n_strands, functions=()):
     return streams, n_barriers, forced_full
 
 
+BITS_ENTRY_COST = float(os.environ.get("CW_BITS_ENTRY_COST", "0.3"))      # one destination of a D_BITS row (a 16th of a table read + ~20 instructions)
 CALL_COST = float(os.environ.get("CW_CALL_COST", "20000"))               # an interpreted function (long_div: ~10^5 instructions)
 CALL_COST_NATIVE = float(os.environ.get("CW_CALL_COST_NATIVE", "300"))   # a native routine (one binary-GCD inverse + products: ~150 K clk)
 CALL_COST_LONG_DIV = float(os.environ.get("CW_CALL_COST_LONG_DIV", "40"))  # native long_div (a dozen Knuth digits)
 ROW_OVERHEAD = float(os.environ.get("CW_ROW_OVERHEAD", "4"))   # scheduler cost units charged to every row
 EXTRA_COST = float(os.environ.get("CW_EXTRA_COST", "2"))     # ... and to every extra destination (two 1-KiB stores)
 FULL_PERIOD = 8        # every FULL_PERIOD-th barrier also drains global stores
-AFFINITY_SLACK = float(os.environ.get("CW_AFFINITY_SLACK", "1.25"))  # a strand may take this much more than the average load of a level to keep data local
+AFFINITY_SLACK = float(os.environ.get("CW_AFFINITY_SLACK", "1.25"))
+AFFINITY_SLACK_INTERP = float(os.environ.get("CW_AFFINITY_SLACK_INTERP", "1.0"))   # (interpreted rows: balance first, every row costs the same)  # a strand may take this much more than the average load of a level to keep data local
 
 
 def lds_slots_for(n_strands: int) -> int:
@@ -1294,7 +1350,7 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None, mont
     rows, dconsts, n_vtemps, cid, plain = _expand(fc)
     rows, n_vtemps, n_inv_batches = _batch_inversions(rows, n_vtemps, cid)
     rows, n_lin, n_bit = _fuse_linear(rows, plain, q, cid)
-    rows, n_bitsums = _fold_bit_sums(rows, q, cid) if os.environ.get("CW_FOLD_BITSUMS", "1") != "0" else (rows, 0)
+    n_bitsums = _fuse_linear.n_bitsum
     n_conv = 0
     if mont:
         if functions and (fc.code["op"] == O.CALL).any():
@@ -1334,7 +1390,7 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None, mont
         if n_signals >= X_NEXT:
             raise ValueError("bit-field rows need signal numbers below 2^29")
         rows, n_bits_fused = _fuse_bits(rows)
-    streams, n_levels, forced_full = _schedule(rows, n_signals, n_strands, functions)
+    streams, n_levels, forced_full = _schedule(rows, n_signals, n_strands, functions, interp_costs=has_calls)
     if n_bits_fused:
         # a row that takes a bit of the D_BITS row right in front of it as a / b / c operand would have requested it before
         # the bits were stored (operands are fetched one row ahead): a spacer row in between

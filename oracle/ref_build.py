@@ -288,6 +288,10 @@ def build_default_circuits():
         # (only the flat circuit and the .dat are needed here: one strand variant, no emitted code)
         cp = compile_program(prog, d, name, sym=False, strands=(1,), jit=False, fpjit=False)
         build_circuit(cp)
+    # the reference's 64-bit runtime for `bench.py --workload poseidon2_goldilocks` (parity + CPU baseline of that line)
+    from circom_amd.frontend.flatten import flatten
+    if not (ref_dir("goldilocks") / "poseidon2").exists():
+        build_circuit64(flatten(Program(Poseidon(2), prime="goldilocks")), "poseidon2")
 
 
 # ---- the 64-bit runtime (`--prime goldilocks`): oracle side only -------------------------------------------------------

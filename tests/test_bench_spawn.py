@@ -49,6 +49,23 @@ def test_bench_gpus_8_weak_scaling_launch(tmp_path):
     assert out["gathered"] == {"status_words": 8 * 37, "public_signal_rows": 8 * 37}
 
 
+def test_config5_job_shape_over_8_ranks(tmp_path):
+    """BASELINE config 5's launch - 1 024 instances of a tier-2 circuit on the BLS12-381 prime over 8 ranks - rehearsed with the
+    verifier's building block (bigmultmodp: the same functions, the same launch / shard / gather code; the verifier's own
+    artefacts take minutes to lower): every rank owns 128 instances, and the one exchange is a status word + the public signals
+    (here the k = 3 output limbs) of every instance, from each peer to rank 0"""
+    r = _run(["--gpus", "8", "--host-only", "--workload", "bigmultmodp", "--total-batch", "1024"], tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong"
+    assert out["shards"] == [128] * 8 and out["gathered"] == {"status_words": 1024, "public_signal_rows": 1024}
+    assert out["gather_bytes_per_peer"] == (4 + 32 * 3) * 128 and 0.02 < out["predicted_gather_ms"] < 0.03
+    sys.path.insert(0, str(ROOT))
+    from circom_amd.sharding import shard_range
+    assert [shard_range(1024, r_, 8) for r_ in (0, 7)] == [(0, 128), (896, 1024)]
+    assert [b - a for a, b in (shard_range(1000, r_, 8) for r_ in range(8))] == [125] * 8
+
+
 def test_batches_in_flight_follow_the_fill_of_the_chip():
     sys.path.insert(0, str(ROOT))
     import bench
