@@ -310,9 +310,9 @@ class BoolInputs:
 XGMI_LINK_GBS = 153.0            # per point-to-point link (MI355X_MICROARCH.md); every peer reaches rank 0 over its own link
 
 
-def xgmi_gather_ms(n_public: int, rows_per_peer: int) -> float:
+def xgmi_gather_ms(public_bytes_per_instance: int, rows_per_peer: int) -> float:
     """the job's one exchange, predicted: each peer's status words + public signals to rank 0, links in parallel"""
-    return 0.02 + (4 + 32 * n_public) * rows_per_peer / (XGMI_LINK_GBS * 1e9) * 1e3
+    return 0.02 + (4 + public_bytes_per_instance) * rows_per_peer / (XGMI_LINK_GBS * 1e9) * 1e3
 
 
 def batch_witness_bytes(b, i, n_wit):
@@ -468,7 +468,7 @@ def host_only_rehearsal(args, world, rank):
                           "shards": [int(x) for x in shard_sizes.tolist()],
                           # the job's one exchange on the GPU path: status word + public signals of every instance, peer -> rank 0
                           "gather_bytes_per_peer": (4 + 32 * circ.n_public) * B,
-                          "predicted_gather_ms": xgmi_gather_ms(circ.n_public, B) if world > 1 else 0.0}))
+                          "predicted_gather_ms": xgmi_gather_ms(32 * circ.n_public, B) if world > 1 else 0.0}))
     batch.close()
     circ.close()
     if dist:
@@ -786,7 +786,7 @@ def main():
 
     # correctness gate + the one data-path collective: gather per-instance status words on rank 0
     # (status words + public signals of every instance; full witnesses stay on the GPU that computed them)
-    from circom_amd.sharding import gather_status, gather_rows
+    from circom_amd.sharding import gather_status, gather_public
     status = gather_status(torch.from_numpy(batch.status().astype(np.int32)).to(dev), dist, rank, world)
     n_bad = int((status != 0).sum().item()) if rank == 0 else 0
     n_total = int(status.numel()) if rank == 0 else 0
@@ -795,8 +795,10 @@ def main():
         batch.public_signals_device(pub.data_ptr())
         torch.cuda.synchronize()
     pub_local = pub
-    pub = gather_rows(pub, dist, rank, world)
+    # (bit-level circuits send one bit per public signal: 2^21 SHA-256 digests are 64 MB per rank, not 17 GB)
+    pub, pub_form = gather_public(pub, dist, rank, world)
     n_pub_gathered = int(pub.shape[0]) if rank == 0 else 0
+    pub_bytes_per_instance = (int(pub.shape[1]) if pub_form == "bits" else 32 * circ.n_public) if rank == 0 else 0
 
     gen_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / args.steps
     chk_ms = sum(e[1].elapsed_time(e[2]) for e in evs) / args.steps
@@ -1132,14 +1134,15 @@ def main():
             "parity": parity,
             "parity_checked": parity["parity_checked"] if parity else 0,
             "gathered": {"status_words": n_total, "public_signal_rows": n_pub_gathered,
-                         "public_signals_per_instance": circ.n_public},
+                         "public_signals_per_instance": circ.n_public, "public_signals_sent_as": pub_form,
+                         "bytes_per_instance": 4 + pub_bytes_per_instance},
             "cpu_baseline": None,
         }
         if args.shard_of:
             # BASELINE config 4 is ONE job of `total_batch` instances over `shard_of` GPUs: every GPU runs its shard once.  The
             # steady-state `value` above keeps several shards in flight on this GPU; the job itself costs one shard's latency
             # (a dependency chain, the same on every rank) plus the final gather of status words and public signals.
-            gather_ms = xgmi_gather_ms(circ.n_public, B)
+            gather_ms = xgmi_gather_ms(pub_bytes_per_instance, B)
             one = isolated["ms_per_step"]
             out["one_shot_job"] = {"shard_instances": B, "shard_ms_alone": one, "gather_ms_assumed": gather_ms,
                                    "predicted_job_ms": one + gather_ms, "ranks": args.shard_of,
@@ -1155,9 +1158,9 @@ def main():
             out["multi_gpu_prediction"] = {
                 "assumptions": "xGMI link 153 GB/s per peer -> rank 0, 20 us per gather (MI355X_MICROARCH.md); unmeasured on this 1-GPU box",
                 "by_ranks": {str(n_): {"steady_state_witnesses_per_s": n_ * value,
-                                        "one_shot_job_ms": one + (xgmi_gather_ms(circ.n_public, B) if n_ > 1 else 0.0),
-                                        "one_shot_witnesses_per_s": n_ * B / ((one + (xgmi_gather_ms(circ.n_public, B) if n_ > 1 else 0.0)) * 1e-3),
-                                        "gather_bytes_per_peer": (4 + 32 * circ.n_public) * B} for n_ in (1, 2, 4, 8)},
+                                        "one_shot_job_ms": one + (xgmi_gather_ms(pub_bytes_per_instance, B) if n_ > 1 else 0.0),
+                                        "one_shot_witnesses_per_s": n_ * B / ((one + (xgmi_gather_ms(pub_bytes_per_instance, B) if n_ > 1 else 0.0)) * 1e-3),
+                                        "gather_bytes_per_peer": (4 + pub_bytes_per_instance) * B} for n_ in (1, 2, 4, 8)},
                 "latency_bound": bool(not batch.bitmode and (B + batch.lanes - 1) // batch.lanes < 2 * 256),
                 "latency_bound_note": "a batch whose workgroups do not cover the chip twice runs for the length of its dependency chain whatever "
                                       "its size: sharding such a job over more GPUs does not shorten it (DESIGN 7)"}

@@ -28,11 +28,23 @@ def _worker(rank, world, port, total, out_dir):
     ids = torch.arange(lo, hi, dtype=torch.int64)
     pub = ((ids[:, None, None] * 7 + torch.arange(2)[None, :, None] * 3 + torch.arange(32)[None, None, :]) % 251).to(torch.uint8)
     gpub = gather_rows(pub, dist, rank, world)
+    # the compact exchange: public signals that are all 0 / 1 on EVERY rank travel as bits (11 signals -> 2 bytes per instance);
+    # one rank with a field-sized value makes every rank send elements
+    from circom_amd.sharding import gather_public
+    bitpub = torch.zeros((hi - lo, 11, 32), dtype=torch.uint8)
+    bitpub[:, :, 0] = ((ids[:, None] >> torch.arange(11)[None, :]) & 1).to(torch.uint8)
+    gbits, form = gather_public(bitpub, dist, rank, world)
+    mixed = bitpub.clone()
+    if rank == 1:
+        mixed[0, 3, 5] = 9
+    gmixed, form2 = gather_public(mixed, dist, rank, world)
+    assert (form, form2) == ("bits", "elements")
     if rank == 0:
         torch.save(got, os.path.join(out_dir, "gathered.pt"))
         torch.save(gpub, os.path.join(out_dir, "public.pt"))
+        torch.save((gbits, gmixed), os.path.join(out_dir, "public_bits.pt"))
     else:
-        assert got is None and gpub is None
+        assert got is None and gpub is None and gbits is None and gmixed is None
     dist.barrier()
     dist.destroy_process_group()
 
@@ -64,6 +76,13 @@ def test_two_rank_gloo_status_gather(tmp_path):
     ids = torch.arange(0, total, dtype=torch.int64)
     wpub = ((ids[:, None, None] * 7 + torch.arange(2)[None, :, None] * 3 + torch.arange(32)[None, None, :]) % 251).to(torch.uint8)
     assert gpub.shape == (total, 2, 32) and torch.equal(gpub, wpub)
+    from circom_amd.sharding import unpack_bit_rows
+    gbits, gmixed = torch.load(tmp_path / "public_bits.pt")
+    assert gbits.shape == (total, 2) and gbits.dtype == torch.uint8
+    full = unpack_bit_rows(gbits, 11)
+    assert full.shape == (total, 11, 32) and not full[:, :, 1:].any()
+    assert torch.equal(full[:, :, 0].to(torch.int64), (ids[:, None] >> torch.arange(11)[None, :]) & 1)
+    assert gmixed.shape == (total, 11, 32) and gmixed[501, 3, 5] == 9 and torch.equal(gmixed[:, :, 0], full[:, :, 0])
 
 
 def _cabi_worker(rank, world, port, total, shared_dir):
