@@ -108,6 +108,15 @@ def emit_jit(net, fc, jit="auto"):
     if jp is None:
         return None
     jp.code = bitjit.assemble(bitjit.to_asm(jp))
+    # the stand-alone audit of the table this program writes (cw_check_r1cs under CW_R1CS_AUDIT=1 / after cw_device_bits): the
+    # check's gates alone on LOADED rows - a second, much smaller code object; its scratch rows extend the chunk
+    if os.environ.get("CW_JIT_AUDIT", "1") != "0":
+        ja = bitjit.lower_jit(net, fc, audit_of=jp)
+        if ja is not None:
+            jp.audit_code = bitjit.assemble(bitjit.to_asm(ja))
+            jp.n_slots = max(jp.n_slots, ja.n_slots)
+            jp.stats["audit_instructions"] = ja.stats["instructions"]
+            jp.stats["audit_loads"] = ja.stats["prefetched"] + ja.stats["late_loads"]
     return jp
 
 

@@ -36,6 +36,7 @@ struct JitProgram {
     uint64_t n_slots = 0;                    // rows (256 bytes) per chunk
     std::vector<uint32_t> sig_slot;          // signal -> row
     std::vector<uint8_t> code;               // ELF code object (hipModuleLoadData)
+    std::vector<uint8_t> audit_code;         // ELF of the stand-alone audit of the table (same kernel name and arguments); may be empty
     bool check_complete = false;             // the fused R1CS check covers every constraint of the circuit
     uint32_t n_vgpr = 0, n_agpr = 0;
 };
@@ -48,6 +49,7 @@ inline const char *validate_jit(const JitProgram &p, uint32_t n_signals, uint32_
         if (s >= p.n_slots || s == 2) return "emitted program: signal slot out of range";
     if (p.code.size() < 64 || memcmp(p.code.data(), "\177ELF", 4)) return "emitted program: not a code object";
     if (p.n_vgpr + p.n_agpr > 512 || p.n_vgpr < 8) return "emitted program: register counts";
+    if (!p.audit_code.empty() && (p.audit_code.size() < 64 || memcmp(p.audit_code.data(), "\177ELF", 4))) return "emitted program: audit is not a code object";
     return nullptr;
 }
 

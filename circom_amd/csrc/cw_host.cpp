@@ -272,6 +272,7 @@ struct cw_circuit {
     bool has_jit = false;
     cwbits::JitProgram jit;
     std::map<int, std::pair<hipModule_t, hipFunction_t>> jit_mod;   // device -> loaded module
+    std::map<int, std::pair<hipModule_t, hipFunction_t>> jit_audit_mod;   // ... of the audit program (loaded on first use)
     std::vector<uint32_t> r_cc, r_cctab;   // per term: id of its canonical coefficient in r_cctab (8 words each)
     // log(...) statements (LogBucket): the LAST n_logv of n_signals are hidden signals holding their arguments
     uint32_t n_logv = 0;
@@ -972,7 +973,7 @@ static int load_tape(cw_circuit *c, const char *path) {
         uint32_t jh[8];
         memcpy(jh, b.data() + off, 32);
         off += 32;
-        if (jh[0] != 1 || jh[7]) return fail(CW_EIO, "tape emitted program: unknown format version (lowered by another release)");
+        if (jh[0] != 1) return fail(CW_EIO, "tape emitted program: unknown format version (lowered by another release)");
         cwbits::JitProgram &jp = c->jit;
         jp.n_slots = (uint64_t)jh[1] | ((uint64_t)jh[2] << 32);
         const uint64_t code_bytes = jh[3], padded = (code_bytes + 3) & ~3ull;
@@ -985,6 +986,10 @@ static int load_tape(cw_circuit *c, const char *path) {
         off += (size_t)c->n_signals * 4;
         jp.code.assign(b.data() + off, b.data() + off + code_bytes);
         off += (size_t)padded;
+        const uint64_t audit_bytes = jh[7], audit_padded = (audit_bytes + 3) & ~3ull;     // the audit's code object (may be absent)
+        if (audit_padded > b.size() - off) return fail(CW_EIO, "tape emitted program truncated");
+        jp.audit_code.assign(b.data() + off, b.data() + off + audit_bytes);
+        off += (size_t)audit_padded;
         if (const char *why = cwbits::validate_jit(jp, c->n_signals, c->n_inputs)) return fail(CW_EIO, std::string("tape: ") + why);
         c->has_jit = true;
     }
@@ -1296,6 +1301,8 @@ extern "C" void cw_free(cw_circuit *c) {
     for (auto &kv : c->jit_mod) {               // modules of the emitted bit-plane code, one per device that ran it
         if (hipSetDevice(kv.first) == hipSuccess) hipModuleUnload(kv.second.first);
     }
+    for (auto &kv : c->jit_audit_mod)
+        if (hipSetDevice(kv.first) == hipSuccess) hipModuleUnload(kv.second.first);
     for (auto &fj : c->fpjit)
         for (auto &kv : fj.mod)
             if (hipSetDevice(kv.first) == hipSuccess) hipModuleUnload(kv.second.first);
@@ -1804,7 +1811,8 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
         std::vector<uint64_t> dex(v.extras.size() + 16, 0);            // (padded: a D_BITS row reads sixteen entries per trip)
         for (size_t k = 0; k < v.extras.size(); k++) {
             uint32_t x = v.extras[k];
-            if (bits_entry[k]) dex[k] = ((x & X_NEXT) ? X_NEXT_DEV : 0ull) | resolve((x & X_TMP) ? K_TMP : K_SIG, x & 0x1FFFFFFFu);
+            if (bits_entry[k])
+                dex[k] = ((x & X_NEXT) ? X_NEXT_DEV : 0ull) | ((x & X_TMP) ? 0ull : X_LO_DEV) | resolve((x & X_TMP) ? K_TMP : K_SIG, x & 0x1FFFFFFFu);
             else if (x & X_LDS) dex[k] = (1ull << 63) | ((uint64_t)(x & 0x3FFFFFFFu) * lds_slot);
             else dex[k] = resolve((x & X_TMP) ? K_TMP : K_SIG, x & 0x3FFFFFFFu);
         }
@@ -1825,6 +1833,11 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
         for (uint32_t st = 0; st < v.n_strands; st++) {
             tab[2 * st] = soff[st];
             tab[2 * st + 1] = soff[st] + (v.stream_off[st + 1] - v.stream_off[st]);
+        }
+        if (std::find(bits_entry.begin(), bits_entry.end(), (uint8_t)1) != bits_entry.end()) {
+            // D_BITS rows store the lower half of their signal destinations only (cw_tape.h X_LO_DEV): the table starts cleared
+            if (c->mont) return fail(CW_EIO, "tape: bit-field rows in a schedule of Montgomery-form signals");
+            TRY(hipMemsetAsync(b->d_V, 0, b->v_bytes, b->stream));
         }
         TRY(upload(&b->d_rows, drows, b->stream));
         TRY(upload(&b->d_stream_off, tab, b->stream));
@@ -2584,6 +2597,26 @@ extern "C" int cw_check_r1cs(cw_batch *b) {
         // (cw_device_bits) may have changed it: then, and with CW_R1CS_AUDIT=1, every group is audited from the table.
         const void *only = b->jit && c->jit.check_complete && !b->table_dirty && !getenv("CW_R1CS_AUDIT") ? b->d_r1flag : nullptr;
         TMARK(b, 3);
+        if (!only && b->jit && c->jit.check_complete && !c->jit.audit_code.empty() && !getenv("CW_R1CS_AUDIT_GENERAL")) {
+            // the audit as emitted code: every constraint recomputed from the table's rows (one coalesced row per wire and wave),
+            // flags into the (cleared) R1CS flag array; the general kernels below then only name the first bad row of the
+            // instances it flagged
+            auto it = c->jit_audit_mod.find(b->device);
+            if (it == c->jit_audit_mod.end()) {
+                hipModule_t mod = nullptr;
+                hipFunction_t fn = nullptr;
+                hipError_t e1 = hipModuleLoadData(&mod, c->jit.audit_code.data());
+                if (e1 == hipSuccess) e1 = hipModuleGetFunction(&fn, mod, cwbits::JIT_KERNEL);
+                if (e1 != hipSuccess) return fail(CW_EDEVICE, std::string("loading the emitted audit code failed: ") + hipGetErrorString(e1));
+                it = c->jit_audit_mod.emplace(b->device, std::make_pair(mod, fn)).first;
+            }
+            HIPCHK(hipMemsetAsync(b->d_r1flag, 0, (size_t)b->n_groups_padded * 8, b->stream));
+            struct { void *T, *fb, *r1; } args = {b->d_T, b->d_fbmask, b->d_r1flag};
+            size_t asz = sizeof(args);
+            void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+            HIPCHK(hipModuleLaunchKernel(it->second.second, b->n_groups_padded / 32, 1, 1, 64, 1, 1, 0, b->stream, nullptr, cfg));
+            only = b->d_r1flag;
+        }
         HIPCHK(cwk_bits_r1cs(b->stream, b->d_erecs, b->n_evrows, b->d_wchunk, b->n_wchunks, b->d_wterms, b->d_wctab, b->d_wrow,
                              b->d_ichunk, b->n_ichunks, b->d_iterms, b->d_itab, b->d_irow, b->d_T, b->bits_slots, b->bits_sh, only,
                              b->n_groups, b->batch, b->d_status, b->d_first_bad, c->P));

@@ -338,7 +338,10 @@ __device__ __forceinline__ void eval_step(const CwDRow &row, const fe &xa, const
                     const uint32_t w = k >> 5;
                     const uint32_t limb = w == 0 ? a.v[0] : w == 1 ? a.v[1] : w == 2 ? a.v[2] : w == 3 ? a.v[3] : w == 4 ? a.v[4]
                                           : w == 5 ? a.v[5] : w == 6 ? a.v[6] : a.v[7];
-                    store_off(ys[t] & ~X_NEXT_DEV, c, fe_small((limb >> (k & 31)) & 1u));
+                    const uint32_t bit = (limb >> (k & 31)) & 1u;
+                    const uint64_t off = ys[t] & ~(X_NEXT_DEV | X_LO_DEV);
+                    if (ys[t] & X_LO_DEV) *(uint4 *)((char *)c.Vb + off + c.vlo) = make_uint4(bit, 0u, 0u, 0u);   // (wave-uniform choice)
+                    else store_off(off, c, fe_small(bit));
                 }
             }
         }

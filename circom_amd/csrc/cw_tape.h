@@ -29,6 +29,11 @@ enum : uint32_t { KD_NONE = 2 };   // destination kind "no store" (value only fo
 // between a D_BITS row and a row that reads one of its bits as a prefetched operand).
 #define X_NEXT 0x20000000u
 #define X_NEXT_DEV (1ull << 62)
+// ... and on the device: this destination is a SIGNAL slot, whose upper 16 bytes stay zero for the life of the batch (the table
+// is cleared when the batch is created, a signal's only writer is this row, a bit is 0 or 1): only the lower half is stored -
+// the row's cost is its vector-memory instructions (the CU issues one per ~25 clocks: 2.2 M destinations per instance group
+// of the ECDSA verifier)
+#define X_LO_DEV (1ull << 61)
 
 struct CwRow {       // 16 bytes, read with one scalar dwordx4 load
     uint32_t w0;     // see SH_* above; BARRIER rows: dst = 1 -> also drain global stores

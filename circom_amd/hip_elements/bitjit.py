@@ -438,11 +438,22 @@ class JitProgram:
         self.check_complete = False
         self.stats = {}
         self.code = None                # code object (ELF) bytes once assembled
+        self.node_slot = None           # evaluation node -> row of the table (-1: none)
+        self.audit_code = None          # code object of the stand-alone audit of this program's table (lower_jit(audit_of=))
+        self.is_audit = False
 
 
-def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384, fuse_check: bool = True, hoist: int = 256):
-    """BitNet (bitblast.py) -> JitProgram with IR.  Returns None when there is nothing to evaluate."""
+def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384, fuse_check: bool = True, hoist: int = 256, audit_of=None):
+    """BitNet (bitblast.py) -> JitProgram with IR.  Returns None when there is nothing to evaluate.
+    audit_of = the program lowered from the same network: lower the STAND-ALONE AUDIT of its table instead - the gates of the
+    R1CS check alone, their wires LOADED from the rows that program stored (one coalesced 256-byte row per wire and wave: the
+    table's own layout), nothing evaluated, nothing stored but scratch behind the table.  `cw_check_r1cs` runs it when the
+    caller asks for an audit (CW_R1CS_AUDIT=1) or may have changed the table (cw_device_bits): the general check kernels
+    read 8 bytes out of every 256-byte row in this layout (271 ms for 2^21 instances of Sha256(2048))."""
     n_eval = len(net.tt)
+    audit = audit_of is not None
+    if audit and not (fuse_check and fc.constraints and audit_of.check_complete):
+        return None
     if fuse_check and fc.constraints:
         G, viol, cst = build_check(net, fc)
     else:
@@ -457,14 +468,22 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
     is_signal[sn] = True
     is_gate = [t <= 0xFF for t in TT]
     is_gate[0] = is_gate[1] = False
-    live = is_signal.tolist()
-    for x in net.asserts:
-        live[x] = True
-    for x in viol:
-        live[x] = True
-    for nid in range(n_nodes - 1, 1, -1):
-        if live[nid] and is_gate[nid]:
-            live[A[nid]] = live[B[nid]] = live[C[nid]] = True
+    if audit:
+        live = [False] * n_nodes               # the check's own gates only; their wires are rows of the table
+        for x in viol:
+            live[x] = True
+        for nid in range(n_nodes - 1, n_eval - 1, -1):
+            if live[nid] and is_gate[nid]:
+                live[A[nid]] = live[B[nid]] = live[C[nid]] = True
+    else:
+        live = is_signal.tolist()
+        for x in net.asserts:
+            live[x] = True
+        for x in viol:
+            live[x] = True
+        for nid in range(n_nodes - 1, 1, -1):
+            if live[nid] and is_gate[nid]:
+                live[A[nid]] = live[B[nid]] = live[C[nid]] = True
     # order: evaluation gates in creation order (= program order of the witness code) - except that a gate whose operands
     # were ALL created long before it moves up behind the youngest of them (circomlib's SHA-256 computes a block twice: the
     # `<--` hint function first, then the constrained components, whose values are the hint's gates again plus a few of
@@ -482,15 +501,17 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
         i = nid - n_eval
         kl[nid] = max(kl[G.rowkey[i]], kl[A[nid]], kl[B[nid]], kl[C[nid]])
     key = np.asarray(kl, dtype=np.int64)
-    gates = np.array([i for i in range(2, n_nodes) if is_gate[i] and live[i]], dtype=np.int64)
+    gates = np.array([i for i in range(n_eval if audit else 2, n_nodes) if is_gate[i] and live[i]], dtype=np.int64)
     if len(gates) == 0:
         return None
     order = gates[np.lexsort((gates, key[gates]))].tolist()
     n_ops = len(order)
-    assert_set = set(int(x) for x in net.asserts if x > 1)
+    assert_set = set() if audit else set(int(x) for x in net.asserts if x > 1)
     viol_set = set(int(x) for x in viol if x > 1)
-    const_assert = any(x == 1 for x in net.asserts)      # an assertion that is constant true-violation: every instance falls back
+    const_assert = (not audit) and any(x == 1 for x in net.asserts)      # an assertion that is constant true-violation: every instance falls back
     const_viol = any(x == 1 for x in viol)
+    if audit and any(x < n_eval and x > 1 for x in viol_set):
+        return None                                # (a violation value that is an evaluation gate itself: not a shape build_check makes)
 
     # uses per node (positions in `order`), consumed front to back
     uses = [None] * n_nodes
@@ -521,9 +542,16 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
     st_idx = [-1] * n_nodes                       # in-order index of the store that wrote mem_slot (-1: written before the kernel)
     pend = [-1] * n_nodes                         # in-order index of a load in flight into loc_v
     vheap, aheap = [], []                         # (-next use, node)
-    for s, nid in net.input_node.items():
-        mem_slot[nid] = IN_BASE + (s - fc.main_input_start)
-    next_slot = IN_BASE + fc.n_main_inputs
+    if audit:
+        ns_ = np.asarray(audit_of.node_slot, dtype=np.int64)
+        assert len(ns_) == n_eval
+        for nid in np.nonzero(ns_ >= 0)[0].tolist():
+            mem_slot[nid] = int(ns_[nid])
+        next_slot = int(audit_of.n_slots)          # scratch rows of the audit live behind the table's own
+    else:
+        for s, nid in net.input_node.items():
+            mem_slot[nid] = IN_BASE + (s - fc.main_input_start)
+        next_slot = IN_BASE + fc.n_main_inputs
     ir = []
     emit = ir.append
     vm_issued = 0
@@ -676,6 +704,8 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
                     stats["late_loads"] += 1
                     if g >= n_eval:
                         stats["loads_for_check"] += 1
+                elif audit:
+                    return None                    # a wire of the check that the evaluation never stored: no audit program
                 else:
                     raise RuntimeError("value %d is nowhere" % o)
         for o in pin:
@@ -732,8 +762,19 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
     jp = JitProgram()
     jp.ir = ir
     jp.n_slots = (next_slot + 15) // 16 * 16
+    if audit:
+        jp.sig_slot = audit_of.sig_slot
+        jp.n_signals, jp.n_inputs, jp.input_start = audit_of.n_signals, audit_of.n_inputs, audit_of.input_start
+        jp.n_vgpr, jp.n_agpr = n_vgpr, n_agpr
+        jp.check_complete = True
+        stats["instructions"] = len(ir)
+        stats["slots"] = jp.n_slots
+        jp.stats = stats
+        jp.is_audit = True
+        return jp
     sig_slot = np.zeros(fc.n_signals, dtype=np.uint32)
     ms = np.asarray(mem_slot, dtype=np.int64)
+    jp.node_slot = ms[:n_eval].copy()             # evaluation node -> row (-1: never stored), for the audit program (audit_of=)
     node_slot = ms[sn]
     node_slot[sn == 0] = 0
     node_slot[sn == 1] = 1

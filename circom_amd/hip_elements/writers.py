@@ -127,8 +127,9 @@ def write_tape(path, tapes, bittape=None, jit=None, fpjit=()):
                             records n_vrows*64 x 2 u32; command blocks n_vrows/8 x 24 u32; signal -> slot; assertion slots
             emitted 256-bit code (optional, after everything else; hip_elements/fpjit.py): see the end of this function
             emitted code    (if n_bit_programs == 2, hip_elements/bitjit.py)  8 x u32: 1, n_slots lo, hi, code bytes, flags (bit 0:
-                            the fused R1CS check covers every constraint), VGPRs, AccVGPRs, 0; signal -> slot; the gfx950 code
-                            object (ELF), padded to 4 bytes
+                            the fused R1CS check covers every constraint), VGPRs, AccVGPRs, bytes of the AUDIT code object
+                            (0: none); signal -> slot; the gfx950 code object (ELF), padded to 4 bytes; then the audit code
+                            object (bitjit.lower_jit(audit_of=): the check's gates on loaded rows), padded to 4 bytes
     """
     if isinstance(tapes, Tape):
         tapes = [tapes]
@@ -188,10 +189,12 @@ def write_tape(path, tapes, bittape=None, jit=None, fpjit=()):
             f.write(np.ascontiguousarray(bittape.assert_slots, dtype="<u4").tobytes())
         if jit is not None:
             assert bittape is not None and jit.code is not None and jit.n_signals == t0.n_signals
+            audit = getattr(jit, "audit_code", None) or b""
             f.write(struct.pack("<8I", 1, jit.n_slots & 0xFFFFFFFF, jit.n_slots >> 32, len(jit.code), 1 if jit.check_complete else 0,
-                                jit.n_vgpr, jit.n_agpr, 0))
+                                jit.n_vgpr, jit.n_agpr, len(audit)))
             f.write(np.ascontiguousarray(jit.sig_slot, dtype="<u4").tobytes())
             f.write(jit.code + b"\0" * (-len(jit.code) % 4))
+            f.write(audit + b"\0" * (-len(audit) % 4))
         if fpjit:
             # emitted 256-bit code of strand variants (hip_elements/fpjit.py), an optional trailing section: "FPJT" | u32 format
             # 1 | u32 n | per program 8 x u32 {n_strands, code bytes, LDS bytes, scratch bytes, VGPRs, bitmap words, 0, 0} + the

@@ -228,6 +228,13 @@ class Batch:
         sh = self.bits_sh
         return (((group >> sh) * self.bits_slots + slot) << sh) + (group & ((1 << sh) - 1))
 
+    def device_bits(self):
+        """(device pointer, bytes, slots per group) of the bit table (cw_device_bits); taking it makes the next check_r1cs audit
+        the whole table - the caller may have changed it"""
+        nb, spg = C.c_uint64(), C.c_uint64()
+        p = lib().cw_device_bits(self.h, C.byref(nb), C.byref(spg))
+        return (int(p) if p else 0), int(nb.value), int(spg.value)
+
     def signal_slots(self) -> np.ndarray:
         p = lib().cw_batch_signal_slots(self.h)
         return np.ctypeslib.as_array(p, shape=(self.circuit.n_signals,)).copy() if p else None

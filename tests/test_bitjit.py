@@ -107,6 +107,47 @@ def test_fused_check_flags_exactly_the_violating_instances(prog):
         assert 0 < n_bad < 64
 
 
+@pytest.mark.parametrize("prog", [Program(BadBit(12)), Program(BadWeighted(12, False)), Program(BadWords(31, True)), Program(Sha256(64))])
+def test_audit_program_rechecks_the_table_the_evaluation_left(prog):
+    """lower_jit(audit_of=): the check's gates alone, their wires LOADED from the rows the evaluation stored.  On the table
+    as the evaluation left it the audit raises the same flags as the fused check; on a table somebody changed afterwards
+    (cw_device_bits hands out the raw pointer) it flags exactly the instances whose witness no longer satisfies the system"""
+    fc = flatten(prog)
+    net = BB.bitblast(fc)
+    big = fc.n_signals > 10000
+    for nv, na, pf in (((256, 256, 384),) if big else ((256, 256, 384), (20, 6, 8))):
+        jp = BJ.lower_jit(net, fc, n_vgpr=nv, n_agpr=na, prefetch=pf)
+        ja = BJ.lower_jit(net, fc, n_vgpr=nv, n_agpr=na, prefetch=pf, audit_of=jp)
+        assert ja is not None and ja.is_audit and ja.n_slots >= jp.n_slots
+        assert not any(ins[0] in ("st", "sta") and ins[2] < jp.n_slots for ins in ja.ir)      # stores: scratch behind the table only
+        assert ja.stats["gates"] == jp.stats["check_gates"] or ja.stats["gates"] <= jp.stats["check_gates"]
+        W = 24 if big else 64
+        rows = _rows(fc, W, 11)
+        for i in range(0, W, 3):
+            rows[i] = [0] * fc.n_main_inputs
+        mem, fb, bad = _run(jp, fc, rows)
+        table = {k: v for k, v in mem.items() if k < jp.n_slots}
+        ja_run = type("J", (), {"ir": ja.ir, "n_slots": ja.n_slots, "n_vgpr": ja.n_vgpr, "n_agpr": ja.n_agpr})
+        _, fb2, bad2 = run_ir(ja_run, dict(table), W)
+        assert fb2 == 0 and bad2 == bad
+        # flip one stored wire in a few instances: the audit must flag exactly the instances that now violate a constraint
+        rng = random.Random(5)
+        victim = None
+        cand = [s_ for s_ in range(1, fc.n_signals) if not fc.main_input_start <= s_ < fc.main_input_start + fc.n_main_inputs]
+        for s_ in rng.sample(cand, min(40, len(cand))):
+            if any(s_ in A or s_ in B_ or s_ in C for A, B_, C in fc.constraints):
+                victim = s_
+                break
+        assert victim is not None
+        flip = sum(1 << i for i in (1, 5, W - 2))
+        t2 = dict(table)
+        t2[int(jp.sig_slot[victim])] ^= flip
+        _, _, bad3 = run_ir(ja_run, t2, W)
+        for i in range(W):
+            sig = [(t2[int(jp.sig_slot[s])] >> i) & 1 for s in range(fc.n_signals)]
+            assert bool((bad3 >> i) & 1) == (check_r1cs(fc.fp.q, fc.constraints, sig) is not None), i
+
+
 @template
 def WideRow(c, n):
     """a long linear row with field-sized weights over 2 n distinct wires (no exact integer comparison possible)"""

@@ -550,6 +550,61 @@ def test_gpu_bitplane_r1cs_whole_words(tmp_path, engine, flip, second_only):
 
 
 @pytest.mark.gpu
+def test_gpu_emitted_audit_of_a_table_somebody_changed(tmp_path, monkeypatch):
+    """the stand-alone audit of an emitted-code batch is emitted code too (bitjit.lower_jit(audit_of=): the check's gates on
+    rows LOADED from the table): clean on the table the evaluation left, and after a caller took the raw table (cw_device_bits)
+    and flipped one wire in three instances, exactly the instances whose witness now violates a constraint are flagged, with
+    the first violated row - by the emitted audit and by the general kernels (CW_R1CS_AUDIT_GENERAL=1) alike"""
+    import ctypes as C
+    monkeypatch.setenv("CW_BITS_JIT", "1")
+    cp, c = _gpu(tmp_path, Program(BitGadget(16)), "bg16a")
+    assert cp.jit.audit_code and cp.jit.check_complete
+    fc = cp.flat
+    B = 300
+    rows = _rand_bits(fc, B, 21)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    results = []
+    for general in (False, True):
+        if general:
+            monkeypatch.setenv("CW_R1CS_AUDIT_GENERAL", "1")
+        b = c.batch(B)
+        assert b.jit
+        b.set_inputs(rows)
+        b.run(); b.check_r1cs(); b.sync()
+        assert (b.status() == 0).all()
+        ptr, nbytes, spg = b.device_bits()                         # from here on every check audits the table
+        assert ptr and spg == b.bits_slots
+        b.check_r1cs(); b.sync()
+        assert (b.status() == 0).all()                              # the untouched table passes its audit
+        # flip the value of one constrained wire in instances 5, 70 and 299
+        victim = next(s_ for s_ in range(fc.n_signals - 1, 0, -1) if any(s_ in A or s_ in B_ or s_ in C_ for A, B_, C_ in fc.constraints)
+                      and not fc.main_input_start <= s_ < fc.main_input_start + fc.n_main_inputs)
+        slot = int(b.signal_slots()[victim])
+        for i in (5, 70, 299):
+            off = 8 * b.bits_index(i // 64, slot)
+            word = C.c_uint64()
+            assert hip.hipMemcpy(C.byref(word), C.c_void_p(ptr + off), 8, 2) == 0
+            word.value ^= 1 << (i % 64)
+            assert hip.hipMemcpy(C.c_void_p(ptr + off), C.byref(word), 8, 1) == 0
+        b.check_r1cs(); b.sync()
+        st, fb = b.status(), b.r1cs_first_bad()
+        n_bad = 0
+        for i in range(B):
+            w = b.witness(i)
+            want = check_r1cs(c.q, fc.constraints, w)
+            assert bool(st[i] & 4) == (want is not None), (general, i)
+            if want is not None:
+                assert fb[i] == want and i in (5, 70, 299)
+                n_bad += 1
+        assert n_bad >= 1
+        results.append((st.tolist(), fb.tolist()))
+        b.close()
+    assert results[0] == results[1]
+    c.close()
+
+
+@pytest.mark.gpu
 def test_gpu_sha256_two_blocks_bitplane(tmp_path, engine):
     cp, c = _gpu(tmp_path, Program(Sha256(512)), "sha256_512")
     fc = cp.flat
