@@ -885,6 +885,22 @@ def main():
             set_in(b_)
         del pub2
 
+    # the stand-alone audit of an emitted-code batch (what a sceptical caller runs: CW_R1CS_AUDIT=1 re-checks every constraint
+    # from the table instead of trusting the fused check): the emitted audit program, and the general kernels for comparison
+    audit = None
+    if rank == 0 and batch.bitmode and batch.jit and not args.no_small:
+        audit = {}
+        for key_, envs in (("emitted_audit_ms", {"CW_R1CS_AUDIT": "1"}), ("general_kernels_ms", {"CW_R1CS_AUDIT": "1", "CW_R1CS_AUDIT_GENERAL": "1"})):
+            os.environ.update(envs)
+            try:
+                batch.check_r1cs(); batch.sync()
+                batch.check_r1cs(); batch.sync()
+                audit[key_] = batch.kernel_ms()["check"]
+            finally:
+                for k_ in envs:
+                    del os.environ[k_]
+        assert (batch.status() == 0).all(), "the audit flags instances the fused check passed"
+
     # Fp mul/s half of the metric: 2^24 lanes x 1024 dependent Montgomery products, bn128 and bls12381
     fp_mul = {}
     if rank == 0:
@@ -982,7 +998,7 @@ def main():
                          "fused_r1cs_check": {k[6:]: v for k, v in js.items() if k.startswith("check_")}}
             chk_kern_ms = isolated["r1cs_check_ms"]
             roof_r1cs = {"bound": "none (fused)", "kernel": "fused into cw_bits_jit; cw_bits_r1cs_* audit only the groups it flags", "kernel_ms": chk_kern_ms,
-                         "frac": None, "traffic": prof.get("r1cs"),
+                         "frac": None, "traffic": prof.get("r1cs"), "stand_alone_audit": audit,
                          "note": "every non-trivial constraint is evaluated on the registers that hold its wires while the witness is generated "
                                  "(SURVEY 8d: B_chk -> 0); the stand-alone kernels remain as the audit (CW_R1CS_AUDIT=1, or after cw_device_bits)"}
             roof_valu = {"bound": "valu", "kernel": ek, "unit": "VALU wave-instructions/s", "achieved": valu_insts / (kern_ms * 1e-3), "peak": valu_peak,
