@@ -65,7 +65,8 @@ def lower_bitplane(fc: FlatCircuit, bits="auto"):
     """The bit-plane program of a circuit whose signals are all boolean for 0/1 inputs (SHA-256 and friends), or None.
     bits: True = whenever the analysis succeeds, False = never, "auto" = only for circuits large enough to matter (an
     instance whose inputs are not 0/1 is re-run by the 256-bit schedule, so tiny arithmetic circuits gain nothing)."""
-    lower_bitplane.net = None
+    lower_bitplane.net = None         # the gate network of this call, for emit_jit (read it right after the call: not re-entrant;
+                                      # lower_bitplane_net() below returns both)
     if bits is False or (bits == "auto" and fc.n_signals < BITS_AUTO_MIN_SIGNALS) or fc.n_main_inputs == 0:
         return None
     if (fc.code["op"] == O.LOG).any():
@@ -93,6 +94,22 @@ def lower_bitplane(fc: FlatCircuit, bits="auto"):
 
 lower_bitplane.net = None           # the gate network of the last call (compile_program hands it to the code emitter)
 
+
+def lower_bitplane_net(fc: FlatCircuit, bits="auto"):
+    """(bit-plane program | None, its gate network | None) - the re-entrant form of lower_bitplane"""
+    bt = lower_bitplane(fc, bits)
+    net, lower_bitplane.net = lower_bitplane.net, None
+    return bt, (net if bt is not None else None)
+
+
+def _emit_failure(what, ex, strict):
+    """an emitter that cannot produce its code object (no ROCm LLVM on this host, an assembler error): `auto` keeps the tape
+    valid without emitted code - the interpreting kernels run every schedule - and says so; an explicit request re-raises"""
+    if strict:
+        raise ex
+    import warnings
+    warnings.warn("circom_amd: %s not emitted (%s: %s); the tape carries the interpreted program only" % (what, type(ex).__name__, str(ex)[:200]))
+
 JIT_AUTO_MIN_GATES = 20_000         # "auto": circuits below this never see batches where the emitted code wins
 
 
@@ -104,16 +121,25 @@ def emit_jit(net, fc, jit="auto"):
     if net is None or jit is False or (jit == "auto" and net.stats.get("gates", 0) < JIT_AUTO_MIN_GATES):
         return None
     from .hip_elements import bitjit
+    import subprocess
     jp = bitjit.lower_jit(net, fc)
     if jp is None:
         return None
-    jp.code = bitjit.assemble(bitjit.to_asm(jp))
+    try:
+        jp.code = bitjit.assemble(bitjit.to_asm(jp))
+    except (RuntimeError, OSError, subprocess.CalledProcessError) as ex:
+        _emit_failure("the bit-plane program's code", ex, jit is True)
+        return None
     # the stand-alone audit of the table this program writes (cw_check_r1cs under CW_R1CS_AUDIT=1 / after cw_device_bits): the
     # check's gates alone on LOADED rows - a second, much smaller code object; its scratch rows extend the chunk
     if os.environ.get("CW_JIT_AUDIT", "1") != "0":
         ja = bitjit.lower_jit(net, fc, audit_of=jp)
         if ja is not None:
-            jp.audit_code = bitjit.assemble(bitjit.to_asm(ja))
+            try:
+                jp.audit_code = bitjit.assemble(bitjit.to_asm(ja))
+            except (RuntimeError, OSError, subprocess.CalledProcessError) as ex:
+                _emit_failure("the audit program's code", ex, False)
+                return jp
             jp.n_slots = max(jp.n_slots, ja.n_slots)
             jp.stats["audit_instructions"] = ja.stats["instructions"]
             jp.stats["audit_loads"] = ja.stats["prefetched"] + ja.stats["late_loads"]
@@ -136,6 +162,7 @@ def emit_fpjit(tapes, fc, fpjit="auto", fuse_check=True):
     if fpjit is False:
         return ()
     from .hip_elements import fpjit as FJ
+    import subprocess
     out = []
     for t in tapes:
         if getattr(t, "kind", 0) != 0:
@@ -147,18 +174,27 @@ def emit_fpjit(tapes, fc, fpjit="auto", fuse_check=True):
         # as the evaluation itself - it pays where the launch is throughput-bound (the wires are in registers and caches instead
         # of a second pass over HBM), not where a small batch waits on its dependency chain
         for cons in ((None, fc.constraints) if (fuse_check and fc.constraints) else (None,)):
+            spool_dir = None
             try:
                 # (beyond ~300 K rows the text goes to a file as it is produced: tens of millions of lines)
                 spool = None
                 if len(t.rows) > 300_000:
                     import tempfile
-                    spool = os.path.join(tempfile.mkdtemp(prefix="cw_fpjit_"), "k.s")
+                    spool_dir = tempfile.mkdtemp(prefix="cw_fpjit_")
+                    spool = os.path.join(spool_dir, "k.s")
                 p = FJ.emit(t, constraints=cons, spool_path=spool)
+                FJ.assemble(p)
             except NotImplementedError:
                 if fpjit is True:
                     raise
                 break
-            FJ.assemble(p)
+            except (RuntimeError, OSError, subprocess.CalledProcessError) as ex:
+                _emit_failure("the rows' code (%d strands)" % t.n_strands, ex, fpjit is True)
+                break
+            finally:
+                if spool_dir is not None:
+                    import shutil
+                    shutil.rmtree(spool_dir, ignore_errors=True)
             out.append(p)
     return tuple(out)
 

@@ -70,7 +70,8 @@ __global__ void __launch_bounds__(64) cw_bits_ingest_kernel(const uint4 *__restr
     const uint32_t i0 = g * 64, ni = min(64u, batch - i0);
     uint64_t mine = 0, badmask = 0;
     // (four instances in flight per wave with streaming loads were measured SLOWER: 26.4 ms against 24.4 ms for the 137 GB image
-    // of 2 M instances of Sha256(2048) - 5.2 against 5.6 TB/s)
+    // of 2 M instances of Sha256(2048) - 5.2 against 5.6 TB/s; round 5: whole-line loads - lane l reads the l-th 16-byte piece of
+    // a 1 KiB run, even lanes the lower halves - change nothing: 24.3 / 24.7 ms against 24.5 / 24.7, profiles/r05g_*)
     for (uint32_t ii = 0; ii < ni; ii++) {
         uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
         if (have) {

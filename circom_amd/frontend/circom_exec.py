@@ -25,8 +25,13 @@ a sub-component declared with tags only accepts a signal that carries them; a va
 value; a parent reads `component.out.tag`.  A tag VALUE does not flow INTO a component (its body is traced once per
 parameter set, before the parent assigns its inputs).
 
-Not supported (each raises CircuitError with the source position): custom templates / `extern_c`, `while` on an unknown
-condition in a TEMPLATE body.
+Not supported (each raises CircuitError with the source position, never a silent difference): custom templates / `extern_c`
+(the device-side slot is a native body); `while` on an unknown condition in a TEMPLATE body; a tag VALUE read
+inside the component it flows into (`signal input {maxbit} x; var m = x.maxbit;` - "tag maxbit has no value": the reference
+re-executes the template per tag-value set); functions that recurse on run-time values ("recursion on run-time values is not
+supported"), and in the abstract pre-run a recursion under an unknown condition ends in "function calls nested too deeply"
+instead of becoming a run-time function; a division by a KNOWN zero inside an untaken run-time branch aborts compilation
+(the reference only fails if the branch runs).  The front-end is frozen at this state (SURVEY §2 rows 1/2/4 are out of scope).
 """
 from __future__ import annotations
 

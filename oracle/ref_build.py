@@ -49,6 +49,7 @@ def build_circuit(cp, force=False):
     h.update(repr(list(getattr(cp.flat, "log_strings", ()))).encode())
     h.update(repr(getattr(cp.flat, "io_map", ())).encode())
     h.update(open(Path(__file__).resolve().parent / "emit_ref_cpp.py", "rb").read())   # the emitter itself
+    h.update(b"CIRCUIT_OPT=-O3")                                  # (oracle/Makefile: binaries built at -O1 in earlier rounds are stale)
     fp = h.hexdigest()
     fp_file = d / (cp.name + ".fp")
     fresh = fp_file.exists() and fp_file.read_text().strip() == fp
@@ -223,9 +224,9 @@ def time_reference(cp, workload: str, seconds_budget: float = 15.0):
                      "(common/calcwit.cpp + generic/fr.cpp --no_asm GMP build), compute-only in-process loop, "
                      "wall %.1f s" % (n, n_per_core, cores, workload, wall),
            # the field library and the runtime are built at -O3 as the reference's makefile does (c_elements/generic/makefile:2);
-           # the circuit's own <name>.cpp - a straight line of calls into them, 10 MB of source per SHA-256 block pair - at -O1
-           # (oracle/Makefile CIRCUIT_OPT: -O3 on it costs tens of minutes of g++ per circuit for call-bound code)
-           "circuit_opt": "fr.cpp / calcwit.cpp / main.cpp -O3, <name>.cpp -O1 (oracle/Makefile CIRCUIT_OPT)"}
+           # the circuit's own <name>.cpp - a straight line of calls into them, 10 MB of source per SHA-256 block pair - at -O3 as
+           # well (oracle/Makefile CIRCUIT_OPT = c_elements/generic/makefile:2; round 4 built it at -O1)
+           "circuit_opt": "fr.cpp / calcwit.cpp / main.cpp / <name>.cpp all -O3 (oracle/Makefile, as c_elements/generic/makefile)"}
     # (i) end to end: JSON parse + process start + .dat load + compute + .wtns write, `cores` processes at a time
     try:
         res["end_to_end"] = _time_cli(cp, gen, cores, min(8.0, seconds_budget * 0.5))
@@ -269,6 +270,18 @@ def _time_cli(cp, gen, cores, budget):
             "sample": "%d runs of `./%s input.json out.wtns` (%d at a time)" % (done, cp.name, cores)}
 
 
+def _flat_only(prog, d, name):
+    """what build_circuit needs of a compiled circuit - the flat program and its .dat - without lowering it (minutes for the
+    ECDSA verifier)"""
+    from types import SimpleNamespace
+    from circom_amd.frontend.flatten import flatten
+    from circom_amd.hip_elements import writers
+    fc = flatten(prog)
+    dat = os.path.join(d, name + ".dat")
+    writers.write_dat(dat, fc)
+    return SimpleNamespace(name=name, flat=fc, dat_path=dat)
+
+
 def build_default_circuits():
     """Called from __graft_entry__.build(): prebuild the oracle binaries the GPU-side tests/bench use."""
     import tempfile as _t
@@ -288,6 +301,10 @@ def build_default_circuits():
         # (only the flat circuit and the .dat are needed here: one strand variant, no emitted code)
         cp = compile_program(prog, d, name, sym=False, strands=(1,), jit=False, fpjit=False)
         build_circuit(cp)
+    # BASELINE config 5's verifier (2.47 M signals: half a minute of tracing, minutes of g++): parity + CPU baseline of its bench line
+    # (only the flat program and its .dat: build_circuit compares fingerprints and returns when the binary is current)
+    import bench
+    build_circuit(_flat_only(bench.make_program("ecdsa_verify"), d, "ecdsa_verify"))
     # the reference's 64-bit runtime for `bench.py --workload poseidon2_goldilocks` (parity + CPU baseline of that line)
     from circom_amd.frontend.flatten import flatten
     if not (ref_dir("goldilocks") / "poseidon2").exists():

@@ -441,3 +441,24 @@ def test_replay_of_emitted_ir_library_circuits(bodies):
     want, st0 = eval_tape(t, inp)
     got, st1 = replay_tape(t, p, bodies, inp)
     assert st0 == 0 and (got, st1) == (want, st0) and fpjit_eval.replay.first_bad is None
+
+
+def test_no_assembler_on_the_host_leaves_a_valid_tape(tmp_path, monkeypatch):
+    """`auto` emission must not fail the compile when clang / ld.lld of the ROCm LLVM are missing or reject the text -
+    the tape then carries the interpreted program only (with a warning); an explicit fpjit=True still raises"""
+    from circom_amd.hip_elements import bitjit
+    from circom_amd import runtime as rt
+
+    def boom():
+        raise RuntimeError("no ROCm LLVM on this host")
+    monkeypatch.setattr(bitjit, "_llvm_bin", boom)
+    monkeypatch.delenv("CW_FPJIT", raising=False)
+    with pytest.warns(UserWarning, match="not emitted"):
+        cp = compile_program(Program(Poseidon(2)), str(tmp_path), "p2", sym=False, strands=(4,), fpjit="auto")
+    assert cp.fpjit == ()
+    rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path).close()
+    with pytest.raises(RuntimeError, match="no ROCm LLVM"):
+        compile_program(Program(Poseidon(2)), str(tmp_path), "p2b", sym=False, strands=(4,), fpjit=True)
+    import glob
+    import tempfile
+    assert not glob.glob(os.path.join(tempfile.gettempdir(), "cw_fpjit_*", "k.s"))
