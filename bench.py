@@ -204,11 +204,11 @@ def get_compiled(name: str, batch: int, cache_root: str, rank: int, dist):
         # arithmetic circuits: the rows of every strand variant as emitted code as well (hip_elements/fpjit.py); schedules with
         # run-time functions on several strands / with the native long_div (config 5's verifier) run on the interpreting kernel
         fps = compiler.emit_fpjit(tapes, fc, False if bittape is not None else "auto")
-        writers.write_tape(p(".cwt"), tapes, bittape, jp, fps)
+        rid = writers.write_r1cs(p(".r1cs"), fc)
+        writers.write_tape(p(".cwt"), tapes, bittape, jp, fps, r1cs_id=rid)
         json.dump(jp.stats if jp is not None else {}, open(p(".jit.json"), "w"))
         json.dump([dict(fp_.stats, n_strands=fp_.n_strands, code_bytes=len(fp_.code)) for fp_ in fps], open(p(".fpjit.json"), "w"))
         writers.write_dat(p(".dat"), fc)
-        writers.write_r1cs(p(".r1cs"), fc)
         open(done, "w").write(fp)
     if lock is not None:
         lock.close()                    # (releases the flock)

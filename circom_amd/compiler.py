@@ -250,9 +250,9 @@ def compile_program(prog: Program, outdir: str, name: str, sym: bool = True, str
     tape = tapes[0]
     p = lambda ext: os.path.join(outdir, name + ext)
     fps = emit_fpjit(tapes, fc, False if (bittape is not None and fpjit == "auto") else fpjit)
-    writers.write_tape(p(".cwt"), tapes, bittape, jp, fps)
+    rid = writers.write_r1cs(p(".r1cs"), fc)          # first: the tape records which constraint system its fused checks belong to
+    writers.write_tape(p(".cwt"), tapes, bittape, jp, fps, r1cs_id=rid)
     writers.write_dat(p(".dat"), fc)
-    writers.write_r1cs(p(".r1cs"), fc)
     if sym:
         writers.write_sym(p(".sym"), fc)
     return Compiled(name, outdir, p(".cwt"), p(".dat"), p(".r1cs"), p(".sym"), fc, tape, bittape, jp, fps)

@@ -37,6 +37,7 @@ struct JitProgram {
     std::vector<uint32_t> sig_slot;          // signal -> row
     std::vector<uint8_t> code;               // ELF code object (hipModuleLoadData)
     std::vector<uint8_t> audit_code;         // ELF of the stand-alone audit of the table (same kernel name and arguments); may be empty
+    uint32_t r1cs_crc = 0, r1cs_len = 0;     // constraint section of the .r1cs the fused check / the audit were built from (0, 0: unknown)
     bool check_complete = false;             // the fused R1CS check covers every constraint of the circuit
     uint32_t n_vgpr = 0, n_agpr = 0;
 };

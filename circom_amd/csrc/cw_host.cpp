@@ -233,8 +233,27 @@ struct FpJit {
     uint32_t n_covered = 0;
     std::vector<uint8_t> code;                                       // ELF code object (hipModuleLoadData)
     std::map<int, std::pair<hipModule_t, hipFunction_t>> mod;        // device -> loaded module
+    uint32_t r1cs_crc = 0, r1cs_len = 0;                             // the .r1cs constraint section `covered` refers to (0, 0: unknown)
 };
 constexpr const char *FPJIT_KERNEL = "cw_fp_jit";
+
+// CRC-32 (IEEE, zlib's) of the constraint section of a .r1cs: the identity of the constraint system emitted checks were built
+// from (hip_elements/writers.py write_r1cs returns it, write_tape stores it)
+static uint32_t crc32_ieee(const uint8_t *p, size_t n) {
+    static uint32_t tab[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            tab[i] = c;
+        }
+        init = true;
+    }
+    uint32_t c = 0xFFFFFFFFu;
+    for (size_t i = 0; i < n; i++) c = tab[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
 
 struct cw_circuit {
     U256 q;
@@ -282,6 +301,7 @@ struct cw_circuit {
     // batches alive on this circuit (side batches included): their device images of the witness list (d_w2s, d_wslot,
     // d_gather) are sized once at creation, so the list may only change while this is zero (cw_set_witness_list)
     std::atomic<int> live_batches{0};
+    bool r1cs_matches_code = true;         // the loaded .r1cs is the constraint system the emitted checks were built from (load_r1cs)
 };
 
 static uint64_t fnv1a(const char *s, size_t n) {   // calcwit.cpp:17-24
@@ -970,11 +990,19 @@ static int load_tape(cw_circuit *c, const char *path) {
         // emitted code: 8 x u32 {format 1, n_slots lo, hi, code bytes, flags (bit 0: the fused R1CS check covers every
         // constraint), VGPRs, AccVGPRs, 0}, signal -> slot map, the code object (padded to 4 bytes)
         if (off + 32 > b.size()) return fail(CW_EIO, "tape emitted program truncated");
-        uint32_t jh[8];
+        uint32_t jh[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         memcpy(jh, b.data() + off, 32);
         off += 32;
-        if (jh[0] != 1) return fail(CW_EIO, "tape emitted program: unknown format version (lowered by another release)");
+        if (jh[0] == 2) {                          // format 2: + identity of the constraint system the checks were built from
+            if (off + 8 > b.size()) return fail(CW_EIO, "tape emitted program truncated");
+            memcpy(jh + 8, b.data() + off, 8);
+            off += 8;
+        } else if (jh[0] != 1 || jh[7]) {
+            return fail(CW_EIO, "tape emitted program: unknown format version (lowered by another release)");
+        }
         cwbits::JitProgram &jp = c->jit;
+        jp.r1cs_crc = jh[8];
+        jp.r1cs_len = jh[9];
         jp.n_slots = (uint64_t)jh[1] | ((uint64_t)jh[2] << 32);
         const uint64_t code_bytes = jh[3], padded = (code_bytes + 3) & ~3ull;
         jp.check_complete = jh[4] & 1u;
@@ -1007,7 +1035,7 @@ static int load_tape(cw_circuit *c, const char *path) {
             memcpy(ph, b.data() + off, 32);
             off += 32;
             const uint64_t padded = ((uint64_t)ph[1] + 3) & ~3ull;
-            if (ph[0] == 0 || ph[0] > 16 || (ph[0] & (ph[0] - 1)) || ph[2] > 160 * 1024 || ph[3] > 4096 || ph[4] > 512 || ph[6] || ph[7] ||
+            if (ph[0] == 0 || ph[0] > 16 || (ph[0] & (ph[0] - 1)) || ph[2] > 160 * 1024 || ph[3] > 4096 || ph[4] > 512 ||
                 ph[1] < 64 || (uint64_t)ph[5] * 4 > b.size() - off || padded > b.size() - off - (uint64_t)ph[5] * 4)
                 return fail(CW_EIO, "tape emitted 256-bit code: bad header");
             std::vector<uint32_t> cov(ph[5]);
@@ -1023,6 +1051,8 @@ static int load_tape(cw_circuit *c, const char *path) {
             fj.scratch_bytes = ph[3];
             fj.n_vgpr = ph[4];
             fj.covered = std::move(cov);
+            fj.r1cs_crc = ph[6];                   // (0, 0 in tapes of earlier releases: the row count is then the only guard)
+            fj.r1cs_len = ph[7];
             for (uint32_t w : fj.covered) fj.n_covered += (uint32_t)__builtin_popcount(w);
             fj.code.assign(b.data() + off, b.data() + off + ph[1]);
             off += (size_t)padded;
@@ -1157,6 +1187,28 @@ static int load_r1cs(cw_circuit *c, const char *path) {
     if (n_wires != c->n_witness) return fail(CW_EIO, "r1cs wire count differs from the witness size");
     if ((uint64_t)n_cons > seclen[2] / 12) return fail(CW_EIO, "r1cs constraint count exceeds its section");   // 3 x u32 nnz each
     c->n_constraints = n_cons;
+    {
+        // Checks baked into emitted code (the fused check and the audit of the bit-plane code, the `covered` rows of the 256-bit
+        // code) were built from ONE constraint system: they are trusted only for a .r1cs whose constraint section is byte for byte
+        // that one (same CRC-32, same length).  Any other file - even one with the same number of rows - is checked in full by the
+        // stand-alone kernels, and the programs with baked-in checks are not used.
+        const uint32_t crc = crc32_ieee(sec[2], (size_t)seclen[2]), len = (uint32_t)seclen[2];
+        c->r1cs_matches_code = true;
+        if (c->has_jit && (c->jit.r1cs_crc || c->jit.r1cs_len) && (c->jit.r1cs_crc != crc || c->jit.r1cs_len != len)) {
+            c->jit.check_complete = false;
+            c->jit.audit_code.clear();
+            c->r1cs_matches_code = false;
+        }
+        for (size_t k = 0; k < c->fpjit.size();) {
+            FpJit &fj = c->fpjit[k];
+            if (fj.n_covered && (fj.r1cs_crc || fj.r1cs_len) && (fj.r1cs_crc != crc || fj.r1cs_len != len)) {
+                c->fpjit.erase(c->fpjit.begin() + (long)k);
+                c->r1cs_matches_code = false;
+                continue;
+            }
+            k++;
+        }
+    }
     c->r_ptr.assign(1, 0);
     c->r_ptr.reserve((size_t)n_cons * 3 + 1);
     // coefficient table: id 0 = +1, id 1 = -1, others = c*R mod q
@@ -1343,6 +1395,7 @@ extern "C" int cw_set_witness_list(cw_circuit *c, const uint32_t *signals, uint3
     c->n_witness = n;
     return CW_OK;
 }
+extern "C" int cw_emitted_checks_match(const cw_circuit *c) { return c && c->r1cs_matches_code ? 1 : 0; }
 extern "C" uint32_t cw_input_start(const cw_circuit *c) { return c->input_start; }
 extern "C" uint32_t cw_n_constraints(const cw_circuit *c) { return c->n_constraints; }
 // public signals = main's outputs then its public inputs = witness positions 1 .. n_public (r1cs header nPubOut/nPubIn)

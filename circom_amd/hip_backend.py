@@ -28,9 +28,9 @@ def lower_cwf(cwf_path: str, outdir: str, name: str, strands=(1, 4, 16), bits="a
     tapes = [lower(fc, n_strands=s, mont=mont) for s in strands]
     p = lambda ext: os.path.join(outdir, name + ext)
     fps = compiler.emit_fpjit(tapes, fc, False if bittape is not None else "auto")             # the rows as emitted code
-    writers.write_tape(p(".cwt"), tapes, bittape, jp, fps)
+    rid = writers.write_r1cs(p(".r1cs"), fc)
+    writers.write_tape(p(".cwt"), tapes, bittape, jp, fps, r1cs_id=rid)
     writers.write_dat(p(".dat"), fc)
-    writers.write_r1cs(p(".r1cs"), fc)
     return p(".cwt"), p(".dat"), p(".r1cs")
 
 

@@ -96,7 +96,7 @@ TAPE_MAGIC = b"CWTP"
 TAPE_VERSION = 11
 
 
-def write_tape(path, tapes, bittape=None, jit=None, fpjit=()):
+def write_tape(path, tapes, bittape=None, jit=None, fpjit=(), r1cs_id=None):
     """`.cwt` layout (little endian).  `tapes` = one Tape or a list of Tapes of the SAME circuit lowered with
     different strand counts (the runtime picks the variant that fills the chip for the batch at hand).
          0  "CWTP" | u32 version | u32 n64 | u32 n_variants
@@ -126,10 +126,13 @@ def write_tape(path, tapes, bittape=None, jit=None, fpjit=()):
             bit program     (if n_bit_programs, hip_elements/bitsched.py)  8 x u32: ring, n_vrows, n_slots lo, hi, cache, n_asserts, 2, 0;
                             records n_vrows*64 x 2 u32; command blocks n_vrows/8 x 24 u32; signal -> slot; assertion slots
             emitted 256-bit code (optional, after everything else; hip_elements/fpjit.py): see the end of this function
-            emitted code    (if n_bit_programs == 2, hip_elements/bitjit.py)  8 x u32: 1, n_slots lo, hi, code bytes, flags (bit 0:
+            emitted code    (if n_bit_programs == 2, hip_elements/bitjit.py)  10 x u32: 2, n_slots lo, hi, code bytes, flags (bit 0:
                             the fused R1CS check covers every constraint), VGPRs, AccVGPRs, bytes of the AUDIT code object
-                            (0: none); signal -> slot; the gfx950 code object (ELF), padded to 4 bytes; then the audit code
-                            object (bitjit.lower_jit(audit_of=): the check's gates on loaded rows), padded to 4 bytes
+                            (0: none), CRC-32 and byte length of the constraint section of the .r1cs the checks were built from
+                            (0, 0: unknown; write_r1cs returns them - cw_load trusts fused checks only when the .r1cs it is given
+                            has the same section); signal -> slot; the gfx950 code object (ELF), padded to 4 bytes; then the
+                            audit code object (bitjit.lower_jit(audit_of=): the check's gates on loaded rows), padded to 4 bytes
+                            (format 1 of earlier releases: 8 words, no audit, no identity)
     """
     if isinstance(tapes, Tape):
         tapes = [tapes]
@@ -190,8 +193,9 @@ def write_tape(path, tapes, bittape=None, jit=None, fpjit=()):
         if jit is not None:
             assert bittape is not None and jit.code is not None and jit.n_signals == t0.n_signals
             audit = getattr(jit, "audit_code", None) or b""
-            f.write(struct.pack("<8I", 1, jit.n_slots & 0xFFFFFFFF, jit.n_slots >> 32, len(jit.code), 1 if jit.check_complete else 0,
-                                jit.n_vgpr, jit.n_agpr, len(audit)))
+            rid = r1cs_id or (0, 0)
+            f.write(struct.pack("<10I", 2, jit.n_slots & 0xFFFFFFFF, jit.n_slots >> 32, len(jit.code), 1 if jit.check_complete else 0,
+                                jit.n_vgpr, jit.n_agpr, len(audit), rid[0], rid[1] & 0xFFFFFFFF))
             f.write(np.ascontiguousarray(jit.sig_slot, dtype="<u4").tobytes())
             f.write(jit.code + b"\0" * (-len(jit.code) % 4))
             f.write(audit + b"\0" * (-len(audit) % 4))
@@ -207,7 +211,9 @@ def write_tape(path, tapes, bittape=None, jit=None, fpjit=()):
                 for i, cbit in enumerate(fp.covered):
                     if cbit:
                         cov[i >> 5] |= np.uint32(1 << (i & 31))
-                f.write(struct.pack("<8I", fp.n_strands, len(fp.code), fp.lds_bytes, fp.scratch_bytes, getattr(fp, "n_vgpr", 128), len(cov), 0, 0))
+                rid = (r1cs_id or (0, 0)) if any(fp.covered or ()) else (0, 0)
+                f.write(struct.pack("<8I", fp.n_strands, len(fp.code), fp.lds_bytes, fp.scratch_bytes, getattr(fp, "n_vgpr", 128), len(cov),
+                                    rid[0], rid[1] & 0xFFFFFFFF))
                 f.write(cov.tobytes())
                 f.write(fp.code + b"\0" * (-len(fp.code) % 4))
 
@@ -247,6 +253,8 @@ def write_r1cs(path, fc: FlatCircuit, wire_of_signal=None):
         for typ, body in ((2, sec2), (1, sec1), (3, sec3)):
             f.write(struct.pack("<IQ", typ, len(body)))
             f.write(body)
+    import zlib
+    return zlib.crc32(sec2) & 0xFFFFFFFF, len(sec2)     # identity of the constraint system (write_tape r1cs_id=)
 
 
 def write_sym(path, fc: FlatCircuit):

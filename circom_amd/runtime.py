@@ -85,6 +85,7 @@ _SIGS = {
     "cw_remaining_inputs": (C.c_int64, [C.c_void_p, C.c_uint32]),
     "cw_run": (C.c_int, [C.c_void_p]),
     "cw_check_r1cs": (C.c_int, [C.c_void_p]),
+    "cw_emitted_checks_match": (C.c_int, [C.c_void_p]),
     "cw_batch_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "cw_batch_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "cw_sync": (C.c_int, [C.c_void_p]),
@@ -149,6 +150,7 @@ class Circuit:
         self.h = h
         L = lib()
         self.n_signals = L.cw_n_signals(h)
+        self.emitted_checks_match = bool(L.cw_emitted_checks_match(h))    # False: the .r1cs is not the one the emitted checks were built from
         self.n_witness = L.cw_n_witness(h)
         self.n_inputs = L.cw_n_inputs(h)
         self.input_start = L.cw_input_start(h)

@@ -69,6 +69,10 @@ uint32_t cw_n_inputs(const cw_circuit *c);           /* get_main_input_signal_no
  * cw_n_witness() returns n.  CW_EINVAL while any batch of the circuit is alive: a batch sizes its device images of the list
  * when it is created, so the list is fixed before the first cw_batch_create (or after the last cw_batch_free). */
 int cw_set_witness_list(cw_circuit *c, const uint32_t *signals, uint32_t n);
+/* 1 unless the .r1cs given to cw_load is NOT the constraint system the tape's emitted checks were built from (the tape records
+ * CRC-32 and length of that file's constraint section): then the fused checks / covered rows / audit program are not used and
+ * the stand-alone kernels check every row of the file that was loaded.  (No reference counterpart: its runtime never checks.) */
+int cw_emitted_checks_match(const cw_circuit *c);
 uint32_t cw_input_start(const cw_circuit *c);        /* get_main_input_signal_start() */
 uint32_t cw_n_constraints(const cw_circuit *c);      /* from the .r1cs header, 0 if none loaded */
 uint32_t cw_n_public(const cw_circuit *c);     /* nPubOut + nPubIn of the r1cs header */

@@ -184,3 +184,33 @@ def test_advisor_round1_loader_cases(tmp_path):
     with pytest.raises(rt.CwError):
         attempt(r=dup)
     attempt().close()                                                        # the unmodified files still load
+
+
+def test_emitted_checks_are_trusted_only_for_the_r1cs_they_were_built_from(tmp_path, monkeypatch):
+    """the fused checks / covered rows are baked into the emitted code at lowering time; the only guard that the .r1cs
+    given to cw_load is THAT system used to be its row count.  The tape now records CRC-32 + length of the file's constraint
+    section: another file with the same rows count switches the baked-in checks off (the stand-alone kernels check every row)"""
+    import struct
+    from circom_amd import runtime as rt
+    from circom_amd.compiler import compile_program
+    from circom_amd.frontend.dsl import Program
+    from circom_amd.circuits.poseidon import Poseidon
+    from test_bitplane import BitGadget
+    monkeypatch.setenv("CW_FPJIT", "1")
+    for name, prog, kw in (("p2", Program(Poseidon(2)), dict(strands=(4,))), ("bg", Program(BitGadget(16)), dict(strands=(1,), bits=True, jit=True))):
+        cp = compile_program(prog, str(tmp_path), name, sym=False, **kw)
+        c = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
+        assert c.emitted_checks_match
+        c.close()
+        raw = bytearray(open(cp.r1cs_path, "rb").read())
+        # constraint section = the first section of the file (type 2): flip the low byte of the first coefficient
+        assert struct.unpack_from("<I", raw, 12)[0] == 2
+        pos = 24                                                   # file header 12 + section header 12: nnz of the first block
+        while struct.unpack_from("<I", raw, pos)[0] == 0:          # (empty linear combinations have no terms to change)
+            pos += 4
+        raw[pos + 4 + 4] ^= 2                                      # nnz, wire id, then the coefficient's low byte
+        other = tmp_path / (name + "_other.r1cs")
+        other.write_bytes(bytes(raw))
+        c = rt.Circuit(cp.tape_path, cp.dat_path, other)
+        assert not c.emitted_checks_match and c.n_constraints == len(cp.flat.constraints)
+        c.close()
