@@ -292,6 +292,8 @@ def _expand(fc: FlatCircuit):
         return k, v
 
     rows = []
+    n_pow2 = 0
+    pow2_divisions = os.environ.get("CW_POW2_DIV", "1") != "0"
     row_seq, cur_seq = [], 0        # rows[k] comes from flat operation row_seq[k] (eval_flat's index of a failing check)
     flat_index = idx.tolist()
     for i in range(len(op)):
@@ -327,6 +329,18 @@ def _expand(fc: FlatCircuit):
             # the arguments are operands of the call for every dependency analysis (they are read from memory)
             r_.terms = [[K_TMP, bv[i] + k, 0] for k in range(fc.functions[av[i]]["n_args"])]
             rows.append(r_)
+        elif (o == O.IDIV or o == O.MOD) and bk[i] == K_CONST and consts_in[bv[i]] % q > 0 \
+                and (consts_in[bv[i]] % q) & ((consts_in[bv[i]] % q) - 1) == 0 and pow2_divisions:
+            # x \ 2^k = x >> k and x % 2^k = x & (2^k - 1) on canonical values (Fr_idiv / Fr_mod divide the residues as integers,
+            # generic/fr.cpp; a constant non-zero divisor cannot fail): a shift / a mask instead of a Knuth-D division - the carry
+            # chains of circom-ecdsa's big-integer gadgets (`t % 2^n`, `t \ 2^n` per limb) are serial, 20 K clocks per division
+            c_ = consts_in[bv[i]] % q
+            ka, va = opnd(ak[i], av[i])
+            if o == O.IDIV:
+                rows.append(_Row(D_SHR, dk[i] if dk[i] != K_NONE else KD_NONE, dv[i], ka, va, K_CONST, cid(c_.bit_length() - 1)))
+            else:
+                rows.append(_Row(D_BAND, dk[i] if dk[i] != K_NONE else KD_NONE, dv[i], ka, va, K_CONST, cid(c_ - 1)))
+            n_pow2 += 1
         elif o == O.SELECT:
             ka, va = opnd(ak[i], av[i])
             kb, vb = opnd(bk[i], bv[i])
@@ -342,6 +356,7 @@ def _expand(fc: FlatCircuit):
     for r_, sq in zip(rows, row_seq):
         r_.seq = min(sq, SEQ_MAX)
     _expand.n_proved = int(proved.sum())
+    _expand.n_pow2 = n_pow2
     return rows, dconsts, nxt[0], cid, plain
 
 
@@ -1737,6 +1752,7 @@ def lower(fc: FlatCircuit, witness_map=None, n_strands: int = 1, pipe=None, mont
         "inv": int((dops == D_INV).sum()),
         "inv_batches": n_inv_batches,
         "bits_rows": int((dops == D_BITS).sum()), "bits_fused": n_bits_fused, "bit_sums_folded": n_bitsums,
+        "pow2_divisions": getattr(_expand, "n_pow2", 0),
         "linsum_splits": n_split,
         "barriers": n_levels,
         "full_barriers": len(full_after),

@@ -184,3 +184,35 @@ def test_random_circuits_match_the_reference_runtime(seed, prime, tmp_path):
         sig, failed = eval_flat(Q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp)
         assert failed is None
         assert open(pre + "%d.wtns" % i, "rb").read() == wtns_bytes(Q, sig), (seed, i)
+
+
+def test_division_by_a_constant_power_of_two_is_a_shift():
+    """`x \\ 2^k` / `x % 2^k` with a constant divisor become D_SHR / D_BAND rows (lower.py pass A: no Knuth-D division, no failing
+    row); other constant divisors keep the division.  Same witness as the flat program on edge values."""
+    from circom_amd.frontend.dsl import Program, template
+    from circom_amd.frontend.flatten import flatten
+    from circom_amd.hip_elements import lower as L
+    from oracle.tape_eval import eval_flat, eval_tape
+
+    @template
+    def Limbs(c):
+        x = c.input("x")
+        out = c.output("out", 6)
+        c.hint(out[0], x % (1 << 64))
+        c.hint(out[1], x // (1 << 64))
+        c.hint(out[2], x % 7)
+        c.hint(out[3], x // 7)
+        c.hint(out[4], (x + 5) // (1 << 200))
+        c.hint(out[5], x % 1)
+    for prime in ("bn128", "bls12381"):
+        fc = flatten(Program(Limbs(), prime=prime))
+        q = fc.fp.q
+        t = L.lower(fc, n_strands=1)
+        ops = [int(r[0]) & 0xFF for r in t.rows]
+        assert ops.count(L.D_SHR) == 2 and ops.count(L.D_IDIV) == 1 and ops.count(L.D_MOD) == 1 and t.stats["pow2_divisions"] >= 4
+        for x in (0, 1, (1 << 64) - 1, 1 << 64, (1 << 200) - 5, q - 1, q >> 1, 12345678901234567890123456789):
+            inp = {fc.main_input_start: x % q}
+            want, failed = eval_flat(q, fc.n_signals, fc.n_temps, fc.constants, fc.code, inp)
+            got, st = eval_tape(t, inp)
+            assert failed is None and st == 0 and got == want
+            assert want[1:7] == [x % q % (1 << 64), x % q >> 64, x % q % 7, x % q // 7, ((x % q + 5) % q) >> 200, 0]
