@@ -146,7 +146,16 @@ def test_poseidon2_batch_bit_exact(tmp_path):
     ins[2] = [c.q - 1, c.q - 1]
     b = c.batch(n)
     b.set_inputs(ins)
-    b.run(); b.check_r1cs(); b.sync()
+    with pytest.raises(rt.CwError, match="timing is off"):
+        b.kernel_ms()
+    b.set_timing(True)                                             # events around the parts of run / check on the batch's stream
+    b.run()
+    km = b.kernel_ms()
+    assert km["ingest"] > 0 and km["eval"] > 0 and km["check"] is None        # the check has not run yet
+    b.check_r1cs(); b.sync()
+    km = b.kernel_ms()
+    assert 0 < km["ingest"] < 50 and 0 < km["eval"] < 500 and 0 < km["check"] < 500
+    b.set_timing(False)
     assert (b.status() == 0).all()
     assert b.signal(0, 1) == 7853200120776062878684798364095072458815029376092732009249414926327459813530
     # every instance: hash output vs the plain-integer Poseidon
