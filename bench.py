@@ -199,6 +199,10 @@ def get_compiled(name: str, batch: int, cache_root: str, rank: int, dist):
             strands = (1,)                  # the 256-bit schedule only serves instances re-run with non-boolean inputs
             mont = False
         tapes = [lower(fc, n_strands=s, mont=mont) for s in strands]
+        if tapes[0].functions and tapes[0].n_strands > 1 and 1 not in strands and compiler.parallel_speedup(tapes[0]) < 2.0:
+            # strands that would mostly wait for one chain of calls (BigMultModP = one long_div + a few rows): the single-strand
+            # variant - which has an emitted form - goes into the tape too, and cw_batch_create prefers it
+            tapes.insert(0, lower(fc, n_strands=1, mont=mont))
         jp = compiler.emit_jit(compiler.lower_bitplane.net, fc) if bittape is not None else None     # the same network as emitted code
         compiler.lower_bitplane.net = None
         # arithmetic circuits: the rows of every strand variant as emitted code as well (hip_elements/fpjit.py); schedules with

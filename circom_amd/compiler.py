@@ -41,6 +41,44 @@ def strands_for(batch: int):
     return (1,)
 
 
+def parallel_speedup(tape) -> float:
+    """work / critical path of a strand schedule under the measured costs of interpreted rows (lower.py _COST_INTERP; the twin of
+    cw_host.cpp's choice in cw_batch_create): per barrier epoch the busiest strand's cost, summed, against the cost of all
+    rows.  A circuit that is one long call plus a few rows (BigMultModP) gets ~1 whatever the strand count: its single-strand
+    variant (which has an emitted form) should be in the tape as well."""
+    import numpy as np
+    from .hip_elements import lower as L
+    rows, so, S = np.asarray(tape.rows), tape.stream_off, tape.n_strands
+    if S <= 1 or len(rows) == 0:
+        return 1.0
+    fixed = {L.D_MULC: 8.0, L.D_MADDC: 8.0, L.D_MADD: 8.0, L.D_MUL2: 10.0, L.D_IDIV: 23.0, L.D_MOD: 23.0, L.D_INV: 180.0, L.D_POW: 6000.0}
+    per = []
+    n_ep = 0
+    for s_ in range(S):
+        r = rows[int(so[s_]):int(so[s_ + 1])]
+        op = r[:, 0] & 0xFF
+        nx = (r[:, 0] >> L.SH_NX) & 0xFFF
+        c = np.full(len(r), 6.0)
+        for k, v in fixed.items():
+            c[op == k] = v
+        c[op == L.D_LINSUM] = 6.0 + 4.8 * r[op == L.D_LINSUM, 2]
+        c[op == L.D_DOTC] = 6.0 + 6.0 * r[op == L.D_DOTC, 2]
+        c[op == L.D_BITS] = 6.0 + 0.3 * nx[op == L.D_BITS]
+        for i in np.nonzero(op == L.D_CALL)[0]:
+            nat = tape.functions[int(r[i, 2])][2]
+            c[i] = 20000.0 if nat is None else 130.0 if nat[0] == 4 else 170.0
+        c[op == L.D_BARRIER] = 0.0
+        ep = np.cumsum(op == L.D_BARRIER)
+        e = np.bincount(ep, weights=c)
+        per.append(e)
+        n_ep = max(n_ep, len(e))
+    E = np.zeros((S, n_ep))
+    for s_, e in enumerate(per):
+        E[s_, :len(e)] = e
+    crit = float(E.max(axis=0).sum())
+    return float(E.sum()) / crit if crit > 0 else 1.0
+
+
 def choose_mont(fc: FlatCircuit) -> bool:
     """Montgomery-form signals (lower.py pass A6) pay off for arithmetic circuits: every product of two run-time values
     saves one of its two Montgomery products, every value that an integer operator touches (bit extraction, shifts, bitwise,

@@ -215,6 +215,7 @@ struct HashEntry {
 struct Variant {               // one lowering of the schedule for a given strand count
     uint32_t n_strands = 1, n_tslots = 0, n_lds = 0;
     uint32_t prio_mask = 0;        // strands whose share of the work is within 20 % of the heaviest one (s_setprio)
+    double work = 0, crit = 0;     // circuits with functions: total cost of the rows / sum over barrier epochs of the busiest strand's
     uint32_t n_active = 1;         // strands that carry work (a 3-lane circuit leaves 13 of 16 strands with barriers only)
     bool wide_linsum = false;      // schedule dominated by long small-coefficient sums -> 4 operand loads in flight
     // kind 1 = pipelined single-wave schedule (hip_elements/pipe.py): prows = 8 words per row, extras = the load lists
@@ -944,6 +945,52 @@ static int load_tape(cw_circuit *c, const char *path) {
             }
             var.n_active += load[st] > 0;
         }
+        if (!c->fn_tab.empty()) {
+            // Circuits with run-time functions: how much shorter than the work is the variant's critical path?  Per barrier epoch the
+            // busiest strand's cost (the MEASURED costs of interpreted rows, lower.py _COST_INTERP: a call is 130 - 20 000 units
+            // on ONE strand while the others wait), summed; cw_batch_create skips a multi-strand variant that does not at least
+            // halve the single strand's time (BigMultModP = one long_div call + a few rows: 16 strands only take wave slots).
+            auto cost_of = [&](const CwRow &rw) -> double {
+                const uint32_t op = rw.w0 & 0xFF, nx = (rw.w0 >> SH_NX) & 0xFFF;
+                switch (op) {
+                case D_CALL: {
+                    const uint32_t kind = rw.a < n_functions ? (c->fn_tab[(size_t)rw.a * 4 + 3] & 15u) : 0u;
+                    return kind == 0 ? 20000.0 : kind == 4 ? 130.0 : 170.0;
+                }
+                case D_BITS: return 6.0 + 0.3 * nx;
+                case D_LINSUM: return 6.0 + 4.8 * rw.a;
+                case D_DOTC: return 6.0 + 6.0 * rw.a;
+                case D_MULC: case D_MADDC: case D_MADD: return 8.0;
+                case D_MUL2: return 10.0;
+                case D_IDIV: case D_MOD: return 23.0;
+                case D_INV: return 180.0;
+                case D_POW: return 6000.0;
+                default: return 6.0;
+                }
+            };
+            std::vector<std::vector<double>> ep(var.n_strands);
+            size_t n_ep = 0;
+            for (uint32_t st = 0; st < var.n_strands; st++) {
+                double cur = 0;
+                for (uint32_t r = var.stream_off[st]; r < var.stream_off[st + 1]; r++) {
+                    const uint32_t op = var.rows[r].w0 & 0xFF;
+                    if (op == D_BARRIER) { ep[st].push_back(cur); cur = 0; continue; }
+                    cur += cost_of(var.rows[r]);
+                }
+                ep[st].push_back(cur);
+                n_ep = std::max(n_ep, ep[st].size());
+            }
+            var.work = var.crit = 0;
+            for (size_t e = 0; e < n_ep; e++) {
+                double mx = 0;
+                for (uint32_t st = 0; st < var.n_strands; st++) {
+                    const double x = e < ep[st].size() ? ep[st][e] : 0.0;
+                    var.work += x;
+                    mx = std::max(mx, x);
+                }
+                var.crit += mx;
+            }
+        }
         const double heaviest = *std::max_element(load.begin(), load.end());
         var.prio_mask = 0;
         for (uint32_t st = 0; st < var.n_strands && st < 32; st++)
@@ -1526,8 +1573,9 @@ struct cw_batch {
     // where they run - bench.py's roofline figures): 0 run begins | 1 inputs ingested | 2 evaluation done | 3 check begins | 4 check done
     bool timing = false;
     hipEvent_t tev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool tset[5] = {false, false, false, false, false};     // recorded since timing was switched on (an event never recorded "queries" fine)
 };
-#define TMARK(b, k) do { if ((b)->timing) hipEventRecord((b)->tev[k], (b)->stream); } while (0)
+#define TMARK(b, k) do { if ((b)->timing) { hipEventRecord((b)->tev[k], (b)->stream); (b)->tset[k] = true; } } while (0)
 
 template <typename T>
 static hipError_t upload(T **dst, const std::vector<T> &src, hipStream_t s) {
@@ -1634,9 +1682,17 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
     {
         uint64_t groups = (batch + 63) / 64;
         const Variant *best = nullptr;
+        double work1 = 0;                              // circuits with functions: the single strand's time (any variant's work is the same rows)
+        for (auto &v : c->variants)
+            if (!v.kind && v.work > 0 && (work1 == 0 || v.n_strands == 1)) work1 = v.work;
         for (auto &v : c->variants) {
             if (v.kind) continue;
             if (groups * v.n_strands > 8192 && v.n_strands > 1) continue;
+            if (v.n_strands > 1 && v.crit > 0 && work1 < 2.0 * v.crit && !getenv("CW_STRANDS")) {
+                bool have1 = false;
+                for (auto &u : c->variants) have1 |= !u.kind && u.n_strands == 1;
+                if (have1) continue;                   // its strands mostly wait for one chain (a call): no shorter than one strand
+            }
             if (!best || v.n_active > best->n_active || (v.n_active == best->n_active && v.n_strands < best->n_strands))
                 best = &v;
         }
@@ -2609,6 +2665,7 @@ extern "C" int cw_batch_set_timing(cw_batch *b, int on) {
         for (hipEvent_t &e : b->tev)
             if (!e) HIPCHK(hipEventCreate(&e));
     b->timing = on != 0;
+    for (bool &x : b->tset) x = false;
     return CW_OK;
 }
 
@@ -2623,7 +2680,7 @@ extern "C" int cw_batch_kernel_ms(cw_batch *b, float ms[3]) {
     const int pairs[3][2] = {{0, 1}, {1, 2}, {3, 4}};
     for (int k = 0; k < 3; k++) {
         ms[k] = -1.0f;
-        if (hipEventQuery(b->tev[pairs[k][0]]) == hipSuccess && hipEventQuery(b->tev[pairs[k][1]]) == hipSuccess) {
+        if (b->tset[pairs[k][0]] && b->tset[pairs[k][1]]) {
             float t = 0;
             if (hipEventElapsedTime(&t, b->tev[pairs[k][0]], b->tev[pairs[k][1]]) == hipSuccess) ms[k] = t;
         }

@@ -168,11 +168,12 @@ def test_full_size_verifier_on_the_oracle():
 
 
 @pytest.mark.gpu
-def test_gpu_toy_verifier_with_interpreted_functions(tmp_path):
+def test_gpu_toy_verifier_with_interpreted_functions(tmp_path, monkeypatch):
     """a 16-bit prime is outside the device's field code: the function bodies run in the per-lane interpreter (run-time loops,
-    run-time indexed limbs, divergent lanes)"""
+    run-time indexed limbs, divergent lanes) - on one strand (what cw_batch_create picks: the calls are one serial chain, more
+    strands would only wait) and, forced, on 16 strands (calls as heavy units between FULL barriers, D_BITS rows)"""
     from circom_amd import runtime as rt
-    cp = compile_program(Program(S.ECDSAVerifyNoPubkeyCheck(TN, TK, TOY, 4), prime="bls12381"), str(tmp_path), "ecdsa_toy", sym=False, strands=(1,))
+    cp = compile_program(Program(S.ECDSAVerifyNoPubkeyCheck(TN, TK, TOY, 4), prime="bls12381"), str(tmp_path), "ecdsa_toy", sym=False, strands=(1, 16))
     assert all(f[2] is None for f in cp.tape.functions)
     c = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
     rnd = random.Random(6)
@@ -180,14 +181,24 @@ def test_gpu_toy_verifier_with_interpreted_functions(tmp_path):
     rows = [S.sign(TOY, TN, TK, rnd) for _ in range(B)]
     for i in range(0, B, 7):
         rows[i][2 * TK] ^= 1                                      # invalid signatures among them
-    b = c.batch(B)
-    b.set_inputs(rows)
-    b.run(); b.check_r1cs(); b.sync()
-    assert (b.status() == 0).all()
-    for i in (0, 1, 7, 50, 95):
-        sig, failed = _eval(cp.flat, rows[i])
-        assert failed is None and b.witness(i) == sig and sig[1] == (0 if i % 7 == 0 else 1)
-    b.close(); c.close()
+    seen = []
+    for want in (None, 16, 1):
+        if want is None:
+            monkeypatch.delenv("CW_STRANDS", raising=False)
+        else:
+            monkeypatch.setenv("CW_STRANDS", str(want))
+        b = c.batch(B)
+        assert want is None or b.strands == want
+        seen.append(b.strands)
+        b.set_inputs(rows)
+        b.run(); b.check_r1cs(); b.sync()
+        assert (b.status() == 0).all()
+        for i in (0, 1, 7, 50, 95):
+            sig, failed = _eval(cp.flat, rows[i])
+            assert failed is None and b.witness(i) == sig and sig[1] == (0 if i % 7 == 0 else 1)
+        b.close()
+    assert set(seen) == {1, 16}
+    c.close()
 
 
 @pytest.mark.gpu
