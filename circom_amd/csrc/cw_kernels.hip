@@ -473,16 +473,9 @@ cw_eval_kernel(const CwDRow *__restrict__ rows, const uint32_t *__restrict__ str
     // The idle lanes are masked off for the whole kernel; every wave still reaches every barrier.
     // the strand(s) that carry the longest share of the schedule (the serial S-box chain of Poseidon) win the issue
     // arbitration of their SIMD against the waves of other workgroups: measured 1.03 -> 0.94 ms on Poseidon(2) x 65 536
-    if (prio_mask & 0x80000000u) {
-        // by AGE: the SIMD's arbiter serves its oldest wave first, so of the four strands that share a SIMD (hardware waves w,
-        // w + 4, w + 8, w + 12 of a 16-strand workgroup) the youngest arrives last at almost every barrier (profiles/
-        // r05e_ecdsa_verify_16strands_per_operator_clocks.log: strands 12-15 are the last to arrive in 74 % of the levels although
-        // the loads are balanced) - the younger the wave, the higher its priority
-        const uint32_t age = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
-        if (age == 1) __builtin_amdgcn_s_setprio(1);
-        else if (age == 2) __builtin_amdgcn_s_setprio(2);
-        else if (age >= 3) __builtin_amdgcn_s_setprio(3);
-    } else if ((prio_mask >> wave) & 1u) __builtin_amdgcn_s_setprio(3);
+    // (round 5: priority by wave AGE - the youngest of the four waves that share a SIMD arrives last at 74 % of the barriers of the
+    // ECDSA verifier's levels - was measured: 294.6 / 298.1 ms against 294.2 / 296.1, no effect; removed)
+    if ((prio_mask >> wave) & 1u) __builtin_amdgcn_s_setprio(3);
     if (lane < lanes) {
     const uint32_t i = blockIdx.x * lanes + lane;                  // < Bp (Bp is a multiple of 256 >= batch)
     EvalCtx c;
