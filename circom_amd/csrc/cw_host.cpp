@@ -277,6 +277,7 @@ struct cw_circuit {
     // r1cs (CSR)
     uint32_t n_constraints = 0;
     std::vector<uint32_t> r_ptr, r_slot, r_coef, r_ctab, r_orig;
+    std::vector<uint8_t> r_bool;           // per row in processing order: the row is b * (b -+ 1) = 0 (cw_r1cs_plan.h T_BOOL)
     // circom functions with run-time control flow (D_CALL): concatenated bytecode + per function {first ins, n ins, n regs}
     std::vector<uint32_t> fn_code, fn_tab;
     // bit-plane program (cw_bits.hip) when every signal of the circuit is provably boolean for 0/1 inputs
@@ -1353,6 +1354,8 @@ static int load_r1cs(cw_circuit *c, const char *path) {
     n_coef.reserve(c->r_coef.size());
     n_cc.reserve(c->r_cc.size());
     c->r_orig.resize(n_cons);
+    c->r_bool.clear();
+    c->r_bool.reserve(n_cons);
     for (uint32_t j = 0; j < n_cons; j++) {
         uint32_t k = (uint32_t)key[j];
         for (int part = 0; part < 3; part++) {
@@ -1367,6 +1370,27 @@ static int load_r1cs(cw_circuit *c, const char *path) {
         bool eq2 = (a0 == a1) && (a1 == b1) && (c1 - b1 == 2) &&
                    ((c->r_coef[b1] == 0 && c->r_coef[b1 + 1] == 1) || (c->r_coef[b1] == 1 && c->r_coef[b1 + 1] == 0));
         c->r_orig[j] = k | (eq2 ? 0x80000000u : 0u);
+        // b * (b - 1) = 0 / b * (1 - b) = 0 (either order of the factors, C empty): the stream plan checks "b is 0 or 1" directly
+        {
+            auto single = [&](uint32_t lo, uint32_t hi, uint32_t &w) {
+                if (hi - lo != 1 || c->r_coef[lo] != 0 || c->r_slot[lo] == 0) return false;
+                w = c->r_slot[lo];
+                return true;
+            };
+            auto minus_one = [&](uint32_t lo, uint32_t hi, uint32_t w) {       // {1: -1, w: +1} or {1: +1, w: -1}, any order
+                if (hi - lo != 2) return false;
+                for (int sw = 0; sw < 2; sw++) {
+                    const uint32_t tc = lo + sw, tw = lo + 1 - sw;
+                    if (c->r_slot[tc] == 0 && c->r_slot[tw] == w &&
+                        ((c->r_coef[tc] == 1 && c->r_coef[tw] == 0) || (c->r_coef[tc] == 0 && c->r_coef[tw] == 1)))
+                        return true;
+                }
+                return false;
+            };
+            uint32_t w = 0;
+            const bool isbool = c1 == b1 && ((single(a0, a1, w) && minus_one(a1, b1, w)) || (single(a1, b1, w) && minus_one(a0, a1, w)));
+            c->r_bool.push_back(isbool ? 1 : 0);
+        }
     }
     c->r_ptr.swap(n_ptr);
     c->r_slot.swap(n_slot);
@@ -1991,7 +2015,8 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
             uint32_t tpc = 192;
             if (const char *e = getenv("CW_R1CS_TERMS")) tpc = (uint32_t)std::max(8, atoi(e));
             const bool audit = getenv("CW_R1CS_AUDIT") != nullptr;
-            p = cwplan::build_stream(c->r_ptr, c->r_slot, c->r_coef, c->r_orig, tpc, b->fp_fn && !audit ? b->fp_covered : nullptr);
+            p = cwplan::build_stream(c->r_ptr, c->r_slot, c->r_coef, c->r_orig, tpc, b->fp_fn && !audit ? b->fp_covered : nullptr,
+                                     getenv("CW_R1CS_NO_BOOL") ? nullptr : &c->r_bool);
         }
         if (p.chunk.empty()) p.chunk.assign(4, 0);                   // every row is checked by the emitted code: nothing to stream
         if (p.row_orig.empty()) p.row_orig.assign(1, 0);

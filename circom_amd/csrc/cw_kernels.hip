@@ -814,7 +814,11 @@ __device__ __forceinline__ void r1_term(const fe &wv, uint32_t w0, uint32_t ci, 
                                         const uint32_t *__restrict__ row_orig, const FpParams &P) {
     const uint32_t acc = (w0 >> 27) & 3u, endk = (w0 >> 29) & 3u;
     bool ok = true;
-    if (endk == 3) ok = fe_eq(s.cur, wv);                           // second wire of a pure equality row: x == y
+    if (w0 & (1u << 26)) {                                          // (cwplan::T_BOOL) the row b * (b - 1) = 0: b is 0 or 1
+        fe one_ = fe_small(1);
+        if (MONT) { FE_UNROLL for (int k = 0; k < 8; k++) one_.v[k] = P.one_m[k]; }
+        ok = fe_is_zero(wv) | fe_eq(wv, one_);
+    } else if (endk == 3) ok = fe_eq(s.cur, wv);                    // second wire of a pure equality row: x == y
     else if (acc == 3) s.cur = wv;                                  // its first wire
     else {
         fe w = wv;

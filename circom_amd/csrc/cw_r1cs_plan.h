@@ -36,6 +36,10 @@ constexpr uint32_t SLOT_MASK = (1u << SLOT_BITS) - 1;
 constexpr uint32_t T_ACC_SH = 27, T_END_SH = 29;
 constexpr uint32_t END_QUAD = 1, END_LIN = 2, END_EQ2 = 3, ACC_EQ2 = 3;
 constexpr uint32_t COEF_CONST = 0x80000000u, T_PART_END = 0x80000000u;
+// stream plan only: bit 26 of word 0 = the whole row is b * (b - 1) = 0 (or b * (1 - b) = 0): ONE term naming b, which must be 0 or 1 -
+// one wire read and a comparison instead of three terms and a product.  (Num2Bits writes one such row per bit: 2.3 M of the 2.49 M
+// rows of the ECDSA verifier.)
+constexpr uint32_t T_BOOL = 1u << 26;
 
 struct Plan {
     uint32_t entries = 0, n_chunks = 0;
@@ -181,7 +185,7 @@ inline Plan build(const std::vector<uint32_t> &ptr, const std::vector<uint32_t> 
 // skip: optional bitmap over the constraints' indices in the .r1cs file - rows the emitted evaluation code has already checked
 inline Plan build_stream(const std::vector<uint32_t> &ptr, const std::vector<uint32_t> &slot,
                          const std::vector<uint32_t> &coef, const std::vector<uint32_t> &orig, uint32_t terms_per_chunk,
-                         const std::vector<uint32_t> *skip = nullptr) {
+                         const std::vector<uint32_t> *skip = nullptr, const std::vector<uint8_t> *boolrow = nullptr) {
     Plan p;
     const uint32_t n_rows = (uint32_t)(ptr.size() / 3);
     uint32_t chunk_t0 = 0, chunk_row0 = 0;
@@ -194,6 +198,12 @@ inline Plan build_stream(const std::vector<uint32_t> &ptr, const std::vector<uin
         }
         const bool lin = (pa == pb) || (pb == pc);
         const bool eq2 = (orig[row] >> 31) != 0;
+        if (boolrow && row < boolrow->size() && (*boolrow)[row]) {
+            // (the loader recognised the row: one of A / B is the single term +b, the other is b - 1 or 1 - b, C is empty)
+            const uint32_t bslot = slot[(pb - pa == 1) ? pa : pb];
+            p.terms.push_back(bslot | T_BOOL | (END_QUAD << T_END_SH) | T_PART_END);
+            p.terms.push_back(0);
+        } else
         for (uint32_t t = pa; t < pe; t++) {
             uint32_t part = t < pb ? 0 : (t < pc ? 1 : 2), endk = 0;
             if (t + 1 == pe) endk = eq2 ? END_EQ2 : (lin ? END_LIN : END_QUAD);
