@@ -297,6 +297,61 @@ def test_r1cs_check_reports_the_first_violated_row_per_instance(tmp_path, mode, 
     b.close(); c.close()
 
 
+@template
+def LooseBits(c, n):
+    # out[k] is meant to be bit k of `a`, but the witness code of bit (b mod n) copies a whole 3-bit field instead: the boolean rows
+    # out[k] * (out[k] - 1) = 0 (what Num2Bits writes per bit) are the only thing that can notice; written in all four shapes
+    a = c.input("a")
+    b = c.input("b")
+    out = c.output("out", n)
+    for k in range(n):
+        wrong = (b % n).eq(k)
+        c.hint(out[k], ((a >> k) & 1) + wrong * ((a >> k) & 6))
+        if k % 4 == 0:
+            c.enforce(out[k] * (out[k] - 1), 0, runtime_check=False)
+        elif k % 4 == 1:
+            c.enforce((out[k] - 1) * out[k], 0, runtime_check=False)
+        elif k % 4 == 2:
+            c.enforce(out[k] * (1 - out[k]), 0, runtime_check=False)
+        else:
+            c.enforce((1 - out[k]) * out[k], 0, runtime_check=False)
+
+
+@pytest.mark.parametrize("mont", [False, True])
+def test_r1cs_check_boolean_rows(tmp_path, mont, monkeypatch):
+    """b * (b - 1) = 0 rows are checked as "b is 0 or 1" (one wire read, cw_r1cs_plan.h T_BOOL) on canonical and on
+    Montgomery-form tables: the first violated row of every instance is the oracle's, and the general path
+    (CW_R1CS_NO_BOOL=1) reports the same"""
+    monkeypatch.setenv("CW_MONT", "1" if mont else "0")
+    monkeypatch.setenv("CW_R1CS_TERMS", "24")
+    n = 37
+    cp, c = _compile(tmp_path, Program(LooseBits(n)), "loosebits%d" % mont)
+    assert c.montgomery == mont
+    B = 200
+    ins = [[(i * 2654435761) % (1 << 40), i] for i in range(B)]
+    seen = []
+    for general in (False, True):
+        if general:
+            monkeypatch.setenv("CW_R1CS_NO_BOOL", "1")
+        b = c.batch(B)
+        b.set_inputs(ins)
+        b.run(); b.check_r1cs(); b.sync()
+        st, fb = b.status(), b.r1cs_first_bad()
+        n_bad = 0
+        for i in range(B):
+            w = b.witness(i)
+            want = check_r1cs(c.q, cp.flat.constraints, w)
+            assert bool(st[i] & rt.ST_R1CS_FAILED) == (want is not None), i
+            if want is not None:
+                assert fb[i] == want, (i, fb[i], want)
+                n_bad += 1
+        assert 0 < n_bad < B
+        seen.append((st.tolist(), fb.tolist()))
+        b.close()
+    assert seen[0] == seen[1]
+    c.close()
+
+
 def test_run_refuses_missing_inputs(tmp_path):
     cp, c = _compile(tmp_path, Program(Multiplier2()), "m2")
     b = c.batch(2)
