@@ -917,6 +917,10 @@ static int load_tape(cw_circuit *c, const char *path) {
                 }
             }
             var.wide_linsum = lin_terms * 4 > (size_t)nrows;        // more than a quarter of a term per row on average
+            // schedules of circuits with run-time functions are interpreted on 16 strands, where every term of a sum is a dependent
+            // table read: four in flight instead of two took the ECDSA verifier from 293 to 245 ms per launch
+            if (!c->fn_tab.empty()) var.wide_linsum = true;
+            if (const char *e = getenv("CW_WIDE_LINSUM")) var.wide_linsum = atoi(e) != 0;     // (experiments)
         }
         if (var.extra_off[var.n_strands] + 4 != nextras) return fail(CW_EIO, "tape variant: bad extra offsets");
         if (var.stream_off[var.n_strands] != nrows) return fail(CW_EIO, "tape variant: bad stream offsets");
