@@ -455,7 +455,14 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
     if audit and not (fuse_check and fc.constraints and audit_of.check_complete):
         return None
     if fuse_check and fc.constraints:
-        G, viol, cst = build_check(net, fc)
+        # (the audit program of the same network - lower_jit(audit_of=) right after the main one - reuses the gates of the check:
+        # building them is a quarter of the lowering of the 1M-constraint SHA-256)
+        cached = getattr(net, "_check_cache", None)
+        if cached is not None and cached[0] is fc:
+            G, viol, cst = cached[1]
+        else:
+            G, viol, cst = build_check(net, fc)
+            net._check_cache = (fc, (G, viol, cst))
     else:
         G, viol, cst = _Gates(n_eval), [], {"trivial": 0, "lut": 0, "int": 0, "unchecked": len(fc.constraints)}
     TT = list(net.tt) + G.tt
