@@ -58,33 +58,55 @@ __global__ void __launch_bounds__(256) cw_bits_init_kernel(uint64_t *T, uint64_t
 }
 
 // ---- ingest: AoS canonical inputs [batch][n_in][32 B] -> one mask per (group, input) -----------------------------------
-// (setInputSignal's `signalValues[si] = val`, calcwit.cpp:93, for 64 instances at a time).  A wave handles 64 inputs
-// of one group: lane k owns input k0 + k and walks the 64 instances of the group, so every load instruction reads
-// 2 KiB contiguous (64 consecutive inputs of one instance) and the lane shifts the value's low bit into its own mask;
-// the 64 masks leave as one coalesced 512-byte store.  Values other than 0/1 flag their instance.
-__global__ void __launch_bounds__(64) cw_bits_ingest_kernel(const uint4 *__restrict__ in, uint64_t *__restrict__ T,
-                                                             uint64_t slots, uint32_t sh, uint32_t input_slot0, uint32_t n_in,
-                                                             uint32_t batch, uint64_t *fbmask) {
-    const uint32_t lane = threadIdx.x, g = blockIdx.x, k = blockIdx.y * 64 + lane;
-    const bool have = k < n_in;
+// (setInputSignal's `signalValues[si] = val`, calcwit.cpp:93, for 64 instances at a time).  A workgroup of four waves handles
+// 256 consecutive inputs of one group: thread t owns input c * 256 + t and walks the 64 instances of the group, so every pair
+// of load instructions of a wave reads 2 KiB contiguous, the workgroup 8 KiB of one instance's 32 n_in-byte record; the thread
+// shifts the value's low bit into its own mask and keeps its own "not a bit" mask (values other than 0/1 flag their instance:
+// one atomicOr per offending thread, none in the loop); a wave's 64 masks leave as one store instruction.
+// Order matters more than the loop body (tools/ubench_ingest.hip, profiles/r05n_ubench_ingest*.txt, 137 GB of inputs; a
+// read-only uint4 sum of the same buffer reaches 6.45 TB/s on the same box):
+//   one wave per workgroup, groups fastest (rounds 3-5)                        24.2 ms   5.69 TB/s
+//   the same with 4 / 8 / 16 loads in flight per wave (unrolled, lane flags)    24.3-24.5 (round 3: streaming loads 26.4; round 5:
+//                                                                               whole-line loads 24.3-24.7)
+//   chunks of one group fastest                                                 28.3 ms: the waves that run together march through
+//                                                                               the 64 KB records of their groups in step
+//   chunks fastest + every group starts at its own instance (hash(g) & 63)      23.4 ms
+//   that, four waves per workgroup on consecutive chunks, unrolled x 4          22.2 ms   6.19 TB/s   <- this kernel
+//   (two waves 22.6, eight 23.2, sixteen 23.3; unrolled x 2 22.9, x 8 22.5; no rotation 24.0-24.4)
+#define BITS_INGEST_WAVES 4
+__global__ void __launch_bounds__(64 * BITS_INGEST_WAVES)
+cw_bits_ingest_kernel(const uint4 *__restrict__ in, uint64_t *__restrict__ T, uint64_t slots, uint32_t sh, uint32_t input_slot0, uint32_t n_in,
+                      uint32_t batch, uint64_t *fbmask, uint32_t n_chunks) {
+    const uint32_t c = blockIdx.x % n_chunks, g = blockIdx.x / n_chunks;
+    const uint32_t k = c * (64 * BITS_INGEST_WAVES) + threadIdx.x;
+    if (k >= n_in) return;                                           // no cross-lane operation below
     const uint32_t i0 = g * 64, ni = min(64u, batch - i0);
-    uint64_t mine = 0, badmask = 0;
-    // (four instances in flight per wave with streaming loads were measured SLOWER: 26.4 ms against 24.4 ms for the 137 GB image
-    // of 2 M instances of Sha256(2048) - 5.2 against 5.6 TB/s; round 5: whole-line loads - lane l reads the l-th 16-byte piece of
-    // a 1 KiB run, even lanes the lower halves - change nothing: 24.3 / 24.7 ms against 24.5 / 24.7, profiles/r05g_*)
-    for (uint32_t ii = 0; ii < ni; ii++) {
-        uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
-        if (have) {
-            const size_t src = ((size_t)(i0 + ii) * n_in + k) * 2;
-            lo = in[src];
-            hi = in[src + 1];
+    uint64_t mine = 0, bad = 0;
+    const uint4 *base = in + ((size_t)i0 * n_in + k) * 2;
+    const size_t step = (size_t)n_in * 2;
+    if (ni == 64) {
+        const uint32_t r = (g * 0x9E3779B1u) >> 26;                  // the group's first instance
+#pragma unroll 4
+        for (uint32_t ii = 0; ii < 64; ii++) {
+            const uint32_t inst = (ii + r) & 63u;
+            const uint4 *p = base + inst * step;
+            const uint4 lo = p[0], hi = p[1];
+            const uint32_t rest = lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w;
+            mine |= (uint64_t)(lo.x & 1u) << inst;
+            bad |= (uint64_t)((lo.x > 1u) | (rest != 0u)) << inst;
         }
-        const bool isbit = (lo.x <= 1u) & ((lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) == 0u);
-        mine |= (uint64_t)(lo.x & 1u) << ii;
-        if (__any(!isbit)) badmask |= 1ull << ii;                   // wave-uniform
+    } else {
+        const uint4 *p = base;
+        for (uint32_t ii = 0; ii < ni; ii++) {
+            const uint4 lo = p[0], hi = p[1];
+            p += step;
+            const uint32_t rest = lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w;
+            mine |= (uint64_t)(lo.x & 1u) << ii;
+            bad |= (uint64_t)((lo.x > 1u) | (rest != 0u)) << ii;
+        }
     }
-    if (have) bits_group(T, slots, sh, g)[(size_t)(input_slot0 + k) << sh] = mine;
-    if (lane == 0 && badmask) atomicOr((unsigned long long *)&fbmask[g], (unsigned long long)badmask);
+    bits_group(T, slots, sh, g)[(size_t)(input_slot0 + k) << sh] = mine;
+    if (bad) atomicOr((unsigned long long *)&fbmask[g], (unsigned long long)bad);
 }
 
 // ---- the gate program ------------------------------------------------------------------------------------------------------
@@ -730,11 +752,12 @@ hipError_t cwk_bits_init(hipStream_t s, void *T, uint64_t slots, uint32_t sh, ui
 }
 hipError_t cwk_bits_ingest(hipStream_t s, const void *in, void *T, uint64_t slots, uint32_t sh, uint32_t input_slot0, uint32_t n_in,
                            uint32_t batch, void *fbmask) {
-    if (n_in == 0) return hipSuccess;
-    dim3 g((batch + 63) / 64, (n_in + 63) / 64);
-    if (g.y > 65535u) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(cw_bits_ingest_kernel, g, dim3(64), 0, s, (const uint4 *)in, (uint64_t *)T, slots, sh, input_slot0, n_in,
-                       batch, (uint64_t *)fbmask);
+    if (n_in == 0 || batch == 0) return hipSuccess;
+    const uint32_t per = 64 * BITS_INGEST_WAVES, n_chunks = (n_in + per - 1) / per;
+    const uint64_t blocks = (uint64_t)((batch + 63) / 64) * n_chunks;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(cw_bits_ingest_kernel, dim3((uint32_t)blocks), dim3(per), 0, s, (const uint4 *)in, (uint64_t *)T, slots, sh, input_slot0, n_in,
+                       batch, (uint64_t *)fbmask, n_chunks);
     return hipGetLastError();
 }
 hipError_t cwk_bits_eval(hipStream_t s, const void *recs, const uint32_t *cmds, uint32_t n_batches, uint32_t ring, uint32_t cache,

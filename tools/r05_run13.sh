@@ -1,0 +1,16 @@
+# round 5, GPU call 13: the ingest kernel with rotated group starts / four waves per workgroup (tools/ubench_ingest.hip) in the library:
+# the whole GPU suite, smoke, the default line, rocprofv3 trace + PMC passes of the default command, config 2's line
+set -x
+export TMPDIR=/tmp
+R=$PWD
+mkdir -p gpurun_out
+(time timeout 1400 python -m pytest tests -m gpu -q --durations=12) > gpurun_out/r05n_gpu_suite.log 2>&1
+tail -20 gpurun_out/r05n_gpu_suite.log
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r05n_smoke.log 2>&1; tail -2 gpurun_out/r05n_smoke.log
+(time python bench.py) > gpurun_out/r05n_bench_sha256_2048_2M.json 2> gpurun_out/r05n_default.err; tail -4 gpurun_out/r05n_default.err
+rm -f gpurun_out/traffic.json
+bash tools/profile.sh r05n_sha256_2048_2M sha256_2048:2097152 2>&1 | tail -30
+python bench.py --workload sha256_512 --batch 4096 --steps 20 --warmup 3 > gpurun_out/r05n_bench_sha256_512_4096.json 2>/dev/null
+for f in gpurun_out/r05n_bench_*.json; do tail -1 $f | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('$f', '%.5g' % d['value'], d['ms_per_step'], d['isolated'].get('kernels_ms'), d.get('in_step_kernels_ms'), d['roofline'].get('frac'), d['roofline'].get('traffic'), (d.get('parity') or {}).get('parity_checked'), (d.get('cpu_baseline') or {}).get('value'), d['config'].get('compile_cached'))"; done
