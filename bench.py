@@ -1203,7 +1203,10 @@ def main():
                 b1.run(); b1.check_r1cs(); b1.sync()
                 assert (b1.status() == 0).all()
                 row_bytes = len(w2s) * 32
-                chunk = max(1, min(B, (1 << 30) // row_bytes))
+                # launches of >= 8 groups of 64 instances let the egress kernel walk the groups fastest (cw_bits.hip,
+                # tools/ubench_egress.hip: 4.8 -> 5.2-5.8 TB/s); two buffers of up to 6 GiB, whole groups
+                chunk = (6 << 30) // row_bytes
+                chunk = max(1, min(B, chunk // 64 * 64 if chunk >= 64 else chunk))
                 bufs = [torch.empty((chunk, len(w2s), 32), dtype=torch.uint8, device=dev) for _ in range(2)]
                 seen = [0]
 
@@ -1233,7 +1236,7 @@ def main():
                     "egress_ms": e_ms, "egress_wall_ms": wall_ms, "GB/s": B * row_bytes / (e_ms * 1e-3) / 1e9,
                     "frac_of_hbm_peak": B * row_bytes / (e_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "chunk_instances": chunk,
                     "is": "the reference's default-level (--O1) witness as 32-byte elements for the WHOLE batch, written chunk by chunk "
-                          "into two rotating 1 GiB device buffers (cw_stream_witnesses_device); witnesses_per_s = the step plus this egress"}
+                          "into two rotating device buffers of chunk_instances each (cw_stream_witnesses_device); witnesses_per_s = the step plus this egress"}
                 b1.close()
             except Exception as ex:                                   # noqa: BLE001  (a report, never a reason to fail the line)
                 out["value_canonical_O1"] = {"error": repr(ex)[:300]}

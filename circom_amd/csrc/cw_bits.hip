@@ -425,18 +425,25 @@ cw_bits_assert_kernel(const uint64_t *__restrict__ T, uint64_t slots, const uint
 }
 
 // ---- egress: canonical 32-byte values from the bit table (getWitness + Fr_toLongNormal, main.cpp:326-332) ----------------
-// out[j][k] (32 bytes) = value of witness element k in instance first + j.  The kernel is a pure HBM writer: a wave owns 32
-// consecutive elements and walks 64 instances; lane l holds the mask of element k0 + l / 2 (ONE 8-byte read per 2 KiB
-// written, through wslot = sig_slot o w2s composed on the host) and every store instruction writes the 1 KiB that 32
+// out[j][k] (32 bytes) = value of witness element k in instance first + j.  The kernel is a pure HBM writer: a wave owns
+// 32 * BITS_GATHER_RUN consecutive elements and walks 64 instances; lane l holds the mask of element k0 + l / 2 (ONE 8-byte read
+// per 2 KiB written, through wslot = sig_slot o w2s composed on the host) and every store instruction writes the 1 KiB that 32
 // elements of one instance occupy (global_store_dwordx4, consecutive lanes -> consecutive 16-byte halves).  Round 2's
 // kernel ran one thread per element with two dependent index loads per 32 bytes: 0.53 of the HBM peak.
-#define BITS_GATHER_RUN 4      // consecutive 1 KiB pieces (32 elements each) a wave writes per instance: 4 KiB runs, 16 KiB per block
+// Round 5 (tools/ubench_egress.hip on the --O1 witness of the default line, 156 809 wires, profiles/r05n_ubench_egress*.txt; a
+// one-pass 16-byte fill of the same buffers writes 6.9 TB/s, hipMemsetAsync 6.7): streaming (nt) stores 4.29 TB/s -> plain
+// stores 4.7 - 4.8; 8 KiB instead of 4 KiB runs per wave 4.8 - 4.9; with 8 or more groups of 64 instances per launch the grid
+// walks the GROUPS fastest (the workgroups that run together then write the same elements of different instances): 5.1 - 5.8
+// for launches of 1 024 instances, 5.4 - 5.5 for 2 048 (elements fastest: 4.5 - 4.9); a sweep in pure address order (one
+// instance per workgroup, the mask words re-read from L2) 3.0, rotated starts 4.2 - 5.1, other workgroup sizes 4.6 - 4.8.
+#define BITS_GATHER_RUN 8      // consecutive 1 KiB pieces (32 elements each) a wave writes per instance: 8 KiB runs, 32 KiB per block
 __global__ void __launch_bounds__(256)
 cw_bits_gather_kernel(const uint64_t *__restrict__ T, uint64_t slots, uint32_t lsh, const uint32_t *__restrict__ wslot, uint32_t n_wit,
-                      uint32_t first, uint32_t count, uint4 *__restrict__ out) {
+                      uint32_t first, uint32_t count, uint4 *__restrict__ out, uint32_t groups_fastest) {
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t k0 = (blockIdx.x * 4 + wv) * 32 * BITS_GATHER_RUN;        // this wave's elements
-    const uint32_t j0 = blockIdx.y * 64;                                     // its 64 output instances
+    const uint32_t bk = groups_fastest ? blockIdx.y : blockIdx.x, bj = groups_fastest ? blockIdx.x : blockIdx.y;
+    const uint32_t k0 = (bk * 4 + wv) * 32 * BITS_GATHER_RUN;               // this wave's elements
+    const uint32_t j0 = bj * 64;                                             // its 64 output instances
     if (k0 >= n_wit) return;
     const uint32_t i0 = first + j0, g = i0 >> 6, sh = i0 & 63u;
     const bool two = sh && (uint64_t)(i0 + 64 - sh) < (uint64_t)first + count;
@@ -460,10 +467,7 @@ cw_bits_gather_kernel(const uint64_t *__restrict__ T, uint64_t slots, uint32_t l
 #pragma unroll
         for (int r = 0; r < BITS_GATHER_RUN; r++) {
             const uint32_t bit = low_half ? (uint32_t)(win[r] >> jj) & 1u : 0u;
-            if (have[r]) {
-                const u32x4 v = {bit, 0u, 0u, 0u};
-                __builtin_nontemporal_store(v, (u32x4 *)(o + r * 64));
-            }
+            if (have[r]) o[r * 64] = make_uint4(bit, 0u, 0u, 0u);
         }
         o += (size_t)n_wit * 2;
     }
@@ -777,10 +781,12 @@ hipError_t cwk_bits_eval(hipStream_t s, const void *recs, const uint32_t *cmds, 
 hipError_t cwk_bits_gather(hipStream_t s, const void *T, uint64_t slots, uint32_t sh, const uint32_t *wslot, uint32_t n_wit, uint32_t first,
                            uint32_t count, void *out) {
     if (!count || !n_wit) return hipSuccess;
+    const uint32_t kblocks = (n_wit + 128 * BITS_GATHER_RUN - 1) / (128 * BITS_GATHER_RUN);
     for (uint32_t done = 0; done < count; done += 65535u * 64u) {       // grid.y limit
-        const uint32_t n = count - done < 65535u * 64u ? count - done : 65535u * 64u;
-        hipLaunchKernelGGL(cw_bits_gather_kernel, dim3((n_wit + 128 * BITS_GATHER_RUN - 1) / (128 * BITS_GATHER_RUN), (n + 63) / 64), dim3(256), 0, s, (const uint64_t *)T, slots, sh,
-                           wslot, n_wit, first + done, n, (uint4 *)out + (size_t)done * n_wit * 2);
+        const uint32_t n = count - done < 65535u * 64u ? count - done : 65535u * 64u, groups = (n + 63) / 64;
+        const uint32_t gf = groups >= 8 && kblocks <= 65535u;           // see the kernel's comment
+        hipLaunchKernelGGL(cw_bits_gather_kernel, gf ? dim3(groups, kblocks) : dim3(kblocks, groups), dim3(256), 0, s, (const uint64_t *)T, slots,
+                           sh, wslot, n_wit, first + done, n, (uint4 *)out + (size_t)done * n_wit * 2, gf);
     }
     return hipGetLastError();
 }

@@ -432,6 +432,46 @@ def test_gpu_bitplane_matches_oracle_on_every_instance(tmp_path, engine):
 
 
 @pytest.mark.gpu
+def test_gpu_ingest_and_egress_orders_at_many_groups(tmp_path, engine):
+    """round 5's memory orders: the 32-byte ingest walks full groups from a per-group rotated first instance (four waves on
+    consecutive 256-input chunks; 384 inputs = a full and a half chunk; the ragged last group takes the plain loop), the egress
+    walks the GROUPS fastest from 8 groups per launch on (18 here; 3 205 witness elements = three full element blocks and a
+    ragged one).  Every instance against the oracle, unaligned windows against the bulk image, the per-instance path (one
+    group per launch: elements fastest) against both."""
+    cp, c = _gpu(tmp_path, Program(BitGadget(128)), "bg128")
+    fc = cp.flat
+    B = 1100
+    rows = _rand_bits(fc, B, 21)
+    rows[700][5] = 2                                           # not a bit, in a full group: flagged by its own lane, re-run wide
+    rows[1099][383] = c.q - 1                                  # and in the ragged group, last input
+    b = c.batch(B)
+    assert b.bitmode and b.jit == (engine == "jit")
+    b.set_inputs(rows)
+    b.run(); b.check_r1cs(); b.sync()
+    st = b.status()
+    bulk = b.witnesses()
+    assert bulk.shape == (B, fc.n_signals, 32)
+    vals = bulk[:, :, :8].copy().view(np.uint64)[:, :, 0]
+    for i in range(B):
+        sig, failed = _flat(fc, rows[i])
+        if failed is not None:
+            assert st[i] & 1, i
+            continue
+        assert not (st[i] & 1), i
+        if i in (700, 1099):
+            assert [int.from_bytes(bulk[i, k].tobytes(), "little") for k in range(fc.n_signals)] == sig, i
+        else:
+            assert not bulk[i, :, 8:].any() and vals[i].tolist() == sig, i
+    for first, n in ((37, 900), (64, 576), (1, 1099), (1000, 100)):
+        assert (b.witnesses(first, n) == bulk[first:first + n]).all(), (first, n)
+    for i in (0, 63, 64, 699, 701, 1098):
+        assert b.witness(i) == vals[i].tolist()
+    pub = b.public_signals()
+    assert (pub == bulk[:, 1:1 + c.n_public]).all()
+    b.close(); c.close()
+
+
+@pytest.mark.gpu
 def test_gpu_non_boolean_inputs_are_rerun_by_the_wide_schedule(tmp_path, engine):
     cp, c = _gpu(tmp_path, Program(BitGadget(8)), "bg8")
     fc = cp.flat
