@@ -803,6 +803,36 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
 
 
 # ---- assembly text ---------------------------------------------------------------------------------------------------------
+_VOP2 = {0b1000: "v_and_b32", 0b0110: "v_xor_b32", 0b1110: "v_or_b32", 0b1001: "v_xnor_b32"}
+
+
+def gate_asm(ins) -> str:
+    """one gate ('g', dst, s0, s1, s2, table; table bit (s0 << 2 | s1 << 1 | s2); operand -1 = constant 0, -2 = constant ones).
+    The kernel is straight-line code that is FETCHED rather than cached (12.9 MB per wave for the 1 M-constraint SHA-256), so
+    bytes of code are time: a gate with one constant operand that is AND / OR / XOR / XNOR of the other two (40 % of SHA-256's
+    gates: the partial terms of Ch / Maj / the adders' carries against a known bit) takes the 4-byte VOP2 form instead of the
+    8-byte v_bitop3_b32 (-14 % code).  `tests/test_bitjit.py` evaluates the printed text against the table."""
+    _, dst, a, b, c, tt = ins
+    ops = (a, b, c)
+    var = [x for x in ops if x >= 0]
+    if len(var) == 2 and var[0] != var[1]:
+        red = 0
+        for m in range(4):
+            bits = iter(((m >> 1) & 1, m & 1))
+            full = 0
+            for pos, x in enumerate(ops):
+                v = 0 if x == -1 else 1 if x == -2 else next(bits)
+                full |= v << (2 - pos)
+            red |= ((tt >> full) & 1) << m
+        op = _VOP2.get(red)
+        if op is not None:
+            return "  %s v%d, v%d, v%d\n" % (op, dst, var[0], var[1])
+
+    def opnd(x):
+        return "0" if x == -1 else "-1" if x == -2 else "v%d" % x
+    return "  v_bitop3_b32 v%d, %s, %s, %s bitop3:0x%x\n" % (dst, opnd(a), opnd(b), opnd(c), tt)
+
+
 def to_asm(jp: JitProgram) -> str:
     """gfx950 assembly of the program.  Kernel arguments: bit table, fallback masks, R1CS flags (three pointers); one
     wave (workgroup of 64) per chunk of 2 048 instances."""
@@ -848,7 +878,7 @@ def to_asm(jp: JitProgram) -> str:
     for ins in jp.ir:
         k = ins[0]
         if k == "g":
-            add("  v_bitop3_b32 v%d, %s, %s, %s bitop3:0x%x\n" % (ins[1], opnd(ins[2]), opnd(ins[3]), opnd(ins[4]), ins[5]))
+            add(gate_asm(ins))
         elif k == "st" or k == "sta":
             off = ins[2] * ROW_BYTES
             pg = off // PAGE

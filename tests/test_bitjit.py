@@ -205,6 +205,46 @@ def test_replay_rejects_broken_programs():
         _run(jp, fc, rows)
 
 
+def _eval_gate_text(line, regs):
+    """value a printed gate line leaves in its destination, on 32-bit registers `regs` (name -> int)"""
+    tok = line.replace(",", " ").split()
+    op, dst, srcs = tok[0], tok[1], tok[2:]
+
+    def val(x):
+        return 0 if x == "0" else 0xFFFFFFFF if x == "-1" else regs[x]
+    if op == "v_bitop3_b32":
+        tt = int(srcs[3].split(":")[1], 16)
+        a, b, c = (val(x) for x in srcs[:3])
+        out = 0
+        for i in range(32):
+            idx = ((a >> i) & 1) << 2 | ((b >> i) & 1) << 1 | ((c >> i) & 1)
+            out |= ((tt >> idx) & 1) << i
+        return dst, out
+    a, b = val(srcs[0]), val(srcs[1])
+    return dst, {"v_and_b32": a & b, "v_or_b32": a | b, "v_xor_b32": a ^ b, "v_xnor_b32": ~(a ^ b) & 0xFFFFFFFF}[op]
+
+
+def test_every_printed_gate_form_computes_its_table():
+    """gate_asm prints a gate with one constant operand as a 4-byte VOP2 instruction when the remaining function is AND / OR /
+    XOR / XNOR: every table x every placement of constants / repeated registers, the printed text evaluated on random registers
+    against the table itself"""
+    r = random.Random(5)
+    regs = {"v%d" % i: r.getrandbits(32) for i in range(3, 9)}
+    short = 0
+    for tt in range(256):
+        for ops in ((3, 4, 5), (-1, 4, 5), (3, -1, 5), (3, 4, -1), (-2, 4, 5), (3, -2, 5), (3, 4, -2), (-1, -1, 5), (-2, 4, -1),
+                    (3, 3, 5), (-1, 4, 4), (3, -2, 3), (-1, -2, -1)):
+            line = BJ.gate_asm(("g", 8, ops[0], ops[1], ops[2], tt))
+            short += not line.lstrip().startswith("v_bitop3")
+            dst, got = _eval_gate_text(line, regs)
+            a, b, c = (0 if x == -1 else 0xFFFFFFFF if x == -2 else regs["v%d" % x] for x in ops)
+            want = 0
+            for i in range(32):
+                want |= ((tt >> (((a >> i) & 1) << 2 | ((b >> i) & 1) << 1 | ((c >> i) & 1))) & 1) << i
+            assert dst == "v8" and got == want, (tt, ops, line)
+    assert short > 300                                                      # 4 of 16 two-input functions x 6 placements x 16 don't-care fillings
+
+
 def test_assembly_and_tape_section(tmp_path):
     """the text assembles with the ROCm LLVM tools into a code object that names the kernel; the .cwt carries it and the
     C-ABI loader accepts it (and refuses a damaged section)"""
@@ -214,7 +254,10 @@ def test_assembly_and_tape_section(tmp_path):
     cp = compile_program(Program(BitGadget(8)), str(tmp_path), "bg8j", sym=False, strands=(1,), bits=True, jit=True)
     assert cp.jit is not None and cp.jit.code[:4] == b"\x7fELF" and BJ.KERNEL_NAME.encode() in cp.jit.code
     asm = BJ.to_asm(cp.jit)
-    assert asm.count("v_bitop3_b32") == cp.jit.stats["gates"] and "s_endpgm" in asm
+    n_acc = sum(1 for i in cp.jit.ir if i[0] == "acc")                      # `acc` rows print as v_or_b32 too
+    forms = {f: asm.count(f + " ") for f in ("v_bitop3_b32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_xnor_b32")}
+    assert sum(forms.values()) - n_acc == cp.jit.stats["gates"] and "s_endpgm" in asm
+    assert forms["v_bitop3_b32"] < cp.jit.stats["gates"]                    # some gates took the 4-byte forms (and assembled)
     c = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
     assert c.bits_info()
     c.close()
