@@ -1240,12 +1240,22 @@ def main():
                 b1.close()
             except Exception as ex:                                   # noqa: BLE001  (a report, never a reason to fail the line)
                 out["value_canonical_O1"] = {"error": repr(ex)[:300]}
-        print(json.dumps(out))
+        line = json.dumps(out)
     for b_ in batches:
         b_.close()
     circ.close()
     if dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # the ONE JSON line is the last thing on stdout: RCCL prints a version banner through C stdio, which a pipe only sees when
+        # that buffer is flushed - without this it lands BEHIND the line (seen with CW_FORCE_DIST=1, profiles/r05t_*)
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
