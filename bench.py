@@ -1244,17 +1244,22 @@ def main():
     for b_ in batches:
         b_.close()
     circ.close()
-    if dist:
-        dist.destroy_process_group()
-    if rank == 0:
-        # the ONE JSON line is the last thing on stdout: RCCL prints a version banner through C stdio, which a pipe only sees when
-        # that buffer is flushed - without this it lands BEHIND the line (seen with CW_FORCE_DIST=1, profiles/r05t_*)
+    # the ONE JSON line is the last thing on stdout: RCCL prints a version banner through C stdio, which a pipe only sees when that
+    # buffer is flushed - without this it lands BEHIND the line (seen with CW_FORCE_DIST=1, profiles/r05t_*).  Every rank empties
+    # its buffers, all meet, then rank 0 prints.
+    def flush_all():
         try:
             import ctypes
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
         sys.stdout.flush()
+    flush_all()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        flush_all()
         print(line, flush=True)
 
 
