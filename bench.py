@@ -41,6 +41,11 @@ VALU_CLK_PER_WAVE_INST = 2.0       # a SIMD-32 issues a wave64 VALU instruction 
 LONE_WAVE_CLK_PER_INST = 4.1       # ONE wave issues at most one instruction of any kind per ~4.1 clocks (tools/ubench_isa)
 BITS_VALU_PER_VROW = 10            # cw_bits_eval_kernel<64>, from the disassembly: 3 operand offsets, 2 mask expansions, 1 result
 BITS_INSTS_PER_VROW = 15           # offset, 4 v_bitop3  + 3 ds_read_b64, 1 ds_write_b64, 1 s_waitcnt
+# one Montgomery product of the 256-bit engine (fp256.hip.h fe_mmul, 9 x 29-bit limbs): 266 VALU instructions, 162 of them
+# v_mad_u64_u32; chip-wide issue rates measured by tools/ubench_isa (profiles/r03_ubench_isa.json, 8 waves per SIMD)
+FPMUL_INSTS, FPMUL_MADS = 266, 162
+MAD_U64_WAVE_INSTS_PER_S = 5.4796e11      # v_mad_u64_u32 (half rate)
+SIMPLE_VALU_WAVE_INSTS_PER_S = 9.8689e11  # v_and_b32 / v_add_u32 class (full rate)
 JIT_BATCH = 1 << 21                # the emitted bit-plane code runs one wave per 2 048 instances: 1 024 waves = one per SIMD
 DEFAULT_BATCH = {"bigmultmodp": 8192, "ecdsa_verify": 1024, "sha256_2048": JIT_BATCH, "sha256_512": 4096, "poseidon2": 65536, "semaphore20": 8192, "semaphore20p": 8192,
                  "semaphore20w": 8192}
@@ -324,6 +329,24 @@ def batch_witness_bytes(b, i, n_wit):
     wb = b.witness_bytes(i)
     assert len(wb) == n_wit * 32
     return wb
+
+
+def in_step_view(roof: dict, alg: float, peak: float, iso_ms, in_ms, runs) -> dict:
+    """VERDICT r5 #1a: the headline figures of a roofline object are those of the kernel INSIDE the timed region (mean over
+    its steps, other batches in flight beside it); the same kernel running alone stays beside them under `isolated`."""
+    if not roof or not iso_ms:
+        return roof
+    use = in_ms or iso_ms
+    roof["isolated"] = {"kernel_ms": iso_ms, "achieved": alg / (iso_ms * 1e-3) / roof.get("_scale", 1e9),
+                        "frac": alg / (iso_ms * 1e-3) / roof.get("_scale", 1e9) / peak, "is": "one step running alone on the GPU (one HIP-event pair)"}
+    roof["kernel_ms"] = use
+    roof["achieved"] = alg / (use * 1e-3) / roof.get("_scale", 1e9)
+    roof["frac"] = roof["achieved"] / peak
+    roof["in_step_ms"] = in_ms
+    roof["kernel_ms_is"] = ("mean over the %d launches of the timed region (cw_batch_kernel_ms_mean: HIP events on each batch's own stream), "
+                            "other batches in flight beside it" % runs) if in_ms else "one step alone (no in-step marks)"
+    roof.pop("_scale", None)
+    return roof
 
 
 def dominant_roofline(roof_eval, roof_r1cs, roof_ingest, gen_ms, chk_ms, jit, packed):
@@ -766,6 +789,10 @@ def main():
     for i in range(max(args.warmup, n_fl)):
         step(i)
     torch.cuda.synchronize()
+    # from here on every run of every batch keeps its own marks (cw_batch_set_timing(b, 2), a ring of 64): the kernels' durations
+    # INSIDE the timed region are averages over all its steps - what a rocprofv3 kernel trace of the region averages to
+    for b_ in batches:
+        b_.set_timing("history")
     if dist:
         dist.barrier()
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
@@ -781,10 +808,17 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    # the parts' intervals of the LAST timed step of every batch in flight (they ran beside each other)
-    in_step_k = [b_.kernel_ms() for b_ in batches[:min(n_fl, args.steps)]]
-    in_step = {k: (sum(d_[k] for d_ in in_step_k if d_[k] is not None) / max(1, sum(1 for d_ in in_step_k if d_[k] is not None)))
-               if any(d_[k] is not None for d_ in in_step_k) else None for k in ("ingest", "eval", "check")}
+    # the parts' intervals averaged over EVERY timed step (each batch in flight keeps the marks of its last 64 runs; the steps
+    # ran beside each other)
+    in_step_k = [b_.kernel_ms_mean() for b_ in batches[:min(n_fl, args.steps)]]
+    in_step, in_step_runs = {}, {}
+    for k in ("ingest", "eval", "check"):
+        tot = sum(m_[k] * n_[k] for m_, n_ in in_step_k if m_[k] is not None)
+        cnt = sum(n_[k] for m_, n_ in in_step_k if m_[k] is not None)
+        in_step[k] = tot / cnt if cnt else None
+        in_step_runs[k] = cnt
+    for b_ in batches:
+        b_.set_timing(True)                                  # the side measurements below read the LAST run again
     for b_ in batches[1:]:                                   # every batch in flight computed the same instances
         assert (b_.status() == batch.status()).all()
 
@@ -840,6 +874,41 @@ def main():
         whole_ms = e_ms * B / n_e
         egress = {"instances": n_e, "extrapolated_from": n_e if n_e < B else None, "chunk_instances": chunk, "ms": e_ms, "GB/s": e_gbs, "frac_of_hbm_peak": e_gbs / HBM_PEAK_GBS,
                   "whole_batch_ms": whole_ms, "witnesses_per_s_with_egress": B / ((step_ms + whole_ms) * 1e-3)}
+        if n_e < B and whole_ms < 40e3 and not args.no_small:
+            # VERDICT r5 #1c: no extrapolation - the image of EVERY instance of the batch is written (two rotating buffers of
+            # `chunk` instances; 2^21 instances of the 1 M-signal circuit = 68.7 TB through HBM, ~12 s)
+            del bufs
+            chunk = max(1, min(B, (4 << 30) // row_bytes))
+            bufs = [torch.empty((chunk, circ.n_witness, 32), dtype=torch.uint8, device=dev) for _ in range(2)]
+            seen_ = [0]
+
+            def count_(first, n, ptr, st):
+                seen_[0] += n
+                return 0
+            batch.stream_witnesses_device(0, min(B, 2 * chunk), chunk, bufs[0].data_ptr(), bufs[1].data_ptr(), noop)
+            torch.cuda.synchronize()
+            e0.record(streams[0])
+            batch.stream_witnesses_device(0, B, chunk, bufs[0].data_ptr(), bufs[1].data_ptr(), count_)
+            e1.record(streams[0])
+            torch.cuda.synchronize()
+            assert seen_[0] == B
+            w_ms = e0.elapsed_time(e1)
+            # the last instance of the last chunk against the per-instance egress (cw_get_witness)
+            k_last = (B - 1) % chunk
+            got_ = bufs[((B - 1) // chunk) % 2][k_last].cpu().numpy()
+            full_ = np.frombuffer(batch_witness_bytes(batch, B - 1, circ.n_witness), dtype=np.uint8).reshape(circ.n_witness, 32)
+            assert (got_ == full_).all(), "bulk egress differs from the per-instance egress"
+            w_gbs = B * row_bytes / (w_ms * 1e-3) / 1e9
+            egress.update({"sample": {"instances": n_e, "ms": e_ms, "GB/s": e_gbs}, "instances": B, "extrapolated_from": None, "chunk_instances": chunk,
+                           "ms": w_ms, "GB/s": w_gbs, "frac_of_hbm_peak": w_gbs / HBM_PEAK_GBS, "whole_batch_ms": w_ms,
+                           "bytes": float(B) * row_bytes, "witnesses_per_s_with_egress": B / ((step_ms + w_ms) * 1e-3)})
+            n_e, e_ms = min(B, chunk * 8), None
+        if e_ms is None:                                     # (the slice the overlapped run below uses, with the larger buffers)
+            e0.record(streams[0])
+            batch.stream_witnesses_device(0, n_e, chunk, bufs[0].data_ptr(), bufs[1].data_ptr(), noop)
+            e1.record(streams[0])
+            torch.cuda.synchronize()
+            e_ms = e0.elapsed_time(e1)
         if n_fl > 1:
             # egress of this batch's slice on stream 0 while the other batch runs whole steps on stream 1
             k_steps = max(1, int(round(e_ms / max(step_ms, 1e-3))))
@@ -1000,13 +1069,24 @@ def main():
                                         "lone_wave_frac": (js.get("instructions", 0) / (kern_ms * 1e-3)) / (clk / LONE_WAVE_CLK_PER_INST)},
                          "gate_evaluations_per_s": float(js.get("gates", 0)) * B / (kern_ms * 1e-3),
                          "fused_r1cs_check": {k[6:]: v for k, v in js.items() if k.startswith("check_")}}
+            roof_eval = in_step_view(roof_eval, tab_bytes, HBM_PEAK_GBS, kern_ms, in_step["eval"], in_step_runs["eval"])
+            te = roof_eval["traffic_estimate"]
+            te["GB/s_incl_re_reads"] = (tab_bytes + reload_bytes) / (roof_eval["kernel_ms"] * 1e-3) / 1e9
+            te["frac_incl_re_reads"] = te["GB/s_incl_re_reads"] / HBM_PEAK_GBS
+            ms_use = roof_eval["kernel_ms"]
+            roof_eval["valu_issue"].update({"wave_insts_per_s": valu_insts / (ms_use * 1e-3), "frac": valu_insts / (ms_use * 1e-3) / valu_peak,
+                                            "all_instructions_per_s": insts / (ms_use * 1e-3),
+                                            "lone_wave_frac": (js.get("instructions", 0) / (ms_use * 1e-3)) / (clk / LONE_WAVE_CLK_PER_INST),
+                                            "isolated_frac": valu_insts / (kern_ms * 1e-3) / valu_peak})
+            roof_eval["gate_evaluations_per_s"] = float(js.get("gates", 0)) * B / (ms_use * 1e-3)
             chk_kern_ms = isolated["r1cs_check_ms"]
             roof_r1cs = {"bound": "none (fused)", "kernel": "fused into cw_bits_jit; cw_bits_r1cs_* audit only the groups it flags", "kernel_ms": chk_kern_ms,
                          "frac": None, "traffic": prof.get("r1cs"), "stand_alone_audit": audit,
                          "note": "every non-trivial constraint is evaluated on the registers that hold its wires while the witness is generated "
                                  "(SURVEY 8d: B_chk -> 0); the stand-alone kernels remain as the audit (CW_R1CS_AUDIT=1, or after cw_device_bits)"}
-            roof_valu = {"bound": "valu", "kernel": ek, "unit": "VALU wave-instructions/s", "achieved": valu_insts / (kern_ms * 1e-3), "peak": valu_peak,
-                         "frac": valu_insts / (kern_ms * 1e-3) / valu_peak, "valu_insts_source": valu_src, "kernel_ms": kern_ms, "clock_hz": clk}
+            roof_valu = {"bound": "valu", "kernel": ek, "unit": "VALU wave-instructions/s", "achieved": valu_insts / (ms_use * 1e-3), "peak": valu_peak,
+                         "frac": valu_insts / (ms_use * 1e-3) / valu_peak, "valu_insts_source": valu_src, "kernel_ms": ms_use, "clock_hz": clk,
+                         "isolated": {"kernel_ms": kern_ms, "achieved": valu_insts / (kern_ms * 1e-3), "frac": valu_insts / (kern_ms * 1e-3) / valu_peak}}
             ing_ms = (isolated["kernels_ms"]["ingest"] if not args.packed_inputs else None) or isolated.get("ingest_ms")
             roof_ingest = None if not ing_ms else {"bound": "hbm", "kernel": "cw_bits_ingest_kernel", "unit": "GB/s", "achieved": 32.0 * n_in * B / (ing_ms * 1e-3) / 1e9,
                            "peak": HBM_PEAK_GBS, "frac": 32.0 * n_in * B / (ing_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel_ms": ing_ms,
@@ -1016,6 +1096,8 @@ def main():
                            "algorithmic_bytes_per_launch": 32.0 * n_in * B,
                            "algorithmic_bytes_are": "the boundary's input image: 32 bytes per input signal and instance, read once",
                            "traffic": prof.get("ingest"), "traffic_source": prof.get("counters_from"), "traffic_measured_in_run": False}
+            if roof_ingest:
+                roof_ingest = in_step_view(roof_ingest, 32.0 * n_in * B, HBM_PEAK_GBS, ing_ms, in_step["ingest"], in_step_runs["ingest"])
         elif batch.bitmode:
             # The bit-plane engine holds ONE BIT per distinct signal value and instance: its kernels neither read nor write
             # the 32-byte image, so SURVEY 8d's byte roof does not bind them (round 2 divided the image's bytes by their
@@ -1080,12 +1162,57 @@ def main():
                          # the check of an arithmetic circuit is bound by instruction issue, not by bytes (Poseidon(2): 7.1e8 wave
                          # instructions per launch, most of them half-rate 32-bit multiplies): fraction of the 2-clock VALU peak
                          "valu_issue_frac": (prof["r1cs_valu_insts"] / (chk_k * 1e-3) / valu_peak) if prof.get("r1cs_valu_insts") else None}
+            if not prof.get("eval_avg_us"):
+                roof_eval = in_step_view(roof_eval, alg_gen, HBM_PEAK_GBS, gen_k, in_step["eval"], in_step_runs["eval"])
+            if chk_gbs is not None and not prof.get("r1cs_avg_us"):
+                roof_r1cs = in_step_view(roof_r1cs, alg_chk, HBM_PEAK_GBS, chk_k, in_step["check"], in_step_runs["check"])
+            gen_iso, gen_k = gen_k, roof_eval["kernel_ms"]
             fpk = circ.n_mmul * B / (gen_k * 1e-3)
             roof_valu = {"bound": "valu", "kernel": ek, "unit": "Fp-mul/s", "achieved": fpk, "peak": fp_mul_per_s,
-                         "frac": fpk / fp_mul_per_s if fp_mul_per_s else None,
+                         "frac": fpk / fp_mul_per_s if fp_mul_per_s else None, "kernel_ms": gen_k,
+                         "isolated": {"kernel_ms": gen_iso, "achieved": circ.n_mmul * B / (gen_iso * 1e-3),
+                                      "frac": circ.n_mmul * B / (gen_iso * 1e-3) / fp_mul_per_s if fp_mul_per_s else None},
                          "valu_wave_insts_per_s": (prof["eval_valu_insts"] / (gen_k * 1e-3)) if prof.get("eval_valu_insts") else None,
                          "valu_issue_frac": (prof["eval_valu_insts"] / (gen_k * 1e-3) / valu_peak) if prof.get("eval_valu_insts") else None}
             roof_ingest = None
+        # What ONE STEP achieves (VERDICT r5 #1a): the bytes a step must move - the boundary's input image, and everything its
+        # kernels move by the counters (or by the emitter's own count) - over ms_per_step of the timed region, against the HBM spec
+        step_ms_ = elapsed / args.steps * 1e3
+        in_bytes = 32.0 * n_in * B
+        if batch.bitmode and batch.jit:
+            all_bytes_est = (0.0 if args.packed_inputs else in_bytes) + tab_bytes + reload_bytes
+            cnt = [prof.get(k_) for k_ in (("eval",) if args.packed_inputs else ("ingest", "eval"))]
+            all_bytes_cnt = sum(cnt) if all(c_ is not None for c_ in cnt) else None
+        elif batch.bitmode:
+            all_bytes_est, all_bytes_cnt = in_bytes + 2 * tab_bytes, None
+        else:
+            all_bytes_est = 32.0 * (n_in + circ.n_signals) * B * (1.0 if getattr(batch, "fused_check", False) else 2.0)
+            cnt = [prof.get(k_) for k_ in ("eval", "r1cs")]
+            all_bytes_cnt = sum(cnt) if all(c_ is not None for c_ in cnt) else None
+        iso_parts = [v_ for v_ in (isolated["kernels_ms"] or {}).values() if v_]
+        step_obj = {"ms_per_step": step_ms_, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "input_bytes": in_bytes, "input_GB/s": in_bytes / (step_ms_ * 1e-3) / 1e9,
+                    "input_frac": in_bytes / (step_ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "all_traffic_bytes": all_bytes_cnt or all_bytes_est,
+                    "all_traffic_source": ("PMC counters (profiles/traffic.json), ingest + evaluation" if all_bytes_cnt else
+                                           "estimate: input image + value / bit table written" + (" + the rows the emitted code re-reads (its own count)" if batch.bitmode and batch.jit else "")),
+                    "all_traffic_GB/s": (all_bytes_cnt or all_bytes_est) / (step_ms_ * 1e-3) / 1e9,
+                    "all_traffic_frac": (all_bytes_cnt or all_bytes_est) / (step_ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "sum_of_parts_alone_ms": sum(iso_parts) if iso_parts else None,
+                    "in_step_kernel_ms": in_step, "in_step_runs": in_step_runs,
+                    "is": "bytes per step / ms_per_step (the driver's clock) / 8 TB/s; sum_of_parts_alone_ms = the step's kernels each running "
+                          "alone, added up: a step below it overlaps its parts"}
+        # The Fp-mul half of the metric against ITS roof (VERDICT r5 #1b): a product is 266 VALU instructions, 162 of them the
+        # half-rate v_mad_u64_u32; peak = 64 lanes / (162 / rate(v_mad_u64_u32) + 104 / rate(full-rate VALU)), both rates measured
+        # chip-wide by tools/ubench_isa (profiles/r03_ubench_isa.json)
+        fp_peak = 64.0 / (FPMUL_MADS / MAD_U64_WAVE_INSTS_PER_S + (FPMUL_INSTS - FPMUL_MADS) / SIMPLE_VALU_WAVE_INSTS_PER_S)
+        roof_fpmul = None if not fp_mul_per_s else {
+            "bound": "valu", "kernel": "cw_mulbench_kernel (2^%d lanes x 1024 dependent Montgomery products, bn128)" % (args.fp_bench_lanes.bit_length() - 1),
+            "unit": "Fp-mul/s", "achieved": fp_mul_per_s, "peak": fp_peak, "frac": fp_mul_per_s / fp_peak,
+            "instructions_per_product": FPMUL_INSTS, "v_mad_u64_u32_per_product": FPMUL_MADS,
+            "rates_wave_insts_per_s": {"v_mad_u64_u32": MAD_U64_WAVE_INSTS_PER_S, "full_rate_valu": SIMPLE_VALU_WAVE_INSTS_PER_S,
+                                       "source": "tools/ubench_isa, profiles/r03_ubench_isa.json (8 waves per SIMD)"},
+            "by_prime": {k_: {"achieved": v_, "frac": v_ / fp_peak} for k_, v_ in fp_mul.items()}}
         # witnesses per second INCLUDING the 32-byte image (SURVEY 8d's definition of a witness's bytes): the step plus the
         # egress of the whole batch, sequentially; with the egress overlapped (another batch evaluating meanwhile) the step
         # hides behind it
@@ -1132,6 +1259,8 @@ def main():
             "roofline_eval": roof_eval,
             "roofline_r1cs": roof_r1cs,
             "roofline_ingest": roof_ingest,
+            "step": step_obj,
+            "roofline_fpmul": roof_fpmul,
             # second bound of SURVEY §8d (integer work, no MFMA): VALU issue in bit-plane mode, Fp products per second
             # against the measured Fp-multiply peak (micro-benchmark, 2^24 x 1024) for the 256-bit schedule
             "roofline_valu": roof_valu,
@@ -1186,6 +1315,19 @@ def main():
                                       "its size: sharding such a job over more GPUs does not shorten it (DESIGN 7)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cp, args.workload)
+            # the Fp-mul half on the same cores: the reference's own Fr_mul in a dependent chain per core (oracle/_ref, fr_shim.cpp)
+            try:
+                from oracle import ref_build
+                fpm = {pn: ref_build.time_fp_mul(pn, 3.0) for pn in ("bn128", "bls12381")}
+                if out["cpu_baseline"] is None:
+                    out["cpu_baseline"] = {"value": None, "unit": "witnesses/s", "cores": fpm["bn128"]["cores"], "kind": "reference", "sample": "witness leg unavailable"}
+                out["cpu_baseline"]["fp_mul_per_s"] = fpm["bn128"]["value"]
+                out["cpu_baseline"]["fp_mul"] = fpm
+                if fp_mul_per_s:
+                    out["cpu_baseline"]["fp_mul_gpu_over_cpu"] = fp_mul_per_s / fpm["bn128"]["value"]
+            except Exception as ex:                                   # noqa: BLE001  (a report, never a reason to fail the line)
+                if out["cpu_baseline"] is not None:
+                    out["cpu_baseline"]["fp_mul_error"] = repr(ex)[:200]
         if world == 1 and batch.bitmode and _o1_size.witness2signal is not None and not args.no_small and not args.batch:
             # What a prover takes (VERDICT r4 #4b): the witness of the system the reference builds by DEFAULT (--O1: constant and
             # renaming substitutions), as 32-byte field elements, for EVERY instance of the batch - no sample, no extrapolation.

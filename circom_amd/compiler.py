@@ -160,27 +160,45 @@ def emit_jit(net, fc, jit="auto"):
         return None
     from .hip_elements import bitjit
     import subprocess
+    # ONE body per repeated template (the reference's code structure: template.rs:160-474): when the circuit instantiates a large
+    # template several times (the compression blocks of SHA-256), the emitter works on a network in which those instances' input
+    # signals are PORTS - every instance then has the same gates - and emits the body once, in a loop (bitjit.lower_jit).  The
+    # interpreter's program keeps the fully folded network it was given.  CW_JIT_LOOP=0: straight-line code as before.
+    if os.environ.get("CW_JIT_LOOP", "1") != "0":
+        ports, marks = bitjit.instance_ports(fc)
+        if ports:
+            from .hip_elements.bitblast import bitblast
+            net_p = bitblast(fc, ports=ports, marks=marks)
+            if net_p is not None:
+                net = net_p
     jp = bitjit.lower_jit(net, fc)
     if jp is None:
         return None
+    # the stand-alone audit of the table this program writes (cw_check_r1cs under CW_R1CS_AUDIT=1 / after cw_device_bits): the
+    # check's gates alone on LOADED rows - a second, much smaller code object; its scratch rows extend the chunk.  It is lowered
+    # BEFORE either program is printed: the chunk stride (rows per chunk x 256 bytes) is an immediate of the code, and both
+    # programs, the tape header and every kernel that walks the table must agree on it (the main program used to be
+    # assembled with its own row count and the header then raised to the audit's)
+    ja = None
+    if os.environ.get("CW_JIT_AUDIT", "1") != "0":
+        ja = bitjit.lower_jit(net, fc, audit_of=jp)
+        if ja is not None:
+            jp.n_slots = ja.n_slots = max(jp.n_slots, ja.n_slots)
     try:
         jp.code = bitjit.assemble(bitjit.to_asm(jp))
     except (RuntimeError, OSError, subprocess.CalledProcessError) as ex:
         _emit_failure("the bit-plane program's code", ex, jit is True)
         return None
-    # the stand-alone audit of the table this program writes (cw_check_r1cs under CW_R1CS_AUDIT=1 / after cw_device_bits): the
-    # check's gates alone on LOADED rows - a second, much smaller code object; its scratch rows extend the chunk
-    if os.environ.get("CW_JIT_AUDIT", "1") != "0":
-        ja = bitjit.lower_jit(net, fc, audit_of=jp)
-        if ja is not None:
-            try:
-                jp.audit_code = bitjit.assemble(bitjit.to_asm(ja))
-            except (RuntimeError, OSError, subprocess.CalledProcessError) as ex:
-                _emit_failure("the audit program's code", ex, False)
-                return jp
-            jp.n_slots = max(jp.n_slots, ja.n_slots)
-            jp.stats["audit_instructions"] = ja.stats["instructions"]
-            jp.stats["audit_loads"] = ja.stats["prefetched"] + ja.stats["late_loads"]
+    jp.code_stride = jp.n_slots * bitjit.ROW_BYTES
+    if ja is not None:
+        try:
+            jp.audit_code = bitjit.assemble(bitjit.to_asm(ja))
+        except (RuntimeError, OSError, subprocess.CalledProcessError) as ex:
+            _emit_failure("the audit program's code", ex, False)
+            return jp                           # (the main code keeps the raised stride: the header carries jp.n_slots as well)
+        jp.audit_stride = ja.n_slots * bitjit.ROW_BYTES
+        jp.stats["audit_instructions"] = ja.stats["instructions"]
+        jp.stats["audit_loads"] = ja.stats["prefetched"] + ja.stats["late_loads"]
     return jp
 
 
@@ -202,6 +220,7 @@ def emit_fpjit(tapes, fc, fpjit="auto", fuse_check=True):
     from .hip_elements import fpjit as FJ
     import subprocess
     out = []
+    skipped = []
     for t in tapes:
         if getattr(t, "kind", 0) != 0:
             continue
@@ -222,9 +241,14 @@ def emit_fpjit(tapes, fc, fpjit="auto", fuse_check=True):
                     spool = os.path.join(spool_dir, "k.s")
                 p = FJ.emit(t, constraints=cons, spool_path=spool)
                 FJ.assemble(p)
-            except NotImplementedError:
+            except NotImplementedError as ex:
+                # a variant that is interpreter-only by design (several strands around run-time function calls, the native
+                # long_div: fpjit.emit says which): skipped - with a warning under an explicit request, which only fails when
+                # NO variant of the circuit could be emitted
+                skipped.append(str(ex))
                 if fpjit is True:
-                    raise
+                    import warnings
+                    warnings.warn("circom_amd: the %d-strand variant runs on the interpreting kernel (%s)" % (t.n_strands, ex))
                 break
             except (RuntimeError, OSError, subprocess.CalledProcessError) as ex:
                 _emit_failure("the rows' code (%d strands)" % t.n_strands, ex, fpjit is True)
@@ -234,6 +258,8 @@ def emit_fpjit(tapes, fc, fpjit="auto", fuse_check=True):
                     import shutil
                     shutil.rmtree(spool_dir, ignore_errors=True)
             out.append(p)
+    if fpjit is True and not out and skipped:
+        raise NotImplementedError("no variant of this circuit has an emitted form: " + "; ".join(sorted(set(skipped))))
     return tuple(out)
 
 

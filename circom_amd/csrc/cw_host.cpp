@@ -351,12 +351,29 @@ static const char *validate_variant(const Variant &v, uint32_t n_signals, uint32
     };
     for (uint32_t st = 0; st < v.n_strands; st++) {
         size_t xp = v.extra_off[st], tp = v.term_off[st];
+        // the bits a D_BITS row stores are not there yet when the row right behind it requests its operands (one row ahead):
+        // the lowering puts a spacer row in between (lower.py, "spacer"); a tape without it would read stale slots silently
+        size_t bits_lo = 0, bits_hi = 0;                      // extras of the D_BITS row directly in front of this one
         for (size_t r = v.stream_off[st]; r < v.stream_off[st + 1]; r++) {
             const CwRow &row = v.rows[r];
             const uint32_t op = row.w0 & 0xFF, dk = (row.w0 >> SH_DK) & 7, ak = (row.w0 >> SH_AK) & 7, bk = (row.w0 >> SH_BK) & 7;
             const uint32_t nx = (row.w0 >> SH_NX) & 0xFFF;
             if (op >= D_NOPS) return "unknown opcode";
-            if (op == D_BARRIER) continue;
+            if (op == D_BARRIER) { bits_lo = bits_hi = 0; continue; }
+            if (bits_hi > bits_lo && op != D_LINSUM && op != D_DOTC && op != D_CALL) {
+                auto stored_by_prev = [&](uint32_t kind, uint32_t idx) {
+                    if (kind != K_SIG && kind != K_TMP) return false;
+                    for (size_t e = bits_lo; e < bits_hi && e < nextras; e++) {
+                        const uint32_t x = v.extras[e] & ~X_NEXT;
+                        if ((x & X_TMP) ? (kind == K_TMP && (x & 0x1FFFFFFFu) == idx) : (kind == K_SIG && x == idx)) return true;
+                    }
+                    return false;
+                };
+                if (stored_by_prev(ak, row.a) || (op != D_BIT && op != D_BITS && stored_by_prev(bk, row.b)))
+                    return "a row reads a bit of the bit-field row directly in front of it (spacer row missing)";
+            }
+            bits_lo = bits_hi = 0;
+            if (op == D_BITS) { bits_lo = xp; bits_hi = xp + nx; }
             if (dk == K_SIG ? row.dst >= n_signals : dk == K_TMP ? row.dst >= v.n_tslots : dk == K_LDS ? row.dst >= v.n_lds : dk != KD_NONE)
                 return "destination out of range";
             if (op == D_LINSUM || op == D_DOTC) {
@@ -1599,11 +1616,27 @@ struct cw_batch {
     uint64_t *d_r1flag = nullptr;                      // per group: instances whose fused R1CS check fired (emitted code)
     // cw_batch_set_timing: events on the batch's stream around the parts of cw_run / cw_check_r1cs (their own intervals, measured
     // where they run - bench.py's roofline figures): 0 run begins | 1 inputs ingested | 2 evaluation done | 3 check begins | 4 check done
+    // cw_batch_set_timing(b, 2) keeps the marks of the last CW_TIMING_RING runs (a new set per cw_run): cw_batch_kernel_ms_mean
+    // averages a part over every set recorded since timing was switched on - the figure a timed region produces, not one launch
     bool timing = false;
-    hipEvent_t tev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool tset[5] = {false, false, false, false, false};     // recorded since timing was switched on (an event never recorded "queries" fine)
+    struct TSet { hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; bool set[5] = {false, false, false, false, false}; };
+    std::vector<TSet> tring = std::vector<TSet>(1);   // [0] alone: the marks of the LAST run / check
+    size_t tcur = 0;
+    bool tfresh = true;                                // no run since timing was switched on: the first one takes set 0
 };
-#define TMARK(b, k) do { if ((b)->timing) { hipEventRecord((b)->tev[k], (b)->stream); (b)->tset[k] = true; } } while (0)
+#define CW_TIMING_RING 64
+static inline void cw_tmark(cw_batch *b, int k) {
+    if (!b->timing) return;
+    if (k == 0 && b->tring.size() > 1) {               // a run begins: its marks (and its check's) go to the next set of the ring
+        if (!b->tfresh) b->tcur = (b->tcur + 1) % b->tring.size();
+        for (bool &x : b->tring[b->tcur].set) x = false;
+    }
+    b->tfresh = false;
+    cw_batch::TSet &t = b->tring[b->tcur];
+    hipEventRecord(t.ev[k], b->stream);
+    t.set[k] = true;
+}
+#define TMARK(b, k) cw_tmark((b), (k))
 
 template <typename T>
 static hipError_t upload(T **dst, const std::vector<T> &src, hipStream_t s) {
@@ -1623,8 +1656,9 @@ extern "C" void cw_batch_free(cw_batch *b) {
     }
     hipSetDevice(b->device);
     hipStreamSynchronize(b->stream);
-    for (hipEvent_t e : b->tev)
-        if (e) hipEventDestroy(e);
+    for (cw_batch::TSet &t : b->tring)
+        for (hipEvent_t e : t.ev)
+            if (e) hipEventDestroy(e);
     if (b->fb) cw_batch_free(b->fb);
     void *bptrs[] = {b->d_V64, b->d_consts64, b->d_rows64, b->d_terms64, b->d_T, b->d_fbmask, b->d_r1flag, b->d_brecs, b->d_bcmds, b->d_aslots, b->d_wslot, b->d_fbinst, b->d_erecs, b->d_wchunk, b->d_wterms, b->d_wctab, b->d_wrow,
                      b->d_ichunk, b->d_iterms, b->d_itab, b->d_irow, b->d_sigslot};
@@ -1972,7 +2006,10 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
             tab[2 * st + 1] = soff[st] + (v.stream_off[st + 1] - v.stream_off[st]);
         }
         if (std::find(bits_entry.begin(), bits_entry.end(), (uint8_t)1) != bits_entry.end()) {
-            // D_BITS rows store the lower half of their signal destinations only (cw_tape.h X_LO_DEV): the table starts cleared
+            // D_BITS rows store the lower half of their signal destinations only (cw_tape.h X_LO_DEV): the table starts cleared.
+            // INVARIANT for the life of the batch: nothing else ever writes the upper 16 bytes of such a slot - every writer of
+            // the value table is a row of this schedule (a slot has one producer: lower.py's clobber replay), inputs land in
+            // input slots (never bit destinations), and the bit-plane fallback re-runs whole instances through these same rows
             if (c->mont) return fail(CW_EIO, "tape: bit-field rows in a schedule of Montgomery-form signals");
             TRY(hipMemsetAsync(b->d_V, 0, b->v_bytes, b->stream));
         }
@@ -2690,13 +2727,29 @@ extern "C" int cw_batch_set_timing(cw_batch *b, int on) {
     if (!b) return fail(CW_EINVAL, "null batch");
     NEED_DEVICE(b);
     HIPCHK(hipSetDevice(b->device));
-    if (on)
-        for (hipEvent_t &e : b->tev)
-            if (!e) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (on) {
+        const size_t want = on >= 2 ? CW_TIMING_RING : 1;
+        if (b->tring.size() < want) b->tring.resize(want);
+        for (cw_batch::TSet &t : b->tring)
+            for (hipEvent_t &e : t.ev)
+                if (!e) HIPCHK(hipEventCreate(&e));
+        if (on < 2 && b->tring.size() > 1) {               // back to "last run only": keep one set
+            for (size_t k = 1; k < b->tring.size(); k++)
+                for (hipEvent_t e : b->tring[k].ev)
+                    if (e) hipEventDestroy(e);
+            b->tring.resize(1);
+        }
+    }
     b->timing = on != 0;
-    for (bool &x : b->tset) x = false;
+    b->tcur = 0;
+    b->tfresh = true;
+    for (cw_batch::TSet &t : b->tring)
+        for (bool &x : t.set) x = false;
     return CW_OK;
 }
+
+static const int cw_tpairs[3][2] = {{0, 1}, {1, 2}, {3, 4}};
 
 // ms[0] = table init + input ingest, ms[1] = the evaluation kernel(s), ms[2] = cw_check_r1cs, of the LAST run / check of the batch
 // (the stream is drained first); a part that has not run since timing was switched on reads -1
@@ -2706,13 +2759,34 @@ extern "C" int cw_batch_kernel_ms(cw_batch *b, float ms[3]) {
     if (!b->timing) return fail(CW_ESTATE, "cw_batch_kernel_ms: timing is off (cw_batch_set_timing)");
     HIPCHK(hipSetDevice(b->device));
     HIPCHK(hipStreamSynchronize(b->stream));
-    const int pairs[3][2] = {{0, 1}, {1, 2}, {3, 4}};
+    const cw_batch::TSet &ts = b->tring[b->tcur];
     for (int k = 0; k < 3; k++) {
         ms[k] = -1.0f;
-        if (b->tset[pairs[k][0]] && b->tset[pairs[k][1]]) {
+        if (ts.set[cw_tpairs[k][0]] && ts.set[cw_tpairs[k][1]]) {
             float t = 0;
-            if (hipEventElapsedTime(&t, b->tev[pairs[k][0]], b->tev[pairs[k][1]]) == hipSuccess) ms[k] = t;
+            if (hipEventElapsedTime(&t, ts.ev[cw_tpairs[k][0]], ts.ev[cw_tpairs[k][1]]) == hipSuccess) ms[k] = t;
         }
+    }
+    return CW_OK;
+}
+
+// the same three parts averaged over every run recorded since cw_batch_set_timing(b, 2) (at most the last CW_TIMING_RING);
+// counts[k] = the runs part k was averaged over (0: ms[k] = -1)
+extern "C" int cw_batch_kernel_ms_mean(cw_batch *b, float ms[3], int counts[3]) {
+    if (!b || !ms || !counts) return fail(CW_EINVAL, "cw_batch_kernel_ms_mean: bad argument");
+    NEED_DEVICE(b);
+    if (!b->timing) return fail(CW_ESTATE, "cw_batch_kernel_ms_mean: timing is off (cw_batch_set_timing)");
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (int k = 0; k < 3; k++) {
+        double sum = 0;
+        counts[k] = 0;
+        for (const cw_batch::TSet &ts : b->tring)
+            if (ts.set[cw_tpairs[k][0]] && ts.set[cw_tpairs[k][1]]) {
+                float t = 0;
+                if (hipEventElapsedTime(&t, ts.ev[cw_tpairs[k][0]], ts.ev[cw_tpairs[k][1]]) == hipSuccess) { sum += t; counts[k]++; }
+            }
+        ms[k] = counts[k] ? (float)(sum / counts[k]) : -1.0f;
     }
     return CW_OK;
 }

@@ -102,20 +102,28 @@ class FlatCircuit:
             tbase[i + 1] = tbase[i] + inst.n_temps
         self.n_temps = int(tbase[-1])
 
+        # rows of the flat code that a component's whole subtree occupies: one contiguous range (a child's code is spliced in
+        # where it fires).  The code emitters use it to find the instances of a repeated template (hip_elements/bitjit.py loops)
+        n_emitted = [0]
+        self.comp_code_range = [(0, 0)] * len(order)
+
         def emit(ci):
             inst, base, _, _ = order[ci]
             tb = int(tbase[ci])
             segs = cache.get(inst.id)
             if segs is None:
                 segs = prep(inst)
+            first = n_emitted[0]
             for kind, item in segs:
                 if kind == "seg":
+                    n_emitted[0] += len(item["op"])
                     chunks["op"].append(item["op"])
                     for kk, vv in (("dk", "dv"), ("ak", "av"), ("bk", "bv"), ("ck", "cv")):
                         chunks[kk].append(item[kk])
                         chunks[vv].append(item[vv] + base * item[vv + "_s"] + tb * item[vv + "_t"])
                 else:
                     emit(ci + inst.children[item][4])
+            self.comp_code_range[ci] = (first, n_emitted[0])
 
         emit(0)
         self.code = {k: (np.concatenate(v) if v else np.zeros(0, dtype=np.int64)) for k, v in chunks.items()}

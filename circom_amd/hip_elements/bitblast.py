@@ -142,6 +142,12 @@ class BitNet:
         self.c = [0, 0]
         self.level = [0, 0]
         self.input_node = {}              # main input signal -> node
+        self.marks = {}                   # row of the flat code -> number of nodes when the analysis reached it (bitblast(marks=))
+        self.port_src = {}                # PORT node -> the node whose value it carries (bitblast(ports=)): the input signals of the
+                                          # instances of a repeated template.  The analysis treats a port like a main input -
+                                          # nothing is folded or shared through it - and the emitted code reads it from the ROW of
+                                          # its source (the reference's template body reads signalValues[mySignalStart + i] the
+                                          # same way, template.rs:297-304), so every instance has the same gate network
         self.sig_node = None              # signal -> node (every signal is a bit in bit mode)
         self.asserts = []                 # nodes that must be 0 (violation functions of unproved `===`)
         self.stats = {}
@@ -151,8 +157,19 @@ class BitNet:
 
 
 class _Blaster:
-    def __init__(self, fc):
+    def __init__(self, fc, ports=None, marks=None):
         self.fc = fc
+        # ports: [(first signal, count), ...] per instance of a repeated template - its input signals (ascending, disjoint)
+        self.port_group = None
+        if ports:
+            pg = np.full(fc.n_signals, -1, dtype=np.int64)
+            for gi, rngs in enumerate(ports):
+                for s0, n_ in rngs:
+                    pg[s0:s0 + n_] = gi
+            self.port_group = pg.tolist()
+            self.port_ranges = ports
+            self.port_node = {}           # signal -> its port node (all ports of an instance are created together, in signal order)
+        self.marks = set(int(m) for m in marks) if marks is not None else None    # rows of the flat code: node count when reached
         q = fc.fp.q
         half = q >> 1
         self.consts = [c - q if c > half else c for c in fc.constants]
@@ -163,13 +180,38 @@ class _Blaster:
         self.lin_cache = {}               # signature -> BV
         self.n_proved = 0
         self.n_gates = 0
+        # arrival levels RELATIVE to the last mark (the start of a repeated template's instance): the carry-save trees order
+        # their operands by arrival; with absolute levels an instance fed by the previous instance's outputs would build other
+        # adders than the first one, which is fed by inputs and constants (nodes older than `floor` count as level 0)
+        self.floor = 0
+        self.rlevel = [0, 0]
 
     # ---- nodes ---------------------------------------------------------------------------------------------
     def new_input(self, sig):
         n = self.net
         nid = len(n.tt)
         n.tt.append(0x100); n.a.append(0); n.b.append(0); n.c.append(0); n.level.append(0)
+        self.rlevel.append(0)
         n.input_node[sig] = nid
+        return nid
+
+    def port(self, sig, src):
+        """the port node of input signal `sig` of a repeated template's instance, now carrying the value of node `src`.  The ports
+        of one instance are created TOGETHER when the first of them is assigned, in signal order: their ids - which order the
+        operands of every gate - then relate to each other and to the instance's gates the same way in every instance, whatever
+        order the parent wires them in and whatever it wires them to"""
+        n = self.net
+        nid = self.port_node.get(sig)
+        if nid is None:
+            for s0, cnt in self.port_ranges[self.port_group[sig]]:
+                for s_ in range(s0, s0 + cnt):
+                    self.port_node[s_] = len(n.tt)
+                    n.tt.append(0x100); n.a.append(0); n.b.append(0); n.c.append(0); n.level.append(0)
+                    self.rlevel.append(0)
+            nid = self.port_node[sig]
+        if nid in n.port_src:
+            raise Unsupported("an input signal of a component is assigned twice")
+        n.port_src[nid] = src
         return nid
 
     def gate(self, leaves, tt):
@@ -196,6 +238,8 @@ class _Blaster:
             n.tt.append(key[0]); n.a.append(key[1]); n.b.append(key[2]); n.c.append(key[3])
             lv = n.level
             n.level.append(1 + max(lv[key[1]], lv[key[2]], lv[key[3]]))
+            rl, fl = self.rlevel, self.floor
+            rl.append(1 + max(rl[key[1]] if key[1] >= fl else 0, rl[key[2]] if key[2] >= fl else 0, rl[key[3]] if key[3] >= fl else 0))
             self.cse[key] = nid
             self.n_gates += 1
         return nid
@@ -519,12 +563,12 @@ class _Blaster:
         for k in range(nb):
             if (c0 >> k) & 1:
                 cols[k].append(1)
-        lv = net.level
+        lv, fl = self.rlevel, self.floor
         # Wallace rounds: every column with >= 3 entries is cut into triples (earliest arrivals first)
         while max(len(c) for c in cols) > 2:
             nxt = [[] for _ in range(nb)]
             for k in range(nb):
-                col = sorted(cols[k], key=lambda x: lv[x])
+                col = sorted(cols[k], key=lambda x: lv[x] if x >= fl else 0)
                 i = 0
                 while len(col) - i >= 3:
                     x, y, z = col[i], col[i + 1], col[i + 2]
@@ -804,6 +848,7 @@ class _Blaster:
             np.add.at(uses, code[vv][m], 1)
         uses = uses.tolist()
         consts = self.consts
+        port_group = self.port_group
         sig = [None] * fc.n_signals
         sig[0] = ((), 1)
         for k in range(fc.n_main_inputs):
@@ -824,7 +869,11 @@ class _Blaster:
         ADD, SUB, MUL, NEG, COPY = O.ADD, O.SUB, O.MUL, O.NEG, O.COPY
         SHL, SHR, BAND, BOR, BXOR = O.SHL, O.SHR, O.BAND, O.BOR, O.BXOR
         WIDE = _WIDE
+        marks = self.marks
+        mark_at = self.net.marks
         for i in range(n):
+            if marks is not None and i in marks:
+                mark_at[i] = self.floor = len(self.net.tt)
             o = op[i]
             if o == O.RUN:
                 continue
@@ -876,12 +925,16 @@ class _Blaster:
                     if type(r) is not tuple:
                         raise Unsupported("signal %d is not provably a bit" % dv[i])
                 nid = self.node_of(r)
+                if port_group is not None and port_group[dv[i]] >= 0:
+                    nid = self.port(dv[i], nid)
                 sig[dv[i]] = ((nid,), 2) if nid > 1 else ((), nid)
             elif dk[i] == K_TMP:
                 if type(r) is Lin and r.own is None:
                     r.own = dv[i]
                 tmp[dv[i]] = r
         net = self.net
+        if marks is not None and n in marks:
+            mark_at[n] = len(net.tt)
         sn = np.zeros(fc.n_signals, dtype=np.int64)
         for s, v in enumerate(sig):
             if v is None:
@@ -894,10 +947,16 @@ class _Blaster:
         return net
 
 
-def bitblast(fc):
-    """FlatCircuit -> BitNet, or None when the circuit is not (entirely) a boolean computation of 0/1 inputs"""
+def bitblast(fc, ports=None, marks=None):
+    """FlatCircuit -> BitNet, or None when the circuit is not (entirely) a boolean computation of 0/1 inputs.
+    ports: per instance of a repeated template the ranges [(first signal, count)] of its INPUT signals: whatever is stored into
+    one of them - a constant, an input, the previous instance's output - is not propagated: the signal gets a PORT node of its
+    own (`BitNet.port_src`: port -> the node it carries).  The code emitter asks for this (bitjit.instance_ports), so that every
+    instance has the same gate network whatever its inputs are wired to, and reads the ports from their sources' rows.
+    marks: rows of the flat code; `BitNet.marks[row]` = number of nodes when the analysis reached that row (the node range of
+    a component's subtree, with FlatCircuit.comp_code_range)."""
     try:
-        return _Blaster(fc).run()
+        return _Blaster(fc, ports, marks).run()
     except Unsupported as e:
         bitblast.why = str(e)
         return None
@@ -916,13 +975,21 @@ def simulate(net: BitNet, input_masks: dict, width: int):
     for s, nid in net.input_node.items():
         val[nid] = input_masks[s] & full
     tt, a, b, c = net.tt, net.a, net.b, net.c
+    src = getattr(net, "port_src", {})
+
+    def rs(x):                                   # a port reads the node it carries (which may be created after the port)
+        while x in src:
+            x = src[x]
+        return x
     for i in range(2, n):
         t = tt[i]
         if t > 0xFF:
             continue
-        A, B, C = val[a[i]], val[b[i]], val[c[i]]
+        A, B, C = val[rs(a[i])], val[rs(b[i])], val[rs(c[i])]
         nA, nB = full ^ A, full ^ B
         lo = ((nA & nB) if t & 1 else 0) | ((A & nB) if t & 2 else 0) | ((nA & B) if t & 4 else 0) | ((A & B) if t & 8 else 0)
         hi = ((nA & nB) if t & 16 else 0) | ((A & nB) if t & 32 else 0) | ((nA & B) if t & 64 else 0) | ((A & B) if t & 128 else 0)
         val[i] = (lo & (full ^ C)) | (hi & C)
+    for p_ in src:
+        val[p_] = val[rs(p_)]
     return val

@@ -318,6 +318,18 @@ LUT_MAX_WIRES = 6
 INT_COEF_LIMIT = 1 << 64
 
 
+def _resolve_ports(net) -> dict:
+    """port node -> the real node (gate, main input, constant 0 / 1) whose value it carries, chains followed"""
+    src = getattr(net, "port_src", None) or {}
+    out = {}
+    for p_ in src:
+        x = p_
+        while x in src:
+            x = src[x]
+        out[p_] = x
+    return out
+
+
 def build_check(net, fc):
     """Fused R1CS check: gates behind the evaluation network whose leaves are the nodes of the constraint wires.
     Returns (_Gates, viol nodes, stats).  stats['unchecked'] = constraints the fused check does not cover (the stand-alone
@@ -334,12 +346,16 @@ def build_check(net, fc):
         v %= q
         return v - q if v > half else v
 
-    def lin(d):
+    ports = _resolve_ports(net)
+
+    def lin(d, through_ports=False):
         """{signal: coef} -> (c0, {node: coef}) in signed representatives"""
         c0 = 0
         t = {}
         for s, cf in d.items():
             nd = int(sn[s]) if s else 1
+            if through_ports:
+                nd = ports.get(nd, nd)
             if nd == 0:
                 continue
             cf = signed(cf)
@@ -368,6 +384,27 @@ def build_check(net, fc):
             st["trivial"] += 1                # the same relation over the same nodes was checked already
             continue
         seen[key] = True
+        if ports and any(w in ports for w in wires):
+            # a wire that is a PORT (the input signal of a repeated template's instance) carries its source's value by
+            # construction - the emitted code reads it from the source's row: `hin[k] === previous out[k]`, which the parent's
+            # `<==` adds, holds identically.  Such a row is trivial if it is with every port replaced by what it carries.
+            ra0, rat = lin(A, True)
+            rb0, rbt = lin(B, True)
+            rc0, rct = lin(C, True)
+            rw = sorted(set(rat) | set(rbt) | set(rct))
+            if len(rw) <= LUT_MAX_WIRES:
+                holds = True
+                for m in range(1 << len(rw)):
+                    av, bv, cv = ra0, rb0, rc0
+                    for j, w in enumerate(rw):
+                        if (m >> j) & 1:
+                            av += rat.get(w, 0); bv += rbt.get(w, 0); cv += rct.get(w, 0)
+                    if (av * bv - cv) % q:
+                        holds = False
+                        break
+                if holds:
+                    st["trivial"] += 1
+                    continue
         if len(wires) <= LUT_MAX_WIRES:
             n = len(wires)
             tt = 0
@@ -443,13 +480,207 @@ class JitProgram:
         self.is_audit = False
 
 
-def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384, fuse_check: bool = True, hoist: int = 256, audit_of=None):
+OPAQUE_MIN_SIGNALS = 20000     # instances of a repeated template at least this large: loop candidates (their inputs become ports)
+LOOP_MIN_BODY_GATES = 2048
+
+
+def loop_templates(fc, min_signals: int = OPAQUE_MIN_SIGNALS):
+    """The reference emits ONE body per template (`<T>_<id>_run`, compiler/src/circuit_design/template.rs:160-474) and runs it
+    once per instance; the candidates for that treatment here: templates instantiated at least twice with the same parameters
+    whose instance (with its sub-components) has at least `min_signals` signals.  -> [(template instance id, [component
+    indices in code order])], largest coverage first."""
+    if not hasattr(fc, "comp_code_range") or getattr(fc, "prog", None) is None:
+        return []
+    insts = fc.prog.inst_list
+    groups = {}
+    for ci, iid in enumerate(fc.comp_inst):
+        if ci and insts[iid].n_total >= min_signals:
+            groups.setdefault(iid, []).append(ci)
+    out = [(iid, sorted(cis, key=lambda c_: fc.comp_code_range[c_][0])) for iid, cis in groups.items() if len(cis) >= 2]
+    out.sort(key=lambda e: -insts[e[0]].n_total * len(e[1]))
+    return out
+
+
+def instance_ports(fc, min_signals: int = OPAQUE_MIN_SIGNALS):
+    """(ports, marks) for `bitblast(fc, ports=, marks=)`: per instance of a loop candidate the ranges of its INPUT signals -
+    whatever the parent wires to them (the IV constants of the first SHA-256 block, the previous block's output, the padding of
+    the last) they are run-time values of the reference's template body - and the rows of the flat code where each
+    instance's code begins and ends.  (None, None) when the circuit has no candidate."""
+    cands = loop_templates(fc, min_signals)
+    if not cands:
+        return None, None
+    from ..frontend.dsl import _prod
+    ports, marks = [], set()
+    insts = fc.prog.inst_list
+    for iid, cis in cands:
+        for ci in cis:
+            base = fc.comp_sigstart[ci]
+            ports.append(sorted((base + off, _prod(dims)) for _, dims, off in insts[iid].decls["i"]))
+            marks.update(fc.comp_code_range[ci])
+    return ports, marks
+
+
+def _plan_segments(net, fc, n_eval, TT, A, B, C, is_gate, live, G, flags, hoist, want_loop, al):
+    """Order of evaluation, segment by segment.  Without a loop: ONE segment (the whole program).  With the instances of a
+    repeated template found in the network (their node ranges: net.marks at FlatCircuit.comp_code_range): prologue | one segment
+    per instance | epilogue, every gate ordered inside its own segment; the longest run of instances whose ordered gate lists
+    are ISOMORPHIC (same tables, same operand structure, same stored / asserted / violation flags; operands from outside the
+    instance - its ports, in general any value of another segment - form the same pattern) becomes the loop.
+    -> (order: int64 array of gate ids, seg_of: int32 array over nodes, bounds: [start of segment i in order], loop) with
+    loop = None | dict(first=segment index, K=iterations, ext=[K][n_ext] node ids)"""
+    n_nodes = len(TT)
+    An, Bn, Cn = (np.asarray(x, dtype=np.int64) for x in (A, B, C))
+    gate_mask = np.asarray(is_gate, dtype=bool)
+    live_mask = np.asarray(live, dtype=bool) & gate_mask
+    cands = []
+    if want_loop and getattr(net, "marks", None):
+        for iid, cis in loop_templates(fc):
+            rng = [(net.marks[r0], net.marks[r1]) for r0, r1 in (fc.comp_code_range[ci] for ci in cis) if r0 in net.marks and r1 in net.marks]
+            if len(rng) >= 2 and all(rng[i][1] <= rng[i + 1][0] for i in range(len(rng) - 1)):
+                cands.append(rng)
+    rowkey = G.rowkey
+    dbg = bool(os.environ.get("CW_JIT_LOOP_DEBUG"))
+    for rng in cands + [None]:
+        seg = np.zeros(n_nodes, dtype=np.int32)
+        floors = [0]
+        if rng is not None:
+            ok = True
+            for k, (n0, n1) in enumerate(rng):
+                seg[n0:n1] = k + 1
+                floors.append(n0)
+                if k and live_mask[rng[k - 1][1]:n0].any():
+                    ok = False                         # gates between two instances (glue of the parent): no clean iteration
+            if not ok:
+                if dbg:
+                    print("loop candidate dropped: live gates between two instances")
+                continue
+            seg[rng[-1][1]:n_eval] = len(rng) + 1
+            floors.append(rng[-1][1])
+            seg[~gate_mask] = 0
+            # the PORTS of an instance (created in front of its gates) belong to it: a constraint over ports alone is checked in
+            # their instance's iteration, where the rows they are read from exist
+            port_ids = np.fromiter(getattr(net, "port_src", {}).keys(), dtype=np.int64)
+            if len(port_ids):
+                lo = 0
+                for k, (n0, n1) in enumerate(rng):
+                    seg[port_ids[(port_ids >= lo) & (port_ids < n0)]] = k + 1
+                    lo = n1
+        sl = seg.tolist()
+        # check gates: the latest segment among their operands (wires that are inputs / ports / prologue values
+        # do not pull a constraint out of the prologue)
+        for nid in range(n_eval, n_nodes):
+            sl[nid] = max(sl[al[A[nid]]], sl[al[B[nid]]], sl[al[C[nid]]]) if rng is None else max(sl[A[nid]], sl[B[nid]], sl[C[nid]])
+        # keys: evaluation gates in creation order - except that a gate whose operands (of its own segment) were ALL created long
+        # before it moves up behind the youngest of them (circomlib's SHA-256 computes a block twice: the `<--` hint function
+        # first, then the constrained components, whose values are the hint's gates again plus a few of their own - the `mid`
+        # products, partial sums: created a whole block later than everything they read and are read with); every check gate sits
+        # where the youngest wire of its constraint is produced.  Operands of other segments count as "there from the start".
+        kl = [0] * n_nodes
+        for nid in range(2, n_eval):
+            if is_gate[nid]:
+                sg = sl[nid]
+                m = -1
+                km = floors[sg]
+                for o in (A[nid], B[nid], C[nid]):
+                    o = al[o]                      # (a port waits for the value it carries)
+                    if o > 1 and is_gate[o] and sl[o] == sg:
+                        if o > m:
+                            m = o
+                        if kl[o] > km:
+                            km = kl[o]
+                kl[nid] = nid if (m >= 0 and nid - m <= hoist) else km
+        for nid in range(n_eval, n_nodes):
+            sg = sl[nid]
+            km = floors[sg]
+            for o in (rowkey[nid - n_eval], A[nid], B[nid], C[nid]):
+                o = al[o]
+                if o > 1 and sl[o] == sg and kl[o] > km:
+                    km = kl[o]
+            kl[nid] = km
+        seg = np.asarray(sl, dtype=np.int32)
+        key = np.asarray(kl, dtype=np.int64)
+        gates = np.nonzero(live_mask)[0]
+        if flags["audit"]:
+            gates = gates[gates >= n_eval]
+        if len(gates) == 0:
+            return None
+        order = gates[np.lexsort((gates, key[gates], seg[gates]))]
+        n_seg = len(floors)
+        bounds = np.searchsorted(seg[order], np.arange(n_seg + 1)).tolist()
+        if rng is None:
+            return order, seg, bounds, None
+        # ---- isomorphism of the instances -----------------------------------------------------------------------------
+        import hashlib
+        posn = np.zeros(n_nodes, dtype=np.int64)
+        posn[order] = np.arange(len(order)) - np.asarray(bounds, dtype=np.int64)[seg[order]]
+        TTn = np.asarray(TT, dtype=np.int64)
+        fl = flags["signal"].astype(np.int64) | (flags["assert"].astype(np.int64) << 1) | (flags["viol"].astype(np.int64) << 2)
+        digests, exts = [], []
+        for k in range(len(rng)):
+            g = order[bounds[k + 1]:bounds[k + 2]]
+            ops = np.stack([An[g], Bn[g], Cn[g]], axis=1)                       # [L][3]
+            internal = gate_mask[ops] & (seg[ops] == k + 1)
+            code = np.where(internal, posn[ops], np.where(ops <= 1, -1 - ops, np.int64(-3)))
+            extm = (~internal) & (ops > 1)
+            flat = ops[extm]
+            if len(flat):
+                uq, first, inv = np.unique(flat, return_index=True, return_inverse=True)
+                rank = np.empty(len(uq), dtype=np.int64)
+                by_first = np.argsort(first, kind="stable")
+                rank[by_first] = np.arange(len(uq))
+                code[extm] = -3 - rank[inv]
+                exts.append(uq[by_first])
+            else:
+                exts.append(np.zeros(0, dtype=np.int64))
+            h = hashlib.blake2b(digest_size=16)
+            h.update(TTn[g].tobytes()); h.update(code.tobytes()); h.update(fl[g].tobytes())
+            digests.append(h.digest())
+            if dbg:
+                if k == 0:
+                    ref_ = (TTn[g], code, fl[g], g)
+                else:
+                    n_ = min(len(g), len(ref_[0]))
+                    g, code = g[:n_], code[:n_]
+                    ref_c = tuple(x[:n_] for x in ref_)
+                    d_tt, d_code, d_fl = (TTn[g] != ref_c[0]), (code != ref_c[1]).any(axis=1), (fl[g] != ref_c[2])
+                    print("  instance %d vs 0: tables differ at %d, operands at %d, flags at %d positions" % (k, d_tt.sum(), d_code.sum(), d_fl.sum()))
+                    for nm, dm in (("operands", d_code), ("flags", d_fl), ("tables", d_tt)):
+                        for j in np.nonzero(dm)[0][:4].tolist():
+                            print("    %s @%d: node %d eval=%s tt=%x code=%s fl=%d | ref node %d tt=%x code=%s fl=%d" % (
+                                nm, j, g[j], g[j] < n_eval, TTn[g[j]], code[j].tolist(), fl[g[j]], ref_c[3][j], ref_c[0][j], ref_c[1][j].tolist(), ref_c[2][j]))
+        best = (0, 0)
+        k = 0
+        while k < len(rng):
+            j = k
+            while j + 1 < len(rng) and digests[j + 1] == digests[k]:
+                j += 1
+            if j - k + 1 > best[1]:
+                best = (k, j - k + 1)
+            k = j + 1
+        k0, K = best
+        L = bounds[k0 + 2] - bounds[k0 + 1]
+        if dbg:
+            print("loop candidate: %d instances, gates per instance %s, digests %s -> run of %d from %d" %
+                  (len(rng), [bounds[k + 2] - bounds[k + 1] for k in range(len(rng))], [d.hex()[:6] for d in digests], K, k0))
+        if K < 2 or L < LOOP_MIN_BODY_GATES:
+            continue
+        ext = np.stack([exts[k0 + i] for i in range(K)]) if len(exts[k0]) else np.zeros((K, 0), dtype=np.int64)
+        return order, seg, bounds, {"first": k0 + 1, "K": K, "ext": ext}
+    raise AssertionError("unreachable")
+
+
+def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384, fuse_check: bool = True, hoist: int = 256, audit_of=None,
+              loop: bool = True):
     """BitNet (bitblast.py) -> JitProgram with IR.  Returns None when there is nothing to evaluate.
     audit_of = the program lowered from the same network: lower the STAND-ALONE AUDIT of its table instead - the gates of the
     R1CS check alone, their wires LOADED from the rows that program stored (one coalesced 256-byte row per wire and wave: the
     table's own layout), nothing evaluated, nothing stored but scratch behind the table.  `cw_check_r1cs` runs it when the
     caller asks for an audit (CW_R1CS_AUDIT=1) or may have changed the table (cw_device_bits): the general check kernels
-    read 8 bytes out of every 256-byte row in this layout (271 ms for 2^21 instances of Sha256(2048))."""
+    read 8 bytes out of every 256-byte row in this layout (271 ms for 2^21 instances of Sha256(2048)).
+    loop: emit ONE body for the instances of a repeated template and run it once per instance (`_plan_segments`; needs a
+    network built with bitblast(ports=, marks=) from `instance_ports(fc)`): code size follows the templates, not the circuit -
+    the reference's own structure (template.rs:160-474, loop_bucket.rs:77).  Inside the body a row is addressed relative to
+    the iteration's base, a value from outside the iteration through a per-iteration table of row offsets (IR "ldx")."""
     n_eval = len(net.tt)
     audit = audit_of is not None
     if audit and not (fuse_check and fc.constraints and audit_of.check_complete):
@@ -475,6 +706,10 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
     is_signal[sn] = True
     is_gate = [t <= 0xFF for t in TT]
     is_gate[0] = is_gate[1] = False
+    ports = _resolve_ports(net)                # port -> the node whose row it is read from
+    al = list(range(n_nodes))
+    for p_, x in ports.items():
+        al[p_] = x
     if audit:
         live = [False] * n_nodes               # the check's own gates only; their wires are rows of the table
         for x in viol:
@@ -488,37 +723,63 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
             live[x] = True
         for x in viol:
             live[x] = True
+        for x in ports.values():
+            live[x] = True                     # (what a port carries: the values wired to a component's inputs are signals anyway)
         for nid in range(n_nodes - 1, 1, -1):
             if live[nid] and is_gate[nid]:
                 live[A[nid]] = live[B[nid]] = live[C[nid]] = True
-    # order: evaluation gates in creation order (= program order of the witness code) - except that a gate whose operands
-    # were ALL created long before it moves up behind the youngest of them (circomlib's SHA-256 computes a block twice: the
-    # `<--` hint function first, then the constrained components, whose values are the hint's gates again plus a few of
-    # their own - the `mid` products, partial sums: created a whole block later than everything they read and are read with);
-    # every check gate sits where the youngest wire of its constraint is produced
-    key = np.zeros(n_nodes, dtype=np.int64)
-    kl = key.tolist()
-    for nid in range(2, n_eval):
-        if is_gate[nid]:
-            m = max(A[nid], B[nid], C[nid])
-            kl[nid] = nid if nid - m <= hoist else max(kl[A[nid]], kl[B[nid]], kl[C[nid]])
-        else:
-            kl[nid] = 0                        # inputs are there from the start
-    for nid in range(n_eval, n_nodes):
-        i = nid - n_eval
-        kl[nid] = max(kl[G.rowkey[i]], kl[A[nid]], kl[B[nid]], kl[C[nid]])
-    key = np.asarray(kl, dtype=np.int64)
-    gates = np.array([i for i in range(n_eval if audit else 2, n_nodes) if is_gate[i] and live[i]], dtype=np.int64)
-    if len(gates) == 0:
-        return None
-    order = gates[np.lexsort((gates, key[gates]))].tolist()
-    n_ops = len(order)
     assert_set = set() if audit else set(int(x) for x in net.asserts if x > 1)
     viol_set = set(int(x) for x in viol if x > 1)
     const_assert = (not audit) and any(x == 1 for x in net.asserts)      # an assertion that is constant true-violation: every instance falls back
     const_viol = any(x == 1 for x in viol)
     if audit and any(x < n_eval and x > 1 for x in viol_set):
         return None                                # (a violation value that is an evaluation gate itself: not a shape build_check makes)
+    fa = np.zeros(n_nodes, dtype=bool)
+    fa[list(assert_set)] = True
+    fv = np.zeros(n_nodes, dtype=bool)
+    fv[list(viol_set)] = True
+    planned = _plan_segments(net, fc, n_eval, TT, A, B, C, is_gate, live, G,
+                             {"audit": audit, "signal": is_signal, "assert": fa, "viol": fv}, hoist, loop and not audit, al)
+    if planned is None:
+        return None
+    order_all, seg_of, bounds, lp = planned
+    # the plan the allocator walks: prologue (+ instances in front of the loop) | ONE instance of the loop | the rest
+    must_store = is_signal.copy()
+    gm = np.asarray(is_gate, dtype=bool)
+    al_n = np.asarray(al, dtype=np.int64)
+    if ports and not audit:
+        srcs = np.fromiter(ports.values(), dtype=np.int64, count=len(ports))
+        must_store[srcs[gm[srcs]]] = True          # a port is read from its source's row
+    if lp is not None:
+        s0, K = lp["first"], lp["K"]
+        b0, b1, b2 = bounds[s0], bounds[s0 + 1], bounds[s0 + K]
+        L_body = b1 - b0
+        order = np.concatenate([order_all[:b1], order_all[b2:]]).tolist()
+        bodies = order_all[b0:b2].reshape(K, L_body)
+        # a value of the loop that something outside its own iteration reads must have a row - in EVERY iteration alike
+        An, Bn, Cn = (np.asarray(x, dtype=np.int64) for x in (A, B, C))
+        users = order_all
+        used_out = np.zeros(n_nodes, dtype=bool)
+        for Xn in (An, Bn, Cn):
+            o = al_n[Xn[users]]                                 # (through ports: the gate whose row is read)
+            m = gm[o] & (seg_of[o] >= s0) & (seg_of[o] < s0 + K) & (seg_of[o] != seg_of[users])
+            used_out[o[m]] = True
+        force = used_out[bodies].any(axis=0)
+        must_store[bodies[0][force]] = True
+        ext_nodes = lp["ext"]                                   # [K][n_ext]
+        ext_src = al_n[ext_nodes]
+        must_store[ext_src[gm[ext_src]]] = True                 # prologue values the loop reads: through their rows
+        ext_index = {int(nd): e for e, nd in enumerate(ext_nodes[0].tolist())}
+        body_seg = s0
+    else:
+        order = order_all.tolist()
+        b0 = b1 = -1
+        K = 1
+        ext_index = {}
+        body_seg = -1
+    n_ops = len(order)
+    seg_l = seg_of.tolist()
+    must_l = must_store.tolist()
 
     # uses per node (positions in `order`), consumed front to back
     uses = [None] * n_nodes
@@ -558,6 +819,7 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
     else:
         for s, nid in net.input_node.items():
             mem_slot[nid] = IN_BASE + (s - fc.main_input_start)
+        mem_slot[0], mem_slot[1] = 0, 1            # the constant rows (a port may carry a constant)
         next_slot = IN_BASE + fc.n_main_inputs
     ir = []
     emit = ir.append
@@ -565,6 +827,13 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
     vm_done = -1                                  # every memory operation with index <= vm_done has completed
     stats = {"gates": 0, "stores": 0, "prefetched": 0, "late_loads": 0, "agpr_writes": 0, "agpr_reads": 0, "scratch_stores": 0,
              "waits": 0, "loads_for_check": 0}
+    dyn = dict(stats)                             # the same counts as EXECUTED (the loop's body counts once per iteration)
+    in_body = False
+    loop_base = 0
+
+    def count(k_, n=1):
+        stats[k_] += n
+        dyn[k_] += n * (K if in_body else 1)
 
     def wait_for(idx):
         nonlocal vm_done
@@ -574,15 +843,21 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
         if n > 63:
             n = 63
         emit(("w", n))
-        stats["waits"] += 1
+        count("waits")
         vm_done = vm_issued - 1 - n
 
     def issue_load(node, v):
         nonlocal vm_issued
-        si = st_idx[node]
+        src = al[node]                            # (a port: the row of the value it carries)
+        si = st_idx[src]
         if si >= 0:
             wait_for(si)                          # the row was written by this wave: the store must have completed
-        emit(("ld", v, mem_slot[node]))
+        if not in_body:
+            emit(("ld", v, mem_slot[src]))
+        elif seg_l[node] == body_seg and is_gate[node]:
+            emit(("ldL", v, mem_slot[node] - loop_base))
+        else:
+            emit(("ldx", v, ext_index[node]))     # a value from outside the iteration: its row comes from the iteration's table
         pend[node] = vm_issued
         vm_issued += 1
 
@@ -590,7 +865,10 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
         nonlocal vm_issued, next_slot
         mem_slot[node] = next_slot
         next_slot += 1
-        emit((kind, reg, mem_slot[node]))
+        if in_body:
+            emit((kind + "L", reg, mem_slot[node] - loop_base))
+        else:
+            emit((kind, reg, mem_slot[node]))
         st_idx[node] = vm_issued
         vm_issued += 1
 
@@ -613,7 +891,7 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
         a = loc_a[nd]
         if mem_slot[nd] < 0:
             issue_store("sta", a, nd)
-            stats["scratch_stores"] += 1
+            count("scratch_stores")
         loc_a[nd] = -1
         return a
 
@@ -650,12 +928,12 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
             a = alloc_a(nu)
             if a >= 0:
                 emit(("aw", a, v))
-                stats["agpr_writes"] += 1
+                count("agpr_writes")
                 loc_a[victim] = a
                 heapq.heappush(aheap, (-nu, victim))
             elif mem_slot[victim] < 0:
                 issue_store("st", v, victim)
-                stats["scratch_stores"] += 1
+                count("scratch_stores")
         return v
 
     def alloc_v(pin):
@@ -678,22 +956,76 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
 
     empty = frozenset()
     held_viol = [-1]                              # VGPR of a violation value waiting for its partner (not in any heap: never evicted)
+
+    def boundary():
+        """loop entry / exit: nothing lives in a register across it.  Values that are read again get a row (if they have none),
+        every memory operation completes, the register files start empty."""
+        nonlocal free_v, free_a, vm_done
+        if held_viol[0] >= 0:
+            emit(("acc", 2, held_viol[0]))
+            held_viol[0] = -1
+        for heap, loc, kind in ((vheap, loc_v, "st"), (aheap, loc_a, "sta")):
+            for nnu, nd in heap:
+                if loc[nd] >= 0 and next_use(nd) == -nnu and mem_slot[nd] < 0:
+                    if kind == "st" and pend[nd] >= 0:
+                        wait_for(pend[nd])
+                        pend[nd] = -1
+                    issue_store(kind, loc[nd], nd)
+                    count("scratch_stores")
+        for heap, loc in ((vheap, loc_v), (aheap, loc_a)):
+            for _, nd in heap:
+                loc[nd] = -1
+                pend[nd] = -1
+            del heap[:]
+        if vm_issued:
+            wait_for(vm_issued - 1)
+        free_v = list(range(n_vgpr - 1, V_FIRST - 1, -1))
+        free_a = list(range(n_agpr - 1, -1, -1))
+
+    loop_at = -1                                  # position of the ("loop", ...) instruction in the IR
+
+    def end_loop():
+        nonlocal in_body, next_slot
+        boundary()
+        R = next_slot - loop_base
+        in_body = False
+        # the rows of the other iterations: the same local row, R rows further per iteration
+        ms0 = np.asarray([mem_slot[int(x)] for x in bodies[0]], dtype=np.int64)
+        stored_ = ms0 >= 0
+        for i in range(1, K):
+            for nd, r in zip(bodies[i][stored_].tolist(), (ms0[stored_] + i * R).tolist()):
+                mem_slot[nd] = r
+        next_slot = loop_base + K * R
+        tab = np.asarray([[mem_slot[al[int(nd)]] for nd in row] for row in ext_nodes], dtype=np.int64).reshape(K, -1)
+        assert (tab >= 0).all(), "a value the loop reads from outside its iteration has no row"
+        ir[loop_at] = ("loop", K, R, loop_base, tab.astype(np.uint32))
+        emit(("endloop",))
+
     for p in range(n_ops):
+        if p == b0:
+            boundary()
+            loop_base = next_slot
+            loop_at = len(ir)
+            emit(("loop",))                       # (filled in at the end of the body)
+            in_body = True
+        elif p == b1:
+            end_loop()
+        region = 0 if p < b0 else 1 if p < b1 else 2
         # -- prefetch what the gate PREFETCH positions ahead reads from memory; a second look a quarter of that distance ahead
         # catches values that were resident at the first look and have been dropped since (they have a row: dropping is free)
         for pf in (p + prefetch, p + prefetch // 4):
-            if pf >= n_ops or pf == p:
+            if pf >= n_ops or pf == p or (0 if pf < b0 else 1 if pf < b1 else 2) != region:
                 continue
             g2 = order[pf]
             for o in (A[g2], B[g2], C[g2]):
-                if o > 1 and loc_v[o] < 0 and loc_a[o] < 0 and mem_slot[o] >= 0:
+                if o > 1 and loc_v[o] < 0 and loc_a[o] < 0 and mem_slot[al[o]] >= 0:
                     v = alloc_v(empty)
                     loc_v[o] = v
                     issue_load(o, v)
                     heapq.heappush(vheap, (-next_use(o), o))
-                    stats["prefetched"] += 1
+                    count("prefetched")
                     if g2 >= n_eval:
-                        stats["loads_for_check"] += 1
+                        count("loads_for_check")
         g = order[p]
         ops = (A[g], B[g], C[g])
         pin = set(o for o in ops if o > 1)
@@ -703,14 +1035,14 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
                 loc_v[o] = v
                 if loc_a[o] >= 0:
                     emit(("ar", v, loc_a[o]))
-                    stats["agpr_reads"] += 1
+                    count("agpr_reads")
                     free_a.append(loc_a[o])
                     loc_a[o] = -1
-                elif mem_slot[o] >= 0:
+                elif mem_slot[al[o]] >= 0:
                     issue_load(o, v)
-                    stats["late_loads"] += 1
+                    count("late_loads")
                     if g >= n_eval:
-                        stats["loads_for_check"] += 1
+                        count("loads_for_check")
                 elif audit:
                     return None                    # a wire of the check that the evaluation never stored: no audit program
                 else:
@@ -732,15 +1064,15 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
                 release(o)
             else:
                 heapq.heappush(vheap, (-u[i], o))
-        stored = bool(is_signal[g])
+        stored = must_l[g]
         nu = next_use(g)
         d = alloc_v(pin)
         emit(("g", d, srcs[0], srcs[1], srcs[2], TT[g]))
-        stats["gates"] += 1
+        count("gates")
         loc_v[g] = d
         if stored:
             issue_store("st", d, g)
-            stats["stores"] += 1
+            count("stores" if is_signal[g] else "scratch_stores")
         if g in assert_set:
             emit(("acc", 1, d))
         if g in viol_set:
@@ -759,6 +1091,8 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
             loc_v[g] = -1
         else:
             heapq.heappush(vheap, (-nu, g))
+    if lp is not None and n_ops == b1:                # (the loop ends the program: no gate behind it ran the exit code above)
+        end_loop()
     if held_viol[0] >= 0:
         emit(("acc", 2, held_viol[0]))
     if const_assert:
@@ -779,6 +1113,8 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
         jp.stats = stats
         jp.is_audit = True
         return jp
+    for p_, x in ports.items():
+        mem_slot[p_] = mem_slot[x]                # the signal of a port lives in the row of the value it carries
     sig_slot = np.zeros(fc.n_signals, dtype=np.uint32)
     ms = np.asarray(mem_slot, dtype=np.int64)
     jp.node_slot = ms[:n_eval].copy()             # evaluation node -> row (-1: never stored), for the audit program (audit_of=)
@@ -798,6 +1134,12 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
     stats["instructions"] = len(ir)
     stats["slots"] = jp.n_slots
     stats["nodes"] = n_nodes
+    if lp is not None:
+        body_len = ir.index(("endloop",)) - loop_at - 1
+        stats["loop"] = {"iterations": K, "body_instructions": body_len, "rows_per_iteration": int(ir[loop_at][2]),
+                         "external_values": int(ir[loop_at][4].shape[1]), "segments": len(bounds) - 1}
+        dyn["instructions"] = len(ir) + (K - 1) * body_len
+        stats["executed"] = dyn                   # what a wave EXECUTES (bench.py prices the kernel with these)
     jp.stats = stats
     return jp
 
@@ -833,9 +1175,18 @@ def gate_asm(ins) -> str:
     return "  v_bitop3_b32 v%d, %s, %s, %s bitop3:0x%x\n" % (dst, opnd(a), opnd(b), opnd(c), tt)
 
 
+S_ITER, S_COUNT, S_TOP, S_TAB = 40, 41, 42, 44       # loop state: iteration base (bytes), iterations left, loop top pc, table cursor
+S_EXT0, EXT_SLOTS, EXT_BATCH = 48, 6, 8                # row offsets of external values: 6 x s_load_dwordx8 (s48 .. s95)
+N_SGPR = 96
+
+
 def to_asm(jp: JitProgram) -> str:
     """gfx950 assembly of the program.  Kernel arguments: bit table, fallback masks, R1CS flags (three pointers); one
-    wave (workgroup of 64) per chunk of 2 048 instances."""
+    wave (workgroup of 64) per chunk of 2 048 instances.
+    A loop (IR "loop" ... "endloop") runs its body once per instance of the repeated template: rows of the body are addressed
+    relative to the iteration's base (s40, advanced by the body's rows), values from outside the iteration through the
+    iteration's table of row offsets, which sits behind the code (s[44:45] walks it; entries come in through s_load_dwordx8
+    into six rotating octets of SGPRs) - the reference's `signalValues[mySignalStart + ...]` (template.rs:297-304)."""
     chunk_bytes = jp.n_slots * ROW_BYTES
     assert chunk_bytes < (1 << 32)
     L = []
@@ -850,46 +1201,82 @@ def to_asm(jp: JitProgram) -> str:
         "  s_mul_i32 s11, s2, s10\n  s_mul_hi_u32 s17, s2, s10\n"
         "  s_add_u32 s12, s4, s11\n  s_addc_u32 s13, s5, s17\n  s_and_b32 s13, s13, 0xffff\n"
         "  s_mov_b32 s14, s10\n  s_mov_b32 s15, 0x00020000\n" % chunk_bytes)
-    st_page = -1
+    st_page = [-1]
     pages = {}                   # page -> sgpr
     lru = []                     # pages, most recent last
     free_s = list(range(20 + N_PAGE_SGPRS - 1, 19, -1))
+    in_loop = [False]
+    ext_slot = {}                # batch of the iteration's table -> first sgpr
+    ext_lru = []
+    tables = []                  # the loops' tables, printed behind the code
+    loop_no = [0]
+
+    def reset_pages():
+        st_page[0] = -1
+        pages.clear()
+        del lru[:]
+        del free_s[:]
+        free_s.extend(range(20 + N_PAGE_SGPRS - 1, 19, -1))
+        ext_slot.clear()
+        del ext_lru[:]
+
+    def page_set(s_, pg):
+        if in_loop[0]:
+            add("  s_add_u32 s%d, s%d, 0x%x\n" % (s_, S_ITER, pg * PAGE))
+        else:
+            add("  s_mov_b32 s%d, 0x%x\n" % (s_, pg * PAGE))
 
     def load_page(pg):
-        s = pages.get(pg)
-        if s is not None:
+        s_ = pages.get(pg)
+        if s_ is not None:
             if lru[-1] != pg:
                 lru.remove(pg)
                 lru.append(pg)
-            return s
+            return s_
         if free_s:
-            s = free_s.pop()
+            s_ = free_s.pop()
         else:
             old = lru.pop(0)
-            s = pages.pop(old)
-        pages[pg] = s
+            s_ = pages.pop(old)
+        pages[pg] = s_
         lru.append(pg)
-        add("  s_mov_b32 s%d, 0x%x\n" % (s, pg * PAGE))
-        return s
+        page_set(s_, pg)
+        return s_
 
-    def opnd(x):
-        return "0" if x == -1 else "-1" if x == -2 else "v%d" % x
+    def ext_sgpr(e):
+        b = e // EXT_BATCH
+        s_ = ext_slot.get(b)
+        if s_ is None:
+            if len(ext_slot) < EXT_SLOTS:
+                s_ = S_EXT0 + EXT_BATCH * len(ext_slot)
+            else:
+                old = ext_lru.pop(0)
+                s_ = ext_slot.pop(old)
+            ext_slot[b] = s_
+            add("  s_load_dwordx8 s[%d:%d], s[%d:%d], 0x%x\n  s_waitcnt lgkmcnt(0)\n" % (s_, s_ + EXT_BATCH - 1, S_TAB, S_TAB + 1, b * EXT_BATCH * 4))
+        elif ext_lru[-1] != b:
+            ext_lru.remove(b)
+        if not ext_lru or ext_lru[-1] != b:
+            ext_lru.append(b)
+        return s_ + e % EXT_BATCH
 
     for ins in jp.ir:
         k = ins[0]
         if k == "g":
             add(gate_asm(ins))
-        elif k == "st" or k == "sta":
+        elif k in ("st", "sta", "stL", "staL"):
             off = ins[2] * ROW_BYTES
             pg = off // PAGE
-            if pg != st_page:
-                add("  s_mov_b32 s16, 0x%x\n" % (pg * PAGE))
-                st_page = pg
-            add("  buffer_store_dword %s%d, v0, s[12:15], s16 offen offset:%d nt\n" % ("v" if k == "st" else "a", ins[1], off % PAGE))
-        elif k == "ld":
+            if pg != st_page[0]:
+                page_set(16, pg)
+                st_page[0] = pg
+            add("  buffer_store_dword %s%d, v0, s[12:15], s16 offen offset:%d nt\n" % ("v" if k in ("st", "stL") else "a", ins[1], off % PAGE))
+        elif k == "ld" or k == "ldL":
             off = ins[2] * ROW_BYTES
-            s = load_page(off // PAGE)
-            add("  buffer_load_dword v%d, v0, s[12:15], s%d offen offset:%d\n" % (ins[1], s, off % PAGE))
+            s_ = load_page(off // PAGE)
+            add("  buffer_load_dword v%d, v0, s[12:15], s%d offen offset:%d\n" % (ins[1], s_, off % PAGE))
+        elif k == "ldx":
+            add("  buffer_load_dword v%d, v0, s[12:15], s%d offen\n" % (ins[1], ext_sgpr(ins[2])))
         elif k == "w":
             add("  s_waitcnt vmcnt(%d)\n" % ins[1])
         elif k == "aw":
@@ -902,26 +1289,54 @@ def to_asm(jp: JitProgram) -> str:
             add("  v_or3_b32 v%d, v%d, v%d, v%d\n" % (ins[1], ins[1], ins[2], ins[3]))
         elif k == "accc":
             add("  v_mov_b32 v%d, -1\n" % ins[1])
+        elif k == "loop":
+            _, K, R, base, tab = ins
+            n_ext_pad = max(EXT_BATCH, (tab.shape[1] + EXT_BATCH - 1) // EXT_BATCH * EXT_BATCH)
+            tables.append((loop_no[0], n_ext_pad, tab))
+            # s[44:45] = address of the table (pc-relative: it sits behind s_endpgm in this section); s[42:43] = the loop's top
+            add("  s_mov_b32 s%d, 0x%x\n  s_mov_b32 s%d, %d\n  s_getpc_b64 s[%d:%d]\n.Lanchor%d:\n"
+                "  s_add_u32 s%d, s%d, cw_ext_tab%d-.Lanchor%d\n  s_addc_u32 s%d, s%d, 0\n  s_getpc_b64 s[%d:%d]\n"
+                % (S_ITER, base * ROW_BYTES, S_COUNT, K, S_TAB, S_TAB + 1, loop_no[0], S_TAB, S_TAB, loop_no[0], loop_no[0], S_TAB + 1, S_TAB + 1,
+                   S_TOP, S_TOP + 1))
+            in_loop[0] = True
+            in_loop.append((R, n_ext_pad))
+            reset_pages()
+        elif k == "endloop":
+            R, n_ext_pad = in_loop.pop()
+            add("  s_add_u32 s%d, s%d, 0x%x\n  s_add_u32 s%d, s%d, 0x%x\n  s_addc_u32 s%d, s%d, 0\n"
+                "  s_sub_u32 s%d, s%d, 1\n  s_cmp_lg_u32 s%d, 0\n  s_cbranch_scc0 .Ldone%d\n  s_setpc_b64 s[%d:%d]\n.Ldone%d:\n"
+                % (S_ITER, S_ITER, R * ROW_BYTES, S_TAB, S_TAB, n_ext_pad * 4, S_TAB + 1, S_TAB + 1,
+                   S_COUNT, S_COUNT, S_COUNT, loop_no[0], S_TOP, S_TOP + 1, loop_no[0]))
+            in_loop[0] = False
+            loop_no[0] += 1
+            reset_pages()
         else:
             raise ValueError(k)
     # flags: one dword per lane = 32 instances; fallback masks / R1CS flags are uint64 per group of 64 instances, i.e. dword
     # chunk * 64 + lane of the array
     add("  s_lshl_b32 s17, s2, 8\n  v_add_u32 v0, s17, v0\n"
         "  global_atomic_or v0, v1, s[6:7]\n  global_atomic_or v0, v2, s[8:9]\n"
-        "  s_endpgm\n.Lend:\n.size %s, .Lend-%s\n" % (KERNEL_NAME, KERNEL_NAME))
+        "  s_endpgm\n")
+    for no, n_ext_pad, tab in tables:
+        add(".p2align 6\ncw_ext_tab%d:\n" % no)
+        for row in tab:
+            vals = [int(x) * ROW_BYTES for x in row] + [0] * (n_ext_pad - len(row))
+            for i in range(0, len(vals), 16):
+                add("  .long " + ", ".join("0x%x" % v for v in vals[i:i + 16]) + "\n")
+    add(".Lend:\n.size %s, .Lend-%s\n" % (KERNEL_NAME, KERNEL_NAME))
     add(".rodata\n.p2align 6\n.amdhsa_kernel %s\n"
         "  .amdhsa_user_sgpr_kernarg_segment_ptr 1\n  .amdhsa_system_sgpr_workgroup_id_x 1\n  .amdhsa_system_vgpr_workitem_id 0\n"
-        "  .amdhsa_next_free_vgpr %d\n  .amdhsa_accum_offset %d\n  .amdhsa_next_free_sgpr 40\n"
+        "  .amdhsa_next_free_vgpr %d\n  .amdhsa_accum_offset %d\n  .amdhsa_next_free_sgpr %d\n"
         "  .amdhsa_group_segment_fixed_size 0\n  .amdhsa_private_segment_fixed_size 0\n  .amdhsa_kernarg_size 24\n"
-        ".end_amdhsa_kernel\n" % (KERNEL_NAME, jp.n_vgpr + jp.n_agpr, jp.n_vgpr))
+        ".end_amdhsa_kernel\n" % (KERNEL_NAME, jp.n_vgpr + jp.n_agpr, jp.n_vgpr, N_SGPR))
     add(".amdgpu_metadata\n---\namdhsa.version: [1, 2]\namdhsa.kernels:\n  - .name: %s\n    .symbol: %s.kd\n"
         "    .kernarg_segment_size: 24\n    .group_segment_fixed_size: 0\n    .private_segment_fixed_size: 0\n"
-        "    .kernarg_segment_align: 8\n    .wavefront_size: 64\n    .sgpr_count: 40\n    .vgpr_count: %d\n    .agpr_count: %d\n"
+        "    .kernarg_segment_align: 8\n    .wavefront_size: 64\n    .sgpr_count: %d\n    .vgpr_count: %d\n    .agpr_count: %d\n"
         "    .max_flat_workgroup_size: 64\n    .args:\n"
         "      - {.size: 8, .offset: 0, .value_kind: global_buffer, .address_space: global}\n"
         "      - {.size: 8, .offset: 8, .value_kind: global_buffer, .address_space: global}\n"
         "      - {.size: 8, .offset: 16, .value_kind: global_buffer, .address_space: global}\n"
-        "...\n.end_amdgpu_metadata\n" % (KERNEL_NAME, KERNEL_NAME, jp.n_vgpr + jp.n_agpr, jp.n_agpr))
+        "...\n.end_amdgpu_metadata\n" % (KERNEL_NAME, KERNEL_NAME, N_SGPR, jp.n_vgpr + jp.n_agpr, jp.n_agpr))
     return "".join(L)
 
 

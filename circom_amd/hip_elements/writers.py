@@ -194,6 +194,12 @@ def write_tape(path, tapes, bittape=None, jit=None, fpjit=(), r1cs_id=None):
             assert bittape is not None and jit.code is not None and jit.n_signals == t0.n_signals
             audit = getattr(jit, "audit_code", None) or b""
             rid = r1cs_id or (0, 0)
+            # the chunk stride is an immediate of both code objects (bitjit.to_asm): it must be the row count this header carries,
+            # which every other kernel that walks the table takes as the stride (compiler.emit_jit records what it assembled)
+            for what in ("code_stride", "audit_stride"):
+                baked = getattr(jit, what, None)
+                if baked is not None and (what == "code_stride" or audit):
+                    assert baked == jit.n_slots * 256, "emitted %s %d != header rows %d x 256" % (what, baked, jit.n_slots)
             f.write(struct.pack("<10I", 2, jit.n_slots & 0xFFFFFFFF, jit.n_slots >> 32, len(jit.code), 1 if jit.check_complete else 0,
                                 jit.n_vgpr, jit.n_agpr, len(audit), rid[0], rid[1] & 0xFFFFFFFF))
             f.write(np.ascontiguousarray(jit.sig_slot, dtype="<u4").tobytes())

@@ -88,6 +88,7 @@ _SIGS = {
     "cw_emitted_checks_match": (C.c_int, [C.c_void_p]),
     "cw_batch_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "cw_batch_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "cw_batch_kernel_ms_mean": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "cw_sync": (C.c_int, [C.c_void_p]),
     "cw_get_status": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cw_get_witness": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
@@ -299,13 +300,21 @@ class Batch:
 
     def set_timing(self, on=True):
         """HIP events around the parts of run() / check_r1cs() on this batch's stream (cw_batch_set_timing)"""
-        _chk(lib().cw_batch_set_timing(self.h, 1 if on else 0))
+        _chk(lib().cw_batch_set_timing(self.h, 2 if on == "history" else 1 if on else 0))
 
     def kernel_ms(self):
         """{"ingest": ms, "eval": ms, "check": ms} of the last run / check (None: that part has not run); drains the stream"""
         out = (C.c_float * 3)()
         _chk(lib().cw_batch_kernel_ms(self.h, out))
         return {k: (float(v) if v >= 0 else None) for k, v in zip(("ingest", "eval", "check"), out)}
+
+    def kernel_ms_mean(self):
+        """the same parts averaged over every run since set_timing("history") (cw_batch_kernel_ms_mean): ({part: ms | None},
+        {part: runs averaged over})"""
+        out, cnt = (C.c_float * 3)(), (C.c_int * 3)()
+        _chk(lib().cw_batch_kernel_ms_mean(self.h, out, cnt))
+        names = ("ingest", "eval", "check")
+        return {k: (float(v) if v >= 0 else None) for k, v in zip(names, out)}, {k: int(n) for k, n in zip(names, cnt)}
 
     # -- results ------------------------------------------------------------------------------------
     def status(self) -> np.ndarray:

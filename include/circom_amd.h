@@ -151,6 +151,10 @@ int cw_check_r1cs(cw_batch *b);
  * evaluation kernel(s), ms[2] = the R1CS check; -1 for a part that has not run since timing was switched on. */
 int cw_batch_set_timing(cw_batch *b, int on);
 int cw_batch_kernel_ms(cw_batch *b, float ms[3]);
+/* on = 2 keeps the marks of the last 64 runs of the batch; cw_batch_kernel_ms_mean averages each part over every run recorded
+ * since (counts[k] = how many): the kernels' durations INSIDE a timed region, other batches in flight beside them - the figure
+ * a rocprofv3 kernel-trace average of the same region reproduces. */
+int cw_batch_kernel_ms_mean(cw_batch *b, float ms[3], int counts[3]);
 int cw_sync(cw_batch *b);
 
 /* results (synchronise the stream first) */

@@ -47,8 +47,43 @@ def run_ir(jp, rows: dict, width: int):
             raise JitHazard("instruction %d overwrites v%d while a load into it is in flight" % (i, x))
         V[x] = val
 
-    for i, ins in enumerate(jp.ir):
+    # a loop (bitjit.lower_jit(loop=True)): the body runs once per iteration with its rows relative to the iteration's base and
+    # the values from outside the iteration read through the iteration's table; NOTHING may live in a register across an
+    # iteration boundary (the allocator promises it: every register is poisoned there) and no memory operation may be in flight
+    prog = []
+    i = 0
+    ir = jp.ir
+    while i < len(ir):
+        if ir[i][0] == "loop":
+            j = i + 1
+            while ir[j][0] != "endloop":
+                j += 1
+            _, K, R, base, tab = ir[i]
+            for it in range(K):
+                prog.append((i, ("iter", it)))
+                for q in range(i + 1, j):
+                    x = ir[q]
+                    if x[0] in ("stL", "staL", "ldL"):
+                        x = (x[0][:-1], x[1], base + it * R + x[2])
+                    elif x[0] == "ldx":
+                        x = ("ld", x[1], int(tab[it][x[2]]))
+                    prog.append((q, x))
+            prog.append((j, ("iter", -1)))
+            i = j + 1
+        else:
+            prog.append((i, ir[i]))
+            i += 1
+
+    for i, ins in prog:
         k = ins[0]
+        if k == "iter":
+            if pend or done != issued - 1:
+                raise JitHazard("memory operations in flight across a loop boundary (instruction %d)" % i)
+            for r in range(3, len(V)):
+                V[r] = None
+            for r in range(len(A)):
+                A[r] = None
+            continue
         if k == "g":
             s0, s1, s2 = rd(ins[2], i), rd(ins[3], i), rd(ins[4], i)
             tt = ins[5]

@@ -356,3 +356,42 @@ def run_cli64(cli: Path, input_json: str, out_wtns: Path):
         return subprocess.run([str(cli), p, str(out_wtns)], capture_output=True, text=True)
     finally:
         os.unlink(p)
+
+
+def time_fp_mul(prime: str = "bn128", seconds_budget: float = 4.0):
+    """The "Fp mul/s" half of the metric on the host: the reference's own `Fr_mul` (generic/fr.cpp:559-637,
+    long Montgomery x long Montgomery -> Fr_rawMMul :110-164) in a dependent chain, one chain per usable core (ctypes releases
+    the GIL for the length of the call), through oracle/_ref/<prime>/libfr_shim.so (fr_shim.cpp ofr_mul_chain).  The chain's end
+    value is checked against Python integers.  Returns a dict for bench.py's cpu_baseline (never raises past the caller's try)."""
+    import threading
+    from .ref_shim import RefFr
+    so = ref_dir(prime) / "libfr_shim.so"
+    fr = RefFr(so)
+    q = fr.q
+    a, b = 0x1234567890ABCDEF1234567890ABCDEF % q, (q - 0xFEDCBA987654321) % q
+    cores, affinity, quota = host_cores()
+    n0 = 1 << 20
+    t0 = time.perf_counter()
+    got = fr.mul_chain(a, b, n0)
+    dt = max(time.perf_counter() - t0, 1e-6)
+    assert got == a * pow(b, n0, q) % q, "Fr_mul chain differs from Python integers"     # (the shim converts at its boundary)
+    single = n0 / dt
+    n = max(n0, int(single * seconds_budget * 0.8))
+    secs = [0.0] * cores
+
+    def work(k):
+        t1 = time.perf_counter()
+        fr.mul_chain(a + k, b, n)
+        secs[k] = time.perf_counter() - t1
+    th = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    wall = time.perf_counter() - t0
+    agg = sum(n / s for s in secs if s > 0)
+    return {"value": agg, "unit": "Fp-mul/s", "cores": cores, "per_core": agg / cores, "single_core_alone": single, "prime": prime,
+            "kind": "reference",
+            "sample": "%d dependent Fr_mul (Montgomery x Montgomery, generic/fr.cpp --no_asm build) per core x %d cores, wall %.1f s; "
+                      "chain end value checked against Python integers" % (n, cores, wall)}

@@ -211,4 +211,41 @@ def test_metric_workload_sha256_2048_emitted_code_at_2M(tmp_path):
     finally:
         del os.environ["CW_R1CS_AUDIT"]
     assert (b.status() == 0).all()
+    # ... and the SAME batch through the boundary's own input format: the canonical 32-byte image of all 2^21 x
+    # 2 048 inputs (137 GB, built on the device as bench.py does) through cw_bits_ingest_kernel - the dominant kernel of the
+    # benchmark step at the benchmark shape.  Every digest must equal the packed run's, the goldens' full .wtns files again.
+    import torch
+    dev = torch.device("cuda", 0)
+    pub = torch.empty((B, c.n_public, 32), dtype=torch.uint8, device=dev)
+    b.public_signals_device(pub.data_ptr()); b.sync()
+    assert not bool(pub[:, :, 1:].any().item())
+    want_bits = pub[:, :, 0].clone()
+    del pub
+    d_m = torch.from_numpy(masks.view(np.int64)).to(dev)                          # [G][n_inputs]
+    d_in = torch.zeros((B, c.n_inputs, 32), dtype=torch.uint8, device=dev)
+    j = torch.arange(64, device=dev, dtype=torch.int64).view(1, 64, 1)
+    for g0 in range(0, G, 1024):
+        g1 = min(G, g0 + 1024)
+        d_in[g0 * 64:g1 * 64, :, 0] = ((d_m[g0:g1].unsqueeze(1) >> j) & 1).to(torch.uint8).reshape((g1 - g0) * 64, c.n_inputs)
+    del d_m
+    b2 = c.batch(B)
+    b2.set_inputs_device(d_in.data_ptr())
+    b2.run(); b2.check_r1cs(); b2.sync()
+    assert (b2.status() == 0).all()
+    pub = torch.empty((B, c.n_public, 32), dtype=torch.uint8, device=dev)
+    b2.public_signals_device(pub.data_ptr()); b2.sync()
+    assert not bool(pub[:, :, 1:].any().item()) and torch.equal(pub[:, :, 0], want_bits), "32-byte ingest and packed inputs disagree"
+    del pub, want_bits
+    for pos, vec in zip(at, vecs):
+        p = tmp_path / ("h%d.wtns" % pos)
+        b2.write_wtns(pos, p)
+        _check(vec, p.read_bytes())
+    # one instance whose input is NOT a bit in one place: the ingest must send exactly that instance to the 256-bit fallback
+    d_in[B // 3, 7, 0] = 2
+    b2.set_inputs_device(d_in.data_ptr())
+    b2.run(); b2.check_r1cs(); b2.sync()
+    st = b2.status()
+    assert (np.delete(st, B // 3) == 0).all()
+    del d_in
+    b2.close()
     b.close(); c.close()

@@ -275,3 +275,45 @@ def test_assembly_and_tape_section(tmp_path):
     cp2 = compile_program(Program(BitGadget(8)), str(tmp_path), "bg8i", sym=False, strands=(1,), bits=True, jit=False)
     assert cp2.jit is None
     rt.Circuit(cp2.tape_path, cp2.dat_path, cp2.r1cs_path).close()
+
+
+def test_chunk_stride_baked_into_both_code_objects_is_the_header_row_count(tmp_path, monkeypatch):
+    """the chunk stride is an immediate of the emitted code (rows per chunk x 256 bytes in s10).  The audit's
+    scratch rows extend the chunk, so BOTH programs must be printed with the raised row count - the one the tape header carries
+    and every other kernel that walks the table uses.  Register-starved lowerings make the audit of a small circuit spill."""
+    import functools
+    import re
+    from circom_amd import compiler
+    fc = flatten(Program(BitGadget(16)))
+    net = BB.bitblast(fc)
+    real_lower, real_asm = BJ.lower_jit, BJ.to_asm
+    lowered, strides = [], []
+
+    def starved(net_, fc_, **kw):
+        main = "audit_of" not in kw
+        # the audit gets fewer registers than the program whose table it reads: its scratch rows are what raises the row count
+        jp = real_lower(net_, fc_, n_vgpr=24 if main else 12, n_agpr=8 if main else 0, prefetch=16 if main else 4, **kw)
+        lowered.append(jp)
+        return jp
+
+    def spy(jp):
+        text = real_asm(jp)
+        strides.append((jp.is_audit, int(re.search(r"s_mov_b32 s10, (0x[0-9a-f]+)", text).group(1), 16)))
+        return text
+    monkeypatch.setattr(BJ, "lower_jit", starved)
+    monkeypatch.setattr(BJ, "to_asm", spy)
+    monkeypatch.setattr(BJ, "assemble", lambda text: b"\x7fELF" + text.encode()[:64])
+    jp = compiler.emit_jit(net, fc, True)
+    main_rows, audit_rows = (real_lower(net, fc, n_vgpr=24, n_agpr=8, prefetch=16).n_slots, lowered[1].stats["slots"])
+    assert audit_rows > main_rows, "the audit of this lowering was meant to spill scratch rows"
+    assert jp.n_slots == audit_rows
+    assert sorted(strides) == [(False, jp.n_slots * BJ.ROW_BYTES), (True, jp.n_slots * BJ.ROW_BYTES)]
+    assert jp.code_stride == jp.audit_stride == jp.n_slots * BJ.ROW_BYTES
+    # ... and the writer refuses a program whose code was printed with another stride than its header says
+    from circom_amd.hip_elements import writers
+    from circom_amd.hip_elements.lower import lower
+    from circom_amd.compiler import lower_bitplane_net
+    bt, _ = lower_bitplane_net(fc, True)
+    jp.code_stride -= BJ.ROW_BYTES * 16
+    with pytest.raises(AssertionError, match="code_stride"):
+        writers.write_tape(str(tmp_path / "x.cwt"), [lower(fc, n_strands=1, mont=False)], bt, jp, ())

@@ -645,6 +645,42 @@ def test_gpu_emitted_audit_of_a_table_somebody_changed(tmp_path, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_gpu_emitted_code_beyond_one_chunk_when_the_audit_spills(tmp_path, monkeypatch):
+    """the audit program of Sha256(64) spills scratch rows behind the table, which raises the rows per chunk -
+    the stride every kernel walks the table with, and an immediate of BOTH emitted code objects.  Three chunks (the second and
+    third sit at base + k * stride): every digest against hashlib, full witnesses from every chunk against the oracle, and
+    the emitted audit of the table (CW_R1CS_AUDIT=1) clean."""
+    import hashlib
+    monkeypatch.setenv("CW_BITS_JIT", "1")
+    cp, c = _gpu(tmp_path, Program(Sha256(64)), "sha256_64s")
+    assert cp.jit.audit_code and cp.jit.n_slots > cp.jit.stats["slots"], "this circuit's audit was expected to add scratch rows"
+    assert cp.jit.code_stride == cp.jit.audit_stride == cp.jit.n_slots * 256
+    fc = cp.flat
+    B = 2048 * 2 + 700
+    rng = np.random.default_rng(3)
+    msgs = rng.integers(0, 256, size=(B, 8), dtype=np.uint8)
+    rows = np.unpackbits(msgs, axis=1)                               # msb first, as the circuit's inputs
+    b = c.batch(B)
+    assert b.jit and b.bits_slots == cp.jit.n_slots
+    b.set_inputs(rows.tolist())
+    b.run(); b.check_r1cs(); b.sync()
+    assert (b.status() == 0).all()
+    pub = b.public_signals()
+    assert not pub[:, :256, 1:].any()
+    got = np.packbits(pub[:, :256, 0], axis=1)
+    want = np.frombuffer(b"".join(hashlib.sha256(m.tobytes()).digest() for m in msgs), dtype=np.uint8).reshape(B, 32)
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, "digest of instance %d (chunk %d) differs from hashlib" % (int(bad[0]), int(bad[0]) // 2048)
+    for i in (0, 2047, 2048, 4095, 4096, B - 1):
+        sig, failed = _flat(fc, rows[i].tolist())
+        assert failed is None and b.witness(i) == sig, i
+    monkeypatch.setenv("CW_R1CS_AUDIT", "1")
+    b.check_r1cs(); b.sync()
+    assert (b.status() == 0).all()
+    b.close(); c.close()
+
+
+@pytest.mark.gpu
 def test_gpu_sha256_two_blocks_bitplane(tmp_path, engine):
     cp, c = _gpu(tmp_path, Program(Sha256(512)), "sha256_512")
     fc = cp.flat
