@@ -215,7 +215,7 @@ def get_compiled(name: str, batch: int, cache_root: str, rank: int, dist):
         fps = compiler.emit_fpjit(tapes, fc, False if bittape is not None else "auto")
         rid = writers.write_r1cs(p(".r1cs"), fc)
         writers.write_tape(p(".cwt"), tapes, bittape, jp, fps, r1cs_id=rid)
-        json.dump(jp.stats if jp is not None else {}, open(p(".jit.json"), "w"))
+        json.dump(dict(jp.stats, code_bytes=len(jp.code), audit_code_bytes=len(jp.audit_code or b"")) if jp is not None else {}, open(p(".jit.json"), "w"))
         json.dump([dict(fp_.stats, n_strands=fp_.n_strands, code_bytes=len(fp_.code)) for fp_ in fps], open(p(".fpjit.json"), "w"))
         writers.write_dat(p(".dat"), fc)
         open(done, "w").write(fp)
@@ -1040,7 +1040,10 @@ def main():
             # alone; the evaluation's own time comes from the packed-input steps, whose ingest is a 10 us copy); instruction and
             # reload counts are the emitter's (it wrote every instruction: cp.jit_stats), counter figures from profiles/ if taken
             # on this source.
-            js = getattr(cp, "jit_stats", {}) or {}
+            js_static = getattr(cp, "jit_stats", {}) or {}
+            # what a wave EXECUTES: a looped body (one per repeated template, bitjit.lower_jit) counts once per iteration;
+            # js_static keeps the code's own size
+            js = dict(js_static, **(js_static.get("executed") or {}))
             chunks = (B + 2047) // 2048
             ek = "cw_bits_jit (emitted per circuit)"
             kern_ms = isolated["kernels_ms"]["eval"] or isolated.get("eval_only_ms") or isolated["eval_ms"]
@@ -1064,6 +1067,8 @@ def main():
                                               "GB/s_incl_re_reads": (tab_bytes + reload_bytes) / (kern_ms * 1e-3) / 1e9,
                                               "frac_incl_re_reads": (tab_bytes + reload_bytes) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          "waves": chunks, "instructions_per_wave": js.get("instructions"), "gates_per_wave": js.get("gates"),
+                         "code": {"instructions": js_static.get("instructions"), "loop": js_static.get("loop"),
+                                  "code_object_bytes": js_static.get("code_bytes")},
                          "valu_issue": {"wave_insts_per_s": valu_insts / (kern_ms * 1e-3), "peak": valu_peak, "frac": valu_insts / (kern_ms * 1e-3) / valu_peak,
                                         "valu_insts_source": valu_src, "all_instructions_per_s": insts / (kern_ms * 1e-3),
                                         "lone_wave_frac": (js.get("instructions", 0) / (kern_ms * 1e-3)) / (clk / LONE_WAVE_CLK_PER_INST)},

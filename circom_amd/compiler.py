@@ -149,6 +149,7 @@ def _emit_failure(what, ex, strict):
     warnings.warn("circom_amd: %s not emitted (%s: %s); the tape carries the interpreted program only" % (what, type(ex).__name__, str(ex)[:200]))
 
 JIT_AUTO_MIN_GATES = 20_000         # "auto": circuits below this never see batches where the emitted code wins
+JIT_LOOP_MIN_GATES = 1_500_000      # "auto": networks above this get ONE looped body per repeated template (see emit_jit)
 
 
 def emit_jit(net, fc, jit="auto"):
@@ -164,7 +165,13 @@ def emit_jit(net, fc, jit="auto"):
     # template several times (the compression blocks of SHA-256), the emitter works on a network in which those instances' input
     # signals are PORTS - every instance then has the same gates - and emits the body once, in a loop (bitjit.lower_jit).  The
     # interpreter's program keeps the fully folded network it was given.  CW_JIT_LOOP=0: straight-line code as before.
-    if os.environ.get("CW_JIT_LOOP", "1") != "0":
+    # Measured (profiles/r06a_*): the looped code of the 5-block SHA-256 is 2.4 MB instead of 13 MB but 10 % SLOWER
+    # (12.4 -> 13.6 ms at 2^21 instances): the kernel is bound by the rows it stores, ports keep the IV / the padding from folding
+    # into the first and last block (+9 % rows), and straight-line code is fetched as fast as a 2 MB body (tools/ubench_loop.hip).
+    # So "auto" rolls only what would not be practical as a straight line: networks above JIT_LOOP_MIN_GATES gates (the 53-block
+    # SHA-256: 137 MB of code unrolled, 2.4 MB + tables rolled).  CW_JIT_LOOP=1 / 0 force it on / off.
+    loop_mode = os.environ.get("CW_JIT_LOOP", "auto")
+    if loop_mode != "0" and (loop_mode == "1" or net.stats.get("gates", 0) > JIT_LOOP_MIN_GATES):
         ports, marks = bitjit.instance_ports(fc)
         if ports:
             from .hip_elements.bitblast import bitblast
@@ -181,7 +188,11 @@ def emit_jit(net, fc, jit="auto"):
     # assembled with its own row count and the header then raised to the audit's)
     ja = None
     if os.environ.get("CW_JIT_AUDIT", "1") != "0":
-        ja = bitjit.lower_jit(net, fc, audit_of=jp)
+        try:
+            ja = bitjit.lower_jit(net, fc, audit_of=jp)
+        except bitjit._AuditTooBig:
+            # (the audit's iteration wanted more scratch rows than a loop iteration of the main program has to spare)
+            ja = bitjit.lower_jit(net, fc, audit_of=jp, loop=False)
         if ja is not None:
             jp.n_slots = ja.n_slots = max(jp.n_slots, ja.n_slots)
     try:

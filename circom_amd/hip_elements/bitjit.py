@@ -478,19 +478,29 @@ class JitProgram:
         self.node_slot = None           # evaluation node -> row of the table (-1: none)
         self.audit_code = None          # code object of the stand-alone audit of this program's table (lower_jit(audit_of=))
         self.is_audit = False
+        self.loop = None                # {"base", "R", "used", "first", "K"}: the rows of the loop's iterations (lower_jit(loop=True))
+
+
+AUDIT_SCRATCH_ROWS = 128        # spare rows at the end of every iteration of a loop: scratch of the audit program's iteration
+
+
+class _AuditTooBig(Exception):
+    """the audit's iteration needs more scratch rows than the main program left per iteration"""
 
 
 OPAQUE_MIN_SIGNALS = 20000     # instances of a repeated template at least this large: loop candidates (their inputs become ports)
 LOOP_MIN_BODY_GATES = 2048
 
 
-def loop_templates(fc, min_signals: int = OPAQUE_MIN_SIGNALS):
+def loop_templates(fc, min_signals=None):
     """The reference emits ONE body per template (`<T>_<id>_run`, compiler/src/circuit_design/template.rs:160-474) and runs it
     once per instance; the candidates for that treatment here: templates instantiated at least twice with the same parameters
     whose instance (with its sub-components) has at least `min_signals` signals.  -> [(template instance id, [component
     indices in code order])], largest coverage first."""
     if not hasattr(fc, "comp_code_range") or getattr(fc, "prog", None) is None:
         return []
+    if min_signals is None:
+        min_signals = OPAQUE_MIN_SIGNALS
     insts = fc.prog.inst_list
     groups = {}
     for ci, iid in enumerate(fc.comp_inst):
@@ -501,7 +511,7 @@ def loop_templates(fc, min_signals: int = OPAQUE_MIN_SIGNALS):
     return out
 
 
-def instance_ports(fc, min_signals: int = OPAQUE_MIN_SIGNALS):
+def instance_ports(fc, min_signals=None):
     """(ports, marks) for `bitblast(fc, ports=, marks=)`: per instance of a loop candidate the ranges of its INPUT signals -
     whatever the parent wires to them (the IV constants of the first SHA-256 block, the previous block's output, the padding of
     the last) they are run-time values of the reference's template body - and the rows of the flat code where each
@@ -520,7 +530,7 @@ def instance_ports(fc, min_signals: int = OPAQUE_MIN_SIGNALS):
     return ports, marks
 
 
-def _plan_segments(net, fc, n_eval, TT, A, B, C, is_gate, live, G, flags, hoist, want_loop, al):
+def _plan_segments(net, fc, n_eval, TT, A, B, C, is_gate, live, G, flags, hoist, want_loop, al, main_loop=None, node_slot=None):
     """Order of evaluation, segment by segment.  Without a loop: ONE segment (the whole program).  With the instances of a
     repeated template found in the network (their node ranges: net.marks at FlatCircuit.comp_code_range): prologue | one segment
     per instance | epilogue, every gate ordered inside its own segment; the longest run of instances whose ordered gate lists
@@ -563,7 +573,7 @@ def _plan_segments(net, fc, n_eval, TT, A, B, C, is_gate, live, G, flags, hoist,
             if len(port_ids):
                 lo = 0
                 for k, (n0, n1) in enumerate(rng):
-                    seg[port_ids[(port_ids >= lo) & (port_ids < n0)]] = k + 1
+                    seg[port_ids[(port_ids >= lo) & (port_ids < n1)]] = k + 1      # (its own, and those of its sub-components)
                     lo = n1
         sl = seg.tolist()
         # check gates: the latest segment among their operands (wires that are inputs / ports / prologue values
@@ -621,6 +631,16 @@ def _plan_segments(net, fc, n_eval, TT, A, B, C, is_gate, live, G, flags, hoist,
             ops = np.stack([An[g], Bn[g], Cn[g]], axis=1)                       # [L][3]
             internal = gate_mask[ops] & (seg[ops] == k + 1)
             code = np.where(internal, posn[ops], np.where(ops <= 1, -1 - ops, np.int64(-3)))
+            if flags["audit"]:
+                # the audit loads its wires: an evaluation gate of the same instance is a ROW of the main program's iteration
+                # (the same local row in every iteration), only the check's own gates are positions of this program
+                wire = internal & (ops < n_eval)
+                it = k + 1 - main_loop["first"]
+                if 0 <= it < main_loop["K"]:
+                    code = np.where(wire, (np.int64(1) << 40) + node_slot[np.minimum(ops, n_eval - 1)] - (main_loop["base"] + it * main_loop["R"]), code)
+                    internal = internal | wire               # (not an external value)
+                else:
+                    internal = internal & ~wire              # an instance outside the main program's loop: plain rows
             extm = (~internal) & (ops > 1)
             flat = ops[extm]
             if len(flat):
@@ -658,11 +678,16 @@ def _plan_segments(net, fc, n_eval, TT, A, B, C, is_gate, live, G, flags, hoist,
                 best = (k, j - k + 1)
             k = j + 1
         k0, K = best
+        if flags["audit"]:
+            # the audit walks the table the main program's loop wrote: the same iterations or none
+            k0, K = main_loop["first"] - 1, main_loop["K"]
+            if len(set(digests[k0:k0 + K])) != 1:
+                continue
         L = bounds[k0 + 2] - bounds[k0 + 1]
         if dbg:
             print("loop candidate: %d instances, gates per instance %s, digests %s -> run of %d from %d" %
                   (len(rng), [bounds[k + 2] - bounds[k + 1] for k in range(len(rng))], [d.hex()[:6] for d in digests], K, k0))
-        if K < 2 or L < LOOP_MIN_BODY_GATES:
+        if K < 2 or (L < LOOP_MIN_BODY_GATES and not flags["audit"]) or L == 0:
             continue
         ext = np.stack([exts[k0 + i] for i in range(K)]) if len(exts[k0]) else np.zeros((K, 0), dtype=np.int64)
         return order, seg, bounds, {"first": k0 + 1, "K": K, "ext": ext}
@@ -739,7 +764,10 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
     fv = np.zeros(n_nodes, dtype=bool)
     fv[list(viol_set)] = True
     planned = _plan_segments(net, fc, n_eval, TT, A, B, C, is_gate, live, G,
-                             {"audit": audit, "signal": is_signal, "assert": fa, "viol": fv}, hoist, loop and not audit, al)
+                             {"audit": audit, "signal": is_signal, "assert": fa, "viol": fv}, hoist,
+                             loop and (not audit or getattr(audit_of, "loop", None) is not None), al,
+                             getattr(audit_of, "loop", None) if audit else None,
+                             np.asarray(audit_of.node_slot, dtype=np.int64) if audit else None)
     if planned is None:
         return None
     order_all, seg_of, bounds, lp = planned
@@ -855,6 +883,7 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
         if not in_body:
             emit(("ld", v, mem_slot[src]))
         elif seg_l[node] == body_seg and is_gate[node]:
+            # a row of this iteration (the audit: a wire the main program's iteration stored, or the audit's own scratch)
             emit(("ldL", v, mem_slot[node] - loop_base))
         else:
             emit(("ldx", v, ext_index[node]))     # a value from outside the iteration: its row comes from the iteration's table
@@ -984,18 +1013,30 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
 
     loop_at = -1                                  # position of the ("loop", ...) instruction in the IR
 
+    loop_info = [None]
+    outer_next = [0]
+
     def end_loop():
         nonlocal in_body, next_slot
         boundary()
-        R = next_slot - loop_base
         in_body = False
-        # the rows of the other iterations: the same local row, R rows further per iteration
-        ms0 = np.asarray([mem_slot[int(x)] for x in bodies[0]], dtype=np.int64)
-        stored_ = ms0 >= 0
-        for i in range(1, K):
-            for nd, r in zip(bodies[i][stored_].tolist(), (ms0[stored_] + i * R).tolist()):
-                mem_slot[nd] = r
-        next_slot = loop_base + K * R
+        if audit:
+            # the audit's scratch rows sit in the spare rows the main program left at the end of every iteration
+            R = audit_of.loop["R"]
+            if next_slot > loop_base + R:
+                raise _AuditTooBig()
+            next_slot = outer_next[0]
+        else:
+            used = next_slot - loop_base
+            R = used + (AUDIT_SCRATCH_ROWS if (fuse_check and fc.constraints) else 0)
+            # the rows of the other iterations: the same local row, R rows further per iteration
+            ms0 = np.asarray([mem_slot[int(x)] for x in bodies[0]], dtype=np.int64)
+            stored_ = ms0 >= 0
+            for i in range(1, K):
+                for nd, r in zip(bodies[i][stored_].tolist(), (ms0[stored_] + i * R).tolist()):
+                    mem_slot[nd] = r
+            next_slot = loop_base + K * R
+            loop_info[0] = {"base": loop_base, "R": R, "used": used, "first": lp["first"], "K": K}
         tab = np.asarray([[mem_slot[al[int(nd)]] for nd in row] for row in ext_nodes], dtype=np.int64).reshape(K, -1)
         assert (tab >= 0).all(), "a value the loop reads from outside its iteration has no row"
         ir[loop_at] = ("loop", K, R, loop_base, tab.astype(np.uint32))
@@ -1004,7 +1045,12 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
     for p in range(n_ops):
         if p == b0:
             boundary()
-            loop_base = next_slot
+            if audit:
+                outer_next[0] = next_slot
+                loop_base = audit_of.loop["base"]
+                next_slot = loop_base + audit_of.loop["used"]
+            else:
+                loop_base = next_slot
             loop_at = len(ir)
             emit(("loop",))                       # (filled in at the end of the body)
             in_body = True
@@ -1103,6 +1149,7 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
     jp = JitProgram()
     jp.ir = ir
     jp.n_slots = (next_slot + 15) // 16 * 16
+    jp.loop = loop_info[0]
     if audit:
         jp.sig_slot = audit_of.sig_slot
         jp.n_signals, jp.n_inputs, jp.input_start = audit_of.n_signals, audit_of.n_inputs, audit_of.input_start

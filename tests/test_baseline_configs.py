@@ -221,6 +221,8 @@ def test_metric_workload_sha256_2048_emitted_code_at_2M(tmp_path):
     assert not bool(pub[:, :, 1:].any().item())
     want_bits = pub[:, :, 0].clone()
     del pub
+    b.close()                                                        # (its table: the image below needs the room)
+    torch.cuda.empty_cache()
     d_m = torch.from_numpy(masks.view(np.int64)).to(dev)                          # [G][n_inputs]
     d_in = torch.zeros((B, c.n_inputs, 32), dtype=torch.uint8, device=dev)
     j = torch.arange(64, device=dev, dtype=torch.int64).view(1, 64, 1)
@@ -236,6 +238,7 @@ def test_metric_workload_sha256_2048_emitted_code_at_2M(tmp_path):
     b2.public_signals_device(pub.data_ptr()); b2.sync()
     assert not bool(pub[:, :, 1:].any().item()) and torch.equal(pub[:, :, 0], want_bits), "32-byte ingest and packed inputs disagree"
     del pub, want_bits
+    torch.cuda.empty_cache()
     for pos, vec in zip(at, vecs):
         p = tmp_path / ("h%d.wtns" % pos)
         b2.write_wtns(pos, p)
@@ -248,4 +251,5 @@ def test_metric_workload_sha256_2048_emitted_code_at_2M(tmp_path):
     assert (np.delete(st, B // 3) == 0).all()
     del d_in
     b2.close()
-    b.close(); c.close()
+    c.close()
+    torch.cuda.empty_cache()

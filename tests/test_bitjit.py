@@ -317,3 +317,122 @@ def test_chunk_stride_baked_into_both_code_objects_is_the_header_row_count(tmp_p
     jp.code_stride -= BJ.ROW_BYTES * 16
     with pytest.raises(AssertionError, match="code_stride"):
         writers.write_tape(str(tmp_path / "x.cwt"), [lower(fc, n_strands=1, mont=False)], bt, jp, ())
+
+
+# ---- one body per repeated template: loops -------------------------------------------------------------------------------------
+@template
+def MixBlock(c, n):
+    """a small stand-in for a compression block: state `hin`, message `inp` -> new state; adders, xor3 / maj cells, constants"""
+    hin = c.input("hin", n)
+    inp = c.input("inp", n)
+    out = c.output("out", n)
+    x3 = c.component("x3", Xor3(n))
+    mj = c.component("mj", Maj_t(n))
+    for k in range(n):
+        c.set(x3["a"][k], hin[k]); c.set(x3["b"][k], inp[(k + 3) % n]); c.set(x3["c"][k], hin[(k + 5) % n])
+        c.set(mj["a"][k], inp[k]); c.set(mj["b"][k], hin[(k + 1) % n]); c.set(mj["c"][k], inp[(k + 7) % n])
+    s1 = c.component("s1", BinSum(n, 3))
+    for k in range(n):
+        c.set(s1["in"][0][k], x3["out"][k]); c.set(s1["in"][1][k], mj["out"][k]); c.set(s1["in"][2][k], (0x5A5A5A5A >> k) & 1)
+    s2 = c.component("s2", BinSum(n, 2))
+    for k in range(n):
+        c.set(s2["in"][0][k], s1["out"][k]); c.set(s2["in"][1][k], hin[k])
+    for k in range(n):
+        c.set(out[k], s2["out"][k])
+
+
+@template
+def MixChain(c, n, blocks):
+    """`blocks` instances of one template in a chain: the first reads constants where the others read their predecessor, the
+    last reads constants where the others read inputs - the shape of circomlib's Sha256 (IV, padding)"""
+    msg = c.input("msg", n * (blocks - 1) + n // 2)
+    out = c.output("out", n)
+    prev = None
+    for i in range(blocks):
+        b = c.component("blk", MixBlock(n), i)
+        for k in range(n):
+            c.set(b["hin"][k], ((0x6A09E667 >> k) & 1) if prev is None else prev["out"][(k + 1) % n])
+            j = i * n + k
+            c.set(b["inp"][k], msg[j] if j < n * (blocks - 1) + n // 2 else (k & 1))
+        prev = b
+    for k in range(n):
+        c.set(out[k], prev["out"][k])
+
+
+from circom_amd.circuits.sha256 import Xor3, Maj_t, BinSum  # noqa: E402
+
+
+@pytest.mark.parametrize("nv,na,pf", [(256, 256, 384), (28, 8, 16), (14, 0, 4)])
+def test_repeated_template_becomes_one_looped_body(nv, na, pf, monkeypatch):
+    """ONE body per repeated template (template.rs:160-474): the instances' input signals become ports, the gate lists of the
+    instances are isomorphic, the emitter prints one of them inside a loop with per-iteration rows and a table of the rows its
+    ports read.  The replay (registers poisoned at every iteration boundary) reproduces the flat code for every signal, the
+    fused check and the looped audit flag exactly the violating instances, under generous and starved register files."""
+    monkeypatch.setattr(BJ, "OPAQUE_MIN_SIGNALS", 40)
+    monkeypatch.setattr(BJ, "LOOP_MIN_BODY_GATES", 16)
+    fc = flatten(Program(MixChain(16, 5)))
+    ports, marks = BJ.instance_ports(fc)
+    assert ports and len(ports) >= 5             # (at this threshold the blocks' sub-components are candidates too: nested ports)
+    net = BB.bitblast(fc, ports=ports, marks=marks)
+    assert len(net.port_src) >= 5 * 32
+    jp = BJ.lower_jit(net, fc, n_vgpr=nv, n_agpr=na, prefetch=pf)
+    assert jp.loop and jp.loop["K"] == 5 and jp.stats["loop"]["iterations"] == 5
+    straight = BJ.lower_jit(net, fc, n_vgpr=nv, n_agpr=na, prefetch=pf, loop=False)
+    assert straight.loop is None and jp.stats["instructions"] < straight.stats["instructions"] / 3
+    assert jp.stats["executed"]["gates"] == straight.stats["gates"]
+    rows = _rows(fc, 48, 13)
+    mem, fb, bad = _run(jp, fc, rows)
+    assert fb == 0 and bad == 0
+    _check_witnesses(jp, fc, rows, mem)
+    mem_s, _, _ = _run(straight, fc, rows)
+    _check_witnesses(straight, fc, rows, mem_s)
+    # the audit of the looped program's table: looped as well, its scratch inside the spare rows of every iteration
+    ja = BJ.lower_jit(net, fc, n_vgpr=nv, n_agpr=na, prefetch=pf, audit_of=jp)
+    assert ja is not None and any(i[0] == "loop" for i in ja.ir) and ja.n_slots >= jp.n_slots
+    table = {k: v for k, v in mem.items() if k < jp.n_slots}
+    ja_run = type("J", (), {"ir": ja.ir, "n_slots": ja.n_slots, "n_vgpr": ja.n_vgpr, "n_agpr": ja.n_agpr})
+    _, fb2, bad2 = run_ir(ja_run, dict(table), 48)
+    assert fb2 == 0 and bad2 == 0
+    rng = random.Random(3)
+    cand = [s_ for s_ in range(1, fc.n_signals) if not fc.main_input_start <= s_ < fc.main_input_start + fc.n_main_inputs
+            and any(s_ in A or s_ in B_ or s_ in C for A, B_, C in fc.constraints)]
+    for victim in rng.sample(cand, 6):
+        t2 = dict(table)
+        t2[int(jp.sig_slot[victim])] ^= sum(1 << i for i in (0, 17, 46))
+        _, _, bad3 = run_ir(ja_run, t2, 48)
+        for i in range(48):
+            sig = [(t2[int(jp.sig_slot[s])] >> i) & 1 for s in range(fc.n_signals)]
+            assert bool((bad3 >> i) & 1) == (check_r1cs(fc.fp.q, fc.constraints, sig) is not None), (victim, i)
+    # both programs assemble; the looped one carries its row tables behind the code
+    if nv == 256 and os.path.exists("/opt/rocm/lib/llvm/bin/clang"):      # (the starved register files are not launchable shapes)
+        text = BJ.to_asm(jp)
+        assert "cw_ext_tab0:" in text and "s_setpc_b64" in text and text.count("s_load_dwordx8") >= 1
+        assert BJ.assemble(text)[:4] == b"\x7fELF" and BJ.assemble(BJ.to_asm(ja))[:4] == b"\x7fELF"
+
+
+def test_instances_wired_differently_share_no_loop_when_their_gates_differ(monkeypatch):
+    """the loop is only formed over instances whose ordered gate lists are isomorphic: a chain whose middle instance is a
+    different template instance (other parameter) keeps straight-line code - and still evaluates correctly through its ports"""
+    monkeypatch.setattr(BJ, "OPAQUE_MIN_SIGNALS", 40)
+    monkeypatch.setattr(BJ, "LOOP_MIN_BODY_GATES", 16)
+
+    @template
+    def Odd(c):
+        msg = c.input("msg", 40)
+        out = c.output("out", 16)
+        a = c.component("a", MixBlock(16))
+        b = c.component("b", MixBlock(16))
+        for k in range(16):
+            c.set(a["hin"][k], msg[k]); c.set(a["inp"][k], msg[16 + k])
+        for k in range(16):
+            c.set(b["hin"][k], a["out"][k]); c.set(b["inp"][k], a["out"][(k + 2) % 16] if k < 8 else msg[32 + k - 8])
+        for k in range(16):
+            c.set(out[k], b["out"][k])
+    fc = flatten(Program(Odd()))
+    ports, marks = BJ.instance_ports(fc)
+    net = BB.bitblast(fc, ports=ports, marks=marks)
+    jp = BJ.lower_jit(net, fc)
+    rows = _rows(fc, 32, 4)
+    mem, fb, bad = _run(jp, fc, rows)
+    assert fb == 0 and bad == 0
+    _check_witnesses(jp, fc, rows, mem)          # (two isomorphic instances: a loop of two, or none - either way exact)
