@@ -196,7 +196,7 @@ def get_compiled(name: str, batch: int, cache_root: str, rank: int, dist):
                 os.replace(p(ext) + ".tmp", p(ext))
     if rank == 0 and not cached:
         os.makedirs(d, exist_ok=True)
-        bittape = None if os.environ.get("CW_BITS", "1") == "0" else compiler.lower_bitplane(fc)
+        bittape, bitnet = (None, None) if os.environ.get("CW_BITS", "1") == "0" else compiler.lower_bitplane_net(fc)
         mont = compiler.choose_mont(fc)     # arithmetic circuits keep their signals in Montgomery form on the device
         if os.environ.get("CW_MONT"):
             mont = os.environ["CW_MONT"] != "0"
@@ -208,8 +208,8 @@ def get_compiled(name: str, batch: int, cache_root: str, rank: int, dist):
             # strands that would mostly wait for one chain of calls (BigMultModP = one long_div + a few rows): the single-strand
             # variant - which has an emitted form - goes into the tape too, and cw_batch_create prefers it
             tapes.insert(0, lower(fc, n_strands=1, mont=mont))
-        jp = compiler.emit_jit(compiler.lower_bitplane.net, fc) if bittape is not None else None     # the same network as emitted code
-        compiler.lower_bitplane.net = None
+        jp = compiler.emit_jit(bitnet, fc) if bittape is not None else None     # the same network as emitted code
+        del bitnet
         # arithmetic circuits: the rows of every strand variant as emitted code as well (hip_elements/fpjit.py); schedules with
         # run-time functions on several strands / with the native long_div (config 5's verifier) run on the interpreting kernel
         fps = compiler.emit_fpjit(tapes, fc, False if bittape is not None else "auto")
@@ -374,6 +374,12 @@ def auto_in_flight(bitmode: bool, B: int, lanes: int) -> int:
 def in_flight_for(batch) -> int:
     """... and a single-strand emitted program on a chip-filling batch (one wave per SIMD per batch) wants a third batch in
     flight: Poseidon(2) x 65 536: 2 -> 59.2 M, 3 -> 62.1 M, 4 -> 58.4 M witnesses/s (tools/fpjit_poseidon_inflight.sh)"""
+    if batch.bitmode and getattr(batch, "jit", False) and (batch.n + 2047) // 2048 >= 1024:
+        # emitted bit-plane code on a chip-filling batch: the ingest (HBM reads at the read roof) and the emitted kernel (HBM
+        # writes) of two batches in flight slow each other down exactly as much as they overlap - 35.4 ms per step either way
+        # (profiles/r05r_*, r06a_*: 35.38 in flight vs 22.17 + 13.15 alone) - so the steps run one after the other: every
+        # kernel's in-step duration is then its own, and the step is the sum of its kernels
+        return 1
     n = auto_in_flight(batch.bitmode, batch.n, batch.lanes)
     if not batch.bitmode and getattr(batch, "emitted", False) and batch.strands == 1 and (batch.n + 63) // 64 >= 1024:
         n = max(n, 3)

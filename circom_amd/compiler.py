@@ -99,26 +99,24 @@ BITS_AUTO_MIN_SIGNALS_PER_GATE = 16     # "auto" wants at least one gate per 16 
 BITS_KEEP_STRANDS_BELOW = 200_000       # signals: smaller circuits keep every strand variant next to the bit program
 
 
-def lower_bitplane(fc: FlatCircuit, bits="auto"):
-    """The bit-plane program of a circuit whose signals are all boolean for 0/1 inputs (SHA-256 and friends), or None.
-    bits: True = whenever the analysis succeeds, False = never, "auto" = only for circuits large enough to matter (an
-    instance whose inputs are not 0/1 is re-run by the 256-bit schedule, so tiny arithmetic circuits gain nothing)."""
-    lower_bitplane.net = None         # the gate network of this call, for emit_jit (read it right after the call: not re-entrant;
-                                      # lower_bitplane_net() below returns both)
+def lower_bitplane_net(fc: FlatCircuit, bits="auto"):
+    """(bit-plane program | None, its gate network | None) of a circuit whose signals are all boolean for 0/1 inputs (SHA-256 and
+    friends).  bits: True = whenever the analysis succeeds, False = never, "auto" = only for circuits large enough to matter
+    (an instance whose inputs are not 0/1 is re-run by the 256-bit schedule, so tiny arithmetic circuits gain nothing).
+    The network goes to the code emitter (emit_jit)."""
     if bits is False or (bits == "auto" and fc.n_signals < BITS_AUTO_MIN_SIGNALS) or fc.n_main_inputs == 0:
-        return None
+        return None, None
     if (fc.code["op"] == O.LOG).any():
-        return None         # logged values live in the 256-bit table (hidden signals); the bit table has no place for them
+        return None, None   # logged values live in the 256-bit table (hidden signals); the bit table has no place for them
     from .hip_elements.bitblast import bitblast
     from .hip_elements.bitsched import lower_bits
     net = bitblast(fc)
     if net is None:
-        return None
+        return None, None
     # Evidence that the circuit really is bit-level, tested BEFORE the mapping and the two scheduling passes (ADVICE r3: an
     # arithmetic circuit with range checks used to pay the whole lowering just to be rejected)
     if bits == "auto" and net.stats["gates"] * BITS_AUTO_MIN_SIGNALS_PER_GATE < fc.n_signals:
-        return None
-    lower_bitplane.net = net
+        return None, None
     from .hip_elements.bitmap import map_network
     bt = lower_bits(map_network(net), fc)
     # Evidence that the circuit really is bit-level: the analysis only proves "boolean IF the inputs are 0/1" - a Num2Bits or
@@ -126,18 +124,13 @@ def lower_bitplane(fc: FlatCircuit, bits="auto"):
     # would then send every instance through the non-boolean fallback.  A bit-level circuit has gates in proportion to its
     # signals (SHA-256: 0.7 per signal).
     if bt is not None and bits == "auto" and bt.stats["gates"] * BITS_AUTO_MIN_SIGNALS_PER_GATE < fc.n_signals:
-        return None
-    return bt
-
-
-lower_bitplane.net = None           # the gate network of the last call (compile_program hands it to the code emitter)
-
-
-def lower_bitplane_net(fc: FlatCircuit, bits="auto"):
-    """(bit-plane program | None, its gate network | None) - the re-entrant form of lower_bitplane"""
-    bt = lower_bitplane(fc, bits)
-    net, lower_bitplane.net = lower_bitplane.net, None
+        return None, None
     return bt, (net if bt is not None else None)
+
+
+def lower_bitplane(fc: FlatCircuit, bits="auto"):
+    """the bit-plane program alone (see lower_bitplane_net)"""
+    return lower_bitplane_net(fc, bits)[0]
 
 
 def _emit_failure(what, ex, strict):
@@ -299,9 +292,9 @@ def compile_program(prog: Program, outdir: str, name: str, sym: bool = True, str
         if sym:
             writers.write_sym(p64(".sym"), fc)
         return Compiled(name, outdir, p64(".cwt"), p64(".dat"), p64(".r1cs"), p64(".sym"), fc, t64)
-    bittape = None if os.environ.get("CW_BITS", "1") == "0" else lower_bitplane(fc, bits)      # CW_BITS=0: no bit program in the tape
-    jp = emit_jit(lower_bitplane.net, fc, jit) if bittape is not None else None
-    lower_bitplane.net = None
+    bittape, net = (None, None) if os.environ.get("CW_BITS", "1") == "0" else lower_bitplane_net(fc, bits)   # CW_BITS=0: no bit program in the tape
+    jp = emit_jit(net, fc, jit) if bittape is not None else None
+    del net
     if bittape is not None:
         # the 256-bit schedule serves the instances re-run with non-boolean inputs - possibly the whole batch (a caller that
         # feeds field-valued inputs): small circuits keep their multi-strand variants, for a 1M-signal circuit one

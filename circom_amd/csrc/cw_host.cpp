@@ -267,6 +267,7 @@ struct cw_circuit {
     std::vector<FpJit> fpjit;              // emitted code of strand variants (at most one per strand count)
     uint32_t n_dat_consts = 0xFFFFFFFFu, n_io_templates = 0;   // sections of the .dat (0xFFFFFFFF: constants count unknown)
     struct IoDef { uint32_t offset = 0, size = 0, bus_id = 0; std::vector<uint32_t> lengths; };
+    std::vector<std::vector<IoDef>> bus_map;           // the .dat's bus-field map: per bus instance its fields (load_dat)
     struct IoTemplate { uint32_t id = 0; std::vector<IoDef> defs; };
     std::vector<IoTemplate> io_map;        // TemplateInstanceIOMap read from the .dat (Mixed component clusters)
     std::vector<uint32_t> consts;          // n_consts * 8
@@ -1214,7 +1215,40 @@ static int load_dat(cw_circuit *c, const char *path) {
         }
         c->io_map.push_back(std::move(t));
     }
-    if (at != nw) return fail(CW_EIO, ".dat: bytes behind the io-map (bus-field maps are not supported)");
+    // the bus-field map (c_code_generator.rs:740-794, main.cpp:95-121): per bus instance the number of fields and per field
+    // {offset inside the bus, number of dimensions - 1, dimensions[1..], size of one element, id of the field's own bus}.  The
+    // reference binary reads get_size_of_bus_field_map() entries; here the section runs to the end of the file.  Like the
+    // io-map it is validated and kept (cw_bus_map_size / cw_bus_field), never needed by the evaluator.
+    c->bus_map.clear();
+    while (at < nw) {
+        const uint32_t nf = w32[at++];
+        if (nf > 65536) return fail(CW_EIO, ".dat bus-field map: implausible number of fields");
+        std::vector<cw_circuit::IoDef> fields;
+        for (uint32_t d = 0; d < nf; d++) {
+            if (at + 2 > nw) return fail(CW_EIO, ".dat bus-field map truncated");
+            cw_circuit::IoDef def;
+            def.offset = w32[at];
+            const uint32_t nl = w32[at + 1];
+            at += 2;
+            if (nl > 16 || at + nl + 2 > nw) return fail(CW_EIO, ".dat bus-field map truncated");
+            def.lengths.assign(w32.begin() + at, w32.begin() + at + nl);
+            at += nl;
+            def.size = w32[at];
+            def.bus_id = w32[at + 1];
+            at += 2;
+            uint64_t span = def.size;
+            for (uint32_t l : def.lengths) span *= std::max<uint32_t>(l, 1);
+            if (def.size == 0 || def.offset >= c->n_signals || span > c->n_signals)
+                return fail(CW_EIO, ".dat bus-field map: field definition out of range");
+            fields.push_back(std::move(def));
+        }
+        c->bus_map.push_back(std::move(fields));
+    }
+    // a field's own bus is an EARLIER entry (a nested bus is completed before the bus that holds it; 0 also stands for "a signal")
+    for (size_t bi = 0; bi < c->bus_map.size(); bi++)
+        for (const cw_circuit::IoDef &f : c->bus_map[bi])
+            if (f.bus_id >= c->bus_map.size() || (f.bus_id && f.bus_id >= bi))
+                return fail(CW_EIO, ".dat bus-field map: a field refers to a bus that is not an earlier entry");
     return CW_OK;
 }
 
@@ -1458,6 +1492,18 @@ extern "C" int64_t cw_io_map_offset(const cw_circuit *c, uint32_t template_id, u
     for (const auto &t : c->io_map)
         if (t.id == template_id) return signal_code < t.defs.size() ? (int64_t)t.defs[signal_code].offset : -1;
     return -1;
+}
+// get_size_of_bus_field_map() and one field of the map (Circom_Circuit::busInsId2FieldInfo, circom.hpp:42; main.cpp:95-121)
+extern "C" uint32_t cw_bus_map_size(const cw_circuit *c) { return c ? (uint32_t)c->bus_map.size() : 0; }
+extern "C" int cw_bus_field(const cw_circuit *c, uint32_t bus_id, uint32_t field, uint32_t *offset, uint32_t *size, uint32_t *field_bus_id,
+                            uint32_t *n_lengths) {
+    if (!c || bus_id >= c->bus_map.size() || field >= c->bus_map[bus_id].size()) return fail(CW_EINVAL, "cw_bus_field: no such bus / field");
+    const cw_circuit::IoDef &f = c->bus_map[bus_id][field];
+    if (offset) *offset = f.offset;
+    if (size) *size = f.size;
+    if (field_bus_id) *field_bus_id = f.bus_id;
+    if (n_lengths) *n_lengths = (uint32_t)f.lengths.size();
+    return CW_OK;
 }
 extern "C" uint32_t cw_n_signals(const cw_circuit *c) { return c->n_signals - c->n_logv; }     // the circuit's signals (hidden log values excluded)
 extern "C" uint32_t cw_n_log_statements(const cw_circuit *c) { return c ? (uint32_t)c->logs.size() : 0; }

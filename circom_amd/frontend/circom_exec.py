@@ -1313,6 +1313,17 @@ def build_program(archive: Archive, prime="bn128", inspect=False):
         prog.public = tuple(expanded)
         prog._reorder_main_public()
     _qualify_main_bus_inputs(prog)
+    # the bus-field map of the `.dat` (c_code_generator.rs:740-794; filled by build.rs:601-626 get_info_buses): per bus instance -
+    # in the order the layouts were completed, a nested bus before the one that holds it - its fields in declaration order:
+    # (offset inside the bus, dimensions, size of ONE element, id of the field's own bus | None, name)
+    ids = {id(lay): i for i, lay in enumerate(world._bus_layouts.values())}
+    prog.bus_field_map = []
+    for lay in world._bus_layouts.values():
+        fields = []
+        for fname in lay.order:
+            off, dims, sub = lay.fields[fname]
+            fields.append((int(off), tuple(int(d) for d in dims), int(sub.size) if sub is not None else 1, ids[id(sub)] if sub is not None else None, fname))
+        prog.bus_field_map.append(fields)
     return prog
 
 

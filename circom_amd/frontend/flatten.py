@@ -129,6 +129,7 @@ class FlatCircuit:
         self.code = {k: (np.concatenate(v) if v else np.zeros(0, dtype=np.int64)) for k, v in chunks.items()}
         self.constraints = cons
         self.io_map = self._build_io_map()
+        self.bus_field_map = list(getattr(self.prog, "bus_field_map", ()))   # (the text front-end's buses; the eDSL has none)
         self.log_strings = list(getattr(self.prog, "log_strings", ()))
         self.n_log_values = int(((self.code["op"] == O.LOG) & (self.code["ak"] != O.K_NONE)).sum())
 

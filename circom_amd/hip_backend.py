@@ -19,9 +19,9 @@ def lower_cwf(cwf_path: str, outdir: str, name: str, strands=(1, 4, 16), bits="a
     from .hip_elements.lower import lower
     fc = read_cwf(cwf_path)
     os.makedirs(outdir, exist_ok=True)
-    bittape = None if os.environ.get("CW_BITS", "1") == "0" else compiler.lower_bitplane(fc, bits)
-    jp = compiler.emit_jit(compiler.lower_bitplane.net, fc) if bittape is not None else None      # the gate network as emitted code
-    compiler.lower_bitplane.net = None
+    bittape, net = (None, None) if os.environ.get("CW_BITS", "1") == "0" else compiler.lower_bitplane_net(fc, bits)
+    jp = compiler.emit_jit(net, fc) if bittape is not None else None      # the gate network as emitted code
+    del net
     mont = False if bittape is not None else compiler.choose_mont(fc)
     if bittape is not None and fc.n_signals >= compiler.BITS_KEEP_STRANDS_BELOW:
         strands = (1,)

@@ -74,14 +74,31 @@ def write_dat(path, fc: FlatCircuit, witness2signal=None):
         f.write(np.asarray(witness2signal, dtype="<u8").tobytes())
         f.write(b"".join(dat_constant(v, fc.fp) for v in fc.constants))
         f.write(dat_io_map(getattr(fc, "io_map", ())))
+        f.write(dat_bus_field_map(getattr(fc, "bus_field_map", ())))
     return size
+
+
+def dat_bus_field_map(buses) -> bytes:
+    """bus-field map, the last section of the `.dat` (c_code_generator.rs:740-794 `generate_dat_bus_field_info`; reader
+    main.cpp:95-121): per bus instance the number of fields and, per field, offset | number of dimensions - 1 (0 for a scalar)
+    | dimensions[1..] | size of one element | id of the field's own bus (0 when it is a signal: the reference writes 0 for
+    None) - all u32 little endian.  The reference binary reads get_size_of_bus_field_map() entries; cw_load reads to the
+    end of the file.  Every access is resolved at trace time here, so - like the io-map - the section only matters for the
+    files: the reference runtime loads a `.dat` of a circuit with buses, and the loader validates it."""
+    out = []
+    for fields in buses:
+        out.append(struct.pack("<I", len(fields)))
+        for offset, dims, size, bus, _name in fields:
+            out.append(struct.pack("<II", offset, max(len(dims) - 1, 0)))
+            out.extend(struct.pack("<I", d) for d in dims[1:])
+            out.append(struct.pack("<II", size, bus or 0))
+    return b"".join(out)
 
 
 def dat_io_map(io_map) -> bytes:
     """io-map section of the `.dat` (c_code_generator.rs:681-738 `generate_dat_io_signals_info`; reader main.cpp:60-92):
     the template ids, then per template: number of io signals and, per signal, offset | number of lengths - 1 (0 for a
-    scalar) | lengths[1..] | element size | bus id - all u32 little endian.  (The bus-field map that follows it in the
-    reference is empty here: the front-end has no buses.)"""
+    scalar) | lengths[1..] | element size | bus id - all u32 little endian.  (The bus-field map follows: dat_bus_field_map.)"""
     out = [struct.pack("<I", tid) for tid, _ in io_map]
     for _, defs in io_map:
         out.append(struct.pack("<I", len(defs)))

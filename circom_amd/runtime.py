@@ -49,6 +49,8 @@ _SIGS = {
     "cw_n_signals": (C.c_uint32, [C.c_void_p]),
     "cw_io_map_size": (C.c_uint32, [C.c_void_p]),
     "cw_io_map_offset": (C.c_int64, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "cw_bus_map_size": (C.c_uint32, [C.c_void_p]),
+    "cw_bus_field": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32] + [C.POINTER(C.c_uint32)] * 4),
     "cw_n_witness": (C.c_uint32, [C.c_void_p]),
     "cw_n_inputs": (C.c_uint32, [C.c_void_p]),
     "cw_set_witness_list": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]),

@@ -59,6 +59,13 @@ uint32_t cw_n_signals(const cw_circuit *c);          /* get_total_signal_no() */
  * read, validated and exposed because the file format carries it. */
 uint32_t cw_io_map_size(const cw_circuit *c);
 int64_t cw_io_map_offset(const cw_circuit *c, uint32_t template_id, uint32_t signal_code);
+/* get_size_of_bus_field_map(): bus instances described in the .dat's bus-field map (c_code_generator.rs:740-794;
+ * Circom_Circuit::busInsId2FieldInfo, circom.hpp:42; reader main.cpp:95-121), and one field of one of them: its offset inside
+ * the bus, the size of one element, the id of the field's own bus (0: a signal, as the reference writes it) and the number of
+ * dimensions behind the first.  Read, validated and exposed because the file format carries it (CW_EINVAL: no such field). */
+uint32_t cw_bus_map_size(const cw_circuit *c);
+int cw_bus_field(const cw_circuit *c, uint32_t bus_id, uint32_t field, uint32_t *offset, uint32_t *size, uint32_t *field_bus_id,
+                 uint32_t *n_lengths);
 uint32_t cw_n_witness(const cw_circuit *c);          /* get_size_of_witness() */
 uint32_t cw_n_inputs(const cw_circuit *c);           /* get_main_input_signal_no() */
 /* The witness of a SIMPLIFIED constraint system (the reference's default --O1, constraint_list/src/constraint_simplification.rs,

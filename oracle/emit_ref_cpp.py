@@ -288,7 +288,7 @@ def emit(fc, path, hashmap_size: int, n_witness=None):
     if not W64:
         out.append("uint get_size_of_constants() {return %d;}" % len(fc.constants))
     out.append("uint get_size_of_io_map() {return %d;}" % len(getattr(fc, "io_map", ())))
-    out.append("uint get_size_of_bus_field_map() {return 0;}")
+    out.append("uint get_size_of_bus_field_map() {return %d;}" % len(getattr(fc, "bus_field_map", ())))
     # generate_function_release_memory_component, c_code_generator.rs:914-933
     out.append("void release_memory_component(Circom_CalcWit* ctx, uint pos) {{ if (pos != 0){{ if(ctx->componentMemory[pos].subcomponents) "
                "delete []ctx->componentMemory[pos].subcomponents; ctx->componentMemory[pos].subcomponents = NULL; }} }}")

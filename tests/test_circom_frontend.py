@@ -475,6 +475,77 @@ component main = Main();
     assert failed is None and sig[1] == 3 * 10 + 11 + 15 + 1
 
 
+def test_bus_field_map_section_of_the_dat(tmp_path, ref_dir_bn128):
+    """c_code_generator.rs:740-794 / build.rs:601-626: the last section of the `.dat` describes every bus instance of the program
+    - a nested bus before the bus that holds it - by its fields in declaration order: offset, dimensions[1..], size of one
+    element, id of the field's own bus.  The writer emits it, the C-ABI loader validates and exposes it (and refuses a damaged
+    one), and the REFERENCE RUNTIME (main.cpp:95-121 reads get_size_of_bus_field_map() entries) loads the file and computes
+    the witness of a circuit with buses in main's inputs."""
+    import struct
+    src = """pragma circom 2.2.0;
+bus Point(n) { signal x[n]; signal y; }
+bus Seg() { Point(2) a; Point(2) b[2][3]; signal w; }
+template Main() { signal input k; input Seg() s; input Point(1) ps[2]; signal output o;
+  o <== s.a.x[1] * s.b[1][2].y + s.w + ps[1].y + k; }
+component main = Main();
+"""
+    prog = program_from_text(src)
+    fc = flatten(prog)
+    # bus instances in the order their layouts were completed: Point(2) (inside Seg), Seg, Point(1)
+    assert [[f[4] for f in b] for b in fc.bus_field_map] == [["x", "y"], ["a", "b", "w"], ["x", "y"]]
+    assert fc.bus_field_map[0] == [(0, (2,), 1, None, "x"), (2, (), 1, None, "y")]
+    assert fc.bus_field_map[1] == [(0, (), 3, 0, "a"), (3, (2, 3), 3, 0, "b"), (21, (), 1, None, "w")]
+    from circom_amd import runtime as rt
+    from circom_amd.compiler import compile_program
+    from circom_amd.hip_elements.writers import dat_bus_field_map, wtns_bytes
+    cp = compile_program(prog, str(tmp_path), "busmap", sym=False, strands=(1,))
+    blob = dat_bus_field_map(fc.bus_field_map)
+    words = struct.unpack("<%dI" % (len(blob) // 4), blob)
+    #            Point(2): 2 fields | x: offset 0, 0 further dims, size 1, bus 0 | y: offset 2 ...
+    assert words[:9] == (2, 0, 0, 1, 0, 2, 0, 1, 0)
+    #            Seg: 3 fields | a: 0, 0 dims, size 3, bus 0 | b: offset 3, ONE further dimension (3), size 3, bus 0 | w: 21, 0, 1, 0
+    assert words[9:23] == (3, 0, 0, 3, 0, 3, 1, 3, 3, 0, 21, 0, 1, 0)
+    dat = open(cp.dat_path, "rb").read()
+    assert dat.endswith(blob)
+    c = rt.Circuit(cp.tape_path, cp.dat_path, None)
+    L = rt.lib()
+    assert L.cw_bus_map_size(c.h) == 3
+    import ctypes as C
+    off, size, bus, nl = (C.c_uint32() for _ in range(4))
+    assert L.cw_bus_field(c.h, 1, 1, C.byref(off), C.byref(size), C.byref(bus), C.byref(nl)) == 0
+    assert (off.value, size.value, bus.value, nl.value) == (3, 3, 0, 1)
+    assert L.cw_bus_field(c.h, 1, 3, None, None, None, None) != 0 and L.cw_bus_field(c.h, 3, 0, None, None, None, None) != 0
+    c.close()
+    # damaged sections are refused: truncated, a field beyond the circuit's signals, a field whose own bus is a LATER entry
+    at = len(dat) - len(blob)
+    bad = [dat[:-4], dat[:-8]]
+    b1 = bytearray(dat); b1[at + 4:at + 8] = struct.pack("<I", fc.n_signals); bad.append(bytes(b1))          # Point(2).x at n_signals
+    b2 = bytearray(dat); b2[at + 4 * 13:at + 4 * 14] = struct.pack("<I", 2); bad.append(bytes(b2))           # Seg.a's bus := 2 (Point(1), later)
+    for blob_ in bad:
+        (tmp_path / "bad.dat").write_bytes(blob_)
+        with pytest.raises(rt.CwError):
+            rt.Circuit(cp.tape_path, tmp_path / "bad.dat", None)
+    # the reference runtime loads the .dat (both its CLI and the in-process loop) and writes the witness
+    from oracle import ref_build
+    try:
+        ref_build.build_circuit(cp)
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    src_cpp = (ref_build.ref_dir(fc.prime) / "busmap.cpp").read_text()
+    assert "get_size_of_bus_field_map() {return 3;}" in src_cpp
+    row = list(range(1, fc.n_main_inputs + 1))
+    sig, failed = run(fc, row)
+    assert failed is None
+    out = tmp_path / "cli.wtns"
+    names = {n: (st, sz) for n, st, sz in fc.inputs}
+    obj = {"k": str(row[0]), "s": [str(v) for v in row[names["s"][0] - fc.main_input_start:][:names["s"][1]]],
+           "ps": [str(v) for v in row[names["ps"][0] - fc.main_input_start:][:names["ps"][1]]]}
+    import json
+    r = ref_build.run_cli(cp, json.dumps(obj), out)
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == wtns_bytes(fc.fp.q, sig)
+
+
 def test_modular_inverse_by_fermat_from_text_runs_its_loop_at_run_time(tmp_path):
     """mod_inv -> mod_exp of circomlib/bigint_func.circom: a KNOWN loop of n * k trips whose body is two long products and
     divisions.  The compiler unrolls while the body is small and hands the remaining trips to a run-time loop once 4 096
