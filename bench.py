@@ -47,7 +47,7 @@ FPMUL_INSTS, FPMUL_MADS = 266, 162
 MAD_U64_WAVE_INSTS_PER_S = 5.4796e11      # v_mad_u64_u32 (half rate)
 SIMPLE_VALU_WAVE_INSTS_PER_S = 9.8689e11  # v_and_b32 / v_add_u32 class (full rate)
 JIT_BATCH = 1 << 21                # the emitted bit-plane code runs one wave per 2 048 instances: 1 024 waves = one per SIMD
-DEFAULT_BATCH = {"bigmultmodp": 8192, "ecdsa_verify": 1024, "sha256_2048": JIT_BATCH, "sha256_512": 4096, "poseidon2": 65536, "semaphore20": 8192, "semaphore20p": 8192,
+DEFAULT_BATCH = {"bigmultmodp": 8192, "ecdsa_verify": 1024, "sha256_2048": JIT_BATCH, "sha256_27008": 1 << 19, "sha256_512": 4096, "poseidon2": 65536, "semaphore20": 8192, "semaphore20p": 8192,
                  "semaphore20w": 8192}
 
 
@@ -386,7 +386,18 @@ def in_flight_for(batch) -> int:
     return n
 
 
-def parity_check(cp, circ, batch, h_in, workload: str, n_sample: int = 4, digest_bits=None):
+def golden_messages(workload: str):
+    """[(instance position rule, message bytes, wtns sha256, wtns length)] of tests/golden/reference_wtns_<workload>.json: vectors
+    the REFERENCE runtime wrote in the container that has the reference tree (make_golden_27008.py), for workloads whose
+    reference binary and tables are too large to travel with the snapshot.  [] when there is no such file."""
+    f = ROOT / "tests" / "golden" / ("reference_wtns_%s.json" % workload)
+    if not f.is_file():
+        return []
+    g = json.load(open(f))
+    return [(bytes.fromhex(v["message_hex"]), v["wtns_sha256"], int(v["wtns_len"])) for v in g.get("vectors", ()) if "message_hex" in v]
+
+
+def parity_check(cp, circ, batch, h_in, workload: str, n_sample: int = 4, digest_bits=None, golden_at=None):
     """Oracle comparison at the benchmark batch (after the timed region).  Returns a dict for the JSON line; raises
     AssertionError on any mismatch (a fast wrong answer is not a result)."""
     import numpy as np
@@ -399,11 +410,30 @@ def parity_check(cp, circ, batch, h_in, workload: str, n_sample: int = 4, digest
     from circom_amd.hip_elements.writers import wtns_bytes
     td = tempfile.mkdtemp(prefix="cw_parity_")
     got = {}
+    if golden_at:
+        # instances that carry the golden messages: the `.wtns` the C ABI writes against the hash of the REFERENCE runtime's file
+        for pos, (msg, sha, length) in golden_at.items():
+            fn = os.path.join(td, "gold_%d.wtns" % pos)
+            batch.write_wtns(pos, fn)
+            h = hashlib.sha256()
+            n = 0
+            with open(fn, "rb") as f:
+                for blk in iter(lambda: f.read(1 << 24), b""):
+                    h.update(blk)
+                    n += len(blk)
+            os.unlink(fn)
+            assert n == length and h.hexdigest() == sha, "PARITY FAILURE: .wtns of instance %d differs from the reference runtime's golden" % pos
+        out["golden_instances"] = sorted(golden_at)
+        out["oracle"] = "reference C++ runtime, golden .wtns hashes (tests/golden/reference_wtns_%s.json), full files" % workload
+        picks = []
+        out["instances"] = sorted(golden_at)
     for i in picks:                                       # through the C ABI's writeBinWitness (cw_write_wtns)
         batch.write_wtns(i, os.path.join(td, "g_%d.wtns" % i))
         got[i] = open(os.path.join(td, "g_%d.wtns" % i), "rb").read()
     want = None
     try:
+        if not picks:
+            raise RuntimeError("golden vectors were compared")
         from oracle import ref_build
         cli, loop = ref_build.build_circuit(cp)          # cached binary if its fingerprint matches this circuit
         if loop.exists():
@@ -413,7 +443,7 @@ def parity_check(cp, circ, batch, h_in, workload: str, n_sample: int = 4, digest
             out["oracle"] = "reference C++ runtime (oracle/_ref/%s/%s_loop), full .wtns bytes" % (fc.prime, cp.name)
     except Exception as e:      # fall back to the Python restatement below
         out["oracle_note"] = "reference binary unusable: %s" % str(e)[:120]
-    if want is None:
+    if want is None and picks:
         from oracle.tape_eval import eval_flat
         want = {}
         for i in picks:
@@ -424,7 +454,10 @@ def parity_check(cp, circ, batch, h_in, workload: str, n_sample: int = 4, digest
         out["oracle"] = "oracle/tape_eval.eval_flat (Python restatement of the emitted calculator), full .wtns bytes"
     for i in picks:
         assert got[i] == want[i], "PARITY FAILURE: .wtns of instance %d differs from the oracle's" % i
-    out["wtns_sha256_first"] = hashlib.sha256(got[picks[0]]).hexdigest()
+    if picks:
+        out["wtns_sha256_first"] = hashlib.sha256(got[picks[0]]).hexdigest()
+    else:
+        out.pop("oracle_note", None)                      # (nothing left for the sampled comparison: the goldens were it)
     if workload.startswith("sha256_"):
         # every instance's digest against hashlib (output bit k = bit 7-(k%8) of digest byte k/8, msb first)
         if digest_bits is None:
@@ -712,8 +745,11 @@ def main():
             raise
         B //= 2                                              # the value table did not fit: halve the batch once
         batch = circ.batch(B, device=local_rank, stream=stream.cuda_stream)
+    golden_at = {}
     # synthetic inputs, resident in HBM before the timed region (different seed per rank = different shard)
     big_bool = batch.bitmode and args.workload.startswith("sha256_") and B * circ.n_inputs * 32 > (8 << 30)
+    if big_bool and B * circ.n_inputs * 32 > 0.5 * torch.cuda.get_device_properties(dev).total_memory:
+        args.packed_inputs = True      # (the canonical image does not fit beside the table: 453 GB for 2^19 x 27 008 inputs)
     if args.packed_inputs or big_bool:
         assert batch.bitmode and args.workload.startswith("sha256_"), "--packed-inputs needs a bit-plane circuit"
         # random message bits from the device's generator (2 M x 2 048 bits: seconds on the host); the host keeps one byte per
@@ -722,6 +758,11 @@ def main():
         gen = torch.Generator(device=dev)
         gen.manual_seed(1 + rank)
         d_bits = torch.randint(0, 2, (B, circ.n_inputs), dtype=torch.uint8, device=dev, generator=gen)
+        gm = golden_messages(args.workload) if rank == 0 else []
+        for k_, (msg_, sha_, len_) in enumerate(gm):
+            pos_ = 0 if k_ == 0 else B - k_                 # the first golden at instance 0, the others at the end of the batch
+            d_bits[pos_] = torch.from_numpy(np.unpackbits(np.frombuffer(msg_, dtype=np.uint8))).to(dev)
+            golden_at[pos_] = (msg_, sha_, len_)
         h_in = BoolInputs(d_bits.cpu().numpy())
         if args.packed_inputs:
             main_masks = h_in.masks()
@@ -853,7 +894,7 @@ def main():
         if args.workload.startswith("sha256_") and circ.n_public >= 256:
             assert not bool(pub_local[:, :256, 1:].any().item()), "digest signals are not bits"
             dg_bits = pub_local[:, :256, 0].contiguous().cpu().numpy()          # reduced on the device: 256 bytes per instance
-        parity = parity_check(cp, circ, batch, h_in, args.workload, args.parity_instances, dg_bits)   # every rank checks its own shard
+        parity = parity_check(cp, circ, batch, h_in, args.workload, args.parity_instances, dg_bits, golden_at)   # every rank checks its own shard
         parity["parity_checked"] = len(parity["instances"])
 
     # canonical egress: the 32-byte-per-element image a prover reads (SURVEY 8d's B_gen: what the reference's

@@ -1222,7 +1222,7 @@ static int load_dat(cw_circuit *c, const char *path) {
     c->bus_map.clear();
     while (at < nw) {
         const uint32_t nf = w32[at++];
-        if (nf > 65536) return fail(CW_EIO, ".dat bus-field map: implausible number of fields");
+        if (nf == 0 || nf > 65536) return fail(CW_EIO, ".dat bus-field map: a bus has at least one field (and not more than 65 536)");
         std::vector<cw_circuit::IoDef> fields;
         for (uint32_t d = 0; d < nf; d++) {
             if (at + 2 > nw) return fail(CW_EIO, ".dat bus-field map truncated");

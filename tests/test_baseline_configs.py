@@ -253,3 +253,57 @@ def test_metric_workload_sha256_2048_emitted_code_at_2M(tmp_path):
     b2.close()
     c.close()
     torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
+def test_sha256_27008_through_the_looped_emitted_code(tmp_path, monkeypatch):
+    """The 1.07 M-constraint SHA-256 at the reference's default `--O1` (53 compression blocks, 10.8 M constraints at `--O0`)
+    through the emitted engine: 53 iterations of ONE block body (hip_elements/bitjit.py loops; 2.6 MB of code instead of 137 MB).
+    2^18 instances with packed inputs: the two reference-runtime goldens inside the batch (their 346 MB `.wtns` files compared
+    through the hash, tests/golden/reference_wtns_sha256_27008.json), sampled digests against hashlib, the fused check clean.
+    The lowered artefacts (30 minutes of lowering, 250 MB gzipped) travel in gpurun_in/cache when they were prebuilt
+    (tools/r06_prebuild_27008.sh); without them the test has nothing to run on."""
+    import glob
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    from circom_amd import runtime as rt
+    name = "sha256_27008"
+    found = [d for d in glob.glob(os.path.join(ROOT, "gpurun_in", "cache", name + "_s1_*")) if os.path.exists(os.path.join(d, "done"))]
+    if not found:
+        pytest.skip("the lowered artefacts of sha256_27008 are not in gpurun_in/cache (tools/r06_prebuild_27008.sh prebuilds them)")
+    monkeypatch.setenv("CW_ARTEFACT_FP", found[0].rsplit("_", 1)[1])
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_wtns_sha256_27008.json")))["vectors"]
+    B = 1 << 18
+    cp, _, cached = bench.get_compiled(name, B, os.path.join(ROOT, "gpurun_in", "cache"), 0, None)
+    assert cached and cp.jit_stats["loop"]["iterations"] == 53 and cp.jit_stats["code_bytes"] < 4 << 20
+    c = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
+    assert c.n_constraints > 10_000_000
+    b = c.batch(B)
+    assert b.bitmode and b.jit
+    rng = np.random.default_rng(5)
+    G = B // 64
+    masks = rng.integers(0, 1 << 63, size=(G, c.n_inputs), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(G, c.n_inputs), dtype=np.uint64)
+    at = [3, B - 5]
+    for pos, vec in zip(at, gold):
+        g, i = pos // 64, np.uint64(pos % 64)
+        bitsv = np.unpackbits(np.frombuffer(bytes.fromhex(vec["message_hex"]), dtype=np.uint8)).astype(np.uint64)
+        masks[g] = (masks[g] & ~(np.uint64(1) << i)) | (bitsv << i)
+    b.set_inputs_bits(masks)
+    b.run(); b.check_r1cs(); b.sync()
+    assert (b.status() == 0).all()
+    for pos, vec in zip(at, gold):
+        p = tmp_path / ("g%d.wtns" % pos)
+        b.write_wtns(pos, p)
+        h, n = hashlib.sha256(), 0
+        with open(p, "rb") as f:
+            for blk in iter(lambda: f.read(1 << 24), b""):
+                h.update(blk); n += len(blk)
+        os.unlink(p)
+        assert n == int(vec["wtns_len"]) and h.hexdigest() == vec["wtns_sha256"], pos
+    for i in (0, 63, 2047, 2048, B // 2 + 77, B - 1):
+        bits = ((masks[i // 64] >> np.uint64(i % 64)) & np.uint64(1)).astype(np.uint8)
+        dg = np.unpackbits(np.frombuffer(hashlib.sha256(np.packbits(bits).tobytes()).digest(), dtype=np.uint8))
+        assert [b.signal(i, 1 + k) for k in range(256)] == dg.tolist(), i
+    b.close(); c.close()

@@ -681,6 +681,65 @@ def test_gpu_emitted_code_beyond_one_chunk_when_the_audit_spills(tmp_path, monke
 
 
 @pytest.mark.gpu
+def test_gpu_looped_body_of_a_repeated_template(tmp_path, monkeypatch):
+    """ONE body per repeated template on the device (bitjit.lower_jit(loop=True); the reference's `<T>_<id>_run`,
+    template.rs:160-474): the three compression blocks of Sha256(1024) run as three iterations of one 346 K-instruction body -
+    rows relative to the iteration's base (s40), the block's inputs (IV constants / previous digest, message bits / padding)
+    through the iteration's table of row offsets behind the code.  Three chunks of instances: every digest against hashlib,
+    full witnesses of every chunk against the oracle, the fused check clean, the LOOPED audit of the table clean - and after a
+    caller flipped one wire of the last block in three instances, the audit flags exactly the instances that now violate."""
+    import ctypes as C
+    import hashlib
+    monkeypatch.setenv("CW_BITS_JIT", "1")
+    monkeypatch.setenv("CW_JIT_LOOP", "1")
+    cp, c = _gpu(tmp_path, Program(Sha256(1024)), "sha256_1024l")
+    assert cp.jit.loop and cp.jit.loop["K"] == 3 and cp.jit.stats["loop"]["external_values"] == 768
+    assert cp.jit.audit_code and len(cp.jit.code) < 4 << 20 and cp.jit.check_complete
+    fc = cp.flat
+    B = 2048 * 2 + 300
+    rng = np.random.default_rng(11)
+    msgs = rng.integers(0, 256, size=(B, 128), dtype=np.uint8)
+    rows = np.unpackbits(msgs, axis=1)
+    b = c.batch(B)
+    assert b.jit
+    b.set_inputs(rows.tolist())
+    b.run(); b.check_r1cs(); b.sync()
+    assert (b.status() == 0).all()
+    pub = b.public_signals()
+    assert not pub[:, :256, 1:].any()
+    got = np.packbits(pub[:, :256, 0], axis=1)
+    want = np.frombuffer(b"".join(hashlib.sha256(m.tobytes()).digest() for m in msgs), dtype=np.uint8).reshape(B, 32)
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, "digest of instance %d (chunk %d) differs from hashlib" % (int(bad[0]), int(bad[0]) // 2048)
+    for i in (0, 2047, 2048, 4096, B - 1):
+        sig, failed = _flat(fc, rows[i].tolist())
+        assert failed is None and b.witness(i) == sig, i
+    monkeypatch.setenv("CW_R1CS_AUDIT", "1")
+    b.check_r1cs(); b.sync()
+    assert (b.status() == 0).all()
+    # a wire of the LAST block (third iteration), flipped in one instance of every chunk
+    ptr, nbytes, spg = b.device_bits()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    victim = next(s_ for s_ in range(fc.n_signals - 2000, 0, -1) if any(s_ in A or s_ in B_ or s_ in C_ for A, B_, C_ in fc.constraints[-20000:]))
+    slot = int(b.signal_slots()[victim])
+    assert slot >= cp.jit.loop["base"] + 2 * cp.jit.loop["R"], "the victim was meant to be a row of the third iteration"
+    for i in (7, 2048 + 70, B - 2):
+        off = 8 * b.bits_index(i // 64, slot)
+        word = C.c_uint64()
+        assert hip.hipMemcpy(C.byref(word), C.c_void_p(ptr + off), 8, 2) == 0
+        word.value ^= 1 << (i % 64)
+        assert hip.hipMemcpy(C.c_void_p(ptr + off), C.byref(word), 8, 1) == 0
+    b.check_r1cs(); b.sync()
+    st, fb = b.status(), b.r1cs_first_bad()
+    flagged = np.nonzero(st & 4)[0].tolist()
+    assert flagged == [7, 2048 + 70, B - 2], flagged
+    for i in flagged:
+        assert fb[i] == check_r1cs(c.q, fc.constraints, b.witness(i))
+    b.close(); c.close()
+
+
+@pytest.mark.gpu
 def test_gpu_sha256_two_blocks_bitplane(tmp_path, engine):
     cp, c = _gpu(tmp_path, Program(Sha256(512)), "sha256_512")
     fc = cp.flat
