@@ -1619,6 +1619,7 @@ struct cw_batch {
     uint32_t *d_rctab = nullptr, *d_rctab29 = nullptr, *d_pchunk = nullptr, *d_prec = nullptr, *d_pterms = nullptr, *d_prow = nullptr;
     uint32_t r1_chunks = 0, r1_entries = 0;
     void *d_in = nullptr;          // AoS staging [batch][n_in][32]
+    void *d_pmask = nullptr;       // cw_set_inputs_bits: the caller's packed masks on the device (8 bytes per input and group)
     void *d_gather = nullptr;      // [n_witness][32]
     void *d_bulk = nullptr;        // staging of cw_get_witnesses: [bulk_rows][n_witness][32]
     uint32_t bulk_rows = 0;
@@ -1707,7 +1708,7 @@ extern "C" void cw_batch_free(cw_batch *b) {
             if (e) hipEventDestroy(e);
     if (b->fb) cw_batch_free(b->fb);
     void *bptrs[] = {b->d_V64, b->d_consts64, b->d_rows64, b->d_terms64, b->d_T, b->d_fbmask, b->d_r1flag, b->d_brecs, b->d_bcmds, b->d_aslots, b->d_wslot, b->d_fbinst, b->d_erecs, b->d_wchunk, b->d_wterms, b->d_wctab, b->d_wrow,
-                     b->d_ichunk, b->d_iterms, b->d_itab, b->d_irow, b->d_sigslot};
+                     b->d_ichunk, b->d_iterms, b->d_itab, b->d_irow, b->d_sigslot, b->d_pmask};
     for (void *p : bptrs)
         if (p) hipFree(p);
     if (b->d_fncode) hipFree(b->d_fncode);
@@ -2259,11 +2260,16 @@ extern "C" int cw_set_inputs_bits(cw_batch *b, const uint64_t *masks) {
     NEED_DEVICE(b);
     if (!b->bitmode) return fail(CW_ESTATE, "packed boolean inputs need a bit-plane batch (cw_batch_bitmode)");
     HIPCHK(hipSetDevice(b->device));
-    // d_in holds 32 bytes per input and instance: the masks (1 bit each) always fit
-    if (int rc = ensure_d_in(b)) return rc;
-    HIPCHK(hipMemcpyAsync(b->d_in, masks, (size_t)b->n_groups * b->c->n_inputs * 8, hipMemcpyHostToDevice, b->stream));
+    // a buffer of their own: the masks are 1 bit per input and instance, the 32-byte staging image (d_in) 256 times that - 226 GB
+    // for 2^18 instances of the 27 008-input SHA-256, which the masks must not need
+    const size_t nbytes = std::max<size_t>((size_t)b->n_groups * b->c->n_inputs * 8, 8);
+    if (!b->d_pmask) {
+        hipError_t e = hipMalloc(&b->d_pmask, nbytes);
+        if (e != hipSuccess) return fail(CW_EDEVICE, "hipMalloc of the packed input masks failed (" + std::to_string(nbytes) + " bytes): " + hipGetErrorString(e));
+    }
+    HIPCHK(hipMemcpyAsync(b->d_pmask, masks, nbytes, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
-    return cw_set_inputs_bits_device(b, b->d_in);
+    return cw_set_inputs_bits_device(b, b->d_pmask);
 }
 
 extern "C" int cw_set_inputs_device(cw_batch *b, const void *d_le32) {

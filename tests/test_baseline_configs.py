@@ -170,6 +170,22 @@ def test_config5_ecdsa_verify_shard_at_128(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.xdist_group(name="hbm")
+def test_metric_workload_32_byte_ingest_at_2M(tmp_path):
+    """the dominant kernel of the benchmark step, `cw_bits_ingest_kernel`, at the benchmark shape - the canonical
+    32-byte image of all 2^21 x 2 048 inputs (137 GB, built on the device as bench.py does), the two reference goldens inside
+    the batch, every digest against the packed-input run of the same batch, one non-boolean input sent to the fallback.
+    Runs in a process of its own (tests/gpu_ingest_at_benchmark_shape.py): torch must initialise its HIP runtime before
+    the library loads the system's, and the 137 GB image must not meet another test's tables in the same process."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_ingest_at_benchmark_shape.py"), str(tmp_path)],
+                       capture_output=True, text=True, timeout=2400)
+    assert r.returncode == 0 and "INGEST OK" in r.stdout, (r.stdout[-3000:] + "\n" + r.stderr[-3000:])
+
+
+@pytest.mark.gpu
+@pytest.mark.xdist_group(name="hbm")
 def test_metric_workload_sha256_2048_emitted_code_at_2M(tmp_path):
     """the benchmark's own configuration: 2^21 instances of the 1 020 832-constraint SHA-256 through the emitted code, the two
     reference goldens inside the batch (their full 32 MB `.wtns` files byte-compared through the digest), sampled digests
@@ -211,51 +227,11 @@ def test_metric_workload_sha256_2048_emitted_code_at_2M(tmp_path):
     finally:
         del os.environ["CW_R1CS_AUDIT"]
     assert (b.status() == 0).all()
-    # ... and the SAME batch through the boundary's own input format: the canonical 32-byte image of all 2^21 x
-    # 2 048 inputs (137 GB, built on the device as bench.py does) through cw_bits_ingest_kernel - the dominant kernel of the
-    # benchmark step at the benchmark shape.  Every digest must equal the packed run's, the goldens' full .wtns files again.
-    import torch
-    dev = torch.device("cuda", 0)
-    pub = torch.empty((B, c.n_public, 32), dtype=torch.uint8, device=dev)
-    b.public_signals_device(pub.data_ptr()); b.sync()
-    assert not bool(pub[:, :, 1:].any().item())
-    want_bits = pub[:, :, 0].clone()
-    del pub
-    b.close()                                                        # (its table: the image below needs the room)
-    torch.cuda.empty_cache()
-    d_m = torch.from_numpy(masks.view(np.int64)).to(dev)                          # [G][n_inputs]
-    d_in = torch.zeros((B, c.n_inputs, 32), dtype=torch.uint8, device=dev)
-    j = torch.arange(64, device=dev, dtype=torch.int64).view(1, 64, 1)
-    for g0 in range(0, G, 1024):
-        g1 = min(G, g0 + 1024)
-        d_in[g0 * 64:g1 * 64, :, 0] = ((d_m[g0:g1].unsqueeze(1) >> j) & 1).to(torch.uint8).reshape((g1 - g0) * 64, c.n_inputs)
-    del d_m
-    b2 = c.batch(B)
-    b2.set_inputs_device(d_in.data_ptr())
-    b2.run(); b2.check_r1cs(); b2.sync()
-    assert (b2.status() == 0).all()
-    pub = torch.empty((B, c.n_public, 32), dtype=torch.uint8, device=dev)
-    b2.public_signals_device(pub.data_ptr()); b2.sync()
-    assert not bool(pub[:, :, 1:].any().item()) and torch.equal(pub[:, :, 0], want_bits), "32-byte ingest and packed inputs disagree"
-    del pub, want_bits
-    torch.cuda.empty_cache()
-    for pos, vec in zip(at, vecs):
-        p = tmp_path / ("h%d.wtns" % pos)
-        b2.write_wtns(pos, p)
-        _check(vec, p.read_bytes())
-    # one instance whose input is NOT a bit in one place: the ingest must send exactly that instance to the 256-bit fallback
-    d_in[B // 3, 7, 0] = 2
-    b2.set_inputs_device(d_in.data_ptr())
-    b2.run(); b2.check_r1cs(); b2.sync()
-    st = b2.status()
-    assert (np.delete(st, B // 3) == 0).all()
-    del d_in
-    b2.close()
-    c.close()
-    torch.cuda.empty_cache()
+    b.close(); c.close()
 
 
 @pytest.mark.gpu
+@pytest.mark.xdist_group(name="hbm")
 def test_sha256_27008_through_the_looped_emitted_code(tmp_path, monkeypatch):
     """The 1.07 M-constraint SHA-256 at the reference's default `--O1` (53 compression blocks, 10.8 M constraints at `--O0`)
     through the emitted engine: 53 iterations of ONE block body (hip_elements/bitjit.py loops; 2.6 MB of code instead of 137 MB).

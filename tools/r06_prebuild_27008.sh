@@ -16,4 +16,5 @@ O=gpurun_in/cache/sha256_27008_s1_b1_ma_r06b
 mkdir -p $O
 for e in cwt dat r1cs; do [ -f $D/sha256_27008.$e.gz ] || gzip -1 -k $D/sha256_27008.$e; cp $D/sha256_27008.$e.gz $O/; done
 cp $D/sha256_27008.jit.json $D/sha256_27008.fpjit.json $D/done $O/
+echo "prebuilt under the explicit key r06b: __graft_entry__.build() keeps this directory" > $O/keep
 du -sh $O
