@@ -694,14 +694,32 @@ def _plan_segments(net, fc, n_eval, TT, A, B, C, is_gate, live, G, flags, hoist,
     raise AssertionError("unreachable")
 
 
-def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384, fuse_check: bool = True, hoist: int = 256, audit_of=None,
-              loop: bool = True):
+STORE_PACE = 0                  # 0: a row store where the value is produced (measured best); n: at most one per n instructions - lower_jit
+STORE_PENDING_MAX = 48          # values whose row store is still to be issued
+
+
+PREFETCH = 192                  # gates of look-ahead for values that come back from memory (round 6: 384 -> 192: 13.1 -> 12.2 ms and
+                                # 13.3 -> 13.0 ms on two boxes, profiles/r06c / r06d_jit_variants.txt; 768: 14.0; 128: worse again)
+
+
+def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = PREFETCH, fuse_check: bool = True, hoist: int = 256, audit_of=None,
+              loop: bool = True, store_pace=None, store_pending=None):
     """BitNet (bitblast.py) -> JitProgram with IR.  Returns None when there is nothing to evaluate.
     audit_of = the program lowered from the same network: lower the STAND-ALONE AUDIT of its table instead - the gates of the
     R1CS check alone, their wires LOADED from the rows that program stored (one coalesced 256-byte row per wire and wave: the
     table's own layout), nothing evaluated, nothing stored but scratch behind the table.  `cw_check_r1cs` runs it when the
     caller asks for an audit (CW_R1CS_AUDIT=1) or may have changed the table (cw_device_bits): the general check kernels
     read 8 bytes out of every 256-byte row in this layout (271 ms for 2^21 instances of Sha256(2048)).
+    store_pace: PACED row stores, an experiment that is kept switched off (0).  A signal's row is stored right behind the gate
+    that produces it: SHA-256's adders then issue 20-30 stores within a hundred instructions and none for the next two hundred
+    (a third of all 128-instruction windows have no store, the busiest tenth 27+), and timing-only variants
+    (profiles/r06c_jit_variants.txt) show the stores costing the kernel exactly their own stream time (13.1 ms with, 6.3 ms
+    without, the store stream alone 6.35) although a uniform stream of the same density overlaps with VALU work completely
+    (tools/ubench_loop.hip).  With store_pace = n a produced value waits in its register (VGPR or AccVGPR:
+    `buffer_store_dword` takes either) and ONE store is issued every n instructions (a register that is wanted back, more than
+    STORE_PENDING_MAX waiting values or a loop boundary flush earlier).  MEASURED (profiles/r06d_jit_variants.txt): pace 8 / 10 /
+    12 = 13.38 / 13.44 / 13.50 ms against 13.28 unpaced - smoothing the stream does not help (bursts of consecutive rows are what
+    the memory system likes), so burstiness is not why the stores do not overlap.
     loop: emit ONE body for the instances of a repeated template and run it once per instance (`_plan_segments`; needs a
     network built with bitblast(ports=, marks=) from `instance_ports(fc)`): code size follows the templates, not the circuit -
     the reference's own structure (template.rs:160-474, loop_bucket.rs:77).  Inside the body a row is addressed relative to
@@ -851,6 +869,14 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
         next_slot = IN_BASE + fc.n_main_inputs
     ir = []
     emit = ir.append
+    if store_pace is None:
+        store_pace = int(os.environ.get("CW_JIT_STORE_PACE", STORE_PACE))
+    pending_max = int(os.environ.get("CW_JIT_STORE_PENDING", STORE_PENDING_MAX)) if store_pending is None else store_pending
+    from collections import deque
+    pending = deque()                             # produced values whose row store has not been issued yet (paced stores)
+    is_pending = [False] * n_nodes
+    n_pending = 0
+    last_store_at = -(1 << 30)                    # IR position of the latest row store
     vm_issued = 0
     vm_done = -1                                  # every memory operation with index <= vm_done has completed
     stats = {"gates": 0, "stores": 0, "prefetched": 0, "late_loads": 0, "agpr_writes": 0, "agpr_reads": 0, "scratch_stores": 0,
@@ -891,7 +917,11 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
         vm_issued += 1
 
     def issue_store(kind, reg, node):
-        nonlocal vm_issued, next_slot
+        nonlocal vm_issued, next_slot, last_store_at, n_pending
+        if is_pending[node]:
+            is_pending[node] = False              # (its paced store is this one)
+            n_pending -= 1
+        last_store_at = len(ir)
         mem_slot[node] = next_slot
         next_slot += 1
         if in_body:
@@ -919,8 +949,9 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
         heapq.heappop(aheap)
         a = loc_a[nd]
         if mem_slot[nd] < 0:
+            was_pending = is_pending[nd]
             issue_store("sta", a, nd)
-            count("scratch_stores")
+            count("stores" if (was_pending and is_signal[nd]) else "scratch_stores")
         loc_a[nd] = -1
         return a
 
@@ -948,6 +979,10 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
             heapq.heappush(vheap, e)
         if victim < 0:
             raise RuntimeError("register allocation: no evictable VGPR")
+        if is_pending[victim]:
+            flush_pending(victim)                 # the store it was waiting for, now; a dead value is gone with it
+            if loc_v[victim] < 0:
+                return free_v.pop()
         v = loc_v[victim]
         loc_v[victim] = -1
         if loc_a[victim] < 0:
@@ -971,6 +1006,13 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
         return evict_v(pin)
 
     def release(node):
+        if is_pending[node]:
+            # its row store is still to come: the register stays, first in line when one is wanted back
+            if loc_v[node] >= 0:
+                heapq.heappush(vheap, (-INF, node))
+            else:
+                heapq.heappush(aheap, (-INF, node))
+            return
         v = loc_v[node]
         if v >= 0:
             if pend[node] >= 0:                   # (cannot happen for a used value: kept for safety)
@@ -983,6 +1025,39 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
             free_a.append(a)
             loc_a[node] = -1
 
+    def flush_pending(node):
+        """issue the row store of a waiting value now (from the VGPR or the AccVGPR it lives in); a value nothing reads again
+        gives its register back"""
+        v, a = loc_v[node], loc_a[node]
+        if v >= 0:
+            if pend[node] >= 0:                   # (cannot be: a waiting value was computed, not loaded)
+                wait_for(pend[node])
+                pend[node] = -1
+            issue_store("st", v, node)
+        else:
+            assert a >= 0, "a value waiting for its store lives in no register"
+            issue_store("sta", a, node)
+        count("stores" if is_signal[node] else "scratch_stores")
+        if next_use(node) == INF:
+            if v >= 0:
+                free_v.append(v)
+                loc_v[node] = -1
+            if a >= 0:
+                free_a.append(a)
+                loc_a[node] = -1
+
+    def pace_stores(everything=False):
+        """one waiting store if the latest is `store_pace` instructions back; more while too many wait; all at a boundary"""
+        while pending:
+            nd = pending[0]
+            if not is_pending[nd]:
+                pending.popleft()                 # (flushed early: its register was wanted)
+                continue
+            if not (everything or n_pending > pending_max or len(ir) - last_store_at >= store_pace):
+                break
+            pending.popleft()
+            flush_pending(nd)
+
     empty = frozenset()
     held_viol = [-1]                              # VGPR of a violation value waiting for its partner (not in any heap: never evicted)
 
@@ -990,6 +1065,7 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
         """loop entry / exit: nothing lives in a register across it.  Values that are read again get a row (if they have none),
         every memory operation completes, the register files start empty."""
         nonlocal free_v, free_a, vm_done
+        pace_stores(everything=True)
         if held_viol[0] >= 0:
             emit(("acc", 2, held_viol[0]))
             held_viol[0] = -1
@@ -1056,6 +1132,8 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
             in_body = True
         elif p == b1:
             end_loop()
+        if pending:
+            pace_stores()
         region = 0 if p < b0 else 1 if p < b1 else 2
         # -- prefetch what the gate PREFETCH positions ahead reads from memory; a second look a quarter of that distance ahead
         # catches values that were resident at the first look and have been dropped since (they have a row: dropping is free)
@@ -1077,6 +1155,8 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
         pin = set(o for o in ops if o > 1)
         for o in pin:
             if loc_v[o] < 0:
+                if al[o] != o and is_pending[al[o]]:
+                    flush_pending(al[o])           # a port reads its source's ROW: the row store it is waiting for, now
                 v = alloc_v(pin)
                 loc_v[o] = v
                 if loc_a[o] >= 0:
@@ -1117,8 +1197,13 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
         count("gates")
         loc_v[g] = d
         if stored:
-            issue_store("st", d, g)
-            count("stores" if is_signal[g] else "scratch_stores")
+            if store_pace > 0:
+                pending.append(g)                 # its row store follows when the store stream has room (pace_stores)
+                is_pending[g] = True
+                n_pending += 1
+            else:
+                issue_store("st", d, g)
+                count("stores" if is_signal[g] else "scratch_stores")
         if g in assert_set:
             emit(("acc", 1, d))
         if g in viol_set:
@@ -1133,10 +1218,14 @@ def lower_jit(net, fc, n_vgpr: int = 256, n_agpr: int = 256, prefetch: int = 384
             else:
                 emit(("acc", 2, d))
         if nu == INF:
-            free_v.append(d)
-            loc_v[g] = -1
+            if is_pending[g]:
+                heapq.heappush(vheap, (-INF, g))  # nothing reads it again, but its row store is still to come
+            else:
+                free_v.append(d)
+                loc_v[g] = -1
         else:
             heapq.heappush(vheap, (-nu, g))
+    pace_stores(everything=True)
     if lp is not None and n_ops == b1:                # (the loop ends the program: no gate behind it ran the exit code above)
         end_loop()
     if held_viol[0] >= 0:

@@ -30,13 +30,13 @@ for spec in sys.argv[2:]:
         k, v = item.split("=")
         kw[k] = (v != "0") if k == "fuse_check" else int(v)
     t0 = time.time()
-    asm_kw = {k: kw.pop(k) for k in list(kw) if k in ("nt", "nowait", "nostore", "noload")}
+    asm_kw = {k: kw.pop(k) for k in list(kw) if k in ("nt", "nowait", "nostore", "noload", "noacc", "nopage")}
     jp = bitjit.lower_jit(net, fc, **kw)
     asm = bitjit.to_asm(jp)
     if asm_kw.get("nt") == 0:
         asm = asm.replace(" nt\n", "\n")
     # timing-only experiments (results are wrong): which instructions make a wave wait
-    drop = tuple(t for k, t in (("nowait", "s_waitcnt vmcnt"), ("nostore", "buffer_store_dword"), ("noload", "buffer_load_dword")) if asm_kw.get(k))
+    drop = tuple(t for k, t in (("nowait", "s_waitcnt vmcnt"), ("nostore", "buffer_store_dword"), ("noload", "buffer_load_dword"), ("noacc", "v_accvgpr_"), ("nopage", "s_mov_b32 s16,")) if asm_kw.get(k))
     if drop:
         asm = "".join(l for l in asm.splitlines(True) if not any(t in l for t in drop))
     jp.code = bitjit.assemble(asm)

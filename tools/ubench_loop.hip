@@ -27,6 +27,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define STORE_STEP                                                                                                    \
     ".if (ctr %% 2) == 1\n buffer_store_dword %0, %10, s[12:15], s24 offen offset:((ctr / 2) %% 16) * 256 nt\n"      \
     ".if ((ctr / 2) %% 16) == 15\n s_add_u32 s24, s24, 0x1000\n .endif\n .endif\n"
+#define STORE_STEP8                                                                                                   \
+    "buffer_store_dword %0, %10, s[12:15], s24 offen offset:(ctr %% 16) * 256 nt\n"                                    \
+    ".if (ctr %% 16) == 15\n s_add_u32 s24, s24, 0x1000\n .endif\n"
 #define BAR_STEP ".if (ctr %% 256) == 255\n s_barrier\n .endif\n"
 #define NO_STEP ""
 
@@ -36,8 +39,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         uint32_t a = t * 2654435761u + seed, b = (t ^ seed) * 40503u + 7u;                                              \
         uint32_t c0 = a + 8, c1 = a + 1, c2 = a + 2, c3 = a + 3, c4 = a + 4, c5 = a + 5, c6 = a + 6, c7 = a + 7;            \
         uint32_t lane4 = (threadIdx.x & 63) * 4;                                                                        \
-        uint8_t *chunk = rows + (size_t)(t >> 6) * (16u << 20);                                                         \
-        asm volatile("s_mov_b32 s12, %11\n s_and_b32 s13, %12, 0xffff\n s_mov_b32 s14, 0x01000000\n s_mov_b32 s15, 0x00020000\n" \
+        uint8_t *chunk = rows + (size_t)(t >> 6) * (32u << 20);                                                         \
+        asm volatile("s_mov_b32 s12, %11\n s_and_b32 s13, %12, 0xffff\n s_mov_b32 s14, 0x02000000\n s_mov_b32 s15, 0x00020000\n" \
                      "s_mov_b32 s24, 0\n s_mov_b32 s20, " S1(ITER) "\n s_getpc_b64 s[22:23]\n"                          \
                      ".set ctr, 0\n .rept " S1(N8) "\n" GROUP8 STEP ".set ctr, ctr + 1\n .endr\n"                        \
                      "s_sub_u32 s20, s20, 1\n s_cmp_lg_u32 s20, 0\n s_cbranch_scc0 1f\n s_setpc_b64 s[22:23]\n 1:\n"      \
@@ -62,6 +65,9 @@ LOOP_KERNEL(st_loop_64k, 8192, 16, STORE_STEP, 64)
 LOOP_KERNEL(st_loop_16k, 2048, 64, STORE_STEP, 64)
 LOOP_KERNEL(st_loop_8k, 1024, 128, STORE_STEP, 64)
 LOOP_KERNEL(st_loop_4k, 512, 256, STORE_STEP, 64)
+LOOP_KERNEL(st8_line_1m, 131072, 1, STORE_STEP8, 64)
+LOOP_KERNEL(st8_loop_64k, 8192, 16, STORE_STEP8, 64)
+LOOP_KERNEL(st8_loop_4k, 512, 256, STORE_STEP8, 64)
 LOOP_KERNEL(bar_line_1m, 131072, 1, BAR_STEP, 256)
 LOOP_KERNEL(bar_loop_256k, 32768, 4, BAR_STEP, 256)
 
@@ -80,7 +86,7 @@ __global__ void __launch_bounds__(256) reader(const u32x4 *in, size_t n16, int p
 typedef void (*kern_t)(uint32_t *, uint8_t *, uint32_t);
 int main() {
     uint32_t *out, *sink; u32x4 *big; uint8_t *rows;
-    const size_t big_bytes = 8ull << 30, rows_bytes = 1024ull * (16u << 20);
+    const size_t big_bytes = 8ull << 30, rows_bytes = 1024ull * (32u << 20);
     CK(hipMalloc(&out, 1024 * 64 * 4)); CK(hipMalloc(&sink, 4)); CK(hipMalloc(&big, big_bytes)); CK(hipMemset(big, 0, big_bytes));
     CK(hipMalloc(&rows, rows_bytes)); CK(hipMemset(rows, 0, rows_bytes));
     hipStream_t s1, s2; CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
@@ -93,6 +99,8 @@ int main() {
               {"+ own row stores: straight line", st_line_1m, 64, 1}, {"+ own row stores: 4 x 256 K", st_loop_256k, 64, 1},
               {"+ own row stores: 16 x 64 K", st_loop_64k, 64, 1}, {"+ own row stores: 64 x 16 K", st_loop_16k, 64, 1},
               {"+ own row stores: 128 x 8 K", st_loop_8k, 64, 1}, {"+ own row stores: 256 x 4 K", st_loop_4k, 64, 1},
+              {"+ own row stores, one per 8: straight line", st8_line_1m, 64, 2}, {"+ own row stores, one per 8: 16 x 64 K", st8_loop_64k, 64, 2},
+              {"+ own row stores, one per 8: 256 x 4 K", st8_loop_4k, 64, 2},
               {"4 waves + s_barrier / 2 K: straight line", bar_line_1m, 256, 0}, {"4 waves + s_barrier / 2 K: 4 x 256 K", bar_loop_256k, 256, 0}};
     const double n_ins = 131072.0 * 8;
     printf("one wave per SIMD on every CU (1 024 waves), %.0f K VALU instructions per wave (5 x 8-byte + 3 x 4-byte per 8)\n", n_ins / 1024);
@@ -119,7 +127,7 @@ int main() {
             }
             printf("%-44s %-16s avg %7.3f ms  best %7.3f ms = %5.2f ns per instruction", e.name, mode == 0 ? "alone" : mode == 1 ? "beside a writer" : "beside a reader",
                    tot / 3, best, best * 1e6 / n_ins);
-            if (e.stores) printf("  own stores %.0f GB/s", 17.18 / best * 1e3);
+            if (e.stores) printf("  own stores %.0f GB/s", 17.18 * e.stores / best * 1e3);
             if (mode) printf("   (the other kernel: %.1f ms for %.0f GB = %.0f GB/s)", bg_ms, 6 * big_bytes * 1e-9, 6 * big_bytes / bg_ms * 1e-6);
             printf("\n");
             fflush(stdout);
