@@ -316,6 +316,7 @@ def _recipe_eval(n, steps, m):
 
 LUT_MAX_WIRES = 6
 INT_COEF_LIMIT = 1 << 64
+SUBSTITUTE_PRODUCTS = True      # build_check: a row's table drops a wire that a checked product row `w = x * y` pins (x, y in the row too)
 
 
 def _resolve_ports(net) -> dict:
@@ -365,6 +366,23 @@ def build_check(net, fc):
                 t[nd] = t.get(nd, 0) + cf
         return signed(c0), {k: signed(v) for k, v in t.items() if v % q}
 
+    # Wires that a CHECKED product row pins: `w = x * y` (single terms whose coefficients cancel) over three distinct wires (Xor3's and Maj's
+    # `mid <== b * c`).  Another row of up to LUT_MAX_WIRES wires that contains w, x and y is checked with w REPLACED by x & y -
+    # one wire less in its table (Xor3's `out` row: 5 -> 4 wires, 4 -> 2 gates) and no need to keep w around for it.  The
+    # instance-level verdict is unchanged: if the product row holds, w = x & y and the other row is evaluated on the very same
+    # values; if it does not hold, the product row itself raises the flag.  (Which row failed first comes from the audit
+    # kernels, which check every row as written.)
+    pinned = {}
+    if SUBSTITUTE_PRODUCTS:
+        for (A, B, C) in fc.constraints:
+            if len(A) == 1 and len(B) == 1 and len(C) == 1:
+                (sa, ca), (sb, cb), (sc, cc) = next(iter(A.items())), next(iter(B.items())), next(iter(C.items()))
+                if sa and sb and sc and cc % q and (ca * cb - cc) % q == 0:          # ca x * cb y = cc w with ca cb = cc: w = x y
+                    x, y, w = int(sn[sa]), int(sn[sb]), int(sn[sc])
+                    if min(x, y, w) > 1 and len({x, y, w}) == 3 and w not in pinned and w not in ports:
+                        pinned[w] = (x, y)
+    st["substituted"] = 0
+
     for (A, B, C) in fc.constraints:
         a0, at = lin(A)
         b0, bt = lin(B)
@@ -406,19 +424,32 @@ def build_check(net, fc):
                     st["trivial"] += 1
                     continue
         if len(wires) <= LUT_MAX_WIRES:
-            n = len(wires)
+            # wires of this row that a product row pins to two other wires of this row (not the product row itself)
+            sub = {}
+            if pinned:
+                for w in wires:
+                    xy = pinned.get(w)
+                    if xy is not None and xy[0] in wires and xy[1] in wires and len(wires) > 3 and xy[0] not in sub and xy[1] not in sub:
+                        sub[w] = xy
+            free = [w for w in wires if w not in sub]
+            n = len(free)
             tt = 0
             for m in range(1 << n):
+                val = {w: (m >> j) & 1 for j, w in enumerate(free)}
+                for w, (x, y) in sub.items():
+                    val[w] = val[x] & val[y]
                 av, bv, cv = a0, b0, c0
-                for j, w in enumerate(wires):
-                    if (m >> j) & 1:
+                for w in wires:
+                    if val[w]:
                         av += at.get(w, 0); bv += bt.get(w, 0); cv += ct.get(w, 0)
                 if (av * bv - cv) % q:
                     tt |= 1 << m
             if tt == 0:
                 st["trivial"] += 1
                 continue
-            v = G.lut(wires, tt)
+            if sub:
+                st["substituted"] += 1
+            v = G.lut(free, tt)
             st["lut"] += 1
             if v:
                 viol.append(v)

@@ -436,3 +436,53 @@ def test_instances_wired_differently_share_no_loop_when_their_gates_differ(monke
     mem, fb, bad = _run(jp, fc, rows)
     assert fb == 0 and bad == 0
     _check_witnesses(jp, fc, rows, mem)          # (two isomorphic instances: a loop of two, or none - either way exact)
+
+
+def test_check_rows_drop_a_wire_that_a_checked_product_row_pins():
+    """build_check: `mid <== b * c` is a checked row of its own, so the `out` rows of Xor3 / Maj are checked with mid replaced by
+    b & c (5 -> 4 wires: fewer gates, and mid need not be kept for them).  Instance-level verdicts must not change: the table an
+    evaluation left is clean, and after flipping ANY single wire - the pinned mid, an operand, the output - in some instances the
+    audit flags exactly the instances that violate a constraint (the product row raises the flag when mid itself is wrong)."""
+    @template
+    def Cells(c, n):
+        a = c.input("a", n); b = c.input("b", n); cc = c.input("c", n)
+        out = c.output("out", n)
+        x3 = c.component("x3", Xor3(n)); mj = c.component("mj", Maj_t(n))
+        for k in range(n):
+            c.set(x3["a"][k], a[k]); c.set(x3["b"][k], b[k]); c.set(x3["c"][k], cc[k])
+        for k in range(n):
+            c.set(mj["a"][k], x3["out"][k]); c.set(mj["b"][k], b[(k + 1) % n]); c.set(mj["c"][k], cc[k])
+        for k in range(n):
+            c.set(out[k], mj["out"][k])
+    fc = flatten(Program(Cells(6)))
+    net = BB.bitblast(fc)
+    with_sub = BJ.lower_jit(net, fc)
+    assert with_sub.stats["check_substituted"] == 12                      # the out rows of 6 Xor3 and 6 Maj cells
+    BJ.SUBSTITUTE_PRODUCTS = False
+    try:
+        net._check_cache = None
+        without = BJ.lower_jit(net, fc)
+    finally:
+        BJ.SUBSTITUTE_PRODUCTS = True
+        net._check_cache = None
+    assert with_sub.stats["check_gates"] < without.stats["check_gates"]
+    jp = BJ.lower_jit(net, fc)
+    ja = BJ.lower_jit(net, fc, audit_of=jp)
+    W = 40
+    rows = _rows(fc, W, 2)
+    mem, fb, bad = _run(jp, fc, rows)
+    assert fb == 0 and bad == 0
+    _check_witnesses(jp, fc, rows, mem)
+    table = {k: v for k, v in mem.items() if k < jp.n_slots}
+    ja_run = type("J", (), {"ir": ja.ir, "n_slots": ja.n_slots, "n_vgpr": ja.n_vgpr, "n_agpr": ja.n_agpr})
+    names = fc.signal_names()
+    flipped_mid = 0
+    for s_ in range(1, fc.n_signals):
+        t2 = dict(table)
+        t2[int(jp.sig_slot[s_])] ^= sum(1 << i for i in (0, 13, W - 1))
+        _, _, bad3 = run_ir(ja_run, t2, W)
+        flipped_mid += ".mid[" in names[s_]
+        for i in range(W):
+            sig = [(t2[int(jp.sig_slot[s])] >> i) & 1 for s in range(fc.n_signals)]
+            assert bool((bad3 >> i) & 1) == (check_r1cs(fc.fp.q, fc.constraints, sig) is not None), (names[s_], i)
+    assert flipped_mid == 12
