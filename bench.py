@@ -187,13 +187,17 @@ def get_compiled(name: str, batch: int, cache_root: str, rank: int, dist):
     cached = os.path.exists(done)
     if cached and rank == 0:
         # large artefacts travel compressed (tools/prebuild_cache.py: the .r1cs of the ECDSA verifier is 407 MB, 34 MB gzipped)
+        # (.xz for the 53-block SHA-256, tools/r06_prebuild_27008.sh: 1.7 GB of tables in 93 MB - gzip leaves 254 MB, and the gpurun
+        # snapshot has a size limit)
         import gzip
+        import lzma
         import shutil
         for ext in (".cwt", ".dat", ".r1cs"):
-            if not os.path.exists(p(ext)) and os.path.exists(p(ext) + ".gz"):
-                with gzip.open(p(ext) + ".gz", "rb") as fi, open(p(ext) + ".tmp", "wb") as fo:
-                    shutil.copyfileobj(fi, fo, 1 << 24)
-                os.replace(p(ext) + ".tmp", p(ext))
+            for suffix, opener in ((".gz", gzip.open), (".xz", lzma.open)):
+                if not os.path.exists(p(ext)) and os.path.exists(p(ext) + suffix):
+                    with opener(p(ext) + suffix, "rb") as fi, open(p(ext) + ".tmp", "wb") as fo:
+                        shutil.copyfileobj(fi, fo, 1 << 24)
+                    os.replace(p(ext) + ".tmp", p(ext))
     if rank == 0 and not cached:
         os.makedirs(d, exist_ok=True)
         bittape, bitnet = (None, None) if os.environ.get("CW_BITS", "1") == "0" else compiler.lower_bitplane_net(fc)

@@ -181,11 +181,15 @@ def emit_jit(net, fc, jit="auto"):
     # assembled with its own row count and the header then raised to the audit's)
     ja = None
     if os.environ.get("CW_JIT_AUDIT", "1") != "0":
+        akw = {}
+        if os.environ.get("CW_JIT_AUDIT_REGS"):     # "vgprs,accvgprs" for the audit program: tests starve it so that it spills scratch rows
+            nv_, na_ = (int(x) for x in os.environ["CW_JIT_AUDIT_REGS"].split(","))
+            akw = {"n_vgpr": nv_, "n_agpr": na_}
         try:
-            ja = bitjit.lower_jit(net, fc, audit_of=jp)
+            ja = bitjit.lower_jit(net, fc, audit_of=jp, **akw)
         except bitjit._AuditTooBig:
             # (the audit's iteration wanted more scratch rows than a loop iteration of the main program has to spare)
-            ja = bitjit.lower_jit(net, fc, audit_of=jp, loop=False)
+            ja = bitjit.lower_jit(net, fc, audit_of=jp, loop=False, **akw)
         if ja is not None:
             jp.n_slots = ja.n_slots = max(jp.n_slots, ja.n_slots)
     try:

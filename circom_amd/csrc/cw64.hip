@@ -93,17 +93,32 @@ __global__ void __launch_bounds__(256) cw64_ingest_kernel(const uint64_t *__rest
 // index of the flat operation (failure reports); 0; 0
 enum : uint32_t { O_COPY = 0, O_ADD, O_SUB, O_MUL, O_DIV, O_IDIV, O_MOD, O_POW, O_NEG, O_SHL, O_SHR, O_BAND, O_BOR, O_BXOR, O_BNOT,
                   O_LT, O_GT, O_LEQ, O_GEQ, O_EQ, O_NEQ, O_LAND, O_LOR, O_LNOT, O_SELECT, O_ASSERT_EQ, O_ASSERT_NZ };
+// Operands of row r + 1 are requested BEFORE row r computes (one wave per SIMD at the benchmark batch: a row is two dependent
+// global loads, arithmetic and a store - without the prefetch every row pays the full load latency); a row that reads what the
+// row in front of it has just produced takes the value from the register instead (wave-uniform test: rows are uniform).
 __global__ void __launch_bounds__(64) cw64_eval_kernel(const uint4 *__restrict__ rows, uint32_t n_rows, const uint64_t *__restrict__ consts,
                                                        uint64_t *V, uint32_t Bp, uint32_t batch, uint32_t *status) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= batch) return;
+    if (i >= batch || n_rows == 0) return;
     uint64_t *Vi = V + i;
     uint32_t st = 0;
+    uint4 x = rows[0], y = rows[1];
+    uint64_t a, b;
+    {
+        const uint32_t ak = (x.x >> 10) & 3, bk = (x.x >> 12) & 3;
+        a = ak == 0 ? Vi[(size_t)x.z * Bp] : ak == 2 ? consts[x.z] : 0;
+        b = bk == 0 ? Vi[(size_t)x.w * Bp] : bk == 2 ? consts[x.w] : 0;
+    }
     for (uint32_t r = 0; r < n_rows; r++) {
-        const uint4 x = rows[2 * r], y = rows[2 * r + 1];               // wave-uniform: scalar loads
-        const uint32_t op = x.x & 0xFF, ak = (x.x >> 10) & 3, bk = (x.x >> 12) & 3, ck = (x.x >> 14) & 3;
-        const uint64_t a = ak == 0 ? Vi[(size_t)x.z * Bp] : ak == 2 ? consts[x.z] : 0;
-        const uint64_t b = bk == 0 ? Vi[(size_t)x.w * Bp] : bk == 2 ? consts[x.w] : 0;
+        const uint32_t op = x.x & 0xFF, ck = (x.x >> 14) & 3;
+        const bool stores = ((x.x >> 8) & 3) == 0 && op != O_ASSERT_EQ && op != O_ASSERT_NZ;
+        // the next row and its operands (the last iteration re-reads the last row: harmless)
+        const uint32_t rn = r + 1 < n_rows ? r + 1 : r;
+        const uint4 nx = rows[2 * rn], ny = rows[2 * rn + 1];               // wave-uniform: scalar loads
+        const uint32_t nak = (nx.x >> 10) & 3, nbk = (nx.x >> 12) & 3;
+        const bool fwd_a = stores && nak == 0 && nx.z == x.y, fwd_b = stores && nbk == 0 && nx.w == x.y;
+        uint64_t na = (nak == 0 && !fwd_a) ? Vi[(size_t)nx.z * Bp] : nak == 2 ? consts[nx.z] : 0;
+        uint64_t nb = (nbk == 0 && !fwd_b) ? Vi[(size_t)nx.w * Bp] : nbk == 2 ? consts[nx.w] : 0;
         uint64_t d = 0;
         bool fail = false;
         switch (op) {
@@ -142,32 +157,48 @@ __global__ void __launch_bounds__(64) cw64_eval_kernel(const uint4 *__restrict__
         }
         if (fail && !(st & 3u))                                      // the first failing check in program order
             st = (op == O_IDIV || op == O_MOD ? CW_ST_ARITH : CW_ST_ASSERT_FAILED) | (y.y << 8);
-        if (((x.x >> 8) & 3) == 0 && op != O_ASSERT_EQ && op != O_ASSERT_NZ) Vi[(size_t)x.y * Bp] = d;
+        if (stores) Vi[(size_t)x.y * Bp] = d;
+        a = fwd_a ? d : na;
+        b = fwd_b ? d : nb;
+        x = nx;
+        y = ny;
     }
     if (st) atomicOr(&status[i], st);
 }
 
 // R1CS: constraint k = three runs of (slot, coefficient) terms; A.w * B.w == C.w.  term = {slot, part | last of the constraint
-// << 2, coefficient lo, hi}
-__global__ void __launch_bounds__(64) cw64_r1cs_kernel(const uint4 *__restrict__ terms, uint32_t n_terms, const uint64_t *__restrict__ V,
-                                                       uint32_t Bp, uint32_t batch, uint32_t *status, uint32_t *first_bad) {
+// << 2, coefficient lo, hi}.  A workgroup checks ONE CHUNK of consecutive constraints (chunk = {first term, terms, first row, 0},
+// cut at constraint boundaries by the host) for 64 instances: the launch is (groups x chunks) workgroups instead of one
+// wave per 64 instances walking the whole system (Poseidon(2): 3 037 dependent load + multiply steps per wave, one wave per
+// SIMD: 1.69 ms; chunked: the chip is full and the loads of different chunks overlap).
+__global__ void __launch_bounds__(64) cw64_r1cs_kernel(const uint4 *__restrict__ chunks, uint32_t n_chunks, const uint4 *__restrict__ terms,
+                                                       const uint64_t *__restrict__ V, uint32_t Bp, uint32_t batch, uint32_t *status,
+                                                       uint32_t *first_bad) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= batch) return;
     const uint64_t *Vi = V + i;
-    uint64_t acc[3] = {0, 0, 0};
-    uint32_t row = 0, bad = 0xFFFFFFFFu;
-    for (uint32_t t = 0; t < n_terms; t++) {
-        const uint4 x = terms[t];
-        const uint64_t w = Vi[(size_t)x.x * Bp], cf = ((uint64_t)x.w << 32) | x.z;
-        const uint64_t pr = gl_mul(w, cf);
-        const uint32_t part = x.y & 3u;
-        acc[0] = part == 0 ? gl_add(acc[0], pr) : acc[0];
-        acc[1] = part == 1 ? gl_add(acc[1], pr) : acc[1];
-        acc[2] = part == 2 ? gl_add(acc[2], pr) : acc[2];
-        if (x.y & 4u) {
-            if (gl_mul(acc[0], acc[1]) != acc[2] && row < bad) bad = row;
-            row++;
-            acc[0] = acc[1] = acc[2] = 0;
+    uint32_t bad = 0xFFFFFFFFu;
+    for (uint32_t cix = blockIdx.y; cix < n_chunks; cix += gridDim.y) {
+        const uint4 ch = chunks[cix];
+        uint64_t acc[3] = {0, 0, 0};
+        uint32_t row = ch.z;
+        uint4 x = terms[ch.x];
+        uint64_t w = Vi[(size_t)x.x * Bp];
+        for (uint32_t t = 0; t < ch.y; t++) {
+            const uint4 nx = terms[ch.x + (t + 1 < ch.y ? t + 1 : t)];      // the next term's wire is in flight during the product
+            const uint64_t nw = Vi[(size_t)nx.x * Bp];
+            const uint64_t pr = gl_mul(w, ((uint64_t)x.w << 32) | x.z);
+            const uint32_t part = x.y & 3u;
+            acc[0] = part == 0 ? gl_add(acc[0], pr) : acc[0];
+            acc[1] = part == 1 ? gl_add(acc[1], pr) : acc[1];
+            acc[2] = part == 2 ? gl_add(acc[2], pr) : acc[2];
+            if (x.y & 4u) {
+                if (gl_mul(acc[0], acc[1]) != acc[2] && row < bad) bad = row;
+                row++;
+                acc[0] = acc[1] = acc[2] = 0;
+            }
+            x = nx;
+            w = nw;
         }
     }
     if (bad != 0xFFFFFFFFu) {
@@ -204,11 +235,11 @@ hipError_t cwk64_eval(hipStream_t s, const void *rows, uint32_t n_rows, const vo
                        (uint64_t *)V, Bp, batch, status);
     return hipGetLastError();
 }
-hipError_t cwk64_r1cs(hipStream_t s, const void *terms, uint32_t n_terms, const void *V, uint32_t Bp, uint32_t batch, uint32_t *status,
-                      uint32_t *first_bad) {
-    if (!n_terms) return hipSuccess;
-    hipLaunchKernelGGL(cw64_r1cs_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, (const uint4 *)terms, n_terms, (const uint64_t *)V, Bp,
-                       batch, status, first_bad);
+hipError_t cwk64_r1cs(hipStream_t s, const void *chunks, uint32_t n_chunks, const void *terms, const void *V, uint32_t Bp, uint32_t batch,
+                      uint32_t *status, uint32_t *first_bad) {
+    if (!n_chunks) return hipSuccess;
+    hipLaunchKernelGGL(cw64_r1cs_kernel, dim3((batch + 63) / 64, n_chunks < 65535u ? n_chunks : 65535u), dim3(64), 0, s, (const uint4 *)chunks,
+                       n_chunks, (const uint4 *)terms, (const uint64_t *)V, Bp, batch, status, first_bad);
     return hipGetLastError();
 }
 hipError_t cwk64_gather(hipStream_t s, const void *V, const uint32_t *w2s, uint32_t n_wit, uint32_t Bp, uint32_t first, uint32_t count,

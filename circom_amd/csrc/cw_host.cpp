@@ -291,6 +291,7 @@ struct cw_circuit {
     std::vector<uint64_t> consts64;
     uint32_t n_slots64 = 0;
     std::vector<uint32_t> r1_terms64;      // R1CS terms {slot, part | end << 2, coefficient lo, hi}
+    std::vector<uint32_t> r1_chunks64;     // chunks of consecutive constraints {first term, terms, first row, 0}: one workgroup each
     bool has_jit = false;
     cwbits::JitProgram jit;
     std::map<int, std::pair<hipModule_t, hipFunction_t>> jit_mod;   // device -> loaded module
@@ -605,6 +606,9 @@ static int load_r1cs64(cw_circuit *c, const char *path) {
     if (n_wires != c->n_witness) return fail(CW_EIO, "r1cs wire count differs from the witness size");
     const uint8_t *p = sec[2], *end = sec[2] + seclen[2];
     c->r1_terms64.clear();
+    c->r1_chunks64.clear();
+    const uint32_t CHUNK_TERMS = 48;                                  // a chunk closes at the first constraint boundary past this
+    uint32_t chunk_first = 0, chunk_row = 0;
     for (uint32_t k = 0; k < n_cons; k++) {
         const size_t first = c->r1_terms64.size();
         for (uint32_t part = 0; part < 3; part++) {
@@ -626,6 +630,12 @@ static int load_r1cs64(cw_circuit *c, const char *path) {
         if (c->r1_terms64.size() == first)                       // an empty constraint still closes a row: 0 * 0 = 0 on the constant wire
             c->r1_terms64.insert(c->r1_terms64.end(), {0u, 2u, 0u, 0u});
         c->r1_terms64[c->r1_terms64.size() - 3] |= 4u;
+        const uint32_t now = (uint32_t)(c->r1_terms64.size() / 4);
+        if (now - chunk_first >= CHUNK_TERMS || k + 1 == n_cons) {
+            c->r1_chunks64.insert(c->r1_chunks64.end(), {chunk_first, now - chunk_first, chunk_row, 0u});
+            chunk_first = now;
+            chunk_row = k + 1;
+        }
     }
     c->n_constraints = n_cons;
     return CW_OK;
@@ -1659,7 +1669,7 @@ struct cw_batch {
     hipFunction_t jit_fn = nullptr;
     // 64-bit runtime: V64[slot][Bp], its program and R1CS terms
     uint64_t *d_V64 = nullptr, *d_consts64 = nullptr;
-    uint32_t *d_rows64 = nullptr, *d_terms64 = nullptr;
+    uint32_t *d_rows64 = nullptr, *d_terms64 = nullptr, *d_chunks64 = nullptr;
     uint64_t *d_r1flag = nullptr;                      // per group: instances whose fused R1CS check fired (emitted code)
     // cw_batch_set_timing: events on the batch's stream around the parts of cw_run / cw_check_r1cs (their own intervals, measured
     // where they run - bench.py's roofline figures): 0 run begins | 1 inputs ingested | 2 evaluation done | 3 check begins | 4 check done
@@ -1707,7 +1717,7 @@ extern "C" void cw_batch_free(cw_batch *b) {
         for (hipEvent_t e : t.ev)
             if (e) hipEventDestroy(e);
     if (b->fb) cw_batch_free(b->fb);
-    void *bptrs[] = {b->d_V64, b->d_consts64, b->d_rows64, b->d_terms64, b->d_T, b->d_fbmask, b->d_r1flag, b->d_brecs, b->d_bcmds, b->d_aslots, b->d_wslot, b->d_fbinst, b->d_erecs, b->d_wchunk, b->d_wterms, b->d_wctab, b->d_wrow,
+    void *bptrs[] = {b->d_V64, b->d_consts64, b->d_rows64, b->d_terms64, b->d_chunks64, b->d_T, b->d_fbmask, b->d_r1flag, b->d_brecs, b->d_bcmds, b->d_aslots, b->d_wslot, b->d_fbinst, b->d_erecs, b->d_wchunk, b->d_wterms, b->d_wctab, b->d_wrow,
                      b->d_ichunk, b->d_iterms, b->d_itab, b->d_irow, b->d_sigslot, b->d_pmask};
     for (void *p : bptrs)
         if (p) hipFree(p);
@@ -2497,6 +2507,7 @@ static int batch_setup64(cw_batch *b) {
     BTRY(upload(&b->d_rows64, c->rows64, b->stream));
     BTRY(upload(&b->d_consts64, c->consts64, b->stream));
     BTRY(upload(&b->d_terms64, c->r1_terms64, b->stream));
+    BTRY(upload(&b->d_chunks64, c->r1_chunks64, b->stream));
     BTRY(upload(&b->d_w2s, c->w2s, b->stream));
     BTRY(hipMalloc((void **)&b->d_status, (size_t)b->Bp * 4));
     BTRY(hipMalloc((void **)&b->d_first_bad, (size_t)b->Bp * 4));
@@ -2852,7 +2863,8 @@ extern "C" int cw_check_r1cs(cw_batch *b) {
     HIPCHK(hipSetDevice(b->device));
     if (c->is64) {
         TMARK(b, 3);
-        HIPCHK(cwk64_r1cs(b->stream, b->d_terms64, (uint32_t)(c->r1_terms64.size() / 4), b->d_V64, b->Bp, b->batch, b->d_status, b->d_first_bad));
+        HIPCHK(cwk64_r1cs(b->stream, b->d_chunks64, (uint32_t)(c->r1_chunks64.size() / 4), b->d_terms64, b->d_V64, b->Bp, b->batch, b->d_status,
+                          b->d_first_bad));
         TMARK(b, 4);
         return CW_OK;
     }

@@ -61,7 +61,7 @@ hipError_t cwk64_init(hipStream_t s, void *V, uint32_t Bp, uint32_t *status, uin
 hipError_t cwk64_ingest(hipStream_t s, const void *in, void *V, uint32_t input_start, uint32_t n_in, uint32_t batch, uint32_t Bp);
 hipError_t cwk64_eval(hipStream_t s, const void *rows, uint32_t n_rows, const void *consts, void *V, uint32_t Bp, uint32_t batch,
                       uint32_t *status);
-hipError_t cwk64_r1cs(hipStream_t s, const void *terms, uint32_t n_terms, const void *V, uint32_t Bp, uint32_t batch, uint32_t *status,
-                      uint32_t *first_bad);
+hipError_t cwk64_r1cs(hipStream_t s, const void *chunks, uint32_t n_chunks, const void *terms, const void *V, uint32_t Bp, uint32_t batch,
+                      uint32_t *status, uint32_t *first_bad);
 hipError_t cwk64_gather(hipStream_t s, const void *V, const uint32_t *w2s, uint32_t n_wit, uint32_t Bp, uint32_t first, uint32_t count,
                         void *out);

@@ -237,7 +237,7 @@ def test_sha256_27008_through_the_looped_emitted_code(tmp_path, monkeypatch):
     through the emitted engine: 53 iterations of ONE block body (hip_elements/bitjit.py loops; 2.6 MB of code instead of 137 MB).
     2^18 instances with packed inputs: the two reference-runtime goldens inside the batch (their 346 MB `.wtns` files compared
     through the hash, tests/golden/reference_wtns_sha256_27008.json), sampled digests against hashlib, the fused check clean.
-    The lowered artefacts (30 minutes of lowering, 250 MB gzipped) travel in gpurun_in/cache when they were prebuilt
+    The lowered artefacts (30 minutes of lowering, 93 MB xz-compressed) travel in gpurun_in/cache when they were prebuilt
     (tools/r06_prebuild_27008.sh); without them the test has nothing to run on."""
     import glob
     import json

@@ -652,6 +652,7 @@ def test_gpu_emitted_code_beyond_one_chunk_when_the_audit_spills(tmp_path, monke
     the emitted audit of the table (CW_R1CS_AUDIT=1) clean."""
     import hashlib
     monkeypatch.setenv("CW_BITS_JIT", "1")
+    monkeypatch.setenv("CW_JIT_AUDIT_REGS", "64,8")          # a starved audit: its spills add scratch rows behind the table
     cp, c = _gpu(tmp_path, Program(Sha256(64)), "sha256_64s")
     assert cp.jit.audit_code and cp.jit.n_slots > cp.jit.stats["slots"], "this circuit's audit was expected to add scratch rows"
     assert cp.jit.code_stride == cp.jit.audit_stride == cp.jit.n_slots * 256
