@@ -93,32 +93,21 @@ __global__ void __launch_bounds__(256) cw64_ingest_kernel(const uint64_t *__rest
 // index of the flat operation (failure reports); 0; 0
 enum : uint32_t { O_COPY = 0, O_ADD, O_SUB, O_MUL, O_DIV, O_IDIV, O_MOD, O_POW, O_NEG, O_SHL, O_SHR, O_BAND, O_BOR, O_BXOR, O_BNOT,
                   O_LT, O_GT, O_LEQ, O_GEQ, O_EQ, O_NEQ, O_LAND, O_LOR, O_LNOT, O_SELECT, O_ASSERT_EQ, O_ASSERT_NZ };
-// Operands of row r + 1 are requested BEFORE row r computes (one wave per SIMD at the benchmark batch: a row is two dependent
-// global loads, arithmetic and a store - without the prefetch every row pays the full load latency); a row that reads what the
-// row in front of it has just produced takes the value from the register instead (wave-uniform test: rows are uniform).
+// (Round 6 tried requesting the operands of row r + 1 before row r computes, with register forwarding of a value the next row
+// reads: 1.15 ms instead of 0.96 ms for Poseidon(2) x 65 536 - the loads of one row already overlap across the waves of a SIMD,
+// the extra bookkeeping does not pay; profiles/r06i_bench_poseidon2_goldilocks.json has that run.  The check below is what
+// moved the line: 38 -> 59 M witnesses/s.)
 __global__ void __launch_bounds__(64) cw64_eval_kernel(const uint4 *__restrict__ rows, uint32_t n_rows, const uint64_t *__restrict__ consts,
                                                        uint64_t *V, uint32_t Bp, uint32_t batch, uint32_t *status) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= batch || n_rows == 0) return;
+    if (i >= batch) return;
     uint64_t *Vi = V + i;
     uint32_t st = 0;
-    uint4 x = rows[0], y = rows[1];
-    uint64_t a, b;
-    {
-        const uint32_t ak = (x.x >> 10) & 3, bk = (x.x >> 12) & 3;
-        a = ak == 0 ? Vi[(size_t)x.z * Bp] : ak == 2 ? consts[x.z] : 0;
-        b = bk == 0 ? Vi[(size_t)x.w * Bp] : bk == 2 ? consts[x.w] : 0;
-    }
     for (uint32_t r = 0; r < n_rows; r++) {
-        const uint32_t op = x.x & 0xFF, ck = (x.x >> 14) & 3;
-        const bool stores = ((x.x >> 8) & 3) == 0 && op != O_ASSERT_EQ && op != O_ASSERT_NZ;
-        // the next row and its operands (the last iteration re-reads the last row: harmless)
-        const uint32_t rn = r + 1 < n_rows ? r + 1 : r;
-        const uint4 nx = rows[2 * rn], ny = rows[2 * rn + 1];               // wave-uniform: scalar loads
-        const uint32_t nak = (nx.x >> 10) & 3, nbk = (nx.x >> 12) & 3;
-        const bool fwd_a = stores && nak == 0 && nx.z == x.y, fwd_b = stores && nbk == 0 && nx.w == x.y;
-        uint64_t na = (nak == 0 && !fwd_a) ? Vi[(size_t)nx.z * Bp] : nak == 2 ? consts[nx.z] : 0;
-        uint64_t nb = (nbk == 0 && !fwd_b) ? Vi[(size_t)nx.w * Bp] : nbk == 2 ? consts[nx.w] : 0;
+        const uint4 x = rows[2 * r], y = rows[2 * r + 1];               // wave-uniform: scalar loads
+        const uint32_t op = x.x & 0xFF, ak = (x.x >> 10) & 3, bk = (x.x >> 12) & 3, ck = (x.x >> 14) & 3;
+        const uint64_t a = ak == 0 ? Vi[(size_t)x.z * Bp] : ak == 2 ? consts[x.z] : 0;
+        const uint64_t b = bk == 0 ? Vi[(size_t)x.w * Bp] : bk == 2 ? consts[x.w] : 0;
         uint64_t d = 0;
         bool fail = false;
         switch (op) {
@@ -157,11 +146,7 @@ __global__ void __launch_bounds__(64) cw64_eval_kernel(const uint4 *__restrict__
         }
         if (fail && !(st & 3u))                                      // the first failing check in program order
             st = (op == O_IDIV || op == O_MOD ? CW_ST_ARITH : CW_ST_ASSERT_FAILED) | (y.y << 8);
-        if (stores) Vi[(size_t)x.y * Bp] = d;
-        a = fwd_a ? d : na;
-        b = fwd_b ? d : nb;
-        x = nx;
-        y = ny;
+        if (((x.x >> 8) & 3) == 0 && op != O_ASSERT_EQ && op != O_ASSERT_NZ) Vi[(size_t)x.y * Bp] = d;
     }
     if (st) atomicOr(&status[i], st);
 }
