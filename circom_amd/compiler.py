@@ -210,7 +210,10 @@ def emit_jit(net, fc, jit="auto"):
     return jp
 
 
-FPJIT_MAX_ROWS = 400_000            # "auto": beyond this the code object (about 100 bytes per row) is not worth its size
+FPJIT_MAX_ROWS = 400_000            # "auto": beyond this the code object (about 100 bytes per row) is not worth its size ...
+FPJIT_MAX_ROWS_CALLS = 4_000_000    # ... except for strand schedules around run-time function calls (config 5's verifier: 1.25 M rows):
+                                    # the interpreting kernel pays ~5 K clocks per row whatever it computes, the emitted rows a
+                                    # fraction of it; such programs are emitted WITHOUT the fused-check twin (twice the code)
 
 
 def emit_fpjit(tapes, fc, fpjit="auto", fuse_check=True):
@@ -232,13 +235,14 @@ def emit_fpjit(tapes, fc, fpjit="auto", fuse_check=True):
     for t in tapes:
         if getattr(t, "kind", 0) != 0:
             continue
-        if fpjit == "auto" and len(t.rows) > FPJIT_MAX_ROWS:
+        big_calls = bool(t.functions) and t.n_strands > 1 and len(t.rows) > FPJIT_MAX_ROWS
+        if fpjit == "auto" and len(t.rows) > (FPJIT_MAX_ROWS_CALLS if big_calls else FPJIT_MAX_ROWS):
             continue
         # two programs per variant: the rows alone, and the rows with the R1CS check fused in.  Which one a batch runs is the
         # runtime's choice (cw_batch_create): recomputing the constraints inside the evaluation costs about as many instructions
         # as the evaluation itself - it pays where the launch is throughput-bound (the wires are in registers and caches instead
         # of a second pass over HBM), not where a small batch waits on its dependency chain
-        for cons in ((None, fc.constraints) if (fuse_check and fc.constraints) else (None,)):
+        for cons in ((None, fc.constraints) if (fuse_check and fc.constraints and not big_calls) else (None,)):
             spool_dir = None
             try:
                 # (beyond ~300 K rows the text goes to a file as it is produced: tens of millions of lines)

@@ -33,7 +33,7 @@ from . import fpjit_bodies as FB
 from .lower import (D_COPY, D_ADD, D_SUB, D_NEG, D_MMUL, D_INV, D_IDIV, D_MOD, D_POW, D_SHL, D_SHR, D_BAND, D_BOR, D_BXOR,
                     D_BNOT, D_LT, D_GT, D_LEQ, D_GEQ, D_EQ, D_NEQ, D_LAND, D_LOR, D_LNOT, D_SELECT, D_EXT, D_ASSERT_EQ,
                     D_ASSERT_NZ, D_BARRIER, D_MUL2, D_MADD, D_MULC, D_MADDC, D_LINSUM, D_BIT, D_DOTC, D_CALL,
-                    SH_DK, SH_AK, SH_BK, SH_NX, SH_FLAG, X_TMP, X_LDS, K_LDS, KD_NONE, KO_PREV)
+                    SH_DK, SH_AK, SH_BK, SH_NX, SH_FLAG, X_TMP, X_LDS, K_LDS, KD_NONE, KO_PREV, D_BITS, X_NEXT, D_ALSO)
 
 KERNEL_NAME = "cw_fp_jit"
 K_SIG, K_TMP, K_CONST = 0, 1, 2
@@ -134,6 +134,31 @@ def expand_steps(tape, strand):
         if op in (D_ASSERT_EQ, D_ASSERT_NZ, D_IDIV, D_MOD, D_CALL):
             seq = int(tape.seqs[sp])
             sp += 1
+        if op == D_ALSO:
+            # the spacer behind a D_BITS row (lower.py): the step behind it requests its operands one step ahead - with the spacer in
+            # between that is after the bits were stored
+            st = _Step()
+            st.inline = ("nop",)
+            xp += nx
+            steps.append(st)
+            continue
+        if op == D_BITS:
+            # consecutive bits of one operand, from bit b_: every extra entry is one store of the current bit, an entry flagged
+            # X_NEXT moves on to the next bit first (cw_tape.h; the interpreter's case D_BITS).  One step: the operand is loaded
+            # once, every entry is a bit extraction and a store (signals: the lower half only - the table starts cleared)
+            ents = []
+            for e in tape.extras[xp:xp + nx]:
+                e = int(e)
+                if e & X_LDS:
+                    raise ValueError("bit-field destinations live in the value table")
+                idx = e & 0x1FFFFFFF
+                ents.append((ns + idx if e & X_TMP else idx, bool(e & X_NEXT), not (e & X_TMP)))
+            xp += nx
+            st = _Step()
+            st.inline = ("bits", b_, tuple(ents))
+            opnd(st, "A", ak, a_)
+            steps.append(st)
+            continue
         stores = []
         if op not in _NO_VALUE and op != D_CALL:
             if dk == K_SIG:
@@ -236,7 +261,9 @@ def expand_steps(tape, strand):
             # tier 2: the interpreter of csrc/cw_call.hip.h as one (heavy) body; arguments and results live in the call's
             # register window in the value table, where ordinary rows stored / will load them
             assert bk == K_TMP
-            st.body = "call_h"
+            # call_h: one wave per workgroup, up to 512 registers, no native long_div; call_k: the strand kernels' 128 VGPRs
+            # (spills into a private segment), with it - what several strands or a long_div function need
+            st.body = "call_k" if (tape.n_strands > 1 or any(f_[2] is not None and f_[2][0] == 4 for f_ in (tape.functions or ()))) else "call_h"
             st.heavy = True
             st.call = (a_, ns + b_, seq)
         else:
@@ -717,6 +744,34 @@ class _Emitter:
                     self.mov_fe(d, ra)
                 elif st.inline[0] == "stashg":
                     self.mov_fe(FB.G_REG, ra)
+                elif st.inline[0] == "nop":
+                    pass
+                elif st.inline[0] == "bits":
+                    kbit = st.inline[1]
+                    for j in range(1, 8):
+                        a("v_mov_b32 v%d, 0" % (d + j))
+                    prev_slot = None
+                    for slot, nxt, lo_only in st.inline[2]:
+                        kbit += 1 if nxt else 0
+                        if kbit < 256:
+                            a("v_bfe_u32 v%d, v%d, %d, 1" % (d, ra + (kbit >> 5), kbit & 31))
+                        else:
+                            a("v_mov_b32 v%d, 0" % d)
+                        if prev_slot is not None and slot == prev_slot + 1:
+                            # (the bits of a Num2Bits are consecutive signals: the next slot is one stride further)
+                            a("s_add_u32 s4, s4, s%d" % S_STRIDE)
+                            a("s_addc_u32 s5, s5, 0")
+                        else:
+                            self.table_addr(slot, 4)
+                        prev_slot = slot
+                        a("global_store_dwordx4 v%d, v[%d:%d], s[4:5]" % (V_VLO, d, d + 3))
+                        self.vm_issued += 1
+                        if not lo_only:
+                            a("global_store_dwordx4 v%d, v[%d:%d], s[4:5]" % (V_VHI, d + 4, d + 7))
+                            self.vm_issued += 1
+                        a("s_nop 1")                  # the store has read D before the next bit overwrites it
+                        self.stats["stores"] += 1
+                    self.ir.append(("bits", ra, st.inline[1], st.inline[2]))
                 else:
                     kbit = st.inline[1]
                     if kbit < 256:
@@ -791,14 +846,9 @@ def emit(tape, bodies=None, constraints=None, spool_path=None) -> FpJitProgram:
         raise ValueError("only strand schedules have an emitted form")
     S = tape.n_strands
     assert S & (S - 1) == 0 and 1 <= S <= 16
-    if S > 1 and tape.functions and (np.asarray(tape.rows)[:, 0] & 0xFF == D_CALL).any():
-        # the interpreter body of run-time functions is compiled for one wave per workgroup (256 VGPRs + AccVGPRs); a workgroup
-        # of several strands leaves a wave 128: those schedules run on the interpreting kernel (cw_eval_kernel)
-        raise NotImplementedError("emitted code of a multi-strand schedule with function calls")
-    if any(f[2] is not None and f[2][0] == 4 for f in (tape.functions or ())):
-        # native long_div (csrc/cw_call.hip.h) is not part of the `call` body (it would push the body past the reach of its
-        # branches and its SGPR budget): the interpreting kernel runs these schedules
-        raise NotImplementedError("emitted code for a schedule whose functions include the native long_div")
+    # (Round 6: schedules of several strands with run-time function calls, and functions with the native long_div, have an emitted
+    # form too - the interpreter body `call_k`, compiled for the strand kernels' 128 VGPRs with a private segment for its spills
+    # (fpjit_bodies.py), and `D_BITS` rows as one step of many stores.  Until then the interpreting kernel ran them: config 5.)
     if bodies is None:
         bodies = FB.build_bodies()
     em = _Emitter(tape, bodies, spool_path)
@@ -888,7 +938,7 @@ def emit(tape, bodies=None, constraints=None, spool_path=None) -> FpJitProgram:
     lds_bytes = PARK_BYTES + n_lds * LDS_SLOT
     n_vgpr, n_agpr = FB.N_VGPR, 0
     if "call_h" in em.used_bodies:                # the interpreter body was compiled for one wave per workgroup: up to 256 + 256
-        assert S == 1, "schedules with run-time functions are single-strand"
+        assert S == 1, "call_h is the single-strand body"
         n_vgpr, n_agpr = 256, (bodies["call_h"].n_agpr + 7) // 8 * 8
     L.append(".rodata\n.p2align 6\n.amdhsa_kernel %s\n"
              "  .amdhsa_user_sgpr_kernarg_segment_ptr 1\n  .amdhsa_system_sgpr_workgroup_id_x 1\n  .amdhsa_system_vgpr_workitem_id 0\n"

@@ -161,6 +161,11 @@ def _specs():
                   "  c.vlo = vlo_; c.vhi = vhi_; c.lane16 = 0; c.lds_hi = 0; c.slot_stride = ks100;\n"
                   "  eval_call_body((uint32_t)sarg, (uint64_t)(uint32_t)(sarg >> 32) * (uint64_t)ks100, c0, st, c, P); }" % (KA_CONSTS, KA_FCODE, KA_FTAB),
                   vin=[(120, "vlo_"), (121, "vhi_")], sin=[(S_ARG, "sarg"), (S_COEF, "c0"), (S_COEF + 2, "c2"), (S_COEF + 3, "c3")], parity="c"))
+    # The same interpreter for the STRAND kernels (16 waves per workgroup: 128 VGPRs per wave; the compiler spills into a private
+    # segment of ~550 bytes per lane) WITH the native long_div: what config 5's verifier calls.  Compiled as a unit of its own
+    # (build_bodies): CW_NO_NATIVE_LONG_DIV, which keeps call_h inside the reach of its branches, is not defined for it.
+    S.append(Body("call_k", next(b_ for b_ in S if b_.name == "call_h").code,
+                  vin=[(120, "vlo_"), (121, "vhi_")], sin=[(S_ARG, "sarg"), (S_COEF, "c0"), (S_COEF + 2, "c2"), (S_COEF + 3, "c3")], parity="k"))
     # row ends of the accumulating operators (no table operand, no parity)
     S.append(Body("linfin", "g = fe_add(g, acc192_to_fe(pos), P); d = fe_sub(g, acc192_to_fe(neg), P);",
                   vout=_fe(D_REG, "d"), acc="lin", g=True))
@@ -180,14 +185,14 @@ def _specs():
     return S
 
 
-def _source(bodies, fe_slow_inline=True):
+def _source(bodies, fe_slow_inline=True, native_long_div=False):
     L = ['#include <hip/hip_runtime.h>', '#define CW_FE_SLOW __forceinline__' if fe_slow_inline else '',
-         '#define CW_CALL_NATIVE __forceinline__', '#define CW_NO_NATIVE_LONG_DIV 1', '#include "%s/cw_call.hip.h"' % CSRC]
+         '#define CW_CALL_NATIVE __forceinline__', '' if native_long_div else '#define CW_NO_NATIVE_LONG_DIV 1', '#include "%s/cw_call.hip.h"' % CSRC]
     pins = _p_pins()
     for b in bodies:
         # heavy: the emitter re-derives its lane offsets afterwards; inv_h cannot even spare the status word's register
         # (the emitter parks it in LDS around the call)
-        keep_v = set(V_OWNED) if b.parity not in ("h", "c") else {124}
+        keep_v = set(V_OWNED) if b.parity not in ("h", "c", "k") else {124}
         no_st = b.name == "inv_h"
         if b.parity == "e":
             keep_v |= set(range(A_O, A_O + 16))
@@ -522,12 +527,14 @@ def parse_bodies(asm: str, bodies):
             allowed_v |= set(range(0, 128))
         elif b.parity == "c":
             allowed_v |= set(range(0, 256))
+        elif b.parity == "k":
+            allowed_v |= set(range(0, 128))
         if not b.keep_d:
             allowed_v |= set(range(D_REG, D_REG + 8))
         if b.acc and not b.g:
             allowed_v -= set(range(G_REG, G_REG + 8))
         allowed_s = set(range(0, 40)) | set(range(S_PARAMS, S_PARAMS + N_PARAM_SGPRS))
-        if b.parity in ("m", "c"):  # the strand's last call / the interpreter read the emitter's registers (status array, table)
+        if b.parity in ("m", "c", "k"):  # the strand's last call / the interpreter read the emitter's registers (status array, table)
             allowed_v |= set(V_OWNED)
             allowed_s |= set(range(S_OWNED, 102))
         out = []
@@ -542,9 +549,9 @@ def parse_bodies(asm: str, bodies):
                     raise RuntimeError("body %s: long branch through SGPRs outside its budget: %s" % (b.name, pair))
                 out.append("%s %s %s" % (LONG_BRANCH, re.sub(r"\.LBB(\d+_\d+)", lambda mm: ".Lfj_%s_%s" % (b.name, mm.group(1)), lbl), pair))
                 continue
-            if b.parity in ("h", "c") and _SCRATCH.match(t):
+            if b.parity in ("h", "c", "k") and _SCRATCH.match(t):
                 b.scratch = True          # a heavy body may spill: the emitted kernel then owns a private segment
-            elif b.parity == "c" and re.match(r"^\s*(global_|flat_|s_load|s_waitcnt)", t):
+            elif b.parity in ("c", "k") and re.match(r"^\s*(global_|flat_|s_load|s_waitcnt)", t):
                 pass                      # the tier-2 interpreter works on memory
             elif b.parity == "m" and re.match(r"^\s*(global_|flat_|s_waitcnt)", t):
                 pass
@@ -578,6 +585,10 @@ def parse_bodies(asm: str, bodies):
         dsr = set(range(S_PARAMS, S_PARAMS + N_PARAM_SGPRS)) | set(range(S_OWNED, 102)) | {S_SEL, S_SEL + 1}
         for r, _ in b.sin:
             dsr |= {r, r + 1} if r in (S_ARG, S_SEL) else {r}
+        if b.parity == "k":
+            # under 128 VGPRs the compiler saves every scalar that is live-in to its test kernel in VGPR lanes, s[0:1] (that
+            # kernel's argument pointer, never used by the body) among them: a read of whatever the two hold, restored unused
+            dsr |= {0, 1}
         bad = _use_before_def(b, dv, dsr)
         if bad:
             raise RuntimeError("body %s reads a register it neither receives nor writes first (hoisted above the marker?): %s" % (b.name, bad))
@@ -594,7 +605,7 @@ def parse_bodies(asm: str, bodies):
     if missing:
         raise RuntimeError("bodies not found in the compiler output: %s" % missing)
     for b in bodies:
-        if b.parity not in ("h", "c"):
+        if b.parity not in ("h", "c", "k"):
             assert not getattr(b, "scratch", False)
     return bodies
 
@@ -611,7 +622,9 @@ def build_bodies(names=None, cache=True):
     bodies = _specs()
     if names is not None:
         bodies = [b for b in bodies if b.name in names]
-    src = _source(bodies)
+    units = [([b for b in bodies if b.parity != "k"], False), ([b for b in bodies if b.parity == "k"], True)]
+    units = [(bs, nld) for bs, nld in units if bs]
+    src = "\n// ---- unit ----\n".join(_source(bs, native_long_div=nld) for bs, nld in units)
     deps = b"".join(open(os.path.join(CSRC, n), "rb").read() for n in ("fp256.hip.h", "cw_rowops.hip.h", "cw_tape.h", "cw_call.hip.h"))
     key = hashlib.sha256(src.encode() + deps + open(__file__, "rb").read()).hexdigest()[:16]
     path = os.path.join(CACHE_DIR, "fpjit_bodies_%s.s" % key)
@@ -635,18 +648,21 @@ def build_bodies(names=None, cache=True):
     if cache and os.path.exists(path):
         asm = open(path).read()
     if asm is None:
+        parts = []
         with tempfile.TemporaryDirectory(prefix="cw_fpjit_") as d:
-            s = os.path.join(d, "bodies.hip")
-            with open(s, "w") as f:
-                f.write(src)
-            # the default (max-occupancy) machine scheduler of this LLVM crashes on some bodies under the physical-register
-            # constraints; the max-ILP strategy does not, and ILP is what a row body wants anyway
-            r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O3", "-S", "--cuda-device-only", "-mllvm",
-                                "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-disable-promote-alloca-to-lds", "-I" + CSRC, "-o",
-                                os.path.join(d, "bodies.s"), s], capture_output=True, text=True)
-            if r.returncode:
-                raise RuntimeError("hipcc failed on the row bodies:\n" + r.stderr[-4000:])
-            asm = open(os.path.join(d, "bodies.s")).read()
+            for ui, (bs, nld) in enumerate(units):
+                s = os.path.join(d, "bodies%d.hip" % ui)
+                with open(s, "w") as f:
+                    f.write(_source(bs, native_long_div=nld))
+                # the default (max-occupancy) machine scheduler of this LLVM crashes on some bodies under the physical-register
+                # constraints; the max-ILP strategy does not, and ILP is what a row body wants anyway
+                r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O3", "-S", "--cuda-device-only", "-mllvm",
+                                    "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-disable-promote-alloca-to-lds", "-I" + CSRC, "-o",
+                                    os.path.join(d, "bodies%d.s" % ui), s], capture_output=True, text=True)
+                if r.returncode:
+                    raise RuntimeError("hipcc failed on the row bodies:\n" + r.stderr[-4000:])
+                parts.append(open(os.path.join(d, "bodies%d.s" % ui)).read())
+        asm = "\n".join(parts)
         if cache:
             os.makedirs(CACHE_DIR, exist_ok=True)
             tmp = path + ".%d" % os.getpid()

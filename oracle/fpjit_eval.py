@@ -109,6 +109,14 @@ def replay(prog_ir, body_info, q: int, n_signals: int, n_tslots: int, n_lds: int
             elif k == "bit":
                 a = rd(st, ins[1], "bit extraction")
                 reg[D_REG] = (a >> ins[2]) & 1 if ins[2] < 256 else 0
+            elif k == "bits":
+                # D_BITS as one step: consecutive bits of the operand, one store per entry (an entry flagged `next` moves on first)
+                a = rd(st, ins[1], "bit-field extraction")
+                kbit = ins[2]
+                for slot, nxt, _lo in ins[3]:
+                    kbit += 1 if nxt else 0
+                    mem[slot] = (a >> kbit) & 1 if kbit < 256 else 0
+                reg[D_REG] = POISON                   # (the row has no value: D holds the last bit's words)
             elif k == "bar":
                 for g, v in reg.items():
                     if isinstance(v, _Pending) and v.seq[0] == "lg":
@@ -138,7 +146,7 @@ def replay(prog_ir, body_info, q: int, n_signals: int, n_tslots: int, n_lds: int
             elif k == "call":
                 name = ins[1]
                 touched, parity = body_info[name]
-                base = name.rsplit("_", 1)[0] if parity in ("e", "o", "h", "c") else name
+                base = name.rsplit("_", 1)[0] if parity in ("e", "o", "h", "c", "k") else name
                 ra, rb = (A_O, B_O) if parity == "o" else (A_E, B_E)
                 what = "body " + name
                 # a load in flight to a register the body may write would land in the middle of its arithmetic

@@ -157,6 +157,9 @@ def test_config5_ecdsa_verify_shard_at_128(tmp_path):
     for pos, vec in zip(at, gold):
         rows[pos] = np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in vec["inputs"]), dtype=np.uint8).reshape(c.n_inputs, 32)
     b = c.batch(B)
+    # round 6: the verifier's 16-strand schedule runs as EMITTED code (hip_elements/fpjit.py: the interpreter body call_k for its
+    # run-time functions incl. the native long_div, D_BITS rows as steps of many stores)
+    assert b.strands == 16 and b.emitted, "config 5 was expected on the emitted engine"
     b.set_inputs(rows)
     b.run(); b.check_r1cs(); b.sync()
     assert (b.status() == 0).all()

@@ -37,7 +37,7 @@ def test_bodies_respect_their_register_budgets(bodies):
         assert base + "_e" in bodies and base + "_o" in bodies
     for name, b in bodies.items():
         assert b.text and b.n_instr > 0
-        if b.parity not in ("h", "c"):
+        if b.parity not in ("h", "c", "k"):
             assert not b.scratch, name
         if b.parity == "e":
             assert not any(24 <= r < 40 for r in b.vwritten), name       # the odd rows' operands are in flight meanwhile
@@ -45,7 +45,7 @@ def test_bodies_respect_their_register_budgets(bodies):
             assert not any(r < 16 for r in b.vwritten), name
         if b.parity != "m":
             owned = (120, 121, 122, 125, 126, 127) + (() if b.chk else (123,))      # v123 = the fused check's finding
-            assert not any(r in b.vwritten for r in owned) or b.parity in ("h", "c"), name
+            assert not any(r in b.vwritten for r in owned) or b.parity in ("h", "c", "k"), name
     assert 250 <= bodies["mmul_e"].n_instr <= 400
 
 
@@ -462,3 +462,57 @@ def test_no_assembler_on_the_host_leaves_a_valid_tape(tmp_path, monkeypatch):
     import glob
     import tempfile
     assert not glob.glob(os.path.join(tempfile.gettempdir(), "cw_fpjit_*", "k.s"))
+
+
+# ---- round 6: several strands around run-time function calls, D_BITS rows ------------------------------------------------------------
+def test_replay_of_emitted_ir_with_calls_on_several_strands(bodies):
+    """Schedules of several strands whose rows include D_CALL (a heavy unit between FULL barriers) and D_BITS (one row = the
+    stores of a whole Num2Bits) have an emitted form since round 6: the interpreter body `call_k` (compiled for the strand
+    kernels' 128 VGPRs, spills in a private segment, native long_div included) and a `bits` step.  Replay == schedule replay."""
+    from circom_amd.circuits.bigint import BigMultModP
+    from circom_amd.hip_elements.lower import D_BITS, D_CALL
+    assert bodies["call_k"].scratch_bytes > 0 and bodies["call_k"].parity == "k"
+    n, k = 16, 2
+    fc = flatten(Program(BigMultModP(n, k), prime="bls12381"))
+    for S in (4, 16):
+        t = lower(fc, n_strands=S)
+        ops = np.asarray(t.rows)[:, 0] & 0xFF
+        assert (ops == D_CALL).any() and (ops == D_BITS).any()
+        p = fpjit.emit(t, bodies, None)
+        assert p.n_vgpr == 128 and p.scratch_bytes == bodies["call_k"].scratch_bytes
+        assert any(ins[0] == "bits" for strand in p.ir for ins in strand) and any(ins[0] == "callfn" for strand in p.ir for ins in strand)
+        fpjit.assemble(p)
+        rnd = random.Random(40 + S)
+        for it in range(5):
+            pp = rnd.randrange(1 << (n * k - 1), 1 << (n * k))
+            a, b = rnd.randrange(pp), rnd.randrange(pp)
+            vals = [(x >> (n * i)) & ((1 << n) - 1) for x in (a, b, pp) for i in range(k)]
+            inp = {fc.main_input_start + j: v for j, v in enumerate(vals)}
+            want, st0 = eval_tape(t, inp)
+            got, st1 = replay_tape(t, p, bodies, inp)
+            assert st0 == 0 and (got, st1) == (want, st0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S", [4, 16])
+def test_gpu_emitted_code_with_calls_on_several_strands(tmp_path, monkeypatch, S):
+    """the same on the device: BigMultModP on 4 / 16 strands through the emitted code (call_k body, bits steps) == the
+    interpreting kernel == the oracle, every instance on its own path through long_div"""
+    from circom_amd.circuits.bigint import BigMultModP
+    n, k = 32, 3
+    cp = compile_program(Program(BigMultModP(n, k), prime="bls12381"), str(tmp_path), "bigmultmodp_s%d" % S, sym=False, strands=(S,), fpjit=True)
+    assert cp.fpjit and all(p.n_strands == S for p in cp.fpjit)
+    rnd = random.Random(12)
+    rows = []
+    for _ in range(300):
+        p = rnd.randrange(1 << (n * k - 1), 1 << (n * k))
+        a, b = rnd.randrange(p), rnd.randrange(p)
+        rows.append([(x >> (n * i)) & ((1 << n) - 1) for x in (a, b, p) for i in range(k)])
+    (w1, s1, f1), (w0, s0, f0) = _run_both(cp, rows, monkeypatch, S, None, False)
+    assert (s1 == 0).all() and (s0 == 0).all() and (f1 == f0).all()
+    assert w1.tobytes() == w0.tobytes()
+    fc = cp.flat
+    for i in (0, 17, 299):
+        sig, failed = eval_flat(fc.fp.q, fc.n_signals, fc.n_temps, fc.constants, fc.code,
+                                {fc.main_input_start + j: v for j, v in enumerate(rows[i])}, functions=fc.functions)
+        assert failed is None and w1[i].tobytes() == b"".join(v.to_bytes(32, "little") for v in sig)
