@@ -1358,6 +1358,15 @@ static int load_r1cs(cw_circuit *c, const char *path) {
                         uint32_t limbs[8];
                         memcpy(limbs, cm.w, 32);
                         c->r_ctab.insert(c->r_ctab.end(), limbs, limbs + 8);
+                        if (!on_one) {
+                            // entry id + 1: what the term is worth on a wire that holds "one" (cw_r1cs_plan.h COEF_BITSEL) - c on a
+                            // canonical table, c R' on a table of Montgomery forms
+                            U256 cr = co;                         // (a coefficient >= q is legal in the file: reduce it)
+                            for (int it = 0; it < 64 && u256_cmp(cr, c->q) >= 0; it++) u256_sub(cr, cr, c->q);
+                            if (u256_cmp(cr, c->q) >= 0) return fail(CW_EIO, "r1cs coefficient is far above the prime");
+                            memcpy(limbs, c->mont ? cm.w : cr.w, 32);
+                            c->r_ctab.insert(c->r_ctab.end(), limbs, limbs + 8);
+                        }
                         cid[key] = id;
                     } else id = it->second;
                     if (on_one) id |= cwplan::COEF_CONST;
@@ -1601,6 +1610,22 @@ extern "C" int cw_r1cs_plan_stats(const cw_circuit *c, uint32_t batch, uint32_t 
     if (!err.empty()) return fail(CW_ESTATE, ("r1cs plan: " + err).c_str());
     uint64_t v[8] = {p.n_chunks, p.n_loads, p.n_terms, p.n_filler, p.n_unique, p.entries, cwplan::DEPTH, 0};
     memcpy(out, v, sizeof v);
+    return CW_OK;
+}
+
+// host-only: the term stream cw_batch_create hands to cw_r1cs_stream_kernel, for replaying it on the CPU (tests/test_r1cs_plan.py)
+extern "C" int cw_r1cs_stream_plan(const cw_circuit *c, uint32_t terms_per_chunk, uint32_t flags, uint64_t sizes[8], uint32_t *chunk,
+                                   uint32_t *terms, uint32_t *row_orig, uint32_t *ctab) {
+    if (!c || !sizes) return fail(CW_EINVAL, "null argument");
+    if (c->n_constraints == 0) return fail(CW_ESTATE, "no .r1cs was loaded for this circuit");
+    cwplan::Plan p = cwplan::build_stream(c->r_ptr, c->r_slot, c->r_coef, c->r_orig, terms_per_chunk ? terms_per_chunk : 192, nullptr,
+                                          (flags & 1u) ? nullptr : &c->r_bool, !(flags & 2u));
+    uint64_t v[8] = {p.chunk.size(), p.terms.size(), p.row_orig.size(), c->r_ctab.size(), p.n_terms, p.n_folded, p.n_bitsel, p.n_chunks};
+    memcpy(sizes, v, sizeof v);
+    if (chunk) memcpy(chunk, p.chunk.data(), p.chunk.size() * 4);
+    if (terms) memcpy(terms, p.terms.data(), p.terms.size() * 4);
+    if (row_orig) memcpy(row_orig, p.row_orig.data(), p.row_orig.size() * 4);
+    if (ctab) memcpy(ctab, c->r_ctab.data(), c->r_ctab.size() * 4);
     return CW_OK;
 }
 
@@ -2114,7 +2139,7 @@ static int batch_create_impl(cw_circuit *c, int device, uint32_t batch, void *st
             if (const char *e = getenv("CW_R1CS_TERMS")) tpc = (uint32_t)std::max(8, atoi(e));
             const bool audit = getenv("CW_R1CS_AUDIT") != nullptr;
             p = cwplan::build_stream(c->r_ptr, c->r_slot, c->r_coef, c->r_orig, tpc, b->fp_fn && !audit ? b->fp_covered : nullptr,
-                                     getenv("CW_R1CS_NO_BOOL") ? nullptr : &c->r_bool);
+                                     getenv("CW_R1CS_NO_BOOL") ? nullptr : &c->r_bool, getenv("CW_R1CS_NO_FOLD") == nullptr);
         }
         if (p.chunk.empty()) p.chunk.assign(4, 0);                   // every row is checked by the emitted code: nothing to stream
         if (p.row_orig.empty()) p.row_orig.assign(1, 0);

@@ -801,6 +801,7 @@ cw_pipe_kernel(const CwPRow *__restrict__ rows, uint32_t n_rows, const uint32_t 
 struct R1State {
     fe A, B, cur;
     uint32_t row, bad;
+    bool allbool;           // the T_BOOL term just processed found 0 or 1 in every lane of the wave (cw_r1cs_plan.h COEF_BITSEL)
 };
 __device__ __forceinline__ fe fe_pick(bool c, const fe &a, const fe &b) {
     fe r;
@@ -818,14 +819,20 @@ __device__ __forceinline__ void r1_term(const fe &wv, uint32_t w0, uint32_t ci, 
         fe one_ = fe_small(1);
         if (MONT) { FE_UNROLL for (int k = 0; k < 8; k++) one_.v[k] = P.one_m[k]; }
         ok = fe_is_zero(wv) | fe_eq(wv, one_);
+        s.allbool = __all(ok);
     } else if (endk == 3) ok = fe_eq(s.cur, wv);                    // second wire of a pure equality row: x == y
     else if (acc == 3) s.cur = wv;                                  // its first wire
     else {
         fe w = wv;
         if (ci >> 31) w = c_load(ctab, ci & 0x7FFFFFFFu);           // coefficient on the constant-1 wire
-        else if (ci >= 2) {                                         // w * c: ctab29 holds c*R' as 9 x 29-bit limbs
+        else if ((ci & (1u << 30)) && s.allbool) {                  // (cwplan::COEF_BITSEL) the wire is 0 or 1 in every lane: b ? c : 0
+            const fe c1 = c_load(ctab, (ci & 0x3FFFFFFFu) + 1);
+            const bool nz = !fe_is_zero(w);
+            FE_UNROLL for (int k = 0; k < 8; k++) w.v[k] = nz ? c1.v[k] : 0u;
+            ci = 0;
+        } else if (ci >= 2) {                                       // w * c: ctab29 holds c*R' as 9 x 29-bit limbs
             fe29 cc;
-            FE_UNROLL for (int k = 0; k < 9; k++) cc.l[k] = ctab29[(size_t)ci * 9 + k];
+            FE_UNROLL for (int k = 0; k < 9; k++) cc.l[k] = ctab29[(size_t)(ci & 0x3FFFFFFFu) * 9 + k];
             w = fe_from29(fe29_mmul(fe_to29(w), cc, P));
         }
         s.cur = (ci == 1) ? fe_sub(s.cur, w, P) : fe_add(s.cur, w, P);
@@ -852,7 +859,8 @@ __device__ __forceinline__ void r1_term(const fe &wv, uint32_t w0, uint32_t ci, 
             if (!ok && oc < s.bad) s.bad = oc;
         }
         s.row++;
-        s.A = fe_zero(); s.B = fe_zero(); s.cur = fe_zero();
+        // a boolean row may ride inside another row, in front of that row's term on the same wire: the accumulators are its host's
+        if (!(w0 & (1u << 26))) { s.A = fe_zero(); s.B = fe_zero(); s.cur = fe_zero(); }
     }
 }
 __device__ __forceinline__ void r1_finish(const R1State &s, uint32_t i, uint32_t batch, uint32_t *status, uint32_t *first_bad) {
@@ -870,6 +878,7 @@ cw_r1cs_stream_kernel(const uint4 *__restrict__ chunk, uint32_t n_chunks, const 
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;               // < Bp
     R1State s;
     s.bad = 0xFFFFFFFFu;
+    s.allbool = false;
     for (uint32_t cix = blockIdx.y; cix < n_chunks; cix += gridDim.y) {   // grid.y is capped at 65535: large systems loop
         const uint4 ch = chunk[cix];                                // first term, n terms, -, first row
         const uint2 *tp = terms + ch.x;                             // the stream is padded: tp[n] is readable
@@ -881,7 +890,8 @@ cw_r1cs_stream_kernel(const uint4 *__restrict__ chunk, uint32_t n_chunks, const 
         // drops a wave per SIMD, and measured no faster)
         for (uint32_t k = 0; k < ch.y; k++) {
             const uint2 t1 = tp[k + 1];
-            const fe w1 = v_load(V, t1.x & 0x3FFFFFFu, Bp, i);
+            fe w1 = w0;                                             // a term on the wire of the term before it (a folded boolean row
+            if (((t1.x ^ t0.x) & 0x3FFFFFFu) != 0) w1 = v_load(V, t1.x & 0x3FFFFFFu, Bp, i);   // and its host's term): one read
             r1_term<MONT>(w0, t0.x, t0.y, s, ctab, ctab29, row_orig, P);
             t0 = t1; w0 = w1;
         }
@@ -935,6 +945,7 @@ cw_r1cs_staged_kernel(const uint4 *__restrict__ chunk, const uint2 *__restrict__
     R1State s;
     s.A = fe_zero(); s.B = fe_zero(); s.cur = fe_zero();
     s.row = ch.w; s.bad = 0xFFFFFFFFu;
+    s.allbool = false;
     uint2 tw = tp[0];
     for (uint32_t j = 0; j < ch.y; j++) {
         const uint2 r = rp[j];

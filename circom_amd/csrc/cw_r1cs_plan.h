@@ -36,6 +36,7 @@ constexpr uint32_t SLOT_MASK = (1u << SLOT_BITS) - 1;
 constexpr uint32_t T_ACC_SH = 27, T_END_SH = 29;
 constexpr uint32_t END_QUAD = 1, END_LIN = 2, END_EQ2 = 3, ACC_EQ2 = 3;
 constexpr uint32_t COEF_CONST = 0x80000000u, T_PART_END = 0x80000000u;
+constexpr uint32_t COEF_BITSEL = 0x40000000u;   // stream plan: the wire was checked "0 or 1" by the T_BOOL term in front (see build_stream)
 // stream plan only: bit 26 of word 0 = the whole row is b * (b - 1) = 0 (or b * (1 - b) = 0): ONE term naming b, which must be 0 or 1 -
 // one wire read and a comparison instead of three terms and a product.  (Num2Bits writes one such row per bit: 2.3 M of the 2.49 M
 // rows of the ECDSA verifier.)
@@ -49,6 +50,7 @@ struct Plan {
     std::vector<uint32_t> terms;    // 2 words per term (+ 2 terms of padding for the kernel's look-ahead)
     std::vector<uint32_t> row_orig; // .r1cs constraint index of every row that has terms, in plan order
     uint64_t n_loads = 0, n_terms = 0, n_filler = 0, n_unique = 0;
+    uint64_t n_folded = 0, n_bitsel = 0;   // stream plan: boolean rows that ride in another row / products replaced by a select
 };
 
 // rows in processing order; ptr has 3 ranges per row (A, B, C) into slot[]/coef[].
@@ -183,36 +185,81 @@ inline Plan build(const std::vector<uint32_t> &ptr, const std::vector<uint32_t> 
 // Stream plan (default kernel, cw_r1cs_stream_kernel): no LDS; the terms name value slots and are read from the
 // value table two terms ahead of their use.  chunk = {first term, n terms, 0, first index into row_orig}.
 // skip: optional bitmap over the constraints' indices in the .r1cs file - rows the emitted evaluation code has already checked
+//
+// FOLDED boolean rows (round 6).  Num2Bits writes `b * (b - 1) = 0` per bit AND one sum `sum 2^k b_k - in = 0` over the same bits:
+// checked as separate rows every bit is read twice (the ECDSA verifier's check moved 171 GB for a table of 81 GB) and every
+// term of the sum costs a Montgomery product.  With `fold`, the boolean row of b travels INSIDE the first other row that reads b,
+// directly in front of that row's term on b: the kernel reads b once (a term that names the slot of the term before it reuses
+// the registers), files the boolean row's verdict under its own constraint index (the T_BOOL term is a complete row: it ends,
+// it advances the row counter, it leaves the accumulators alone), and - term flagged COEF_BITSEL - adds `b ? c : 0` instead of
+// multiplying when every lane of the wave has just been seen to hold 0 or 1 (else the product, so a row's verdict never depends
+// on another row's).  A COEF_BITSEL coefficient id names a PAIR of table entries: id = the multiplier's operand (c R'), id + 1 =
+// what the term is worth when b = 1 (c on a canonical table, c R' on a table of Montgomery forms).
 inline Plan build_stream(const std::vector<uint32_t> &ptr, const std::vector<uint32_t> &slot,
                          const std::vector<uint32_t> &coef, const std::vector<uint32_t> &orig, uint32_t terms_per_chunk,
-                         const std::vector<uint32_t> *skip = nullptr, const std::vector<uint8_t> *boolrow = nullptr) {
+                         const std::vector<uint32_t> *skip = nullptr, const std::vector<uint8_t> *boolrow = nullptr,
+                         bool fold = true) {
     Plan p;
     const uint32_t n_rows = (uint32_t)(ptr.size() / 3);
+    auto skipped = [&](uint32_t row) {
+        if (!skip) return false;
+        const uint32_t o = orig[row] & 0x7FFFFFFFu;
+        return (o >> 5) < skip->size() && (((*skip)[o >> 5] >> (o & 31)) & 1u);
+    };
+    auto is_bool = [&](uint32_t row) { return boolrow && row < boolrow->size() && (*boolrow)[row]; };
+    auto bool_slot = [&](uint32_t row) { return slot[(ptr[3 * row + 1] - ptr[3 * row] == 1) ? ptr[3 * row] : ptr[3 * row + 1]]; };
+    // which boolean row rides in which other row: guest[s] = the boolean row of slot s that some later-emitted row will carry
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
+    std::vector<uint32_t> guest;                 // per slot: boolean row (NONE: none); bit 31 set once a host row was found
+    if (fold && boolrow) {
+        uint32_t mx = 0;
+        for (uint32_t s : slot) mx = std::max(mx, s);
+        guest.assign((size_t)mx + 1, NONE);
+        for (uint32_t row = 0; row < n_rows; row++)
+            if (ptr[3 * row + 3] != ptr[3 * row] && !skipped(row) && is_bool(row) && guest[bool_slot(row)] == NONE) guest[bool_slot(row)] = row;
+        std::vector<uint8_t> hosted(guest.size(), 0);
+        for (uint32_t row = 0; row < n_rows; row++) {
+            if (ptr[3 * row + 3] == ptr[3 * row] || skipped(row) || is_bool(row) || (orig[row] >> 31)) continue;
+            for (uint32_t t = ptr[3 * row]; t < ptr[3 * row + 3]; t++)
+                if (slot[t] && guest[slot[t]] != NONE) hosted[slot[t]] = 1;
+        }
+        for (size_t s = 0; s < guest.size(); s++)
+            if (!hosted[s]) guest[s] = NONE;
+    }
+    auto bool_term = [&](uint32_t row) {
+        p.terms.push_back(bool_slot(row) | T_BOOL | (END_QUAD << T_END_SH) | T_PART_END);
+        p.terms.push_back(0);
+        p.row_orig.push_back(orig[row] & 0x7FFFFFFFu);
+    };
     uint32_t chunk_t0 = 0, chunk_row0 = 0;
     for (uint32_t row = 0; row < n_rows; row++) {
         const uint32_t pa = ptr[3 * row], pb = ptr[3 * row + 1], pc = ptr[3 * row + 2], pe = ptr[3 * row + 3];
         if (pe == pa) continue;
-        if (skip) {
-            const uint32_t o = orig[row] & 0x7FFFFFFFu;
-            if ((o >> 5) < skip->size() && (((*skip)[o >> 5] >> (o & 31)) & 1u)) continue;
-        }
+        if (skipped(row)) continue;
         const bool lin = (pa == pb) || (pb == pc);
         const bool eq2 = (orig[row] >> 31) != 0;
-        if (boolrow && row < boolrow->size() && (*boolrow)[row]) {
+        if (is_bool(row)) {
             // (the loader recognised the row: one of A / B is the single term +b, the other is b - 1 or 1 - b, C is empty)
-            const uint32_t bslot = slot[(pb - pa == 1) ? pa : pb];
-            p.terms.push_back(bslot | T_BOOL | (END_QUAD << T_END_SH) | T_PART_END);
-            p.terms.push_back(0);
-        } else
-        for (uint32_t t = pa; t < pe; t++) {
-            uint32_t part = t < pb ? 0 : (t < pc ? 1 : 2), endk = 0;
-            if (t + 1 == pe) endk = eq2 ? END_EQ2 : (lin ? END_LIN : END_QUAD);
-            else if (eq2) part = ACC_EQ2;
-            const uint32_t pend = (t + 1 == pb || t + 1 == pc || t + 1 == pe) ? T_PART_END : 0;
-            p.terms.push_back(slot[t] | (part << T_ACC_SH) | (endk << T_END_SH) | pend);
-            p.terms.push_back(coef[t]);
+            const uint32_t bs = bool_slot(row);
+            if (bs < guest.size() && guest[bs] == row) continue;          // rides in another row
+            bool_term(row);
+        } else {
+            for (uint32_t t = pa; t < pe; t++) {
+                uint32_t part = t < pb ? 0 : (t < pc ? 1 : 2), endk = 0, ci = coef[t];
+                if (t + 1 == pe) endk = eq2 ? END_EQ2 : (lin ? END_LIN : END_QUAD);
+                else if (eq2) part = ACC_EQ2;
+                if (!eq2 && slot[t] < guest.size() && guest[slot[t]] != NONE) {
+                    bool_term(guest[slot[t]]);
+                    guest[slot[t]] = NONE;                                 // once
+                    if (ci >= 2 && !(ci & COEF_CONST)) { ci |= COEF_BITSEL; p.n_bitsel++; }
+                    p.n_folded++;
+                }
+                const uint32_t pend = (t + 1 == pb || t + 1 == pc || t + 1 == pe) ? T_PART_END : 0;
+                p.terms.push_back(slot[t] | (part << T_ACC_SH) | (endk << T_END_SH) | pend);
+                p.terms.push_back(ci);
+            }
+            p.row_orig.push_back(orig[row] & 0x7FFFFFFFu);
         }
-        p.row_orig.push_back(orig[row] & 0x7FFFFFFFu);
         const uint32_t nt = (uint32_t)(p.terms.size() / 2);
         if (nt - chunk_t0 >= terms_per_chunk) {
             p.chunk.insert(p.chunk.end(), {chunk_t0, nt - chunk_t0, 0u, chunk_row0});

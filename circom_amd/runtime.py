@@ -107,6 +107,7 @@ _SIGS = {
     "cw_n_log_statements": (C.c_uint32, [C.c_void_p]),
     "cw_get_log": (C.c_int64, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_size_t]),
     "cw_r1cs_plan_stats": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "cw_r1cs_stream_plan": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cw_device_values": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "cw_fp_mul_bench": (C.c_int, [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.POINTER(C.c_float)]),
@@ -203,6 +204,17 @@ class Circuit:
         _chk(lib().cw_r1cs_plan_stats(self.h, batch, chunks, entries, out))
         keys = ("chunks", "loads", "terms", "filler_loads", "distinct_wires", "entries", "depth")
         return dict(zip(keys, [int(x) for x in out]))
+
+    def r1cs_stream_plan(self, terms_per_chunk: int = 192, no_bool: bool = False, no_fold: bool = False) -> dict:
+        """The term stream of the default R1CS check kernel, as the batch uploads it (host only; csrc/cw_r1cs_plan.h)."""
+        import numpy as np
+        flags = (1 if no_bool else 0) | (2 if no_fold else 0)
+        sizes = (C.c_uint64 * 8)()
+        _chk(lib().cw_r1cs_stream_plan(self.h, terms_per_chunk, flags, sizes, None, None, None, None))
+        arrs = [np.zeros(int(sizes[k]), dtype=np.uint32) for k in range(4)]
+        _chk(lib().cw_r1cs_stream_plan(self.h, terms_per_chunk, flags, sizes, *[a.ctypes.data_as(C.c_void_p) for a in arrs]))
+        return {"chunk": arrs[0].reshape(-1, 4), "terms": arrs[1].reshape(-1, 2), "row_orig": arrs[2], "ctab": arrs[3].reshape(-1, 8),
+                "n_terms": int(sizes[4]), "n_folded": int(sizes[5]), "n_bitsel": int(sizes[6]), "n_chunks": int(sizes[7])}
 
     def batch(self, batch: int, device: int = 0, stream=None) -> "Batch":
         return Batch(self, batch, device, stream)

@@ -216,6 +216,13 @@ int cw_get_r1cs_first_bad(cw_batch *b, uint32_t *row);
    and `entries` 2-KiB LDS entries per wave (0 = the defaults cw_batch_create would pick for `batch`).
    out[8] = {chunks, loads, terms, filler loads, distinct wires, entries, prefetch depth, 0}. */
 int cw_r1cs_plan_stats(const cw_circuit *c, uint32_t batch, uint32_t chunks, uint32_t entries, uint64_t out[8]);
+/* host-only: the term stream of the default check kernel (csrc/cw_r1cs_plan.h build_stream), as cw_batch_create uploads it, so
+   that a test can replay it on the CPU.  flags: 1 = boolean rows b (b - 1) = 0 stay three terms and a product, 2 = boolean rows
+   do not ride inside the sum that reads the same bit.  sizes[8] = {words of chunk[], words of terms[], words of row_orig[],
+   words of ctab[], terms, boolean rows folded into another row, products replaced by a select, chunks}; a null buffer is not
+   written (call once for the sizes).  No reference counterpart (snarkjs `wtns check` is the reference-side check). */
+int cw_r1cs_stream_plan(const cw_circuit *c, uint32_t terms_per_chunk, uint32_t flags, uint64_t sizes[8], uint32_t *chunk,
+                        uint32_t *terms, uint32_t *row_orig, uint32_t *ctab);
 
 /* raw device pointers for zero-copy consumers (provers): value table, layout in DESIGN.md.  When cw_circuit_montgomery()
    is 1 the table holds x * 2^261 mod q (the schedule of an arithmetic circuit keeps its signals in Montgomery form, so that

@@ -352,6 +352,64 @@ def test_r1cs_check_boolean_rows(tmp_path, mont, monkeypatch):
     c.close()
 
 
+@template
+def LooseNum2Bits(c, n):
+    # Num2Bits with the sum row `sum 2^k out[k] = a` next to the boolean rows, and witness code that writes a 3-bit field into bit
+    # (b mod 2n) when b mod 2n < n: the boolean row of that bit AND the sum fail in that instance, nothing fails in the others
+    a = c.input("a")
+    b = c.input("b")
+    out = c.output("out", n)
+    acc = c.const(0)
+    for k in range(n):
+        wrong = (b % (2 * n)).eq(k)
+        if k == 0:                                            # b mod 2n = 2n - 1: bit 0 flipped - still a bit, only the sum notices
+            flip = (b % (2 * n)).eq(2 * n - 1)
+            c.hint(out[k], (((a >> k) & 1) + flip) % 2 + wrong * ((a >> k) & 6))
+        else:
+            c.hint(out[k], ((a >> k) & 1) + wrong * ((a >> k) & 6))
+        c.enforce(out[k] * (out[k] - 1), 0, runtime_check=False)
+        acc = acc + out[k] * (1 << k)
+    c.enforce(acc, a, runtime_check=False)
+
+
+@pytest.mark.parametrize("mont", [False, True])
+def test_r1cs_check_boolean_rows_folded_into_their_sum(tmp_path, mont, monkeypatch):
+    """the boolean row of a bit rides inside the sum that reads the bit (cw_r1cs_plan.h build_stream): one read per bit, `b ? c : 0`
+    for the term when the whole wave holds bits, the product otherwise - verdicts and first violated rows are the oracle's, and
+    equal to the unfolded (CW_R1CS_NO_FOLD=1) and the general (CW_R1CS_NO_BOOL=1) plans'"""
+    monkeypatch.setenv("CW_MONT", "1" if mont else "0")
+    monkeypatch.setenv("CW_R1CS_TERMS", "24")
+    n = 37
+    cp, c = _compile(tmp_path, Program(LooseNum2Bits(n)), "loosen2b%d" % mont)
+    assert c.montgomery == mont
+    plan = c.r1cs_stream_plan(24)
+    assert plan["n_folded"] == n and plan["n_bitsel"] == n - 1
+    B = 333                                                     # waves 0-1 hold instances with a loose bit, wave 2 onwards only some
+    # waves 0-2: loose bits in some lanes (the product form); waves 3-5: every lane holds bits (the select form), some sums fail
+    ins = [[(i * 2654435761) % (1 << n), i if i < 192 else 2 * n * i + n + (i % n)] for i in range(B)]
+    seen = []
+    for env in (None, "CW_R1CS_NO_FOLD", "CW_R1CS_NO_BOOL"):
+        if env:
+            monkeypatch.setenv(env, "1")
+        b = c.batch(B)
+        b.set_inputs(ins)
+        b.run(); b.check_r1cs(); b.sync()
+        st, fb = b.status(), b.r1cs_first_bad()
+        n_bad = 0
+        for i in range(B):
+            w = b.witness(i)
+            want = check_r1cs(c.q, cp.flat.constraints, w)
+            assert bool(st[i] & rt.ST_R1CS_FAILED) == (want is not None), (env, i)
+            if want is not None:
+                assert fb[i] == want, (env, i, fb[i], want)
+                n_bad += 1
+        assert 0 < n_bad < B
+        seen.append((st.tolist(), fb.tolist()))
+        b.close()
+    assert seen[0] == seen[1] == seen[2]
+    c.close()
+
+
 def test_run_refuses_missing_inputs(tmp_path):
     cp, c = _compile(tmp_path, Program(Multiplier2()), "m2")
     b = c.batch(2)
