@@ -222,7 +222,7 @@ def get_compiled(name: str, batch: int, cache_root: str, rank: int, dist):
         json.dump(dict(jp.stats, code_bytes=len(jp.code), audit_code_bytes=len(jp.audit_code or b"")) if jp is not None else {}, open(p(".jit.json"), "w"))
         json.dump([dict(fp_.stats, n_strands=fp_.n_strands, code_bytes=len(fp_.code)) for fp_ in fps], open(p(".fpjit.json"), "w"))
         writers.write_dat(p(".dat"), fc)
-        open(done, "w").write(fp)
+        open(done, "w").write("%s\n%.1f\n" % (fp, time.perf_counter() - t0))     # fingerprint, seconds of flatten + lowering + emission
     if lock is not None:
         lock.close()                    # (releases the flock)
     if dist:
@@ -236,6 +236,10 @@ def get_compiled(name: str, batch: int, cache_root: str, rank: int, dist):
         cp.fpjit_stats = json.load(open(p(".fpjit.json")))
     except Exception:
         cp.fpjit_stats = []
+    try:
+        cp.compile_s_cold = float(open(done).read().split()[1])          # what the cached artefacts cost when they were made
+    except Exception:
+        cp.compile_s_cold = None
     return cp, time.perf_counter() - t0, cached
 
 
@@ -682,6 +686,8 @@ def main():
     ap.add_argument("--parity-instances", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--graph", choices=("auto", "on", "off"), default=os.environ.get("CW_BENCH_GRAPH", "auto"),
+                    help="steps as one HIP-graph launch each (cw_run_check); auto: when a step alone is shorter than 1 ms")
     ap.add_argument("--no-small", action="store_true", help="skip the batch-4096 side measurement (profiling runs)")
     ap.add_argument("--fp-bench-lanes", type=int, default=1 << 24)
     ap.add_argument("--in-flight", type=int, default=int(os.environ.get("CW_IN_FLIGHT", "0")),
@@ -701,6 +707,14 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
+
+    # Small batches of the 256-bit engine are run many at a time (each a dependency chain of milliseconds on a few CUs).  The HIP
+    # runtime maps its streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): with 4, any number of batches in flight gives 4
+    # launches side by side (profiles/r06p_*: 8 .. 32 in flight, 16 / 32 / 64 lanes per wave - all 3.9 ms per 1 024-instance
+    # Semaphore batch); with 16 queues, full waves and 32 batches in flight the same shard runs at 2.0 ms per batch
+    # (profiles/r06q_*).  Must be in the environment before the runtime initialises; the metric's own line keeps the default.
+    if args.workload != "sha256_2048" and "GPU_MAX_HW_QUEUES" not in os.environ:
+        os.environ["GPU_MAX_HW_QUEUES"] = "16"
 
     import numpy as np
     import torch
@@ -749,6 +763,17 @@ def main():
             raise
         B //= 2                                              # the value table did not fit: halve the batch once
         batch = circ.batch(B, device=local_rank, stream=stream.cuda_stream)
+    # A shard on the 256-bit engine whose tables fit the HBM many times over: the library spreads ONE such batch over the chip by
+    # leaving lanes idle (16 instances per workgroup); with many batches in flight full waves are the better use of a CU
+    many_small = False
+    if (not batch.bitmode and args.in_flight <= 0 and "CW_LANES" not in os.environ and batch.lanes < 64
+            and os.environ.get("GPU_MAX_HW_QUEUES") == "16"):
+        est_ = 32.0 * circ.n_signals * ((B + 255) // 256 * 256) * 1.1
+        if 0.8 * torch.cuda.get_device_properties(dev).total_memory / est_ >= 32 and (B + 63) // 64 <= 16:
+            batch.close()
+            os.environ["CW_LANES"] = "64"
+            batch = circ.batch(B, device=local_rank, stream=stream.cuda_stream)
+            many_small = True
     golden_at = {}
     # synthetic inputs, resident in HBM before the timed region (different seed per rank = different shard)
     big_bool = batch.bitmode and args.workload.startswith("sha256_") and B * circ.n_inputs * 32 > (8 << 30)
@@ -793,6 +818,8 @@ def main():
     n_fl = args.in_flight
     if n_fl <= 0:
         n_fl = in_flight_for(batch)
+    if many_small:
+        n_fl = 32
     n_fl = max(1, n_fl)
     if not batch.bitmode:
         # value tables of a million-signal circuit are tens of GB each (ECDSA verifier x 1 024: 81 GB): as many batches in
@@ -840,21 +867,52 @@ def main():
     for i in range(max(args.warmup, n_fl)):
         step(i)
     torch.cuda.synchronize()
-    # from here on every run of every batch keeps its own marks (cw_batch_set_timing(b, 2), a ring of 64): the kernels' durations
-    # INSIDE the timed region are averages over all its steps - what a rocprofv3 kernel trace of the region averages to
-    for b_ in batches:
-        b_.set_timing("history")
-    if dist:
-        dist.barrier()
+    # A step of a small batch is ~10 launches of microseconds each + the event marks: the HOST sets the pace (Sha256(512) x 4 096:
+    # 0.12 ms per step with 4, 8 or 16 batches in flight, profiles/r06q_*).  Such steps run as ONE HIP-graph launch each
+    # (cw_run_check: captured on the batch's second call, replayed afterwards; GPU tests: tests/test_run_check_graph.py).  Event
+    # marks cannot ride in a graph: the kernels' in-step durations then come from a second, plain pass behind the timed region.
+    use_graph = args.graph == "on" or (args.graph == "auto" and isolated["ms_per_step"] < 1.0 and circ.n_constraints > 0)
+    if use_graph:
+        for b_ in batches:
+            b_.set_timing(False)
+        for _ in range(3):                                    # plain, capture, first replay
+            for b_ in batches:
+                b_.run_check()
+        torch.cuda.synchronize()
+        use_graph = all(b_.graph_captured for b_ in batches)
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        step(s, evs[s])
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    if use_graph:
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(args.steps):
+            batches[s % n_fl].run_check()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        for b_ in batches:
+            b_.set_timing("history")
+        for s in range(min(args.steps, 64 * n_fl)):           # the plain pass: in-step kernel durations, generation / check split
+            step(s, evs[s])
+        torch.cuda.synchronize()
+        evs = evs[:min(args.steps, 64 * n_fl)]
+    else:
+        # from here on every run of every batch keeps its own marks (cw_batch_set_timing(b, 2), a ring of 64): the kernels' durations
+        # INSIDE the timed region are averages over all its steps - what a rocprofv3 kernel trace of the region averages to
+        for b_ in batches:
+            b_.set_timing("history")
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(args.steps):
+            step(s, evs[s])
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
     if dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -889,8 +947,8 @@ def main():
     n_pub_gathered = int(pub.shape[0]) if rank == 0 else 0
     pub_bytes_per_instance = (int(pub.shape[1]) if pub_form == "bits" else 32 * circ.n_public) if rank == 0 else 0
 
-    gen_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / args.steps
-    chk_ms = sum(e[1].elapsed_time(e[2]) for e in evs) / args.steps
+    gen_ms = sum(e[0].elapsed_time(e[1]) for e in evs) / len(evs)
+    chk_ms = sum(e[1].elapsed_time(e[2]) for e in evs) / len(evs)
 
     parity = None
     if not args.no_parity:
@@ -1313,7 +1371,10 @@ def main():
                        "parallelism": "instances sharded x%d, status + public-signal gather only" % world,
                        "inputs": "packed boolean masks (8 bytes per input and 64 instances)" if args.packed_inputs else
                        "canonical 32-byte field elements",
-                       "in_flight": n_fl, "compile_s": compile_s, "compile_cached": compile_cached,
+                       "in_flight": n_fl, "step_launch": ("one HIP graph per step (cw_run_check); in-step kernel durations from a plain pass behind the timed region"
+                                                          if use_graph else "plain launches (cw_run + cw_check_r1cs)"),
+                       "lanes_per_wave": batch.lanes, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
+                       "compile_s": compile_s, "compile_cached": compile_cached, "compile_s_cold": getattr(cp, "compile_s_cold", None),
                        "shard_of": args.shard_of or None, "total_batch": args.total_batch or None},
             "value_canonical": value_canonical,
             "value_canonical_hbm_frac": (egress["frac_of_hbm_peak"] if egress else None),

@@ -1659,6 +1659,10 @@ struct cw_batch {
     void *d_bulk = nullptr;        // staging of cw_get_witnesses: [bulk_rows][n_witness][32]
     uint32_t bulk_rows = 0;
     const void *ext_in = nullptr;  // caller-owned device inputs (cw_set_inputs_device)
+    // cw_run_check: cw_run + cw_check_r1cs captured once as a HIP graph and replayed (one launch per step instead of ~10)
+    hipGraphExec_t rc_graph = nullptr;
+    const void *rc_in = nullptr, *rc_packed = nullptr;   // the input pointers the captured launches carry
+    uint32_t rc_calls = 0;                                // plain calls since the inputs last changed (the first loads modules)
     std::vector<uint32_t> h_stream_begin;
     std::vector<uint8_t> h_in;     // host staging for per-signal assignment
     std::vector<uint8_t> assigned; // [batch][n_in] flags (inputSignalAssigned, calcwit.cpp:28-32)
@@ -1731,6 +1735,8 @@ static hipError_t upload(T **dst, const std::vector<T> &src, hipStream_t s) {
 
 extern "C" void cw_batch_free(cw_batch *b) {
     if (!b) return;
+    if (b->rc_graph) hipGraphExecDestroy(b->rc_graph);
+    b->rc_graph = nullptr;
     if (b->c) b->c->live_batches--;
     if (b->device < 0) {
         delete b;
@@ -2941,6 +2947,67 @@ extern "C" int cw_check_r1cs(cw_batch *b) {
     return CW_OK;
 }
 
+// cw_run + cw_check_r1cs as ONE launch.  A step of a small batch is a dozen launches of microseconds each (table init, ingest,
+// evaluation, two or three check kernels, a merge): the host, not the device, sets the pace (Sha256(512) x 4 096: 0.12 ms per
+// step whatever is in flight).  Both calls only enqueue work on the batch's stream, so the second call with unchanged input
+// pointers records them with stream capture, and every later call replays the graph.  Falls back to the two plain calls while
+// timing marks are on (events are not captured), while inputs set on the host wait for their copy, and on any capture error.
+extern "C" int cw_run_check(cw_batch *b) {
+    if (!b) return fail(CW_EINVAL, "null batch");
+    NEED_DEVICE(b);
+    cw_circuit *c = b->c;
+    if (c->n_constraints == 0) return fail(CW_ESTATE, "no .r1cs was loaded for this circuit");
+    auto plain = [&]() {
+        int rc = cw_run(b);
+        return rc == CW_OK ? cw_check_r1cs(b) : rc;
+    };
+    const void *in = b->ext_in ? b->ext_in : b->d_in;
+    if (b->rc_graph && (b->rc_in != in || b->rc_packed != b->packed_in || b->timing || b->host_dirty)) {
+        hipGraphExecDestroy(b->rc_graph);
+        b->rc_graph = nullptr;
+        b->rc_calls = 0;
+    }
+    if (b->timing || b->host_dirty || getenv("CW_NO_GRAPH")) return plain();
+    if (!b->rc_graph) {
+        if (b->rc_in != in || b->rc_packed != b->packed_in) {
+            b->rc_in = in;
+            b->rc_packed = b->packed_in;
+            b->rc_calls = 0;
+        }
+        if (b->rc_calls++ == 0) return plain();           // loads the code objects, makes every lazy allocation
+        HIPCHK(hipSetDevice(b->device));
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            return plain();
+        }
+        const int rc = plain();
+        const hipError_t e = hipStreamEndCapture(b->stream, &g);
+        if (rc != CW_OK || e != hipSuccess || !g) {
+            if (g) hipGraphDestroy(g);
+            (void)hipGetLastError();
+            return rc != CW_OK ? rc : plain();
+        }
+        const hipError_t e2 = hipGraphInstantiate(&b->rc_graph, g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        if (e2 != hipSuccess) {
+            b->rc_graph = nullptr;
+            (void)hipGetLastError();
+            return plain();
+        }
+    }
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipGraphLaunch(b->rc_graph, b->stream));
+    b->ran = true;
+    if (b->bitmode) {
+        if (b->jit) b->table_dirty = false;
+        b->resolved = false;
+        b->checked = true;
+    }
+    return CW_OK;
+}
+extern "C" int cw_batch_graph_captured(const cw_batch *b) { return b && b->rc_graph != nullptr; }
+
 extern "C" int cw_sync(cw_batch *b) {
     if (!b) return fail(CW_EINVAL, "null batch");
     NEED_DEVICE(b);
@@ -3484,6 +3551,11 @@ extern "C" void *cw_device_bits(cw_batch *b, uint64_t *n_bytes, uint64_t *slots_
     if (!b || !b->bitmode) return nullptr;
     if (n_bytes) *n_bytes = b->t_bytes;
     if (slots_per_group) *slots_per_group = b->bits_slots;
+    if (b->rc_graph) {                      // (cw_run_check's graph holds the check that trusts the table)
+        hipGraphExecDestroy(b->rc_graph);
+        b->rc_graph = nullptr;
+        b->rc_calls = 0;
+    }
     b->table_dirty = true;                  // the caller may write through the pointer: the next R1CS check audits the table itself
     return b->d_T;
 }

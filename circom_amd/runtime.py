@@ -87,6 +87,8 @@ _SIGS = {
     "cw_remaining_inputs": (C.c_int64, [C.c_void_p, C.c_uint32]),
     "cw_run": (C.c_int, [C.c_void_p]),
     "cw_check_r1cs": (C.c_int, [C.c_void_p]),
+    "cw_run_check": (C.c_int, [C.c_void_p]),
+    "cw_batch_graph_captured": (C.c_int, [C.c_void_p]),
     "cw_emitted_checks_match": (C.c_int, [C.c_void_p]),
     "cw_batch_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "cw_batch_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
@@ -308,6 +310,14 @@ class Batch:
 
     def check_r1cs(self):
         _chk(lib().cw_check_r1cs(self.h))
+
+    def run_check(self):
+        """run() + check_r1cs() as one launch: captured as a HIP graph on the second call, replayed afterwards (cw_run_check)"""
+        _chk(lib().cw_run_check(self.h))
+
+    @property
+    def graph_captured(self) -> bool:
+        return bool(lib().cw_batch_graph_captured(self.h))
 
     def sync(self):
         _chk(lib().cw_sync(self.h))

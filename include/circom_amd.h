@@ -152,6 +152,14 @@ int64_t cw_remaining_inputs(const cw_batch *b, uint32_t instance);
 int cw_run(cw_batch *b);
 /* A*w o B*w = C*w over the loaded .r1cs for all instances (second kernel of the north-star). */
 int cw_check_r1cs(cw_batch *b);
+/* cw_run + cw_check_r1cs as one launch: the second call with unchanged input pointers captures the launches of both into a HIP graph
+ * on the batch's stream, later calls replay it (a step of a small batch is a dozen kernel launches of microseconds each - the host
+ * sets the pace otherwise).  Same results, same errors, same asynchrony as the two calls; falls back to them while timing marks are
+ * on, while host-set inputs await their copy, with CW_NO_GRAPH set, or if the capture fails.  The graph is dropped when the
+ * batch's input pointer changes or the caller takes the raw table pointer.  cw_batch_graph_captured: 1 once replaying.
+ * (No reference counterpart: the reference's run + snarkjs' `wtns check` are two processes per witness.) */
+int cw_run_check(cw_batch *b);
+int cw_batch_graph_captured(const cw_batch *b);
 /* Event timing of the parts of cw_run / cw_check_r1cs on the batch's stream (HIP events recorded where the kernels are launched;
  * no reference counterpart: the reference's runtime is one process per witness - this is what bench.py's roofline figures read).
  * cw_batch_kernel_ms drains the stream and returns, for the LAST run / check: ms[0] = table init + input ingest, ms[1] = the
