@@ -1663,6 +1663,8 @@ struct cw_batch {
     hipGraphExec_t rc_graph = nullptr;
     const void *rc_in = nullptr, *rc_packed = nullptr;   // the input pointers the captured launches carry
     uint32_t rc_calls = 0;                                // plain calls since the inputs last changed (the first loads modules)
+    hipStream_t rc_stream = nullptr;                      // the launches are recorded on a private stream (the batch's may be the null
+                                                          // stream, which cannot be captured) and replayed on the batch's own
     std::vector<uint32_t> h_stream_begin;
     std::vector<uint8_t> h_in;     // host staging for per-signal assignment
     std::vector<uint8_t> assigned; // [batch][n_in] flags (inputSignalAssigned, calcwit.cpp:28-32)
@@ -1737,6 +1739,8 @@ extern "C" void cw_batch_free(cw_batch *b) {
     if (!b) return;
     if (b->rc_graph) hipGraphExecDestroy(b->rc_graph);
     b->rc_graph = nullptr;
+    if (b->rc_stream) hipStreamDestroy(b->rc_stream);
+    b->rc_stream = nullptr;
     if (b->c) b->c->live_batches--;
     if (b->device < 0) {
         delete b;
@@ -2977,12 +2981,20 @@ extern "C" int cw_run_check(cw_batch *b) {
         if (b->rc_calls++ == 0) return plain();           // loads the code objects, makes every lazy allocation
         HIPCHK(hipSetDevice(b->device));
         hipGraph_t g = nullptr;
-        if (hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        if (!b->rc_stream && hipStreamCreateWithFlags(&b->rc_stream, hipStreamNonBlocking) != hipSuccess) {
+            b->rc_stream = nullptr;
             (void)hipGetLastError();
             return plain();
         }
+        if (hipStreamBeginCapture(b->rc_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            return plain();
+        }
+        hipStream_t own = b->stream;
+        b->stream = b->rc_stream;                         // every launch of the two calls names b->stream
         const int rc = plain();
-        const hipError_t e = hipStreamEndCapture(b->stream, &g);
+        b->stream = own;
+        const hipError_t e = hipStreamEndCapture(b->rc_stream, &g);
         if (rc != CW_OK || e != hipSuccess || !g) {
             if (g) hipGraphDestroy(g);
             (void)hipGetLastError();
