@@ -371,6 +371,9 @@ def auto_in_flight(bitmode: bool, B: int, lanes: int) -> int:
     chain."""
     if bitmode:             # one wave per SIMD and group slice: 1 024 of them fill the chip (Sha256(512) x 4 096 = 256 waves:
         waves = ((B + 63) // 64) * (64 // max(1, lanes))     # 2 in flight -> 20.0 M, 4 -> 34.1 M, 8 -> 33.0 M witnesses/s)
+        # (16 hardware queues, steps as HIP graphs: 4 in flight 38.0 M, 16 in flight 41.2-41.7 M, profiles/r06s_*, r06w_*)
+        if os.environ.get("GPU_MAX_HW_QUEUES") == "16":
+            return max(2, min(16, 4096 // max(1, waves)))
         return max(2, min(4, 1024 // max(1, waves)))
     # 256-bit engine: twice the batches that fill the 256 CUs, at most eight: the dispatcher does not always put the
     # workgroups of four 64-workgroup batches on four disjoint quarters of the chip (tools/sema_inflight.py: 4 in flight gave
