@@ -691,6 +691,11 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--graph", choices=("auto", "on", "off"), default=os.environ.get("CW_BENCH_GRAPH", "auto"),
                     help="steps as one HIP-graph launch each (cw_run_check); auto: when a step alone is shorter than 1 ms")
+    ap.add_argument("--cu-partitions", type=int, default=int(os.environ.get("CW_BENCH_CU_PARTITIONS", "0")),
+                    help="streams of the batches in flight are created with CU masks (hipExtStreamCreateWithCUMask): partition j = CUs "
+                         "[j * 256 / N, (j + 1) * 256 / N) - every batch in flight gets its own part of the chip and its own hardware queue "
+                         "(an experiment, measured WORSE on the Semaphore shard: 509 K -> 357 K witnesses/s with 16 parts - the wide check "
+                         "kernel is confined to 16 CUs as well; profiles/r06x_sema_shard_cu_masked_streams.txt)")
     ap.add_argument("--no-small", action="store_true", help="skip the batch-4096 side measurement (profiling runs)")
     ap.add_argument("--fp-bench-lanes", type=int, default=1 << 24)
     ap.add_argument("--in-flight", type=int, default=int(os.environ.get("CW_IN_FLIGHT", "0")),
@@ -833,9 +838,32 @@ def main():
         cap = float(os.environ.get("CW_BENCH_HBM_CAP", "0")) or 0.95 * torch.cuda.get_device_properties(dev).total_memory
         n_fl = max(1, min(n_fl, int(cap // max(est, 1.0))))
     streams, batches = [stream], [batch]
-    for _ in range(n_fl - 1):
+    masked = None
+    if args.cu_partitions > 0:
+        # CU-masked streams through the HIP runtime this process already uses (torch's copy of libamdhip64)
+        import ctypes as C_
+        hip_path = sorted({l.split()[-1] for l in open("/proc/self/maps").read().splitlines() if "libamdhip64" in l})[0]
+        hip_ = C_.CDLL(hip_path)
+        hip_.hipExtStreamCreateWithCUMask.argtypes = [C_.POINTER(C_.c_void_p), C_.c_uint32, C_.POINTER(C_.c_uint32)]
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        per = n_cu // args.cu_partitions
+
+        def masked(j):
+            words = (C_.c_uint32 * ((n_cu + 31) // 32))()
+            for cu in range((j % args.cu_partitions) * per, (j % args.cu_partitions + 1) * per):
+                words[cu // 32] |= 1 << (cu % 32)
+            h_ = C_.c_void_p()
+            rc_ = hip_.hipExtStreamCreateWithCUMask(C_.byref(h_), len(words), words)
+            assert rc_ == 0, "hipExtStreamCreateWithCUMask failed: %d" % rc_
+            return torch.cuda.ExternalStream(h_.value, device=dev)
+        # (the first batch was created on the current stream: it moves to a masked stream too)
+        batch.close()
+        streams[0] = stream = masked(0)
+        batches[0] = batch = circ.batch(B, device=local_rank, stream=stream.cuda_stream)
+        set_in(batch)
+    for j_ in range(1, n_fl):
         try:
-            st_ = torch.cuda.Stream(device=dev)
+            st_ = masked(j_) if masked else torch.cuda.Stream(device=dev)
             b_ = circ.batch(B, device=local_rank, stream=st_.cuda_stream)
         except rt.CwError:
             break                                            # no room for another table: fewer batches in flight
@@ -1376,7 +1404,7 @@ def main():
                        "canonical 32-byte field elements",
                        "in_flight": n_fl, "step_launch": ("one HIP graph per step (cw_run_check); in-step kernel durations from a plain pass behind the timed region"
                                                           if use_graph else "plain launches (cw_run + cw_check_r1cs)"),
-                       "lanes_per_wave": batch.lanes, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
+                       "cu_partitions": args.cu_partitions or None, "lanes_per_wave": batch.lanes, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
                        "compile_s": compile_s, "compile_cached": compile_cached, "compile_s_cold": getattr(cp, "compile_s_cold", None),
                        "shard_of": args.shard_of or None, "total_batch": args.total_batch or None},
             "value_canonical": value_canonical,
