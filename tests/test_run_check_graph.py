@@ -96,3 +96,24 @@ def test_graph_replay_on_the_bit_plane_engine(tmp_path, monkeypatch):
             return m
         _rounds(c, cp, _Hip(), B, rows)
         c.close()
+
+
+def test_graph_replay_on_the_64_bit_engine(tmp_path):
+    """--prime goldilocks (csrc/cw64.hip): the same replay through the 64-bit runtime's kernels, with a witness hint that is wrong
+    for odd inputs so that the check's verdict changes from round to round"""
+    from test_bitplane import _Hip
+    from circom_amd import runtime as rt
+    from circom_amd.compiler import compile_program
+    from circom_amd.frontend.dsl import template
+
+    @template
+    def BadSquare(cx):
+        a = cx.input("a")
+        out = cx.output("out")
+        cx.hint(out, a * a + (a & 1))                             # wrong for odd a
+        cx.enforce(out, a * a, runtime_check=False)
+    cp = compile_program(Program(BadSquare(), prime="goldilocks"), str(tmp_path), "badsq_g", sym=False)
+    c = rt.Circuit(cp.tape_path, cp.dat_path, cp.r1cs_path)
+    B = 200
+    _rounds(c, cp, _Hip(), B, lambda r: [[(i * 0x9E3779B97F4A7C15 + r) % c.q] for i in range(B)], expect_bad=True)
+    c.close()
