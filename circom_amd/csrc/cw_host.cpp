@@ -1663,6 +1663,12 @@ struct cw_batch {
     hipGraphExec_t rc_graph = nullptr;
     const void *rc_in = nullptr, *rc_packed = nullptr;   // the input pointers the captured launches carry
     uint32_t rc_calls = 0;                                // plain calls since the inputs last changed (the first loads modules)
+    // argument blocks of the emitted kernels (hipModuleLaunchKernel's `extra` form): members, not locals - a captured launch
+    // (cw_run_check) may keep the POINTERS it was given, and a replay must find the block where the capture saw it
+    struct FpArgs { void *V; uint32_t *status; uint32_t Bp, batch, lanes, pad; FpParams P; uint32_t pad2; const void *consts, *fcode, *ftab; } fp_args;
+    struct JitArgs { void *T, *fb, *r1; } jit_args, audit_args;
+    size_t fp_args_size = sizeof(FpArgs), jit_args_size = sizeof(JitArgs);
+    void *fp_cfg[5], *jit_cfg[5], *audit_cfg[5];
     hipStream_t rc_stream = nullptr;                      // the launches are recorded on a private stream (the batch's may be the null
                                                           // stream, which cannot be captured) and replayed on the batch's own
     std::vector<uint32_t> h_stream_begin;
@@ -2663,9 +2669,10 @@ static int bits_run(cw_batch *b, const void *in) {
     if (b->jit) {
         // one wave per chunk of 2 048 instances runs the circuit's emitted code: gates on registers, every signal value stored
         // once, assertion gates and the fused R1CS check OR-ed into the two flag arrays
-        struct { void *T, *fb, *r1; } args = {b->d_T, b->d_fbmask, b->d_r1flag};
-        size_t asz = sizeof(args);
-        void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+        b->jit_args = {b->d_T, b->d_fbmask, b->d_r1flag};
+        void **cfg = b->jit_cfg;
+        cfg[0] = HIP_LAUNCH_PARAM_BUFFER_POINTER; cfg[1] = &b->jit_args; cfg[2] = HIP_LAUNCH_PARAM_BUFFER_SIZE; cfg[3] = &b->jit_args_size;
+        cfg[4] = HIP_LAUNCH_PARAM_END;
         BTRY(hipModuleLaunchKernel(b->jit_fn, b->n_groups_padded / 32, 1, 1, 64, 1, 1, 0, b->stream, nullptr, cfg));
         b->table_dirty = false;
     } else {
@@ -2789,8 +2796,7 @@ extern "C" int cw_run(cw_batch *b) {
     }
     if (b->fp_fn) {
         // the variant's rows as straight-line code: one workgroup of n_strands waves per `lanes` instances, as cwk_eval
-        struct { void *V; uint32_t *status; uint32_t Bp, batch, lanes, pad; FpParams P; uint32_t pad2;
-                 const void *consts, *fcode, *ftab; } args;              // (the tables of tier 2: the D_CALL body loads their addresses)
+        cw_batch::FpArgs &args = b->fp_args;                        // (the tables of tier 2: the D_CALL body loads their addresses)
         static_assert(sizeof(args) == 272, "argument block of the emitted code (fpjit.KERNARG_BYTES)");
         static_assert(sizeof(FpParams) == 53 * 4, "the emitted code loads 53 parameter words");
         memset(&args, 0, sizeof(args));
@@ -2804,8 +2810,9 @@ extern "C" int cw_run(cw_batch *b) {
         args.fcode = b->d_fncode;
         args.ftab = b->d_fntab;
         HIPCHK(hipMemsetAsync(b->d_status + b->Bp, 0xFF, (size_t)b->Bp * 4, b->stream));    // "no constraint found violated"
-        size_t asz = sizeof(args);
-        void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+        void **cfg = b->fp_cfg;
+        cfg[0] = HIP_LAUNCH_PARAM_BUFFER_POINTER; cfg[1] = &b->fp_args; cfg[2] = HIP_LAUNCH_PARAM_BUFFER_SIZE; cfg[3] = &b->fp_args_size;
+        cfg[4] = HIP_LAUNCH_PARAM_END;
         HIPCHK(hipModuleLaunchKernel(b->fp_fn, (b->batch + b->lanes - 1) / b->lanes, 1, 1, 64 * b->var->n_strands, 1, 1, 0, b->stream,
                                      nullptr, cfg));
         TMARK(b, 2);
@@ -2923,9 +2930,10 @@ extern "C" int cw_check_r1cs(cw_batch *b) {
                 it = c->jit_audit_mod.emplace(b->device, std::make_pair(mod, fn)).first;
             }
             HIPCHK(hipMemsetAsync(b->d_r1flag, 0, (size_t)b->n_groups_padded * 8, b->stream));
-            struct { void *T, *fb, *r1; } args = {b->d_T, b->d_fbmask, b->d_r1flag};
-            size_t asz = sizeof(args);
-            void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+            b->audit_args = {b->d_T, b->d_fbmask, b->d_r1flag};
+            void **cfg = b->audit_cfg;
+            cfg[0] = HIP_LAUNCH_PARAM_BUFFER_POINTER; cfg[1] = &b->audit_args; cfg[2] = HIP_LAUNCH_PARAM_BUFFER_SIZE; cfg[3] = &b->jit_args_size;
+            cfg[4] = HIP_LAUNCH_PARAM_END;
             HIPCHK(hipModuleLaunchKernel(it->second.second, b->n_groups_padded / 32, 1, 1, 64, 1, 1, 0, b->stream, nullptr, cfg));
             only = b->d_r1flag;
         }
