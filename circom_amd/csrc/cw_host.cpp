@@ -2809,7 +2809,7 @@ extern "C" int cw_run(cw_batch *b) {
         args.consts = b->d_consts;
         args.fcode = b->d_fncode;
         args.ftab = b->d_fntab;
-        HIPCHK(hipMemsetAsync(b->d_status + b->Bp, 0xFF, (size_t)b->Bp * 4, b->stream));    // "no constraint found violated"
+        HIPCHK(cwk_fill32(b->stream, b->d_status + b->Bp, 0xFFFFFFFFu, b->Bp));               // "no constraint found violated"
         void **cfg = b->fp_cfg;
         cfg[0] = HIP_LAUNCH_PARAM_BUFFER_POINTER; cfg[1] = &b->fp_args; cfg[2] = HIP_LAUNCH_PARAM_BUFFER_SIZE; cfg[3] = &b->fp_args_size;
         cfg[4] = HIP_LAUNCH_PARAM_END;
@@ -2929,7 +2929,7 @@ extern "C" int cw_check_r1cs(cw_batch *b) {
                 if (e1 != hipSuccess) return fail(CW_EDEVICE, std::string("loading the emitted audit code failed: ") + hipGetErrorString(e1));
                 it = c->jit_audit_mod.emplace(b->device, std::make_pair(mod, fn)).first;
             }
-            HIPCHK(hipMemsetAsync(b->d_r1flag, 0, (size_t)b->n_groups_padded * 8, b->stream));
+            HIPCHK(cwk_fill32(b->stream, (uint32_t *)b->d_r1flag, 0u, (size_t)b->n_groups_padded * 2));
             b->audit_args = {b->d_T, b->d_fbmask, b->d_r1flag};
             void **cfg = b->audit_cfg;
             cfg[0] = HIP_LAUNCH_PARAM_BUFFER_POINTER; cfg[1] = &b->audit_args; cfg[2] = HIP_LAUNCH_PARAM_BUFFER_SIZE; cfg[3] = &b->jit_args_size;

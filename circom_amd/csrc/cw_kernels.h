@@ -18,6 +18,7 @@ hipError_t cwk_eval(hipStream_t s, bool full, bool wide_linsum, const CwDRow *ro
 hipError_t cwk_eval_pipe(hipStream_t s, bool full, bool wide_linsum, uint32_t nb, uint32_t nld, const void *rows, uint32_t n_rows,
                          const uint32_t *loads, const uint64_t *terms, void *V, const uint32_t *consts, const uint32_t *lconsts,
                          uint64_t slot_stride, uint32_t Bp, uint32_t batch, uint32_t lanes, uint32_t *status, const FpParams &P);
+hipError_t cwk_fill32(hipStream_t s, uint32_t *p, uint32_t v, size_t n);     // p[0..n) = v, as a kernel (graph-safe)
 hipError_t cwk_fused_merge(hipStream_t s, const uint32_t *found, uint32_t batch, uint32_t *status, uint32_t *first_bad);
 hipError_t cwk_r1cs(hipStream_t s, const uint32_t *chunk, uint32_t n_chunks, const uint32_t *terms, const uint32_t *ctab,
                     const uint32_t *ctab29, const uint32_t *row_orig, const void *V, uint32_t Bp, uint32_t batch, uint32_t *status,

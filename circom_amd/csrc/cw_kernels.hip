@@ -1182,6 +1182,18 @@ __global__ void __launch_bounds__(CW_BLOCK) cw_fused_merge_kernel(const uint32_t
         atomicOr(&status[i], CW_ST_R1CS_FAILED);
     }
 }
+// 32-bit fill as a KERNEL: cw_run / cw_check_r1cs are also recorded into HIP graphs (cw_run_check), and a memset node of the captured
+// graph was seen to write garbage on the second replay (the finding words of the fused check held host pointers: GPU suite of round
+// 6, profiles/r06ad_*) - the captured paths launch kernels only
+__global__ void __launch_bounds__(CW_BLOCK) cw_fill32_kernel(uint32_t *__restrict__ p, uint32_t v, size_t n) {
+    const size_t i = (size_t)blockIdx.x * CW_BLOCK + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+hipError_t cwk_fill32(hipStream_t s, uint32_t *p, uint32_t v, size_t n) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(cw_fill32_kernel, dim3((unsigned)((n + CW_BLOCK - 1) / CW_BLOCK)), dim3(CW_BLOCK), 0, s, p, v, n);
+    return hipGetLastError();
+}
 hipError_t cwk_fused_merge(hipStream_t s, const uint32_t *found, uint32_t batch, uint32_t *status, uint32_t *first_bad) {
     hipLaunchKernelGGL(cw_fused_merge_kernel, blocks_for(batch), dim3(CW_BLOCK), 0, s, found, batch, status, first_bad);
     return hipGetLastError();

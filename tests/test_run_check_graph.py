@@ -29,7 +29,11 @@ def _rounds(c, cp, hip, B, make_rows, n_rounds=4, expect_bad=False):
         assert g.graph_captured == (r >= 1), r                      # the first call is plain, the second captures, then replays
         p.run(); p.check_r1cs(); p.sync()
         st, fb = g.status(), g.r1cs_first_bad()
-        assert (st == p.status()).all() and (fb == p.r1cs_first_bad()).all(), r
+        if not ((st == p.status()).all() and (fb == p.r1cs_first_bad()).all()):
+            same_w = [g.witness(i) == p.witness(i) for i in (0, 1, B - 1)]
+            raise AssertionError("round %d: status %s / %s, first bad %s / %s, witnesses equal %s, emitted %s fused %s lanes %s" % (
+                r, st[:4].tolist(), p.status()[:4].tolist(), fb[:4].tolist(), p.r1cs_first_bad()[:4].tolist(), same_w,
+                getattr(g, "emitted", None), getattr(g, "fused_check", None), g.lanes))
         for i in sorted({0, 1, B // 2, B - 1, (7 * r + 3) % B}):
             w = g.witness(i)
             assert w == p.witness(i), (r, i)
@@ -65,6 +69,25 @@ def test_graph_replay_on_the_256_bit_engine(tmp_path, mont, monkeypatch):
     cp, c = _compile(tmp_path, Program(FlakyChain(9)), "flaky%d" % mont)
     B = 333
     _rounds(c, cp, _Hip(), B, lambda r: [[(i * 2654435761 + r * 97) % (1 << 61), (i + r) % 20 if (i + r) % 3 else 9 + i] for i in range(B)], expect_bad=True)
+    c.close()
+
+
+def test_graph_replay_with_the_fused_check(tmp_path, monkeypatch):
+    """the emitted program with the R1CS check fused in (CW_FP_FUSED=1): every round breaks a different row of every instance, the
+    replayed step must name this round's rows (finding words, first-bad words and status words are all reset or rewritten inside
+    the step - by kernels: a memset node of the captured graph was seen to write garbage on the second replay)"""
+    from test_bitplane import _Hip
+    from test_gpu_parity import FlakyChain, _compile
+    monkeypatch.setenv("CW_MONT", "1")
+    monkeypatch.setenv("CW_FP_FUSED", "1")
+    cp, c = _compile(tmp_path, Program(FlakyChain(9)), "flakyfused")
+    B = 333
+    probe = c.batch(B)
+    fused = probe.fused_check
+    probe.close()
+    assert fused, "no fused-check program for this circuit: the test would not test what it says"
+    _rounds(c, cp, _Hip(), B, lambda r: [[(i * 2654435761 + r * 97) % (1 << 61), (i + r) % 20 if (i + r) % 3 else 9 + i] for i in range(B)],
+            n_rounds=5, expect_bad=True)
     c.close()
 
 
