@@ -777,11 +777,15 @@ def main():
     if (not batch.bitmode and args.in_flight <= 0 and "CW_LANES" not in os.environ and batch.lanes < 64
             and os.environ.get("GPU_MAX_HW_QUEUES") == "16"):
         est_ = 32.0 * circ.n_signals * ((B + 255) // 256 * 256) * 1.1
-        if 0.8 * torch.cuda.get_device_properties(dev).total_memory / est_ >= 32 and (B + 63) // 64 <= 16:
+        wgs64_ = (B + 63) // 64
+        n_want_ = max(2, min(32, 512 // wgs64_))               # batches in flight that cover the 256 CUs twice with full waves
+        # (1 024 instances: 32 in flight, 171 K -> 489 K witnesses/s; 8 192: 4 in flight, 455 K -> 673 K, profiles/r06ag_*.  The ECDSA
+        # verifier's 81 GB tables fit three times: it keeps 16 lanes per wave.)
+        if 0.8 * torch.cuda.get_device_properties(dev).total_memory / est_ >= n_want_:
             batch.close()
             os.environ["CW_LANES"] = "64"
             batch = circ.batch(B, device=local_rank, stream=stream.cuda_stream)
-            many_small = True
+            many_small = n_want_
     golden_at = {}
     # synthetic inputs, resident in HBM before the timed region (different seed per rank = different shard)
     big_bool = batch.bitmode and args.workload.startswith("sha256_") and B * circ.n_inputs * 32 > (8 << 30)
@@ -827,7 +831,7 @@ def main():
     if n_fl <= 0:
         n_fl = in_flight_for(batch)
     if many_small:
-        n_fl = 32
+        n_fl = many_small
     n_fl = max(1, n_fl)
     if not batch.bitmode:
         # value tables of a million-signal circuit are tens of GB each (ECDSA verifier x 1 024: 81 GB): as many batches in
