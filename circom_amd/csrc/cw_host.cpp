@@ -1466,6 +1466,7 @@ static int load_r1cs(cw_circuit *c, const char *path) {
             c->r_bool.push_back(isbool ? 1 : 0);
         }
     }
+    if (c->r_ctab.size() / 8 >= (1u << 30)) return fail(CW_EIO, "r1cs: too many distinct coefficients");   // ids share a word with COEF_CONST / COEF_BITSEL
     c->r_ptr.swap(n_ptr);
     c->r_slot.swap(n_slot);
     c->r_coef.swap(n_coef);
@@ -1663,6 +1664,7 @@ struct cw_batch {
     hipGraphExec_t rc_graph = nullptr;
     const void *rc_in = nullptr, *rc_packed = nullptr;   // the input pointers the captured launches carry
     uint32_t rc_calls = 0;                                // plain calls since the inputs last changed (the first loads modules)
+    bool rc_failed = false;                               // a capture of these launches failed once: cw_run_check stays on the plain calls
     // argument blocks of the emitted kernels (hipModuleLaunchKernel's `extra` form): members, not locals - a captured launch
     // (cw_run_check) may keep the POINTERS it was given, and a replay must find the block where the capture saw it
     struct FpArgs { void *V; uint32_t *status; uint32_t Bp, batch, lanes, pad; FpParams P; uint32_t pad2; const void *consts, *fcode, *ftab; } fp_args;
@@ -2979,7 +2981,7 @@ extern "C" int cw_run_check(cw_batch *b) {
         b->rc_graph = nullptr;
         b->rc_calls = 0;
     }
-    if (b->timing || b->host_dirty || getenv("CW_NO_GRAPH")) return plain();
+    if (b->timing || b->host_dirty || b->rc_failed || getenv("CW_NO_GRAPH")) return plain();
     if (!b->rc_graph) {
         if (b->rc_in != in || b->rc_packed != b->packed_in) {
             b->rc_in = in;
@@ -2991,10 +2993,12 @@ extern "C" int cw_run_check(cw_batch *b) {
         hipGraph_t g = nullptr;
         if (!b->rc_stream && hipStreamCreateWithFlags(&b->rc_stream, hipStreamNonBlocking) != hipSuccess) {
             b->rc_stream = nullptr;
+            b->rc_failed = true;
             (void)hipGetLastError();
             return plain();
         }
         if (hipStreamBeginCapture(b->rc_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            b->rc_failed = true;
             (void)hipGetLastError();
             return plain();
         }
@@ -3006,11 +3010,13 @@ extern "C" int cw_run_check(cw_batch *b) {
         if (rc != CW_OK || e != hipSuccess || !g) {
             if (g) hipGraphDestroy(g);
             (void)hipGetLastError();
+            b->rc_failed = rc == CW_OK;                   // (an error of the calls themselves is the caller's to see, every time)
             return rc != CW_OK ? rc : plain();
         }
         const hipError_t e2 = hipGraphInstantiate(&b->rc_graph, g, nullptr, nullptr, 0);
         hipGraphDestroy(g);
         if (e2 != hipSuccess) {
+            b->rc_failed = true;
             b->rc_graph = nullptr;
             (void)hipGetLastError();
             return plain();
