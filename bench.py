@@ -379,7 +379,7 @@ def auto_in_flight(bitmode: bool, B: int, lanes: int) -> int:
     # workgroups of four 64-workgroup batches on four disjoint quarters of the chip (tools/sema_inflight.py: 4 in flight gave
     # 62.8 K in one process and 119 K in another, 8 gave 118.9 K and 118.5 K)
     wgs = (B + lanes - 1) // max(1, lanes)
-    return max(2, min(8, 512 // max(1, wgs)))
+    return max(2, min(16 if os.environ.get("GPU_MAX_HW_QUEUES") == "16" else 8, 512 // max(1, wgs)))
 
 
 def in_flight_for(batch) -> int:
