@@ -2962,10 +2962,12 @@ extern "C" int cw_check_r1cs(cw_batch *b) {
 }
 
 // cw_run + cw_check_r1cs as ONE launch.  A step of a small batch is a dozen launches of microseconds each (table init, ingest,
-// evaluation, two or three check kernels, a merge): the host, not the device, sets the pace (Sha256(512) x 4 096: 0.12 ms per
-// step whatever is in flight).  Both calls only enqueue work on the batch's stream, so the second call with unchanged input
-// pointers records them with stream capture, and every later call replays the graph.  Falls back to the two plain calls while
-// timing marks are on (events are not captured), while inputs set on the host wait for their copy, and on any capture error.
+// evaluation, two or three check kernels, a merge); one graph launch instead is worth +6 .. +15 % on Sha256(512) x 4 096 (35.7 ->
+// 41.1 M witnesses/s with 16 hardware queues - the rest of that step's 0.10 ms is the device's, profiles/r06s_*).  Both calls only
+// enqueue work on the batch's stream - KERNELS only, see cwk_fill32 - so the second call with unchanged input pointers records them
+// with stream capture (on a private stream: the batch's may be the null stream), and every later call replays the graph on the
+// batch's own stream.  Falls back to the two plain calls while timing marks are on (events are not captured), while inputs set on
+// the host wait for their copy, and for good after a capture error.
 extern "C" int cw_run_check(cw_batch *b) {
     if (!b) return fail(CW_EINVAL, "null batch");
     NEED_DEVICE(b);
