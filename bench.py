@@ -903,8 +903,8 @@ def main():
     for i in range(max(args.warmup, n_fl)):
         step(i)
     torch.cuda.synchronize()
-    # A step of a small batch is ~10 launches of microseconds each + the event marks: the HOST sets the pace (Sha256(512) x 4 096:
-    # 0.12 ms per step with 4, 8 or 16 batches in flight, profiles/r06q_*).  Such steps run as ONE HIP-graph launch each
+    # A step of a small batch is ~10 launches of microseconds each + the event marks (Sha256(512) x 4 096: 0.12 ms per step with 4, 8 or
+    # 16 batches in flight, profiles/r06q_*; as graph steps 0.10 ms - the rest is the device's).  Such steps run as ONE HIP-graph launch each
     # (cw_run_check: captured on the batch's second call, replayed afterwards; GPU tests: tests/test_run_check_graph.py).  Event
     # marks cannot ride in a graph: the kernels' in-step durations then come from a second, plain pass behind the timed region.
     use_graph = args.graph == "on" or (args.graph == "auto" and isolated["ms_per_step"] < 1.0 and circ.n_constraints > 0)
@@ -1344,7 +1344,8 @@ def main():
                 tot_ = (circ.n_mmul + n_chk) * B / (step_ms_fp * 1e-3)
                 roof_valu["incl_check"] = {"check_products_per_witness": n_chk, "achieved": tot_,
                                            "frac": tot_ / fp_mul_per_s if fp_mul_per_s else None,
-                                           "is": "evaluation + fused-check products of one step / ms_per_step: what the kernel multiplies per second"}
+                                           "is": "evaluation + check products of one step (the check recomputed inside the emitted program; rows it "
+                                                 "leaves are multiplied by the stand-alone kernel in the same step) / ms_per_step"}
             roof_ingest = None
         # What ONE STEP achieves (VERDICT r5 #1a): the bytes a step must move - the boundary's input image, and everything its
         # kernels move by the counters (or by the emitter's own count) - over ms_per_step of the timed region, against the HBM spec
